@@ -1,0 +1,174 @@
+/*
+ * warpstr_hip.h -- C ABI of the MI355X-native WarpSTR caller (step 3: TR calling).
+ *
+ * The upstream project is pure Python and has no FFI for this path; its seams are Python
+ * callables.  Each entry point below states the upstream interface it stands in for
+ * (paths relative to the upstream repository root):
+ *
+ *   wsx_call_batch       <->  CallerWrapper.run(workload) -> List[CallerResult]
+ *                             src/caller/wrapper.py:104-120 (Pool.map of warpstr_call_parallel,
+ *                             251-289; WarpSTR.run, src/caller/caller.py:117-149)
+ *   wsx_warp_batch       <->  WarpSTR.warp(signal, mask) -> WarpResult(trace)
+ *                             src/caller/caller.py:189-193 (_calc_dtw_astates 198-245,
+ *                             _backtracking 247-301)
+ *   wsx_caller_create    <->  CallerWrapper.__init__ / init_pool: automata + config made
+ *                             available to the workers, src/caller/wrapper.py:63-70,92-102
+ *   wsx_automaton        <->  StateAutomata(states, endstate, mask), src/caller/automata.py:36-48
+ *   wsx_params           <->  caller_config / rescaler_config, src/config.py:91-119
+ *   wsx_result           <->  CallerResult, src/caller/caller.py:46-51 (lengths instead of
+ *                             strings: only len(seq)/len(resc_seq) reach overview.csv,
+ *                             src/caller/overview.py:57-73; strings are rebuilt from the traces)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  `mem` says where the bulk buffers live
+ *     (WSX_MEM_HOST: ordinary host memory, the library stages it; WSX_MEM_DEVICE: HBM of the
+ *     caller's device, e.g. a torch tensor's data_ptr()).  Metadata arrays (offsets, automaton
+ *     ids) are always host memory.
+ *   - All buffers are caller-owned; the library keeps no reference after a call returns.
+ *   - Reads are independent.  A failure of one read (the upstream code would raise and abort the
+ *     whole Pool.map, src/caller/caller.py:290-291, 395-397) is reported in wsx_result.status and
+ *     the other reads are unaffected.  The function return value reports process-level errors.
+ *   - Results are positionally aligned with the input order (as Pool.map is).
+ *   - One wsx_caller per device and host thread; calls on one handle are serialised by the caller.
+ */
+#ifndef WARPSTR_HIP_H
+#define WARPSTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSX_ABI_VERSION 1
+
+/* function return codes */
+enum {
+    WSX_SUCCESS = 0,
+    WSX_ERR_INVALID = -1,     /* bad argument */
+    WSX_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    WSX_ERR_HIP = -3,         /* a HIP runtime call failed; see wsx_last_error() */
+    WSX_ERR_UNSUPPORTED = -4, /* configuration outside what the kernels implement */
+    WSX_ERR_NOMEM = -5,
+};
+
+/* per-read status (wsx_result.status); 0 = called */
+enum {
+    WSX_READ_OK = 0,
+    WSX_READ_SHAPE = 1,         /* T <= min_values_per_state (upstream: IndexError, caller.py:206-208) */
+    WSX_READ_BACKTRACK = 2,     /* upstream RuntimeError, caller.py:290-291 */
+    WSX_READ_FIT_POINTS = 3,    /* < 4 states pass filter_alignment (upstream: splrep TypeError) */
+    WSX_READ_FIT_ORDER = 4,     /* degenerate abscissae for the rescaling fit */
+    WSX_READ_FIT_SMOOTH = 5,    /* residual >= s: upstream FITPACK would add knots (threshold > 1) */
+    WSX_READ_NO_REPEAT = 6,     /* no repeat state on the path (upstream IndexError, caller.py:384) */
+    WSX_READ_SEGMENT_RANGE = 7, /* upstream IndexError in find_event_borders/segment (caller.py:395-397) */
+};
+
+enum { WSX_MEM_HOST = 0, WSX_MEM_DEVICE = 1 };
+
+/* One k-mer state automaton (host pointers; copied to the device by wsx_caller_create). */
+typedef struct wsx_automaton {
+    int32_t n_states;           /* S */
+    int32_t endstate;           /* StateAutomata.endstate */
+    int32_t flank_length;       /* Locus.flank_length used to build it */
+    int32_t reserved;
+    const double *value;        /* [S] State.value: expected normalised level */
+    const int32_t *seq_idx;     /* [S] State.seq_idx */
+    const int32_t *pred_ptr;    /* [S+1] CSR offsets of State.incoming */
+    const int32_t *pred_idx;    /* [pred_ptr[S]] predecessor state ids, in `incoming` order */
+    const uint8_t *repeat_mask; /* [S] StateAutomata.mask */
+} wsx_automaton;
+
+typedef struct wsx_params {
+    int32_t min_values_per_state; /* tr_calling_config.min_values_per_state, default 4 (> 1) */
+    int32_t states_in_segment;    /* tr_calling_config.states_in_segment, default 6 (> 1) */
+    double threshold;             /* rescaling.threshold, default 0.5 (0 < . <= 1) */
+    double max_std;               /* rescaling.max_std, default 0.5 */
+    int32_t method_median;        /* rescaling.method: 0 = mean, 1 = median */
+    int32_t reps_as_one;          /* rescaling.reps_as_one */
+} wsx_params;
+
+typedef struct wsx_result {
+    int32_t status;       /* WSX_READ_* */
+    int32_t len1;         /* len(CallerResult.seq)      -> overview.csv `orig` */
+    int32_t len2;         /* len(CallerResult.resc_seq) -> overview.csv `results` (allele length) */
+    int32_t n_trans1;     /* states visited by the first alignment */
+    int32_t n_trans2;     /* states visited by the second alignment */
+    int32_t reserved;
+    double cost1;         /* CallerResult.cost      -> `dtw_cost1` */
+    double cost2;         /* CallerResult.resc_cost -> `dtw_cost2` */
+    double dtw_end_cost1; /* D[T-1, endstate] of the first DP */
+    double dtw_end_cost2; /* D[T-1, endstate] of the second DP */
+} wsx_result;
+
+/* Optional per-sample outputs of wsx_call_batch (any pointer may be NULL). Same `mem` as the
+ * signal; laid out with the same offsets[] as the signal. */
+typedef struct wsx_traces {
+    uint16_t *trace1;    /* state id per sample, first alignment */
+    uint16_t *trace2;    /* state id per sample, alignment of the rescaled signal */
+    double *rescaled;    /* rescale_signal(signal, alignment), caller.py:124 */
+    uint8_t *badmask;    /* mask_bad_repeats(...)[2], caller.py:125-126 */
+} wsx_traces;
+
+typedef struct wsx_caller wsx_caller;
+
+/* Library / device queries. */
+int wsx_abi_version(void);
+int wsx_device_count(void);
+const char *wsx_last_error(void);
+
+/*
+ * Create a caller bound to HIP device `device` holding `n_automata` automata (for one locus:
+ * 0 = template strand, 1 = reverse strand; more for mixed-locus batches).
+ * `stream` is a hipStream_t passed as void* (NULL = the device's default stream); all work of
+ * this handle is enqueued on it.
+ */
+int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
+                      const wsx_params *params, void *stream);
+void wsx_caller_destroy(wsx_caller *c);
+
+/* Upper bound, in bytes, of the device workspace the handle may allocate (default 8 GiB). */
+int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
+
+/*
+ * Call a batch of reads: both alignments, rescaling and bad-repeat masking, per read.
+ *   signal       concatenated normalised squiggles, float64 (ReadSignal.signal), in `mem`
+ *   offsets      host int64[n_reads+1]; read r is signal[offsets[r] .. offsets[r+1])
+ *   automaton_id host int32[n_reads]; which automaton each read is aligned to
+ *                (upstream: rev_sta if ReadSignal.reverse else temp_sta, wrapper.py:279-286)
+ *   results      wsx_result[n_reads] in `mem`
+ *   traces       optional extra outputs (NULL for none)
+ * Synchronous for WSX_MEM_HOST.  For WSX_MEM_DEVICE the work is enqueued on the handle's stream
+ * and the call returns without waiting; use wsx_caller_synchronize (or the stream) before reading.
+ */
+int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets,
+                   const int32_t *automaton_id, int64_t n_reads, wsx_result *results, const wsx_traces *traces);
+
+/*
+ * One DP + traceback per read (WarpSTR.warp).
+ *   mask         optional uint8 per sample (same offsets; NULL = unmasked), in `mem`
+ *   trace        uint16 per sample, in `mem`
+ *   end_cost     optional float64[n_reads]: D[T-1, endstate], in `mem`
+ *   last_row     optional float64, automaton_row_stride doubles per read: D[T-1, :], in `mem`
+ *   status       optional int32[n_reads] (WSX_READ_*), in `mem`
+ */
+int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets,
+                   const int32_t *automaton_id, int64_t n_reads, const uint8_t *mask, uint16_t *trace,
+                   double *end_cost, double *last_row, int32_t last_row_stride, int32_t *status);
+
+int wsx_caller_synchronize(wsx_caller *c);
+
+/*
+ * Timing of the most recent wsx_call_batch on this handle, measured with HIP events on the handle's
+ * stream: total milliseconds in the DP kernels (both passes) and number of DP launches, total
+ * milliseconds of the whole enqueue..finish region.  Blocks until the work has finished.
+ */
+int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms);
+
+/* Name of the DP kernel variant used for automaton `a` (for profiles), e.g. "dtw_pass<4,1,2>". */
+const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WARPSTR_HIP_H */

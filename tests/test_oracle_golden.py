@@ -1,0 +1,138 @@
+"""Pin the CPU oracle against the golden vectors produced by the upstream caller
+(tests/golden/generate_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import DEFAULT_CASES, GOLDEN, assert_close_rel, golden_automaton, load_case
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_full_read_matches_reference(case):
+    z = load_case(case)
+    auts = {0: golden_automaton(z, 't'), 1: golden_automaton(z, 'r')}
+    for i in range(int(z['n_reads'])):
+        rev = int(z['reverse'][i])
+        sig = z[f'r{i}_signal']
+        r = oracle.call_read(auts[rev], sig)
+        assert r.status == 0
+        # state paths identical (src/caller/caller.py:247-301)
+        assert np.array_equal(r.trace1, z[f'r{i}_trace1'])
+        assert np.array_equal(r.trace2, z[f'r{i}_trace2'])
+        # DP terminal row bit-identical (only add/abs/compare are involved)
+        assert np.array_equal(r.dlast1, z[f'r{i}_dlast1'])
+        assert np.array_equal(r.badmask, z[f'r{i}_badmask'])
+        assert r.idx == tuple(int(v) for v in z[f'r{i}_idx'])
+        # FITPACK restatement: bit-identical rescaled signals
+        assert np.array_equal(r.rescaled, z[f'r{i}_rescaled'])
+        assert np.array_equal(r.dlast2, z[f'r{i}_dlast2'])
+        assert np.array_equal(r.rescaled2, z[f'r{i}_rescaled2'])
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert (r.len1, r.len2) == (len(seq), len(rseq))
+        assert_close_rel(r.cost1, z[f'r{i}_cost'][0], 1e-12)
+        assert_close_rel(r.cost2, z[f'r{i}_cost'][1], 1e-12)
+
+
+def test_full_matrix_bit_identical():
+    z = load_case('agc_fl16')
+    rev = int(z['reverse'][0])
+    aut = golden_automaton(z, 'r' if rev else 't')
+    D1 = oracle.dtw_fill(aut, z['r0_signal'])
+    assert np.array_equal(D1, z['r0_D1'])
+    D2 = oracle.dtw_fill(aut, z['r0_rescaled'], z['r0_badmask'])
+    assert np.array_equal(D2, z['r0_D2'])
+    assert np.array_equal(oracle.backtrack(aut, D2, z['r0_rescaled'], z['r0_badmask']), z['r0_trace2'])
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_matrix_checksums(case):
+    z = load_case(case)
+    auts = {0: golden_automaton(z, 't'), 1: golden_automaton(z, 'r')}
+    for i in range(int(z['n_reads'])):
+        D = oracle.dtw_fill(auts[int(z['reverse'][i])], z[f'r{i}_signal'])
+        fin = np.isfinite(D)
+        assert np.count_nonzero(fin) == int(z[f'r{i}_dsum1'][1])
+        assert np.sum(D[fin]) == z[f'r{i}_dsum1'][0]
+
+
+def test_numpy_reductions_bitwise():
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 130, 255, 256, 257, 1000, 4097]:
+        a = rng.normal(size=n) * rng.choice([1e-3, 1.0, 1e3])
+        assert oracle.np_mean(a) == np.mean(a)
+        assert oracle.np_std(a) == np.std(a)
+        assert oracle.np_median(a) == np.median(a)
+        assert oracle.np_mean(list(a)) == np.average(list(a))
+
+
+def test_fitpack_cubic_bitwise():
+    from scipy import interpolate
+    rng = np.random.default_rng(1)
+    for m in [4, 5, 8, 50, 200, 300]:
+        for _ in range(5):
+            x = np.sort(rng.normal(size=m))
+            y = x + rng.uniform(-0.5, 0.5, size=m)
+            tck = interpolate.splrep(x, y, s=m)
+            t, c, fp = oracle.fit_cubic(x, y)
+            assert len(tck[0]) == 8 and np.array_equal(t, tck[0])
+            assert np.array_equal(c, tck[1][:4])
+            q = rng.normal(size=500) * 3
+            assert np.array_equal(oracle.eval_cubic(t, c, q), interpolate.splev(q, tck))
+
+
+def test_segment_against_python_loop():
+    # an independent, direct transcription of the published sliding t-test on tiny inputs
+    from math import sqrt
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        n = int(rng.integers(6, 120))
+        steps = np.repeat(rng.normal(size=n // 5 + 1), 5)[:n]
+        data = steps + rng.normal(scale=0.2, size=n)
+        win = 3
+        ts = []
+        for idx in range(win, n - win + 1):
+            a, b = data[idx - win:idx], data[idx:idx + win]
+            sd = sqrt((np.std(a) ** 2 + np.std(b) ** 2) / win)
+            if sd == 0:
+                sd += 0.0000001
+            ts.append((np.mean(a) - np.mean(b)) / sd)
+        borders, start, prev = 0, False, ts[0]
+        for t in ts:
+            if t > 3 or t < -3:
+                if (t > 3 and t >= prev) or (t < -3 and t <= prev):
+                    start = True
+                else:
+                    borders += int(start)
+                    start = False
+            elif start:
+                borders += 1
+                start = False
+            prev = t
+        assert oracle.segment(data) == borders - 1
+
+
+def test_negative_cases_recorded():
+    z = np.load(os.path.join(GOLDEN, 'neg_fl14.npz'))
+    from warpstr_amd.automata import compile_automaton, reverse_pattern
+    fl = z['flanks']
+    tabs = {0: compile_automaton(str(fl[0]) + '(AGC)' + str(fl[1])),
+            1: compile_automaton(str(fl[2]) + reverse_pattern('(AGC)') + str(fl[3]))}
+    for i, outcome in enumerate(z['outcome']):
+        rev = int(z['reverse'][i])
+        r = oracle.call_read(oracle.Automaton.from_table(tabs[rev], 14), z[f'r{i}_signal'])
+        outcome = str(outcome)
+        if outcome.startswith('ok:'):
+            _, l1, l2 = outcome.split(':')
+            assert r.status == 0 and (r.len1, r.len2) == (int(l1), int(l2))
+        else:
+            assert outcome == 'IndexError' and oracle.STATUS[r.status] in ('segment_range', 'no_repeat')
+
+
+def test_short_read_is_a_status_not_a_crash():
+    z = load_case('agc_fl16')
+    aut = golden_automaton(z, 't')
+    r = oracle.call_read(aut, z['r0_signal'][:4])
+    assert oracle.STATUS[r.status] == 'shape'

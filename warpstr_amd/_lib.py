@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI in include/warpstr_hip.h (warpstr_amd/libwarpstr_hip.so).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no MI355X is visible the
+caller raises.  (Building: ``python -m warpstr_amd.build``.)
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libwarpstr_hip.so')
+
+WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
+READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
+               7: 'segment_range'}
+EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
+           'wsx_caller_set_workspace_limit', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_caller_synchronize',
+           'wsx_caller_last_timing', 'wsx_caller_kernel_name']
+
+
+class WsxAutomaton(C.Structure):
+    _fields_ = [('n_states', C.c_int32), ('endstate', C.c_int32), ('flank_length', C.c_int32), ('reserved', C.c_int32),
+                ('value', C.c_void_p), ('seq_idx', C.c_void_p), ('pred_ptr', C.c_void_p), ('pred_idx', C.c_void_p),
+                ('repeat_mask', C.c_void_p)]
+
+
+class WsxParams(C.Structure):
+    _fields_ = [('min_values_per_state', C.c_int32), ('states_in_segment', C.c_int32), ('threshold', C.c_double),
+                ('max_std', C.c_double), ('method_median', C.c_int32), ('reps_as_one', C.c_int32)]
+
+
+class WsxTraces(C.Structure):
+    _fields_ = [('trace1', C.c_void_p), ('trace2', C.c_void_p), ('rescaled', C.c_void_p), ('badmask', C.c_void_p)]
+
+
+# numpy view of wsx_result
+RESULT_DTYPE = np.dtype([('status', np.int32), ('len1', np.int32), ('len2', np.int32), ('n_trans1', np.int32),
+                         ('n_trans2', np.int32), ('reserved', np.int32), ('cost1', np.float64), ('cost2', np.float64),
+                         ('dtw_end_cost1', np.float64), ('dtw_end_cost2', np.float64)], align=True)
+assert RESULT_DTYPE.itemsize == 56
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(f'{LIB_PATH} not found: build it with `python -m warpstr_amd.build` '
+                                '(the caller has no CPU path)')
+    lib = C.CDLL(LIB_PATH)
+    lib.wsx_last_error.restype = C.c_char_p
+    lib.wsx_caller_kernel_name.restype = C.c_char_p
+    lib.wsx_caller_kernel_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.wsx_caller_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.wsx_caller_destroy.argtypes = [C.c_void_p]
+    lib.wsx_caller_destroy.restype = None
+    lib.wsx_caller_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]
+    lib.wsx_caller_synchronize.argtypes = [C.c_void_p]
+    lib.wsx_call_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]
+    lib.wsx_warp_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.wsx_caller_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double)]
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().wsx_last_error().decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed (code {rc}): {last_error()}')
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

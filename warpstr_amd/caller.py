@@ -1,0 +1,256 @@
+"""Host side of the HIP caller: the reference's step-3 interface over the C ABI.
+
+Mirrors (same names, argument meaning and result fields):
+  ReadSignal                    src/schemas/readsignal.py:6-10
+  CallerResult                  src/caller/caller.py:46-51
+  CallerConfig / RescalerConfig src/config.py:91-119
+  CallerWrapper.run(workload)   src/caller/wrapper.py:104-120  (order-preserving map over reads)
+  WarpSTR.warp                  src/caller/caller.py:189-193   (HipCaller.warp)
+All per-read arithmetic runs on the GPU (libwarpstr_hip.so); this module only packs buffers, and
+turns state paths into base strings (WarpSTR._get_sequence, src/caller/caller.py:178-187).
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .automata import AutomatonTable, locus_automata
+
+
+@dataclass
+class ReadSignal:
+    name: str
+    reverse: bool
+    signal: np.ndarray
+
+
+@dataclass
+class CallerResult:
+    seq: str
+    cost: float
+    resc_seq: str
+    resc_cost: float
+
+
+@dataclass
+class RescalerConfig:
+    reps_as_one: bool = False
+    threshold: float = 0.5
+    max_std: float = 0.5
+    method: str = 'mean'
+
+    def __post_init__(self):
+        assert self.threshold > 0
+        assert self.max_std > 0
+        assert self.method == 'mean' or self.method == 'median'
+
+
+@dataclass
+class CallerConfig:
+    spike_removal: str = 'Brute'
+    min_values_per_state: int = 4
+    states_in_segment: int = 6
+    min_state_similarity: float = 0.75
+    visualize_alignment: bool = True
+    visualize_phase: bool = True
+    visualize_strand: bool = True
+    visualize_cost: bool = True
+
+    def __post_init__(self):
+        assert self.min_values_per_state > 1
+        assert self.states_in_segment > 1
+        assert self.min_state_similarity > 0
+        assert self.spike_removal in ['None', 'median3', 'median5', 'Brute']
+
+
+class ReadCallError(RuntimeError):
+    """A read could not be called (the reference would have raised inside its worker)."""
+
+
+_COMPLEMENT = str.maketrans('ACGT', 'TGCA')
+
+
+def pack_signals(signals: Sequence[np.ndarray]):
+    """Concatenate squiggles -> (float64 buffer, int64 offsets[n+1])."""
+    lens = np.fromiter((len(s) for s in signals), dtype=np.int64, count=len(signals))
+    offsets = np.zeros(len(signals) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    buf = np.empty(int(offsets[-1]), dtype=np.float64)
+    for s, o in zip(signals, offsets[:-1]):
+        buf[o:o + len(s)] = s
+    return buf, offsets
+
+
+class HipCaller:
+    """One handle on one GPU holding the automata of one or more loci (include/warpstr_hip.h)."""
+
+    def __init__(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
+                 caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
+                 device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None):
+        self.lib = _lib.load()
+        if self.lib.wsx_device_count() <= 0:
+            raise RuntimeError('warpstr_amd: no HIP device visible; the caller has no CPU path')
+        self.caller_config = caller_config or CallerConfig()
+        self.rescaler_config = rescaler_config or RescalerConfig()
+        self.automata = list(automata)
+        self.flank_lengths = [int(f) for f in flank_lengths]
+        self._keep = []
+        arr = (_lib.WsxAutomaton * len(self.automata))()
+        for i, (t, fl) in enumerate(zip(self.automata, self.flank_lengths)):
+            bufs = [np.ascontiguousarray(t.value, np.float64), np.ascontiguousarray(t.seq_idx, np.int32),
+                    np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32),
+                    np.ascontiguousarray(t.repeat_mask, np.uint8)]
+            self._keep.append(bufs)
+            arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 0, *[_lib.ptr(b) for b in bufs])
+        prm = _lib.WsxParams(self.caller_config.min_values_per_state, self.caller_config.states_in_segment,
+                             self.rescaler_config.threshold, self.rescaler_config.max_std,
+                             1 if self.rescaler_config.method == 'median' else 0,
+                             1 if self.rescaler_config.reps_as_one else 0)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.wsx_caller_create(C.byref(self.handle), device, C.byref(arr), len(self.automata),
+                                              C.byref(prm), C.c_void_p(stream)), 'wsx_caller_create')
+        if workspace_limit:
+            _lib.check(self.lib.wsx_caller_set_workspace_limit(self.handle, workspace_limit),
+                       'wsx_caller_set_workspace_limit')
+        self.max_states = max(t.n_states for t in self.automata)
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle:
+            self.lib.wsx_caller_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def kernel_name(self, automaton: int = 0) -> str:
+        return self.lib.wsx_caller_kernel_name(self.handle, automaton).decode()
+
+    # ---- host-buffer entry points -------------------------------------------------------------
+    def call(self, signal: np.ndarray, offsets: np.ndarray, automaton_id: np.ndarray, want_traces: bool = False,
+             want_debug: bool = False):
+        """wsx_call_batch on host buffers -> (results structured array, dict of optional per-sample outputs)."""
+        signal = np.ascontiguousarray(signal, np.float64)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
+        n = len(automaton_id)
+        assert len(offsets) == n + 1 and offsets[0] == 0 and offsets[-1] == len(signal)
+        results = np.zeros(n, dtype=_lib.RESULT_DTYPE)
+        extra = {}
+        tr = None
+        if want_traces or want_debug:
+            extra['trace1'] = np.zeros(len(signal), np.uint16)
+            extra['trace2'] = np.zeros(len(signal), np.uint16)
+            if want_debug:
+                extra['rescaled'] = np.zeros(len(signal), np.float64)
+                extra['badmask'] = np.zeros(len(signal), np.uint8)
+            tr = _lib.WsxTraces(_lib.ptr(extra['trace1']), _lib.ptr(extra['trace2']), _lib.ptr(extra.get('rescaled')),
+                                _lib.ptr(extra.get('badmask')))
+        _lib.check(self.lib.wsx_call_batch(self.handle, _lib.WSX_MEM_HOST, _lib.ptr(signal), _lib.ptr(offsets),
+                                           _lib.ptr(automaton_id), n, _lib.ptr(results),
+                                           C.byref(tr) if tr is not None else None), 'wsx_call_batch')
+        return results, extra
+
+    def warp(self, signal: np.ndarray, offsets: np.ndarray, automaton_id: np.ndarray, mask: Optional[np.ndarray] = None,
+             want_last_row: bool = False):
+        """wsx_warp_batch on host buffers -> dict(trace, end_cost, status[, last_row])."""
+        signal = np.ascontiguousarray(signal, np.float64)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
+        n = len(automaton_id)
+        trace = np.zeros(len(signal), np.uint16)
+        end_cost = np.zeros(n, np.float64)
+        status = np.zeros(n, np.int32)
+        stride = self.max_states
+        last_row = np.full((n, stride), np.nan) if want_last_row else None
+        mk = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        _lib.check(self.lib.wsx_warp_batch(self.handle, _lib.WSX_MEM_HOST, _lib.ptr(signal), _lib.ptr(offsets),
+                                           _lib.ptr(automaton_id), n, _lib.ptr(mk), _lib.ptr(trace), _lib.ptr(end_cost),
+                                           _lib.ptr(last_row), stride, _lib.ptr(status)), 'wsx_warp_batch')
+        out = dict(trace=trace, end_cost=end_cost, status=status)
+        if want_last_row:
+            out['last_row'] = last_row
+        return out
+
+    # ---- device-buffer entry point (pointers from torch tensors; asynchronous) -----------------
+    def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
+                    trace1_ptr: int = 0, trace2_ptr: int = 0):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
+        tr = None
+        if trace1_ptr or trace2_ptr:
+            tr = _lib.WsxTraces(C.c_void_p(trace1_ptr or None), C.c_void_p(trace2_ptr or None), None, None)
+        _lib.check(self.lib.wsx_call_batch(self.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(signal_ptr), _lib.ptr(offsets),
+                                           _lib.ptr(automaton_id), len(automaton_id), C.c_void_p(results_ptr),
+                                           C.byref(tr) if tr is not None else None), 'wsx_call_batch')
+
+    def synchronize(self):
+        _lib.check(self.lib.wsx_caller_synchronize(self.handle), 'wsx_caller_synchronize')
+
+    def last_timing(self):
+        dp, nl, tot = C.c_double(), C.c_int32(), C.c_double()
+        _lib.check(self.lib.wsx_caller_last_timing(self.handle, C.byref(dp), C.byref(nl), C.byref(tot)),
+                   'wsx_caller_last_timing')
+        return dict(dp_kernel_ms=dp.value, dp_launches=nl.value, total_ms=tot.value)
+
+
+def sequence_from_trace(table: AutomatonTable, flank_length: int, trace: np.ndarray, reverse: bool) -> str:
+    """WarpSTR._get_sequence (src/caller/caller.py:178-187): last base of every visited state, flanks
+    stripped with the reference's slice arithmetic, reverse-complemented for reverse-strand reads."""
+    trace = np.asarray(trace)
+    starts = np.insert(np.diff(trace) != 0, 0, True)
+    trans = trace[starts]
+    seq = table.last_base[trans].tobytes().decode('ascii')
+    offset = int(table.seq_idx[trans[0]])
+    seq = seq[flank_length - offset:-flank_length]
+    return seq.translate(_COMPLEMENT)[::-1] if reverse else seq
+
+
+class CallerWrapper:
+    """Step-3 driver for one locus (src/caller/wrapper.py:57-120).
+
+    ``flanks`` = (left_template, right_template, left_reverse, right_reverse), i.e. what the
+    squiggler step stores in expected_signals/sequences.csv and ``load_flanks`` reads back.
+    ``threads`` is accepted for interface compatibility; reads are fanned out over GPU wavefronts.
+    """
+
+    def __init__(self, sequence: str, flanks: Sequence[str], flank_length: int, threads: int = 1,
+                 caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
+                 device: int = 0, pore_model=None, on_error: str = 'raise'):
+        self.sequence = sequence.upper()
+        self.flank_length = int(flank_length)
+        self.threads = threads
+        self.on_error = on_error
+        lt, rt, lr, rr = flanks
+        self.temp_sta, self.rev_sta = locus_automata(lt, rt, lr, rr, self.sequence, pore_model)
+        self.hip = HipCaller([self.temp_sta, self.rev_sta], [self.flank_length, self.flank_length], caller_config,
+                             rescaler_config, device=device)
+
+    def run(self, workload: List[ReadSignal]) -> List[CallerResult]:
+        """Run the caller for each piece of signal in the workload; results align with the workload."""
+        if not workload:
+            return []
+        signal, offsets = pack_signals([np.asarray(w.signal, dtype=np.float64) for w in workload])
+        aut = np.array([1 if w.reverse else 0 for w in workload], dtype=np.int32)
+        res, extra = self.hip.call(signal, offsets, aut, want_traces=True)
+        out: List[CallerResult] = []
+        for i, w in enumerate(workload):
+            st = int(res['status'][i])
+            if st != 0:
+                msg = f'read {w.name}: caller status {_lib.READ_STATUS.get(st, st)}'
+                if self.on_error == 'raise':
+                    raise ReadCallError(msg)
+                out.append(CallerResult('', float('nan'), '', float('nan')))
+                continue
+            table = self.rev_sta if w.reverse else self.temp_sta
+            t1 = extra['trace1'][offsets[i]:offsets[i + 1]]
+            t2 = extra['trace2'][offsets[i]:offsets[i + 1]]
+            seq = sequence_from_trace(table, self.flank_length, t1, w.reverse)
+            rseq = sequence_from_trace(table, self.flank_length, t2, w.reverse)
+            assert len(seq) == res['len1'][i] and len(rseq) == res['len2'][i]
+            out.append(CallerResult(seq=seq, cost=float(res['cost1'][i]), resc_seq=rseq, resc_cost=float(res['cost2'][i])))
+        return out

@@ -1,0 +1,728 @@
+// wsx_api.hip -- C ABI of the MI355X-native WarpSTR caller (include/warpstr_hip.h): handle, HBM
+// workspace, chunking, launch sequence.  No compute happens on the host: every stage of the per-read
+// pipeline is a HIP kernel (dtw_kernels.hip, mid_kernels.hip); the host only sorts read ids by
+// length (load balance) and sizes the workspace.
+//
+// Launch sequence per chunk of reads (all on the handle's stream):
+//   dtw_pass (unmasked)  ->  mid(pass 1: run statistics, sort, borders, segmentation mask, cost1)
+//   -> fit (Givens LSQ cubic) -> eval (rescaled signal) -> dtw_pass (masked, rescaled signal)
+//   -> mid(pass 2: run statistics, borders, cost2, allele length)
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/warpstr_hip.h"
+#include "wsx_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            char b_[512];                                                                                         \
+            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            g_err = b_;                                                                                           \
+            return WSX_ERR_HIP;                                                                                   \
+        }                                                                                                         \
+    } while (0)
+
+struct Variant { // which DP kernel an automaton uses
+    int K = 1, F = 2;
+    bool generic = false;
+    int PB() const { return generic ? 4 : (F <= 3 ? 2 : 4); }
+    int R() const { return 32 / PB(); }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic; }
+};
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct wsx_caller {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    wsx_params prm{};
+    std::vector<DevAutomaton> host_aut; // device pointers inside
+    std::vector<Variant> variant;
+    std::vector<int> n_states;
+    DeviceBuf aut_blob, aut_table;
+    uint64_t ws_limit = 16ull << 30;
+    // workspace
+    DeviceBuf meta, samples, reads, bp, stage_sig, stage_out;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
+    size_t dp_events_used = 0;
+    bool timing_valid = false;
+    int max_states = 0;
+};
+
+namespace {
+
+int set_device(wsx_caller *c) { HIPCHK(hipSetDevice(c->device)); return WSX_SUCCESS; }
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve typed arrays out of one allocation
+struct Carver {
+    char *base;
+    size_t used = 0;
+    explicit Carver(void *p) : base((char *)p) {}
+    template <class T> T *take(size_t n)
+    {
+        T *p = (T *)(base + used);
+        used += align_up(n * sizeof(T));
+        return p;
+    }
+};
+
+struct ChunkPlan {
+    int64_t first, count;     // reads
+    int64_t base_off, samples; // samples
+    int max_T;
+};
+
+int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b)
+{
+    if (c->dp_events_used == c->dp_events.size()) {
+        hipEvent_t x, y;
+        HIPCHK(hipEventCreate(&x));
+        HIPCHK(hipEventCreate(&y));
+        c->dp_events.push_back({x, y});
+    }
+    *a = c->dp_events[c->dp_events_used].first;
+    *b = c->dp_events[c->dp_events_used].second;
+    c->dp_events_used++;
+    return WSX_SUCCESS;
+}
+
+// bytes of workspace per sample / per read for a full call
+size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
+{
+    int maxbp = 0;
+    for (auto &v : c->variant) maxbp = std::max(maxbp, v.K * 64 * 4 / v.R() + 1);
+    size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 1 /*mask bits, rounded up*/ + maxbp;
+    if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 1) : 0);
+    return b + 8; // alignment slack
+}
+
+__global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, int first_read, int64_t base_off, int n,
+                                 uint32_t *bits)
+{
+    const int lr = blockIdx.y;
+    if (lr >= n) return;
+    const int r = first_read + lr;
+    const long long off = offsets[r] - base_off;
+    const int T = (int)(offsets[r + 1] - offsets[r]);
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= T) return;
+    uint32_t v = 0;
+    for (int b = 0; b < 32 && w * 32 + b < T; b++) v |= (mask[off + w * 32 + b] ? 1u : 0u) << b;
+    bits[off / 32 + lr + w] = v;
+}
+
+} // namespace
+
+extern "C" {
+
+int wsx_abi_version(void) { return WSX_ABI_VERSION; }
+
+int wsx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *wsx_last_error(void) { return g_err.c_str(); }
+
+int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
+                      const wsx_params *params, void *stream)
+{
+    if (!out || !automata || n_automata <= 0 || !params) {
+        g_err = "wsx_caller_create: null argument";
+        return WSX_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (params->min_values_per_state < 2 || params->states_in_segment < 2 || !(params->threshold > 0) ||
+        !(params->max_std > 0)) {
+        g_err = "wsx_caller_create: invalid parameters (src/config.py:91-119 asserts)";
+        return WSX_ERR_INVALID;
+    }
+    if (params->threshold > 1.0) {
+        g_err = "rescaling.threshold > 1 may leave FITPACK's polynomial branch; not implemented";
+        return WSX_ERR_UNSUPPORTED;
+    }
+    if (params->reps_as_one) {
+        g_err = "rescaling.reps_as_one = True is not implemented by the HIP caller";
+        return WSX_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device available";
+        return WSX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_err = "wsx_caller_create: device index out of range";
+        return WSX_ERR_INVALID;
+    }
+    wsx_caller *c = new wsx_caller();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->prm = *params;
+    HIPCHK(hipSetDevice(device));
+
+    // validate + size the automaton blob
+    size_t blob = 0;
+    for (int a = 0; a < n_automata; a++) {
+        const wsx_automaton &A = automata[a];
+        if (A.n_states <= 0 || A.n_states > 65535 || A.endstate < 0 || A.endstate >= A.n_states || !A.value ||
+            !A.seq_idx || !A.pred_ptr || !A.pred_idx || !A.repeat_mask) {
+            g_err = "wsx_caller_create: malformed automaton";
+            delete c;
+            return WSX_ERR_INVALID;
+        }
+        const int S = A.n_states, E = A.pred_ptr[S];
+        for (int j = 0; j < S; j++)
+            if (A.pred_ptr[j + 1] < A.pred_ptr[j]) {
+                g_err = "wsx_caller_create: pred_ptr not monotone";
+                delete c;
+                return WSX_ERR_INVALID;
+            }
+        for (int e = 0; e < E; e++)
+            if (A.pred_idx[e] < 0 || A.pred_idx[e] >= S) {
+                g_err = "wsx_caller_create: predecessor index out of range";
+                delete c;
+                return WSX_ERR_INVALID;
+            }
+        blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S);
+    }
+    HIPCHK(c->aut_blob.ensure(blob));
+    HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
+    std::vector<char> hblob(blob);
+    size_t used = 0;
+    auto put = [&](const void *src, size_t bytes) -> void * {
+        void *d = (char *)c->aut_blob.p + used;
+        memcpy(hblob.data() + used, src, bytes);
+        used += align_up(bytes);
+        return d;
+    };
+    for (int a = 0; a < n_automata; a++) {
+        const wsx_automaton &A = automata[a];
+        const int S = A.n_states, E = A.pred_ptr[S];
+        DevAutomaton D{};
+        D.n_states = S;
+        D.endstate = A.endstate;
+        D.flank_length = A.flank_length;
+        int mf = 0;
+        for (int j = 0; j < S; j++) mf = std::max(mf, A.pred_ptr[j + 1] - A.pred_ptr[j]);
+        D.max_fanin = mf;
+        D.seq_idx_last = A.seq_idx[S - 1];
+        D.seq_idx_first = A.seq_idx[0];
+        D.value = (const double *)put(A.value, (size_t)S * 8);
+        D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
+        D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
+        int32_t dummy = 0;
+        D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
+        D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
+        c->host_aut.push_back(D);
+        Variant v;
+        v.K = (S + 63) / 64;
+        v.F = std::max(mf, 1);
+        v.generic = !wsx_fast_pass_supported(c->prm.min_values_per_state, v.K, v.F);
+        if (v.generic) {
+            if (mf > 15) {
+                g_err = "automaton fan-in > 15 is not supported";
+                delete c;
+                return WSX_ERR_UNSUPPORTED;
+            }
+            if ((size_t)(c->prm.min_values_per_state + 1) * v.K * 64 * 8 > 150 * 1024) {
+                g_err = "automaton too large for the generic DP kernel's LDS ring";
+                delete c;
+                return WSX_ERR_UNSUPPORTED;
+            }
+        } else {
+            v.F = v.F <= 2 ? 2 : v.F;
+        }
+        c->variant.push_back(v);
+        c->n_states.push_back(S);
+        c->max_states = std::max(c->max_states, S);
+    }
+    HIPCHK(hipMemcpy(c->aut_blob.p, hblob.data(), blob, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreate(&c->ev_begin));
+    HIPCHK(hipEventCreate(&c->ev_end));
+    *out = c;
+    return WSX_SUCCESS;
+}
+
+void wsx_caller_destroy(wsx_caller *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta, &c->samples, &c->reads, &c->bp, &c->stage_sig, &c->stage_out})
+        b->release();
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    for (auto &p : c->dp_events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    delete c;
+}
+
+int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes)
+{
+    if (!c || bytes < (64ull << 20)) return WSX_ERR_INVALID;
+    c->ws_limit = bytes;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_synchronize(wsx_caller *c)
+{
+    if (!c) return WSX_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return WSX_SUCCESS;
+}
+
+const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
+{
+    if (!c || a < 0 || a >= (int)c->variant.size()) return "";
+    const Variant &v = c->variant[a];
+    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, false, v.generic);
+}
+
+} // extern "C"
+
+namespace {
+
+// Common driver for wsx_call_batch (full = true) and wsx_warp_batch (full = false).
+struct BatchIO {
+    int mem;
+    const double *signal;
+    const int64_t *offsets;
+    const int32_t *aut_id;
+    int64_t n;
+    // full call
+    wsx_result *results = nullptr;
+    wsx_traces traces{};
+    // warp only
+    const uint8_t *mask = nullptr;
+    uint16_t *trace = nullptr;
+    double *end_cost = nullptr;
+    double *last_row = nullptr;
+    int32_t last_row_stride = 0;
+    int32_t *status = nullptr;
+};
+
+int run_batch(wsx_caller *c, const BatchIO &io, bool full)
+{
+    if (!c || !io.offsets || !io.aut_id || io.n < 0 || (io.n > 0 && !io.signal)) {
+        g_err = "null argument";
+        return WSX_ERR_INVALID;
+    }
+    if (io.mem != WSX_MEM_HOST && io.mem != WSX_MEM_DEVICE) {
+        g_err = "mem must be WSX_MEM_HOST or WSX_MEM_DEVICE";
+        return WSX_ERR_INVALID;
+    }
+    if (full && !io.results) {
+        g_err = "results is NULL";
+        return WSX_ERR_INVALID;
+    }
+    if (!full && !io.trace) {
+        g_err = "trace is NULL";
+        return WSX_ERR_INVALID;
+    }
+    const int64_t n = io.n;
+    const int nA = (int)c->variant.size();
+    int64_t max_T_all = 0;
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t T = io.offsets[r + 1] - io.offsets[r];
+        if (T < 0 || T > (1 << 30)) {
+            g_err = "offsets must be non-decreasing (read too long or negative length)";
+            return WSX_ERR_INVALID;
+        }
+        if (io.aut_id[r] < 0 || io.aut_id[r] >= nA) {
+            g_err = "automaton_id out of range";
+            return WSX_ERR_INVALID;
+        }
+        max_T_all = std::max(max_T_all, T);
+    }
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->timing_valid = false;
+    c->dp_events_used = 0;
+    if (n == 0) return WSX_SUCCESS;
+    hipStream_t st = c->stream;
+    const bool host = io.mem == WSX_MEM_HOST;
+    const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask);
+
+    // ---- metadata on the device: offsets, automaton ids, launch order ---------------------------
+    // order: reads grouped by DP kernel variant, longest first inside a group (load balance)
+    HIPCHK(c->meta.ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
+    Carver mc(c->meta.p);
+    int64_t *d_offsets = mc.take<int64_t>(n + 1);
+    int32_t *d_autid = mc.take<int32_t>(n);
+    int32_t *d_order = mc.take<int32_t>(n);
+    HIPCHK(hipMemcpyAsync(d_offsets, io.offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_autid, io.aut_id, n * 4, hipMemcpyHostToDevice, st));
+
+    // ---- chunk plan -----------------------------------------------------------------------------
+    const size_t psb = per_sample_bytes(c, host, want_traces || !full);
+    const size_t prb = 256 + (size_t)(io.last_row && host ? c->max_states * 8 : 0);
+    std::vector<ChunkPlan> chunks;
+    {
+        int64_t first = 0;
+        while (first < n) {
+            int64_t cnt = 0, smp = 0;
+            int mt = 0;
+            while (first + cnt < n) {
+                const int64_t T = io.offsets[first + cnt + 1] - io.offsets[first + cnt];
+                const size_t need = (size_t)(smp + T) * psb + (size_t)(cnt + 1) * prb;
+                if (cnt > 0 && need > c->ws_limit) break;
+                smp += T;
+                cnt++;
+                mt = std::max<int>(mt, (int)T);
+            }
+            chunks.push_back({first, cnt, io.offsets[first], smp, mt});
+            first += cnt;
+        }
+    }
+    size_t max_smp = 0, max_cnt = 0;
+    for (auto &ch : chunks) {
+        max_smp = std::max<size_t>(max_smp, ch.samples);
+        max_cnt = std::max<size_t>(max_cnt, ch.count);
+    }
+    int maxbpw = 0; // bp words per sample (upper bound)
+    for (auto &v : c->variant) maxbpw = std::max(maxbpw, (v.K * 64 + v.R() - 1) / v.R());
+    const size_t S1 = max_smp + 64; // per-sample capacity
+    const size_t R1 = max_cnt + 8;
+    // per-sample arrays
+    size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
+                       3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 2 * align_up(S1 * 8) /*fit*/ +
+                       align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
+    HIPCHK(c->samples.ensure(smp_bytes));
+    HIPCHK(c->reads.ensure(R1 * 128 + align_up(R1 * sizeof(wsx_result))));
+    // (off/R + lr + 1) * K*64 words, bounded by samples*maxbpw + reads*K*64*2
+    size_t bp_words = 0;
+    for (auto &v : c->variant)
+        bp_words = std::max(bp_words, (size_t)(S1 / v.R() + R1 + 2) * (size_t)(v.K * 64));
+    HIPCHK(c->bp.ensure(bp_words * 4));
+    if (host) {
+        HIPCHK(c->stage_sig.ensure(S1 * 8));
+        size_t so = align_up(S1 * 2) * 2 + align_up(S1 * 8) + align_up(S1) + align_up(R1 * 8) + align_up(R1 * 4) +
+                    align_up(R1 * (size_t)std::max(io.last_row_stride, 1) * 8);
+        HIPCHK(c->stage_out.ensure(so));
+    }
+
+    HIPCHK(hipEventRecord(c->ev_begin, st));
+    const int m = c->prm.min_values_per_state;
+    std::vector<int32_t> order(n);
+    for (const ChunkPlan &ch : chunks) {
+        const int64_t f = ch.first, cnt = ch.count, boff = ch.base_off;
+        Carver sc(c->samples.p);
+        double *d_resc = sc.take<double>(S1);
+        uint16_t *d_run_state = sc.take<uint16_t>(S1);
+        int32_t *d_run_start = sc.take<int32_t>(S1);
+        double *d_alv = sc.take<double>(S1), *d_ale = sc.take<double>(S1), *d_alc = sc.take<double>(S1);
+        uint8_t *d_alg = sc.take<uint8_t>(S1);
+        double *d_fx = sc.take<double>(S1), *d_fy = sc.take<double>(S1);
+        uint32_t *d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
+        Carver rcv(c->reads.p);
+        int32_t *d_nruns = rcv.take<int32_t>(R1);
+        int32_t *d_status = rcv.take<int32_t>(R1);
+        int32_t *d_fitm = rcv.take<int32_t>(R1);
+        double *d_endcost = rcv.take<double>(R1);
+        double *d_coef = rcv.take<double>(R1 * 6);
+        wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
+
+        // signal of this chunk
+        const double *d_sig;
+        if (host) {
+            HIPCHK(hipMemcpyAsync(c->stage_sig.p, io.signal + boff, (size_t)ch.samples * 8, hipMemcpyHostToDevice, st));
+            d_sig = (const double *)c->stage_sig.p;
+        } else {
+            d_sig = io.signal + boff;
+        }
+        // user-visible per-sample / per-read outputs for this chunk (device pointers)
+        Carver oc(host ? c->stage_out.p : nullptr);
+        uint16_t *d_tr1 = nullptr, *d_tr2 = nullptr;
+        double *d_resc_user = nullptr, *d_endcost_user = nullptr, *d_lastrow = nullptr;
+        uint8_t *d_badmask = nullptr;
+        int32_t *d_status_user = nullptr;
+        wsx_result *d_results = nullptr;
+        if (full) {
+            if (host) {
+                if (io.traces.trace1) d_tr1 = oc.take<uint16_t>(S1);
+                if (io.traces.trace2) d_tr2 = oc.take<uint16_t>(S1);
+                if (io.traces.rescaled) d_resc_user = oc.take<double>(S1);
+                if (io.traces.badmask) d_badmask = oc.take<uint8_t>(S1);
+                d_results = d_results_ws;
+            } else {
+                d_tr1 = io.traces.trace1 ? io.traces.trace1 + boff : nullptr;
+                d_tr2 = io.traces.trace2 ? io.traces.trace2 + boff : nullptr;
+                d_resc_user = io.traces.rescaled ? io.traces.rescaled + boff : nullptr;
+                d_badmask = io.traces.badmask ? io.traces.badmask + boff : nullptr;
+                d_results = io.results + f;
+            }
+        } else {
+            if (host) {
+                d_tr1 = oc.take<uint16_t>(S1);
+                if (io.end_cost) d_endcost_user = oc.take<double>(R1);
+                if (io.status) d_status_user = oc.take<int32_t>(R1);
+                if (io.last_row) d_lastrow = oc.take<double>(R1 * (size_t)io.last_row_stride);
+            } else {
+                d_tr1 = io.trace + boff;
+                d_endcost_user = io.end_cost ? io.end_cost + f : nullptr;
+                d_status_user = io.status ? io.status + f : nullptr;
+                d_lastrow = io.last_row ? io.last_row + (size_t)f * io.last_row_stride : nullptr;
+            }
+        }
+
+        // launch order of this chunk: group by variant, longest first
+        std::vector<std::vector<int32_t>> groups;
+        std::vector<Variant> gvar;
+        for (int64_t r = f; r < f + cnt; r++) {
+            const Variant &v = c->variant[io.aut_id[r]];
+            size_t g = 0;
+            for (; g < gvar.size(); g++)
+                if (gvar[g].same(v)) break;
+            if (g == gvar.size()) {
+                gvar.push_back(v);
+                groups.emplace_back();
+            }
+            groups[g].push_back((int32_t)r);
+        }
+        size_t pos = (size_t)f;
+        std::vector<size_t> gpos;
+        for (auto &g : groups) {
+            std::stable_sort(g.begin(), g.end(), [&](int32_t x, int32_t y) {
+                return (io.offsets[x + 1] - io.offsets[x]) > (io.offsets[y + 1] - io.offsets[y]);
+            });
+            gpos.push_back(pos);
+            std::copy(g.begin(), g.end(), order.begin() + pos);
+            pos += g.size();
+        }
+        HIPCHK(hipMemcpyAsync(d_order + f, order.data() + f, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+
+        // optional input mask (warp-only entry)
+        const uint32_t *pass1_mask = nullptr;
+        if (!full && io.mask) {
+            const uint8_t *d_mask_bytes;
+            if (host) {
+                // reuse the alignment area as staging for the mask bytes
+                HIPCHK(hipMemcpyAsync(d_alg, io.mask + boff, (size_t)ch.samples, hipMemcpyHostToDevice, st));
+                d_mask_bytes = d_alg;
+            } else {
+                d_mask_bytes = io.mask + boff;
+            }
+            dim3 grid((ch.max_T / 32 + 1 + 63) / 64, (unsigned)cnt);
+            hipLaunchKernelGGL(pack_mask_kernel, grid, dim3(64), 0, st, d_mask_bytes, d_offsets, (int)f, boff, (int)cnt,
+                               d_maskbits);
+            HIPCHK(hipGetLastError());
+            pass1_mask = d_maskbits;
+        }
+
+        auto launch_pass = [&](const double *sigp, const uint32_t *maskbits, uint16_t *trace, int check_status,
+                               double *end_cost, double *lastrow, int32_t *status) -> int {
+            for (size_t g = 0; g < groups.size(); g++) {
+                PassArgs pa{};
+                pa.aut = (const DevAutomaton *)c->aut_table.p;
+                pa.signal = sigp;
+                pa.offsets = d_offsets;
+                pa.aut_id = d_autid;
+                pa.order = d_order + gpos[g];
+                pa.n_launch = (int32_t)groups[g].size();
+                pa.first_read = (int32_t)f;
+                pa.base_off = boff;
+                pa.maskbits = maskbits;
+                pa.bp = (uint32_t *)c->bp.p;
+                pa.run_state = d_run_state;
+                pa.run_start = d_run_start;
+                pa.n_runs = d_nruns;
+                pa.trace = trace;
+                pa.end_cost = end_cost;
+                pa.last_row = lastrow;
+                pa.last_row_stride = io.last_row_stride;
+                pa.status = status;
+                pa.check_status = check_status;
+                pa.m = m;
+                hipEvent_t e0, e1;
+                int rc2 = get_event_pair(c, &e0, &e1);
+                if (rc2) return rc2;
+                HIPCHK(hipEventRecord(e0, st));
+                HIPCHK(wsx_launch_pass(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
+                HIPCHK(hipEventRecord(e1, st));
+            }
+            return WSX_SUCCESS;
+        };
+
+        if (!full) {
+            rc = launch_pass(d_sig, pass1_mask, d_tr1, 0, d_endcost_user ? d_endcost_user : d_endcost, d_lastrow,
+                             d_status_user ? d_status_user : d_status);
+            if (rc) return rc;
+            if (host) {
+                HIPCHK(hipMemcpyAsync(io.trace + boff, d_tr1, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
+                if (io.end_cost) HIPCHK(hipMemcpyAsync(io.end_cost + f, d_endcost_user, (size_t)cnt * 8, hipMemcpyDeviceToHost, st));
+                if (io.status) HIPCHK(hipMemcpyAsync(io.status + f, d_status_user, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+                if (io.last_row)
+                    HIPCHK(hipMemcpyAsync(io.last_row + (size_t)f * io.last_row_stride, d_lastrow,
+                                          (size_t)cnt * io.last_row_stride * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st)); // staging buffers are reused by the next chunk
+            }
+            continue;
+        }
+
+        // ---- pass 1 ----
+        rc = launch_pass(d_sig, nullptr, d_tr1, 0, d_endcost, nullptr, d_status);
+        if (rc) return rc;
+        MidArgs ma{};
+        ma.aut = (const DevAutomaton *)c->aut_table.p;
+        ma.prm = DevParams{c->prm.min_values_per_state, c->prm.states_in_segment, c->prm.threshold, c->prm.max_std,
+                           c->prm.method_median, c->prm.reps_as_one};
+        ma.signal = d_sig;
+        ma.offsets = d_offsets;
+        ma.aut_id = d_autid;
+        ma.n_reads = (int32_t)cnt;
+        ma.first_read = (int32_t)f;
+        ma.base_off = boff;
+        ma.run_state = d_run_state;
+        ma.run_start = d_run_start;
+        ma.n_runs = d_nruns;
+        ma.pass = 1;
+        ma.al_value = d_alv;
+        ma.al_expected = d_ale;
+        ma.al_cost = d_alc;
+        ma.al_good = d_alg;
+        ma.fit_x = d_fx;
+        ma.fit_y = d_fy;
+        ma.fit_m = d_fitm;
+        ma.maskbits = d_maskbits;
+        ma.badmask_bytes = d_badmask;
+        ma.status = d_status;
+        ma.end_cost = d_endcost;
+        ma.results = d_results;
+        HIPCHK(wsx_launch_mid(ma, st));
+        FitArgs fa{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, d_coef, d_status};
+        HIPCHK(wsx_launch_fit(fa, st));
+        EvalArgs ea{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_sig, d_coef, d_status, d_resc, d_resc_user};
+        HIPCHK(wsx_launch_eval(ea, ch.max_T, st));
+        // ---- pass 2 ----
+        rc = launch_pass(d_resc, d_maskbits, d_tr2, 1, d_endcost, nullptr, d_status);
+        if (rc) return rc;
+        ma.signal = d_resc;
+        ma.pass = 2;
+        ma.maskbits = nullptr;
+        ma.badmask_bytes = nullptr;
+        HIPCHK(wsx_launch_mid(ma, st));
+        if (host) {
+            HIPCHK(hipMemcpyAsync(io.results + f, d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, st));
+            if (io.traces.trace1) HIPCHK(hipMemcpyAsync(io.traces.trace1 + boff, d_tr1, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
+            if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, d_tr2, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
+            if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, d_resc_user, (size_t)ch.samples * 8, hipMemcpyDeviceToHost, st));
+            if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, d_badmask, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev_end, st));
+    c->timing_valid = true;
+    if (host) HIPCHK(hipStreamSynchronize(st));
+    return WSX_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets, const int32_t *automaton_id,
+                   int64_t n_reads, wsx_result *results, const wsx_traces *traces)
+{
+    BatchIO io{};
+    io.mem = mem;
+    io.signal = signal;
+    io.offsets = offsets;
+    io.aut_id = automaton_id;
+    io.n = n_reads;
+    io.results = results;
+    if (traces) io.traces = *traces;
+    return run_batch(c, io, true);
+}
+
+int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets, const int32_t *automaton_id,
+                   int64_t n_reads, const uint8_t *mask, uint16_t *trace, double *end_cost, double *last_row,
+                   int32_t last_row_stride, int32_t *status)
+{
+    BatchIO io{};
+    io.mem = mem;
+    io.signal = signal;
+    io.offsets = offsets;
+    io.aut_id = automaton_id;
+    io.n = n_reads;
+    io.mask = mask;
+    io.trace = trace;
+    io.end_cost = end_cost;
+    io.last_row = last_row;
+    io.last_row_stride = last_row_stride;
+    io.status = status;
+    if (last_row && c && last_row_stride < c->max_states) {
+        g_err = "last_row_stride smaller than the largest automaton";
+        return WSX_ERR_INVALID;
+    }
+    return run_batch(c, io, false);
+}
+
+int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms)
+{
+    if (!c) return WSX_ERR_INVALID;
+    if (!c->timing_valid) {
+        g_err = "no completed batch to time";
+        return WSX_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_end));
+    float tot = 0.f;
+    HIPCHK(hipEventElapsedTime(&tot, c->ev_begin, c->ev_end));
+    double dp = 0.0;
+    for (size_t i = 0; i < c->dp_events_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->dp_events[i].first, c->dp_events[i].second));
+        dp += ms;
+    }
+    if (dp_kernel_ms) *dp_kernel_ms = dp;
+    if (dp_launches) *dp_launches = (int32_t)c->dp_events_used;
+    if (total_ms) *total_ms = tot;
+    return WSX_SUCCESS;
+}
+
+} // extern "C"

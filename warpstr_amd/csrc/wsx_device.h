@@ -1,0 +1,126 @@
+// wsx_device.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+//
+// HBM layout (one "chunk" = a contiguous range of reads of the batch, sized to the workspace limit):
+//   per-sample arrays are indexed by   loff = offsets[r] - base_off      (signal, rescaled, trace, run lists,
+//                                                                         alignment records)
+//   per-read arrays by                 lr   = r - first_read
+//   packed per-sample bit masks by     loff/32 + lr                       (32 samples per word, one spare word/read)
+//   DP back-pointer scratch by         (loff/R + lr) * K*64 words         (R = samples per 32-bit word, K = states/lane)
+// so no extra prefix sums are needed besides the caller's own offsets[].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WSX_WAVE 64
+#define WSX_MAX_K 5      // states per lane in the register-resident DP kernel (S <= 320)
+#define WSX_MAX_F 4      // fan-in handled by the register-resident DP kernel
+
+struct DevAutomaton {
+    int32_t n_states;
+    int32_t endstate;
+    int32_t flank_length;
+    int32_t max_fanin;
+    int32_t seq_idx_last;   // seq_idx[S-1]
+    int32_t seq_idx_first;  // unused by kernels; kept for debugging
+    const double *value;
+    const int32_t *seq_idx;
+    const int32_t *pred_ptr;
+    const int32_t *pred_idx;
+    const uint8_t *repeat_mask;
+};
+
+struct DevParams {
+    int32_t m;                  // min_values_per_state
+    int32_t states_in_segment;
+    double threshold;
+    double max_std;
+    int32_t method_median;
+    int32_t reps_as_one;
+};
+
+// Arguments of one DP pass (fill + traceback) over the reads listed in `order`.
+struct PassArgs {
+    const DevAutomaton *aut;
+    const double *signal;      // per-sample, already offset to the chunk (index loff + i)
+    const int64_t *offsets;    // global offsets[] (device copy), indexed by global read id
+    const int32_t *aut_id;     // global
+    const int32_t *order;      // read ids of this launch
+    int32_t n_launch;
+    int32_t first_read;
+    int64_t base_off;
+    const uint32_t *maskbits;  // packed mask (NULL = unmasked pass)
+    uint32_t *bp;              // back-pointer scratch
+    uint16_t *run_state;       // runs, in reverse time order
+    int32_t *run_start;
+    int32_t *n_runs;           // per read
+    uint16_t *trace;           // optional per-sample state ids
+    double *end_cost;          // optional per read
+    double *last_row;          // optional per read, stride last_row_stride
+    int32_t last_row_stride;
+    int32_t *status;           // per read: written by pass 1, read (skip if != 0) by pass 2
+    int32_t check_status;      // 1: skip reads whose status is already non-zero and do not write status
+    int32_t m;
+};
+
+// Arguments of the alignment-statistics / masking stage.
+struct MidArgs {
+    const DevAutomaton *aut;
+    DevParams prm;
+    const double *signal;      // signal the trace was computed on
+    const int64_t *offsets;
+    const int32_t *aut_id;
+    int32_t n_reads;           // reads in chunk
+    int32_t first_read;
+    int64_t base_off;
+    const uint16_t *run_state;
+    const int32_t *run_start;
+    const int32_t *n_runs;
+    int32_t pass;              // 1 or 2
+    // alignment records (forward order), per-sample capacity
+    double *al_value;
+    double *al_expected;
+    double *al_cost;
+    uint8_t *al_good;
+    // sorted filtered pairs for the rescaling fit (pass 1)
+    double *fit_x;
+    double *fit_y;
+    int32_t *fit_m;            // per read
+    uint32_t *maskbits;        // out (pass 1)
+    uint8_t *badmask_bytes;    // optional out (pass 1), per sample
+    int32_t *status;           // per read (in/out)
+    const double *end_cost;    // per read, from the DP pass
+    // results
+    void *results;             // wsx_result[] (per read)
+};
+
+struct FitArgs {
+    const int64_t *offsets;
+    int32_t n_reads;
+    int32_t first_read;
+    int64_t base_off;
+    const double *fit_x;
+    const double *fit_y;
+    const int32_t *fit_m;
+    double *coef;              // per read: xb, xe, c0..c3 (6 doubles)
+    int32_t *status;
+};
+
+struct EvalArgs {
+    const int64_t *offsets;
+    int32_t n_reads;
+    int32_t first_read;
+    int64_t base_off;
+    const double *signal;
+    const double *coef;
+    const int32_t *status;
+    double *out;               // rescaled signal
+    double *out_user;          // optional second copy (user-visible), may be NULL
+};
+
+// Host-side launchers (defined next to the kernels).
+hipError_t wsx_launch_pass(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s);
+hipError_t wsx_launch_mid(const MidArgs &a, hipStream_t s);
+hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
+hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
+bool wsx_fast_pass_supported(int m, int K, int F);
+const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic);

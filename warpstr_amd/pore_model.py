@@ -1,0 +1,86 @@
+"""Expected k-mer current levels (the squiggler side of the hot path).
+
+Mirrors the behaviour of the reference's ``PoreModel`` (src/squiggler/pore_model.py:13-47):
+the ONT 6-mer table's ``level_mean`` column is MAD-normalised over all 4096 k-mers
+(src/schemas/fast5.py:104-114) and looked up by k-mer.  Here the table is a flat f64 array
+indexed by the base-4 code of the k-mer (A=0,C=1,G=2,T=3, first base most significant), which
+is also the layout the HIP library receives (``state value`` per automaton state).
+
+Data provenance: ``data/r94_6mer_level_mean.npy`` holds the 4096 ``level_mean`` values of the
+ONT r9.4 450 bps 6-mer template model shipped upstream as
+``example/deps/template_median68pA.model`` (rows are in lexicographic k-mer order).  A TSV in that
+same format can be given instead (config key ``pore_model_path``).
+"""
+import os
+from typing import Optional
+
+import numpy as np
+
+_BASE_CODE = {'A': 0, 'C': 1, 'G': 2, 'T': 3}
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'r94_6mer_level_mean.npy')
+
+
+def normalize_signal_mad(data):
+    """Median/MAD normalisation; same arithmetic as src/schemas/fast5.py:104-114."""
+    data = np.asarray(data)
+    shift = np.mean(np.percentile(data, (46.5, 53.5)))
+    scale = np.median(np.abs(data - shift))
+    return np.asarray((data - shift) / scale)
+
+
+def kmer_code(kmer: str) -> int:
+    code = 0
+    for ch in kmer:
+        code = code * 4 + _BASE_CODE[ch]
+    return code
+
+
+class PoreModel:
+    """k-mer -> normalised expected level."""
+
+    def __init__(self, pore_model_path: Optional[str] = None):
+        if pore_model_path is None:
+            level_mean = np.load(_DATA)
+            self.kmersize = 6
+        else:
+            level_mean, self.kmersize = self._read_tsv(pore_model_path)
+        if level_mean.shape[0] != 4 ** self.kmersize:
+            raise ValueError('pore model table must hold every k-mer exactly once')
+        self.level_norm = normalize_signal_mad(level_mean)
+
+    @staticmethod
+    def _read_tsv(path: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError('Not found pore model table at path', path)
+        with open(path, 'r') as f:
+            header = f.readline().rstrip('\n').split('\t')
+            if 'kmer' not in header or 'level_mean' not in header:
+                raise ValueError('Pore model table do not contains "kmer" and "level_mean" columns')
+            ik, il = header.index('kmer'), header.index('level_mean')
+            rows = [line.rstrip('\n').split('\t') for line in f if line.strip()]
+        k = len(rows[0][ik])
+        out = np.full(4 ** k, np.nan)
+        for r in rows:
+            out[kmer_code(r[ik])] = float(r[il])
+        if np.isnan(out).any():
+            raise ValueError('pore model table is missing k-mers')
+        return out, k
+
+    def get_value(self, kmer: str) -> float:
+        """Level of one k-mer (src/squiggler/pore_model.py:45-47)."""
+        return float(self.level_norm[kmer_code(kmer)])
+
+    def levels_for(self, sequence: str) -> np.ndarray:
+        """Expected level of every k-mer of a plain sequence (src/squiggler/Squiggler.py:20-28)."""
+        k = self.kmersize
+        return np.array([self.get_value(sequence[i:i + k]) for i in range(len(sequence) - k + 1)], dtype=np.float64)
+
+
+_default: Optional[PoreModel] = None
+
+
+def default_pore_model() -> PoreModel:
+    global _default
+    if _default is None:
+        _default = PoreModel()
+    return _default
