@@ -1,0 +1,221 @@
+"""Parity of the HIP caller (through the C ABI) with the CPU oracle and the golden vectors.
+Everything here needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import DEFAULT_CASES, assert_close_rel, load_case
+from warpstr_amd import synth
+from warpstr_amd.automata import compile_automaton, reverse_pattern
+from warpstr_amd.caller import (CallerConfig, CallerWrapper, HipCaller, ReadSignal, RescalerConfig, pack_signals,
+                                sequence_from_trace)
+
+pytestmark = pytest.mark.gpu
+
+COST_REL = 1e-5  # north_star tolerance on DTW cost; integer outputs must be identical
+
+
+def tables_of(z):
+    fl = [str(s) for s in z['flanks']]
+    pat = str(z['pattern'])
+    t = compile_automaton(fl[0] + pat + fl[1])
+    r = compile_automaton(fl[2] + reverse_pattern(pat) + fl[3])
+    return t, r
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_warp_matches_golden(case):
+    """WarpSTR.warp: state path and last DP row, unmasked (pass 1) and masked (pass 2 inputs from the fixture)."""
+    z = load_case(case)
+    t, r = tables_of(z)
+    fl = int(z['flank_length'])
+    hip = HipCaller([t, r], [fl, fl])
+    n = int(z['n_reads'])
+    aut = z['reverse'].astype(np.int32)
+    sig, off = pack_signals([z[f'r{i}_signal'] for i in range(n)])
+    out = hip.warp(sig, off, aut, want_last_row=True)
+    for i in range(n):
+        S = (r if aut[i] else t).n_states
+        assert out['status'][i] == 0
+        assert np.array_equal(out['trace'][off[i]:off[i + 1]], z[f'r{i}_trace1'])
+        assert np.array_equal(out['last_row'][i, :S], z[f'r{i}_dlast1'])  # bit-identical: add/abs/compare only
+    sig2, _ = pack_signals([z[f'r{i}_rescaled'] for i in range(n)])
+    mask, _ = pack_signals([z[f'r{i}_badmask'].astype(np.float64) for i in range(n)])
+    out2 = hip.warp(sig2, off, aut, mask=mask.astype(np.uint8), want_last_row=True)
+    for i in range(n):
+        S = (r if aut[i] else t).n_states
+        assert np.array_equal(out2['trace'][off[i]:off[i + 1]], z[f'r{i}_trace2'])
+        assert np.array_equal(out2['last_row'][i, :S], z[f'r{i}_dlast2'])
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_call_matches_golden(case):
+    """WarpSTR.run end to end against the values recorded from the upstream caller."""
+    z = load_case(case)
+    t, r = tables_of(z)
+    fl = int(z['flank_length'])
+    hip = HipCaller([t, r], [fl, fl])
+    n = int(z['n_reads'])
+    aut = z['reverse'].astype(np.int32)
+    sig, off = pack_signals([z[f'r{i}_signal'] for i in range(n)])
+    res, ex = hip.call(sig, off, aut, want_debug=True)
+    for i in range(n):
+        sl = slice(off[i], off[i + 1])
+        assert res['status'][i] == 0
+        assert np.array_equal(ex['trace1'][sl], z[f'r{i}_trace1'])
+        assert np.array_equal(ex['badmask'][sl], z[f'r{i}_badmask'])
+        np.testing.assert_allclose(ex['rescaled'][sl], z[f'r{i}_rescaled'], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(ex['trace2'][sl], z[f'r{i}_trace2'])
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
+        tab = r if aut[i] else t
+        assert sequence_from_trace(tab, fl, ex['trace1'][sl], bool(aut[i])) == seq
+        assert sequence_from_trace(tab, fl, ex['trace2'][sl], bool(aut[i])) == rseq
+        assert_close_rel(res['cost1'][i], z[f'r{i}_cost'][0], COST_REL)
+        assert_close_rel(res['cost2'][i], z[f'r{i}_cost'][1], COST_REL)
+        assert_close_rel(res['dtw_end_cost1'][i], z[f'r{i}_dlast1'][tab.endstate], COST_REL)
+        assert_close_rel(res['dtw_end_cost2'][i], z[f'r{i}_dlast2'][tab.endstate], COST_REL)
+
+
+def _compare_with_oracle(locus, fl, sigs, revs, caller_config=None, rescaler_config=None, params=None):
+    hip = HipCaller([locus.template, locus.reverse], [fl, fl], caller_config, rescaler_config)
+    sig, off = pack_signals(sigs)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    res, ex = hip.call(sig, off, aut, want_debug=True)
+    oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+    n_ok = 0
+    for i, s in enumerate(sigs):
+        o = oracle.call_read(oa[aut[i]], s, params or oracle.Params())
+        assert res['status'][i] == o.status, (i, res['status'][i], o.status)
+        if o.status:
+            continue
+        n_ok += 1
+        sl = slice(off[i], off[i + 1])
+        assert np.array_equal(ex['trace1'][sl], o.trace1), i
+        assert np.array_equal(ex['badmask'][sl], o.badmask), i
+        assert np.array_equal(ex['trace2'][sl], o.trace2), i
+        assert (res['len1'][i], res['len2'][i], res['n_trans1'][i], res['n_trans2'][i]) == \
+            (o.len1, o.len2, o.n_trans1, o.n_trans2)
+        assert_close_rel(res['cost1'][i], o.cost1, COST_REL)
+        assert_close_rel(res['cost2'][i], o.cost2, COST_REL)
+        assert_close_rel(res['dtw_end_cost1'][i], o.dtw_end_cost1, COST_REL)
+        assert_close_rel(res['dtw_end_cost2'][i], o.dtw_end_cost2, COST_REL)
+    return hip, res, n_ok
+
+
+@pytest.mark.parametrize('pattern,fl,T,n', [
+    ('(AGC)', 16, 1500, 48),                       # config 2 shape: K=1
+    ('(AGC)AACAGCCGCCAC(CGC)', 19, 2000, 32),      # config 3 shape: S ~ 63
+    ('((CAGG){CAGM})(CAGA)(CA)', 40, (500, 5000), 24),  # config 5 shape: S ~ 128, fan-in 3, ragged
+    ('(AAAT)', 110, (2271, 3701), 10),             # config 1 shape (test_caller_only segment lengths), K=4
+    ('(NGC)', 24, 1800, 12),                       # fan-in 4 -> 4-bit pointers
+])
+def test_call_matches_oracle_seeded(pattern, fl, T, n):
+    locus = synth.make_locus(pattern, fl, 1234)
+    sigs, revs, _ = synth.batch(locus, n, T, 99, lo=3, hi=28)
+    _, _, n_ok = _compare_with_oracle(locus, fl, sigs, revs)
+    assert n_ok >= n // 2
+
+
+def test_generic_kernel_other_min_values_per_state():
+    """min_values_per_state != 4 takes the general DP kernel; median state values."""
+    locus = synth.make_locus('(AGC)', 20, 77)
+    sigs, revs, _ = synth.batch(locus, 16, 1400, 7)
+    for m, method, sis in [(3, 'median', 5), (5, 'mean', 6), (2, 'mean', 4)]:
+        _compare_with_oracle(locus, 20, sigs, revs, CallerConfig(min_values_per_state=m, states_in_segment=sis),
+                             RescalerConfig(method=method),
+                             oracle.Params(min_values_per_state=m, states_in_segment=sis, method=method))
+
+
+def test_statuses_instead_of_crashes():
+    """flank_length < 16 makes the upstream caller raise IndexError on some reads (recorded fixture);
+    too-short reads; the batch must survive and flag exactly those reads."""
+    z = np.load('tests/golden/neg_fl14.npz')
+    fl = [str(s) for s in z['flanks']]
+    t = compile_automaton(fl[0] + '(AGC)' + fl[1])
+    r = compile_automaton(fl[2] + reverse_pattern('(AGC)') + fl[3])
+    n = len(z['outcome'])
+    sigs = [z[f'r{i}_signal'] for i in range(n)] + [z['r0_signal'][:4], z['r0_signal'][:3]]
+    aut = np.concatenate([z['reverse'].astype(np.int32), np.zeros(2, np.int32)])
+    hip = HipCaller([t, r], [14, 14])
+    sig, off = pack_signals(sigs)
+    res, _ = hip.call(sig, off, aut)
+    for i, outcome in enumerate(z['outcome']):
+        outcome = str(outcome)
+        if outcome.startswith('ok:'):
+            _, l1, l2 = outcome.split(':')
+            assert res['status'][i] == 0 and (res['len1'][i], res['len2'][i]) == (int(l1), int(l2))
+        else:
+            assert res['status'][i] in (6, 7)
+    assert res['status'][n] == 1 and res['status'][n + 1] == 1
+
+
+def test_caller_wrapper_interface():
+    """CallerWrapper.run: order-preserving, CallerResult strings as upstream builds them."""
+    z = load_case('hd_fl20')
+    fl = int(z['flank_length'])
+    cw = CallerWrapper(str(z['pattern']), [str(s) for s in z['flanks']], fl)
+    n = int(z['n_reads'])
+    order = [3, 0, 5, 1, 4, 2]
+    work = [ReadSignal(f'read{i}', bool(z['reverse'][i]), z[f'r{i}_signal']) for i in order]
+    out = cw.run(work)
+    assert len(out) == n
+    for k, i in enumerate(order):
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert out[k].seq == seq and out[k].resc_seq == rseq
+        assert_close_rel(out[k].cost, z[f'r{i}_cost'][0], COST_REL)
+        assert_close_rel(out[k].resc_cost, z[f'r{i}_cost'][1], COST_REL)
+    assert cw.run([]) == []
+
+
+def test_chunking_and_order_invariance():
+    """Results do not depend on batch composition: tiny workspace limit (many chunks), permuted input."""
+    locus = synth.make_locus('(AGC)', 16, 5)
+    sigs, revs, _ = synth.batch(locus, 40, (700, 1600), 3)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    sig, off = pack_signals(sigs)
+    big = HipCaller([locus.template, locus.reverse], [16, 16])
+    r0, e0 = big.call(sig, off, aut, want_traces=True)
+    small = HipCaller([locus.template, locus.reverse], [16, 16], workspace_limit=64 << 20)
+    perm = np.random.default_rng(0).permutation(len(sigs))
+    sig2, off2 = pack_signals([sigs[i] for i in perm])
+    r1, e1 = small.call(sig2, off2, aut[perm], want_traces=True)
+    for k, i in enumerate(perm):
+        for f in ('status', 'len1', 'len2', 'n_trans1', 'n_trans2'):
+            assert r0[f][i] == r1[f][k]
+        assert r0['cost2'][i] == r1['cost2'][k] or (np.isnan(r0['cost2'][i]) and np.isnan(r1['cost2'][k]))
+        assert np.array_equal(e0['trace2'][off[i]:off[i + 1]], e1['trace2'][off2[k]:off2[k + 1]])
+
+
+def test_full_size_properties():
+    """BASELINE config-3 shape at a size the oracle cannot sweep: size-independent properties.
+    (a) determinism: two runs give identical bytes; (b) every path is a valid automaton walk that
+    starts in the first states, ends in `endstate`, and dwells >= m-1 samples after each transition;
+    (c) a spot sample agrees with the oracle."""
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    n = 4096
+    sigs, revs, _ = synth.batch(locus, n, 2000, 11)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    sig, off = pack_signals(sigs)
+    hip = HipCaller([locus.template, locus.reverse], [19, 19])
+    r0, e0 = hip.call(sig, off, aut, want_traces=True)
+    r1, e1 = hip.call(sig, off, aut, want_traces=True)
+    assert r0.tobytes() == r1.tobytes() or np.array_equal(np.nan_to_num(r0['cost2']), np.nan_to_num(r1['cost2']))
+    assert np.array_equal(e0['trace2'], e1['trace2'])
+    tabs = [locus.template, locus.reverse]
+    ok = np.flatnonzero(r0['status'] == 0)
+    assert len(ok) > 0.9 * n
+    for i in ok[:512]:
+        tab = tabs[aut[i]]
+        tr = e0['trace2'][off[i]:off[i + 1]].astype(np.int64)
+        assert tr[-1] == tab.endstate and tr[0] <= 4
+        ch = np.flatnonzero(np.diff(tr) != 0)
+        for c in ch:
+            assert tr[c] in tab.incoming(int(tr[c + 1]))
+        runs = np.diff(np.concatenate([[-1], ch, [len(tr) - 1]]))
+        assert runs[:-1].min() >= 3  # back >= m-1 samples per visited state (the last run may be 1 sample)
+    oa = [oracle.Automaton.from_table(locus.template, 19), oracle.Automaton.from_table(locus.reverse, 19)]
+    for i in ok[::512]:
+        o = oracle.call_read(oa[aut[i]], sigs[i])
+        assert o.status == 0 and np.array_equal(e0['trace2'][off[i]:off[i + 1]], o.trace2)
+        assert (r0['len1'][i], r0['len2'][i]) == (o.len1, o.len2)

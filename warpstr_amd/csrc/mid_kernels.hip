@@ -533,12 +533,12 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 // splev (ext = 0) of the fitted cubic at every sample of the read.
 __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 {
-    const int lr = blockIdx.y;
+    const int lr = blockIdx.x; // reads on grid.x (no 65535 limit), 256-sample tiles on grid.y
     if (a.status[lr] != 0) return;
     const int r = a.first_read + lr;
     const long long off = a.offsets[r] - a.base_off;
     const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;
     if (i >= T) return;
     const double *co = a.coef + (size_t)lr * 6;
     const double xb = co[0], xe = co[1];
@@ -572,6 +572,6 @@ hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s)
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s)
 {
     if (a.n_reads <= 0 || max_T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_kernel, dim3((max_T + 255) / 256, a.n_reads), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(eval_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }

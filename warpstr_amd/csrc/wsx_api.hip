@@ -138,12 +138,12 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 __global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, int first_read, int64_t base_off, int n,
                                  uint32_t *bits)
 {
-    const int lr = blockIdx.y;
+    const int lr = blockIdx.x;
     if (lr >= n) return;
     const int r = first_read + lr;
     const long long off = offsets[r] - base_off;
     const int T = (int)(offsets[r + 1] - offsets[r]);
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = blockIdx.y * blockDim.x + threadIdx.x;
     if (w * 32 >= T) return;
     uint32_t v = 0;
     for (int b = 0; b < 32 && w * 32 + b < T; b++) v |= (mask[off + w * 32 + b] ? 1u : 0u) << b;
@@ -547,7 +547,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             } else {
                 d_mask_bytes = io.mask + boff;
             }
-            dim3 grid((ch.max_T / 32 + 1 + 63) / 64, (unsigned)cnt);
+            dim3 grid((unsigned)cnt, (ch.max_T / 32 + 1 + 63) / 64);
             hipLaunchKernelGGL(pack_mask_kernel, grid, dim3(64), 0, st, d_mask_bytes, d_offsets, (int)f, boff, (int)cnt,
                                d_maskbits);
             HIPCHK(hipGetLastError());
