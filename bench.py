@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the HIP caller on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--samples T]
+
+Workload (config.workload): BASELINE.json configs[2] -- 100k synthetic reads, 2 kSample squiggles, HD-style
+interrupted automaton `(AGC)AACAGCCGCCAC(CGC)` with <= 64 states -- per GPU (weak scaling: reads shard with
+no exchange on the data path; one RCCL all-gather collects the per-read result records each step).
+A "step" is one full call of the batch: both DTW passes, rescaling fit, bad-repeat masking, allele lengths.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATTERN = '(AGC)AACAGCCGCCAC(CGC)'
+FLANK = 19
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VALU_PEAK = 78.6e12 / 2  # fp64 vector adds/s: 78.6 TFLOP/s counts FMA as 2
+
+
+def make_workload(n_reads, T, seed, device):
+    """Clean level sequences on the host (seeded), noise added on the device (seeded)."""
+    import torch
+
+    from warpstr_amd import synth
+    locus = synth.make_locus(PATTERN, FLANK, 2024, max_states=64)
+    rng = np.random.default_rng(seed)
+    n_tpl = min(n_reads, 2048)
+    pm_sigs, revs = [], []
+    for _ in range(n_tpl):
+        rev = bool(rng.random() < 0.5)
+        s, _ = synth.squiggle(locus, rev, T, rng, sigma=0.0)
+        pm_sigs.append(s)
+        revs.append(rev)
+    clean = torch.from_numpy(np.stack(pm_sigs)).to(device)
+    idx = torch.from_numpy(rng.integers(0, n_tpl, size=n_reads)).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    signal = clean[idx] + 0.25 * torch.randn((n_reads, T), generator=g, device=device, dtype=torch.float64)
+    signal = signal.reshape(-1).contiguous()
+    aut = np.array(revs, dtype=np.int32)[idx.cpu().numpy()]
+    offsets = np.arange(n_reads + 1, dtype=np.int64) * T
+    return locus, signal, offsets, aut
+
+
+def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
+    """The CPU oracle (a C port of the reference algorithm; the Python reference cannot travel) on this
+    box's host cores, on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    oa = [oracle.Automaton.from_table(locus.template, FLANK), oracle.Automaton.from_table(locus.reverse, FLANK)]
+    oracle.lib()
+
+    def one(i):
+        return oracle.call_read(oa[aut[i]], signal_host[i * T:(i + 1) * T], debug=False).len2
+
+    t0 = time.perf_counter()
+    one(0)
+    t1 = time.perf_counter() - t0
+    n = int(max(cores, min(len(aut), budget_s * cores / max(t1, 1e-4))))
+    n = min(n, len(aut))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the call
+        list(ex.map(one, range(n)))
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'reads/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--reads', type=int, default=100000)
+    ap.add_argument('--samples', type=int, default=2000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    from warpstr_amd import _lib
+    from warpstr_amd.caller import HipCaller
+    from warpstr_amd.dist import gather_results
+
+    n, T = args.reads, args.samples
+    locus, signal, offsets, aut = make_workload(n, T, 1000 + rank, device)
+    stream = torch.cuda.current_stream().cuda_stream
+    hip = HipCaller([locus.template, locus.reverse], [FLANK, FLANK], device=local, stream=stream,
+                    workspace_limit=96 << 30)
+    results = torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device)
+
+    def step():
+        hip.call_device(signal.data_ptr(), offsets, aut, results.data_ptr())
+        return gather_results(results, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dp_ms, dp_launches = 0.0, 0
+    for _ in range(args.steps):
+        allres = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = hip.last_timing()  # HIP events on the launch stream, last step
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        res = allres.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+        ok = int((res['status'] == 0).sum())
+        S = max(locus.template.n_states, locus.reverse.n_states)
+        total_reads = n * world * args.steps
+        reads_per_s = total_reads / dt
+        # dominant kernel = the DTW pass; 2 launches per step (one per pass), each over n reads.
+        launch_ms = tm['dp_kernel_ms'] / max(tm['dp_launches'], 1)
+        algo_bytes_per_launch = n * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
+        achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        cells_per_s = n * T * S / (launch_ms * 1e-3)
+        out = {
+            'metric': 'reads/s (STR segments aligned)', 'value': reads_per_s, 'unit': 'reads/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[2]: {n} reads/GPU x {T} samples, {PATTERN} flank {FLANK}, '
+                                   f'S={locus.template.n_states}/{locus.reverse.n_states} states, both passes',
+                       'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
+                       'results_gather': 'rccl all_gather' if world > 1 else 'none (1 GPU)'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': hip.kernel_name(0), 'launch_ms': launch_ms,
+                         'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
+            'valu': {'dp_cells_per_s': cells_per_s, 'fp64_ops_per_cell_est': 8,
+                     'frac_of_fp64_valu_peak_est': cells_per_s * 8 / FP64_VALU_PEAK},
+            'dp_kernel_ms_per_step': tm['dp_kernel_ms'], 'device_ms_per_step': tm['total_ms'],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = signal[: min(n, 4096) * T].cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(locus, sample, T, aut[: min(n, 4096)])
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
