@@ -160,12 +160,12 @@ int wsx_caller_synchronize(wsx_caller *c);
 
 /*
  * Timing of the most recent wsx_call_batch on this handle, measured with HIP events on the handle's
- * stream: total milliseconds in the DP kernels (both passes) and number of DP launches, total
+ * stream: total milliseconds in the DP fill kernels (both passes) and number of such launches, total
  * milliseconds of the whole enqueue..finish region.  Blocks until the work has finished.
  */
 int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms);
 
-/* Name of the DP kernel variant used for automaton `a` (for profiles), e.g. "dtw_pass<4,1,2>". */
+/* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<1, 2, false>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);
 
 #ifdef __cplusplus

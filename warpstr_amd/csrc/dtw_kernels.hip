@@ -1,4 +1,4 @@
-// dtw_kernels.hip -- DTW over a k-mer state automaton: DP fill + traceback, one read per wavefront.
+// dtw_kernels.hip -- DTW over a k-mer state automaton: DP fill, traceback, trace expansion.
 //
 // What it computes is WarpSTR.warp (upstream src/caller/caller.py:189-193):
 //   _calc_dtw_astates (198-245)  D[i,j] = min( D[i-1,j] + |s_i - v_j|,                                   "stay"
@@ -11,24 +11,29 @@
 // which is equivalent to the reference's "closest re-computed candidate" rule (stay wins ties,
 // first predecessor wins ties) because the re-computation is exact.
 //
-// Mapping (register-resident kernel `dtw_pass_fast<M,K,F,MASKED>`):
-//   one 64-lane wavefront per read; state j lives in lane j%64, slot j/64 (K slots per lane);
-//   a row (= one signal sample) is processed per step: all states of a row are independent.
-//   Per state the "dwell" partial sums are kept as a shift register g[1..M-1] that runs one row
-//   AHEAD of the DP:   after row i   g[s] = D[i-s+1,j] + |s_{i-s+2}-v_j| + .. + |s_{i+1}-v_j|
-//   so g[1] is the next row's stay candidate, and the value a successor needs at row i+2 is already
-//   final at the end of row i:  E_j(i+2) = g[M-1] (unmasked row)  or  g[M-2] (masked row, M >= 3).
-//   E values are exchanged through LDS (one 8-byte slot per state, double buffered by row parity);
-//   a consumer's LDS reads for row i+1 are issued during row i, a full row before they are needed.
-//   Absent predecessors point at a slot that holds +inf.  Back-pointers are packed PB bits per row
-//   per state into 32-bit words (R rows per word) and written coalesced to a per-read HBM scratch
-//   (256 B per wave-store); the traceback scans them word-wise (count-leading-zeros to jump over
-//   runs of "stay") and emits run-length state lists plus, optionally, the per-sample trace.
+// Kernels
+//   dtw_fill_fast<K,F,MASKED>   register-resident fill for min_values_per_state = 4: one 64-lane wavefront per
+//       read; state j lives in lane j%64, slot j/64 (K slots per lane); one row (= one signal sample) per
+//       step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
+//       g1,g2,g3 that runs one row AHEAD of the DP:
+//             after row i   g_s = D[i-s+1,j] + |s_{i-s+2}-v_j| + .. + |s_{i+1}-v_j|
+//       so g1 is the next row's stay candidate, and the value a successor needs at row i+2 is final at the end
+//       of row i:  E_j(i+2) = g3 (unmasked row) or g2 (masked row).  E values are exchanged through LDS (one
+//       8-byte slot per state, double buffered by row parity); a consumer's LDS reads for row i+1 are issued
+//       during row i, a full row before they are needed.  Absent predecessors point at a slot holding +inf.
+//       Back-pointers are packed PB bits per row per state into 32-bit words (R rows per word) and written
+//       coalesced (256 B per wave-store) to a per-read HBM scratch.
+//   dtw_fill_generic            any m >= 2, fan-in <= 15: last m+1 rows of D in an LDS ring, direct restatement.
+//   traceback_kernel<PB>        one THREAD per read (the walk is a dependent pointer chase of ~#transitions
+//       steps; reads are the parallel axis): scans a state's pointer words downwards with count-leading-zeros
+//       to jump over runs of "stay", emits the run-length state list in reverse time order.
+//   expand_trace_kernel         optional: per-sample state ids from the run list (coalesced, wave per read).
 //
-// Roofline: the recurrence is a min-plus scan; per row and state ~ (3 + 4F) fp64 VALU ops.  HBM
-// traffic per read and pass: 8T (signal) + T*S*PB/8 (pointer scratch, written once, read sparsely)
-// + 2T (trace) -- far below what HBM can deliver; the kernel is bound by fp64 VALU issue
-// (wave64 fp64 op = 4 cycles on a SIMD).
+// Roofline: min-plus recurrence, no MFMA.  Per row and state (F = 2): 6 fp64 adds, 2 fp64 compares, 6 selects.
+// HBM traffic per read and pass: 8T (signal) + T*K*64*PB/8 (pointer scratch, written once, read sparsely by the
+// traceback) + 6*runs; the fill is bound by fp64 VALU issue (a wave64 fp64 op occupies a SIMD for 4 cycles).
+#include <type_traits>
+
 #include "wsx_device.h"
 
 namespace {
@@ -45,83 +50,133 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// python-style ceil for positive ints
 __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// ------------------------------------------------------------------------------------------------
-// Traceback shared by both DP kernels.  Executed redundantly by every lane of the wave (all values
-// are wave-uniform); lanes only diverge when storing the per-sample trace.
-//   bp words: word (wi, j) at bp[(wi*K + j/64)*64 + j%64], PB bits per row, R = 32/PB rows per word.
-// Runs are appended in reverse time order: run_state[q], run_start[q]; adjacent equal states merge
-// (self-loop states), matching the run-length encoding of the trace (caller.py:58-60).
-// ------------------------------------------------------------------------------------------------
-template <int PB>
-__device__ void traceback(const DevAutomaton &A, const uint32_t *bp, int K, int T, int m,
-                          const uint32_t *maskw /* packed mask of this read or NULL */, uint16_t *run_state,
-                          int32_t *run_start, int32_t *n_runs_out, uint16_t *trace, int lane)
+struct ReadGeom {
+    int r, lr, T;
+    long long off;
+};
+
+__device__ __forceinline__ ReadGeom geom(const PassArgs &a, int slot)
 {
-    constexpr int R = 32 / PB;
-    constexpr uint32_t PM = (1u << PB) - 1u;
-    int j = A.endstate;
-    int i = T - 1;
-    int run_end = T - 1;
-    int nr = 0;
-    int last_state = -1;
-    while (true) {
-        const int k = j >> 6, ln = j & 63;
-        int wi = i / R;
-        uint32_t w = bp[((size_t)wi * K + k) * 64 + ln];
-        const int sh = (i % R + 1) * PB;
-        uint32_t wm = (sh >= 32) ? w : (w & ((1u << sh) - 1u));
-        while (wm == 0 && wi > 0) {
-            wi--;
-            wm = bp[((size_t)wi * K + k) * 64 + ln];
-        }
-        wm = (uint32_t)rfl((int)wm);
-        wi = rfl(wi);
-        int start, ptr = 0;
-        if (wm == 0) {
-            start = 0;
-        } else {
-            const int top = 31 - __builtin_clz(wm);
-            const int rr = top / PB;
-            start = wi * R + rr;
-            ptr = (int)((wm >> (rr * PB)) & PM);
-        }
-        // emit run [start, run_end] of state j
-        if (trace) {
-            for (int q = start + lane; q <= run_end; q += 64) trace[q] = (uint16_t)j;
-        }
-        if (j == last_state) {
-            if (lane == 0) run_start[nr - 1] = start;
-        } else {
-            if (lane == 0) {
-                run_state[nr] = (uint16_t)j;
-                run_start[nr] = start;
-            }
-            nr++;
-            last_state = j;
-        }
-        if (wm == 0) break;
-        const int p = A.pred_idx[A.pred_ptr[j] + ptr - 1];
-        int back = m;
-        if (maskw) back = ((maskw[start >> 5] >> (start & 31)) & 1u) ? m - 1 : m;
-        run_end = start - 1;
-        i = start - back;
-        j = rfl(p);
-        if (i < 0) break; // cannot happen: pointers are only set on rows >= m
-    }
-    if (lane == 0) *n_runs_out = nr;
+    ReadGeom g;
+    g.r = a.order[slot];
+    g.lr = g.r - a.first_read;
+    g.off = a.offsets[g.r] - a.base_off;
+    g.T = (int)(a.offsets[g.r + 1] - a.offsets[g.r]);
+    return g;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-resident DP (see file header).
+// Register-resident fill (see file header).  M = 4.
 // ------------------------------------------------------------------------------------------------
-template <int M, int K, int F, bool MASKED>
-__global__ __launch_bounds__(256) void dtw_pass_fast(PassArgs a)
+template <int K, int F>
+struct FillState {
+    double v[K], g1[K], g2[K], g3[K], acur[K], d[K]; // acur = s_i - v_j (signed; |.| is a free source modifier)
+    double e0[K][F], e1[K][F];                       // predecessor exports: row i uses e[i&1], loads e[(i+1)&1]
+    int paddr[K][F];                                  // LDS double index of predecessor f's export slot
+    uint32_t bpw[K];                                  // pointer bits of the current word, newest row in the low bits
+    uint32_t cutclr[K];                               // ~((1<<PB)-1) for corner-cut states, ~0 otherwise
+    bool cutf[K];
+};
+
+// x + |a| as ONE VALU op: the abs is a source modifier.  (Written as asm because the compiler otherwise
+// materialises |a| with two extra 32-bit ops when a is loop-carried.)
+__device__ __forceinline__ double add_abs(double x, double a)
 {
-    static_assert(M == 4, "register-resident kernel is specialised for min_values_per_state = 4");
-    constexpr int PB = (F <= 3) ? 2 : 4;
+    double r;
+    asm("v_add_f64 %0, %1, |%2|" : "=v"(r) : "v"(x), "v"(a));
+    return r;
+}
+
+// min(a, b) as one v_min_f64 (the builtin would first canonicalise both operands: two extra VALU ops).
+// Operands are sums of finite values or +inf: never NaN.
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// bits = (bits << 1) | (cand < best): compare into VCC, then add-with-carry bits+bits+VCC.
+__device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best)
+{
+    asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(cand), "v"(best) : "vcc");
+}
+
+// One DP row for all K slots.  PAR = row parity (selects LDS buffers and the e0/e1 roles at compile time),
+// FORCED: rows 1..3 (D stays inf, only the pipeline advances), CUT: corner-cut rows.
+//   top of row i : issue the LDS reads of E(i+1) (written at the end of row i-1) -- consumed in row i+1
+//   body         : D[i,:] from the exports E(i) read one row earlier
+//   end of row i : write E(i+2)
+// Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
+// reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
+template <int K, int F, bool MASKED, int PAR, bool FORCED, bool CUT>
+__device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane, double snext, bool mask_i2)
+{
+    constexpr int PB = (F <= 2) ? 2 : 4;
+    constexpr int EXW = K * 64 + 1;
+    constexpr int wbuf = PAR * EXW;       // E(i+2) goes to the buffer of parity i
+    constexpr int rbuf = (1 - PAR) * EXW; // E(i+1) lives in the buffer of parity i+1
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const double e = ex[rbuf + st.paddr[k][f]];
+            if (PAR) st.e0[k][f] = e;
+            else st.e1[k][f] = e;
+        }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double best = st.g1[k];
+        if (FORCED) {
+            best = kInf;
+            st.bpw[k] <<= PB;
+        } else {
+            if (PB > F) st.bpw[k] <<= (PB - F);
+            // candidates in the reference's order; bit f lands at position f of this row's field, so push the
+            // highest predecessor first
+            double cand[F], run[F + 1];
+            run[0] = best;
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                cand[f] = add_abs(PAR ? st.e1[k][f] : st.e0[k][f], st.acur[k]);
+                run[f + 1] = min_f64(run[f], cand[f]);
+            }
+#pragma unroll
+            for (int f = F - 1; f >= 0; f--) push_lt(st.bpw[k], cand[f], run[f]);
+            best = run[F];
+            if (CUT) {
+                best = st.cutf[k] ? kInf : best;
+                st.bpw[k] &= st.cutclr[k];
+            }
+        }
+        const double an = snext - st.v[k];
+        const double n3 = add_abs(st.g2[k], an), n2 = add_abs(st.g1[k], an);
+        st.g3[k] = n3;
+        st.g2[k] = n2;
+        st.g1[k] = add_abs(best, an);
+        st.d[k] = best;
+        st.acur[k] = an;
+        if (MASKED) {
+            if (mask_i2) { // wave-uniform branch: masked rows are rare
+                asm volatile("" ::: "memory");
+                ex[wbuf + k * 64 + lane] = n2;
+            } else {
+                ex[wbuf + k * 64 + lane] = n3;
+            }
+        } else {
+            ex[wbuf + k * 64 + lane] = n3;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int K, int F, bool MASKED>
+__global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
+{
+    constexpr int M = 4;
+    constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int R = 32 / PB;
     constexpr int EXW = K * 64 + 1; // export slots per buffer (+1: the +inf slot)
     extern __shared__ double lds[];
@@ -130,17 +185,15 @@ __global__ __launch_bounds__(256) void dtw_pass_fast(PassArgs a)
     const int wib = threadIdx.x >> 6;
     const int slot = rfl(blockIdx.x * 4 + wib);
     if (slot >= a.n_launch) return;
-    const int r = rfl(a.order[slot]);
-    const int lr = r - a.first_read;
-    const long long off = a.offsets[r] - a.base_off;
-    const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
-    const DevAutomaton A = a.aut[a.aut_id[r]];
+    ReadGeom gm = geom(a, slot);
+    const int lr = rfl(gm.lr), T = rfl(gm.T);
+    const long long off = gm.off;
+    const DevAutomaton A = a.aut[a.aut_id[gm.r]];
     const int S = A.n_states;
     if (a.check_status && a.status[lr] != 0) return;
     if (T <= M || S <= M) {
         if (lane == 0) {
             a.status[lr] = 1; // WSX_READ_SHAPE
-            a.n_runs[lr] = 0;
             if (a.end_cost) a.end_cost[lr] = kInf;
         }
         return;
@@ -151,24 +204,23 @@ __global__ __launch_bounds__(256) void dtw_pass_fast(PassArgs a)
     const uint32_t *maskw = MASKED ? (a.maskbits + (off / 32 + lr)) : nullptr;
 
     // ---- per-state constants -----------------------------------------------------------------
-    double v[K];
-    int paddr[K][F];
-    bool cutf[K];
+    FillState<K, F> st;
     const long long boundary = (long long)A.flank_length - 10;
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
-    long long cut_from_ll = 6 * boundary; // rows i >= first_threshold and i > second_threshold
+    long long cut_from_ll = 6 * boundary; // rows with i >= first_threshold and i > second_threshold
     if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
-    const int cut_from = cut_from_ll < 0 ? 0 : (cut_from_ll > T ? T : (int)cut_from_ll);
+    const int cut_from = cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int j = k * 64 + lane;
         const bool valid = j < S;
-        v[k] = valid ? A.value[j] : 0.0;
-        cutf[k] = valid && ((long long)A.seq_idx[j] < after_repeat);
+        st.v[k] = valid ? A.value[j] : 0.0;
+        st.cutf[k] = valid && ((long long)A.seq_idx[j] < after_repeat);
+        st.cutclr[k] = st.cutf[k] ? ~((1u << PB) - 1u) : ~0u;
         const int pp = valid ? A.pred_ptr[j] : 0;
         const int nf = valid ? (A.pred_ptr[j + 1] - pp) : 0;
 #pragma unroll
-        for (int f = 0; f < F; f++) paddr[k][f] = (f < nf) ? A.pred_idx[pp + f] : (EXW - 1);
+        for (int f = 0; f < F; f++) st.paddr[k][f] = (f < nf) ? A.pred_idx[pp + f] : (EXW - 1);
     }
     if (lane == 0) {
         ex[EXW - 1] = kInf;
@@ -178,10 +230,6 @@ __global__ __launch_bounds__(256) void dtw_pass_fast(PassArgs a)
     // ---- row 0 (caller.py:201-208) -----------------------------------------------------------
     const double v0 = A.value[0];
     const double start_val = fabs(sig[0] - v0);
-    double g1[K], g2[K], g3[K]; // the ahead pipeline (named registers: no dynamic indexing)
-    double d[K];
-    double acur[K];
-    uint32_t bpw[K];
     const double s1 = sig[1];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -189,123 +237,106 @@ __global__ __launch_bounds__(256) void dtw_pass_fast(PassArgs a)
         double d0 = kInf;
         if (j == 0) d0 = start_val;
         else if (j <= M && j < S) d0 = start_val + fabs(sig[j] - v0);
-        d[k] = d0;
-        acur[k] = fabs(s1 - v[k]);
-        g1[k] = d0 + acur[k];
-        g2[k] = kInf;
-        g3[k] = kInf;
-        bpw[k] = 0;
-        ex[0 * EXW + j] = kInf;        // E(2): never used (rows < M are forced to inf) but defined
-        ex[1 * EXW + j] = kInf;        // E(1)
+        st.d[k] = d0;
+        st.acur[k] = s1 - st.v[k];
+        st.g1[k] = d0 + fabs(st.acur[k]);
+        st.g2[k] = kInf;
+        st.g3[k] = kInf;
+        st.bpw[k] = 0;
+        ex[0 * EXW + j] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
+        ex[1 * EXW + j] = kInf;
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            st.e0[k][f] = kInf;
+            st.e1[k][f] = kInf;
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    double ecur[K][F];
-#pragma unroll
-    for (int k = 0; k < K; k++)
-#pragma unroll
-        for (int f = 0; f < F; f++) ecur[k][f] = ex[1 * EXW + paddr[k][f]];
 
-    // signal samples are fetched 64 at a time (one coalesced 512-B load) and broadcast by readlane
-    int blk = 0; // cur holds samples [blk*64, blk*64+64)
+    // signal samples are fetched 64 at a time (one coalesced 512-B load) and broadcast by readlane;
+    // block b holds s[64b .. 64b+63]; row i consumes s_{i+1}.
     auto clampi = [&](int x) { return x < T ? x : T - 1; };
-    double cur = sig[clampi(lane)];
-    double nxt = sig[clampi(64 + lane)];
-    uint32_t mwords = 0; // packed mask words [mblk*64 .. +64) of this read, one per lane
-    int mblk = 0;
-    if (MASKED) mwords = maskw[lane < cdiv(T, 32) ? lane : 0];
+    double nxt = sig[clampi(lane)];
+    uint32_t mwords = 0; // packed mask words, one per lane (covers 2048 rows)
+    int mblk = -1;
+    const int last = T - 1;
 
-    for (int i = 1; i < T; i++) {
-        // s_{i+1}
-        const int idx = clampi(i + 1);
-        if ((idx >> 6) != blk) {
-            blk = idx >> 6;
-            cur = nxt;
-            nxt = sig[clampi((blk + 1) * 64 + lane)];
-        }
-        const double snext = readlane_f64(cur, idx & 63);
-        bool mask_i2 = false;
-        if (MASKED) {
-            const int i2 = i + 2;
-            if (i2 < T) {
-                const int wq = i2 >> 5;
-                if ((wq >> 6) != mblk) {
-                    mblk = wq >> 6;
-                    const int widx = mblk * 64 + lane;
-                    mwords = maskw[widx < cdiv(T, 32) ? widx : 0];
-                }
-                const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)mwords, wq & 63);
-                mask_i2 = (mw >> (i2 & 31)) & 1u;
-            }
-        }
-        const bool forced = i < M;
-        const bool cut_row = i >= cut_from;
-        const int wbuf = (i & 1) * EXW;        // E(i+2) goes here
-        const int rbuf = ((i + 1) & 1) * EXW;  // E(i+1) was written at the end of row i-1
-        const int shift = (i % R) * PB;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            double best = g1[k];
-            uint32_t ptr = 0;
-#pragma unroll
-            for (int f = 0; f < F; f++) {
-                const double cand = ecur[k][f] + acur[k];
-                if (cand < best) {
-                    best = cand;
-                    ptr = f + 1;
+    for (int b = 0; b * 64 - 1 <= last; b++) {
+        const double cur = nxt;
+        nxt = sig[clampi((b + 1) * 64 + lane)];
+        int lo = b * 64 - 1, hi = b * 64 + 63; // rows [lo, hi)
+        if (lo < 1) lo = 1;
+        if (hi > T) hi = T;
+
+        // one row, everything wave-uniform except the per-lane state
+        auto row = [&](auto par, auto forced, auto cut, int i) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr bool FORCED = decltype(forced)::value;
+            constexpr bool CUT = decltype(cut)::value;
+            const int idx = i + 1 < T ? i + 1 : T - 1;
+            const double snext = readlane_f64(cur, idx & 63);
+            bool mask_i2 = false;
+            if (MASKED) {
+                const int i2 = i + 2;
+                if (i2 < T) {
+                    const int wq = i2 >> 5;
+                    if ((wq >> 6) != mblk) {
+                        mblk = wq >> 6;
+                        const int widx = mblk * 64 + lane;
+                        mwords = maskw[widx < cdiv(T, 32) ? widx : 0];
+                    }
+                    const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)mwords, wq & 63);
+                    mask_i2 = (mw >> (i2 & 31)) & 1u;
                 }
             }
-            if (forced || (cut_row && cutf[k])) {
-                best = kInf;
-                ptr = 0;
+            dp_row<K, F, MASKED, PAR, FORCED, CUT>(st, ex, lane, snext, mask_i2);
+            if ((i % R) == R - 1 || i == last) {
+                // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
+                const int wi = i / R;
+                const int fill = (R - 1 - (i % R)) * PB;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    bp[((size_t)wi * K + k) * 64 + lane] = st.bpw[k] << fill;
+                    st.bpw[k] = 0;
+                }
             }
-            const double an = fabs(snext - v[k]);
-            const double n3 = g2[k] + an, n2 = g1[k] + an;
-            g3[k] = n3;
-            g2[k] = n2;
-            g1[k] = best + an;
-            d[k] = best;
-            acur[k] = an;
-            double e_out = n3;
-            if (MASKED) e_out = mask_i2 ? n2 : n3;
-            ex[wbuf + k * 64 + lane] = e_out;
-            bpw[k] |= ptr << shift;
-        }
-        if ((i % R) == R - 1 || i == T - 1) {
-            const int wi = i / R;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                bp[((size_t)wi * K + k) * 64 + lane] = bpw[k];
-                bpw[k] = 0;
+        };
+        // rows [plo, phi) of one phase, two rows per iteration so that the e0/e1 roles need no copies
+        auto phase = [&](auto forced, auto cut, int plo, int phi) {
+            int i = plo;
+            if (i < phi && (i & 1)) {
+                row(std::integral_constant<int, 1>{}, forced, cut, i);
+                i++;
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < K; k++)
-#pragma unroll
-            for (int f = 0; f < F; f++) ecur[k][f] = ex[rbuf + paddr[k][f]];
+            for (; i + 1 < phi; i += 2) {
+                row(std::integral_constant<int, 0>{}, forced, cut, i);
+                row(std::integral_constant<int, 1>{}, forced, cut, i + 1);
+            }
+            if (i < phi) row(std::integral_constant<int, 0>{}, forced, cut, i);
+        };
+        const int e0 = hi < M ? hi : M;                                 // forced rows end
+        const int e1 = hi < cut_from ? hi : cut_from;                   // plain rows end
+        phase(std::true_type{}, std::false_type{}, lo, e0);
+        phase(std::false_type{}, std::false_type{}, lo > M ? lo : M, e1);
+        phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, hi);
     }
 
     // ---- outputs of the fill -----------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int j = k * 64 + lane;
-        if (j == A.endstate && a.end_cost) a.end_cost[lr] = d[k];
-        if (a.last_row && j < S) a.last_row[(size_t)lr * a.last_row_stride + j] = d[k];
+        if (j == A.endstate && a.end_cost) a.end_cost[lr] = st.d[k];
+        if (a.last_row && j < S) a.last_row[(size_t)lr * a.last_row_stride + j] = st.d[k];
     }
     if (lane == 0 && !a.check_status) a.status[lr] = 0;
-    // make the pointer words visible to every lane of this wave before the traceback reads them
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    traceback<PB>(A, bp, K, T, M, maskw, a.run_state + off, a.run_start + off, a.n_runs + lr,
-                  a.trace ? a.trace + off : nullptr, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
-// General DP: any m >= 2, any fan-in <= 15, any S that fits the LDS ring.  A direct data-parallel
+// General fill: any m >= 2, any fan-in <= 15, any S that fits the LDS ring.  A direct data-parallel
 // statement of caller.py:217-244: the last m+1 rows of D live in an LDS ring, states are strided over
 // the lanes, dwell sums are recomputed per candidate.  Slow path for unusual configurations.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void dtw_pass_generic(PassArgs a, int K)
+__global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 {
     constexpr int PB = 4;
     constexpr int R = 32 / PB;
@@ -313,18 +344,16 @@ __global__ __launch_bounds__(64) void dtw_pass_generic(PassArgs a, int K)
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x;
     if (slot >= a.n_launch) return;
-    const int r = rfl(a.order[slot]);
-    const int lr = r - a.first_read;
-    const long long off = a.offsets[r] - a.base_off;
-    const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
-    const DevAutomaton A = a.aut[a.aut_id[r]];
+    ReadGeom gm = geom(a, slot);
+    const int lr = rfl(gm.lr), T = rfl(gm.T);
+    const long long off = gm.off;
+    const DevAutomaton A = a.aut[a.aut_id[gm.r]];
     const int S = A.n_states;
     const int m = a.m;
     if (a.check_status && a.status[lr] != 0) return;
     if (T <= m || S <= m) {
         if (lane == 0) {
             a.status[lr] = 1;
-            a.n_runs[lr] = 0;
             if (a.end_cost) a.end_cost[lr] = kInf;
         }
         return;
@@ -341,11 +370,9 @@ __global__ __launch_bounds__(64) void dtw_pass_generic(PassArgs a, int K)
     const double start_val = fabs(sig[0] - v0);
     if (lane == 0) lds[0] = start_val;
     if (lane >= 1 && lane <= m && lane < S) lds[lane] = start_val + fabs(sig[lane] - v0);
-    // rows 1..m-1 stay inf
     const long long boundary = (long long)A.flank_length - 10;
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
     const long long first_threshold = 6 * boundary, second_threshold = (long long)T - 6 * boundary;
-    for (int k = 0; k < K; k++) bp[(size_t)k * 64 + lane] = 0; // word 0 default
     __builtin_amdgcn_wave_barrier();
     uint32_t bpw[WSX_MAX_K * 2];
     for (int k = 0; k < K; k++) bpw[k] = 0;
@@ -382,12 +409,11 @@ __global__ __launch_bounds__(64) void dtw_pass_generic(PassArgs a, int K)
                             ptr = (uint32_t)(e - pp + 1);
                         }
                     }
-                    if (!(best < kInf)) ptr = 0;
                 }
             }
             bpw[k] |= ptr << ((i % R) * PB);
-            // all reads of this row's inputs (rows i-1 and i-back) are to other ring rows
-            if (j < SP) row[j] = best;
+            // this row's inputs (rows i-1 and i-back) live in other ring rows
+            row[j] = best;
         }
         if ((i % R) == R - 1 || i == T - 1) {
             const int wi = i / R;
@@ -405,29 +431,125 @@ __global__ __launch_bounds__(64) void dtw_pass_generic(PassArgs a, int K)
     }
     if (a.last_row)
         for (int j = lane; j < S; j += 64) a.last_row[(size_t)lr * a.last_row_stride + j] = lrow[j];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    traceback<PB>(A, bp, K, T, m, maskw, a.run_state + off, a.run_start + off, a.n_runs + lr,
-                  a.trace ? a.trace + off : nullptr, lane);
 }
 
-template <int M, int K, int F>
-hipError_t launch_fast(const PassArgs &a, bool masked, hipStream_t s)
+// ------------------------------------------------------------------------------------------------
+// Traceback: one thread per read.
+//   bp words: word (wi, j) at bp[(wi*K + j/64)*64 + j%64], PB bits per row, R = 32/PB rows per word.
+// Runs are appended in reverse time order: run_state[q], run_start[q]; adjacent equal states merge
+// (self-loop states), matching the run-length encoding of the trace (caller.py:58-60).
+// ------------------------------------------------------------------------------------------------
+// ENC = 1: bit-per-predecessor fields, row r of a word at bits PB*(R-1-r) (dtw_fill_fast);
+// ENC = 0: numeric pointer fields, row r at bits PB*r (dtw_fill_generic).
+template <int PB, int ENC>
+__global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
+{
+    constexpr int R = 32 / PB;
+    constexpr uint32_t PM = (1u << PB) - 1u;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_launch) return;
+    const ReadGeom gm = geom(a, slot);
+    const int lr = gm.lr, T = gm.T;
+    const long long off = gm.off;
+    if (a.status[lr] != 0) {
+        a.n_runs[lr] = 0;
+        return;
+    }
+    const DevAutomaton &A = a.aut[a.aut_id[gm.r]];
+    const int32_t *pred_ptr = A.pred_ptr, *pred_idx = A.pred_idx;
+    const int m = a.m;
+    const uint32_t *bp = a.bp + (size_t)(off / R + lr) * (K * 64);
+    const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
+    uint16_t *run_state = a.run_state + off;
+    int32_t *run_start = a.run_start + off;
+    int j = A.endstate;
+    int i = T - 1;
+    int nr = 0;
+    int last_state = -1;
+    while (true) {
+        const uint32_t *col = bp + (size_t)(j >> 6) * 64 + (j & 63);
+        int wi = i / R;
+        uint32_t wm = col[(size_t)wi * K * 64];
+        // keep rows <= i of this word
+        if (ENC) {
+            const int sh = (R - 1 - i % R) * PB; // bits below belong to later rows
+            wm = (wm >> sh) << sh;
+        } else {
+            const int sh = (i % R + 1) * PB;
+            if (sh < 32) wm &= (1u << sh) - 1u;
+        }
+        while (wm == 0 && wi > 0) {
+            wi--;
+            wm = col[(size_t)wi * K * 64];
+        }
+        int start = 0, ptr = 0;
+        if (wm != 0) {
+            if (ENC) {
+                const int fld = __builtin_ctz(wm) / PB;            // lowest non-zero field = latest row
+                const uint32_t bits = (wm >> (fld * PB)) & PM;
+                start = wi * R + (R - 1 - fld);
+                ptr = 32 - __builtin_clz(bits);                     // highest set bit + 1
+            } else {
+                const int rr = (31 - __builtin_clz(wm)) / PB;
+                start = wi * R + rr;
+                ptr = (int)((wm >> (rr * PB)) & PM);
+            }
+        }
+        if (j == last_state) {
+            run_start[nr - 1] = start;
+        } else {
+            run_state[nr] = (uint16_t)j;
+            run_start[nr] = start;
+            nr++;
+            last_state = j;
+        }
+        if (wm == 0) break;
+        int back = m;
+        if (maskw) back = ((maskw[start >> 5] >> (start & 31)) & 1u) ? m - 1 : m;
+        j = pred_idx[pred_ptr[j] + ptr - 1];
+        i = start - back;
+        if (i < 0) break; // cannot happen: pointers are only set on rows >= m
+    }
+    a.n_runs[lr] = nr;
+}
+
+// per-sample state ids from the (reverse-ordered) run list; one wavefront per read
+__global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= a.n_launch) return;
+    const ReadGeom gm = geom(a, slot);
+    if (a.status[gm.lr] != 0) return;
+    const int n = a.n_runs[gm.lr];
+    const uint16_t *rs = a.run_state + gm.off;
+    const int32_t *rst = a.run_start + gm.off;
+    uint16_t *trace = a.trace + gm.off;
+    for (int q0 = 0; q0 < n; q0++) {
+        const int start = rst[q0];
+        const int end = (q0 == 0) ? gm.T : rst[q0 - 1]; // reverse order: the previous entry is the next run in time
+        const uint16_t s = rs[q0];
+        for (int q = start + lane; q < end; q += 64) trace[q] = s;
+    }
+}
+
+template <int K, int F>
+hipError_t launch_fill(const PassArgs &a, bool masked, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
     const size_t shmem = 4 * 2 * (K * 64 + 1) * sizeof(double);
-    if (masked) hipLaunchKernelGGL((dtw_pass_fast<M, K, F, true>), dim3(blocks), dim3(256), shmem, s, a);
-    else hipLaunchKernelGGL((dtw_pass_fast<M, K, F, false>), dim3(blocks), dim3(256), shmem, s, a);
+    if (masked) hipLaunchKernelGGL((dtw_fill_fast<K, F, true>), dim3(blocks), dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL((dtw_fill_fast<K, F, false>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
 
-template <int M, int K>
-hipError_t launch_fast_f(const PassArgs &a, int F, bool masked, hipStream_t s)
+template <int K>
+hipError_t launch_fill_f(const PassArgs &a, int F, bool masked, hipStream_t s)
 {
     switch (F) {
-    case 2: return launch_fast<M, K, 2>(a, masked, s);
-    case 3: return launch_fast<M, K, 3>(a, masked, s);
-    case 4: return launch_fast<M, K, 4>(a, masked, s);
+    case 2: return launch_fill<K, 2>(a, masked, s);
+    case 3: return launch_fill<K, 3>(a, masked, s);
+    case 4: return launch_fill<K, 4>(a, masked, s);
     }
     return hipErrorInvalidValue;
 }
@@ -441,27 +563,41 @@ static int fast_f(int F) { return F <= 2 ? 2 : F; }
 const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic)
 {
     static thread_local char buf[64];
-    if (generic) snprintf(buf, sizeof(buf), "dtw_pass_generic");
-    else snprintf(buf, sizeof(buf), "dtw_pass_fast<%d,%d,%d,%d>", m, K, fast_f(F), masked ? 1 : 0);
+    (void)m;
+    if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %s>", K, fast_f(F), masked ? "true" : "false");
     return buf;
 }
 
-hipError_t wsx_launch_pass(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s)
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
         const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double);
-        hipLaunchKernelGGL(dtw_pass_generic, dim3(a.n_launch), dim3(64), shmem, s, a, K);
+        hipLaunchKernelGGL(dtw_fill_generic, dim3(a.n_launch), dim3(64), shmem, s, a, K);
         return hipGetLastError();
     }
     if (m != 4) return hipErrorInvalidValue;
     const int f = fast_f(F);
     switch (K) {
-    case 1: return launch_fast_f<4, 1>(a, f, masked, s);
-    case 2: return launch_fast_f<4, 2>(a, f, masked, s);
-    case 3: return launch_fast_f<4, 3>(a, f, masked, s);
-    case 4: return launch_fast_f<4, 4>(a, f, masked, s);
-    case 5: return launch_fast_f<4, 5>(a, f, masked, s);
+    case 1: return launch_fill_f<1>(a, f, masked, s);
+    case 2: return launch_fill_f<2>(a, f, masked, s);
+    case 3: return launch_fill_f<3>(a, f, masked, s);
+    case 4: return launch_fill_f<4>(a, f, masked, s);
+    case 5: return launch_fill_f<5>(a, f, masked, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s)
+{
+    if (a.n_launch <= 0) return hipSuccess;
+    const int blocks = (a.n_launch + 63) / 64;
+    if (generic) hipLaunchKernelGGL((traceback_kernel<4, 0>), dim3(blocks), dim3(64), 0, s, a, K);
+    else if (fast_f(F) <= 2) hipLaunchKernelGGL((traceback_kernel<2, 1>), dim3(blocks), dim3(64), 0, s, a, K);
+    else hipLaunchKernelGGL((traceback_kernel<4, 1>), dim3(blocks), dim3(64), 0, s, a, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.trace) return e;
+    hipLaunchKernelGGL(expand_trace_kernel, dim3((a.n_launch + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
 }

@@ -4,8 +4,8 @@
 // length (load balance) and sizes the workspace.
 //
 // Launch sequence per chunk of reads (all on the handle's stream):
-//   dtw_pass (unmasked)  ->  mid(pass 1: run statistics, sort, borders, segmentation mask, cost1)
-//   -> fit (Givens LSQ cubic) -> eval (rescaled signal) -> dtw_pass (masked, rescaled signal)
+//   dtw_fill (unmasked) -> traceback -> mid(pass 1: run statistics, sort, borders, segmentation mask, cost1)
+//   -> fit (Givens LSQ cubic) -> eval (rescaled signal) -> dtw_fill (masked, rescaled signal) -> traceback
 //   -> mid(pass 2: run statistics, borders, cost2, allele length)
 #include <algorithm>
 #include <cstdio>
@@ -35,7 +35,7 @@ thread_local std::string g_err;
 struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
-    int PB() const { return generic ? 4 : (F <= 3 ? 2 : 4); }
+    int PB() const { return generic ? 4 : (F <= 2 ? 2 : 4); }
     int R() const { return 32 / PB(); }
     bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic; }
 };
@@ -582,8 +582,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 int rc2 = get_event_pair(c, &e0, &e1);
                 if (rc2) return rc2;
                 HIPCHK(hipEventRecord(e0, st));
-                HIPCHK(wsx_launch_pass(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
+                HIPCHK(wsx_launch_fill(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
                 HIPCHK(hipEventRecord(e1, st));
+                HIPCHK(wsx_launch_traceback(pa, gvar[g].K, gvar[g].F, gvar[g].generic, st));
             }
             return WSX_SUCCESS;
         };

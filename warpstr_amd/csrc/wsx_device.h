@@ -118,7 +118,8 @@ struct EvalArgs {
 };
 
 // Host-side launchers (defined next to the kernels).
-hipError_t wsx_launch_pass(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s);
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s);
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
