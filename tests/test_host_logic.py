@@ -1,0 +1,114 @@
+"""Host-side logic against the fixtures recorded from the upstream code.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import DEFAULT_CASES, GOLDEN, load_case
+from warpstr_amd.automata import compile_automaton, reverse_pattern
+from warpstr_amd.caller import sequence_from_trace
+from warpstr_amd.pore_model import PoreModel, default_pore_model
+from warpstr_amd.signal_prep import brute_remove, process_raw
+from warpstr_amd.units import break_into_units, collapse_repeats
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_automaton_tables_match_reference(case):
+    z = load_case(case)
+    fl = [str(s) for s in z['flanks']]
+    pat = str(z['pattern'])
+    for tag, seq in (('t', fl[0] + pat + fl[1]), ('r', fl[2] + reverse_pattern(pat) + fl[3])):
+        a = compile_automaton(seq)
+        assert a.n_states == len(z[f'{tag}_value']) and a.endstate == int(z[f'{tag}_endstate'])
+        assert np.array_equal(a.value, z[f'{tag}_value'])       # bit-identical levels
+        assert np.array_equal(a.seq_idx, z[f'{tag}_seq_idx'])
+        assert np.array_equal(a.pred_ptr, z[f'{tag}_pred_ptr'])
+        assert np.array_equal(a.pred_idx, z[f'{tag}_pred_idx'])
+        assert np.array_equal(a.repeat_mask, z[f'{tag}_mask'])
+        assert a.kmers == [str(k) for k in z[f'{tag}_kmers']]
+
+
+@pytest.mark.parametrize('case', DEFAULT_CASES)
+def test_sequence_from_trace(case):
+    z = load_case(case)
+    fl = [str(s) for s in z['flanks']]
+    pat = str(z['pattern'])
+    tabs = [compile_automaton(fl[0] + pat + fl[1]), compile_automaton(fl[2] + reverse_pattern(pat) + fl[3])]
+    for i in range(int(z['n_reads'])):
+        rev = int(z['reverse'][i])
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert sequence_from_trace(tabs[rev], int(z['flank_length']), z[f'r{i}_trace1'], bool(rev)) == seq
+        assert sequence_from_trace(tabs[rev], int(z['flank_length']), z[f'r{i}_trace2'], bool(rev)) == rseq
+
+
+def test_units_and_collapse():
+    with open(os.path.join(GOLDEN, 'units.json')) as f:
+        ref = json.load(f)
+    for pat, exp in ref.items():
+        assert reverse_pattern(pat) == exp['reverse']
+        units, repeat_units, offsets = break_into_units(pat)
+        assert (units, repeat_units, offsets) == (exp['units'], exp['repeat_units'], exp['offsets'])
+        for seq, counts in exp['collapse']:
+            assert collapse_repeats(seq, repeat_units, offsets) == counts
+    # a top-level optional block yields an empty repeat unit; upstream spins forever, we refuse
+    _, ru, off = break_into_units('(ARC)TT{GG}A(CCG)')
+    with pytest.raises(RuntimeError):
+        collapse_repeats('AACGGA', ru, off, max_iter=1000)
+
+
+def test_signal_prep_and_pore_model():
+    z = np.load(os.path.join(GOLDEN, 'signal_prep.npz'))
+    cleaned = brute_remove(z['raw'])
+    assert cleaned.dtype == z['raw'].dtype and np.array_equal(cleaned, z['cleaned'])
+    assert np.array_equal(process_raw(z['raw']), z['norm'])
+    assert np.array_equal(process_raw(z['raw'], (100, 220)), z['norm'][100:221])
+    assert np.array_equal(default_pore_model().level_norm, z['pore_level_norm'])
+
+
+def test_pore_model_tsv_roundtrip(tmp_path):
+    pm = default_pore_model()
+    raw = np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'warpstr_amd', 'data', 'r94_6mer_level_mean.npy'))
+    import itertools
+    p = tmp_path / 'model.tsv'
+    with open(p, 'w') as f:
+        f.write('kmer\tlevel_mean\tlevel_stdv\n')
+        for k, v in zip(itertools.product('ACGT', repeat=6), raw):
+            f.write(''.join(k) + f'\t{float(v)!r}\t1.0\n')
+    pm2 = PoreModel(str(p))
+    assert np.array_equal(pm2.level_norm, pm.level_norm)
+    assert pm2.get_value('ACGTAC') == pm.get_value('ACGTAC')
+
+
+def test_config_defaults(tmp_path):
+    from warpstr_amd.config import load_config
+    p = tmp_path / 'cfg.yaml'
+    p.write_text('output: out\nthreads: 4\nrescaling:\n  threshold: 0.4\nloci:\n  - name: L1\n    sequence: (agc)\n'
+                 '    coord: chr1:1-2\n  - name: L2\n    sequence: (AAAT)\n    flank_length: 40\n')
+    c = load_config(str(p))
+    assert c.caller.min_values_per_state == 4 and c.caller.states_in_segment == 6
+    assert c.rescaler.threshold == 0.4 and c.rescaler.max_std == 0.5 and c.rescaler.method == 'mean'
+    assert [(l.name, l.sequence, l.flank_length) for l in c.loci] == [('L1', '(AGC)', 110), ('L2', '(AAAT)', 40)]
+
+
+def test_overview_outputs(tmp_path):
+    import pandas as pd
+
+    from warpstr_amd import overview as ov
+    loc = tmp_path / 'L'
+    (loc / 'expected_signals').mkdir(parents=True)
+    (loc / 'expected_signals' / 'sequences.csv').write_text(
+        'type,sequence\nleft_flank_template,AAAC\nright_flank_template,CCCG\nleft_flank_reverse,CGGG\n'
+        'right_flank_reverse,GTTT\ntemp_ref_pattern,AGCAGC\nrev_ref_pattern,GCTGCT\n')
+    pd.DataFrame({'read_name': ['a', 'b', 'c'], 'run_id': [0, 0, 0], 'reverse': [False, True, False],
+                  'saved': [1, 0, 1], 'l_start_raw': [0, 0, 0], 'r_end_raw': [9, 9, 9],
+                  'results_old': [5, 5, 5]}).to_csv(loc / 'overview.csv', index=False)
+    assert ov.load_flanks(str(loc)) == ('AAAC', 'CCCG', 'CGGG', 'GTTT')
+    path, df = ov.load_overview(str(loc))
+    df = ov.store_results(path, df, [('AGC', 'AGCAGC'), ('AG', 'AGCA')], [(0.1, 0.2), (0.3, 0.4)], str(loc))
+    out = pd.read_csv(path)
+    assert list(out['results']) == [6, -1, 4] and list(out['orig']) == [3, -1, 2]
+    assert list(out['dtw_cost2']) == [0.2, -1.0, 0.4] and 'results_old' not in out.columns
+    allf = (loc / 'predictions' / 'sequences' / 'all.fasta').read_text()
+    assert allf == '>a\nAGCAGC\n\n>c\nAGCA\n\n'
+    assert (loc / 'predictions' / 'sequences' / 'sequences_reverse.fasta').read_text() == ''
