@@ -12,7 +12,7 @@
 // first predecessor wins ties) because the re-computation is exact.
 //
 // Kernels
-//   dtw_fill_fast<K,F,MASKED>   register-resident fill for min_values_per_state = 4: one 64-lane wavefront per
+//   dtw_fill_fast<K,F>          register-resident fill for min_values_per_state = 4: one 64-lane wavefront per
 //       read; state j lives in lane j%64, slot j/64 (K slots per lane); one row (= one signal sample) per
 //       step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
 //       g1,g2,g3 that runs one row AHEAD of the DP:
@@ -111,8 +111,8 @@ __device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best
 //   end of row i : write E(i+2)
 // Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
 // reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
-template <int K, int F, bool MASKED, int PAR, bool FORCED, bool CUT>
-__device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane, double snext, bool mask_i2)
+template <int K, int F, bool MROW, int PAR, bool FORCED, bool CUT>
+__device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane, double snext)
 {
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int EXW = K * 64 + 1;
@@ -158,27 +158,19 @@ __device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane
         st.g1[k] = add_abs(best, an);
         st.d[k] = best;
         st.acur[k] = an;
-        if (MASKED) {
-            if (mask_i2) { // wave-uniform branch: masked rows are rare
-                asm volatile("" ::: "memory");
-                ex[wbuf + k * 64 + lane] = n2;
-            } else {
-                ex[wbuf + k * 64 + lane] = n3;
-            }
-        } else {
-            ex[wbuf + k * 64 + lane] = n3;
-        }
+        ex[wbuf + k * 64 + lane] = MROW ? n2 : n3; // row i+2 masked (back = 3): successors need g2, else g3
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int K, int F, bool MASKED>
+template <int K, int F>
 __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
 {
     constexpr int M = 4;
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int R = 32 / PB;
     constexpr int EXW = K * 64 + 1; // export slots per buffer (+1: the +inf slot)
+    constexpr int WLDS = 2 * EXW + 128; // doubles of LDS per wave: two export buffers + two 64-sample signal blocks
     extern __shared__ double lds[];
 
     const int lane = threadIdx.x & 63;
@@ -199,9 +191,11 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
         return;
     }
     const double *sig = a.signal + off;
-    double *ex = lds + wib * (2 * EXW);
+    double *ex = lds + wib * WLDS;
+    double *sb = ex + 2 * EXW; // signal blocks: sample q lives at sb[q & 127]
     uint32_t *bp = a.bp + (size_t)(off / R + lr) * (K * 64);
-    const uint32_t *maskw = MASKED ? (a.maskbits + (off / 32 + lr)) : nullptr;
+    const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
+    const int nmw = cdiv(T, 32);
 
     // ---- per-state constants -----------------------------------------------------------------
     FillState<K, F> st;
@@ -251,45 +245,48 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
             st.e1[k][f] = kInf;
         }
     }
-    __builtin_amdgcn_wave_barrier();
 
-    // signal samples are fetched 64 at a time (one coalesced 512-B load) and broadcast by readlane;
-    // block b holds s[64b .. 64b+63]; row i consumes s_{i+1}.
+    // Signal: 64 samples per coalesced 512-B load, parked in LDS (two blocks) and broadcast to the wave by a
+    // same-address ds_read -- no VALU involved.  Row i consumes s_{i+1}; it is read one row early.
     auto clampi = [&](int x) { return x < T ? x : T - 1; };
-    double nxt = sig[clampi(lane)];
-    uint32_t mwords = 0; // packed mask words, one per lane (covers 2048 rows)
-    int mblk = -1;
+    sb[lane] = sig[clampi(lane)];
+    double nxt = sig[clampi(64 + lane)];
+    __builtin_amdgcn_wave_barrier();
+    double s_even = 0.0, s_odd = 0.0; // s_q for the even / odd q most recently read
+    s_even = sb[2];                   // row 1 consumes s_2
     const int last = T - 1;
 
     for (int b = 0; b * 64 - 1 <= last; b++) {
-        const double cur = nxt;
-        nxt = sig[clampi((b + 1) * 64 + lane)];
-        int lo = b * 64 - 1, hi = b * 64 + 63; // rows [lo, hi)
+        sb[((b + 1) & 1) * 64 + lane] = nxt; // block b+1 (row 64b+62 reads s_{64b+64} ahead)
+        nxt = sig[clampi((b + 2) * 64 + lane)];
+        __builtin_amdgcn_wave_barrier();
+        const int base = b * 64 - 1;
+        int lo = base, hi = b * 64 + 63; // rows [lo, hi)
         if (lo < 1) lo = 1;
         if (hi > T) hi = T;
 
+        // bm: bit t <=> row base+t exports for a MASKED row (mask bit of sample base+t+2 = 64b+1+t)
+        unsigned long long bm = 0;
+        if (maskw) {
+            const int w0 = 2 * b;
+            const unsigned long long m0 = w0 < nmw ? maskw[w0] : 0u, m1 = w0 + 1 < nmw ? maskw[w0 + 1] : 0u,
+                                     m2 = w0 + 2 < nmw ? maskw[w0 + 2] : 0u;
+            bm = ((m0 | (m1 << 32)) >> 1) | ((m2 & 1ull) << 63);
+            bm = ((unsigned long long)(unsigned)rfl((int)(bm >> 32)) << 32) | (unsigned)rfl((int)bm);
+        }
+
         // one row, everything wave-uniform except the per-lane state
-        auto row = [&](auto par, auto forced, auto cut, int i) {
+        auto row = [&](auto par, auto forced, auto cut, auto msk, int i) {
             constexpr int PAR = decltype(par)::value;
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
-            const int idx = i + 1 < T ? i + 1 : T - 1;
-            const double snext = readlane_f64(cur, idx & 63);
-            bool mask_i2 = false;
-            if (MASKED) {
-                const int i2 = i + 2;
-                if (i2 < T) {
-                    const int wq = i2 >> 5;
-                    if ((wq >> 6) != mblk) {
-                        mblk = wq >> 6;
-                        const int widx = mblk * 64 + lane;
-                        mwords = maskw[widx < cdiv(T, 32) ? widx : 0];
-                    }
-                    const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)mwords, wq & 63);
-                    mask_i2 = (mw >> (i2 & 31)) & 1u;
-                }
-            }
-            dp_row<K, F, MASKED, PAR, FORCED, CUT>(st, ex, lane, snext, mask_i2);
+            constexpr bool MROW = decltype(msk)::value;
+            // prefetch s_{i+2} (parity of i) while consuming s_{i+1} (other parity)
+            const double s_new = sb[(i + 2) & 127];
+            const double snext = PAR ? s_even : s_odd;
+            if (PAR) s_odd = s_new;
+            else s_even = s_new;
+            dp_row<K, F, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
             if ((i % R) == R - 1 || i == last) {
                 // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
                 const int wi = i / R;
@@ -301,21 +298,35 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
                 }
             }
         };
-        // rows [plo, phi) of one phase, two rows per iteration so that the e0/e1 roles need no copies
-        auto phase = [&](auto forced, auto cut, int plo, int phi) {
+        // rows [plo, phi) with constant compile-time flags, two rows per iteration (no register copies)
+        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
             int i = plo;
             if (i < phi && (i & 1)) {
-                row(std::integral_constant<int, 1>{}, forced, cut, i);
+                row(std::integral_constant<int, 1>{}, forced, cut, msk, i);
                 i++;
             }
             for (; i + 1 < phi; i += 2) {
-                row(std::integral_constant<int, 0>{}, forced, cut, i);
-                row(std::integral_constant<int, 1>{}, forced, cut, i + 1);
+                row(std::integral_constant<int, 0>{}, forced, cut, msk, i);
+                row(std::integral_constant<int, 1>{}, forced, cut, msk, i + 1);
             }
-            if (i < phi) row(std::integral_constant<int, 0>{}, forced, cut, i);
+            if (i < phi) row(std::integral_constant<int, 0>{}, forced, cut, msk, i);
         };
-        const int e0 = hi < M ? hi : M;                                 // forced rows end
-        const int e1 = hi < cut_from ? hi : cut_from;                   // plain rows end
+        // a phase, split into maximal runs of equal mask bit so that the row code is branch-free
+        auto phase = [&](auto forced, auto cut, int plo, int phi) {
+            int i = plo;
+            while (i < phi) {
+                const unsigned long long rest = bm >> (i - base);
+                const bool mv = rest & 1ull;
+                const unsigned long long x = mv ? ~rest : rest;
+                const int len = x ? __builtin_ctzll(x) : 64;
+                const int e = (i + len < phi) ? i + len : phi;
+                if (mv) span(forced, cut, std::true_type{}, i, e);
+                else span(forced, cut, std::false_type{}, i, e);
+                i = e;
+            }
+        };
+        const int e0 = hi < M ? hi : M;               // forced rows end
+        const int e1 = hi < cut_from ? hi : cut_from; // plain rows end
         phase(std::true_type{}, std::false_type{}, lo, e0);
         phase(std::false_type{}, std::false_type{}, lo > M ? lo : M, e1);
         phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, hi);
@@ -534,22 +545,21 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
 }
 
 template <int K, int F>
-hipError_t launch_fill(const PassArgs &a, bool masked, hipStream_t s)
+hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
-    const size_t shmem = 4 * 2 * (K * 64 + 1) * sizeof(double);
-    if (masked) hipLaunchKernelGGL((dtw_fill_fast<K, F, true>), dim3(blocks), dim3(256), shmem, s, a);
-    else hipLaunchKernelGGL((dtw_fill_fast<K, F, false>), dim3(blocks), dim3(256), shmem, s, a);
+    const size_t shmem = 4 * (2 * (K * 64 + 1) + 128) * sizeof(double);
+    hipLaunchKernelGGL((dtw_fill_fast<K, F>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
 
 template <int K>
-hipError_t launch_fill_f(const PassArgs &a, int F, bool masked, hipStream_t s)
+hipError_t launch_fill_f(const PassArgs &a, int F, hipStream_t s)
 {
     switch (F) {
-    case 2: return launch_fill<K, 2>(a, masked, s);
-    case 3: return launch_fill<K, 3>(a, masked, s);
-    case 4: return launch_fill<K, 4>(a, masked, s);
+    case 2: return launch_fill<K, 2>(a, s);
+    case 3: return launch_fill<K, 3>(a, s);
+    case 4: return launch_fill<K, 4>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -565,12 +575,14 @@ const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic)
     static thread_local char buf[64];
     (void)m;
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %s>", K, fast_f(F), masked ? "true" : "false");
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d>", K, fast_f(F));
+    (void)masked;
     return buf;
 }
 
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s)
 {
+    (void)masked; // the mask, if any, travels in PassArgs.maskbits
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
         const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double);
@@ -580,11 +592,11 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, 
     if (m != 4) return hipErrorInvalidValue;
     const int f = fast_f(F);
     switch (K) {
-    case 1: return launch_fill_f<1>(a, f, masked, s);
-    case 2: return launch_fill_f<2>(a, f, masked, s);
-    case 3: return launch_fill_f<3>(a, f, masked, s);
-    case 4: return launch_fill_f<4>(a, f, masked, s);
-    case 5: return launch_fill_f<5>(a, f, masked, s);
+    case 1: return launch_fill_f<1>(a, f, s);
+    case 2: return launch_fill_f<2>(a, f, s);
+    case 3: return launch_fill_f<3>(a, f, s);
+    case 4: return launch_fill_f<4>(a, f, s);
+    case 5: return launch_fill_f<5>(a, f, s);
     }
     return hipErrorInvalidValue;
 }

@@ -50,13 +50,28 @@ struct LoadSqDev {
         return d * d;
     }
 };
+// the read's signal staged in LDS (dynamic shared memory, see mid_kernel<true>)
+extern __shared__ double smem[];
+struct LdsPlain {
+    int b;
+    __device__ double operator()(int i) const { return smem[b + i]; }
+};
+struct LdsSqDev {
+    int b;
+    double mean;
+    __device__ double operator()(int i) const
+    {
+        const double d = smem[b + i] - mean;
+        return d * d;
+    }
+};
 struct LoadAbsDiff {
     const double *a, *b;
     __device__ double operator()(int i) const { return fabs(a[i] - b[i]); }
 };
 
 template <class L>
-__device__ double pw_block(const L &ld, int o, int n) // n <= 128
+__device__ __attribute__((noinline)) double pw_block(const L &ld, int o, int n) // n <= 128
 {
     if (n < 8) {
         double res = 0.0;
@@ -83,9 +98,8 @@ __device__ double pw_block(const L &ld, int o, int n) // n <= 128
 
 // Explicit-stack form of the recursion  sum(a,n) = sum(a,n2) + sum(a+n2,n-n2),  n2 = n/2 - (n/2)%8.
 template <class L>
-__device__ double np_pairwise_sum(const L &ld, int n)
+__device__ __attribute__((noinline)) double pw_big(const L &ld, int n)
 {
-    if (n <= 128) return pw_block(ld, 0, n);
     // post-order evaluation; depth <= 24 covers n up to 2^31
     int so[26], sn[26];
     double sv[26];
@@ -125,12 +139,32 @@ __device__ double np_pairwise_sum(const L &ld, int n)
     return ret;
 }
 
+template <class L>
+__device__ __forceinline__ double np_pairwise_sum(const L &ld, int n)
+{
+    if (n <= 128) return pw_block(ld, 0, n);
+    return pw_big(ld, n); // rare: runs longer than 128 samples
+}
+
 __device__ double np_mean(const double *a, int n) { return np_pairwise_sum(LoadPlain{a}, n) / (double)n; }
 
 __device__ double np_std(const double *a, int n)
 {
     const double mean = np_pairwise_sum(LoadPlain{a}, n) / (double)n;
     return sqrt(np_pairwise_sum(LoadSqDev{a, mean}, n) / (double)n);
+}
+
+// mean and std of one run; STAGE: samples come from LDS (index s0 into smem), else from global memory
+template <bool STAGE>
+__device__ __forceinline__ void run_mean_std(const double *sig, int s0, int len, double &mean, double &sd)
+{
+    if (STAGE) {
+        mean = np_pairwise_sum(LdsPlain{s0}, len) / (double)len;
+        sd = sqrt(np_pairwise_sum(LdsSqDev{s0, mean}, len) / (double)len);
+    } else {
+        mean = np_pairwise_sum(LoadPlain{sig + s0}, len) / (double)len;
+        sd = sqrt(np_pairwise_sum(LoadSqDev{sig + s0, mean}, len) / (double)len);
+    }
 }
 
 // k-th order statistic (0-based) of a[0..n) by rank counting; ties broken by index.
@@ -148,20 +182,21 @@ __device__ double select_rank(const double *a, int n, int kth)
     return a[0];
 }
 
-__device__ double np_median(const double *a, int n)
+__device__ __attribute__((noinline)) double np_median(const double *a, int n)
 {
     if (n & 1) return select_rank(a, n, n / 2);
     return (select_rank(a, n, n / 2 - 1) + select_rank(a, n, n / 2)) / 2.0;
 }
 
 // ---- sliding t-test segmentation (caller.py:347-378) ------------------------------------------
-__device__ __forceinline__ double mean3(const double *a) { return (((0.0 + a[0]) + a[1]) + a[2]) / 3.0; }
-__device__ __forceinline__ double std3(const double *a)
+__device__ __forceinline__ double mean3v(double a0, double a1, double a2) { return (((0.0 + a0) + a1) + a2) / 3.0; }
+__device__ __forceinline__ double std3v(double a0, double a1, double a2, double mu)
 {
-    const double mu = mean3(a);
-    const double d0 = a[0] - mu, d1 = a[1] - mu, d2 = a[2] - mu;
+    const double d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu;
     return sqrt((((0.0 + d0 * d0) + d1 * d1) + d2 * d2) / 3.0);
 }
+__device__ __forceinline__ double mean3(const double *a) { return mean3v(a[0], a[1], a[2]); }
+__device__ __forceinline__ double std3(const double *a) { return std3v(a[0], a[1], a[2], mean3(a)); }
 
 // number of detected events minus one in data[0..n), win = 3; n >= 6 (checked by the caller)
 __device__ int segment_count(const double *data, int n)
@@ -208,76 +243,93 @@ __device__ void py_slice(long long a, long long b, long long n, int *lo, int *hi
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mid_kernel(MidArgs a)
+// The stage between the DTW passes as FLAT kernels (each massively parallel, no serialised phases):
+//   run_stats_kernel   one thread per run            : alignment records (mean/std/good/cost)
+//   borders_kernel     one thread per read           : find_event_borders, status, cost, allele length
+//   tstat_kernel       one thread per sample         : sliding-window statistics and t-statistic; zeroes the mask
+//   chunk_kernel       one thread per (read, chunk)  : segment() peak scan -> bad-repeat mask
+//   sort_kernel        one wavefront per read        : stable sort of the accepted (value, expected) pairs
+// ------------------------------------------------------------------------------------------------
+struct ReadView {
+    int r, lr, T, n;
+    long long off;
+    const uint16_t *rs;
+    const int32_t *rst;
+    __device__ int fstate(int k) const { return rs[n - 1 - k]; }
+    __device__ int fstart(int k) const { return rst[n - 1 - k]; }
+    __device__ int fend(int k) const { return (k == n - 1) ? T : rst[n - 2 - k]; } // exclusive
+};
+
+__device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
 {
-    const int lane = threadIdx.x & 63;
+    ReadView v;
+    v.lr = lr;
+    v.r = a.first_read + lr;
+    v.off = a.offsets[v.r] - a.base_off;
+    v.T = (int)(a.offsets[v.r + 1] - a.offsets[v.r]);
+    v.n = a.n_runs[lr];
+    v.rs = a.run_state + v.off;
+    v.rst = a.run_start + v.off;
+    return v;
+}
+
+// (1) alignment records: one per run (create_alignment, reps_as_one = False), caller.py:17-43,65-96
+__global__ __launch_bounds__(256) void run_stats_kernel(MidArgs a)
+{
     const int lr = blockIdx.x;
+    if (a.status[lr] != 0) return;
+    const ReadView v = view(a, lr);
+    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    if (k >= v.n) return;
+    const DevAutomaton &A = a.aut[a.aut_id[v.r]];
+    const double *sig = a.signal + v.off;
+    const int s0 = v.fstart(k), len = v.fend(k) - s0;
+    double val, sd;
+    run_mean_std<false>(sig, s0, len, val, sd);
+    if (a.prm.method_median) val = np_median(sig + s0, len);
+    const double expd = A.value[v.fstate(k)];
+    const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
+    a.al_value[v.off + k] = val;
+    a.al_expected[v.off + k] = expd;
+    a.al_cost[v.off + k] = fabs(val - expd);
+    a.al_good[v.off + k] = good ? 1 : 0;
+}
+
+// (2,3,5) per read: allele length, find_event_borders, chunk range checks, state-wise cost, results
+__global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
+{
+    const int lr = blockIdx.x * blockDim.x + threadIdx.x;
     if (lr >= a.n_reads) return;
-    const int r = a.first_read + lr;
     wsx_result *res = (wsx_result *)a.results + lr;
+    MidRec rec{};
     int status = a.status[lr];
     if (status != 0) {
-        if (lane == 0 && a.pass == 1) {
-            res->status = status;
+        res->status = status;
+        if (a.pass == 1) {
             res->len1 = res->len2 = res->n_trans1 = res->n_trans2 = 0;
             res->reserved = 0;
             res->cost1 = res->cost2 = __builtin_nan("");
             res->dtw_end_cost1 = res->dtw_end_cost2 = kInf;
-        } else if (lane == 0) {
-            res->status = status;
         }
+        a.rec[lr] = rec;
         return;
     }
-    const long long off = a.offsets[r] - a.base_off;
-    const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
-    const DevAutomaton A = a.aut[a.aut_id[r]];
-    const double *sig = a.signal + off;
-    const int n = a.n_runs[lr];
-    const uint16_t *rs = a.run_state + off; // reverse time order
-    const int32_t *rst = a.run_start + off;
-    auto fstate = [&](int k) -> int { return rs[n - 1 - k]; };
-    auto fstart = [&](int k) -> int { return rst[n - 1 - k]; };
-    auto fend = [&](int k) -> int { return (k == n - 1) ? T : rst[n - 2 - k]; }; // exclusive
-    const int m = a.prm.m;
-    const int sis = a.prm.states_in_segment;
+    const ReadView v = view(a, lr);
+    const DevAutomaton &A = a.aut[a.aut_id[v.r]];
+    const int n = v.n, T = v.T, sis = a.prm.states_in_segment;
+    const uint8_t *alg = a.al_good + v.off;
+    const double *alc = a.al_cost + v.off;
 
-    // ---- (1) alignment records: one per run (create_alignment, reps_as_one = False) ------------
-    double *alv = a.al_value + off, *ale = a.al_expected + off, *alc = a.al_cost + off;
-    uint8_t *alg = a.al_good + off;
-    int n_good_local = 0;
-    for (int k = lane; k < n; k += 64) {
-        const int s0 = fstart(k), len = fend(k) - s0;
-        const int st = fstate(k);
-        const double *raw = sig + s0;
-        const double val = a.prm.method_median ? np_median(raw, len) : np_mean(raw, len);
-        const double expd = A.value[st];
-        const bool good = (len >= m) && (np_std(raw, len) < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
-        alv[k] = val;
-        ale[k] = expd;
-        alc[k] = fabs(val - expd);
-        alg[k] = good ? 1 : 0;
-        n_good_local += good ? 1 : 0;
-    }
-    // total number of good records
-    int n_good = n_good_local;
-    for (int o = 32; o > 0; o >>= 1) n_good += __shfl_xor(n_good, o);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- (2) sequence length after flank stripping (_get_sequence) -----------------------------
     int slo, shi;
-    py_slice((long long)A.flank_length - A.seq_idx[fstate(0)], -(long long)A.flank_length, n, &slo, &shi);
+    py_slice((long long)A.flank_length - A.seq_idx[v.fstate(0)], -(long long)A.flank_length, n, &slo, &shi);
     const int seqlen = shi - slo;
 
-    // ---- (3) find_event_borders ----------------------------------------------------------------
-    int start = -1, end = -1;
-    for (int c = 0; c * 64 < n; c++) {
-        const int k = c * 64 + lane;
-        const bool isrep = (k < n) && A.repeat_mask[fstate(k)];
-        const unsigned long long bal = __ballot(isrep);
-        if (bal) {
-            if (start < 0) start = c * 64 + __builtin_ctzll(bal);
-            end = c * 64 + 63 - __builtin_clzll(bal);
+    int n_good = 0, start = -1, end = -1;
+    for (int k = 0; k < n; k++) {
+        n_good += alg[k];
+        if (A.repeat_mask[v.fstate(k)]) {
+            if (start < 0) start = k;
+            end = k;
         }
     }
     int nsel = 0, nb = 0;
@@ -293,13 +345,13 @@ __global__ __launch_bounds__(64) void mid_kernel(MidArgs a)
             if (end >= n) {
                 status = WSX_READ_SEGMENT_RANGE;
             } else {
-                const int es = fstate(end);
-                int eR = -1;
-                for (int c = 0; c * 64 < n; c++) {
-                    const int k = c * 64 + lane;
-                    const unsigned long long bal = __ballot((k < n) && fstate(k) == es);
-                    if (bal) eR = c * 64 + 63 - __builtin_clzll(bal);
-                }
+                const int es = v.fstate(end);
+                int eR = end;
+                for (int k = n - 1; k > end; k--)
+                    if (v.fstate(k) == es) {
+                        eR = k;
+                        break;
+                    }
                 nb = eR - start;
             }
         }
@@ -308,105 +360,180 @@ __global__ __launch_bounds__(64) void mid_kernel(MidArgs a)
             if (nsel == 0) status = WSX_READ_SEGMENT_RANGE;
         }
     }
-    // sel(q) = last sample of run start + q*sis
-    auto sel = [&](int q) -> int { return fend(start + q * sis) - 1; };
-
-    // ---- (4) chunk checks (both passes) and segmentation + mask (pass 1) -----------------------
-    uint32_t *mw = a.maskbits ? a.maskbits + (off / 32 + lr) : nullptr;
-    const int nwords = (T + 31) / 32;
-    if (a.pass == 1 && mw) {
-        for (int w = lane; w < nwords; w += 64) mw[w] = 0;
-        if (a.badmask_bytes)
-            for (int q = lane; q < T; q += 64) a.badmask_bytes[off + q] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
     if (status == 0) {
-        bool bad_range = false;
-        for (int c = lane; c < nsel - 1; c += 64) {
-            const int b0 = sel(c), b1 = sel(c + 1);
-            const int lo = b0 - 3;
-            int hi = b1 + 3;
+        for (int c = 0; c < nsel - 1; c++) { // segment() would index an empty t_stats / wrap a negative slice
+            const int lo = v.fend(start + c * sis) - 1 - 3;
+            int hi = v.fend(start + (c + 1) * sis) - 1 + 3;
             if (hi > T) hi = T;
-            if (lo < 0 || hi - lo - 5 <= 0) {
-                bad_range = true;
-                continue;
-            }
-            if (a.pass == 1) {
-                const int cnt = segment_count(sig + lo, hi - lo);
-                if (cnt >= sis + 1 && mw) {
-                    for (int q = b0; q < b1; q++) {
-                        atomicOr(&mw[q >> 5], 1u << (q & 31));
-                        if (a.badmask_bytes) a.badmask_bytes[off + q] = 1;
-                    }
-                }
-            }
+            if (lo < 0 || hi - lo - 5 <= 0) status = WSX_READ_SEGMENT_RANGE;
         }
-        if (__ballot(bad_range)) status = WSX_READ_SEGMENT_RANGE;
     }
-
-    // ---- (5) state-wise cost over alignment[start:end] ------------------------------------------
     double cost = __builtin_nan("");
     if (status == 0) {
         int clo, chi;
         py_slice(start, end, n, &clo, &chi);
         if (chi > clo) cost = np_pairwise_sum(LoadPlain{alc + clo}, chi - clo) / (double)(chi - clo);
+        rec.start = start;
+        rec.nsel = nsel;
+        rec.p_lo = v.fend(start) - 1 - 3;
+        int p_hi = v.fend(start + (nsel - 1) * sis) - 1 + 3;
+        rec.p_hi = p_hi > T ? T : p_hi;
+        rec.n_good = n_good;
     }
-
-    // ---- (6) rescaling input: good records, stably sorted by value ------------------------------
-    if (status == 0 && a.pass == 1) {
-        double *fx = a.fit_x + off, *fy = a.fit_y + off;
-        for (int kb = 0; kb < n; kb += 64) {
-            const int k = kb + lane;
-            const bool mine = (k < n) && alg[k];
-            const double xk = (k < n) ? alv[k] : 0.0;
-            int rank = 0;
-            for (int qb = 0; qb < n; qb += 64) {
-                const int qq = qb + lane;
-                const double xq_l = (qq < n) ? alv[qq] : 0.0;
-                const unsigned long long gq = __ballot((qq < n) && alg[qq]);
-                const int lim = (n - qb) < 64 ? (n - qb) : 64;
-                for (int t = 0; t < lim; t++) {
-                    if (!((gq >> t) & 1ull)) continue;
-                    const double xq = readlane_f64(xq_l, t);
-                    const int q = qb + t;
-                    rank += (xq < xk) || (xq == xk && q < k);
-                }
-            }
-            if (mine) {
-                fx[rank] = xk;
-                fy[rank] = ale[k];
-            }
-        }
-        if (lane == 0) a.fit_m[lr] = n_good;
+    a.rec[lr] = rec;
+    a.status[lr] = status;
+    res->status = status;
+    if (a.pass == 1) {
+        res->len1 = seqlen;
+        res->n_trans1 = n;
+        res->cost1 = cost;
+        res->len2 = 0;
+        res->n_trans2 = 0;
+        res->reserved = 0;
+        res->cost2 = __builtin_nan("");
+        res->dtw_end_cost1 = a.end_cost ? a.end_cost[lr] : kInf;
+        res->dtw_end_cost2 = kInf;
+    } else {
+        res->len2 = seqlen;
+        res->n_trans2 = n;
+        res->cost2 = cost;
+        if (a.end_cost) res->dtw_end_cost2 = a.end_cost[lr];
     }
+}
 
-    // ---- (7) results ----------------------------------------------------------------------------
-    if (lane == 0) {
-        a.status[lr] = status;
-        res->status = status;
-        if (a.pass == 1) {
-            res->len1 = seqlen;
-            res->n_trans1 = n;
-            res->cost1 = cost;
-            res->len2 = 0;
-            res->n_trans2 = 0;
-            res->reserved = 0;
-            res->cost2 = __builtin_nan("");
-        } else {
-            res->len2 = seqlen;
-            res->n_trans2 = n;
-            res->cost2 = cost;
+// (4a) segment() slides two 3-sample windows over a chunk; the t-statistic at absolute sample p only depends on
+// sig[p-3..p+2], so it is computed once per position for the whole span of the chunks (calc_ttest, caller.py:347-354;
+// np.std(..)**2 squares the rooted value, sic).  Every block also clears its tile of the output mask.
+__global__ __launch_bounds__(256) void tstat_kernel(MidArgs a)
+{
+    __shared__ double wm[256 + 3], ws[256 + 3];
+    const int lr = blockIdx.x;
+    const ReadView v = view(a, lr);
+    const int p0 = blockIdx.y * 256;
+    if (p0 >= v.T) return;
+    const int tid = threadIdx.x;
+    if (a.maskbits && tid < 8 && p0 + tid * 32 < v.T) a.maskbits[v.off / 32 + lr + (p0 >> 5) + tid] = 0;
+    if (a.badmask_bytes && p0 + tid < v.T) a.badmask_bytes[v.off + p0 + tid] = 0;
+    if (a.status[lr] != 0) return;
+    const MidRec rec = a.rec[lr];
+    if (rec.nsel <= 1 || p0 + 256 <= rec.p_lo || p0 >= rec.p_hi) return;
+    const double *sig = a.signal + v.off;
+    // window statistics for positions p0-3 .. p0+255 (those inside [p_lo, p_hi-2))
+    for (int q = tid; q < 259; q += 256) {
+        const int p = p0 - 3 + q;
+        double mu = 0.0, ss = 0.0;
+        if (p >= rec.p_lo && p + 2 < rec.p_hi) {
+            const double a0 = sig[p], a1 = sig[p + 1], a2 = sig[p + 2];
+            mu = mean3v(a0, a1, a2);
+            const double sd = std3v(a0, a1, a2, mu);
+            ss = sd * sd;
         }
-        if (a.end_cost) {
-            if (a.pass == 1) {
-                res->dtw_end_cost1 = a.end_cost[lr];
-                res->dtw_end_cost2 = kInf;
+        wm[q] = mu;
+        ws[q] = ss;
+    }
+    __syncthreads();
+    const int p = p0 + tid;
+    if (p >= rec.p_lo + 3 && p + 2 < rec.p_hi) {
+        double sd = sqrt((ws[tid] + ws[tid + 3]) / 3.0);
+        if (sd == 0.0) sd = sd + 0.0000001;
+        a.scr2[v.off + p] = (wm[tid] - wm[tid + 3]) / sd;
+    }
+}
+
+// (4b) segment() peak scan per chunk (caller.py:357-378), check_segments (342-344), mask_big_events (409-421)
+__global__ __launch_bounds__(64) void chunk_kernel(MidArgs a)
+{
+    const int lr = blockIdx.x;
+    if (a.status[lr] != 0) return;
+    const MidRec rec = a.rec[lr];
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= rec.nsel - 1) return;
+    const ReadView v = view(a, lr);
+    const int sis = a.prm.states_in_segment;
+    const int b0 = v.fend(rec.start + c * sis) - 1, b1 = v.fend(rec.start + (c + 1) * sis) - 1;
+    int hi = b1 + 3;
+    if (hi > v.T) hi = v.T;
+    const double *tst = a.scr2 + v.off;
+    int borders = 0;
+    bool started = false;
+    double prev = tst[b0];
+    for (int p = b0; p + 2 < hi; p++) {
+        const double t = tst[p];
+        if (t > 3 || t < -3) {
+            if ((t > 3 && t >= prev) || (t < -3 && t <= prev)) {
+                started = true;
             } else {
-                res->dtw_end_cost2 = a.end_cost[lr];
+                if (started) borders++;
+                started = false;
+            }
+        } else if (started) {
+            borders++;
+            started = false;
+        }
+        prev = t;
+    }
+    if (borders - 1 >= sis + 1) { // check_segments: >= states_in_segment + 1
+        uint32_t *mw = a.maskbits + (v.off / 32 + lr);
+        for (int w = b0 >> 5; w <= ((b1 - 1) >> 5); w++) {
+            const int q0 = w * 32 > b0 ? w * 32 : b0, q1 = (w + 1) * 32 < b1 ? (w + 1) * 32 : b1;
+            const uint32_t bits = (q1 - q0 >= 32) ? 0xffffffffu : (((1u << (q1 - q0)) - 1u) << (q0 & 31));
+            atomicOr(&mw[w], bits);
+        }
+        if (a.badmask_bytes)
+            for (int q = b0; q < b1; q++) a.badmask_bytes[v.off + q] = 1;
+    }
+}
+
+// (6) rescaling input: accepted records, stably sorted by value (filter_alignment + list.sort, caller.py:304-318):
+// compact (order preserved), then rank = #(x_q < x_k) + #(x_q == x_k, q < k).  One wavefront per read.
+__global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
+{
+    __shared__ double xs[512];
+    const int lane = threadIdx.x & 63;
+    const int lr = blockIdx.x;
+    if (a.status[lr] != 0) return;
+    const ReadView v = view(a, lr);
+    const int n = v.n;
+    const double *alv = a.al_value + v.off, *ale = a.al_expected + v.off;
+    const uint8_t *alg = a.al_good + v.off;
+    double *cx = a.scr0 + v.off, *cy = a.scr1 + v.off;
+    double *fx = a.fit_x + v.off, *fy = a.fit_y + v.off;
+    int base = 0;
+    for (int kb = 0; kb < n; kb += 64) {
+        const int k = kb + lane;
+        const bool g = (k < n) && alg[k];
+        const unsigned long long bal = __ballot(g);
+        const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (g) {
+            cx[pos] = alv[k];
+            cy[pos] = ale[k];
+        }
+        base += __builtin_popcountll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int mfit = base;
+    for (int kb = 0; kb < mfit; kb += 64) {
+        const int k = kb + lane;
+        const double xk = (k < mfit) ? cx[k] : 0.0;
+        int rank = 0;
+        for (int qb = 0; qb < mfit; qb += 512) {
+            const int cnt = (mfit - qb) < 512 ? (mfit - qb) : 512;
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < cnt; q += 64) xs[q] = cx[qb + q];
+            __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < cnt; q++) {
+                const double xq = xs[q]; // LDS broadcast
+                rank += (xq < xk) ? 1 : 0;
+                rank += (xq == xk && (qb + q) < k) ? 1 : 0;
             }
         }
+        if (k < mfit) {
+            fx[rank] = xk;
+            fy[rank] = cy[k];
+        }
     }
+    if (lane == 0) a.fit_m[lr] = mfit;
 }
 
 // ---- FITPACK pieces ---------------------------------------------------------------------------
@@ -555,10 +682,20 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 
 } // namespace
 
-hipError_t wsx_launch_mid(const MidArgs &a, hipStream_t s)
+hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
 {
     if (a.n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mid_kernel, dim3(a.n_reads), dim3(64), 0, s, a);
+    const int m = a.prm.m;
+    // a run spans >= m-1 samples (except possibly the first and last): bound on runs per read
+    const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
+    hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+    if (a.pass == 1) {
+        const int max_chunks = max_runs / a.prm.states_in_segment + 2;
+        hipLaunchKernelGGL(tstat_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(chunk_kernel, dim3(a.n_reads, (max_chunks + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(sort_kernel, dim3(a.n_reads), dim3(64), 0, s, a);
+    }
     return hipGetLastError();
 }
 

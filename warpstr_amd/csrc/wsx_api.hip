@@ -130,7 +130,8 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 {
     int maxbp = 0;
     for (auto &v : c->variant) maxbp = std::max(maxbp, v.K * 64 * 4 / v.R() + 1);
-    size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 1 /*mask bits, rounded up*/ + maxbp;
+    size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 24 /*scratch*/ +
+               1 /*mask bits, rounded up*/ + maxbp;
     if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 1) : 0);
     return b + 8; // alignment slack
 }
@@ -430,10 +431,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     const size_t R1 = max_cnt + 8;
     // per-sample arrays
     size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
-                       3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 2 * align_up(S1 * 8) /*fit*/ +
+                       3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
     HIPCHK(c->samples.ensure(smp_bytes));
-    HIPCHK(c->reads.ensure(R1 * 128 + align_up(R1 * sizeof(wsx_result))));
+    HIPCHK(c->reads.ensure(R1 * 160 + align_up(R1 * sizeof(wsx_result)) + 4096));
     // (off/R + lr + 1) * K*64 words, bounded by samples*maxbpw + reads*K*64*2
     size_t bp_words = 0;
     for (auto &v : c->variant)
@@ -458,6 +459,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         double *d_alv = sc.take<double>(S1), *d_ale = sc.take<double>(S1), *d_alc = sc.take<double>(S1);
         uint8_t *d_alg = sc.take<uint8_t>(S1);
         double *d_fx = sc.take<double>(S1), *d_fy = sc.take<double>(S1);
+        double *d_scr0 = sc.take<double>(S1), *d_scr1 = sc.take<double>(S1), *d_scr2 = sc.take<double>(S1);
         uint32_t *d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
         Carver rcv(c->reads.p);
         int32_t *d_nruns = rcv.take<int32_t>(R1);
@@ -465,6 +467,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         int32_t *d_fitm = rcv.take<int32_t>(R1);
         double *d_endcost = rcv.take<double>(R1);
         double *d_coef = rcv.take<double>(R1 * 6);
+        MidRec *d_rec = rcv.take<MidRec>(R1);
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
 
         // signal of this chunk
@@ -629,12 +632,16 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.fit_x = d_fx;
         ma.fit_y = d_fy;
         ma.fit_m = d_fitm;
+        ma.rec = d_rec;
+        ma.scr0 = d_scr0;
+        ma.scr1 = d_scr1;
+        ma.scr2 = d_scr2;
         ma.maskbits = d_maskbits;
         ma.badmask_bytes = d_badmask;
         ma.status = d_status;
         ma.end_cost = d_endcost;
         ma.results = d_results;
-        HIPCHK(wsx_launch_mid(ma, st));
+        HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
         FitArgs fa{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, d_coef, d_status};
         HIPCHK(wsx_launch_fit(fa, st));
         EvalArgs ea{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_sig, d_coef, d_status, d_resc, d_resc_user};
@@ -646,7 +653,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.pass = 2;
         ma.maskbits = nullptr;
         ma.badmask_bytes = nullptr;
-        HIPCHK(wsx_launch_mid(ma, st));
+        HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
         if (host) {
             HIPCHK(hipMemcpyAsync(io.results + f, d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, st));
             if (io.traces.trace1) HIPCHK(hipMemcpyAsync(io.traces.trace1 + boff, d_tr1, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));

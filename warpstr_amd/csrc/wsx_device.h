@@ -62,6 +62,16 @@ struct PassArgs {
     int32_t m;
 };
 
+// Per-read record produced by borders_kernel for the segmentation kernels.
+struct MidRec {
+    int32_t start;   // first repeat transition (index into the run list)
+    int32_t nsel;    // number of selected chunk boundaries
+    int32_t p_lo;    // first sample any chunk reads (sel(0) - 3)
+    int32_t p_hi;    // one past the last sample any chunk reads
+    int32_t n_good;
+    int32_t pad;
+};
+
 // Arguments of the alignment-statistics / masking stage.
 struct MidArgs {
     const DevAutomaton *aut;
@@ -76,6 +86,7 @@ struct MidArgs {
     const int32_t *run_start;
     const int32_t *n_runs;
     int32_t pass;              // 1 or 2
+    int32_t tcap;              // doubles of LDS reserved for the staged signal (set by the launcher)
     // alignment records (forward order), per-sample capacity
     double *al_value;
     double *al_expected;
@@ -85,6 +96,8 @@ struct MidArgs {
     double *fit_x;
     double *fit_y;
     int32_t *fit_m;            // per read
+    MidRec *rec;               // per read
+    double *scr0, *scr1, *scr2; // per-sample scratch (window statistics, t-statistics, compaction)
     uint32_t *maskbits;        // out (pass 1)
     uint8_t *badmask_bytes;    // optional out (pass 1), per sample
     int32_t *status;           // per read (in/out)
@@ -120,7 +133,7 @@ struct EvalArgs {
 // Host-side launchers (defined next to the kernels).
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s);
-hipError_t wsx_launch_mid(const MidArgs &a, hipStream_t s);
+hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
