@@ -149,6 +149,14 @@ def main():
         algo_bytes_per_launch = n * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         cells_per_s = n * T * S / (launch_ms * 1e-3)
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json), same workload only
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+                tj = json.load(f)
+            if tj['workload'] == {'reads': n, 'samples': T}:
+                traffic = tj['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'reads/s (STR segments aligned)', 'value': reads_per_s, 'unit': 'reads/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -158,11 +166,11 @@ def main():
                        'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
                        'results_gather': 'rccl all_gather' if world > 1 else 'none (1 GPU)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': hip.kernel_name(0), 'launch_ms': launch_ms,
                          'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
-            'valu': {'dp_cells_per_s': cells_per_s, 'fp64_ops_per_cell_est': 8,
-                     'frac_of_fp64_valu_peak_est': cells_per_s * 8 / FP64_VALU_PEAK},
+            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.8,
+                     'note': 'PMC: SQ_INSTS_VALU/row = 13.8, VALU active ~85% of SIMD cycles at ~1.93 GHz'},
             'dp_kernel_ms_per_step': tm['dp_kernel_ms'], 'device_ms_per_step': tm['total_ms'],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -127,6 +127,45 @@ def test_generic_kernel_other_min_values_per_state():
                              oracle.Params(min_values_per_state=m, states_in_segment=sis, method=method))
 
 
+@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone'])
+def test_alternative_configs_match_golden(case):
+    """Non-default settings recorded from the upstream caller: generic DP kernel (m = 3), median state values,
+    5-state segments; reps_as_one with other thresholds."""
+    import json
+    import os
+    z = load_case(case)
+    with open(os.path.join('tests', 'golden', case + '.config.json')) as f:
+        cfg = json.load(f)
+    t, r = tables_of(z)
+    fl = int(z['flank_length'])
+    hip = HipCaller([t, r], [fl, fl],
+                    CallerConfig(min_values_per_state=cfg.get('min_values_per_state', 4),
+                                 states_in_segment=cfg.get('states_in_segment', 6)),
+                    RescalerConfig(reps_as_one=cfg.get('reps_as_one', False), threshold=cfg.get('threshold', 0.5),
+                                   max_std=cfg.get('max_std', 0.5), method=cfg.get('method', 'mean')))
+    n = int(z['n_reads'])
+    aut = z['reverse'].astype(np.int32)
+    sig, off = pack_signals([z[f'r{i}_signal'] for i in range(n)])
+    res, ex = hip.call(sig, off, aut, want_debug=True)
+    for i in range(n):
+        sl = slice(off[i], off[i + 1])
+        assert res['status'][i] == 0
+        assert np.array_equal(ex['trace1'][sl], z[f'r{i}_trace1'])
+        assert np.array_equal(ex['badmask'][sl], z[f'r{i}_badmask'])
+        np.testing.assert_allclose(ex['rescaled'][sl], z[f'r{i}_rescaled'], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(ex['trace2'][sl], z[f'r{i}_trace2'])
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
+        assert_close_rel(res['cost1'][i], z[f'r{i}_cost'][0], COST_REL)
+        assert_close_rel(res['cost2'][i], z[f'r{i}_cost'][1], COST_REL)
+
+
+def test_reps_as_one_matches_oracle():
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 20, 9)
+    sigs, revs, _ = synth.batch(locus, 24, 1800, 13)
+    _compare_with_oracle(locus, 20, sigs, revs, None, RescalerConfig(reps_as_one=True), oracle.Params(reps_as_one=True))
+
+
 def test_statuses_instead_of_crashes():
     """flank_length < 16 makes the upstream caller raise IndexError on some reads (recorded fixture);
     too-short reads; the batch must survive and flag exactly those reads."""

@@ -136,3 +136,27 @@ def test_short_read_is_a_status_not_a_crash():
     aut = golden_automaton(z, 't')
     r = oracle.call_read(aut, z['r0_signal'][:4])
     assert oracle.STATUS[r.status] == 'shape'
+
+
+@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone'])
+def test_alternative_configs(case):
+    """Non-default tr_calling_config / rescaling settings (min_values_per_state=3 + median + 5-state segments;
+    reps_as_one with other thresholds): the oracle follows the reference there too."""
+    z = load_case(case)
+    with open(os.path.join(GOLDEN, case + '.config.json')) as f:
+        cfg = json.load(f)
+    prm = oracle.Params(min_values_per_state=cfg.get('min_values_per_state', 4),
+                        states_in_segment=cfg.get('states_in_segment', 6), threshold=cfg.get('threshold', 0.5),
+                        max_std=cfg.get('max_std', 0.5), method=cfg.get('method', 'mean'),
+                        reps_as_one=cfg.get('reps_as_one', False))
+    auts = {0: golden_automaton(z, 't'), 1: golden_automaton(z, 'r')}
+    for i in range(int(z['n_reads'])):
+        r = oracle.call_read(auts[int(z['reverse'][i])], z[f'r{i}_signal'], prm)
+        assert r.status == 0
+        assert np.array_equal(r.trace1, z[f'r{i}_trace1']) and np.array_equal(r.trace2, z[f'r{i}_trace2'])
+        assert np.array_equal(r.rescaled, z[f'r{i}_rescaled']) and np.array_equal(r.badmask, z[f'r{i}_badmask'])
+        assert r.idx == tuple(int(v) for v in z[f'r{i}_idx'])
+        seq, rseq = [str(s) for s in z[f'r{i}_seq']]
+        assert (r.len1, r.len2) == (len(seq), len(rseq))
+        assert_close_rel(r.cost1, z[f'r{i}_cost'][0], 1e-12)
+        assert_close_rel(r.cost2, z[f'r{i}_cost'][1], 1e-12)

@@ -295,6 +295,51 @@ __global__ __launch_bounds__(256) void run_stats_kernel(MidArgs a)
     a.al_good[v.off + k] = good ? 1 : 0;
 }
 
+// (1') rescaling.reps_as_one = True (caller.py:69-79): one record per distinct state on the path, in ascending
+// state order, over ALL samples of that state (time order).  Rarely used option: one thread per read, serial.
+__global__ __launch_bounds__(64) void reps_stats_kernel(MidArgs a)
+{
+    const int lr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lr >= a.n_reads) return;
+    if (a.status[lr] != 0) return;
+    const ReadView v = view(a, lr);
+    const DevAutomaton &A = a.aut[a.aut_id[v.r]];
+    const int S = A.n_states, n = v.n;
+    int32_t *cnt = a.state_scratch + (size_t)lr * 2 * a.max_states, *stoff = cnt + a.max_states;
+    const double *sig = a.signal + v.off;
+    double *gs = a.scr0 + v.off;
+    for (int j = 0; j < S; j++) cnt[j] = 0;
+    for (int k = 0; k < n; k++) cnt[v.fstate(k)] += v.fend(k) - v.fstart(k);
+    int o = 0;
+    for (int j = 0; j < S; j++) {
+        stoff[j] = o;
+        o += cnt[j];
+        cnt[j] = 0;
+    }
+    for (int k = 0; k < n; k++) {
+        const int j = v.fstate(k), s0 = v.fstart(k), len = v.fend(k) - s0;
+        const int b = stoff[j] + cnt[j];
+        for (int t = 0; t < len; t++) gs[b + t] = sig[s0 + t];
+        cnt[j] += len;
+    }
+    int u = 0;
+    for (int j = 0; j < S; j++) {
+        const int len = cnt[j];
+        if (len == 0) continue;
+        double val, sd;
+        run_mean_std<false>(gs, stoff[j], len, val, sd);
+        if (a.prm.method_median) val = np_median(gs + stoff[j], len);
+        const double expd = A.value[j];
+        const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
+        a.al_value[v.off + u] = val;
+        a.al_expected[v.off + u] = expd;
+        a.al_cost[v.off + u] = fabs(val - expd);
+        a.al_good[v.off + u] = good ? 1 : 0;
+        u++;
+    }
+    a.n_align[lr] = u;
+}
+
 // (2,3,5) per read: allele length, find_event_borders, chunk range checks, state-wise cost, results
 __global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
 {
@@ -324,9 +369,10 @@ __global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
     py_slice((long long)A.flank_length - A.seq_idx[v.fstate(0)], -(long long)A.flank_length, n, &slo, &shi);
     const int seqlen = shi - slo;
 
+    const int na = a.n_align ? a.n_align[lr] : n; // alignment records: one per run, or per distinct state
     int n_good = 0, start = -1, end = -1;
+    for (int k = 0; k < na; k++) n_good += alg[k];
     for (int k = 0; k < n; k++) {
-        n_good += alg[k];
         if (A.repeat_mask[v.fstate(k)]) {
             if (start < 0) start = k;
             end = k;
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
     double cost = __builtin_nan("");
     if (status == 0) {
         int clo, chi;
-        py_slice(start, end, n, &clo, &chi);
+        py_slice(start, end, na, &clo, &chi);
         if (chi > clo) cost = np_pairwise_sum(LoadPlain{alc + clo}, chi - clo) / (double)(chi - clo);
         rec.start = start;
         rec.nsel = nsel;
@@ -493,7 +539,7 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
     const int lr = blockIdx.x;
     if (a.status[lr] != 0) return;
     const ReadView v = view(a, lr);
-    const int n = v.n;
+    const int n = a.n_align ? a.n_align[lr] : v.n;
     const double *alv = a.al_value + v.off, *ale = a.al_expected + v.off;
     const uint8_t *alg = a.al_good + v.off;
     double *cx = a.scr0 + v.off, *cy = a.scr1 + v.off;
@@ -688,7 +734,8 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     const int m = a.prm.m;
     // a run spans >= m-1 samples (except possibly the first and last): bound on runs per read
     const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
-    hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 255) / 256), dim3(256), 0, s, a);
+    if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;

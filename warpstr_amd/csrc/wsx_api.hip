@@ -78,7 +78,7 @@ struct wsx_caller {
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30;
     // workspace
-    DeviceBuf meta, samples, reads, bp, stage_sig, stage_out;
+    DeviceBuf meta, samples, reads, bp, stage_sig, stage_out, reps;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
     size_t dp_events_used = 0;
@@ -181,10 +181,6 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     }
     if (params->threshold > 1.0) {
         g_err = "rescaling.threshold > 1 may leave FITPACK's polynomial branch; not implemented";
-        return WSX_ERR_UNSUPPORTED;
-    }
-    if (params->reps_as_one) {
-        g_err = "rescaling.reps_as_one = True is not implemented by the HIP caller";
         return WSX_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -291,7 +287,7 @@ void wsx_caller_destroy(wsx_caller *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta, &c->samples, &c->reads, &c->bp, &c->stage_sig, &c->stage_out})
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta, &c->samples, &c->reads, &c->bp, &c->stage_sig, &c->stage_out, &c->reps})
         b->release();
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -434,7 +430,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                        3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
     HIPCHK(c->samples.ensure(smp_bytes));
-    HIPCHK(c->reads.ensure(R1 * 160 + align_up(R1 * sizeof(wsx_result)) + 4096));
+    HIPCHK(c->reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
+    if (full && c->prm.reps_as_one) HIPCHK(c->reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
     // (off/R + lr + 1) * K*64 words, bounded by samples*maxbpw + reads*K*64*2
     size_t bp_words = 0;
     for (auto &v : c->variant)
@@ -468,6 +465,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         double *d_endcost = rcv.take<double>(R1);
         double *d_coef = rcv.take<double>(R1 * 6);
         MidRec *d_rec = rcv.take<MidRec>(R1);
+        int32_t *d_nalign = rcv.take<int32_t>(R1);
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
 
         // signal of this chunk
@@ -633,6 +631,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.fit_y = d_fy;
         ma.fit_m = d_fitm;
         ma.rec = d_rec;
+        ma.n_align = c->prm.reps_as_one ? d_nalign : nullptr;
+        ma.state_scratch = (int32_t *)c->reps.p;
+        ma.max_states = c->max_states;
         ma.scr0 = d_scr0;
         ma.scr1 = d_scr1;
         ma.scr2 = d_scr2;

@@ -97,6 +97,9 @@ struct MidArgs {
     double *fit_y;
     int32_t *fit_m;            // per read
     MidRec *rec;               // per read
+    int32_t *n_align;          // per read: record count in reps_as_one mode, else NULL
+    int32_t *state_scratch;    // reps_as_one: 2*max_states ints per read
+    int32_t max_states;
     double *scr0, *scr1, *scr2; // per-sample scratch (window statistics, t-statistics, compaction)
     uint32_t *maskbits;        // out (pass 1)
     uint8_t *badmask_bytes;    // optional out (pass 1), per sample
