@@ -85,7 +85,7 @@ typedef struct wsx_params {
     double threshold;             /* rescaling.threshold, default 0.5 (0 < . <= 1) */
     double max_std;               /* rescaling.max_std, default 0.5 */
     int32_t method_median;        /* rescaling.method: 0 = mean, 1 = median */
-    int32_t reps_as_one;          /* rescaling.reps_as_one */
+    int32_t reps_as_one;          /* rescaling.reps_as_one (0/1) */
 } wsx_params;
 
 typedef struct wsx_result {

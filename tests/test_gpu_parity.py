@@ -258,3 +258,37 @@ def test_full_size_properties():
         o = oracle.call_read(oa[aut[i]], sigs[i])
         assert o.status == 0 and np.array_equal(e0['trace2'][off[i]:off[i + 1]], o.trace2)
         assert (r0['len1'][i], r0['len2'][i]) == (o.len1, o.len2)
+
+
+def test_mixed_loci_one_batch():
+    """BASELINE config 5 shape in miniature: several loci (different kernel variants: K = 1, 2, 4; fan-in 2..4) and
+    both strands in ONE handle and ONE call; each read must equal its single-locus oracle result."""
+    specs = [('(AGC)', 16, (900, 1500)), ('((CAGG){CAGM})(CAGA)(CA)', 40, (1500, 4000)), ('(AAAT)', 110, (2300, 3000)),
+             ('(NGC)', 24, (1200, 1800))]
+    tables, fls, sigs, aid, oauts = [], [], [], [], []
+    rng = np.random.default_rng(21)
+    for li, (pat, fl, T) in enumerate(specs):
+        locus = synth.make_locus(pat, fl, 300 + li)
+        tables += [locus.template, locus.reverse]
+        fls += [fl, fl]
+        oauts += [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+        s, revs, _ = synth.batch(locus, 6, T, 50 + li, lo=2, hi=12)
+        sigs += s
+        aid += [2 * li + int(r) for r in revs]
+    perm = rng.permutation(len(sigs))
+    sigs = [sigs[i] for i in perm] + [np.zeros(0), np.zeros(3)]          # plus an empty and a too-short read
+    aid = np.array([aid[i] for i in perm] + [0, 1], dtype=np.int32)
+    hip = HipCaller(tables, fls)
+    sig, off = pack_signals(sigs)
+    res, ex = hip.call(sig, off, aid, want_traces=True)
+    assert res['status'][-1] == 1 and res['status'][-2] == 1
+    for i in range(len(sigs) - 2):
+        o = oracle.call_read(oauts[aid[i]], sigs[i])
+        assert res['status'][i] == o.status
+        if o.status == 0:
+            assert np.array_equal(ex['trace2'][off[i]:off[i + 1]], o.trace2)
+            assert (res['len1'][i], res['len2'][i]) == (o.len1, o.len2)
+            assert_close_rel(res['cost2'][i], o.cost2, COST_REL)
+    # an empty batch is a no-op
+    r0, _ = hip.call(np.zeros(0), np.zeros(1, np.int64), np.zeros(0, np.int32))
+    assert len(r0) == 0
