@@ -144,17 +144,21 @@ def main():
         S = max(locus.template.n_states, locus.reverse.n_states)
         total_reads = n * world * args.steps
         reads_per_s = total_reads / dt
-        # dominant kernel = the DTW pass; 2 launches per step (one per pass), each over n reads.
-        launch_ms = tm['dp_kernel_ms'] / max(tm['dp_launches'], 1)
-        algo_bytes_per_launch = n * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
+        # dominant kernel = the DTW fill.  One step = 2 passes over n reads, issued as `launches` kernel launches
+        # (the library splits big batches into chunks that overlap on two streams); durations are HIP events
+        # recorded on the launch streams around each fill launch.
+        launches = max(tm['dp_launches'], 1)
+        launch_ms = tm['dp_kernel_ms'] / launches
+        reads_per_launch = 2.0 * n / launches
+        algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        cells_per_s = n * T * S / (launch_ms * 1e-3)
+        cells_per_s = reads_per_launch * T * S / (launch_ms * 1e-3)
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json), same workload only
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
                 tj = json.load(f)
-            if tj['workload'] == {'reads': n, 'samples': T}:
-                traffic = tj['hbm_bytes_per_launch']
+            if tj['workload']['samples'] == T:
+                traffic = tj['hbm_bytes_per_launch'] / tj['workload']['reads'] * reads_per_launch
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -167,7 +171,8 @@ def main():
                        'results_gather': 'rccl all_gather' if world > 1 else 'none (1 GPU)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'kernel': hip.kernel_name(0), 'launch_ms': launch_ms,
+                         'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
+                         'reads_per_launch': reads_per_launch,
                          'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
             'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.8,
                      'note': 'PMC: SQ_INSTS_VALU/row = 13.8, VALU active ~85% of SIMD cycles at ~1.93 GHz'},

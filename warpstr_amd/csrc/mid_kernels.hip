@@ -12,29 +12,17 @@
 // operation in fp64 (compiled with -ffp-contract=off), see oracle/warpstr_oracle.c for the CPU twin
 // used by the parity tests.
 //
-// Parallelisation:
-//   mid_kernel   one wavefront per read; lanes stride over the read's runs (alignment records),
-//                over its segmentation chunks and over the rank computation of the stable sort.
-//   fit_kernel   one THREAD per read: the Givens triangularisation is a sequential recurrence over
-//                the sorted points (4 rotations, each 3 divisions + 1 sqrt, per point), so reads are
-//                the parallel axis.
-//   eval_kernel  one thread per sample: cubic B-spline evaluation (de Boor recurrence, 6 divisions).
+// Parallelisation: flat kernels, no serialised phases (see the kernel list further down):
+//   run_stats_kernel   thread per run             borders_kernel   thread per read
+//   tstat_kernel       thread per sample          chunk_kernel     thread per (read, chunk)
+//   sort_kernel        wavefront per read         fit_kernel       thread per read (sequential Givens recurrence)
+//   eval_kernel        thread per sample (de Boor evaluation, 6 divisions)
 #include "../../include/warpstr_hip.h"
 #include "wsx_device.h"
 
 namespace {
 
 constexpr double kInf = __builtin_huge_val();
-
-__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    long long b = __double_as_longlong(v);
-    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 // ---- NumPy pairwise summation (n < 8: plain loop; n <= 128: 8 accumulators; else split) --------
 struct LoadPlain {
@@ -50,26 +38,6 @@ struct LoadSqDev {
         return d * d;
     }
 };
-// the read's signal staged in LDS (dynamic shared memory, see mid_kernel<true>)
-extern __shared__ double smem[];
-struct LdsPlain {
-    int b;
-    __device__ double operator()(int i) const { return smem[b + i]; }
-};
-struct LdsSqDev {
-    int b;
-    double mean;
-    __device__ double operator()(int i) const
-    {
-        const double d = smem[b + i] - mean;
-        return d * d;
-    }
-};
-struct LoadAbsDiff {
-    const double *a, *b;
-    __device__ double operator()(int i) const { return fabs(a[i] - b[i]); }
-};
-
 template <class L>
 __device__ __attribute__((noinline)) double pw_block(const L &ld, int o, int n) // n <= 128
 {
@@ -146,25 +114,11 @@ __device__ __forceinline__ double np_pairwise_sum(const L &ld, int n)
     return pw_big(ld, n); // rare: runs longer than 128 samples
 }
 
-__device__ double np_mean(const double *a, int n) { return np_pairwise_sum(LoadPlain{a}, n) / (double)n; }
-
-__device__ double np_std(const double *a, int n)
-{
-    const double mean = np_pairwise_sum(LoadPlain{a}, n) / (double)n;
-    return sqrt(np_pairwise_sum(LoadSqDev{a, mean}, n) / (double)n);
-}
-
-// mean and std of one run; STAGE: samples come from LDS (index s0 into smem), else from global memory
-template <bool STAGE>
+// mean and std of one run (np.average / np.std of the run's samples)
 __device__ __forceinline__ void run_mean_std(const double *sig, int s0, int len, double &mean, double &sd)
 {
-    if (STAGE) {
-        mean = np_pairwise_sum(LdsPlain{s0}, len) / (double)len;
-        sd = sqrt(np_pairwise_sum(LdsSqDev{s0, mean}, len) / (double)len);
-    } else {
-        mean = np_pairwise_sum(LoadPlain{sig + s0}, len) / (double)len;
-        sd = sqrt(np_pairwise_sum(LoadSqDev{sig + s0, mean}, len) / (double)len);
-    }
+    mean = np_pairwise_sum(LoadPlain{sig + s0}, len) / (double)len;
+    sd = sqrt(np_pairwise_sum(LoadSqDev{sig + s0, mean}, len) / (double)len);
 }
 
 // k-th order statistic (0-based) of a[0..n) by rank counting; ties broken by index.
@@ -194,39 +148,6 @@ __device__ __forceinline__ double std3v(double a0, double a1, double a2, double 
 {
     const double d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu;
     return sqrt((((0.0 + d0 * d0) + d1 * d1) + d2 * d2) / 3.0);
-}
-__device__ __forceinline__ double mean3(const double *a) { return mean3v(a[0], a[1], a[2]); }
-__device__ __forceinline__ double std3(const double *a) { return std3v(a[0], a[1], a[2], mean3(a)); }
-
-// number of detected events minus one in data[0..n), win = 3; n >= 6 (checked by the caller)
-__device__ int segment_count(const double *data, int n)
-{
-    const int win = 3;
-    const int nt = n - 2 * win + 1;
-    int borders = 0;
-    bool start = false;
-    double prev = 0.0;
-    for (int q = 0; q < nt; q++) {
-        const double *a1 = data + q, *a2 = data + q + win;
-        const double s1 = std3(a1), s2 = std3(a2);
-        double sd = sqrt((s1 * s1 + s2 * s2) / (double)win);
-        if (sd == 0.0) sd = sd + 0.0000001;
-        const double t = (mean3(a1) - mean3(a2)) / sd;
-        if (q == 0) prev = t;
-        if (t > 3 || t < -3) {
-            if ((t > 3 && t >= prev) || (t < -3 && t <= prev)) {
-                start = true;
-            } else {
-                if (start) borders++;
-                start = false;
-            }
-        } else if (start) {
-            borders++;
-            start = false;
-        }
-        prev = t;
-    }
-    return borders - 1;
 }
 
 // Python slice bounds [a:b] on a sequence of length n
@@ -285,7 +206,7 @@ __global__ __launch_bounds__(256) void run_stats_kernel(MidArgs a)
     const double *sig = a.signal + v.off;
     const int s0 = v.fstart(k), len = v.fend(k) - s0;
     double val, sd;
-    run_mean_std<false>(sig, s0, len, val, sd);
+    run_mean_std(sig, s0, len, val, sd);
     if (a.prm.method_median) val = np_median(sig + s0, len);
     const double expd = A.value[v.fstate(k)];
     const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
@@ -327,7 +248,7 @@ __global__ __launch_bounds__(64) void reps_stats_kernel(MidArgs a)
         const int len = cnt[j];
         if (len == 0) continue;
         double val, sd;
-        run_mean_std<false>(gs, stoff[j], len, val, sd);
+        run_mean_std(gs, stoff[j], len, val, sd);
         if (a.prm.method_median) val = np_median(gs + stoff[j], len);
         const double expd = A.value[j];
         const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);

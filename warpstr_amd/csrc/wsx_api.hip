@@ -9,6 +9,7 @@
 //   -> mid(pass 2: run statistics, borders, cost2, allele length)
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -78,7 +79,18 @@ struct wsx_caller {
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30;
     // workspace
-    DeviceBuf meta, samples, reads, bp, stage_sig, stage_out, reps;
+    // Two workspace sets: consecutive chunks alternate between the handle's stream and an internal one, so that
+    // the latency/bandwidth-bound stages of one chunk (traceback, run statistics, fit, ...) overlap the
+    // VALU-bound DP fill of the other.
+    struct Work {
+        DeviceBuf samples, reads, bp, stage_sig, stage_out, reps;
+    } work[2];
+    DeviceBuf meta;
+    void *pinned = nullptr; // host staging of offsets / automaton ids / launch order (caller buffers are not kept)
+    size_t pinned_cap = 0;
+    hipEvent_t ev_meta = nullptr; // recorded after the last metadata upload of a call
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
     size_t dp_events_used = 0;
@@ -278,6 +290,10 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&c->ev_begin));
     HIPCHK(hipEventCreate(&c->ev_end));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     *out = c;
     return WSX_SUCCESS;
 }
@@ -287,8 +303,15 @@ void wsx_caller_destroy(wsx_caller *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta, &c->samples, &c->reads, &c->bp, &c->stage_sig, &c->stage_out, &c->reps})
-        b->release();
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
+    for (auto &w : c->work)
+        for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto &p : c->dp_events) {
@@ -392,8 +415,25 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int64_t *d_offsets = mc.take<int64_t>(n + 1);
     int32_t *d_autid = mc.take<int32_t>(n);
     int32_t *d_order = mc.take<int32_t>(n);
-    HIPCHK(hipMemcpyAsync(d_offsets, io.offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_autid, io.aut_id, n * 4, hipMemcpyHostToDevice, st));
+    // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
+    // caller's arrays are not referenced after this function returns
+    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+    HIPCHK(hipEventSynchronize(c->ev_meta)); // previous call's uploads (no-op if never recorded)
+    if (pin_bytes > c->pinned_cap) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_cap = 0;
+        HIPCHK(hipHostMalloc(&c->pinned, pin_bytes + pin_bytes / 4, hipHostMallocDefault));
+        c->pinned_cap = pin_bytes + pin_bytes / 4;
+    }
+    Carver pc(c->pinned);
+    int64_t *h_offsets = pc.take<int64_t>(n + 1);
+    int32_t *h_autid = pc.take<int32_t>(n);
+    int32_t *h_order = pc.take<int32_t>(n);
+    memcpy(h_offsets, io.offsets, (n + 1) * 8);
+    memcpy(h_autid, io.aut_id, n * 4);
+    HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_autid, h_autid, n * 4, hipMemcpyHostToDevice, st));
 
     // ---- chunk plan -----------------------------------------------------------------------------
     const size_t psb = per_sample_bytes(c, host, want_traces || !full);
@@ -416,6 +456,27 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             first += cnt;
         }
     }
+    // Big single-chunk batches are split so that chunks can overlap on the two streams (the latency-bound stages of
+    // one chunk run under the VALU-bound fill of another).  WSX_CHUNKS overrides the split count (tuning knob).
+    if (chunks.size() == 1 && n >= 4096) {
+        int want = n >= 32768 ? 4 : 2;
+        if (const char *e = getenv("WSX_CHUNKS")) want = std::max(1, atoi(e));
+        const ChunkPlan whole = chunks[0];
+        chunks.clear();
+        int64_t first = 0;
+        for (int part = 0; part < want && first < n; part++) {
+            const int64_t target = whole.samples * (part + 1) / want; // cumulative samples at the end of this part
+            int64_t cnt = 0;
+            int mt = 0;
+            while (first + cnt < n && (io.offsets[first + cnt] - io.offsets[0] < target || part == want - 1)) {
+                mt = std::max<int>(mt, (int)(io.offsets[first + cnt + 1] - io.offsets[first + cnt]));
+                cnt++;
+            }
+            if (cnt == 0) continue;
+            chunks.push_back({first, cnt, io.offsets[first], io.offsets[first + cnt] - io.offsets[first], mt});
+            first += cnt;
+        }
+    }
     size_t max_smp = 0, max_cnt = 0;
     for (auto &ch : chunks) {
         max_smp = std::max<size_t>(max_smp, ch.samples);
@@ -429,27 +490,42 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
                        3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
-    HIPCHK(c->samples.ensure(smp_bytes));
-    HIPCHK(c->reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
-    if (full && c->prm.reps_as_one) HIPCHK(c->reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
+    const int n_work = chunks.size() > 1 ? 2 : 1;
+    for (int w = 0; w < n_work; w++) {
+        HIPCHK(c->work[w].samples.ensure(smp_bytes));
+        HIPCHK(c->work[w].reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
+        if (full && c->prm.reps_as_one)
+            HIPCHK(c->work[w].reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
+    }
     // (off/R + lr + 1) * K*64 words, bounded by samples*maxbpw + reads*K*64*2
     size_t bp_words = 0;
     for (auto &v : c->variant)
         bp_words = std::max(bp_words, (size_t)(S1 / v.R() + R1 + 2) * (size_t)(v.K * 64));
-    HIPCHK(c->bp.ensure(bp_words * 4));
-    if (host) {
-        HIPCHK(c->stage_sig.ensure(S1 * 8));
+    for (int w = 0; w < n_work; w++) HIPCHK(c->work[w].bp.ensure(bp_words * 4));
+    for (int w = 0; w < n_work && host; w++) {
+        HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
         size_t so = align_up(S1 * 2) * 2 + align_up(S1 * 8) + align_up(S1) + align_up(R1 * 8) + align_up(R1 * 4) +
                     align_up(R1 * (size_t)std::max(io.last_row_stride, 1) * 8);
-        HIPCHK(c->stage_out.ensure(so));
+        HIPCHK(c->work[w].stage_out.ensure(so));
     }
 
-    HIPCHK(hipEventRecord(c->ev_begin, st));
+    const hipStream_t main_st = c->stream;
+    HIPCHK(hipEventRecord(c->ev_begin, main_st));
+    if (n_work > 1) { // fork: the internal stream starts after everything already queued on the handle's stream
+        HIPCHK(hipEventRecord(c->ev_fork, main_st));
+        HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    }
     const int m = c->prm.min_values_per_state;
-    std::vector<int32_t> order(n);
-    for (const ChunkPlan &ch : chunks) {
+    int32_t *order = h_order;
+    bool staggered = false;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const ChunkPlan &ch = chunks[ci];
+        wsx_caller::Work &W = c->work[ci % n_work];
+        st = (ci % n_work) ? c->aux_stream : main_st;
+        // this work set's staging buffers were last used two chunks ago on the same stream (host copies)
+        if (host && ci >= (size_t)n_work) HIPCHK(hipStreamSynchronize(st));
         const int64_t f = ch.first, cnt = ch.count, boff = ch.base_off;
-        Carver sc(c->samples.p);
+        Carver sc(W.samples.p);
         double *d_resc = sc.take<double>(S1);
         uint16_t *d_run_state = sc.take<uint16_t>(S1);
         int32_t *d_run_start = sc.take<int32_t>(S1);
@@ -458,7 +534,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         double *d_fx = sc.take<double>(S1), *d_fy = sc.take<double>(S1);
         double *d_scr0 = sc.take<double>(S1), *d_scr1 = sc.take<double>(S1), *d_scr2 = sc.take<double>(S1);
         uint32_t *d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
-        Carver rcv(c->reads.p);
+        Carver rcv(W.reads.p);
         int32_t *d_nruns = rcv.take<int32_t>(R1);
         int32_t *d_status = rcv.take<int32_t>(R1);
         int32_t *d_fitm = rcv.take<int32_t>(R1);
@@ -471,13 +547,13 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         // signal of this chunk
         const double *d_sig;
         if (host) {
-            HIPCHK(hipMemcpyAsync(c->stage_sig.p, io.signal + boff, (size_t)ch.samples * 8, hipMemcpyHostToDevice, st));
-            d_sig = (const double *)c->stage_sig.p;
+            HIPCHK(hipMemcpyAsync(W.stage_sig.p, io.signal + boff, (size_t)ch.samples * 8, hipMemcpyHostToDevice, st));
+            d_sig = (const double *)W.stage_sig.p;
         } else {
             d_sig = io.signal + boff;
         }
         // user-visible per-sample / per-read outputs for this chunk (device pointers)
-        Carver oc(host ? c->stage_out.p : nullptr);
+        Carver oc(host ? W.stage_out.p : nullptr);
         uint16_t *d_tr1 = nullptr, *d_tr2 = nullptr;
         double *d_resc_user = nullptr, *d_endcost_user = nullptr, *d_lastrow = nullptr;
         uint8_t *d_badmask = nullptr;
@@ -532,10 +608,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 return (io.offsets[x + 1] - io.offsets[x]) > (io.offsets[y + 1] - io.offsets[y]);
             });
             gpos.push_back(pos);
-            std::copy(g.begin(), g.end(), order.begin() + pos);
+            std::copy(g.begin(), g.end(), order + pos);
             pos += g.size();
         }
-        HIPCHK(hipMemcpyAsync(d_order + f, order.data() + f, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_order + f, order + f, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
 
         // optional input mask (warp-only entry)
         const uint32_t *pass1_mask = nullptr;
@@ -568,7 +644,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 pa.first_read = (int32_t)f;
                 pa.base_off = boff;
                 pa.maskbits = maskbits;
-                pa.bp = (uint32_t *)c->bp.p;
+                pa.bp = (uint32_t *)W.bp.p;
                 pa.run_state = d_run_state;
                 pa.run_start = d_run_start;
                 pa.n_runs = d_nruns;
@@ -585,6 +661,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 HIPCHK(hipEventRecord(e0, st));
                 HIPCHK(wsx_launch_fill(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
                 HIPCHK(hipEventRecord(e1, st));
+                if (ci == 0 && n_work > 1 && !staggered) { // stagger the two streams by one fill
+                    staggered = true;
+                    HIPCHK(hipStreamWaitEvent(c->aux_stream, e1, 0));
+                }
                 HIPCHK(wsx_launch_traceback(pa, gvar[g].K, gvar[g].F, gvar[g].generic, st));
             }
             return WSX_SUCCESS;
@@ -601,7 +681,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 if (io.last_row)
                     HIPCHK(hipMemcpyAsync(io.last_row + (size_t)f * io.last_row_stride, d_lastrow,
                                           (size_t)cnt * io.last_row_stride * 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st)); // staging buffers are reused by the next chunk
             }
             continue;
         }
@@ -632,7 +711,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.fit_m = d_fitm;
         ma.rec = d_rec;
         ma.n_align = c->prm.reps_as_one ? d_nalign : nullptr;
-        ma.state_scratch = (int32_t *)c->reps.p;
+        ma.state_scratch = (int32_t *)W.reps.p;
         ma.max_states = c->max_states;
         ma.scr0 = d_scr0;
         ma.scr1 = d_scr1;
@@ -661,12 +740,16 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, d_tr2, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
             if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, d_resc_user, (size_t)ch.samples * 8, hipMemcpyDeviceToHost, st));
             if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, d_badmask, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
         }
     }
-    HIPCHK(hipEventRecord(c->ev_end, st));
+    if (n_work > 1) { // join: the handle's stream continues only after the internal stream has drained
+        HIPCHK(hipEventRecord(c->ev_join, c->aux_stream));
+        HIPCHK(hipStreamWaitEvent(main_st, c->ev_join, 0));
+    }
+    HIPCHK(hipEventRecord(c->ev_meta, main_st));
+    HIPCHK(hipEventRecord(c->ev_end, main_st));
     c->timing_valid = true;
-    if (host) HIPCHK(hipStreamSynchronize(st));
+    if (host) HIPCHK(hipStreamSynchronize(main_st));
     return WSX_SUCCESS;
 }
 
