@@ -11,6 +11,8 @@
  *   wsx_warp_batch       <->  WarpSTR.warp(signal, mask) -> WarpResult(trace)
  *                             src/caller/caller.py:189-193 (_calc_dtw_astates 198-245,
  *                             _backtracking 247-301)
+ *   wsx_prepare_signals  <->  Fast5.get_data_processed for every `saved` read (get_workload),
+ *                             src/schemas/fast5.py:45-57, src/caller/wrapper.py:44-54
  *   wsx_caller_create    <->  CallerWrapper.__init__ / init_pool: automata + config made
  *                             available to the workers, src/caller/wrapper.py:63-70,92-102
  *   wsx_automaton        <->  StateAutomata(states, endstate, mask), src/caller/automata.py:36-48
@@ -155,6 +157,24 @@ int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
 int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets,
                    const int32_t *automaton_id, int64_t n_reads, const uint8_t *mask, uint16_t *trace,
                    double *end_cost, double *last_row, int32_t last_row_stride, int32_t *status);
+
+/*
+ * Raw squiggles -> normalised STR segments (Fast5.get_data_processed, src/schemas/fast5.py:45-57; the per-read part of
+ * get_workload, src/caller/wrapper.py:44-54): spike removal in the raw int16 domain (brute_remove, fast5.py:90-101),
+ * MAD normalisation over the WHOLE read (normalize_signal_mad, 104-114), then the slice
+ * [seg_start[r] : seg_end[r] + 1] (overview.csv columns l_start_raw, r_end_raw).
+ *   raw            concatenated int16 raw signals of whole reads, in `mem`
+ *   raw_offsets    host int64[n_reads+1]
+ *   seg_start/end  host int64[n_reads] (inclusive end, as upstream)
+ *   spike_removal  0 = None, 1 = Brute (tr_calling_config.spike_removal; median3/median5 are not on the GPU)
+ *   signal_out     float64 output, concatenated by out_offsets (host int64[n_reads+1], lengths must equal the slice
+ *                  lengths); can be passed straight to wsx_call_batch with the same offsets
+ *   shift_scale    optional float64[2*n_reads] (shift, scale per read), in `mem`
+ * Synchronous.
+ */
+int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_t *raw_offsets, const int64_t *seg_start,
+                        const int64_t *seg_end, int64_t n_reads, int32_t spike_removal, double *signal_out,
+                        const int64_t *out_offsets, double *shift_scale);
 
 int wsx_caller_synchronize(wsx_caller *c);
 

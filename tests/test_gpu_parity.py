@@ -292,3 +292,34 @@ def test_mixed_loci_one_batch():
     # an empty batch is a no-op
     r0, _ = hip.call(np.zeros(0), np.zeros(1, np.int64), np.zeros(0, np.int32))
     assert len(r0) == 0
+
+
+def test_signal_loader_matches_reference_and_host():
+    """wsx_prepare_signals (spike removal, whole-read MAD normalisation, slice) against the vector recorded from the
+    upstream Fast5 code and against the host restatement on seeded raw reads; then straight into the caller."""
+    from warpstr_amd.signal_prep import process_raw
+    z = np.load('tests/golden/signal_prep.npz')
+    locus = synth.make_locus('(AGC)', 16, 5)
+    hip = HipCaller([locus.template, locus.reverse], [16, 16])
+    rng = np.random.default_rng(4)
+    raws, pos = [z['raw']], [(100, 3500)]
+    for k in range(12):
+        n = int(rng.integers(5, 30000))
+        raw = rng.normal(520, 70, size=n).astype(np.int16)
+        idx = rng.integers(0, n, size=max(1, n // 200))
+        raw[idx] = rng.choice([100, 1200, 30, 2500, 249, 1001], size=len(idx))
+        if k % 3 == 0 and n > 50:                       # runs of adjacent outliers, also at the very start / end
+            raw[10:14] = 1500
+            raw[0:3] = 2000
+            raw[n - 2:] = 10
+        raws.append(raw)
+        a = int(rng.integers(0, n))
+        pos.append((a, int(rng.integers(a, n + 50))))   # r_end may exceed the read (python slices clamp)
+    for mode in ('Brute', 'None'):
+        out, ooff, ss = hip.prepare_signals(raws, pos, mode)
+        for i, (raw, p) in enumerate(zip(raws, pos)):
+            ref = process_raw(raw, p, mode)
+            got = out[ooff[i]:ooff[i + 1]]
+            assert len(got) == len(ref) and np.array_equal(got, ref), (mode, i)
+    out, ooff, _ = hip.prepare_signals([z['raw']], [(0, len(z['raw']) - 1)], 'Brute')
+    assert np.array_equal(out, z['norm'])              # bit-identical to upstream normalize_signal_mad(brute_remove(raw))

@@ -16,7 +16,8 @@ WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
                7: 'segment_range'}
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
-           'wsx_caller_set_workspace_limit', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_caller_synchronize',
+           'wsx_caller_set_workspace_limit', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
+           'wsx_caller_synchronize',
            'wsx_caller_last_timing', 'wsx_caller_kernel_name']
 
 
@@ -70,6 +71,8 @@ def load():
                                    C.c_void_p]
     lib.wsx_warp_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.wsx_prepare_signals.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.wsx_caller_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_double)]
     _lib = lib

@@ -176,6 +176,30 @@ class HipCaller:
             out['last_row'] = last_row
         return out
 
+    def prepare_signals(self, raws: Sequence[np.ndarray], positions: Sequence[Sequence[int]], spike_removal: str = 'Brute'):
+        """wsx_prepare_signals on host buffers: raw int16 reads + (l_start_raw, r_end_raw) ->
+        (normalised float64 buffer, offsets) ready for call(); also returns the (shift, scale) table."""
+        if spike_removal not in ('None', 'Brute'):
+            raise ValueError('only spike_removal None / Brute run on the GPU (median3/median5: warpstr_amd.signal_prep)')
+        n = len(raws)
+        lens = np.fromiter((len(r) for r in raws), dtype=np.int64, count=n)
+        roff = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=roff[1:])
+        raw = np.empty(int(roff[-1]), np.int16)
+        for r, o in zip(raws, roff[:-1]):
+            raw[o:o + len(r)] = r
+        lo = np.array([p[0] for p in positions], np.int64)
+        hi = np.array([p[1] for p in positions], np.int64)
+        seglen = np.array([len(range(*slice(int(a), int(b) + 1).indices(int(L)))) for a, b, L in zip(lo, hi, lens)], np.int64)
+        ooff = np.zeros(n + 1, np.int64)
+        np.cumsum(seglen, out=ooff[1:])
+        out = np.empty(int(ooff[-1]), np.float64)
+        ss = np.zeros((n, 2), np.float64)
+        _lib.check(self.lib.wsx_prepare_signals(self.handle, _lib.WSX_MEM_HOST, _lib.ptr(raw), _lib.ptr(roff), _lib.ptr(lo),
+                                                _lib.ptr(hi), n, 1 if spike_removal == 'Brute' else 0, _lib.ptr(out),
+                                                _lib.ptr(ooff), _lib.ptr(ss)), 'wsx_prepare_signals')
+        return out, ooff, ss
+
     # ---- device-buffer entry point (pointers from torch tensors; asynchronous) -----------------
     def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
                     trace1_ptr: int = 0, trace2_ptr: int = 0):

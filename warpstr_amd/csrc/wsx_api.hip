@@ -79,18 +79,20 @@ struct wsx_caller {
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30;
     // workspace
-    // Two workspace sets: consecutive chunks alternate between the handle's stream and an internal one, so that
-    // the latency/bandwidth-bound stages of one chunk (traceback, run statistics, fit, ...) overlap the
-    // VALU-bound DP fill of the other.
+    // Up to WSX_MAX_STREAMS workspace sets: consecutive chunks rotate over the handle's stream and internal ones,
+    // so that the latency/bandwidth-bound stages of some chunks (traceback, run statistics, fit, ...) run under the
+    // VALU-bound DP fill of others.
     struct Work {
         DeviceBuf samples, reads, bp, stage_sig, stage_out, reps;
-    } work[2];
+    } work[WSX_MAX_STREAMS];
+    hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
+    hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
+    int n_streams = 4;
     DeviceBuf meta;
     void *pinned = nullptr; // host staging of offsets / automaton ids / launch order (caller buffers are not kept)
     size_t pinned_cap = 0;
     hipEvent_t ev_meta = nullptr; // recorded after the last metadata upload of a call
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
     size_t dp_events_used = 0;
@@ -292,8 +294,11 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipEventCreate(&c->ev_end));
     HIPCHK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
+    for (int w = 1; w < c->n_streams; w++) {
+        HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
+    }
     *out = c;
     return WSX_SUCCESS;
 }
@@ -303,15 +308,19 @@ void wsx_caller_destroy(wsx_caller *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    for (int w = 1; w < WSX_MAX_STREAMS; w++)
+        if (c->aux[w]) (void)hipStreamSynchronize(c->aux[w]);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (int w = 1; w < WSX_MAX_STREAMS; w++) {
+        if (c->aux[w]) (void)hipStreamDestroy(c->aux[w]);
+        if (c->ev_joins[w]) (void)hipEventDestroy(c->ev_joins[w]);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto &p : c->dp_events) {
@@ -344,6 +353,11 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 }
 
 } // extern "C"
+
+// accessors for the other translation units of the library (wsx_prep.hip)
+int wsx_internal_device(wsx_caller *c) { return c->device; }
+hipStream_t wsx_internal_stream(wsx_caller *c) { return c->stream; }
+void wsx_internal_set_error(const char *msg) { g_err = msg; }
 
 namespace {
 
@@ -459,7 +473,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // Big single-chunk batches are split so that chunks can overlap on the two streams (the latency-bound stages of
     // one chunk run under the VALU-bound fill of another).  WSX_CHUNKS overrides the split count (tuning knob).
     if (chunks.size() == 1 && n >= 4096) {
-        int want = n >= 32768 ? 4 : 2;
+        int want = n >= 32768 ? 2 * c->n_streams : (n >= 8192 ? c->n_streams : 2);
+        if (c->n_streams == 1) want = 1;
         if (const char *e = getenv("WSX_CHUNKS")) want = std::max(1, atoi(e));
         const ChunkPlan whole = chunks[0];
         chunks.clear();
@@ -490,7 +505,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
                        3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
-    const int n_work = chunks.size() > 1 ? 2 : 1;
+    const int n_work = (int)std::min<size_t>(chunks.size(), (size_t)c->n_streams);
     for (int w = 0; w < n_work; w++) {
         HIPCHK(c->work[w].samples.ensure(smp_bytes));
         HIPCHK(c->work[w].reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
@@ -511,17 +526,17 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     const hipStream_t main_st = c->stream;
     HIPCHK(hipEventRecord(c->ev_begin, main_st));
-    if (n_work > 1) { // fork: the internal stream starts after everything already queued on the handle's stream
+    if (n_work > 1) { // fork: the internal streams start after everything already queued on the handle's stream
         HIPCHK(hipEventRecord(c->ev_fork, main_st));
-        HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        for (int w = 1; w < n_work; w++) HIPCHK(hipStreamWaitEvent(c->aux[w], c->ev_fork, 0));
     }
     const int m = c->prm.min_values_per_state;
     int32_t *order = h_order;
-    bool staggered = false;
+    int staggered = 0;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const ChunkPlan &ch = chunks[ci];
         wsx_caller::Work &W = c->work[ci % n_work];
-        st = (ci % n_work) ? c->aux_stream : main_st;
+        st = (ci % n_work) ? c->aux[ci % n_work] : main_st;
         // this work set's staging buffers were last used two chunks ago on the same stream (host copies)
         if (host && ci >= (size_t)n_work) HIPCHK(hipStreamSynchronize(st));
         const int64_t f = ch.first, cnt = ch.count, boff = ch.base_off;
@@ -661,9 +676,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 HIPCHK(hipEventRecord(e0, st));
                 HIPCHK(wsx_launch_fill(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
                 HIPCHK(hipEventRecord(e1, st));
-                if (ci == 0 && n_work > 1 && !staggered) { // stagger the two streams by one fill
-                    staggered = true;
-                    HIPCHK(hipStreamWaitEvent(c->aux_stream, e1, 0));
+                if ((int)ci + 1 < n_work && staggered == (int)ci) { // stagger: stream w+1 starts after stream w's first fill
+                    staggered = (int)ci + 1;
+                    HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e1, 0));
                 }
                 HIPCHK(wsx_launch_traceback(pa, gvar[g].K, gvar[g].F, gvar[g].generic, st));
             }
@@ -743,8 +758,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         }
     }
     if (n_work > 1) { // join: the handle's stream continues only after the internal stream has drained
-        HIPCHK(hipEventRecord(c->ev_join, c->aux_stream));
-        HIPCHK(hipStreamWaitEvent(main_st, c->ev_join, 0));
+        for (int w = 1; w < n_work; w++) {
+            HIPCHK(hipEventRecord(c->ev_joins[w], c->aux[w]));
+            HIPCHK(hipStreamWaitEvent(main_st, c->ev_joins[w], 0));
+        }
     }
     HIPCHK(hipEventRecord(c->ev_meta, main_st));
     HIPCHK(hipEventRecord(c->ev_end, main_st));

@@ -13,7 +13,8 @@
 
 #define WSX_WAVE 64
 #define WSX_MAX_K 5      // states per lane in the register-resident DP kernel (S <= 320)
-#define WSX_MAX_F 4      // fan-in handled by the register-resident DP kernel
+#define WSX_MAX_F 4
+#define WSX_MAX_STREAMS 4 // chunks of a batch rotate over this many HIP streams      // fan-in handled by the register-resident DP kernel
 
 struct DevAutomaton {
     int32_t n_states;

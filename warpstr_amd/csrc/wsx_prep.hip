@@ -1,0 +1,344 @@
+// wsx_prep.hip -- raw squiggle -> normalised squiggle segment on the GPU (the loader that feeds the caller).
+//
+// Upstream: Fast5.get_data_processed (src/schemas/fast5.py:45-57) =
+//   remove_spikes 'Brute' (brute_remove, 90-101): samples > 1000 or < 250 at index > 2 are replaced, in index order
+//       and in the raw integer dtype, by np.median(out[i-2:i+3]) (already-replaced neighbours are used);
+//   normalize_signal_mad (104-114) over the WHOLE read: shift = mean(percentile(x, [46.5, 53.5])),
+//       scale = median(|x - shift|), norm = (x - shift) / scale;
+//   slice [l_start_raw : r_end_raw + 1].
+// NumPy semantics restated: percentile 'linear' (virtual index (n-1)q, lerp a + (b-a)g, or b - (b-a)(1-g) for g >= 0.5),
+// median = mean of the middle one/two order statistics, float -> int16 store truncates toward zero.
+//
+// Parallelisation
+//   copy_kernel       thread per sample
+//   spike_kernel      thread per sample; the thread at the head of a chain of outliers (gaps <= 2) fixes the whole chain
+//                     serially -- chains further apart than 2 samples never touch each other's windows
+//   hist_kernel       thread per sample: 65536-bin histogram per read (int16 has only 2^16 values, so every order
+//                     statistic of the read comes from counting; no sort)
+//   stats_kernel      wavefront per read: cumulative walk -> percentiles -> shift; two-sided merge around shift
+//                     -> median absolute deviation -> scale
+//   norm_kernel       thread per output sample: (x - shift) / scale of the requested slice
+#include <algorithm>
+#include <vector>
+
+#include "../../include/warpstr_hip.h"
+#include "wsx_device.h"
+
+namespace {
+
+struct PrepArgs {
+    const int16_t *raw;
+    int16_t *clean;
+    const int64_t *roff;   // device, [n+1], offsets of the chunk's reads into raw/clean (already chunk-relative)
+    const int64_t *seg_lo; // device, [n] l_start_raw
+    const int64_t *seg_hi; // device, [n] r_end_raw (inclusive)
+    const int64_t *ooff;   // device, [n+1] output offsets (chunk-relative)
+    uint32_t *hist;        // [n][65536]
+    double *shift_scale;   // [n][2]
+    double *out;
+    int n;
+    int max_len;
+};
+
+__device__ __forceinline__ bool is_outlier(const int16_t *raw, long long i)
+{
+    const int v = raw[i];
+    return i > 2 && (v > 1000 || v < 250);
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const long long len = a.roff[r + 1] - a.roff[r];
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256)
+        a.clean[a.roff[r] + i] = a.raw[a.roff[r] + i];
+}
+
+// np.median of 2..5 int16 values, stored back into int16 (truncation toward zero)
+__device__ int16_t median_small(int *w, int cnt)
+{
+    for (int x = 1; x < cnt; x++) { // insertion sort
+        const int key = w[x];
+        int y = x - 1;
+        while (y >= 0 && w[y] > key) {
+            w[y + 1] = w[y];
+            y--;
+        }
+        w[y + 1] = key;
+    }
+    double med;
+    if (cnt & 1) med = (0.0 + (double)w[cnt / 2]) / 1.0;
+    else med = ((0.0 + (double)w[cnt / 2 - 1]) + (double)w[cnt / 2]) / 2.0;
+    return (int16_t)med;
+}
+
+__global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const long long len = a.roff[r + 1] - a.roff[r];
+    const int16_t *raw = a.raw + a.roff[r];
+    int16_t *out = a.clean + a.roff[r];
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256) {
+        if (!is_outlier(raw, i)) continue;
+        // head of a chain: neither of the two previous samples is an outlier
+        if ((i >= 1 && is_outlier(raw, i - 1)) || (i >= 2 && is_outlier(raw, i - 2))) continue;
+        long long j = i;
+        while (true) {
+            int w[5];
+            int cnt = 0;
+            for (long long q = j - 2; q < j + 3 && q < len; q++) w[cnt++] = out[q];
+            out[j] = median_small(w, cnt);
+            if (j + 1 < len && is_outlier(raw, j + 1)) j = j + 1;
+            else if (j + 2 < len && is_outlier(raw, j + 2)) j = j + 2;
+            else break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const long long len = a.roff[r + 1] - a.roff[r];
+    const int16_t *x = a.clean + a.roff[r];
+    uint32_t *h = a.hist + (size_t)r * 65536;
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256)
+        atomicAdd(&h[(int)x[i] + 32768], 1u);
+}
+
+// value of the order statistic of rank k (0-based) given the histogram: smallest v with cum(v) > k
+// wave-cooperative; returns the same value in every lane
+__device__ int order_stat(const uint32_t *h, long long k, int lane)
+{
+    long long before = 0;
+    for (int base = 0; base < 65536; base += 64) {
+        const unsigned c = h[base + lane];
+        if (__ballot(c != 0) == 0ull) continue; // empty 64-bin group (most of the int16 range)
+        // inclusive scan over the wave
+        unsigned long long inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        const unsigned long long total = __shfl(inc, 63);
+        if (before + (long long)total > k) {
+            const unsigned long long hit = __ballot(before + (long long)inc > k);
+            return base + __builtin_ctzll(hit) - 32768;
+        }
+        before += (long long)total;
+    }
+    return 32767;
+}
+
+__device__ double np_lerp(double a, double b, double t)
+{
+    const double diff = b - a;
+    double r = a + diff * t;
+    if (t >= 0.5) r = b - diff * (1.0 - t);
+    return r;
+}
+
+__global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long n = a.roff[r + 1] - a.roff[r];
+    const uint32_t *h = a.hist + (size_t)r * 65536;
+    if (n <= 0) {
+        if (lane == 0) {
+            a.shift_scale[2 * r] = 0.0;
+            a.shift_scale[2 * r + 1] = 1.0;
+        }
+        return;
+    }
+    // np.percentile(x, (46.5, 53.5)), method 'linear'
+    double pct[2];
+    const double qs[2] = {46.5 / 100.0, 53.5 / 100.0};
+    for (int t = 0; t < 2; t++) {
+        const double vi = (double)(n - 1) * qs[t];
+        long long prev = (long long)floor(vi), next = prev + 1;
+        if (vi >= (double)(n - 1)) prev = next = n - 1;
+        if (vi < 0) prev = next = 0;
+        const double gamma = vi - floor(vi);
+        const double xa = (double)order_stat(h, prev, lane), xb = (double)order_stat(h, next, lane);
+        pct[t] = np_lerp(xa, xb, gamma);
+    }
+    const double shift = ((0.0 + pct[0]) + pct[1]) / 2.0;
+    // median(|x - shift|): walk outwards from shift over the occupied bins, smaller distance first
+    double scale = 0.0;
+    if (lane == 0) {
+        long long need_hi = n / 2, need_lo = (n % 2) ? n / 2 : n / 2 - 1; // ranks of the middle order statistics
+        int lo = (int)floor(shift), hi = lo + 1;                          // lo <= shift < hi
+        if (lo > 32767) { lo = 32767; hi = 32768; }
+        if (lo < -32769) { lo = -32769; hi = -32768; }
+        long long seen = 0;
+        double d_lo = 0.0, d_hi = 0.0;
+        bool got_lo = false, got_hi = false;
+        while (!got_hi && (lo >= -32768 || hi <= 32767)) {
+            const double dl = lo >= -32768 ? fabs((double)lo - shift) : __builtin_huge_val();
+            const double dh = hi <= 32767 ? fabs((double)hi - shift) : __builtin_huge_val();
+            int v;
+            double d;
+            if (dl <= dh) {
+                v = lo--;
+                d = dl;
+            } else {
+                v = hi++;
+                d = dh;
+            }
+            const long long c = h[v + 32768];
+            if (c == 0) continue;
+            if (!got_lo && seen + c > need_lo) {
+                d_lo = d;
+                got_lo = true;
+            }
+            if (seen + c > need_hi) {
+                d_hi = d;
+                got_hi = true;
+            }
+            seen += c;
+        }
+        scale = (n % 2) ? (0.0 + d_hi) / 1.0 : ((0.0 + d_lo) + d_hi) / 2.0;
+        a.shift_scale[2 * r] = shift;
+        a.shift_scale[2 * r + 1] = scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const long long len = a.roff[r + 1] - a.roff[r];
+    long long lo = a.seg_lo[r], hi = a.seg_hi[r] + 1; // python slice [lo:hi)
+    if (lo < 0) lo += len;
+    if (lo < 0) lo = 0;
+    if (lo > len) lo = len;
+    if (hi < 0) hi += len;
+    if (hi < 0) hi = 0;
+    if (hi > len) hi = len;
+    const long long cnt = a.ooff[r + 1] - a.ooff[r]; // == max(hi - lo, 0), computed by the host the same way
+    const double shift = a.shift_scale[2 * r], scale = a.shift_scale[2 * r + 1];
+    const int16_t *x = a.clean + a.roff[r] + lo;
+    double *out = a.out + a.ooff[r];
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.y * 256)
+        out[i] = ((double)x[i] - shift) / scale;
+}
+
+} // namespace
+
+int wsx_internal_device(wsx_caller *c);
+hipStream_t wsx_internal_stream(wsx_caller *c);
+void wsx_internal_set_error(const char *msg);
+
+#define PCHK(expr)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            char b_[512];                                                                                \
+            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            wsx_internal_set_error(b_);                                                                  \
+            for (void *p_ : to_free) (void)hipFree(p_);                                                  \
+            return WSX_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_t *raw_offsets,
+                                   const int64_t *seg_start, const int64_t *seg_end, int64_t n_reads, int32_t spike_removal,
+                                   double *signal_out, const int64_t *out_offsets, double *shift_scale)
+{
+    std::vector<void *> to_free;
+    if (!c || !raw_offsets || !seg_start || !seg_end || !out_offsets || n_reads < 0 || (n_reads > 0 && (!raw || !signal_out))) {
+        wsx_internal_set_error("wsx_prepare_signals: null argument");
+        return WSX_ERR_INVALID;
+    }
+    if (spike_removal != 0 && spike_removal != 1) {
+        wsx_internal_set_error("spike_removal: only None (0) and Brute (1) run on the GPU; median3/median5 are host-side");
+        return WSX_ERR_UNSUPPORTED;
+    }
+    if (mem != WSX_MEM_HOST && mem != WSX_MEM_DEVICE) {
+        wsx_internal_set_error("mem must be WSX_MEM_HOST or WSX_MEM_DEVICE");
+        return WSX_ERR_INVALID;
+    }
+    for (int64_t r = 0; r < n_reads; r++) {
+        const int64_t len = raw_offsets[r + 1] - raw_offsets[r];
+        int64_t lo = seg_start[r], hi = seg_end[r] + 1;
+        if (len < 0) {
+            wsx_internal_set_error("raw_offsets must be non-decreasing");
+            return WSX_ERR_INVALID;
+        }
+        if (lo < 0) lo += len;
+        lo = std::min(std::max<int64_t>(lo, 0), len);
+        if (hi < 0) hi += len;
+        hi = std::min(std::max<int64_t>(hi, 0), len);
+        if (out_offsets[r + 1] - out_offsets[r] != std::max<int64_t>(hi - lo, 0)) {
+            wsx_internal_set_error("out_offsets do not match the slices [l_start_raw : r_end_raw + 1]");
+            return WSX_ERR_INVALID;
+        }
+    }
+    if (n_reads == 0) return WSX_SUCCESS;
+    PCHK(hipSetDevice(wsx_internal_device(c)));
+    hipStream_t st = wsx_internal_stream(c);
+    const bool host = mem == WSX_MEM_HOST;
+    const int64_t chunk_reads = 4096; // 1 GiB of histograms
+    uint32_t *d_hist = nullptr;
+    PCHK(hipMalloc((void **)&d_hist, (size_t)std::min<int64_t>(n_reads, chunk_reads) * 65536 * 4));
+    to_free.push_back(d_hist);
+    for (int64_t f = 0; f < n_reads; f += chunk_reads) {
+        const int64_t cnt = std::min(chunk_reads, n_reads - f);
+        const int64_t rbase = raw_offsets[f], rsz = raw_offsets[f + cnt] - rbase;
+        const int64_t obase = out_offsets[f], osz = out_offsets[f + cnt] - obase;
+        std::vector<int64_t> h_roff(cnt + 1), h_ooff(cnt + 1);
+        int64_t max_len = 0;
+        for (int64_t r = 0; r <= cnt; r++) {
+            h_roff[r] = raw_offsets[f + r] - rbase;
+            h_ooff[r] = out_offsets[f + r] - obase;
+            if (r < cnt) max_len = std::max(max_len, raw_offsets[f + r + 1] - raw_offsets[f + r]);
+        }
+        int16_t *d_raw = nullptr, *d_clean = nullptr;
+        int64_t *d_meta = nullptr;
+        double *d_ss = nullptr, *d_out = nullptr;
+        std::vector<void *> chunk_free;
+        auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
+            if (e == hipSuccess) {
+                chunk_free.push_back(*p);
+                to_free.push_back(*p);
+            }
+            return e;
+        };
+        if (host) {
+            PCHK(alloc((void **)&d_raw, (size_t)rsz * 2));
+            PCHK(hipMemcpyAsync(d_raw, raw + rbase, (size_t)rsz * 2, hipMemcpyHostToDevice, st));
+            PCHK(alloc((void **)&d_out, (size_t)osz * 8));
+        } else {
+            d_raw = const_cast<int16_t *>(raw) + rbase;
+            d_out = signal_out + obase;
+        }
+        PCHK(alloc((void **)&d_clean, (size_t)rsz * 2));
+        PCHK(alloc((void **)&d_meta, (size_t)(4 * cnt + 2) * 8));
+        PCHK(alloc((void **)&d_ss, (size_t)cnt * 16));
+        int64_t *d_roff = d_meta, *d_ooff = d_meta + cnt + 1, *d_lo = d_ooff + cnt + 1, *d_hi = d_lo + cnt;
+        PCHK(hipMemcpyAsync(d_roff, h_roff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        PCHK(hipMemcpyAsync(d_ooff, h_ooff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        PCHK(hipMemcpyAsync(d_lo, seg_start + f, cnt * 8, hipMemcpyHostToDevice, st));
+        PCHK(hipMemcpyAsync(d_hi, seg_end + f, cnt * 8, hipMemcpyHostToDevice, st));
+        PCHK(hipMemsetAsync(d_hist, 0, (size_t)cnt * 65536 * 4, st));
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_ss, d_out, (int)cnt, (int)max_len};
+        const unsigned gy = (unsigned)std::min<int64_t>(std::max<int64_t>((max_len + 255) / 256, 1), 4096);
+        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        if (spike_removal == 1) hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stats_kernel, dim3((unsigned)cnt), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(norm_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        PCHK(hipGetLastError());
+        if (host) PCHK(hipMemcpyAsync(signal_out + obase, d_out, (size_t)osz * 8, hipMemcpyDeviceToHost, st));
+        if (shift_scale) {
+            PCHK(hipMemcpyAsync(shift_scale + 2 * f, d_ss, (size_t)cnt * 16, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+        }
+        PCHK(hipStreamSynchronize(st)); // chunk buffers are freed below
+        for (void *p : chunk_free) {
+            (void)hipFree(p);
+            to_free.erase(std::find(to_free.begin(), to_free.end(), p));
+        }
+    }
+    (void)hipFree(d_hist);
+    return WSX_SUCCESS;
+}
