@@ -97,10 +97,16 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    # one process per GPU; WARPSTR_BENCH_BACKEND=gloo lets the multi-rank logic be exercised on a 1-GPU box
+    backend = os.environ.get('WARPSTR_BENCH_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count() if backend != 'nccl' else local
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from warpstr_amd import _lib
     from warpstr_amd.caller import HipCaller
@@ -115,6 +121,9 @@ def main():
 
     def step():
         hip.call_device(signal.data_ptr(), offsets, aut, results.data_ptr())
+        if world > 1 and backend != 'nccl':  # test path: CPU collective
+            torch.cuda.synchronize()
+            return gather_results(results.cpu(), world)
         return gather_results(results, world)
 
     for _ in range(args.warmup):
@@ -134,7 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = hip.last_timing()  # HIP events on the launch stream, last step
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -168,7 +177,7 @@ def main():
             'config': {'workload': f'BASELINE configs[2]: {n} reads/GPU x {T} samples, {PATTERN} flank {FLANK}, '
                                    f'S={locus.template.n_states}/{locus.reverse.n_states} states, both passes',
                        'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
-                       'results_gather': 'rccl all_gather' if world > 1 else 'none (1 GPU)'},
+                       'results_gather': (f'{backend} all_gather' if world > 1 else 'none (1 GPU)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
