@@ -323,3 +323,16 @@ def test_signal_loader_matches_reference_and_host():
             assert len(got) == len(ref) and np.array_equal(got, ref), (mode, i)
     out, ooff, _ = hip.prepare_signals([z['raw']], [(0, len(z['raw']) - 1)], 'Brute')
     assert np.array_equal(out, z['norm'])              # bit-identical to upstream normalize_signal_mad(brute_remove(raw))
+
+
+def test_large_automaton_and_long_read():
+    """Edges of the supported range: S = 490 > 320 takes the general DP kernel (LDS ring, 8 states per lane);
+    a 20 kSample read exercises many signal blocks, mask words and back-pointer words."""
+    big = synth.make_locus('(RY)', 110, 8)
+    assert big.template.n_states > 320
+    sigs, revs, _ = synth.batch(big, 3, 4500, 2, lo=3, hi=12)
+    _compare_with_oracle(big, 110, sigs, revs)
+    loc = synth.make_locus('(AGC)', 16, 3)
+    sigs, revs, _ = synth.batch(loc, 2, 20000, 4, lo=200, hi=400)
+    _, res, n_ok = _compare_with_oracle(loc, 16, sigs, revs)
+    assert n_ok == 2 and res['len2'].min() > 500
