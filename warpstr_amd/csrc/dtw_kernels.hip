@@ -32,6 +32,8 @@
 // Roofline: min-plus recurrence, no MFMA.  Per row and state (F = 2): 6 fp64 adds, 2 fp64 compares, 6 selects.
 // HBM traffic per read and pass: 8T (signal) + T*K*64*PB/8 (pointer scratch, written once, read sparsely by the
 // traceback) + 6*runs; the fill is bound by fp64 VALU issue (a wave64 fp64 op occupies a SIMD for 4 cycles).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "wsx_device.h"
@@ -473,6 +475,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
+    const uint64_t *pred4 = A.pred4;
+    const size_t stride = (size_t)K * 64;
     int j = A.endstate;
     int i = T - 1;
     int nr = 0;
@@ -480,7 +484,9 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
     while (true) {
         const uint32_t *col = bp + (size_t)(j >> 6) * 64 + (j & 63);
         int wi = i / R;
-        uint32_t wm = col[(size_t)wi * K * 64];
+        // two words per step (the current one and the one below) halve the dependent loads over runs of "stay"
+        uint32_t wm = col[(size_t)wi * stride];
+        uint32_t wn = wi > 0 ? col[(size_t)(wi - 1) * stride] : 0u;
         // keep rows <= i of this word
         if (ENC) {
             const int sh = (R - 1 - i % R) * PB; // bits below belong to later rows
@@ -491,7 +497,12 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
         }
         while (wm == 0 && wi > 0) {
             wi--;
-            wm = col[(size_t)wi * K * 64];
+            wm = wn;
+            if (wm == 0 && wi > 0) {
+                wi--;
+                wm = col[(size_t)wi * stride];
+                wn = wi > 0 ? col[(size_t)(wi - 1) * stride] : 0u;
+            }
         }
         int start = 0, ptr = 0;
         if (wm != 0) {
@@ -517,7 +528,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
         if (wm == 0) break;
         int back = m;
         if (maskw) back = ((maskw[start >> 5] >> (start & 31)) & 1u) ? m - 1 : m;
-        j = pred_idx[pred_ptr[j] + ptr - 1];
+        if (ENC) j = (int)((pred4[j] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
+        else j = pred_idx[pred_ptr[j] + ptr - 1];
         i = start - back;
         if (i < 0) break; // cannot happen: pointers are only set on rows >= m
     }
@@ -548,7 +560,15 @@ template <int K, int F>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
-    const size_t shmem = 4 * (2 * (K * 64 + 1) + 128) * sizeof(double);
+    size_t shmem = 4 * (2 * (K * 64 + 1) + 128) * sizeof(double);
+    // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
+    // kernels of other chunks that run beside the fill on other streams.
+    static const int cap_blocks = [] {
+        const char *e = getenv("WSX_FILL_BLOCKS_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
+    if (shmem > 64 * 1024) shmem = 64 * 1024;
     hipLaunchKernelGGL((dtw_fill_fast<K, F>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }

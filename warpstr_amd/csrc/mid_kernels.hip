@@ -39,6 +39,32 @@ struct LoadSqDev {
     }
 };
 template <class L>
+__device__ __forceinline__ double pw_block_inl(const L &ld, int o, int n) // n <= 128
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += ld(o + i);
+        return res;
+    }
+    double r0 = ld(o), r1 = ld(o + 1), r2 = ld(o + 2), r3 = ld(o + 3), r4 = ld(o + 4), r5 = ld(o + 5), r6 = ld(o + 6),
+           r7 = ld(o + 7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += ld(o + i);
+        r1 += ld(o + i + 1);
+        r2 += ld(o + i + 2);
+        r3 += ld(o + i + 3);
+        r4 += ld(o + i + 4);
+        r5 += ld(o + i + 5);
+        r6 += ld(o + i + 6);
+        r7 += ld(o + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += ld(o + i);
+    return res;
+}
+
+template <class L>
 __device__ __attribute__((noinline)) double pw_block(const L &ld, int o, int n) // n <= 128
 {
     if (n < 8) {
@@ -194,19 +220,39 @@ __device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
     return v;
 }
 
-// (1) alignment records: one per run (create_alignment, reps_as_one = False), caller.py:17-43,65-96
-__global__ __launch_bounds__(256) void run_stats_kernel(MidArgs a)
+// (1) alignment records: one per run (create_alignment, reps_as_one = False), caller.py:17-43,65-96.
+// A block handles 64 consecutive runs, i.e. one contiguous span of the signal: the span is loaded coalesced into LDS
+// (when it fits) and every thread then walks its own run there.
+#define RS_CAP 1024
+__global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
 {
+    __shared__ double buf[RS_CAP];
     const int lr = blockIdx.x;
     if (a.status[lr] != 0) return;
     const ReadView v = view(a, lr);
-    const int k = blockIdx.y * blockDim.x + threadIdx.x;
-    if (k >= v.n) return;
+    const int k0 = blockIdx.y * 64;
+    if (k0 >= v.n) return;
+    const int klast = (k0 + 64 < v.n ? k0 + 64 : v.n) - 1;
+    const int tid = threadIdx.x;
     const DevAutomaton &A = a.aut[a.aut_id[v.r]];
     const double *sig = a.signal + v.off;
+    const int s_lo = v.fstart(k0), s_hi = v.fend(klast);
+    const bool staged = (s_hi - s_lo) <= RS_CAP;
+    if (staged) {
+        for (int q = tid; q < s_hi - s_lo; q += 64) buf[q] = sig[s_lo + q];
+        __syncthreads();
+    }
+    const int k = k0 + tid;
+    if (k > klast) return;
     const int s0 = v.fstart(k), len = v.fend(k) - s0;
     double val, sd;
-    run_mean_std(sig, s0, len, val, sd);
+    if (staged && len <= 128) { // common case: straight-line LDS reads
+        const double *p = buf + (s0 - s_lo);
+        val = pw_block_inl(LoadPlain{p}, 0, len) / (double)len;
+        sd = sqrt(pw_block_inl(LoadSqDev{p, val}, 0, len) / (double)len);
+    } else {
+        run_mean_std(sig, s0, len, val, sd);
+    }
     if (a.prm.method_median) val = np_median(sig + s0, len);
     const double expd = A.value[v.fstate(k)];
     const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
@@ -656,7 +702,7 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     // a run spans >= m-1 samples (except possibly the first and last): bound on runs per read
     const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
     if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;

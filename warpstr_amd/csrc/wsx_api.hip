@@ -235,7 +235,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 delete c;
                 return WSX_ERR_INVALID;
             }
-        blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S);
+        blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
+                align_up(S * 8);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -265,6 +266,11 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         int32_t dummy = 0;
         D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
         D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
+        std::vector<uint64_t> p4(S, 0);
+        for (int j = 0; j < S; j++)
+            for (int e = A.pred_ptr[j], q = 0; e < A.pred_ptr[j + 1] && q < 4; e++, q++)
+                p4[j] |= (uint64_t)(uint16_t)A.pred_idx[e] << (16 * q);
+        D.pred4 = (const uint64_t *)put(p4.data(), (size_t)S * 8);
         c->host_aut.push_back(D);
         Variant v;
         v.K = (S + 63) / 64;

@@ -14,7 +14,7 @@
 #define WSX_WAVE 64
 #define WSX_MAX_K 5      // states per lane in the register-resident DP kernel (S <= 320)
 #define WSX_MAX_F 4
-#define WSX_MAX_STREAMS 4 // chunks of a batch rotate over this many HIP streams      // fan-in handled by the register-resident DP kernel
+#define WSX_MAX_STREAMS 8 // chunks of a batch rotate over this many HIP streams      // fan-in handled by the register-resident DP kernel
 
 struct DevAutomaton {
     int32_t n_states;
@@ -28,6 +28,7 @@ struct DevAutomaton {
     const int32_t *pred_ptr;
     const int32_t *pred_idx;
     const uint8_t *repeat_mask;
+    const uint64_t *pred4;  // per state: its first four predecessors, 16 bits each (one load in the traceback)
 };
 
 struct DevParams {
