@@ -336,3 +336,18 @@ def test_large_automaton_and_long_read():
     sigs, revs, _ = synth.batch(loc, 2, 20000, 4, lo=200, hi=400)
     _, res, n_ok = _compare_with_oracle(loc, 16, sigs, revs)
     assert n_ok == 2 and res['len2'].min() > 500
+
+
+def test_noise_free_reads_exercise_ties():
+    """sigma = 0: repeated k-mers give runs with exactly equal means (the stable sort's tie-break), zero standard
+    deviations (the t-test's 1e-7 guard) and exact ties between DP candidates (stay wins, first predecessor wins)."""
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 20, 4)
+    rng = np.random.default_rng(8)
+    sigs, revs = [], []
+    for i in range(12):
+        rev = bool(i % 2)
+        s, _ = synth.squiggle(locus, rev, 1600, rng, lo=6, hi=25, sigma=0.0 if i < 8 else 1e-3)
+        sigs.append(s)
+        revs.append(rev)
+    _, _, n_ok = _compare_with_oracle(locus, 20, sigs, revs)
+    assert n_ok >= 6

@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int R = 32 / PB;
     constexpr int EXW = K * 64 + 1; // export slots per buffer (+1: the +inf slot)
-    constexpr int WLDS = 2 * EXW + 128; // doubles of LDS per wave: two export buffers + two 64-sample signal blocks
+    constexpr int WLDS = 2 * EXW + 136; // doubles of LDS per wave: two export buffers + two 64-sample signal blocks
+                                        // (+8: samples 0..7 of the even block mirrored at 128..135, so that eight
+                                        // consecutive samples never wrap)
     extern __shared__ double lds[];
 
     const int lane = threadIdx.x & 63;
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     // same-address ds_read -- no VALU involved.  Row i consumes s_{i+1}; it is read one row early.
     auto clampi = [&](int x) { return x < T ? x : T - 1; };
     sb[lane] = sig[clampi(lane)];
+    if (lane < 8) sb[128 + lane] = sb[lane];
     double nxt = sig[clampi(64 + lane)];
     __builtin_amdgcn_wave_barrier();
     double s_even = 0.0, s_odd = 0.0; // s_q for the even / odd q most recently read
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
 
     for (int b = 0; b * 64 - 1 <= last; b++) {
         sb[((b + 1) & 1) * 64 + lane] = nxt; // block b+1 (row 64b+62 reads s_{64b+64} ahead)
+        if (((b + 1) & 1) == 0 && lane < 8) sb[128 + lane] = nxt;
         nxt = sig[clampi((b + 2) * 64 + lane)];
         __builtin_amdgcn_wave_barrier();
         const int base = b * 64 - 1;
@@ -278,13 +282,12 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
         }
 
         // one row, everything wave-uniform except the per-lane state
-        auto row = [&](auto par, auto forced, auto cut, auto msk, int i) {
+        // s_new = s_{i+2}, prefetched (parity of i) while the row consumes s_{i+1} (other parity)
+        auto row = [&](auto par, auto forced, auto cut, auto msk, int i, double s_new) {
             constexpr int PAR = decltype(par)::value;
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
-            // prefetch s_{i+2} (parity of i) while consuming s_{i+1} (other parity)
-            const double s_new = sb[(i + 2) & 127];
             const double snext = PAR ? s_even : s_odd;
             if (PAR) s_odd = s_new;
             else s_even = s_new;
@@ -300,18 +303,39 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
                 }
             }
         };
-        // rows [plo, phi) with constant compile-time flags, two rows per iteration (no register copies)
+        // rows [plo, phi) with constant compile-time flags.  Rows come two per iteration (the even/odd register roles
+        // then need no copies); for K <= 2, aligned groups of eight rows share ONE LDS address computation for their
+        // signal samples (immediate offsets 0..56 from it).
         auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
+            using P0 = std::integral_constant<int, 0>;
+            using P1 = std::integral_constant<int, 1>;
             int i = plo;
             if (i < phi && (i & 1)) {
-                row(std::integral_constant<int, 1>{}, forced, cut, msk, i);
+                row(P1{}, forced, cut, msk, i, sb[(i + 2) & 127]);
                 i++;
             }
-            for (; i + 1 < phi; i += 2) {
-                row(std::integral_constant<int, 0>{}, forced, cut, msk, i);
-                row(std::integral_constant<int, 1>{}, forced, cut, msk, i + 1);
+            if constexpr (K <= 2) {
+                for (; i + 1 < phi && (i & 7); i += 2) {
+                    row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
+                    row(P1{}, forced, cut, msk, i + 1, sb[(i + 3) & 127]);
+                }
+                for (; i + 8 <= phi; i += 8) {
+                    const double *sg = sb + ((i + 2) & 127); // <= 122: sg[0..7] stays inside the mirrored buffer
+                    row(P0{}, forced, cut, msk, i, sg[0]);
+                    row(P1{}, forced, cut, msk, i + 1, sg[1]);
+                    row(P0{}, forced, cut, msk, i + 2, sg[2]);
+                    row(P1{}, forced, cut, msk, i + 3, sg[3]);
+                    row(P0{}, forced, cut, msk, i + 4, sg[4]);
+                    row(P1{}, forced, cut, msk, i + 5, sg[5]);
+                    row(P0{}, forced, cut, msk, i + 6, sg[6]);
+                    row(P1{}, forced, cut, msk, i + 7, sg[7]);
+                }
             }
-            if (i < phi) row(std::integral_constant<int, 0>{}, forced, cut, msk, i);
+            for (; i + 1 < phi; i += 2) {
+                row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
+                row(P1{}, forced, cut, msk, i + 1, sb[(i + 3) & 127]);
+            }
+            if (i < phi) row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
         };
         // a phase, split into maximal runs of equal mask bit so that the row code is branch-free
         auto phase = [&](auto forced, auto cut, int plo, int phi) {
@@ -560,7 +584,7 @@ template <int K, int F>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
-    size_t shmem = 4 * (2 * (K * 64 + 1) + 128) * sizeof(double);
+    size_t shmem = 4 * (2 * (K * 64 + 1) + 136) * sizeof(double);
     // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
     // kernels of other chunks that run beside the fill on other streams.
     static const int cap_blocks = [] {

@@ -529,7 +529,9 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
     for (int kb = 0; kb < mfit; kb += 64) {
         const int k = kb + lane;
         const double xk = (k < mfit) ? cx[k] : 0.0;
-        int rank = 0;
+        // rank = #(x_q < x_k) + #(x_q == x_k, q < k).  Exact ties between run means are practically absent, so the hot
+        // loop only counts "<" and "<="; a lane that sees any tie besides itself recounts with the index tie-break.
+        int n_lt = 0, n_le = 0;
         for (int qb = 0; qb < mfit; qb += 512) {
             const int cnt = (mfit - qb) < 512 ? (mfit - qb) : 512;
             __builtin_amdgcn_wave_barrier();
@@ -537,9 +539,13 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
             __builtin_amdgcn_wave_barrier();
             for (int q = 0; q < cnt; q++) {
                 const double xq = xs[q]; // LDS broadcast
-                rank += (xq < xk) ? 1 : 0;
-                rank += (xq == xk && (qb + q) < k) ? 1 : 0;
+                n_lt += (xq < xk) ? 1 : 0;
+                n_le += (xq <= xk) ? 1 : 0;
             }
+        }
+        int rank = n_lt;
+        if (k < mfit && n_le - n_lt > 1) { // ties: stable order by original position
+            for (int q = 0; q < k; q++) rank += (cx[q] == xk) ? 1 : 0;
         }
         if (k < mfit) {
             fx[rank] = xk;
