@@ -183,8 +183,10 @@ def main():
                          'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
                          'reads_per_launch': reads_per_launch,
                          'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
-            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.8,
-                     'note': 'PMC: SQ_INSTS_VALU/row = 13.8, VALU active ~85% of SIMD cycles at ~1.93 GHz'},
+            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.05,
+                     'note': 'PMC: SQ_INSTS_VALU = 13.05 per row per wave (floor of this formulation: 12); the fill '
+                             'launches overlap other chunks\' kernels on 4 streams, so launch_ms is a co-scheduled '
+                             'duration (6.3-6.5 ms per 100k reads when the kernel runs alone)'},
             'dp_kernel_ms_per_step': tm['dp_kernel_ms'], 'device_ms_per_step': tm['total_ms'],
         }
         if world == 1 and not args.no_cpu_baseline:
