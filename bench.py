@@ -77,6 +77,24 @@ def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
             'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
 
 
+VALU_INSTS_PER_ROW = 13.05   # SQ_INSTS_VALU per DP row per wave (profiles/r01_pmc_valu_per_kernel.txt)
+N_SIMD, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 2.4e9, 1.93e9
+
+
+def valu_roofline(tm1, n, T):
+    """What actually bounds the fill: wave-level VALU instruction issue (every VALU op, fp64 or 32-bit, occupies a
+    SIMD for 4 cycles per wave64).  Measured on an extra single-stream step (HIP events around the fill launches)."""
+    launches = max(tm1['dp_launches'], 1)
+    ms = tm1['dp_kernel_ms'] / launches
+    rows = 2.0 * n * T / launches                      # wave-rows per launch (one wave per read)
+    achieved = rows * VALU_INSTS_PER_ROW / (ms * 1e-3)  # wave-instructions per second
+    peak = N_SIMD * CLK_MAX_HZ / 4.0
+    return {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'wave64 VALU instr/s',
+            'frac': achieved / peak, 'frac_at_observed_clock': achieved / (N_SIMD * CLK_OBSERVED_HZ / 4.0),
+            'launch_ms_alone': ms, 'launches': launches,
+            'note': 'peak = 1024 SIMDs x 2.4 GHz / 4 cycles; the chip holds ~1.93 GHz under this fp64 load (GRBM_GUI_ACTIVE)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -141,7 +159,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tm = hip.last_timing()  # HIP events on the launch stream, last step
+    tm = hip.last_timing()  # HIP events on the launch streams, last step
+    # untimed extra step on ONE stream: the fill kernel's duration when nothing runs beside it (VALU roofline)
+    hip.set_streams(1)
+    step()
+    torch.cuda.synchronize()
+    tm1 = hip.last_timing()
+    hip.set_streams(4)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,6 +207,7 @@ def main():
                          'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
                          'reads_per_launch': reads_per_launch,
                          'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
+            'valu_roofline': valu_roofline(tm1, n, T),
             'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.05,
                      'note': 'PMC: SQ_INSTS_VALU = 13.05 per row per wave (floor of this formulation: 12); the fill '
                              'launches overlap other chunks\' kernels on 4 streams, so launch_ms is a co-scheduled '

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 1
+#define WSX_ABI_VERSION 2
 
 /* function return codes */
 enum {
@@ -73,12 +73,14 @@ typedef struct wsx_automaton {
     int32_t n_states;           /* S */
     int32_t endstate;           /* StateAutomata.endstate */
     int32_t flank_length;       /* Locus.flank_length used to build it */
-    int32_t reserved;
+    int32_t reverse;            /* 1: sequences of this automaton are reverse-complemented (reverse-strand reads,
+                                   WarpSTR._get_sequence, src/caller/caller.py:187) */
     const double *value;        /* [S] State.value: expected normalised level */
     const int32_t *seq_idx;     /* [S] State.seq_idx */
     const int32_t *pred_ptr;    /* [S+1] CSR offsets of State.incoming */
     const int32_t *pred_idx;    /* [pred_ptr[S]] predecessor state ids, in `incoming` order */
     const uint8_t *repeat_mask; /* [S] StateAutomata.mask */
+    const uint8_t *last_base;   /* [S] ASCII of State.kmer[-1]; may be NULL (then no sequences can be requested) */
 } wsx_automaton;
 
 typedef struct wsx_params {
@@ -110,6 +112,8 @@ typedef struct wsx_traces {
     uint16_t *trace2;    /* state id per sample, alignment of the rescaled signal */
     double *rescaled;    /* rescale_signal(signal, alignment), caller.py:124 */
     uint8_t *badmask;    /* mask_bad_repeats(...)[2], caller.py:125-126 */
+    uint8_t *seq1;       /* CallerResult.seq as ASCII: read r occupies [offsets[r], offsets[r] + len1) */
+    uint8_t *seq2;       /* CallerResult.resc_seq as ASCII: [offsets[r], offsets[r] + len2) */
 } wsx_traces;
 
 typedef struct wsx_caller wsx_caller;
@@ -129,8 +133,11 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                       const wsx_params *params, void *stream);
 void wsx_caller_destroy(wsx_caller *c);
 
-/* Upper bound, in bytes, of the device workspace the handle may allocate (default 8 GiB). */
+/* Upper bound, in bytes, of the device workspace the handle may allocate (default 16 GiB). */
 int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
+
+/* Number of HIP streams big batches are spread over (1..8, default 4; 1 = everything on the handle's stream). */
+int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
 
 /*
  * Call a batch of reads: both alignments, rescaling and bad-repeat masking, per read.

@@ -31,13 +31,13 @@ def test_exports_match_header(lib):
     assert declared and sorted(_lib.EXPORTS) == declared
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.wsx_abi_version() == 1
+    assert lib.wsx_abi_version() == 2
 
 
 def test_struct_layouts():
-    assert C.sizeof(_lib.WsxAutomaton) == 56
+    assert C.sizeof(_lib.WsxAutomaton) == 64
     assert C.sizeof(_lib.WsxParams) == 32
-    assert C.sizeof(_lib.WsxTraces) == 32
+    assert C.sizeof(_lib.WsxTraces) == 48
     assert _lib.RESULT_DTYPE.itemsize == 56
     assert [_lib.RESULT_DTYPE.fields[k][1] for k in ('status', 'len1', 'len2', 'cost1', 'dtw_end_cost2')] == \
         [0, 4, 8, 24, 48]
@@ -56,7 +56,7 @@ def test_no_gpu_fails_loudly(lib):
     # and at the ABI level
     h = C.c_void_p()
     t = locus.template
-    bufs = [np.ascontiguousarray(t.value), t.seq_idx, t.pred_ptr, t.pred_idx, t.repeat_mask]
+    bufs = [np.ascontiguousarray(t.value), t.seq_idx, t.pred_ptr, t.pred_idx, t.repeat_mask, t.last_base]
     a = (_lib.WsxAutomaton * 1)(_lib.WsxAutomaton(t.n_states, t.endstate, 16, 0, *[_lib.ptr(b) for b in bufs]))
     p = _lib.WsxParams(4, 6, 0.5, 0.5, 0, 0)
     rc = lib.wsx_caller_create(C.byref(h), 0, C.byref(a), 1, C.byref(p), None)

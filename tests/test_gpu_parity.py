@@ -58,7 +58,7 @@ def test_call_matches_golden(case):
     n = int(z['n_reads'])
     aut = z['reverse'].astype(np.int32)
     sig, off = pack_signals([z[f'r{i}_signal'] for i in range(n)])
-    res, ex = hip.call(sig, off, aut, want_debug=True)
+    res, ex = hip.call(sig, off, aut, want_debug=True, want_seqs=True)
     for i in range(n):
         sl = slice(off[i], off[i + 1])
         assert res['status'][i] == 0
@@ -68,6 +68,9 @@ def test_call_matches_golden(case):
         assert np.array_equal(ex['trace2'][sl], z[f'r{i}_trace2'])
         seq, rseq = [str(s) for s in z[f'r{i}_seq']]
         assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
+        # sequences built on the device (flank stripping, reverse complement) == CallerResult.seq / .resc_seq
+        assert ex['seq1'][off[i]:off[i] + len(seq)].tobytes().decode() == seq
+        assert ex['seq2'][off[i]:off[i] + len(rseq)].tobytes().decode() == rseq
         tab = r if aut[i] else t
         assert sequence_from_trace(tab, fl, ex['trace1'][sl], bool(aut[i])) == seq
         assert sequence_from_trace(tab, fl, ex['trace2'][sl], bool(aut[i])) == rseq

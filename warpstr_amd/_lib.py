@@ -16,15 +16,15 @@ WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
                7: 'segment_range'}
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
-           'wsx_caller_set_workspace_limit', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
+           'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize',
            'wsx_caller_last_timing', 'wsx_caller_kernel_name']
 
 
 class WsxAutomaton(C.Structure):
-    _fields_ = [('n_states', C.c_int32), ('endstate', C.c_int32), ('flank_length', C.c_int32), ('reserved', C.c_int32),
+    _fields_ = [('n_states', C.c_int32), ('endstate', C.c_int32), ('flank_length', C.c_int32), ('reverse', C.c_int32),
                 ('value', C.c_void_p), ('seq_idx', C.c_void_p), ('pred_ptr', C.c_void_p), ('pred_idx', C.c_void_p),
-                ('repeat_mask', C.c_void_p)]
+                ('repeat_mask', C.c_void_p), ('last_base', C.c_void_p)]
 
 
 class WsxParams(C.Structure):
@@ -33,7 +33,8 @@ class WsxParams(C.Structure):
 
 
 class WsxTraces(C.Structure):
-    _fields_ = [('trace1', C.c_void_p), ('trace2', C.c_void_p), ('rescaled', C.c_void_p), ('badmask', C.c_void_p)]
+    _fields_ = [('trace1', C.c_void_p), ('trace2', C.c_void_p), ('rescaled', C.c_void_p), ('badmask', C.c_void_p),
+                ('seq1', C.c_void_p), ('seq2', C.c_void_p)]
 
 
 # numpy view of wsx_result
@@ -66,6 +67,7 @@ def load():
     lib.wsx_caller_destroy.argtypes = [C.c_void_p]
     lib.wsx_caller_destroy.restype = None
     lib.wsx_caller_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]
+    lib.wsx_caller_set_streams.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_caller_synchronize.argtypes = [C.c_void_p]
     lib.wsx_call_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]

@@ -88,7 +88,10 @@ class HipCaller:
 
     def __init__(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
-                 device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None):
+                 device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None,
+                 reverse_flags: Optional[Sequence[bool]] = None):
+        """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
+        default: odd positions (template, reverse, template, reverse, ...)."""
         self.lib = _lib.load()
         if self.lib.wsx_device_count() <= 0:
             raise RuntimeError('warpstr_amd: no HIP device visible; the caller has no CPU path')
@@ -98,12 +101,16 @@ class HipCaller:
         self.flank_lengths = [int(f) for f in flank_lengths]
         self._keep = []
         arr = (_lib.WsxAutomaton * len(self.automata))()
+        if reverse_flags is None:
+            reverse_flags = [bool(i & 1) for i in range(len(self.automata))]
+        self.reverse_flags = [bool(x) for x in reverse_flags]
         for i, (t, fl) in enumerate(zip(self.automata, self.flank_lengths)):
             bufs = [np.ascontiguousarray(t.value, np.float64), np.ascontiguousarray(t.seq_idx, np.int32),
                     np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32),
-                    np.ascontiguousarray(t.repeat_mask, np.uint8)]
+                    np.ascontiguousarray(t.repeat_mask, np.uint8), np.ascontiguousarray(t.last_base, np.uint8)]
             self._keep.append(bufs)
-            arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 0, *[_lib.ptr(b) for b in bufs])
+            arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if self.reverse_flags[i] else 0,
+                                       *[_lib.ptr(b) for b in bufs])
         prm = _lib.WsxParams(self.caller_config.min_values_per_state, self.caller_config.states_in_segment,
                              self.rescaler_config.threshold, self.rescaler_config.max_std,
                              1 if self.rescaler_config.method == 'median' else 0,
@@ -132,7 +139,7 @@ class HipCaller:
 
     # ---- host-buffer entry points -------------------------------------------------------------
     def call(self, signal: np.ndarray, offsets: np.ndarray, automaton_id: np.ndarray, want_traces: bool = False,
-             want_debug: bool = False):
+             want_debug: bool = False, want_seqs: bool = False):
         """wsx_call_batch on host buffers -> (results structured array, dict of optional per-sample outputs)."""
         signal = np.ascontiguousarray(signal, np.float64)
         offsets = np.ascontiguousarray(offsets, np.int64)
@@ -142,14 +149,18 @@ class HipCaller:
         results = np.zeros(n, dtype=_lib.RESULT_DTYPE)
         extra = {}
         tr = None
-        if want_traces or want_debug:
-            extra['trace1'] = np.zeros(len(signal), np.uint16)
-            extra['trace2'] = np.zeros(len(signal), np.uint16)
+        if want_traces or want_debug or want_seqs:
+            if want_traces or want_debug:
+                extra['trace1'] = np.zeros(len(signal), np.uint16)
+                extra['trace2'] = np.zeros(len(signal), np.uint16)
             if want_debug:
                 extra['rescaled'] = np.zeros(len(signal), np.float64)
                 extra['badmask'] = np.zeros(len(signal), np.uint8)
-            tr = _lib.WsxTraces(_lib.ptr(extra['trace1']), _lib.ptr(extra['trace2']), _lib.ptr(extra.get('rescaled')),
-                                _lib.ptr(extra.get('badmask')))
+            if want_seqs:
+                extra['seq1'] = np.zeros(len(signal), np.uint8)
+                extra['seq2'] = np.zeros(len(signal), np.uint8)
+            tr = _lib.WsxTraces(_lib.ptr(extra.get('trace1')), _lib.ptr(extra.get('trace2')), _lib.ptr(extra.get('rescaled')),
+                                _lib.ptr(extra.get('badmask')), _lib.ptr(extra.get('seq1')), _lib.ptr(extra.get('seq2')))
         _lib.check(self.lib.wsx_call_batch(self.handle, _lib.WSX_MEM_HOST, _lib.ptr(signal), _lib.ptr(offsets),
                                            _lib.ptr(automaton_id), n, _lib.ptr(results),
                                            C.byref(tr) if tr is not None else None), 'wsx_call_batch')
@@ -207,10 +218,13 @@ class HipCaller:
         automaton_id = np.ascontiguousarray(automaton_id, np.int32)
         tr = None
         if trace1_ptr or trace2_ptr:
-            tr = _lib.WsxTraces(C.c_void_p(trace1_ptr or None), C.c_void_p(trace2_ptr or None), None, None)
+            tr = _lib.WsxTraces(C.c_void_p(trace1_ptr or None), C.c_void_p(trace2_ptr or None), None, None, None, None)
         _lib.check(self.lib.wsx_call_batch(self.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(signal_ptr), _lib.ptr(offsets),
                                            _lib.ptr(automaton_id), len(automaton_id), C.c_void_p(results_ptr),
                                            C.byref(tr) if tr is not None else None), 'wsx_call_batch')
+
+    def set_streams(self, n: int):
+        _lib.check(self.lib.wsx_caller_set_streams(self.handle, n), 'wsx_caller_set_streams')
 
     def synchronize(self):
         _lib.check(self.lib.wsx_caller_synchronize(self.handle), 'wsx_caller_synchronize')
@@ -260,7 +274,7 @@ class CallerWrapper:
             return []
         signal, offsets = pack_signals([np.asarray(w.signal, dtype=np.float64) for w in workload])
         aut = np.array([1 if w.reverse else 0 for w in workload], dtype=np.int32)
-        res, extra = self.hip.call(signal, offsets, aut, want_traces=True)
+        res, extra = self.hip.call(signal, offsets, aut, want_seqs=True)
         out: List[CallerResult] = []
         for i, w in enumerate(workload):
             st = int(res['status'][i])
@@ -270,11 +284,8 @@ class CallerWrapper:
                     raise ReadCallError(msg)
                 out.append(CallerResult('', float('nan'), '', float('nan')))
                 continue
-            table = self.rev_sta if w.reverse else self.temp_sta
-            t1 = extra['trace1'][offsets[i]:offsets[i + 1]]
-            t2 = extra['trace2'][offsets[i]:offsets[i + 1]]
-            seq = sequence_from_trace(table, self.flank_length, t1, w.reverse)
-            rseq = sequence_from_trace(table, self.flank_length, t2, w.reverse)
-            assert len(seq) == res['len1'][i] and len(rseq) == res['len2'][i]
+            o = int(offsets[i])
+            seq = extra['seq1'][o:o + int(res['len1'][i])].tobytes().decode('ascii')
+            rseq = extra['seq2'][o:o + int(res['len2'][i])].tobytes().decode('ascii')
             out.append(CallerResult(seq=seq, cost=float(res['cost1'][i]), resc_seq=rseq, resc_cost=float(res['cost2'][i])))
         return out

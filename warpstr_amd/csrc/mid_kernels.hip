@@ -414,6 +414,30 @@ __global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
     }
 }
 
+// (2b) optional: the called sequence as ASCII (WarpSTR._get_sequence, caller.py:178-187): last base of every visited
+// state, flanks stripped with the reference's slice arithmetic, reverse-complemented for reverse-strand automata.
+__global__ __launch_bounds__(256) void sequence_kernel(MidArgs a)
+{
+    const int lr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (lr >= a.n_reads || a.status[lr] != 0) return;
+    const ReadView v = view(a, lr);
+    const DevAutomaton &A = a.aut[a.aut_id[v.r]];
+    int slo, shi;
+    py_slice((long long)A.flank_length - A.seq_idx[v.fstate(0)], -(long long)A.flank_length, v.n, &slo, &shi);
+    uint8_t *out = a.seq_out + v.off;
+    const int len = shi - slo;
+    for (int q = lane; q < len; q += 64) {
+        uint8_t b = A.last_base[v.fstate(slo + q)];
+        int pos = q;
+        if (A.reverse) {
+            pos = len - 1 - q;
+            b = b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b;
+        }
+        out[pos] = b;
+    }
+}
+
 // (4a) segment() slides two 3-sample windows over a chunk; the t-statistic at absolute sample p only depends on
 // sig[p-3..p+2], so it is computed once per position for the whole span of the chunks (calc_ttest, caller.py:347-354;
 // np.std(..)**2 squares the rooted value, sic).  Every block also clears its tile of the output mask.
@@ -710,6 +734,7 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+    if (a.seq_out) hipLaunchKernelGGL(sequence_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;
         hipLaunchKernelGGL(tstat_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);

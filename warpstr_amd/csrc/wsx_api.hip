@@ -98,6 +98,7 @@ struct wsx_caller {
     size_t dp_events_used = 0;
     bool timing_valid = false;
     int max_states = 0;
+    bool have_bases = true; // every automaton came with last_base
 };
 
 namespace {
@@ -236,7 +237,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 return WSX_ERR_INVALID;
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
-                align_up(S * 8);
+                align_up(S * 8) + align_up(S);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -259,13 +260,15 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         for (int j = 0; j < S; j++) mf = std::max(mf, A.pred_ptr[j + 1] - A.pred_ptr[j]);
         D.max_fanin = mf;
         D.seq_idx_last = A.seq_idx[S - 1];
-        D.seq_idx_first = A.seq_idx[0];
+        D.reverse = A.reverse ? 1 : 0;
         D.value = (const double *)put(A.value, (size_t)S * 8);
         D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
         D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
         int32_t dummy = 0;
         D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
         D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
+        D.last_base = A.last_base ? (const uint8_t *)put(A.last_base, (size_t)S) : nullptr;
+        if (!A.last_base) c->have_bases = false;
         std::vector<uint64_t> p4(S, 0);
         for (int j = 0; j < S; j++)
             for (int e = A.pred_ptr[j], q = 0; e < A.pred_ptr[j + 1] && q < 4; e++, q++)
@@ -340,6 +343,20 @@ int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes)
 {
     if (!c || bytes < (64ull << 20)) return WSX_ERR_INVALID;
     c->ws_limit = bytes;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams)
+{
+    if (!c || n_streams < 1 || n_streams > WSX_MAX_STREAMS) return WSX_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    for (int w = 1; w < n_streams; w++) {
+        if (!c->aux[w]) {
+            HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
+        }
+    }
+    c->n_streams = n_streams;
     return WSX_SUCCESS;
 }
 
@@ -426,7 +443,12 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     if (n == 0) return WSX_SUCCESS;
     hipStream_t st = c->stream;
     const bool host = io.mem == WSX_MEM_HOST;
-    const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask);
+    const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
+                                      io.traces.seq1 || io.traces.seq2);
+    if (full && (io.traces.seq1 || io.traces.seq2) && !c->have_bases) {
+        g_err = "sequences requested but an automaton was created without last_base";
+        return WSX_ERR_INVALID;
+    }
 
     // ---- metadata on the device: offsets, automaton ids, launch order ---------------------------
     // order: reads grouped by DP kernel variant, longest first inside a group (load balance)
@@ -525,7 +547,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     for (int w = 0; w < n_work; w++) HIPCHK(c->work[w].bp.ensure(bp_words * 4));
     for (int w = 0; w < n_work && host; w++) {
         HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
-        size_t so = align_up(S1 * 2) * 2 + align_up(S1 * 8) + align_up(S1) + align_up(R1 * 8) + align_up(R1 * 4) +
+        size_t so = align_up(S1 * 2) * 2 + align_up(S1 * 8) + 3 * align_up(S1) + align_up(R1 * 8) + align_up(R1 * 4) +
                     align_up(R1 * (size_t)std::max(io.last_row_stride, 1) * 8);
         HIPCHK(c->work[w].stage_out.ensure(so));
     }
@@ -577,7 +599,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         Carver oc(host ? W.stage_out.p : nullptr);
         uint16_t *d_tr1 = nullptr, *d_tr2 = nullptr;
         double *d_resc_user = nullptr, *d_endcost_user = nullptr, *d_lastrow = nullptr;
-        uint8_t *d_badmask = nullptr;
+        uint8_t *d_badmask = nullptr, *d_seq1 = nullptr, *d_seq2 = nullptr;
         int32_t *d_status_user = nullptr;
         wsx_result *d_results = nullptr;
         if (full) {
@@ -586,12 +608,16 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 if (io.traces.trace2) d_tr2 = oc.take<uint16_t>(S1);
                 if (io.traces.rescaled) d_resc_user = oc.take<double>(S1);
                 if (io.traces.badmask) d_badmask = oc.take<uint8_t>(S1);
+                if (io.traces.seq1) d_seq1 = oc.take<uint8_t>(S1);
+                if (io.traces.seq2) d_seq2 = oc.take<uint8_t>(S1);
                 d_results = d_results_ws;
             } else {
                 d_tr1 = io.traces.trace1 ? io.traces.trace1 + boff : nullptr;
                 d_tr2 = io.traces.trace2 ? io.traces.trace2 + boff : nullptr;
                 d_resc_user = io.traces.rescaled ? io.traces.rescaled + boff : nullptr;
                 d_badmask = io.traces.badmask ? io.traces.badmask + boff : nullptr;
+                d_seq1 = io.traces.seq1 ? io.traces.seq1 + boff : nullptr;
+                d_seq2 = io.traces.seq2 ? io.traces.seq2 + boff : nullptr;
                 d_results = io.results + f;
             }
         } else {
@@ -741,6 +767,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.badmask_bytes = d_badmask;
         ma.status = d_status;
         ma.end_cost = d_endcost;
+        ma.seq_out = d_seq1;
         ma.results = d_results;
         HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
         FitArgs fa{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, d_coef, d_status};
@@ -754,6 +781,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.pass = 2;
         ma.maskbits = nullptr;
         ma.badmask_bytes = nullptr;
+        ma.seq_out = d_seq2;
         HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
         if (host) {
             HIPCHK(hipMemcpyAsync(io.results + f, d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, st));
@@ -761,6 +789,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, d_tr2, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
             if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, d_resc_user, (size_t)ch.samples * 8, hipMemcpyDeviceToHost, st));
             if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, d_badmask, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
+            if (io.traces.seq1) HIPCHK(hipMemcpyAsync(io.traces.seq1 + boff, d_seq1, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
+            if (io.traces.seq2) HIPCHK(hipMemcpyAsync(io.traces.seq2 + boff, d_seq2, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
         }
     }
     if (n_work > 1) { // join: the handle's stream continues only after the internal stream has drained

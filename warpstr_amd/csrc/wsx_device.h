@@ -22,12 +22,13 @@ struct DevAutomaton {
     int32_t flank_length;
     int32_t max_fanin;
     int32_t seq_idx_last;   // seq_idx[S-1]
-    int32_t seq_idx_first;  // unused by kernels; kept for debugging
+    int32_t reverse;        // reverse-strand automaton: called sequences are reverse-complemented
     const double *value;
     const int32_t *seq_idx;
     const int32_t *pred_ptr;
     const int32_t *pred_idx;
     const uint8_t *repeat_mask;
+    const uint8_t *last_base; // ASCII of the k-mer's last base, or NULL
     const uint64_t *pred4;  // per state: its first four predecessors, 16 bits each (one load in the traceback)
 };
 
@@ -107,6 +108,7 @@ struct MidArgs {
     uint8_t *badmask_bytes;    // optional out (pass 1), per sample
     int32_t *status;           // per read (in/out)
     const double *end_cost;    // per read, from the DP pass
+    uint8_t *seq_out;          // optional: called sequence of this pass as ASCII (per-sample layout), or NULL
     // results
     void *results;             // wsx_result[] (per read)
 };
