@@ -36,66 +36,65 @@ def load_flanks(locus_path: str) -> Tuple[str, str, str, str]:
     return rows[0], rows[1], rows[2], rows[3]
 
 
-def append_results(seq_results: Sequence[Tuple[str, str]], cost_results: Sequence[Tuple[float, float]], df_overview):
-    fasta_lst, newcol, dbg1, dbg2, dbg3 = [], [], [], [], []
-    idx = 0
-    for row in df_overview.itertuples():
-        if row.saved:
-            newcol.append(len(seq_results[idx][1]))
-            dbg1.append(len(seq_results[idx][0]))
-            dbg2.append(cost_results[idx][0])
-            dbg3.append(cost_results[idx][1])
-            fasta_lst.append((row.Index, seq_results[idx][1], row.reverse))
-            idx += 1
-        else:
-            newcol.append(-1)
-            dbg1.append(-1)
-            dbg2.append(-1)
-            dbg3.append(-1)
-    return fasta_lst, newcol, dbg1, dbg2, dbg3
+def result_columns(df_overview, seq_results: Sequence[Tuple[str, str]], cost_results: Sequence[Tuple[float, float]]):
+    """Per-row values of the four step-3 columns: called reads in overview order, -1 for rows that were not `saved`
+    (src/caller/overview.py:57-73).  Also returns the (read, resc_seq, reverse) triples for the FASTA files."""
+    saved = np.asarray(df_overview['saved']).astype(bool)
+    n_saved = int(saved.sum())
+    if n_saved != len(seq_results) or n_saved != len(cost_results):
+        raise ValueError(f'{n_saved} saved reads in the overview but {len(seq_results)} results')
+    cols = {name: np.full(len(saved), -1, dtype=dt) for name, dt in
+            (('results', np.int64), ('orig', np.int64), ('dtw_cost1', np.float64), ('dtw_cost2', np.float64))}
+    where = np.flatnonzero(saved)
+    cols['results'][where] = [len(s[1]) for s in seq_results]
+    cols['orig'][where] = [len(s[0]) for s in seq_results]
+    cols['dtw_cost1'][where] = [c[0] for c in cost_results]
+    cols['dtw_cost2'][where] = [c[1] for c in cost_results]
+    names = df_overview.index.to_numpy()[where]
+    strands = np.asarray(df_overview['reverse']).astype(bool)[where]
+    fasta = [(str(nm), s[1], bool(rv)) for nm, s, rv in zip(names, seq_results, strands)]
+    return cols, fasta
 
 
-def write_results_to_fasta(fasta_lst, locus_path: str):
+def write_results_to_fasta(fasta, locus_path: str):
+    """predictions/sequences/{all,sequences_template,sequences_reverse}.fasta; record = '>id', sequence, blank line
+    (src/caller/overview.py:76-100)."""
     base = os.path.join(locus_path, PREDICTIONS_SUBDIR, 'sequences')
     os.makedirs(base, exist_ok=True)
-    targets = {'all.fasta': lambda rev: True, 'sequences_template.fasta': lambda rev: rev is False or rev == 0,
-               'sequences_reverse.fasta': lambda rev: bool(rev)}
-    for name, keep in targets.items():
-        with open(os.path.join(base, name), 'w') as f:
-            for fid, seq, rev in fasta_lst:
-                rev = bool(rev) if isinstance(rev, (np.bool_, bool, int, np.integer)) else rev
-                if name == 'all.fasta' or keep(rev):
-                    f.write('>' + fid + '\n' + seq + '\n\n')
+    selections = (('all.fasta', None), ('sequences_template.fasta', False), ('sequences_reverse.fasta', True))
+    for fname, strand in selections:
+        with open(os.path.join(base, fname), 'w') as f:
+            f.writelines(f'>{rid}\n{seq}\n\n' for rid, seq, rev in fasta if strand is None or rev == strand)
 
 
-def save_overview(overview_path, df_overview, newcol, dbg1, dbg2, dbg3):
-    prev = [c for c in df_overview.columns if c.startswith('result')]
-    df_overview.drop(columns=prev, inplace=True)
-    df_overview['results'] = newcol
-    df_overview['orig'] = dbg1
-    df_overview['dtw_cost1'] = dbg2
-    df_overview['dtw_cost2'] = dbg3
+def store_results(overview_path, df_overview, seq_results, cost_results, locus_path: str):
+    """Write the FASTA files and the overview with (re)placed `results, orig, dtw_cost1, dtw_cost2` columns; any older
+    column starting with 'result' is dropped first (src/caller/overview.py:48-54,103-115)."""
+    cols, fasta = result_columns(df_overview, seq_results, cost_results)
+    write_results_to_fasta(fasta, locus_path)
+    stale = [c for c in df_overview.columns if c.startswith('result')]
+    df_overview = df_overview.drop(columns=stale)
+    for name in ('results', 'orig', 'dtw_cost1', 'dtw_cost2'):
+        df_overview[name] = cols[name]
     df_overview.to_csv(overview_path)
     return df_overview
 
 
-def store_results(overview_path, df_overview, seq_results, cost_results, locus_path: str):
-    fasta_lst, newcol, dbg1, dbg2, dbg3 = append_results(seq_results, cost_results, df_overview)
-    write_results_to_fasta(fasta_lst, locus_path)
-    return save_overview(overview_path, df_overview, newcol, dbg1, dbg2, dbg3)
-
-
 def store_collapsed(results, units: List[str], rep_units: List[List[str]], reverse_lst: List[bool], locus_path: str):
-    preds = {}
-    for idx, unit in enumerate(units):
-        if len(results[0][idx]) > 1:
-            preds['main_' + rep_units[idx][0]] = np.array([np.sum(j[idx]) for j in results])
-            for idx2, k in enumerate(rep_units[idx][1:]):
-                preds['inter_' + k[len(rep_units[idx][0]):]] = np.array([j[idx][idx2 + 1] for j in results])
+    """predictions/complexSTR_analysis/complex_repeat_units.csv (src/caller/overview.py:11-34): one row per read;
+    a unit with alternatives gives `main_<first>` (all its counts summed) plus one `inter_<suffix>` column per further
+    alternative, a plain unit gives one column named after its bases; last column `reverse`."""
+    table = {}
+    for u, (unit, alts) in enumerate(zip(units, rep_units)):
+        counts = np.array([r[u] for r in results], dtype=np.int64).reshape(len(results), -1)
+        if counts.shape[1] > 1:
+            table['main_' + alts[0]] = counts.sum(axis=1)
+            for a_idx in range(1, len(alts)):
+                table['inter_' + alts[a_idx][len(alts[0]):]] = counts[:, a_idx]
         else:
-            preds[unit.strip('(').strip(')')] = np.array([j[idx][0] for j in results])
-    preds['reverse'] = reverse_lst
-    df = pd.DataFrame.from_dict(preds)
+            table[unit.strip('(').strip(')')] = counts[:, 0]
+    table['reverse'] = list(reverse_lst)
+    df = pd.DataFrame(table)
     out = os.path.join(locus_path, PREDICTIONS_SUBDIR, COMPLEX_SUBDIR)
     os.makedirs(out, exist_ok=True)
     df.to_csv(os.path.join(out, 'complex_repeat_units.csv'))
