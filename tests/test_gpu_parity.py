@@ -354,3 +354,46 @@ def test_noise_free_reads_exercise_ties():
         revs.append(rev)
     _, _, n_ok = _compare_with_oracle(locus, 20, sigs, revs)
     assert n_ok >= 6
+
+
+def test_main_wrapper_end_to_end(tmp_path):
+    """Step 3 as the pipeline sees it: overview.csv + flank file in, overview columns / FASTA / complex-unit CSV out
+    (src/caller/wrapper.py:17-41), then step 4 on the written overview.  Expected values come from the CPU oracle."""
+    import pandas as pd
+
+    from warpstr_amd.genotyper import run_genotyping_overview
+    from warpstr_amd.units import break_into_units, collapse_repeats
+    from warpstr_amd.wrapper import main_wrapper
+    pattern, fl = '(AGC)AACAGCCGCCAC(CGC)', 20
+    locus = synth.make_locus(pattern, fl, 77)
+    sigs, revs, _ = synth.batch(locus, 14, 1700, 5, lo=8, hi=14)
+    loc = tmp_path / 'HD'
+    (loc / 'expected_signals').mkdir(parents=True)
+    (loc / 'expected_signals' / 'sequences.csv').write_text(
+        'type,sequence\n' + ''.join(f'{k},{v}\n' for k, v in zip(
+            ['left_flank_template', 'right_flank_template', 'left_flank_reverse', 'right_flank_reverse'],
+            [locus.left_t, locus.right_t, locus.left_r, locus.right_r])))
+    names = [f'read{i:02d}' for i in range(len(sigs) + 2)]
+    saved = [1] * len(sigs) + [0, 0]
+    pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': list(revs) + [False, True], 'saved': saved,
+                  'l_start_raw': 0, 'r_end_raw': 0}).to_csv(loc / 'overview.csv', index=False)
+    store = {f'{n}.fast5': s for n, s in zip(names, sigs)}
+    df, dfc = main_wrapper(str(loc), pattern, fl, signal_loader=lambda path, a, b: store[path.split('/')[-1]])
+    oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+    out = pd.read_csv(loc / 'overview.csv')
+    _, ru, offs = break_into_units(pattern)
+    for i, s in enumerate(sigs):
+        o = oracle.call_read(oa[int(revs[i])], s)
+        assert o.status == 0
+        assert (out['results'][i], out['orig'][i]) == (o.len2, o.len1)
+        assert_close_rel(out['dtw_cost1'][i], o.cost1, COST_REL)
+        assert_close_rel(out['dtw_cost2'][i], o.cost2, COST_REL)
+    assert list(out['results'][-2:]) == [-1, -1]
+    fasta = (loc / 'predictions' / 'sequences' / 'all.fasta').read_text().split('\n\n')
+    assert len([r for r in fasta if r.strip()]) == len(sigs)
+    first = fasta[0].splitlines()
+    assert first[0] == '>read00' and len(first[1]) == out['results'][0]
+    assert dfc is not None and list(dfc.columns) == ['AGC', 'CGC', 'reverse']
+    assert collapse_repeats(first[1], ru, offs) == [[int(dfc['AGC'][0])], [int(dfc['CGC'][0])]]
+    gt = run_genotyping_overview(str(loc), random_state=0)
+    assert (loc / 'predictions' / 'alleles.csv').exists() and gt.first_allele > 0

@@ -90,3 +90,16 @@ def store_predictions(gt: Genotype, locus_path: str, gt_bc: Optional[Genotype] =
         if gt_bc:
             f.write(f'{gt_bc.first_allele},{gt_bc.first_allele_sz},{gt_bc.second_allele},{gt_bc.second_allele_sz}')
     return path
+
+
+def run_genotyping_overview(locus_path: str, overview=None, **kw) -> Genotype:
+    """Genotype a locus from its overview.csv (`results` of the `saved` reads) and write predictions/alleles.csv
+    (src/genotyper/genotyping.py:68-82,95-118)."""
+    if overview is None:
+        from .overview import load_overview
+        _, overview = load_overview(locus_path)
+    vals = [int(r.results) for r in overview.itertuples() if r.saved]
+    gt = run_genotyping(vals, **kw)
+    store_predictions(gt, locus_path)
+    print(f'Allele lengths as given by WarpSTR: {gt.alleles}')
+    return gt
