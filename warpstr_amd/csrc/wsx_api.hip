@@ -99,6 +99,8 @@ struct wsx_caller {
     bool timing_valid = false;
     int max_states = 0;
     bool have_bases = true; // every automaton came with last_base
+    std::vector<hipEvent_t> sched_events;
+    size_t sched_used = 0;
 };
 
 namespace {
@@ -332,6 +334,7 @@ void wsx_caller_destroy(wsx_caller *c)
 
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    for (auto &e : c->sched_events) (void)hipEventDestroy(e);
     for (auto &p : c->dp_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -540,10 +543,24 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         if (full && c->prm.reps_as_one)
             HIPCHK(c->work[w].reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
     }
-    // (off/R + lr + 1) * K*64 words, bounded by samples*maxbpw + reads*K*64*2
+    // back-pointer scratch: one region per distinct DP kernel variant ((off/R + lr + 1) * K*64 words each), so that
+    // launch groups of one chunk never share words (their fills and tracebacks may then be issued in any order)
+    std::vector<Variant> uvar;
+    std::vector<size_t> uoff;
     size_t bp_words = 0;
-    for (auto &v : c->variant)
-        bp_words = std::max(bp_words, (size_t)(S1 / v.R() + R1 + 2) * (size_t)(v.K * 64));
+    for (auto &v : c->variant) {
+        bool seen = false;
+        for (auto &u : uvar) seen = seen || u.same(v);
+        if (seen) continue;
+        uvar.push_back(v);
+        uoff.push_back(bp_words);
+        bp_words += align_up((size_t)(S1 / v.R() + R1 + 2) * (size_t)(v.K * 64), 64);
+    }
+    auto bp_offset = [&](const Variant &v) -> size_t {
+        for (size_t u = 0; u < uvar.size(); u++)
+            if (uvar[u].same(v)) return uoff[u];
+        return 0;
+    };
     for (int w = 0; w < n_work; w++) HIPCHK(c->work[w].bp.ensure(bp_words * 4));
     for (int w = 0; w < n_work && host; w++) {
         HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
@@ -554,192 +571,143 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     const hipStream_t main_st = c->stream;
     HIPCHK(hipEventRecord(c->ev_begin, main_st));
-    if (n_work > 1) { // fork: the internal streams start after everything already queued on the handle's stream
-        HIPCHK(hipEventRecord(c->ev_fork, main_st));
-        for (int w = 1; w < n_work; w++) HIPCHK(hipStreamWaitEvent(c->aux[w], c->ev_fork, 0));
-    }
     const int m = c->prm.min_values_per_state;
     int32_t *order = h_order;
-    int staggered = 0;
-    for (size_t ci = 0; ci < chunks.size(); ci++) {
-        const ChunkPlan &ch = chunks[ci];
-        wsx_caller::Work &W = c->work[ci % n_work];
-        st = (ci % n_work) ? c->aux[ci % n_work] : main_st;
-        // this work set's staging buffers were last used two chunks ago on the same stream (host copies)
-        if (host && ci >= (size_t)n_work) HIPCHK(hipStreamSynchronize(st));
-        const int64_t f = ch.first, cnt = ch.count, boff = ch.base_off;
+
+    // ---- per-chunk context: every device pointer, the launch groups, the stage arguments -------------------------
+    struct Ctx {
+        ChunkPlan ch;
+        wsx_caller::Work *W;
+        const double *d_sig;
+        double *d_resc, *d_resc_user, *d_endcost, *d_endcost_user, *d_lastrow, *d_coef;
+        uint16_t *d_tr1, *d_tr2;
+        uint8_t *d_badmask, *d_seq1, *d_seq2, *d_alg;
+        int32_t *d_status, *d_status_user, *d_nruns;
+        uint32_t *d_maskbits;
+        wsx_result *d_results;
+        std::vector<std::vector<int32_t>> groups;
+        std::vector<Variant> gvar;
+        std::vector<size_t> gpos;
+        PassArgs pa;
+        MidArgs ma;
+        FitArgs fa;
+        EvalArgs ea;
+    };
+    std::vector<Ctx> ctxs(chunks.size());
+
+    // Carve the work set of chunk ci, upload its launch order (and, for host buffers, its signal) on stream s.
+    auto prepare = [&](size_t ci, hipStream_t s) -> int {
+        Ctx &x = ctxs[ci];
+        x.ch = chunks[ci];
+        x.W = &c->work[ci % n_work];
+        wsx_caller::Work &W = *x.W;
+        const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
         Carver sc(W.samples.p);
-        double *d_resc = sc.take<double>(S1);
+        x.d_resc = sc.take<double>(S1);
         uint16_t *d_run_state = sc.take<uint16_t>(S1);
         int32_t *d_run_start = sc.take<int32_t>(S1);
         double *d_alv = sc.take<double>(S1), *d_ale = sc.take<double>(S1), *d_alc = sc.take<double>(S1);
-        uint8_t *d_alg = sc.take<uint8_t>(S1);
+        x.d_alg = sc.take<uint8_t>(S1);
         double *d_fx = sc.take<double>(S1), *d_fy = sc.take<double>(S1);
         double *d_scr0 = sc.take<double>(S1), *d_scr1 = sc.take<double>(S1), *d_scr2 = sc.take<double>(S1);
-        uint32_t *d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
+        x.d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
         Carver rcv(W.reads.p);
-        int32_t *d_nruns = rcv.take<int32_t>(R1);
-        int32_t *d_status = rcv.take<int32_t>(R1);
+        x.d_nruns = rcv.take<int32_t>(R1);
+        x.d_status = rcv.take<int32_t>(R1);
         int32_t *d_fitm = rcv.take<int32_t>(R1);
-        double *d_endcost = rcv.take<double>(R1);
-        double *d_coef = rcv.take<double>(R1 * 6);
+        x.d_endcost = rcv.take<double>(R1);
+        x.d_coef = rcv.take<double>(R1 * 6);
         MidRec *d_rec = rcv.take<MidRec>(R1);
         int32_t *d_nalign = rcv.take<int32_t>(R1);
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
 
-        // signal of this chunk
-        const double *d_sig;
         if (host) {
-            HIPCHK(hipMemcpyAsync(W.stage_sig.p, io.signal + boff, (size_t)ch.samples * 8, hipMemcpyHostToDevice, st));
-            d_sig = (const double *)W.stage_sig.p;
+            HIPCHK(hipMemcpyAsync(W.stage_sig.p, io.signal + boff, (size_t)x.ch.samples * 8, hipMemcpyHostToDevice, s));
+            x.d_sig = (const double *)W.stage_sig.p;
         } else {
-            d_sig = io.signal + boff;
+            x.d_sig = io.signal + boff;
         }
-        // user-visible per-sample / per-read outputs for this chunk (device pointers)
+        // user-visible per-sample / per-read outputs of this chunk (device pointers)
         Carver oc(host ? W.stage_out.p : nullptr);
-        uint16_t *d_tr1 = nullptr, *d_tr2 = nullptr;
-        double *d_resc_user = nullptr, *d_endcost_user = nullptr, *d_lastrow = nullptr;
-        uint8_t *d_badmask = nullptr, *d_seq1 = nullptr, *d_seq2 = nullptr;
-        int32_t *d_status_user = nullptr;
-        wsx_result *d_results = nullptr;
+        x.d_tr1 = x.d_tr2 = nullptr;
+        x.d_resc_user = x.d_endcost_user = x.d_lastrow = nullptr;
+        x.d_badmask = x.d_seq1 = x.d_seq2 = nullptr;
+        x.d_status_user = nullptr;
+        x.d_results = nullptr;
         if (full) {
             if (host) {
-                if (io.traces.trace1) d_tr1 = oc.take<uint16_t>(S1);
-                if (io.traces.trace2) d_tr2 = oc.take<uint16_t>(S1);
-                if (io.traces.rescaled) d_resc_user = oc.take<double>(S1);
-                if (io.traces.badmask) d_badmask = oc.take<uint8_t>(S1);
-                if (io.traces.seq1) d_seq1 = oc.take<uint8_t>(S1);
-                if (io.traces.seq2) d_seq2 = oc.take<uint8_t>(S1);
-                d_results = d_results_ws;
+                if (io.traces.trace1) x.d_tr1 = oc.take<uint16_t>(S1);
+                if (io.traces.trace2) x.d_tr2 = oc.take<uint16_t>(S1);
+                if (io.traces.rescaled) x.d_resc_user = oc.take<double>(S1);
+                if (io.traces.badmask) x.d_badmask = oc.take<uint8_t>(S1);
+                if (io.traces.seq1) x.d_seq1 = oc.take<uint8_t>(S1);
+                if (io.traces.seq2) x.d_seq2 = oc.take<uint8_t>(S1);
+                x.d_results = d_results_ws;
             } else {
-                d_tr1 = io.traces.trace1 ? io.traces.trace1 + boff : nullptr;
-                d_tr2 = io.traces.trace2 ? io.traces.trace2 + boff : nullptr;
-                d_resc_user = io.traces.rescaled ? io.traces.rescaled + boff : nullptr;
-                d_badmask = io.traces.badmask ? io.traces.badmask + boff : nullptr;
-                d_seq1 = io.traces.seq1 ? io.traces.seq1 + boff : nullptr;
-                d_seq2 = io.traces.seq2 ? io.traces.seq2 + boff : nullptr;
-                d_results = io.results + f;
+                x.d_tr1 = io.traces.trace1 ? io.traces.trace1 + boff : nullptr;
+                x.d_tr2 = io.traces.trace2 ? io.traces.trace2 + boff : nullptr;
+                x.d_resc_user = io.traces.rescaled ? io.traces.rescaled + boff : nullptr;
+                x.d_badmask = io.traces.badmask ? io.traces.badmask + boff : nullptr;
+                x.d_seq1 = io.traces.seq1 ? io.traces.seq1 + boff : nullptr;
+                x.d_seq2 = io.traces.seq2 ? io.traces.seq2 + boff : nullptr;
+                x.d_results = io.results + f;
             }
         } else {
             if (host) {
-                d_tr1 = oc.take<uint16_t>(S1);
-                if (io.end_cost) d_endcost_user = oc.take<double>(R1);
-                if (io.status) d_status_user = oc.take<int32_t>(R1);
-                if (io.last_row) d_lastrow = oc.take<double>(R1 * (size_t)io.last_row_stride);
+                x.d_tr1 = oc.take<uint16_t>(S1);
+                if (io.end_cost) x.d_endcost_user = oc.take<double>(R1);
+                if (io.status) x.d_status_user = oc.take<int32_t>(R1);
+                if (io.last_row) x.d_lastrow = oc.take<double>(R1 * (size_t)io.last_row_stride);
             } else {
-                d_tr1 = io.trace + boff;
-                d_endcost_user = io.end_cost ? io.end_cost + f : nullptr;
-                d_status_user = io.status ? io.status + f : nullptr;
-                d_lastrow = io.last_row ? io.last_row + (size_t)f * io.last_row_stride : nullptr;
+                x.d_tr1 = io.trace + boff;
+                x.d_endcost_user = io.end_cost ? io.end_cost + f : nullptr;
+                x.d_status_user = io.status ? io.status + f : nullptr;
+                x.d_lastrow = io.last_row ? io.last_row + (size_t)f * io.last_row_stride : nullptr;
             }
         }
 
-        // launch order of this chunk: group by variant, longest first
-        std::vector<std::vector<int32_t>> groups;
-        std::vector<Variant> gvar;
+        // launch order of this chunk: group by kernel variant, longest first (load balance)
         for (int64_t r = f; r < f + cnt; r++) {
             const Variant &v = c->variant[io.aut_id[r]];
             size_t g = 0;
-            for (; g < gvar.size(); g++)
-                if (gvar[g].same(v)) break;
-            if (g == gvar.size()) {
-                gvar.push_back(v);
-                groups.emplace_back();
+            for (; g < x.gvar.size(); g++)
+                if (x.gvar[g].same(v)) break;
+            if (g == x.gvar.size()) {
+                x.gvar.push_back(v);
+                x.groups.emplace_back();
             }
-            groups[g].push_back((int32_t)r);
+            x.groups[g].push_back((int32_t)r);
         }
         size_t pos = (size_t)f;
-        std::vector<size_t> gpos;
-        for (auto &g : groups) {
-            std::stable_sort(g.begin(), g.end(), [&](int32_t x, int32_t y) {
-                return (io.offsets[x + 1] - io.offsets[x]) > (io.offsets[y + 1] - io.offsets[y]);
+        for (auto &g : x.groups) {
+            std::stable_sort(g.begin(), g.end(), [&](int32_t p, int32_t q) {
+                return (io.offsets[p + 1] - io.offsets[p]) > (io.offsets[q + 1] - io.offsets[q]);
             });
-            gpos.push_back(pos);
+            x.gpos.push_back(pos);
             std::copy(g.begin(), g.end(), order + pos);
             pos += g.size();
         }
-        HIPCHK(hipMemcpyAsync(d_order + f, order + f, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_order + f, order + f, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
 
-        // optional input mask (warp-only entry)
-        const uint32_t *pass1_mask = nullptr;
-        if (!full && io.mask) {
-            const uint8_t *d_mask_bytes;
-            if (host) {
-                // reuse the alignment area as staging for the mask bytes
-                HIPCHK(hipMemcpyAsync(d_alg, io.mask + boff, (size_t)ch.samples, hipMemcpyHostToDevice, st));
-                d_mask_bytes = d_alg;
-            } else {
-                d_mask_bytes = io.mask + boff;
-            }
-            dim3 grid((unsigned)cnt, (ch.max_T / 32 + 1 + 63) / 64);
-            hipLaunchKernelGGL(pack_mask_kernel, grid, dim3(64), 0, st, d_mask_bytes, d_offsets, (int)f, boff, (int)cnt,
-                               d_maskbits);
-            HIPCHK(hipGetLastError());
-            pass1_mask = d_maskbits;
-        }
+        PassArgs &pa = x.pa;
+        pa = PassArgs{};
+        pa.aut = (const DevAutomaton *)c->aut_table.p;
+        pa.offsets = d_offsets;
+        pa.aut_id = d_autid;
+        pa.first_read = (int32_t)f;
+        pa.base_off = boff;
+        pa.bp = (uint32_t *)W.bp.p;
+        pa.run_state = d_run_state;
+        pa.run_start = d_run_start;
+        pa.n_runs = x.d_nruns;
+        pa.last_row_stride = io.last_row_stride;
+        pa.m = m;
 
-        auto launch_pass = [&](const double *sigp, const uint32_t *maskbits, uint16_t *trace, int check_status,
-                               double *end_cost, double *lastrow, int32_t *status) -> int {
-            for (size_t g = 0; g < groups.size(); g++) {
-                PassArgs pa{};
-                pa.aut = (const DevAutomaton *)c->aut_table.p;
-                pa.signal = sigp;
-                pa.offsets = d_offsets;
-                pa.aut_id = d_autid;
-                pa.order = d_order + gpos[g];
-                pa.n_launch = (int32_t)groups[g].size();
-                pa.first_read = (int32_t)f;
-                pa.base_off = boff;
-                pa.maskbits = maskbits;
-                pa.bp = (uint32_t *)W.bp.p;
-                pa.run_state = d_run_state;
-                pa.run_start = d_run_start;
-                pa.n_runs = d_nruns;
-                pa.trace = trace;
-                pa.end_cost = end_cost;
-                pa.last_row = lastrow;
-                pa.last_row_stride = io.last_row_stride;
-                pa.status = status;
-                pa.check_status = check_status;
-                pa.m = m;
-                hipEvent_t e0, e1;
-                int rc2 = get_event_pair(c, &e0, &e1);
-                if (rc2) return rc2;
-                HIPCHK(hipEventRecord(e0, st));
-                HIPCHK(wsx_launch_fill(pa, m, gvar[g].K, gvar[g].F, maskbits != nullptr, gvar[g].generic, st));
-                HIPCHK(hipEventRecord(e1, st));
-                if ((int)ci + 1 < n_work && staggered == (int)ci) { // stagger: stream w+1 starts after stream w's first fill
-                    staggered = (int)ci + 1;
-                    HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e1, 0));
-                }
-                HIPCHK(wsx_launch_traceback(pa, gvar[g].K, gvar[g].F, gvar[g].generic, st));
-            }
-            return WSX_SUCCESS;
-        };
-
-        if (!full) {
-            rc = launch_pass(d_sig, pass1_mask, d_tr1, 0, d_endcost_user ? d_endcost_user : d_endcost, d_lastrow,
-                             d_status_user ? d_status_user : d_status);
-            if (rc) return rc;
-            if (host) {
-                HIPCHK(hipMemcpyAsync(io.trace + boff, d_tr1, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
-                if (io.end_cost) HIPCHK(hipMemcpyAsync(io.end_cost + f, d_endcost_user, (size_t)cnt * 8, hipMemcpyDeviceToHost, st));
-                if (io.status) HIPCHK(hipMemcpyAsync(io.status + f, d_status_user, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
-                if (io.last_row)
-                    HIPCHK(hipMemcpyAsync(io.last_row + (size_t)f * io.last_row_stride, d_lastrow,
-                                          (size_t)cnt * io.last_row_stride * 8, hipMemcpyDeviceToHost, st));
-            }
-            continue;
-        }
-
-        // ---- pass 1 ----
-        rc = launch_pass(d_sig, nullptr, d_tr1, 0, d_endcost, nullptr, d_status);
-        if (rc) return rc;
-        MidArgs ma{};
+        MidArgs &ma = x.ma;
+        ma = MidArgs{};
         ma.aut = (const DevAutomaton *)c->aut_table.p;
         ma.prm = DevParams{c->prm.min_values_per_state, c->prm.states_in_segment, c->prm.threshold, c->prm.max_std,
                            c->prm.method_median, c->prm.reps_as_one};
-        ma.signal = d_sig;
         ma.offsets = d_offsets;
         ma.aut_id = d_autid;
         ma.n_reads = (int32_t)cnt;
@@ -747,12 +715,11 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.base_off = boff;
         ma.run_state = d_run_state;
         ma.run_start = d_run_start;
-        ma.n_runs = d_nruns;
-        ma.pass = 1;
+        ma.n_runs = x.d_nruns;
         ma.al_value = d_alv;
         ma.al_expected = d_ale;
         ma.al_cost = d_alc;
-        ma.al_good = d_alg;
+        ma.al_good = x.d_alg;
         ma.fit_x = d_fx;
         ma.fit_y = d_fy;
         ma.fit_m = d_fitm;
@@ -763,38 +730,164 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.scr0 = d_scr0;
         ma.scr1 = d_scr1;
         ma.scr2 = d_scr2;
-        ma.maskbits = d_maskbits;
-        ma.badmask_bytes = d_badmask;
-        ma.status = d_status;
-        ma.end_cost = d_endcost;
-        ma.seq_out = d_seq1;
-        ma.results = d_results;
-        HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
-        FitArgs fa{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, d_coef, d_status};
-        HIPCHK(wsx_launch_fit(fa, st));
-        EvalArgs ea{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_sig, d_coef, d_status, d_resc, d_resc_user};
-        HIPCHK(wsx_launch_eval(ea, ch.max_T, st));
-        // ---- pass 2 ----
-        rc = launch_pass(d_resc, d_maskbits, d_tr2, 1, d_endcost, nullptr, d_status);
-        if (rc) return rc;
-        ma.signal = d_resc;
+        ma.status = x.d_status;
+        ma.end_cost = x.d_endcost;
+        ma.results = x.d_results;
+        x.fa = FitArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, x.d_coef, x.d_status};
+        x.ea = EvalArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, x.d_sig, x.d_coef, x.d_status, x.d_resc, x.d_resc_user};
+        return WSX_SUCCESS;
+    };
+
+    // DP fill of one pass for every launch group of the chunk (timed with HIP events on the launching stream)
+    auto do_fill = [&](Ctx &x, const double *sigp, const uint32_t *maskbits, int check_status, double *end_cost,
+                       double *lastrow, int32_t *status, hipStream_t s) -> int {
+        for (size_t g = 0; g < x.groups.size(); g++) {
+            PassArgs pa = x.pa;
+            pa.signal = sigp;
+            pa.bp += bp_offset(x.gvar[g]);
+            pa.order = d_order + x.gpos[g];
+            pa.n_launch = (int32_t)x.groups[g].size();
+            pa.maskbits = maskbits;
+            pa.end_cost = end_cost;
+            pa.last_row = lastrow;
+            pa.status = status;
+            pa.check_status = check_status;
+            hipEvent_t e0, e1;
+            int rc2 = get_event_pair(c, &e0, &e1);
+            if (rc2) return rc2;
+            HIPCHK(hipEventRecord(e0, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, maskbits != nullptr, x.gvar[g].generic, s));
+            HIPCHK(hipEventRecord(e1, s));
+        }
+        return WSX_SUCCESS;
+    };
+    auto do_traceback = [&](Ctx &x, const uint32_t *maskbits, uint16_t *trace, int32_t *status, hipStream_t s) -> int {
+        for (size_t g = 0; g < x.groups.size(); g++) {
+            PassArgs pa = x.pa;
+            pa.bp += bp_offset(x.gvar[g]);
+            pa.order = d_order + x.gpos[g];
+            pa.n_launch = (int32_t)x.groups[g].size();
+            pa.maskbits = maskbits;
+            pa.trace = trace;
+            pa.status = status;
+            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].generic, s));
+        }
+        return WSX_SUCCESS;
+    };
+    // the four stages of a full call
+    auto stage_f1 = [&](Ctx &x, hipStream_t s) -> int {
+        return do_fill(x, x.d_sig, nullptr, 0, x.d_endcost, nullptr, x.d_status, s);
+    };
+    auto stage_m1 = [&](Ctx &x, hipStream_t s) -> int {
+        int rc2 = do_traceback(x, nullptr, x.d_tr1, x.d_status, s);
+        if (rc2) return rc2;
+        MidArgs ma = x.ma;
+        ma.signal = x.d_sig;
+        ma.pass = 1;
+        ma.maskbits = x.d_maskbits;
+        ma.badmask_bytes = x.d_badmask;
+        ma.seq_out = x.d_seq1;
+        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, s));
+        HIPCHK(wsx_launch_fit(x.fa, s));
+        HIPCHK(wsx_launch_eval(x.ea, x.ch.max_T, s));
+        return WSX_SUCCESS;
+    };
+    auto stage_f2 = [&](Ctx &x, hipStream_t s) -> int {
+        return do_fill(x, x.d_resc, x.d_maskbits, 1, x.d_endcost, nullptr, x.d_status, s);
+    };
+    auto stage_m2 = [&](Ctx &x, hipStream_t s) -> int {
+        int rc2 = do_traceback(x, x.d_maskbits, x.d_tr2, x.d_status, s);
+        if (rc2) return rc2;
+        MidArgs ma = x.ma;
+        ma.signal = x.d_resc;
         ma.pass = 2;
         ma.maskbits = nullptr;
         ma.badmask_bytes = nullptr;
-        ma.seq_out = d_seq2;
-        HIPCHK(wsx_launch_mid(ma, ch.max_T, st));
+        ma.seq_out = x.d_seq2;
+        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, s));
         if (host) {
-            HIPCHK(hipMemcpyAsync(io.results + f, d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, st));
-            if (io.traces.trace1) HIPCHK(hipMemcpyAsync(io.traces.trace1 + boff, d_tr1, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
-            if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, d_tr2, (size_t)ch.samples * 2, hipMemcpyDeviceToHost, st));
-            if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, d_resc_user, (size_t)ch.samples * 8, hipMemcpyDeviceToHost, st));
-            if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, d_badmask, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
-            if (io.traces.seq1) HIPCHK(hipMemcpyAsync(io.traces.seq1 + boff, d_seq1, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
-            if (io.traces.seq2) HIPCHK(hipMemcpyAsync(io.traces.seq2 + boff, d_seq2, (size_t)ch.samples, hipMemcpyDeviceToHost, st));
+            const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
+            const size_t ns = (size_t)x.ch.samples;
+            HIPCHK(hipMemcpyAsync(io.results + f, x.d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, s));
+            if (io.traces.trace1) HIPCHK(hipMemcpyAsync(io.traces.trace1 + boff, x.d_tr1, ns * 2, hipMemcpyDeviceToHost, s));
+            if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, x.d_tr2, ns * 2, hipMemcpyDeviceToHost, s));
+            if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, x.d_resc_user, ns * 8, hipMemcpyDeviceToHost, s));
+            if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, x.d_badmask, ns, hipMemcpyDeviceToHost, s));
+            if (io.traces.seq1) HIPCHK(hipMemcpyAsync(io.traces.seq1 + boff, x.d_seq1, ns, hipMemcpyDeviceToHost, s));
+            if (io.traces.seq2) HIPCHK(hipMemcpyAsync(io.traces.seq2 + boff, x.d_seq2, ns, hipMemcpyDeviceToHost, s));
         }
-    }
-    if (n_work > 1) { // join: the handle's stream continues only after the internal stream has drained
-        for (int w = 1; w < n_work; w++) {
+        return WSX_SUCCESS;
+    };
+    // the single stage of wsx_warp_batch (one DP + traceback, optional input mask)
+    auto stage_warp = [&](Ctx &x, hipStream_t s) -> int {
+        const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
+        const uint32_t *pass1_mask = nullptr;
+        if (io.mask) {
+            const uint8_t *d_mask_bytes;
+            if (host) { // the alignment area doubles as staging for the mask bytes
+                HIPCHK(hipMemcpyAsync(x.d_alg, io.mask + boff, (size_t)x.ch.samples, hipMemcpyHostToDevice, s));
+                d_mask_bytes = x.d_alg;
+            } else {
+                d_mask_bytes = io.mask + boff;
+            }
+            dim3 grid((unsigned)cnt, (x.ch.max_T / 32 + 1 + 63) / 64);
+            hipLaunchKernelGGL(pack_mask_kernel, grid, dim3(64), 0, s, d_mask_bytes, d_offsets, (int)f, boff, (int)cnt,
+                               x.d_maskbits);
+            HIPCHK(hipGetLastError());
+            pass1_mask = x.d_maskbits;
+        }
+        int32_t *status = x.d_status_user ? x.d_status_user : x.d_status;
+        int rc2 = do_fill(x, x.d_sig, pass1_mask, 0, x.d_endcost_user ? x.d_endcost_user : x.d_endcost, x.d_lastrow, status, s);
+        if (rc2) return rc2;
+        rc2 = do_traceback(x, pass1_mask, x.d_tr1, status, s);
+        if (rc2) return rc2;
+        if (host) {
+            HIPCHK(hipMemcpyAsync(io.trace + boff, x.d_tr1, (size_t)x.ch.samples * 2, hipMemcpyDeviceToHost, s));
+            if (io.end_cost) HIPCHK(hipMemcpyAsync(io.end_cost + f, x.d_endcost_user, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+            if (io.status) HIPCHK(hipMemcpyAsync(io.status + f, x.d_status_user, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+            if (io.last_row)
+                HIPCHK(hipMemcpyAsync(io.last_row + (size_t)f * io.last_row_stride, x.d_lastrow,
+                                      (size_t)cnt * io.last_row_stride * 8, hipMemcpyDeviceToHost, s));
+        }
+        return WSX_SUCCESS;
+    };
+    auto sched_event = [&](hipEvent_t *e) -> int {
+        if (c->sched_used == c->sched_events.size()) {
+            hipEvent_t ev;
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->sched_events.push_back(ev);
+        }
+        *e = c->sched_events[c->sched_used++];
+        return WSX_SUCCESS;
+    };
+    c->sched_used = 0;
+
+    {
+        // ---- chunks rotate over the streams, each chunk's stages in order on its stream, staggered by one fill --------
+        if (n_work > 1) {
+            HIPCHK(hipEventRecord(c->ev_fork, main_st));
+            for (int w = 1; w < n_work; w++) HIPCHK(hipStreamWaitEvent(c->aux[w], c->ev_fork, 0));
+        }
+        for (size_t ci = 0; ci < chunks.size(); ci++) {
+            Ctx &x = ctxs[ci];
+            st = (ci % n_work) ? c->aux[ci % n_work] : main_st;
+            // this work set's staging buffers were last used n_work chunks ago on the same stream (host copies)
+            if (host && ci >= (size_t)n_work) HIPCHK(hipStreamSynchronize(st));
+            if ((rc = prepare(ci, st))) return rc;
+            if (!full) {
+                if ((rc = stage_warp(x, st))) return rc;
+                continue;
+            }
+            if ((rc = stage_f1(x, st))) return rc;
+            if ((int)ci + 1 < n_work) { // stagger: the next stream starts after this chunk's first fill
+                hipEvent_t e;
+                if ((rc = sched_event(&e))) return rc;
+                HIPCHK(hipEventRecord(e, st));
+                HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e, 0));
+            }
+            if ((rc = stage_m1(x, st)) || (rc = stage_f2(x, st)) || (rc = stage_m2(x, st))) return rc;
+        }
+        for (int w = 1; w < n_work; w++) { // join: the handle's stream continues only after the internal ones drained
             HIPCHK(hipEventRecord(c->ev_joins[w], c->aux[w]));
             HIPCHK(hipStreamWaitEvent(main_st, c->ev_joins[w], 0));
         }
