@@ -45,6 +45,44 @@ def _worker(rank, world, port, lengths, out_dir):
     dist.destroy_process_group()
 
 
+class _FakeCaller:
+    """Stands in for HipCaller in this CPU test: a deterministic function of each read's samples."""
+
+    def call(self, sig, off, aut):
+        rec = np.zeros(len(aut), dtype=_lib.RESULT_DTYPE)
+        for i in range(len(aut)):
+            s = sig[off[i]:off[i + 1]]
+            rec['len2'][i] = len(s) + int(aut[i])
+            rec['cost2'][i] = float(s.sum())
+        return rec, {}
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from warpstr_amd.dist import call_sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    sigs = [rng.normal(size=int(n)) for n in rng.integers(50, 400, size=23)]
+    aut = rng.integers(0, 2, size=23)
+    full = call_sharded(_FakeCaller(), sigs, aut, world, rank)
+    np.save(os.path.join(out_dir, f'sharded_{rank}.npy'), full)
+    dist.destroy_process_group()
+
+
+def test_call_sharded_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    sigs = [rng.normal(size=int(n)) for n in rng.integers(50, 400, size=23)]
+    aut = rng.integers(0, 2, size=23)
+    for r in range(world):
+        got = np.load(os.path.join(tmp_path, f'sharded_{r}.npy'))
+        assert [int(v) for v in got['len2']] == [len(s) + int(a) for s, a in zip(sigs, aut)]
+        assert np.array_equal(got['cost2'], np.array([float(s.sum()) for s in sigs]))
+
+
 def test_shard_reads_partition():
     rng = np.random.default_rng(0)
     lengths = rng.integers(500, 5000, size=101)

@@ -61,3 +61,18 @@ def gather_results_ragged(local_records: np.ndarray, owned: np.ndarray, n_total:
         idx = np.ascontiguousarray(g[r, :k, itemsize:]).view(np.int64).reshape(-1)
         out[idx] = np.ascontiguousarray(g[r, :k, :itemsize]).view(local_records.dtype).reshape(-1)
     return out
+
+
+def call_sharded(caller, signals: Sequence[np.ndarray], automaton_id: Sequence[int], world: int, rank: int, device=None):
+    """Call a whole workload across `world` ranks (one process per GPU): every rank passes the SAME full workload,
+    calls only its own shard on its GPU (`caller` = this rank's HipCaller, or anything with a compatible `.call`),
+    and receives the complete result table in the original read order (what step 4 / the genotyper consumes).
+    The only communication is the all-gather of the 56-byte result records."""
+    from .caller import pack_signals
+    lengths = [len(s) for s in signals]
+    shards = shard_reads(lengths, world)
+    mine = shards[rank]
+    sig, off = pack_signals([signals[i] for i in mine])
+    aut = np.asarray(automaton_id, dtype=np.int32)[mine]
+    local, _ = caller.call(sig, off, aut)
+    return gather_results_ragged(local, mine, len(signals), world, device)
