@@ -397,3 +397,41 @@ def test_main_wrapper_end_to_end(tmp_path):
     assert collapse_repeats(first[1], ru, offs) == [[int(dfc['AGC'][0])], [int(dfc['CGC'][0])]]
     gt = run_genotyping_overview(str(loc), random_state=0)
     assert (loc / 'predictions' / 'alleles.csv').exists() and gt.first_allele > 0
+
+
+def test_baseline_full_size_recovers_planted_alleles():
+    """BASELINE configs[2] at its full size (100 000 reads x 2 000 samples, HD-style automaton, S <= 64), checked through
+    properties that do not need the oracle at that size: every read is called; the called allele length equals the
+    planted one (3*r1 + 12 + 3*r2 bases) for nearly all reads, as upstream achieves on such data (SURVEY 8c: 399/400);
+    reads that share a clean template and differ only in noise agree; the result is deterministic; and a
+    random sample of the batch equals the oracle."""
+    pattern, fl, T, n = '(AGC)AACAGCCGCCAC(CGC)', 19, 2000, 100000
+    locus = synth.make_locus(pattern, fl, 2024, max_states=64)
+    rng = np.random.default_rng(77)
+    tpl, trev, ttruth = [], [], []
+    for _ in range(512):
+        rev = bool(rng.random() < 0.5)
+        s, counts = synth.squiggle(locus, rev, T, rng, sigma=0.0)
+        tpl.append(s)
+        trev.append(rev)
+        ttruth.append(3 * counts[0] + 12 + 3 * counts[1])
+    tpl = np.stack(tpl)
+    idx = rng.integers(0, len(tpl), size=n)
+    sig = (tpl[idx] + 0.25 * rng.standard_normal((n, T))).reshape(-1)
+    aut = np.array(trev, dtype=np.int32)[idx]
+    truth = np.array(ttruth)[idx]
+    off = np.arange(n + 1, dtype=np.int64) * T
+    hip = HipCaller([locus.template, locus.reverse], [fl, fl], workspace_limit=64 << 30)
+    r0, _ = hip.call(sig, off, aut)
+    r1, _ = hip.call(sig, off, aut)
+    assert r0.tobytes() == r1.tobytes()                                   # deterministic, bit for bit
+    assert (r0['status'] == 0).all()
+    assert np.mean(r0['len2'] == truth) > 0.97
+    assert np.mean(np.abs(r0['len2'] - truth) <= 3) > 0.995              # misses are off by one repeat unit
+    assert np.isfinite(r0['cost2']).all() and (r0['cost2'] > 0).all() and (r0['cost2'] < 0.5).all()
+    oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+    for i in rng.integers(0, n, size=24):
+        o = oracle.call_read(oa[aut[i]], sig[off[i]:off[i + 1]])
+        assert o.status == 0 and (r0['len1'][i], r0['len2'][i]) == (o.len1, o.len2)
+        assert_close_rel(r0['cost2'][i], o.cost2, COST_REL)
+        assert_close_rel(r0['dtw_end_cost2'][i], o.dtw_end_cost2, COST_REL)
