@@ -120,8 +120,9 @@ def test_call_matches_oracle_seeded(pattern, fl, T, n):
     assert n_ok >= n // 2
 
 
-def test_generic_kernel_other_min_values_per_state():
-    """min_values_per_state != 4 takes the general DP kernel; median state values."""
+def test_other_min_values_per_state():
+    """min_values_per_state 3 and 5 run the register-resident kernel with a shorter / longer dwell pipeline,
+    2 takes the general DP kernel (LDS ring); median state values; other segment sizes."""
     locus = synth.make_locus('(AGC)', 20, 77)
     sigs, revs, _ = synth.batch(locus, 16, 1400, 7)
     for m, method, sis in [(3, 'median', 5), (5, 'mean', 6), (2, 'mean', 4)]:

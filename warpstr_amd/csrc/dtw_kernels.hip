@@ -12,13 +12,13 @@
 // first predecessor wins ties) because the re-computation is exact.
 //
 // Kernels
-//   dtw_fill_fast<K,F>          register-resident fill for min_values_per_state = 4: one 64-lane wavefront per
+//   dtw_fill_fast<M,K,F>        register-resident fill for min_values_per_state M in {3,4,5}: one 64-lane wavefront per
 //       read; state j lives in lane j%64, slot j/64 (K slots per lane); one row (= one signal sample) per
 //       step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
-//       g1,g2,g3 that runs one row AHEAD of the DP:
+//       g_1..g_{M-1} that runs one row AHEAD of the DP:
 //             after row i   g_s = D[i-s+1,j] + |s_{i-s+2}-v_j| + .. + |s_{i+1}-v_j|
-//       so g1 is the next row's stay candidate, and the value a successor needs at row i+2 is final at the end
-//       of row i:  E_j(i+2) = g3 (unmasked row) or g2 (masked row).  E values are exchanged through LDS (one
+//       so g_1 is the next row's stay candidate, and the value a successor needs at row i+2 is final at the end
+//       of row i:  E_j(i+2) = g_{M-1} (unmasked row) or g_{M-2} (masked row).  E values are exchanged through LDS (one
 //       8-byte slot per state, double buffered by row parity); a consumer's LDS reads for row i+1 are issued
 //       during row i, a full row before they are needed.  Absent predecessors point at a slot holding +inf.
 //       Back-pointers are packed PB bits per row per state into 32-bit words (R rows per word) and written
@@ -70,11 +70,12 @@ __device__ __forceinline__ ReadGeom geom(const PassArgs &a, int slot)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-resident fill (see file header).  M = 4.
+// Register-resident fill (see file header), for min_values_per_state M in {3, 4, 5}.
 // ------------------------------------------------------------------------------------------------
-template <int K, int F>
+template <int M, int K, int F>
 struct FillState {
-    double v[K], g1[K], g2[K], g3[K], acur[K], d[K]; // acur = s_i - v_j (signed; |.| is a free source modifier)
+    double v[K], acur[K], d[K]; // acur = s_i - v_j (signed; |.| is a free source modifier)
+    double g[K][M];             // g[k][s], s = 1..M-1: the dwell pipeline (g[k][0] unused); always indexed statically
     double e0[K][F], e1[K][F];                       // predecessor exports: row i uses e[i&1], loads e[(i+1)&1]
     int paddr[K][F];                                  // LDS double index of predecessor f's export slot
     uint32_t bpw[K];                                  // pointer bits of the current word, newest row in the low bits
@@ -113,8 +114,8 @@ __device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best
 //   end of row i : write E(i+2)
 // Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
 // reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
-template <int K, int F, bool MROW, int PAR, bool FORCED, bool CUT>
-__device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane, double snext)
+template <int M, int K, int F, bool MROW, int PAR, bool FORCED, bool CUT>
+__device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext)
 {
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int EXW = K * 64 + 1;
@@ -130,7 +131,7 @@ __device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane
         }
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        double best = st.g1[k];
+        double best = st.g[k][1];
         if (FORCED) {
             best = kInf;
             st.bpw[k] <<= PB;
@@ -154,21 +155,21 @@ __device__ __forceinline__ void dp_row(FillState<K, F> &st, double *ex, int lane
             }
         }
         const double an = snext - st.v[k];
-        const double n3 = add_abs(st.g2[k], an), n2 = add_abs(st.g1[k], an);
-        st.g3[k] = n3;
-        st.g2[k] = n2;
-        st.g1[k] = add_abs(best, an);
+#pragma unroll
+        for (int s = M - 1; s >= 2; s--) st.g[k][s] = add_abs(st.g[k][s - 1], an);
+        st.g[k][1] = add_abs(best, an);
         st.d[k] = best;
         st.acur[k] = an;
-        ex[wbuf + k * 64 + lane] = MROW ? n2 : n3; // row i+2 masked (back = 3): successors need g2, else g3
+        // row i+2 masked (back = M-1): successors need the (M-2)-deep sum, else the (M-1)-deep one
+        ex[wbuf + k * 64 + lane] = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int K, int F>
+template <int M, int K, int F>
 __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
 {
-    constexpr int M = 4;
+    static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int R = 32 / PB;
     constexpr int EXW = K * 64 + 1; // export slots per buffer (+1: the +inf slot)
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     const int nmw = cdiv(T, 32);
 
     // ---- per-state constants -----------------------------------------------------------------
-    FillState<K, F> st;
+    FillState<M, K, F> st;
     const long long boundary = (long long)A.flank_length - 10;
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
     long long cut_from_ll = 6 * boundary; // rows with i >= first_threshold and i > second_threshold
@@ -237,9 +238,9 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
         else if (j <= M && j < S) d0 = start_val + fabs(sig[j] - v0);
         st.d[k] = d0;
         st.acur[k] = s1 - st.v[k];
-        st.g1[k] = d0 + fabs(st.acur[k]);
-        st.g2[k] = kInf;
-        st.g3[k] = kInf;
+        st.g[k][1] = d0 + fabs(st.acur[k]);
+#pragma unroll
+        for (int q = 2; q < M; q++) st.g[k][q] = kInf;
         st.bpw[k] = 0;
         ex[0 * EXW + j] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
         ex[1 * EXW + j] = kInf;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
             const double snext = PAR ? s_even : s_odd;
             if (PAR) s_odd = s_new;
             else s_even = s_new;
-            dp_row<K, F, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
+            dp_row<M, K, F, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
             if ((i % R) == R - 1 || i == last) {
                 // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
                 const int wi = i / R;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
     }
 }
 
-template <int K, int F>
+template <int M, int K, int F>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
@@ -593,33 +594,48 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     }();
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
-    hipLaunchKernelGGL((dtw_fill_fast<K, F>), dim3(blocks), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((dtw_fill_fast<M, K, F>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
 
-template <int K>
+template <int M, int K>
 hipError_t launch_fill_f(const PassArgs &a, int F, hipStream_t s)
 {
     switch (F) {
-    case 2: return launch_fill<K, 2>(a, s);
-    case 3: return launch_fill<K, 3>(a, s);
-    case 4: return launch_fill<K, 4>(a, s);
+    case 2: return launch_fill<M, K, 2>(a, s);
+    case 3: return launch_fill<M, K, 3>(a, s);
+    case 4: return launch_fill<M, K, 4>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int M>
+hipError_t launch_fill_k(const PassArgs &a, int K, int F, hipStream_t s)
+{
+    switch (K) {
+    case 1: return launch_fill_f<M, 1>(a, F, s);
+    case 2: return launch_fill_f<M, 2>(a, F, s);
+    case 3: return launch_fill_f<M, 3>(a, F, s);
+    case 4: return launch_fill_f<M, 4>(a, F, s);
+    case 5: return launch_fill_f<M, 5>(a, F, s);
     }
     return hipErrorInvalidValue;
 }
 
 } // namespace
 
-bool wsx_fast_pass_supported(int m, int K, int F) { return m == 4 && K >= 1 && K <= WSX_MAX_K && F >= 1 && F <= WSX_MAX_F; }
+bool wsx_fast_pass_supported(int m, int K, int F)
+{
+    return m >= 3 && m <= 5 && K >= 1 && K <= WSX_MAX_K && F >= 1 && F <= WSX_MAX_F;
+}
 
 static int fast_f(int F) { return F <= 2 ? 2 : F; }
 
 const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic)
 {
     static thread_local char buf[64];
-    (void)m;
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d>", K, fast_f(F));
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d>", m, K, fast_f(F));
     (void)masked;
     return buf;
 }
@@ -633,14 +649,11 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, 
         hipLaunchKernelGGL(dtw_fill_generic, dim3(a.n_launch), dim3(64), shmem, s, a, K);
         return hipGetLastError();
     }
-    if (m != 4) return hipErrorInvalidValue;
     const int f = fast_f(F);
-    switch (K) {
-    case 1: return launch_fill_f<1>(a, f, s);
-    case 2: return launch_fill_f<2>(a, f, s);
-    case 3: return launch_fill_f<3>(a, f, s);
-    case 4: return launch_fill_f<4>(a, f, s);
-    case 5: return launch_fill_f<5>(a, f, s);
+    switch (m) {
+    case 3: return launch_fill_k<3>(a, K, f, s);
+    case 4: return launch_fill_k<4>(a, K, f, s);
+    case 5: return launch_fill_k<5>(a, K, f, s);
     }
     return hipErrorInvalidValue;
 }
