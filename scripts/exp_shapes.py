@@ -22,6 +22,7 @@ def run(name, pattern, fl, T, n, seed=1, max_states=None):
     sig, off = pack_signals(sigs)
     aut = np.array(revs, dtype=np.int32)
     hip = HipCaller([locus.template, locus.reverse], [fl, fl])
+    hip.set_streams(1)  # kernels one at a time: per-kernel durations are not inflated by overlap
     for _ in range(2):
         t0 = time.perf_counter()
         res, _ = hip.call(sig, off, aut)
