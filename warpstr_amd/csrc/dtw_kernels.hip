@@ -114,7 +114,9 @@ __device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best
 //   end of row i : write E(i+2)
 // Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
 // reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
-template <int M, int K, int F, bool MROW, int PAR, bool FORCED, bool CUT>
+// SPLIT: only slot 0 considers F predecessors per state, the other slots 2 (the host places every state with more
+// than two predecessors in slot 0; such states are few: loop entries of nested repeats, IUPAC alternatives).
+template <int M, int K, int F, bool SPLIT, bool MROW, int PAR, bool FORCED, bool CUT>
 __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext)
 {
     constexpr int PB = (F <= 2) ? 2 : 4;
@@ -125,6 +127,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
     for (int k = 0; k < K; k++)
 #pragma unroll
         for (int f = 0; f < F; f++) {
+            if (SPLIT && k > 0 && f >= 2) continue;
             const double e = ex[rbuf + st.paddr[k][f]];
             if (PAR) st.e0[k][f] = e;
             else st.e1[k][f] = e;
@@ -136,18 +139,25 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
             best = kInf;
             st.bpw[k] <<= PB;
         } else {
-            if (PB > F) st.bpw[k] <<= (PB - F);
+            const int Fk = (SPLIT && k > 0) ? 2 : F; // folds to a constant once the slot loop is unrolled
+            if (PB > Fk) st.bpw[k] <<= (PB - Fk);
             // candidates in the reference's order; bit f lands at position f of this row's field, so push the
             // highest predecessor first
             double cand[F], run[F + 1];
             run[0] = best;
 #pragma unroll
             for (int f = 0; f < F; f++) {
-                cand[f] = add_abs(PAR ? st.e1[k][f] : st.e0[k][f], st.acur[k]);
-                run[f + 1] = min_f64(run[f], cand[f]);
+                if (f < Fk) {
+                    cand[f] = add_abs(PAR ? st.e1[k][f] : st.e0[k][f], st.acur[k]);
+                    run[f + 1] = min_f64(run[f], cand[f]);
+                } else {
+                    cand[f] = kInf;
+                    run[f + 1] = run[f];
+                }
             }
 #pragma unroll
-            for (int f = F - 1; f >= 0; f--) push_lt(st.bpw[k], cand[f], run[f]);
+            for (int f = F - 1; f >= 0; f--)
+                if (f < Fk) push_lt(st.bpw[k], cand[f], run[f]);
             best = run[F];
             if (CUT) {
                 best = st.cutf[k] ? kInf : best;
@@ -166,7 +176,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int M, int K, int F>
+template <int M, int K, int F, bool SPLIT>
 __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
 {
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
@@ -209,17 +219,31 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     long long cut_from_ll = 6 * boundary; // rows with i >= first_threshold and i > second_threshold
     if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
     const int cut_from = cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll);
+    int sid[K]; // state handled at position k*64 + lane (-1: none)
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int j = k * 64 + lane;
-        const bool valid = j < S;
+        const int q = k * 64 + lane;
+        int j = q < S ? q : -1;
+        if (A.state_at) {
+            const int t = A.state_at[q];
+            j = t == 0xFFFF ? -1 : t;
+        }
+        sid[k] = j;
+        const bool valid = j >= 0;
         st.v[k] = valid ? A.value[j] : 0.0;
         st.cutf[k] = valid && ((long long)A.seq_idx[j] < after_repeat);
         st.cutclr[k] = st.cutf[k] ? ~((1u << PB) - 1u) : ~0u;
         const int pp = valid ? A.pred_ptr[j] : 0;
         const int nf = valid ? (A.pred_ptr[j + 1] - pp) : 0;
 #pragma unroll
-        for (int f = 0; f < F; f++) st.paddr[k][f] = (f < nf) ? A.pred_idx[pp + f] : (EXW - 1);
+        for (int f = 0; f < F; f++) {
+            int pa = EXW - 1; // the +inf slot
+            if (f < nf) {
+                const int p = A.pred_idx[pp + f];
+                pa = A.pos ? A.pos[p] : p;
+            }
+            st.paddr[k][f] = pa;
+        }
     }
     if (lane == 0) {
         ex[EXW - 1] = kInf;
@@ -232,18 +256,18 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     const double s1 = sig[1];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int j = k * 64 + lane;
+        const int j = sid[k];
         double d0 = kInf;
         if (j == 0) d0 = start_val;
-        else if (j <= M && j < S) d0 = start_val + fabs(sig[j] - v0);
+        else if (j > 0 && j <= M) d0 = start_val + fabs(sig[j] - v0);
         st.d[k] = d0;
         st.acur[k] = s1 - st.v[k];
         st.g[k][1] = d0 + fabs(st.acur[k]);
 #pragma unroll
         for (int q = 2; q < M; q++) st.g[k][q] = kInf;
         st.bpw[k] = 0;
-        ex[0 * EXW + j] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
-        ex[1 * EXW + j] = kInf;
+        ex[0 * EXW + k * 64 + lane] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
+        ex[1 * EXW + k * 64 + lane] = kInf;
 #pragma unroll
         for (int f = 0; f < F; f++) {
             st.e0[k][f] = kInf;
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
             const double snext = PAR ? s_even : s_odd;
             if (PAR) s_odd = s_new;
             else s_even = s_new;
-            dp_row<M, K, F, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
+            dp_row<M, K, F, SPLIT, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
             if ((i % R) == R - 1 || i == last) {
                 // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
                 const int wi = i / R;
@@ -362,9 +386,9 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
     // ---- outputs of the fill -----------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int j = k * 64 + lane;
+        const int j = sid[k];
         if (j == A.endstate && a.end_cost) a.end_cost[lr] = st.d[k];
-        if (a.last_row && j < S) a.last_row[(size_t)lr * a.last_row_stride + j] = st.d[k];
+        if (a.last_row && j >= 0) a.last_row[(size_t)lr * a.last_row_stride + j] = st.d[k];
     }
     if (lane == 0 && !a.check_status) a.status[lr] = 0;
 }
@@ -506,8 +530,10 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
     int i = T - 1;
     int nr = 0;
     int last_state = -1;
+    const uint16_t *pos = A.pos;
     while (true) {
-        const uint32_t *col = bp + (size_t)(j >> 6) * 64 + (j & 63);
+        const int q = pos ? pos[j] : j; // where state j's pointer words live (slot q/64, lane q%64)
+        const uint32_t *col = bp + (size_t)(q >> 6) * 64 + (q & 63);
         int wi = i / R;
         // two words per step (the current one and the one below) halve the dependent loads over runs of "stay"
         uint32_t wm = col[(size_t)wi * stride];
@@ -581,7 +607,7 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
     }
 }
 
-template <int M, int K, int F>
+template <int M, int K, int F, bool SPLIT>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
@@ -594,30 +620,36 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     }();
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
-    hipLaunchKernelGGL((dtw_fill_fast<M, K, F>), dim3(blocks), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, SPLIT>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
 
 template <int M, int K>
-hipError_t launch_fill_f(const PassArgs &a, int F, hipStream_t s)
+hipError_t launch_fill_f(const PassArgs &a, int F, bool split, hipStream_t s)
 {
+    if constexpr (K >= 2) {
+        if (split) { // only meaningful with several slots and more than two predecessors somewhere
+            if (F == 3) return launch_fill<M, K, 3, true>(a, s);
+            if (F == 4) return launch_fill<M, K, 4, true>(a, s);
+        }
+    }
     switch (F) {
-    case 2: return launch_fill<M, K, 2>(a, s);
-    case 3: return launch_fill<M, K, 3>(a, s);
-    case 4: return launch_fill<M, K, 4>(a, s);
+    case 2: return launch_fill<M, K, 2, false>(a, s);
+    case 3: return launch_fill<M, K, 3, false>(a, s);
+    case 4: return launch_fill<M, K, 4, false>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
 template <int M>
-hipError_t launch_fill_k(const PassArgs &a, int K, int F, hipStream_t s)
+hipError_t launch_fill_k(const PassArgs &a, int K, int F, bool split, hipStream_t s)
 {
     switch (K) {
-    case 1: return launch_fill_f<M, 1>(a, F, s);
-    case 2: return launch_fill_f<M, 2>(a, F, s);
-    case 3: return launch_fill_f<M, 3>(a, F, s);
-    case 4: return launch_fill_f<M, 4>(a, F, s);
-    case 5: return launch_fill_f<M, 5>(a, F, s);
+    case 1: return launch_fill_f<M, 1>(a, F, split, s);
+    case 2: return launch_fill_f<M, 2>(a, F, split, s);
+    case 3: return launch_fill_f<M, 3>(a, F, split, s);
+    case 4: return launch_fill_f<M, 4>(a, F, split, s);
+    case 5: return launch_fill_f<M, 5>(a, F, split, s);
     }
     return hipErrorInvalidValue;
 }
@@ -631,18 +663,16 @@ bool wsx_fast_pass_supported(int m, int K, int F)
 
 static int fast_f(int F) { return F <= 2 ? 2 : F; }
 
-const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic)
+const char *wsx_pass_kernel_name(int m, int K, int F, bool split, bool generic)
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d>", m, K, fast_f(F));
-    (void)masked;
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %s>", m, K, fast_f(F), split ? "true" : "false");
     return buf;
 }
 
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s)
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool split, bool generic, hipStream_t s)
 {
-    (void)masked; // the mask, if any, travels in PassArgs.maskbits
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
         const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double);
@@ -651,9 +681,9 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, 
     }
     const int f = fast_f(F);
     switch (m) {
-    case 3: return launch_fill_k<3>(a, K, f, s);
-    case 4: return launch_fill_k<4>(a, K, f, s);
-    case 5: return launch_fill_k<5>(a, K, f, s);
+    case 3: return launch_fill_k<3>(a, K, f, split, s);
+    case 4: return launch_fill_k<4>(a, K, f, split, s);
+    case 5: return launch_fill_k<5>(a, K, f, split, s);
     }
     return hipErrorInvalidValue;
 }

@@ -36,9 +36,10 @@ thread_local std::string g_err;
 struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
+    bool split = false; // states with > 2 predecessors all sit in slot 0, which alone runs F candidates
     int PB() const { return generic ? 4 : (F <= 2 ? 2 : 4); }
     int R() const { return 32 / PB(); }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && split == o.split; }
 };
 
 struct DeviceBuf {
@@ -239,7 +240,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 return WSX_ERR_INVALID;
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
-                align_up(S * 8) + align_up(S);
+                align_up(S * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -276,11 +277,29 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             for (int e = A.pred_ptr[j], q = 0; e < A.pred_ptr[j + 1] && q < 4; e++, q++)
                 p4[j] |= (uint64_t)(uint16_t)A.pred_idx[e] << (16 * q);
         D.pred4 = (const uint64_t *)put(p4.data(), (size_t)S * 8);
-        c->host_aut.push_back(D);
         Variant v;
         v.K = (S + 63) / 64;
         v.F = std::max(mf, 1);
         v.generic = !wsx_fast_pass_supported(c->prm.min_values_per_state, v.K, v.F);
+        // Several slots and a few states with more than two predecessors: give those states slot 0 (positions
+        // 0..63), so that only that slot pays for the extra candidates.
+        int n_hi = 0;
+        for (int j = 0; j < S; j++) n_hi += (A.pred_ptr[j + 1] - A.pred_ptr[j]) > 2;
+        D.pos = nullptr;
+        D.state_at = nullptr;
+        if (!v.generic && v.K >= 2 && mf > 2 && n_hi <= 64 && !getenv("WSX_NO_SPLIT")) {
+            v.split = true;
+            std::vector<uint16_t> pos(S), state_at((size_t)v.K * 64, 0xFFFF);
+            int q = 0; // positions 0..n_hi-1: the high-fan-in states, then every other state, both in state order
+            for (int j = 0; j < S; j++)
+                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) > 2) pos[j] = (uint16_t)q++;
+            for (int j = 0; j < S; j++)
+                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) <= 2) pos[j] = (uint16_t)q++;
+            for (int j = 0; j < S; j++) state_at[pos[j]] = (uint16_t)j;
+            D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
+            D.state_at = (const uint16_t *)put(state_at.data(), state_at.size() * 2);
+        }
+        c->host_aut.push_back(D);
         if (v.generic) {
             if (mf > 15) {
                 g_err = "automaton fan-in > 15 is not supported";
@@ -375,7 +394,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
-    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, false, v.generic);
+    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.split, v.generic);
 }
 
 } // extern "C"
@@ -756,7 +775,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, maskbits != nullptr, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].split, x.gvar[g].generic, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;

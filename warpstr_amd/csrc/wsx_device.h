@@ -29,6 +29,8 @@ struct DevAutomaton {
     const int32_t *pred_idx;
     const uint8_t *repeat_mask;
     const uint8_t *last_base; // ASCII of the k-mer's last base, or NULL
+    const uint16_t *pos;      // state -> position (slot*64 + lane) in the register-resident fill; NULL = identity
+    const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
     const uint64_t *pred4;  // per state: its first four predecessors, 16 bits each (one load in the traceback)
 };
 
@@ -138,10 +140,10 @@ struct EvalArgs {
 };
 
 // Host-side launchers (defined next to the kernels).
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool masked, bool generic, hipStream_t s);
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool split, bool generic, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
-const char *wsx_pass_kernel_name(int m, int K, int F, bool masked, bool generic);
+const char *wsx_pass_kernel_name(int m, int K, int F, bool split, bool generic);
