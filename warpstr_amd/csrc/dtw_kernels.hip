@@ -114,9 +114,9 @@ __device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best
 //   end of row i : write E(i+2)
 // Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
 // reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
-// SPLIT: only slot 0 considers F predecessors per state, the other slots 2 (the host places every state with more
-// than two predecessors in slot 0; such states are few: loop entries of nested repeats, IUPAC alternatives).
-template <int M, int K, int F, bool SPLIT, bool MROW, int PAR, bool FORCED, bool CUT>
+// FL < F ("split"): only slot 0 considers F predecessors per state, the other slots FL (the host places every state
+// with more than FL predecessors in slot 0; such states are few: loop entries, IUPAC alternatives).  FL == F: uniform.
+template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT>
 __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext)
 {
     constexpr int PB = (F <= 2) ? 2 : 4;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
     for (int k = 0; k < K; k++)
 #pragma unroll
         for (int f = 0; f < F; f++) {
-            if (SPLIT && k > 0 && f >= 2) continue;
+            if (k > 0 && f >= FL) continue;
             const double e = ex[rbuf + st.paddr[k][f]];
             if (PAR) st.e0[k][f] = e;
             else st.e1[k][f] = e;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
             best = kInf;
             st.bpw[k] <<= PB;
         } else {
-            const int Fk = (SPLIT && k > 0) ? 2 : F; // folds to a constant once the slot loop is unrolled
+            const int Fk = (k > 0) ? FL : F; // folds to a constant once the slot loop is unrolled
             if (PB > Fk) st.bpw[k] <<= (PB - Fk);
             // candidates in the reference's order; bit f lands at position f of this row's field, so push the
             // highest predecessor first
@@ -176,9 +176,10 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int M, int K, int F, bool SPLIT>
+template <int M, int K, int F, int FL>
 __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
 {
+    static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
     constexpr int PB = (F <= 2) ? 2 : 4;
     constexpr int R = 32 / PB;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
             const double snext = PAR ? s_even : s_odd;
             if (PAR) s_odd = s_new;
             else s_even = s_new;
-            dp_row<M, K, F, SPLIT, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
             if ((i % R) == R - 1 || i == last) {
                 // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
                 const int wi = i / R;
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
     }
 }
 
-template <int M, int K, int F, bool SPLIT>
+template <int M, int K, int F, int FL>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
@@ -620,36 +621,38 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     }();
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
-    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, SPLIT>), dim3(blocks), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL>), dim3(blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
 
 template <int M, int K>
-hipError_t launch_fill_f(const PassArgs &a, int F, bool split, hipStream_t s)
+hipError_t launch_fill_f(const PassArgs &a, int F, int FL, hipStream_t s)
 {
-    if constexpr (K >= 2) {
-        if (split) { // only meaningful with several slots and more than two predecessors somewhere
-            if (F == 3) return launch_fill<M, K, 3, true>(a, s);
-            if (F == 4) return launch_fill<M, K, 4, true>(a, s);
-        }
+    if constexpr (K >= 2 && M == 4) { // split variants (FL < F): several slots, default min_values_per_state
+        if (F == 2 && FL == 1) return launch_fill<M, K, 2, 1>(a, s);
+        if (F == 3 && FL == 1) return launch_fill<M, K, 3, 1>(a, s);
+        if (F == 3 && FL == 2) return launch_fill<M, K, 3, 2>(a, s);
+        if (F == 4 && FL == 1) return launch_fill<M, K, 4, 1>(a, s);
+        if (F == 4 && FL == 2) return launch_fill<M, K, 4, 2>(a, s);
     }
+    if (FL != F) return hipErrorInvalidValue;
     switch (F) {
-    case 2: return launch_fill<M, K, 2, false>(a, s);
-    case 3: return launch_fill<M, K, 3, false>(a, s);
-    case 4: return launch_fill<M, K, 4, false>(a, s);
+    case 2: return launch_fill<M, K, 2, 2>(a, s);
+    case 3: return launch_fill<M, K, 3, 3>(a, s);
+    case 4: return launch_fill<M, K, 4, 4>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
 template <int M>
-hipError_t launch_fill_k(const PassArgs &a, int K, int F, bool split, hipStream_t s)
+hipError_t launch_fill_k(const PassArgs &a, int K, int F, int FL, hipStream_t s)
 {
     switch (K) {
-    case 1: return launch_fill_f<M, 1>(a, F, split, s);
-    case 2: return launch_fill_f<M, 2>(a, F, split, s);
-    case 3: return launch_fill_f<M, 3>(a, F, split, s);
-    case 4: return launch_fill_f<M, 4>(a, F, split, s);
-    case 5: return launch_fill_f<M, 5>(a, F, split, s);
+    case 1: return launch_fill_f<M, 1>(a, F, FL, s);
+    case 2: return launch_fill_f<M, 2>(a, F, FL, s);
+    case 3: return launch_fill_f<M, 3>(a, F, FL, s);
+    case 4: return launch_fill_f<M, 4>(a, F, FL, s);
+    case 5: return launch_fill_f<M, 5>(a, F, FL, s);
     }
     return hipErrorInvalidValue;
 }
@@ -663,15 +666,17 @@ bool wsx_fast_pass_supported(int m, int K, int F)
 
 static int fast_f(int F) { return F <= 2 ? 2 : F; }
 
-const char *wsx_pass_kernel_name(int m, int K, int F, bool split, bool generic)
+bool wsx_split_supported(int m, int K) { return m == 4 && K >= 2; }
+
+const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool generic)
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %s>", m, K, fast_f(F), split ? "true" : "false");
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d>", m, K, fast_f(F), FL);
     return buf;
 }
 
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool split, bool generic, hipStream_t s)
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
@@ -681,9 +686,9 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool split, b
     }
     const int f = fast_f(F);
     switch (m) {
-    case 3: return launch_fill_k<3>(a, K, f, split, s);
-    case 4: return launch_fill_k<4>(a, K, f, split, s);
-    case 5: return launch_fill_k<5>(a, K, f, split, s);
+    case 3: return launch_fill_k<3>(a, K, f, FL, s);
+    case 4: return launch_fill_k<4>(a, K, f, FL, s);
+    case 5: return launch_fill_k<5>(a, K, f, FL, s);
     }
     return hipErrorInvalidValue;
 }

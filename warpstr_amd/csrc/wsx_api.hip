@@ -36,10 +36,10 @@ thread_local std::string g_err;
 struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
-    bool split = false; // states with > 2 predecessors all sit in slot 0, which alone runs F candidates
+    int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
     int PB() const { return generic ? 4 : (F <= 2 ? 2 : 4); }
     int R() const { return 32 / PB(); }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && split == o.split; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL; }
 };
 
 struct DeviceBuf {
@@ -281,20 +281,30 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         v.K = (S + 63) / 64;
         v.F = std::max(mf, 1);
         v.generic = !wsx_fast_pass_supported(c->prm.min_values_per_state, v.K, v.F);
-        // Several slots and a few states with more than two predecessors: give those states slot 0 (positions
-        // 0..63), so that only that slot pays for the extra candidates.
-        int n_hi = 0;
-        for (int j = 0; j < S; j++) n_hi += (A.pred_ptr[j + 1] - A.pred_ptr[j]) > 2;
+        // Several slots and only a few states with many predecessors (loop entries, IUPAC alternatives): give those
+        // states slot 0 (positions 0..63), so that only that slot pays for the extra candidates.  Slots 1.. then
+        // consider FL predecessors: 1 when every state with two or more fits in slot 0, else 2.
         D.pos = nullptr;
         D.state_at = nullptr;
-        if (!v.generic && v.K >= 2 && mf > 2 && n_hi <= 64 && !getenv("WSX_NO_SPLIT")) {
-            v.split = true;
+        const int Fk = v.F <= 2 ? 2 : v.F;
+        v.FL = Fk;
+        if (!v.generic && wsx_split_supported(c->prm.min_values_per_state, v.K) && !getenv("WSX_NO_SPLIT")) {
+            int n_ge2 = 0, n_gt2 = 0;
+            for (int j = 0; j < S; j++) {
+                const int nf = A.pred_ptr[j + 1] - A.pred_ptr[j];
+                n_ge2 += nf >= 2;
+                n_gt2 += nf > 2;
+            }
+            if (n_ge2 <= 64) v.FL = 1;
+            else if (Fk > 2 && n_gt2 <= 64) v.FL = 2;
+        }
+        if (v.FL < Fk) {
             std::vector<uint16_t> pos(S), state_at((size_t)v.K * 64, 0xFFFF);
-            int q = 0; // positions 0..n_hi-1: the high-fan-in states, then every other state, both in state order
+            int q = 0; // positions 0..: the states with more than FL predecessors, then every other state, in state order
             for (int j = 0; j < S; j++)
-                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) > 2) pos[j] = (uint16_t)q++;
+                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) > v.FL) pos[j] = (uint16_t)q++;
             for (int j = 0; j < S; j++)
-                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) <= 2) pos[j] = (uint16_t)q++;
+                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) <= v.FL) pos[j] = (uint16_t)q++;
             for (int j = 0; j < S; j++) state_at[pos[j]] = (uint16_t)j;
             D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
             D.state_at = (const uint16_t *)put(state_at.data(), state_at.size() * 2);
@@ -394,7 +404,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
-    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.split, v.generic);
+    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.generic);
 }
 
 } // extern "C"
@@ -775,7 +785,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].split, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].generic, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;

@@ -140,10 +140,11 @@ struct EvalArgs {
 };
 
 // Host-side launchers (defined next to the kernels).
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, bool split, bool generic, hipStream_t s);
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
-const char *wsx_pass_kernel_name(int m, int K, int F, bool split, bool generic);
+const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool generic);
+bool wsx_split_supported(int m, int K);
