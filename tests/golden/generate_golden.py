@@ -97,6 +97,11 @@ def run_reference_read(ns, sta, flank_length, reverse, signal, full_matrix=False
 def gen_case(ns, name, pattern, fl, fseed, T, n_reads, rseed, lohi, outdir):
     locus = synth.make_locus(pattern, fl, fseed)
     sigs, revs, truth = synth.batch(locus, n_reads, T, rseed, lo=lohi[0], hi=lohi[1])
+    write_case(ns, name, pattern, fl, locus, sigs, revs, truth, outdir)
+
+
+def write_case(ns, name, pattern, fl, locus, sigs, revs, truth, outdir, extra=None):
+    n_reads = len(sigs)
     # make sure both strands are present
     tmp_seq = locus.left_t + pattern + locus.right_t
     rev_seq = locus.left_r + ns.wrapper.CallerWrapper.reverse_uniq_sequence(pattern) + locus.right_r
@@ -121,7 +126,41 @@ def gen_case(ns, name, pattern, fl, fseed, T, n_reads, rseed, lohi, outdir):
             data[f'r{i}_{k}'] = v
         print(f'  {name} read {i} rev={int(rev)} T={len(sig)} S={len(stas[rev].states)} truth={truth[i]} '
               f'len1={len(r["seq"][0])} len2={len(r["seq"][1])} cost={r["cost"]}')
+    data.update(extra or {})
     np.savez_compressed(os.path.join(outdir, f'{name}.npz'), **data)
+
+
+def gen_real(ns, outdir):
+    """The upstream test case (README.md section 2, test/test_caller_only/example.csv: 10 real R9.4 reads of an (AAAT)
+    locus).  Raw samples come out of the upstream multi-read fast5 through this repository's reader (h5py and the VBZ
+    plugin are absent offline); spike removal, normalisation and the caller are the reference's own functions.  GRCh38
+    is not available, so the flanks are the pile-up consensus written by real/make_flanks.py.  The fast5 and the csv are
+    copied beside the vectors as data fixtures for the loader tests."""
+    import csv
+    import shutil
+    from types import SimpleNamespace
+    from warpstr_amd.fast5 import Fast5File
+    real = os.path.join(outdir, 'real')
+    with open(os.path.join(real, 'flanks.json')) as f:
+        fj = json.load(f)
+    ref_root = '/root/reference'
+    rows = list(csv.DictReader(open(os.path.join(ref_root, 'test/test_caller_only/example.csv'))))
+    shutil.copyfile(os.path.join(ref_root, 'test/test_caller_only/example.csv'), os.path.join(real, 'example.csv'))
+    shutil.copyfile(os.path.join(ref_root, rows[0]['fast5_path']), os.path.join(real, 'batch_0.fast5'))
+    locus = SimpleNamespace(left_t=fj['left_template'], right_t=fj['right_template'], left_r=fj['left_reverse'],
+                            right_r=fj['right_reverse'])
+    sigs, revs, names, pos = [], [], [], []
+    with Fast5File(os.path.join(ref_root, rows[0]['fast5_path'])) as f5:
+        for row in rows:
+            raw = f5.raw_signal(row['read_name'])
+            norm = ns.normalize_signal_mad(ns.Fast5.brute_remove(raw))  # fast5.py:45-57 with spike_removal = Brute
+            lo, hi = int(row['l_start_raw']), int(row['r_end_raw'])
+            sigs.append(np.asarray(norm[lo:hi + 1], dtype=np.float64))
+            revs.append(row['reverse'].upper() == 'TRUE')
+            names.append(row['read_name'])
+            pos.append((lo, hi, len(raw)))
+    extra = {'names': np.array(names), 'raw_span': np.array(pos, dtype=np.int64)}
+    write_case(ns, 'real_aaat', fj['sequence'], fj['flank_length'], locus, sigs, revs, [[-1]] * len(sigs), outdir, extra)
 
 
 def gen_units(ns, outdir):
@@ -209,6 +248,9 @@ def main():
             continue
         print(case[0])
         gen_case(ns, *case, HERE)
+    if not args.only or args.only == 'real_aaat':
+        print('real_aaat')
+        gen_real(ns, HERE)
     if not args.only:
         gen_units(ns, HERE)
         gen_negative(ns, HERE)

@@ -6,7 +6,7 @@ import numpy as np
 from oracle import oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-DEFAULT_CASES = ['agc_fl16', 'agc_fl29', 'aaat_fl110', 'hd_fl20', 'dm2_fl40', 'ngc_fl20', 'agc_fl16_ragged']
+DEFAULT_CASES = ['agc_fl16', 'agc_fl29', 'aaat_fl110', 'hd_fl20', 'dm2_fl40', 'ngc_fl20', 'agc_fl16_ragged', 'real_aaat']
 
 
 def load_case(name):

@@ -436,3 +436,46 @@ def test_baseline_full_size_recovers_planted_alleles():
         assert o.status == 0 and (r0['len1'][i], r0['len2'][i]) == (o.len1, o.len2)
         assert_close_rel(r0['cost2'][i], o.cost2, COST_REL)
         assert_close_rel(r0['dtw_end_cost2'][i], o.dtw_end_cost2, COST_REL)
+
+
+def test_upstream_test_case_real_reads(tmp_path):
+    """The upstream test case end to end (README.md section 2; test/test_caller_only): example.csv + the multi-read
+    VBZ fast5 -> caller-only overview -> int16 reads prepared on the GPU -> both passes -> overview.csv -> genotype.
+    Per-read lengths and costs must equal what the upstream caller produced from the same samples and flanks
+    (tests/golden/real_aaat.npz), and the genotype is the README's (44, 40)."""
+    import json
+    import os
+
+    import pandas as pd
+
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5, overview as ov
+    from warpstr_amd.genotyper import run_genotyping_overview
+    from warpstr_amd.wrapper import main_wrapper, prepare_caller_only
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    real = os.path.join(GOLDEN, 'real')
+    z = load_case('real_aaat')
+    with open(os.path.join(real, 'flanks.json')) as f:
+        fj = json.load(f)
+    d = tmp_path / 'test' / 'test_input' / 'test_run1' / 'fast5s'
+    d.mkdir(parents=True)
+    os.symlink(os.path.join(real, 'batch_0.fast5'), d / 'batch_0.fast5')
+    loc = prepare_caller_only(os.path.join(real, 'example.csv'), str(tmp_path / 'out'), base_dir=str(tmp_path))
+    loc = loc['Human_STR_1108232']
+    ov.store_flanks(loc, [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']])
+    df, dfc = main_wrapper(loc, fj['sequence'], fj['flank_length'])
+    assert dfc is None
+    out = pd.read_csv(os.path.join(loc, 'overview.csv'))
+    assert list(out['read_name']) == [str(n) for n in z['names']]
+    for i in range(int(z['n_reads'])):
+        seq, rseq = (str(s) for s in z[f'r{i}_seq'])
+        assert (int(out['orig'][i]), int(out['results'][i])) == (len(seq), len(rseq))
+        assert_close_rel(out['dtw_cost1'][i], z[f'r{i}_cost'][0], COST_REL)
+        assert_close_rel(out['dtw_cost2'][i], z[f'r{i}_cost'][1], COST_REL)
+    fasta = open(os.path.join(loc, 'predictions', 'sequences', 'all.fasta')).read().split('\n\n')
+    assert fasta[0].splitlines()[1] == str(z['r0_seq'][1])
+    gt = run_genotyping_overview(loc, random_state=0)
+    assert gt.is_hetero and sorted(gt.alleles, reverse=True) == [44, 40]

@@ -273,13 +273,25 @@ class CallerWrapper:
         if not workload:
             return []
         signal, offsets = pack_signals([np.asarray(w.signal, dtype=np.float64) for w in workload])
-        aut = np.array([1 if w.reverse else 0 for w in workload], dtype=np.int32)
+        return self._run_packed([w.name for w in workload], [w.reverse for w in workload], signal, offsets)
+
+    def run_raw(self, names: Sequence[str], reverses: Sequence[bool], raws: Sequence[np.ndarray],
+                positions: Sequence[Sequence[int]], spike_removal: str = 'Brute') -> List[CallerResult]:
+        """Same as run(), from raw DAC reads: spike removal, whole-read normalisation and the slice
+        [l_start_raw, r_end_raw] (Fast5.get_data_processed, src/schemas/fast5.py:45-57) happen on the GPU."""
+        if not names:
+            return []
+        signal, offsets, _ = self.hip.prepare_signals(raws, positions, spike_removal)
+        return self._run_packed(list(names), list(reverses), signal, offsets)
+
+    def _run_packed(self, names, reverses, signal, offsets) -> List[CallerResult]:
+        aut = np.array([1 if r else 0 for r in reverses], dtype=np.int32)
         res, extra = self.hip.call(signal, offsets, aut, want_seqs=True)
         out: List[CallerResult] = []
-        for i, w in enumerate(workload):
+        for i, name in enumerate(names):
             st = int(res['status'][i])
             if st != 0:
-                msg = f'read {w.name}: caller status {_lib.READ_STATUS.get(st, st)}'
+                msg = f'read {name}: caller status {_lib.READ_STATUS.get(st, st)}'
                 if self.on_error == 'raise':
                     raise ReadCallError(msg)
                 out.append(CallerResult('', float('nan'), '', float('nan')))

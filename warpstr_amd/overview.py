@@ -36,6 +36,19 @@ def load_flanks(locus_path: str) -> Tuple[str, str, str, str]:
     return rows[0], rows[1], rows[2], rows[3]
 
 
+FLANK_NAMES = ['left_flank_template', 'right_flank_template', 'left_flank_reverse', 'right_flank_reverse']
+
+
+def store_flanks(locus_path: str, flanks: Sequence[str]):
+    """Write the flank file load_flanks reads, in the squiggler step's format (src/squiggler/Squiggler.py:69-75); for
+    callers that get the flanks from somewhere other than a reference genome."""
+    os.makedirs(os.path.join(locus_path, LOCUS_INFO_SUBDIR), exist_ok=True)
+    with open(os.path.join(locus_path, LOCUS_INFO_SUBDIR, LOCUS_FLANKS), 'w') as f:
+        f.write('type,sequence\n')
+        for name, seq in zip(FLANK_NAMES, flanks):
+            f.write(f'{name},{seq.upper()}\n')
+
+
 def result_columns(df_overview, seq_results: Sequence[Tuple[str, str]], cost_results: Sequence[Tuple[float, float]]):
     """Per-row values of the four step-3 columns: called reads in overview order, -1 for rows that were not `saved`
     (src/caller/overview.py:57-73).  Also returns the (read, resc_seq, reverse) triples for the FASTA files."""

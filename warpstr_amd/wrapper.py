@@ -12,6 +12,7 @@ import numpy as np
 
 from . import overview as ov
 from .caller import CallerConfig, CallerWrapper, ReadSignal, RescalerConfig
+from .fast5 import read_raw_signal
 from .signal_prep import process_raw
 from .units import break_into_units, collapse_repeats
 
@@ -19,19 +20,14 @@ FAST5_SUBDIR, ANNOT_SUBDIR = 'fast5', 'annot'
 
 
 def _fast5_loader(spike_removal: str) -> Callable[[str, int, int], np.ndarray]:
-    try:
-        import h5py  # noqa: F401
-    except ImportError as e:  # pragma: no cover - h5py is absent in the build image
-        raise RuntimeError('reading .fast5 needs h5py (and the VBZ HDF5 plugin); pass `signal_loader=` '
-                           'to main_wrapper to supply normalised segments another way') from e
-
+    """Host-side loader (used for the median3/median5 spike filters, which have no GPU kernel)."""
     def load(path: str, l_start_raw: int, r_end_raw: int) -> np.ndarray:
-        import h5py
-        with h5py.File(path, 'r') as h:
-            rname = list(h['Raw']['Reads'].keys())[0]
-            raw = np.asarray(h['Raw']['Reads'][rname]['Signal'])
-        return process_raw(raw, (l_start_raw, r_end_raw), spike_removal)
+        return process_raw(read_raw_signal(path), (l_start_raw, r_end_raw), spike_removal)
     return load
+
+
+def annot_fast5_path(path: str, run_id, read_name: str) -> str:
+    return os.path.join(path, FAST5_SUBDIR, str(run_id), ANNOT_SUBDIR, read_name + '.fast5')
 
 
 def get_workload(df_overview, path: str, signal_loader: Callable[[str, int, int], np.ndarray]) -> List[ReadSignal]:
@@ -39,10 +35,27 @@ def get_workload(df_overview, path: str, signal_loader: Callable[[str, int, int]
     work: List[ReadSignal] = []
     for row in df_overview.itertuples():
         if row.saved:
-            fast5path = os.path.join(path, FAST5_SUBDIR, str(row.run_id), ANNOT_SUBDIR, row.Index + '.fast5')
+            fast5path = annot_fast5_path(path, row.run_id, row.Index)
             sig = signal_loader(fast5path, int(row.l_start_raw), int(row.r_end_raw))
             work.append(ReadSignal(row.Index, bool(row.reverse), np.asarray(sig, dtype=np.float64)))
     return work
+
+
+def get_raw_workload(df_overview, path: str, raw_reader: Callable[[str], np.ndarray] = read_raw_signal):
+    """The same rows as get_workload, as raw DAC reads + (l_start_raw, r_end_raw): input of CallerWrapper.run_raw."""
+    names, reverses, raws, positions = [], [], [], []
+    for row in df_overview.itertuples():
+        if row.saved:
+            names.append(row.Index)
+            reverses.append(bool(row.reverse))
+            fast5path = annot_fast5_path(path, row.run_id, row.Index)
+            if raw_reader is read_raw_signal and not os.path.exists(fast5path) and hasattr(row, 'fast5_path'):
+                raw = read_raw_signal(str(row.fast5_path), row.Index)  # caller-only input: read kept in its multi-read file
+            else:
+                raw = raw_reader(fast5path)
+            raws.append(np.ascontiguousarray(raw, dtype=np.int16))
+            positions.append((int(row.l_start_raw), int(row.r_end_raw)))
+    return names, reverses, raws, positions
 
 
 def main_wrapper(locus_path: str, sequence: str, flank_length: int, threads: int = 1,
@@ -50,11 +63,16 @@ def main_wrapper(locus_path: str, sequence: str, flank_length: int, threads: int
                  signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None, device: int = 0):
     caller_config = caller_config or CallerConfig()
     overview_path, df_overview = ov.load_overview(locus_path)
-    loader = signal_loader or _fast5_loader(caller_config.spike_removal)
-    workload = get_workload(df_overview, locus_path, loader)
     cw = CallerWrapper(sequence, ov.load_flanks(locus_path), flank_length, threads, caller_config, rescaler_config,
                        device=device)
-    results = cw.run(workload)
+    if signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
+        # default: int16 reads straight from the .fast5 files, prepared on the GPU
+        names, reverses, raws, positions = get_raw_workload(df_overview, locus_path)
+        results = cw.run_raw(names, reverses, raws, positions, caller_config.spike_removal)
+    else:
+        workload = get_workload(df_overview, locus_path, signal_loader or _fast5_loader(caller_config.spike_removal))
+        reverses = [w.reverse for w in workload]
+        results = cw.run(workload)
     seq_results = [(r.seq, r.resc_seq) for r in results]
     cost_results = [(r.cost, r.resc_cost) for r in results]
     df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus_path)
@@ -62,5 +80,31 @@ def main_wrapper(locus_path: str, sequence: str, flank_length: int, threads: int
     units, repeat_units, offsets = break_into_units(sequence.upper())
     if len(units) > 1:
         collapsed = [collapse_repeats(s[1], repeat_units, offsets) for s in seq_results]
-        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, [w.reverse for w in workload], locus_path)
+        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus_path)
     return df_overview, df_collapsed
+
+
+def prepare_caller_only(csv_path: str, output: str, base_dir: str = '.'):
+    """Caller-only input (prepare_caller_only.py:41-112): a CSV with columns fast5_path, locus, read_name, reverse,
+    l_start_raw, r_end_raw [, run_id] becomes <output>/<locus>/overview.csv (+ run_id 'run_0', saved 1).  The reference
+    also copies every read into a single-read .fast5 under fast5/<run_id>/annot/; here the reads stay where they are
+    (get_raw_workload follows the overview's fast5_path column), so nothing is rewritten.  Returns {locus: path}."""
+    import pandas as pd
+    df = pd.read_csv(csv_path, dtype={'read_name': str, 'locus': str, 'fast5_path': str})
+    required = ['fast5_path', 'locus', 'read_name', 'reverse', 'l_start_raw', 'r_end_raw']
+    if any(c not in df.columns for c in required) or any(c not in required + ['run_id'] for c in df.columns):
+        raise ValueError(f'Not all required columns present in input CSV file. Required fields are: {required}')
+    if 'run_id' not in df.columns:
+        df['run_id'] = 'run_0'
+    df['saved'] = 1
+    df['fast5_path'] = [p if os.path.isabs(p) else os.path.abspath(os.path.join(base_dir, p)) for p in df['fast5_path']]
+    out = {}
+    for locus, part in df.groupby('locus', sort=False):
+        for p, name in zip(part['fast5_path'], part['read_name']):
+            if not os.path.exists(p):
+                raise FileNotFoundError(f'fast5 file {p} of read {name} does not exist')
+        locus_path = os.path.join(output, locus)
+        os.makedirs(locus_path, exist_ok=True)
+        part.to_csv(os.path.join(locus_path, ov.OVERVIEW_NAME), index=False)
+        out[locus] = locus_path
+    return out
