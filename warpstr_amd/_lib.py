@@ -10,7 +10,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libwarpstr_hip.so')
+LIB_PATH = os.environ.get('WARPSTR_HIP_LIB') or os.path.join(_HERE, 'libwarpstr_hip.so')
 
 WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',

@@ -176,8 +176,14 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef WSX_FILL_MAX_WAVES
+#define WSX_FILL_OCC __attribute__((amdgpu_waves_per_eu(1, WSX_FILL_MAX_WAVES)))
+#else
+#define WSX_FILL_OCC
+#endif
+
 template <int M, int K, int F, int FL>
-__global__ __launch_bounds__(256) void dtw_fill_fast(PassArgs a)
+__global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
@@ -678,6 +684,10 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool generic)
 
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s)
 {
+#ifdef WSX_ONLY_DEFAULT // experiment builds: just the headline variant
+    if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return launch_fill<4, 1, 2, 2>(a, s);
+    return hipErrorInvalidValue;
+#else
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
         const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double);
@@ -691,6 +701,7 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
     case 5: return launch_fill_k<5>(a, K, f, FL, s);
     }
     return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s)

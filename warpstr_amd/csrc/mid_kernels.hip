@@ -17,6 +17,9 @@
 //   tstat_kernel       thread per sample          chunk_kernel     thread per (read, chunk)
 //   sort_kernel        wavefront per read         fit_kernel       thread per read (sequential Givens recurrence)
 //   eval_kernel        thread per sample (de Boor evaluation, 6 divisions)
+#include <algorithm>
+#include <cstdlib>
+
 #include "../../include/warpstr_hip.h"
 #include "wsx_device.h"
 
@@ -224,42 +227,46 @@ __device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
 // A block handles 64 consecutive runs, i.e. one contiguous span of the signal: the span is loaded coalesced into LDS
 // (when it fits) and every thread then walks its own run there.
 #define RS_CAP 1024
+#define RS_GROUPS 4 // grid.y: a read's 64-run groups are dealt round-robin to this many single-wave blocks
 __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
 {
     __shared__ double buf[RS_CAP];
     const int lr = blockIdx.x;
     if (a.status[lr] != 0) return;
     const ReadView v = view(a, lr);
-    const int k0 = blockIdx.y * 64;
-    if (k0 >= v.n) return;
-    const int klast = (k0 + 64 < v.n ? k0 + 64 : v.n) - 1;
     const int tid = threadIdx.x;
     const DevAutomaton &A = a.aut[a.aut_id[v.r]];
     const double *sig = a.signal + v.off;
-    const int s_lo = v.fstart(k0), s_hi = v.fend(klast);
-    const bool staged = (s_hi - s_lo) <= RS_CAP;
-    if (staged) {
-        for (int q = tid; q < s_hi - s_lo; q += 64) buf[q] = sig[s_lo + q];
-        __syncthreads();
+    // (a grid with one block per possible group, T/(m-1)/64 of them, is mostly empty blocks: runs last ~9 samples)
+    for (int k0 = blockIdx.y * 64; k0 < v.n; k0 += RS_GROUPS * 64) {
+        const int klast = (k0 + 64 < v.n ? k0 + 64 : v.n) - 1;
+        const int s_lo = v.fstart(k0), s_hi = v.fend(klast);
+        const bool staged = (s_hi - s_lo) <= RS_CAP;
+        if (staged) {
+            for (int q = tid; q < s_hi - s_lo; q += 64) buf[q] = sig[s_lo + q];
+            __syncthreads();
+        }
+        const int k = k0 + tid;
+        if (k <= klast) {
+            const int s0 = v.fstart(k), len = v.fend(k) - s0;
+            double val, sd;
+            if (staged && len <= 128) { // common case: straight-line LDS reads
+                const double *p = buf + (s0 - s_lo);
+                val = pw_block_inl(LoadPlain{p}, 0, len) / (double)len;
+                sd = sqrt(pw_block_inl(LoadSqDev{p, val}, 0, len) / (double)len);
+            } else {
+                run_mean_std(sig, s0, len, val, sd);
+            }
+            if (a.prm.method_median) val = np_median(sig + s0, len);
+            const double expd = A.value[v.fstate(k)];
+            const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
+            a.al_value[v.off + k] = val;
+            a.al_expected[v.off + k] = expd;
+            a.al_cost[v.off + k] = fabs(val - expd);
+            a.al_good[v.off + k] = good ? 1 : 0;
+        }
+        __syncthreads(); // the staging buffer is reused by the next group
     }
-    const int k = k0 + tid;
-    if (k > klast) return;
-    const int s0 = v.fstart(k), len = v.fend(k) - s0;
-    double val, sd;
-    if (staged && len <= 128) { // common case: straight-line LDS reads
-        const double *p = buf + (s0 - s_lo);
-        val = pw_block_inl(LoadPlain{p}, 0, len) / (double)len;
-        sd = sqrt(pw_block_inl(LoadSqDev{p, val}, 0, len) / (double)len);
-    } else {
-        run_mean_std(sig, s0, len, val, sd);
-    }
-    if (a.prm.method_median) val = np_median(sig + s0, len);
-    const double expd = A.value[v.fstate(k)];
-    const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
-    a.al_value[v.off + k] = val;
-    a.al_expected[v.off + k] = expd;
-    a.al_cost[v.off + k] = fabs(val - expd);
-    a.al_good[v.off + k] = good ? 1 : 0;
 }
 
 // (1') rescaling.reps_as_one = True (caller.py:69-79): one record per distinct state on the path, in ascending
@@ -521,6 +528,84 @@ __global__ __launch_bounds__(64) void chunk_kernel(MidArgs a)
     }
 }
 
+// (4) = (4a) + (4b) in one pass, one 256-thread block per read: the t-statistics stay in LDS, and the peak scan of
+// segment() becomes a count.  The scan's state machine is local: with A(p) := "t[p] is beyond +-3 and not falling back"
+// ((t > 3 and t >= prev) or (t < -3 and t <= prev), prev = t[p-1], or t[p] itself at the first position of the chunk),
+// `started` before position p is exactly A(p-1), so  borders(chunk) = #{p in (b0, b1] : A(p-1) and not A(p)}.
+__global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
+{
+    extern __shared__ int seg_lds[]; // cb[max_chunks + 1]: first sample of every chunk; cnt[max_chunks]
+    __shared__ double wm[256 + 3], ws[256 + 3], tl[256 + 2];
+    int *cb = seg_lds, *cnt = seg_lds + (max_chunks + 1);
+    const int lr = blockIdx.x, tid = threadIdx.x;
+    const ReadView v = view(a, lr);
+    uint32_t *mw = a.maskbits + (v.off / 32 + lr);
+    for (int w = tid; w < (v.T + 31) / 32; w += 256) mw[w] = 0;
+    if (a.badmask_bytes)
+        for (int q = tid; q < v.T; q += 256) a.badmask_bytes[v.off + q] = 0;
+    if (a.status[lr] != 0) return;
+    const MidRec rec = a.rec[lr];
+    const int nch = rec.nsel - 1, sis = a.prm.states_in_segment;
+    if (nch < 1 || nch + 1 > max_chunks) return;
+    for (int c = tid; c <= nch; c += 256) {
+        cb[c] = v.fend(rec.start + c * sis) - 1;
+        if (c < nch) cnt[c] = 0;
+    }
+    const double *sig = a.signal + v.off;
+    for (int p0 = rec.p_lo + 3; p0 + 2 < rec.p_hi; p0 += 256) { // positions p0 .. p0+255 (t exists on [p_lo+3, p_hi-2))
+        const double carry = (tid < 2 && p0 > rec.p_lo + 3) ? tl[256 + tid] : 0.0; // t[p0-2], t[p0-1] of the last tile
+        for (int q = tid; q < 259; q += 256) { // window statistics at p0-3 .. p0+255
+            const int p = p0 - 3 + q;
+            double mu = 0.0, ss = 0.0;
+            if (p >= rec.p_lo && p + 2 < rec.p_hi) {
+                const double a0 = sig[p], a1 = sig[p + 1], a2 = sig[p + 2];
+                mu = mean3v(a0, a1, a2);
+                const double sd = std3v(a0, a1, a2, mu);
+                ss = sd * sd;
+            }
+            wm[q] = mu;
+            ws[q] = ss;
+        }
+        __syncthreads();
+        const int p = p0 + tid;
+        const bool valid = p + 2 < rec.p_hi;
+        double t = 0.0;
+        if (valid) {
+            double sd = sqrt((ws[tid] + ws[tid + 3]) / 3.0);
+            if (sd == 0.0) sd = sd + 0.0000001;
+            t = (wm[tid] - wm[tid + 3]) / sd;
+        }
+        tl[2 + tid] = t;
+        if (tid < 2) tl[tid] = carry;
+        __syncthreads();
+        if (valid && p > cb[0]) {
+            int lo = 0, hi = nch - 1; // the chunk whose first sample is the last one before p
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cb[mid] < p) lo = mid;
+                else hi = mid - 1;
+            }
+            const double t1 = tl[1 + tid], prev1 = (p - 1 == cb[lo]) ? t1 : tl[tid];
+            const bool a1 = (t1 > 3 && t1 >= prev1) || (t1 < -3 && t1 <= prev1);
+            const bool a0 = (t > 3 && t >= t1) || (t < -3 && t <= t1);
+            if (a1 && !a0) atomicAdd(&cnt[lo], 1);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {
+        if (cnt[c] - 1 >= sis + 1) { // check_segments: >= states_in_segment + 1
+            const int b0 = cb[c], b1 = cb[c + 1];
+            for (int w = b0 >> 5; w <= ((b1 - 1) >> 5); w++) {
+                const int q0 = w * 32 > b0 ? w * 32 : b0, q1 = (w + 1) * 32 < b1 ? (w + 1) * 32 : b1;
+                const uint32_t bits = (q1 - q0 >= 32) ? 0xffffffffu : (((1u << (q1 - q0)) - 1u) << (q0 & 31));
+                atomicOr(&mw[w], bits);
+            }
+            if (a.badmask_bytes)
+                for (int q = b0; q < b1; q++) a.badmask_bytes[v.off + q] = 1;
+        }
+    }
+}
+
 // (6) rescaling input: accepted records, stably sorted by value (filter_alignment + list.sort, caller.py:304-318):
 // compact (order preserved), then rank = #(x_q < x_k) + #(x_q == x_k, q < k).  One wavefront per read.
 __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
@@ -703,24 +788,24 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 // splev (ext = 0) of the fitted cubic at every sample of the read.
 __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 {
-    const int lr = blockIdx.x; // reads on grid.x (no 65535 limit), 256-sample tiles on grid.y
+    const int lr = blockIdx.x; // one block per read, striding over its samples
     if (a.status[lr] != 0) return;
     const int r = a.first_read + lr;
     const long long off = a.offsets[r] - a.base_off;
     const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
-    const int i = blockIdx.y * blockDim.x + threadIdx.x;
-    if (i >= T) return;
     const double *co = a.coef + (size_t)lr * 6;
-    const double xb = co[0], xe = co[1];
-    double h[5];
-    bspl4(xb, xe, a.signal[off + i], h);
-    double sp = 0.0;
-    sp = sp + co[2] * h[1];
-    sp = sp + co[3] * h[2];
-    sp = sp + co[4] * h[3];
-    sp = sp + co[5] * h[4];
-    a.out[off + i] = sp;
-    if (a.out_user) a.out_user[off + i] = sp;
+    const double xb = co[0], xe = co[1], c1 = co[2], c2 = co[3], c3 = co[4], c4 = co[5];
+    for (int i = threadIdx.x; i < T; i += 256) {
+        double h[5];
+        bspl4(xb, xe, a.signal[off + i], h);
+        double sp = 0.0;
+        sp = sp + c1 * h[1];
+        sp = sp + c2 * h[2];
+        sp = sp + c3 * h[3];
+        sp = sp + c4 * h[4];
+        a.out[off + i] = sp;
+        if (a.out_user) a.out_user[off + i] = sp;
+    }
 }
 
 } // namespace
@@ -732,13 +817,19 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     // a run spans >= m-1 samples (except possibly the first and last): bound on runs per read
     const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
     if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, (max_runs + 63) / 64), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, std::min((max_runs + 63) / 64, RS_GROUPS)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.seq_out) hipLaunchKernelGGL(sequence_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;
-        hipLaunchKernelGGL(tstat_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(chunk_kernel, dim3(a.n_reads, (max_chunks + 63) / 64), dim3(64), 0, s, a);
+        static const bool two_kernels = getenv("WSX_SEGMENT_TWO_KERNELS") != nullptr; // test knob for the fallback
+        const size_t seg_lds = (size_t)(2 * max_chunks + 1) * sizeof(int);
+        if (seg_lds <= 40 * 1024 && !two_kernels) {
+            hipLaunchKernelGGL(segment_kernel, dim3(a.n_reads), dim3(256), seg_lds, s, a, max_chunks);
+        } else { // reads of > ~90k samples: t-statistics through HBM, one thread per chunk
+            hipLaunchKernelGGL(tstat_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(chunk_kernel, dim3(a.n_reads, (max_chunks + 63) / 64), dim3(64), 0, s, a);
+        }
         hipLaunchKernelGGL(sort_kernel, dim3(a.n_reads), dim3(64), 0, s, a);
     }
     return hipGetLastError();
@@ -754,6 +845,6 @@ hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s)
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s)
 {
     if (a.n_reads <= 0 || max_T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_kernel, dim3(a.n_reads, (max_T + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(eval_kernel, dim3(a.n_reads), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -87,6 +87,8 @@ struct wsx_caller {
         DeviceBuf samples, reads, bp, stage_sig, stage_out, reps;
     } work[WSX_MAX_STREAMS];
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
+    hipStream_t hi[WSX_MAX_STREAMS] = {};   // high-priority companions for the short kernels between the fills
+    bool use_hi = false;
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
     int n_streams = 4;
     DeviceBuf meta;
@@ -334,6 +336,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipEventCreate(&c->ev_end));
     HIPCHK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (const char *e = getenv("WSX_PRIO")) c->use_hi = atoi(e) != 0;
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     for (int w = 1; w < c->n_streams; w++) {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
@@ -348,8 +351,13 @@ void wsx_caller_destroy(wsx_caller *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int w = 1; w < WSX_MAX_STREAMS; w++)
+    for (int w = 0; w < WSX_MAX_STREAMS; w++) {
         if (c->aux[w]) (void)hipStreamSynchronize(c->aux[w]);
+        if (c->hi[w]) {
+            (void)hipStreamSynchronize(c->hi[w]);
+            (void)hipStreamDestroy(c->hi[w]);
+        }
+    }
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
@@ -913,6 +921,26 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 if ((rc = sched_event(&e))) return rc;
                 HIPCHK(hipEventRecord(e, st));
                 HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e, 0));
+            }
+            if (c->use_hi) {
+                const int w = (int)(ci % n_work);
+                if (!c->hi[w]) {
+                    int least = 0, greatest = 0;
+                    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    HIPCHK(hipStreamCreateWithPriority(&c->hi[w], hipStreamNonBlocking, greatest));
+                }
+                hipStream_t sh = c->hi[w];
+                hipEvent_t e;
+                auto hop = [&](hipStream_t from, hipStream_t to) -> int {
+                    if ((rc = sched_event(&e))) return rc;
+                    HIPCHK(hipEventRecord(e, from));
+                    HIPCHK(hipStreamWaitEvent(to, e, 0));
+                    return WSX_SUCCESS;
+                };
+                if ((rc = hop(st, sh)) || (rc = stage_m1(x, sh)) || (rc = hop(sh, st)) || (rc = stage_f2(x, st)) ||
+                    (rc = hop(st, sh)) || (rc = stage_m2(x, sh)) || (rc = hop(sh, st)))
+                    return rc;
+                continue;
             }
             if ((rc = stage_m1(x, st)) || (rc = stage_f2(x, st)) || (rc = stage_m2(x, st))) return rc;
         }
