@@ -479,3 +479,34 @@ def test_upstream_test_case_real_reads(tmp_path):
     assert fasta[0].splitlines()[1] == str(z['r0_seq'][1])
     gt = run_genotyping_overview(loc, random_state=0)
     assert gt.is_hetero and sorted(gt.alleles, reverse=True) == [44, 40]
+
+
+def test_host_buffer_transfer_rings():
+    """Host-buffer batches of >= 16 MB go through the pinned transfer rings (threaded copy in, asynchronous copies
+    both ways, results collected in pinned memory); smaller ones use plain copies.  Same bytes either way, and a
+    second call on the same handle (ring reuse) repeats them."""
+    locus = synth.make_locus('(AGC)', 16, 5)
+    rng = np.random.default_rng(11)
+    base, revs, _ = synth.batch(locus, 48, (500, 900), 7)
+    sigs, rv = [], []
+    for k in range(3400):  # ~ 2.4 M samples = 19 MB
+        s = base[k % len(base)]
+        sigs.append(s + 0.02 * rng.standard_normal(len(s)))
+        rv.append(revs[k % len(base)])
+    aut = np.array([1 if x else 0 for x in rv], dtype=np.int32)
+    sig, off = pack_signals(sigs)
+    assert sig.nbytes >= 16 << 20
+    hip = HipCaller([locus.template, locus.reverse], [16, 16])
+    r_big, e_big = hip.call(sig, off, aut, want_traces=True, want_seqs=True)
+    r_again, e_again = hip.call(sig, off, aut, want_traces=True, want_seqs=True)
+    assert r_big.tobytes() == r_again.tobytes()
+    half = len(sigs) // 2
+    cut = int(off[half])
+    r_a, e_a = hip.call(sig[:cut], off[:half + 1], aut[:half], want_traces=True, want_seqs=True)
+    r_b, e_b = hip.call(sig[cut:], off[half:] - cut, aut[half:], want_traces=True, want_seqs=True)
+    assert sig[:cut].nbytes < 16 << 20 and sig[cut:].nbytes < 16 << 20
+    assert r_big[:half].tobytes() == r_a.tobytes() and r_big[half:].tobytes() == r_b.tobytes()
+    for key in ('trace1', 'trace2', 'seq1', 'seq2'):
+        assert np.array_equal(e_big[key][:cut], e_a[key]) and np.array_equal(e_big[key][cut:], e_b[key])
+        assert np.array_equal(e_big[key], e_again[key])
+    assert int((r_big['status'] == 0).sum()) > 3000

@@ -227,7 +227,9 @@ __device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
 // A block handles 64 consecutive runs, i.e. one contiguous span of the signal: the span is loaded coalesced into LDS
 // (when it fits) and every thread then walks its own run there.
 #define RS_CAP 1024
-#define RS_GROUPS 4 // grid.y: a read's 64-run groups are dealt round-robin to this many single-wave blocks
+#ifndef RS_GROUPS
+#define RS_GROUPS 4
+#endif //// grid.y: a read's 64-run groups are dealt round-robin to this many single-wave blocks
 __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
 {
     __shared__ double buf[RS_CAP];

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/warpstr_hip.h"
@@ -68,6 +69,118 @@ struct DeviceBuf {
     }
 };
 
+// Host <-> device transfers of caller-owned (pageable) buffers go through a ring of pinned pieces: a copy straight
+// from/to pageable memory blocks the calling thread until the stream reaches it, which serialises the chunks of a batch.
+// Uploads: the piece is filled by a few host threads, then sent with an asynchronous copy.  Downloads: the asynchronous
+// copy lands in the piece; the piece is copied out to the caller's buffer when it is needed again or at the end.
+struct PinRing {
+    static constexpr size_t kPiece = 32u << 20;
+    struct Slot {
+        void *pin = nullptr;
+        hipEvent_t ev = nullptr;
+        void *user_dst = nullptr; // download: where the piece goes once `ev` has passed
+        size_t len = 0;
+        bool busy = false;
+    };
+    std::vector<Slot> slots;
+    size_t next = 0;
+    int copy_threads = 4;
+
+    hipError_t init(int n_slots)
+    {
+        if (!slots.empty()) return hipSuccess;
+        slots.resize(n_slots);
+        for (auto &sl : slots) {
+            hipError_t e = hipHostMalloc(&sl.pin, kPiece, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        if (const char *e = getenv("WSX_COPY_THREADS")) copy_threads = std::max(1, atoi(e));
+        copy_threads = std::min<int>(copy_threads, std::max(1u, std::thread::hardware_concurrency()));
+        return hipSuccess;
+    }
+    void release()
+    {
+        for (auto &sl : slots) {
+            if (sl.ev) (void)hipEventDestroy(sl.ev);
+            if (sl.pin) (void)hipHostFree(sl.pin);
+        }
+        slots.clear();
+    }
+    void host_copy(void *dst, const void *src, size_t len) const
+    {
+        const int nt = len >= (4u << 20) ? copy_threads : 1;
+        if (nt <= 1) {
+            memcpy(dst, src, len);
+            return;
+        }
+        std::vector<std::thread> th;
+        const size_t part = (len / nt + 4095) & ~(size_t)4095;
+        for (int t = 1; t < nt; t++) {
+            const size_t o = std::min(len, part * t), e = std::min(len, part * (t + 1));
+            if (e > o) th.emplace_back([=] { memcpy((char *)dst + o, (const char *)src + o, e - o); });
+        }
+        memcpy(dst, src, std::min(len, part));
+        for (auto &t : th) t.join();
+    }
+    hipError_t settle(Slot &sl)
+    {
+        if (!sl.busy) return hipSuccess;
+        hipError_t e = hipEventSynchronize(sl.ev);
+        if (e != hipSuccess) return e;
+        if (sl.user_dst) host_copy(sl.user_dst, sl.pin, sl.len);
+        sl.busy = false;
+        sl.user_dst = nullptr;
+        return hipSuccess;
+    }
+    hipError_t upload(void *dev_dst, const void *host_src, size_t bytes, hipStream_t s)
+    {
+        for (size_t o = 0; o < bytes; o += kPiece) {
+            Slot &sl = slots[next++ % slots.size()];
+            hipError_t e = settle(sl);
+            if (e != hipSuccess) return e;
+            const size_t len = std::min(kPiece, bytes - o);
+            host_copy(sl.pin, (const char *)host_src + o, len);
+            if ((e = hipMemcpyAsync((char *)dev_dst + o, sl.pin, len, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+            if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return e;
+            sl.busy = true;
+        }
+        return hipSuccess;
+    }
+    hipError_t download(void *host_dst, const void *dev_src, size_t bytes, hipStream_t s)
+    {
+        for (size_t o = 0; o < bytes; o += kPiece) {
+            Slot &sl = slots[next++ % slots.size()];
+            hipError_t e = settle(sl);
+            if (e != hipSuccess) return e;
+            const size_t len = std::min(kPiece, bytes - o);
+            if ((e = hipMemcpyAsync(sl.pin, (const char *)dev_src + o, len, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+            if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return e;
+            sl.busy = true;
+            sl.user_dst = (char *)host_dst + o;
+            sl.len = len;
+        }
+        return hipSuccess;
+    }
+    void discard() // pieces left over by a call that failed half-way: their destinations are gone
+    {
+        for (auto &sl : slots) {
+            if (sl.busy) (void)hipEventSynchronize(sl.ev);
+            sl.busy = false;
+            sl.user_dst = nullptr;
+        }
+    }
+    hipError_t drain()
+    {
+        for (size_t k = 0; k < slots.size(); k++) { // oldest first
+            hipError_t e = settle(slots[(next + k) % slots.size()]);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+};
+
 } // namespace
 
 struct wsx_caller {
@@ -87,8 +200,6 @@ struct wsx_caller {
         DeviceBuf samples, reads, bp, stage_sig, stage_out, reps;
     } work[WSX_MAX_STREAMS];
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
-    hipStream_t hi[WSX_MAX_STREAMS] = {};   // high-priority companions for the short kernels between the fills
-    bool use_hi = false;
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
     int n_streams = 4;
     DeviceBuf meta;
@@ -104,6 +215,9 @@ struct wsx_caller {
     bool have_bases = true; // every automaton came with last_base
     std::vector<hipEvent_t> sched_events;
     size_t sched_used = 0;
+    PinRing ring_up, ring_down; // host-buffer calls only (allocated on first use)
+    void *pinned_res = nullptr; // host-buffer calls: the batch's result records land here first
+    size_t pinned_res_cap = 0;
 };
 
 namespace {
@@ -336,7 +450,6 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipEventCreate(&c->ev_end));
     HIPCHK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    if (const char *e = getenv("WSX_PRIO")) c->use_hi = atoi(e) != 0;
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     for (int w = 1; w < c->n_streams; w++) {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
@@ -351,13 +464,11 @@ void wsx_caller_destroy(wsx_caller *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int w = 0; w < WSX_MAX_STREAMS; w++) {
+    for (int w = 1; w < WSX_MAX_STREAMS; w++)
         if (c->aux[w]) (void)hipStreamSynchronize(c->aux[w]);
-        if (c->hi[w]) {
-            (void)hipStreamSynchronize(c->hi[w]);
-            (void)hipStreamDestroy(c->hi[w]);
-        }
-    }
+    c->ring_up.release();
+    c->ring_down.release();
+    if (c->pinned_res) (void)hipHostFree(c->pinned_res);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
@@ -633,6 +744,33 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     std::vector<Ctx> ctxs(chunks.size());
 
     // Carve the work set of chunk ci, upload its launch order (and, for host buffers, its signal) on stream s.
+    // caller-owned host buffers: big batches go through the pinned rings, small ones use plain (blocking) copies
+    const bool ringed = host && (size_t)(io.offsets[n] - io.offsets[0]) * 8 >= (16u << 20);
+    wsx_result *res_dst = io.results;
+    if (ringed) {
+        HIPCHK(c->ring_up.init(4));
+        HIPCHK(c->ring_down.init(8));
+        c->ring_up.discard();
+        c->ring_down.discard();
+        if (full) {
+            const size_t need = (size_t)n * sizeof(wsx_result);
+            if (need > c->pinned_res_cap) {
+                if (c->pinned_res) (void)hipHostFree(c->pinned_res);
+                c->pinned_res = nullptr;
+                c->pinned_res_cap = 0;
+                HIPCHK(hipHostMalloc(&c->pinned_res, need + need / 4, hipHostMallocDefault));
+                c->pinned_res_cap = need + need / 4;
+            }
+            res_dst = (wsx_result *)c->pinned_res;
+        }
+    }
+    auto h2d = [&](void *dst, const void *src, size_t bytes, hipStream_t s) -> hipError_t {
+        return ringed ? c->ring_up.upload(dst, src, bytes, s) : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    };
+    auto d2h = [&](void *dst, const void *src, size_t bytes, hipStream_t s) -> hipError_t {
+        return ringed ? c->ring_down.download(dst, src, bytes, s) : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    };
+
     auto prepare = [&](size_t ci, hipStream_t s) -> int {
         Ctx &x = ctxs[ci];
         x.ch = chunks[ci];
@@ -659,7 +797,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
 
         if (host) {
-            HIPCHK(hipMemcpyAsync(W.stage_sig.p, io.signal + boff, (size_t)x.ch.samples * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(h2d(W.stage_sig.p, io.signal + boff, (size_t)x.ch.samples * 8, s));
             x.d_sig = (const double *)W.stage_sig.p;
         } else {
             x.d_sig = io.signal + boff;
@@ -845,13 +983,13 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         if (host) {
             const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
             const size_t ns = (size_t)x.ch.samples;
-            HIPCHK(hipMemcpyAsync(io.results + f, x.d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, s));
-            if (io.traces.trace1) HIPCHK(hipMemcpyAsync(io.traces.trace1 + boff, x.d_tr1, ns * 2, hipMemcpyDeviceToHost, s));
-            if (io.traces.trace2) HIPCHK(hipMemcpyAsync(io.traces.trace2 + boff, x.d_tr2, ns * 2, hipMemcpyDeviceToHost, s));
-            if (io.traces.rescaled) HIPCHK(hipMemcpyAsync(io.traces.rescaled + boff, x.d_resc_user, ns * 8, hipMemcpyDeviceToHost, s));
-            if (io.traces.badmask) HIPCHK(hipMemcpyAsync(io.traces.badmask + boff, x.d_badmask, ns, hipMemcpyDeviceToHost, s));
-            if (io.traces.seq1) HIPCHK(hipMemcpyAsync(io.traces.seq1 + boff, x.d_seq1, ns, hipMemcpyDeviceToHost, s));
-            if (io.traces.seq2) HIPCHK(hipMemcpyAsync(io.traces.seq2 + boff, x.d_seq2, ns, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(res_dst + f, x.d_results, (size_t)cnt * sizeof(wsx_result), hipMemcpyDeviceToHost, s));
+            if (io.traces.trace1) HIPCHK(d2h(io.traces.trace1 + boff, x.d_tr1, ns * 2, s));
+            if (io.traces.trace2) HIPCHK(d2h(io.traces.trace2 + boff, x.d_tr2, ns * 2, s));
+            if (io.traces.rescaled) HIPCHK(d2h(io.traces.rescaled + boff, x.d_resc_user, ns * 8, s));
+            if (io.traces.badmask) HIPCHK(d2h(io.traces.badmask + boff, x.d_badmask, ns, s));
+            if (io.traces.seq1) HIPCHK(d2h(io.traces.seq1 + boff, x.d_seq1, ns, s));
+            if (io.traces.seq2) HIPCHK(d2h(io.traces.seq2 + boff, x.d_seq2, ns, s));
         }
         return WSX_SUCCESS;
     };
@@ -879,7 +1017,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         rc2 = do_traceback(x, pass1_mask, x.d_tr1, status, s);
         if (rc2) return rc2;
         if (host) {
-            HIPCHK(hipMemcpyAsync(io.trace + boff, x.d_tr1, (size_t)x.ch.samples * 2, hipMemcpyDeviceToHost, s));
+            HIPCHK(d2h(io.trace + boff, x.d_tr1, (size_t)x.ch.samples * 2, s));
             if (io.end_cost) HIPCHK(hipMemcpyAsync(io.end_cost + f, x.d_endcost_user, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
             if (io.status) HIPCHK(hipMemcpyAsync(io.status + f, x.d_status_user, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
             if (io.last_row)
@@ -922,26 +1060,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 HIPCHK(hipEventRecord(e, st));
                 HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e, 0));
             }
-            if (c->use_hi) {
-                const int w = (int)(ci % n_work);
-                if (!c->hi[w]) {
-                    int least = 0, greatest = 0;
-                    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                    HIPCHK(hipStreamCreateWithPriority(&c->hi[w], hipStreamNonBlocking, greatest));
-                }
-                hipStream_t sh = c->hi[w];
-                hipEvent_t e;
-                auto hop = [&](hipStream_t from, hipStream_t to) -> int {
-                    if ((rc = sched_event(&e))) return rc;
-                    HIPCHK(hipEventRecord(e, from));
-                    HIPCHK(hipStreamWaitEvent(to, e, 0));
-                    return WSX_SUCCESS;
-                };
-                if ((rc = hop(st, sh)) || (rc = stage_m1(x, sh)) || (rc = hop(sh, st)) || (rc = stage_f2(x, st)) ||
-                    (rc = hop(st, sh)) || (rc = stage_m2(x, sh)) || (rc = hop(sh, st)))
-                    return rc;
-                continue;
-            }
             if ((rc = stage_m1(x, st)) || (rc = stage_f2(x, st)) || (rc = stage_m2(x, st))) return rc;
         }
         for (int w = 1; w < n_work; w++) { // join: the handle's stream continues only after the internal ones drained
@@ -952,7 +1070,14 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     HIPCHK(hipEventRecord(c->ev_meta, main_st));
     HIPCHK(hipEventRecord(c->ev_end, main_st));
     c->timing_valid = true;
-    if (host) HIPCHK(hipStreamSynchronize(main_st));
+    if (host) {
+        HIPCHK(hipStreamSynchronize(main_st));
+        if (ringed) {
+            HIPCHK(c->ring_up.drain());
+            HIPCHK(c->ring_down.drain());
+            if (full) c->ring_up.host_copy(io.results, c->pinned_res, (size_t)n * sizeof(wsx_result));
+        }
+    }
     return WSX_SUCCESS;
 }
 
