@@ -506,7 +506,28 @@ def test_host_buffer_transfer_rings():
     r_b, e_b = hip.call(sig[cut:], off[half:] - cut, aut[half:], want_traces=True, want_seqs=True)
     assert sig[:cut].nbytes < 16 << 20 and sig[cut:].nbytes < 16 << 20
     assert r_big[:half].tobytes() == r_a.tobytes() and r_big[half:].tobytes() == r_b.tobytes()
-    for key in ('trace1', 'trace2', 'seq1', 'seq2'):
+    for key in ('trace1', 'trace2'):
         assert np.array_equal(e_big[key][:cut], e_a[key]) and np.array_equal(e_big[key][cut:], e_b[key])
         assert np.array_equal(e_big[key], e_again[key])
+    small = {k: np.concatenate([e_a[k], e_b[k]]) for k in ('seq1', 'seq2')}
+    for i in np.flatnonzero(r_big['status'] == 0):  # a sequence occupies the first len bytes of its read's span
+        for key, ln in (('seq1', 'len1'), ('seq2', 'len2')):
+            o, n = int(off[i]), int(r_big[ln][i])
+            assert np.array_equal(e_big[key][o:o + n], small[key][o:o + n])
+            assert np.array_equal(e_big[key][o:o + n], e_again[key][o:o + n])
     assert int((r_big['status'] == 0).sum()) > 3000
+
+
+def test_two_kernel_segmentation_fallback():
+    """Reads too long for the fused segmentation kernel's LDS tables take the t-statistics through HBM and scan the
+    chunks one thread each; the knob forces that path for the golden cases (own process: the knob is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, WSX_SEGMENT_TWO_KERNELS='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
+                          'test_call_matches_golden or test_upstream_test_case_real_reads'],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout
