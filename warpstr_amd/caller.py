@@ -288,16 +288,20 @@ class CallerWrapper:
         aut = np.array([1 if r else 0 for r in reverses], dtype=np.int32)
         res, extra = self.hip.call(signal, offsets, aut, want_seqs=True)
         out: List[CallerResult] = []
+        # plain Python lists and one bytes object per pass: per-read numpy scalar access would dominate big batches
+        status, offs = res['status'].tolist(), np.asarray(offsets).tolist()
+        len1, len2 = res['len1'].tolist(), res['len2'].tolist()
+        cost1, cost2 = res['cost1'].tolist(), res['cost2'].tolist()
+        b1, b2 = extra['seq1'].tobytes(), extra['seq2'].tobytes()
         for i, name in enumerate(names):
-            st = int(res['status'][i])
+            st = status[i]
             if st != 0:
                 msg = f'read {name}: caller status {_lib.READ_STATUS.get(st, st)}'
                 if self.on_error == 'raise':
                     raise ReadCallError(msg)
                 out.append(CallerResult('', float('nan'), '', float('nan')))
                 continue
-            o = int(offsets[i])
-            seq = extra['seq1'][o:o + int(res['len1'][i])].tobytes().decode('ascii')
-            rseq = extra['seq2'][o:o + int(res['len2'][i])].tobytes().decode('ascii')
-            out.append(CallerResult(seq=seq, cost=float(res['cost1'][i]), resc_seq=rseq, resc_cost=float(res['cost2'][i])))
+            o = offs[i]
+            out.append(CallerResult(seq=b1[o:o + len1[i]].decode('ascii'), cost=cost1[i],
+                                    resc_seq=b2[o:o + len2[i]].decode('ascii'), resc_cost=cost2[i]))
         return out
