@@ -536,8 +536,25 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
     int j = A.endstate;
     int i = T - 1;
     int nr = 0;
-    int last_state = -1;
     const uint16_t *pos = A.pos;
+    // Run records are written 16 at a time: a 2-byte and a 4-byte store per run, from 64 lanes that each own a
+    // different read, would miss in L2 on nearly every store (and turn into partial-sector HBM writes).  The open run
+    // stays in registers (its start moves while the walk stays in the same state); finished runs queue up in LDS.
+    __shared__ uint16_t q_state[16][64];
+    __shared__ int32_t q_start[16][64];
+    const int lane = threadIdx.x;
+    int open_state = -1, open_start = 0;
+    auto push = [&](int state, int start) {
+        q_state[nr & 15][lane] = (uint16_t)state;
+        q_start[nr & 15][lane] = start;
+        nr++;
+        if ((nr & 15) == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) run_state[nr - 16 + e] = q_state[e][lane];
+#pragma unroll
+            for (int e = 0; e < 16; e++) run_start[nr - 16 + e] = q_start[e][lane];
+        }
+    };
     while (true) {
         const int q = pos ? pos[j] : j; // where state j's pointer words live (slot q/64, lane q%64)
         const uint32_t *col = bp + (size_t)(q >> 6) * 64 + (q & 63);
@@ -575,13 +592,12 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
                 ptr = (int)((wm >> (rr * PB)) & PM);
             }
         }
-        if (j == last_state) {
-            run_start[nr - 1] = start;
+        if (j == open_state) {
+            open_start = start;
         } else {
-            run_state[nr] = (uint16_t)j;
-            run_start[nr] = start;
-            nr++;
-            last_state = j;
+            if (open_state >= 0) push(open_state, open_start);
+            open_state = j;
+            open_start = start;
         }
         if (wm == 0) break;
         int back = m;
@@ -590,6 +606,11 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
         else j = pred_idx[pred_ptr[j] + ptr - 1];
         i = start - back;
         if (i < 0) break; // cannot happen: pointers are only set on rows >= m
+    }
+    if (open_state >= 0) push(open_state, open_start);
+    for (int e = nr & ~15; e < nr; e++) {
+        run_state[e] = q_state[e & 15][lane];
+        run_start[e] = q_start[e & 15][lane];
     }
     a.n_runs[lr] = nr;
 }
