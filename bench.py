@@ -77,8 +77,9 @@ def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
             'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
 
 
-VALU_INSTS_PER_ROW = 13.05   # SQ_INSTS_VALU per DP row per wave (profiles/r01_pmc_valu_per_kernel.txt)
-N_SIMD, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 2.4e9, 1.93e9
+VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s2_pmc.json); the formulation's floor is 10
+LDS_CYCLES_PER_ROW = 10.0    # 2 ds_read_b64 (2 cycles each) + 1 ds_write_b64 (~6): MI355X_MICROARCH.md, LDS table
+N_SIMD, N_CU, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 256, 2.4e9, 1.89e9
 
 
 def valu_roofline(tm1, n, T):
@@ -89,10 +90,14 @@ def valu_roofline(tm1, n, T):
     rows = 2.0 * n * T / launches                      # wave-rows per launch (one wave per read)
     achieved = rows * VALU_INSTS_PER_ROW / (ms * 1e-3)  # wave-instructions per second
     peak = N_SIMD * CLK_MAX_HZ / 4.0
+    lds = rows * LDS_CYCLES_PER_ROW / (ms * 1e-3)       # LDS-pipe cycles per second, all CUs
     return {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'wave64 VALU instr/s',
             'frac': achieved / peak, 'frac_at_observed_clock': achieved / (N_SIMD * CLK_OBSERVED_HZ / 4.0),
             'launch_ms_alone': ms, 'launches': launches,
-            'note': 'peak = 1024 SIMDs x 2.4 GHz / 4 cycles; the chip holds ~1.93 GHz under this fp64 load (GRBM_GUI_ACTIVE)'}
+            'lds_pipe': {'cycles_per_row': LDS_CYCLES_PER_ROW, 'frac': lds / (N_CU * CLK_MAX_HZ),
+                         'frac_at_observed_clock': lds / (N_CU * CLK_OBSERVED_HZ)},
+            'note': 'peak = 1024 SIMDs x 2.4 GHz / 4 cycles; the chip holds ~1.89 GHz under this fp64 load '
+                    '(GRBM_GUI_ACTIVE); the LDS pipe (one per CU: predecessor exchange) is loaded as heavily as the VALU'}
 
 
 def main():
@@ -186,9 +191,9 @@ def main():
         algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         cells_per_s = reads_per_launch * T * S / (launch_ms * 1e-3)
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json), same workload only
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s2_traffic.json), same workload only
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01s2_traffic.json')) as f:
                 tj = json.load(f)
             if tj['workload']['samples'] == T:
                 traffic = tj['hbm_bytes_per_launch'] / tj['workload']['reads'] * reads_per_launch
@@ -208,10 +213,10 @@ def main():
                          'reads_per_launch': reads_per_launch,
                          'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
             'valu_roofline': valu_roofline(tm1, n, T),
-            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': 13.05,
-                     'note': 'PMC: SQ_INSTS_VALU = 13.05 per row per wave (floor of this formulation: 12); the fill '
-                             'launches overlap other chunks\' kernels on 4 streams, so launch_ms is a co-scheduled '
-                             'duration (6.3-6.5 ms per 100k reads when the kernel runs alone)'},
+            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': VALU_INSTS_PER_ROW,
+                     'note': 'PMC: SQ_INSTS_VALU = 10.51 per row per wave (floor of this formulation: 10 = 6 adds, 2 '
+                             'compares, 2 mins); the fill launches overlap other chunks\' kernels on 4 streams, so '
+                             'launch_ms is a co-scheduled duration (5.3-5.4 ms per 100k reads when the kernel runs alone)'},
             'dp_kernel_ms_per_step': tm['dp_kernel_ms'], 'device_ms_per_step': tm['total_ms'],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,6 +34,9 @@ def run(name, pattern, fl, T, n, seed=1, max_states=None):
           f'fill={tm["dp_kernel_ms"]:.2f}ms device={tm["total_ms"]:.2f}ms host_call={dt*1e3:.1f}ms '
           f'fill_cells/s={cells/tm["dp_kernel_ms"]/1e-3:.3g} reads/s(device)={n/tm["total_ms"]/1e-3:.3g}', flush=True)
 
+if len(sys.argv) > 1 and sys.argv[1] == 'cfg3':  # just the headline shape (fill-kernel experiments)
+    run('cfg3', '(AGC)AACAGCCGCCAC(CGC)', 19, 2000, int(sys.argv[2]) if len(sys.argv) > 2 else 50000, seed=2024, max_states=64)
+    sys.exit(0)
 run('cfg2', '(AGC)', 16, 1500, 20000)
 run('cfg3', '(AGC)AACAGCCGCCAC(CGC)', 19, 2000, 20000, seed=2024, max_states=64)
 run('cfg5', '((CAGG){CAGM})(CAGA)(CA)', 40, (500, 5000), 8000)

@@ -12,7 +12,7 @@
 // first predecessor wins ties) because the re-computation is exact.
 //
 // Kernels
-//   dtw_fill_fast<M,K,F>        register-resident fill for min_values_per_state M in {3,4,5}: one 64-lane wavefront per
+//   dtw_fill_fast<M,K,F,FL>     register-resident fill for min_values_per_state M in {3,4,5}: one 64-lane wavefront per
 //       read; state j lives in lane j%64, slot j/64 (K slots per lane); one row (= one signal sample) per
 //       step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
 //       g_1..g_{M-1} that runs one row AHEAD of the DP:
@@ -21,17 +21,24 @@
 //       of row i:  E_j(i+2) = g_{M-1} (unmasked row) or g_{M-2} (masked row).  E values are exchanged through LDS (one
 //       8-byte slot per state, double buffered by row parity); a consumer's LDS reads for row i+1 are issued
 //       during row i, a full row before they are needed.  Absent predecessors point at a slot holding +inf.
-//       Back-pointers are packed PB bits per row per state into 32-bit words (R rows per word) and written
-//       coalesced (256 B per wave-store) to a per-read HBM scratch.
-//   dtw_fill_generic            any m >= 2, fan-in <= 15: last m+1 rows of D in an LDS ring, direct restatement.
-//   traceback_kernel<PB>        one THREAD per read (the walk is a dependent pointer chase of ~#transitions
-//       steps; reads are the parallel axis): scans a state's pointer words downwards with count-leading-zeros
-//       to jump over runs of "stay", emits the run-length state list in reverse time order.
+//       The signal arrives through the scalar data cache (s_load_dwordx16: eight samples per load, used as SGPR
+//       operands).  Back-pointers never touch the vector ALU beyond the compare itself: "candidate f beat everything
+//       before it" for the 64 states of a slot is one v_cmp_lt_f64 into an SGPR pair, and that pair -- one bit per
+//       state -- is stored as it is with a scalar store (s_store_dwordx2/x4).  Per row the read gets NM = F + (K-1)*FL
+//       64-bit masks in HBM.
+//   dtw_fill_generic            any m >= 2, fan-in <= 15: last m+1 rows of D in an LDS ring, direct restatement;
+//       4-bit numeric pointers packed 8 rows per 32-bit word per state.
+//   traceback_stream_kernel<F>  mask layout, K = 1: one THREAD per read streams the read's mask rows downwards (the
+//       rows visited do not depend on the path when there is one slot), tests its current state's bit per row.
+//   traceback_mask_kernel<F,FL> mask layout, K > 1: one wavefront per read, 64 rows of one slot per load, ballots.
+//   traceback_generic_kernel    word layout of dtw_fill_generic, one thread per read.
+//       All three emit the run-length state list in reverse time order.
 //   expand_trace_kernel         optional: per-sample state ids from the run list (coalesced, wave per read).
 //
-// Roofline: min-plus recurrence, no MFMA.  Per row and state (F = 2): 6 fp64 adds, 2 fp64 compares, 6 selects.
-// HBM traffic per read and pass: 8T (signal) + T*K*64*PB/8 (pointer scratch, written once, read sparsely by the
-// traceback) + 6*runs; the fill is bound by fp64 VALU issue (a wave64 fp64 op occupies a SIMD for 4 cycles).
+// Roofline: min-plus recurrence, no MFMA.  Per row and 64 states (F = 2): 6 v_add_f64, 2 v_cmp_lt_f64, 2 v_min_f64 on the
+// vector ALU; 2 ds_read_b64 + 1 ds_write_b64 on the LDS pipe (10 LDS cycles on gfx950, as many as the VALU needs: the two
+// pipes are balanced); 1 scalar store.  HBM traffic per read and pass: 8T (signal) + 8*NM*T (masks, written once, read once
+// by the traceback) + 6*runs.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -41,6 +48,7 @@
 namespace {
 
 constexpr double kInf = __builtin_huge_val();
+#define WSX_AS4 __attribute__((address_space(4)))
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -69,6 +77,13 @@ __device__ __forceinline__ ReadGeom geom(const PassArgs &a, int slot)
     return g;
 }
 
+// Back-pointer masks of a read: NM 64-bit masks per row, rows consecutive, first row 16-byte aligned (one spare row per
+// read absorbs the rounding).
+__device__ __forceinline__ uint64_t *mask_rows(const PassArgs &a, long long off, int lr, int NM)
+{
+    return (uint64_t *)a.bp + ((((size_t)off + (size_t)lr) * (size_t)NM + 1) & ~(size_t)1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident fill (see file header), for min_values_per_state M in {3, 4, 5}.
 // ------------------------------------------------------------------------------------------------
@@ -78,8 +93,6 @@ struct FillState {
     double g[K][M];             // g[k][s], s = 1..M-1: the dwell pipeline (g[k][0] unused); always indexed statically
     double e0[K][F], e1[K][F];                       // predecessor exports: row i uses e[i&1], loads e[(i+1)&1]
     int paddr[K][F];                                  // LDS double index of predecessor f's export slot
-    uint32_t bpw[K];                                  // pointer bits of the current word, newest row in the low bits
-    uint32_t cutclr[K];                               // ~((1<<PB)-1) for corner-cut states, ~0 otherwise
     bool cutf[K];
 };
 
@@ -101,26 +114,62 @@ __device__ __forceinline__ double min_f64(double a, double b)
     return r;
 }
 
-// bits = (bits << 1) | (cand < best): compare into VCC, then add-with-carry bits+bits+VCC.
-__device__ __forceinline__ void push_lt(uint32_t &bits, double cand, double best)
+// Back-pointers are wave masks.  "cand < best-so-far" for all 64 states of a slot is ONE v_cmp_lt_f64 whose result is a
+// 64-bit lane mask in an SGPR pair -- already the packed form (one bit per state), so no VALU op is spent on packing.
+// The pair leaves the wave through the scalar memory pipe (s_store_dwordx2: SMEM issue, not VALU issue).
+__device__ __forceinline__ uint64_t lt_mask(double cand, double best)
 {
-    asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(cand), "v"(best) : "vcc");
+    return __builtin_amdgcn_fcmp(cand, best, 4 /* ordered less-than */);
 }
+
+template <int BYTE_OFF>
+__device__ __forceinline__ void store_mask(uint64_t m, uint64_t *base)
+{
+    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(base), "n"(BYTE_OFF) : "memory");
+}
+
+template <int BYTE_OFF> // two masks, 16-byte aligned destination
+__device__ __forceinline__ void store_mask_pair(uint64_t m0, uint64_t m1, uint64_t *base)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)};
+    asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(base), "n"(BYTE_OFF) : "memory");
+}
+
+// the NM masks of group row R, at base + R*NM (base = the group's first row); pairs go out as one 16-byte store when
+// the row size keeps them 16-byte aligned
+template <int NM, int R, int Q = 0>
+__device__ __forceinline__ void store_row_masks(const uint64_t (&mk)[NM], uint64_t *base)
+{
+    if constexpr (Q < NM) {
+        if constexpr (NM % 2 == 0 && Q + 1 < NM) {
+            store_mask_pair<(R * NM + Q) * 8>(mk[Q], mk[Q + 1], base);
+            store_row_masks<NM, R, Q + 2>(mk, base);
+        } else {
+            store_mask<(R * NM + Q) * 8>(mk[Q], base);
+            store_row_masks<NM, R, Q + 1>(mk, base);
+        }
+    }
+}
+
+// masks per row: slot 0 holds F, every further slot FL; mask (k, f) is entry mask_index(k, f) of the row record
+template <int F, int FL>
+__host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f : F + (k - 1) * FL + f; }
 
 // One DP row for all K slots.  PAR = row parity (selects LDS buffers and the e0/e1 roles at compile time),
 // FORCED: rows 1..3 (D stays inf, only the pipeline advances), CUT: corner-cut rows.
 //   top of row i : issue the LDS reads of E(i+1) (written at the end of row i-1) -- consumed in row i+1
 //   body         : D[i,:] from the exports E(i) read one row earlier
 //   end of row i : write E(i+2)
-// Back-pointer encoding: F bits per row (bit f set <=> predecessor f beat everything before it in the
-// reference's order: stay, pred 0, pred 1, ..); the arg-min is the highest set bit; 0 = stay.
+// Back-pointer encoding: per row, slot and candidate f one 64-bit mask (bit = lane): set <=> predecessor f beat everything
+// before it in the reference's order (stay, pred 0, pred 1, ..); the arg-min is the highest f whose bit is set; none = stay.
 // FL < F ("split"): only slot 0 considers F predecessors per state, the other slots FL (the host places every state
 // with more than FL predecessors in slot 0; such states are few: loop entries, IUPAC alternatives).  FL == F: uniform.
 template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT>
-__device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext)
+__device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext,
+                                       uint64_t (&mk)[F + (K - 1) * FL], const uint64_t (&cutm)[K])
 {
-    constexpr int PB = (F <= 2) ? 2 : 4;
-    constexpr int EXW = K * 64 + 1;
+    constexpr int EXW = K * 64 + 32;
     constexpr int wbuf = PAR * EXW;       // E(i+2) goes to the buffer of parity i
     constexpr int rbuf = (1 - PAR) * EXW; // E(i+1) lives in the buffer of parity i+1
 #pragma unroll
@@ -135,34 +184,25 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double best = st.g[k][1];
+        const int Fk = (k > 0) ? FL : F; // folds to a constant once the slot loop is unrolled
         if (FORCED) {
             best = kInf;
-            st.bpw[k] <<= PB;
+#pragma unroll
+            for (int f = 0; f < F; f++)
+                if (f < Fk) mk[mask_index<F, FL>(k, f)] = 0;
         } else {
-            const int Fk = (k > 0) ? FL : F; // folds to a constant once the slot loop is unrolled
-            if (PB > Fk) st.bpw[k] <<= (PB - Fk);
-            // candidates in the reference's order; bit f lands at position f of this row's field, so push the
-            // highest predecessor first
-            double cand[F], run[F + 1];
-            run[0] = best;
+            // candidates in the reference's order: stay, then the predecessors
 #pragma unroll
             for (int f = 0; f < F; f++) {
                 if (f < Fk) {
-                    cand[f] = add_abs(PAR ? st.e1[k][f] : st.e0[k][f], st.acur[k]);
-                    run[f + 1] = min_f64(run[f], cand[f]);
-                } else {
-                    cand[f] = kInf;
-                    run[f + 1] = run[f];
+                    const double cand = add_abs(PAR ? st.e1[k][f] : st.e0[k][f], st.acur[k]);
+                    uint64_t lt = lt_mask(cand, best);
+                    if (CUT) lt &= ~cutm[k];
+                    mk[mask_index<F, FL>(k, f)] = lt;
+                    best = min_f64(best, cand);
                 }
             }
-#pragma unroll
-            for (int f = F - 1; f >= 0; f--)
-                if (f < Fk) push_lt(st.bpw[k], cand[f], run[f]);
-            best = run[F];
-            if (CUT) {
-                best = st.cutf[k] ? kInf : best;
-                st.bpw[k] &= st.cutclr[k];
-            }
+            if (CUT) best = st.cutf[k] ? kInf : best;
         }
         const double an = snext - st.v[k];
 #pragma unroll
@@ -187,12 +227,9 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
-    constexpr int PB = (F <= 2) ? 2 : 4;
-    constexpr int R = 32 / PB;
-    constexpr int EXW = K * 64 + 1; // export slots per buffer (+1: the +inf slot)
-    constexpr int WLDS = 2 * EXW + 136; // doubles of LDS per wave: two export buffers + two 64-sample signal blocks
-                                        // (+8: samples 0..7 of the even block mirrored at 128..135, so that eight
-                                        // consecutive samples never wrap)
+    constexpr int NM = F + (K - 1) * FL; // back-pointer masks per row
+    constexpr int EXW = K * 64 + 32; // export slots per buffer (+32 slots that hold +inf, one per bank pair)
+    constexpr int WLDS = 2 * EXW; // doubles of LDS per wave: two export buffers
     extern __shared__ double lds[];
 
     const int lane = threadIdx.x & 63;
@@ -214,8 +251,7 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
     }
     const double *sig = a.signal + off;
     double *ex = lds + wib * WLDS;
-    double *sb = ex + 2 * EXW; // signal blocks: sample q lives at sb[q & 127]
-    uint32_t *bp = a.bp + (size_t)(off / R + lr) * (K * 64);
+    uint64_t *bp = mask_rows(a, off, lr, NM); // row i's masks at bp[i*NM ..]
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     const int nmw = cdiv(T, 32);
 
@@ -227,6 +263,7 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
     if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
     const int cut_from = cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll);
     int sid[K]; // state handled at position k*64 + lane (-1: none)
+    uint64_t cutm[K]; // lanes of slot k that the corner cut removes
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int q = k * 64 + lane;
@@ -239,22 +276,15 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
         const bool valid = j >= 0;
         st.v[k] = valid ? A.value[j] : 0.0;
         st.cutf[k] = valid && ((long long)A.seq_idx[j] < after_repeat);
-        st.cutclr[k] = st.cutf[k] ? ~((1u << PB) - 1u) : ~0u;
-        const int pp = valid ? A.pred_ptr[j] : 0;
-        const int nf = valid ? (A.pred_ptr[j + 1] - pp) : 0;
+        cutm[k] = __ballot(st.cutf[k]);
+        // LDS slot of predecessor f's export; absent predecessors point at a +inf slot that the host chose so that the
+        // read is free of bank conflicts (wsx_api.hip: fill_paddr)
 #pragma unroll
-        for (int f = 0; f < F; f++) {
-            int pa = EXW - 1; // the +inf slot
-            if (f < nf) {
-                const int p = A.pred_idx[pp + f];
-                pa = A.pos ? A.pos[p] : p;
-            }
-            st.paddr[k][f] = pa;
-        }
+        for (int f = 0; f < F; f++) st.paddr[k][f] = A.paddr[(k * WSX_MAX_F + f) * 64 + lane];
     }
-    if (lane == 0) {
-        ex[EXW - 1] = kInf;
-        ex[2 * EXW - 1] = kInf;
+    if (lane < 32) {
+        ex[K * 64 + lane] = kInf;
+        ex[EXW + K * 64 + lane] = kInf;
     }
 
     // ---- row 0 (caller.py:201-208) -----------------------------------------------------------
@@ -272,7 +302,6 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
         st.g[k][1] = d0 + fabs(st.acur[k]);
 #pragma unroll
         for (int q = 2; q < M; q++) st.g[k][q] = kInf;
-        st.bpw[k] = 0;
         ex[0 * EXW + k * 64 + lane] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
         ex[1 * EXW + k * 64 + lane] = kInf;
 #pragma unroll
@@ -282,92 +311,73 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
         }
     }
 
-    // Signal: 64 samples per coalesced 512-B load, parked in LDS (two blocks) and broadcast to the wave by a
-    // same-address ds_read -- no VALU involved.  Row i consumes s_{i+1}; it is read one row early.
-    auto clampi = [&](int x) { return x < T ? x : T - 1; };
-    sb[lane] = sig[clampi(lane)];
-    if (lane < 8) sb[128 + lane] = sb[lane];
-    double nxt = sig[clampi(64 + lane)];
-    __builtin_amdgcn_wave_barrier();
-    double s_even = 0.0, s_odd = 0.0; // s_q for the even / odd q most recently read
-    s_even = sb[2];                   // row 1 consumes s_2
+    // Signal: the wave reads its samples through the scalar data cache.  The pointer is cast to the constant address
+    // space, so the uniform loads below become s_load_dwordx16 -- eight samples per instruction, straight into SGPRs --
+    // and the adds take them as scalar operands: no LDS traffic and no VALU op for the broadcast.  (The signal is
+    // read-only for the whole launch.)  A vector load of the lines one block ahead only warms L2 for those scalar loads.
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    typedef d8 d8u __attribute__((aligned(8)));
+    const WSX_AS4 double *cs = (const WSX_AS4 double *)sig;
     const int last = T - 1;
+    auto sample = [&](int q) -> double { return cs[q < T ? q : last]; };
+    auto clampi = [&](int x) { return x < T ? x : last; };
+    double warm = sig[clampi(64 + lane)];
 
-    for (int b = 0; b * 64 - 1 <= last; b++) {
-        sb[((b + 1) & 1) * 64 + lane] = nxt; // block b+1 (row 64b+62 reads s_{64b+64} ahead)
-        if (((b + 1) & 1) == 0 && lane < 8) sb[128 + lane] = nxt;
-        nxt = sig[clampi((b + 2) * 64 + lane)];
-        __builtin_amdgcn_wave_barrier();
-        const int base = b * 64 - 1;
-        int lo = base, hi = b * 64 + 63; // rows [lo, hi)
+    for (int b = 0; b * 64 <= last; b++) {
+        asm volatile("" ::"v"(warm)); // the previous block's warm-up load has landed long ago: no stall
+        warm = sig[clampi((b + 2) * 64 + lane)];
+        const int base = b * 64;
+        int lo = base, hi = base + 64; // rows [lo, hi)
         if (lo < 1) lo = 1;
         if (hi > T) hi = T;
 
-        // bm: bit t <=> row base+t exports for a MASKED row (mask bit of sample base+t+2 = 64b+1+t)
+        // bm: bit t <=> row base+t exports for a MASKED row (mask bit of sample base+t+2)
         unsigned long long bm = 0;
         if (maskw) {
             const int w0 = 2 * b;
             const unsigned long long m0 = w0 < nmw ? maskw[w0] : 0u, m1 = w0 + 1 < nmw ? maskw[w0 + 1] : 0u,
                                      m2 = w0 + 2 < nmw ? maskw[w0 + 2] : 0u;
-            bm = ((m0 | (m1 << 32)) >> 1) | ((m2 & 1ull) << 63);
+            bm = ((m0 | (m1 << 32)) >> 2) | ((m2 & 3ull) << 62);
             bm = ((unsigned long long)(unsigned)rfl((int)(bm >> 32)) << 32) | (unsigned)rfl((int)bm);
         }
 
-        // one row, everything wave-uniform except the per-lane state
-        // s_new = s_{i+2}, prefetched (parity of i) while the row consumes s_{i+1} (other parity)
-        auto row = [&](auto par, auto forced, auto cut, auto msk, int i, double s_new) {
+        // one row, everything wave-uniform except the per-lane state; snext = s_{i+1}
+        auto row = [&](auto par, auto forced, auto cut, auto msk, auto rc, uint64_t *gp, double snext) {
             constexpr int PAR = decltype(par)::value;
+            constexpr int R = decltype(rc)::value; // row R of the group whose first row's masks are at gp
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
-            const double snext = PAR ? s_even : s_odd;
-            if (PAR) s_odd = s_new;
-            else s_even = s_new;
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext);
-            if ((i % R) == R - 1 || i == last) {
-                // word complete (row r of the word sits at bits PB*(R-1-r)); left-align a partial last word
-                const int wi = i / R;
-                const int fill = (R - 1 - (i % R)) * PB;
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    bp[((size_t)wi * K + k) * 64 + lane] = st.bpw[k] << fill;
-                    st.bpw[k] = 0;
-                }
-            }
+            uint64_t mk[NM];
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext, mk, cutm);
+            if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
         };
-        // rows [plo, phi) with constant compile-time flags.  Rows come two per iteration (the even/odd register roles
-        // then need no copies); for K <= 2, aligned groups of eight rows share ONE LDS address computation for their
-        // signal samples (immediate offsets 0..56 from it).
+        // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
+        // 64-byte scalar load; the rows before and after such groups load theirs one by one
         auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
             using P0 = std::integral_constant<int, 0>;
             using P1 = std::integral_constant<int, 1>;
+            using R0 = std::integral_constant<int, 0>;
+            auto one = [&](int r) {
+                uint64_t *gp = bp + (size_t)(unsigned)r * NM;
+                if (r & 1) row(P1{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+                else row(P0{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+            };
             int i = plo;
-            if (i < phi && (i & 1)) {
-                row(P1{}, forced, cut, msk, i, sb[(i + 2) & 127]);
-                i++;
+            for (; i < phi && (i & 7); i++) one(i);
+            for (; i + 8 <= phi && i + 8 < T; i += 8) {
+                const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
+                uint64_t *gp = bp + (size_t)(unsigned)i * NM;
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 2>{}, gp, v[2]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 3>{}, gp, v[3]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 4>{}, gp, v[4]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 5>{}, gp, v[5]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 6>{}, gp, v[6]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 7>{}, gp, v[7]);
             }
-            if constexpr (K <= 2) {
-                for (; i + 1 < phi && (i & 7); i += 2) {
-                    row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
-                    row(P1{}, forced, cut, msk, i + 1, sb[(i + 3) & 127]);
-                }
-                for (; i + 8 <= phi; i += 8) {
-                    const double *sg = sb + ((i + 2) & 127); // <= 122: sg[0..7] stays inside the mirrored buffer
-                    row(P0{}, forced, cut, msk, i, sg[0]);
-                    row(P1{}, forced, cut, msk, i + 1, sg[1]);
-                    row(P0{}, forced, cut, msk, i + 2, sg[2]);
-                    row(P1{}, forced, cut, msk, i + 3, sg[3]);
-                    row(P0{}, forced, cut, msk, i + 4, sg[4]);
-                    row(P1{}, forced, cut, msk, i + 5, sg[5]);
-                    row(P0{}, forced, cut, msk, i + 6, sg[6]);
-                    row(P1{}, forced, cut, msk, i + 7, sg[7]);
-                }
-            }
-            for (; i + 1 < phi; i += 2) {
-                row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
-                row(P1{}, forced, cut, msk, i + 1, sb[(i + 3) & 127]);
-            }
-            if (i < phi) row(P0{}, forced, cut, msk, i, sb[(i + 2) & 127]);
+            for (; i < phi; i++) one(i);
         };
         // a phase, split into maximal runs of equal mask bit so that the row code is branch-free
         auto phase = [&](auto forced, auto cut, int plo, int phi) {
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
         if (a.last_row && j >= 0) a.last_row[(size_t)lr * a.last_row_stride + j] = st.d[k];
     }
     if (lane == 0 && !a.check_status) a.status[lr] = 0;
+    asm volatile("s_dcache_wb" ::: "memory"); // scalar stores sit in the scalar data cache until written back
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,16 +514,264 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Traceback: one thread per read.
-//   bp words: word (wi, j) at bp[(wi*K + j/64)*64 + j%64], PB bits per row, R = 32/PB rows per word.
-// Runs are appended in reverse time order: run_state[q], run_start[q]; adjacent equal states merge
-// (self-loop states), matching the run-length encoding of the trace (caller.py:58-60).
+// Traceback over the mask layout of dtw_fill_fast: one wavefront per read.
+//   row i of the read holds NM 64-bit masks at bp[i*NM + mask_index(k, f)]; bit = lane of the state in slot k.
+// A block is 64 consecutive rows (64b .. 64b+63) of ONE slot, one row per lane: a coalesced load.  Whether the state
+// at (slot, bit) was entered at a row is that row's lane testing bit `bit`; a ballot turns the block into a 64-row
+// history of the state and count-leading-zeros finds the latest entry at or below the current row.  Successive states
+// that live in the same slot are walked without touching memory (with K = 1 a block serves every transition inside
+// its 64 rows), and the two blocks below are already in flight while a block is walked.  The walk runs in position
+// space (slot*64 + lane): per lane the wave keeps its position's predecessor positions (pred4) and state id, read
+// with v_readlane -- no memory access per transition.  Runs are appended in reverse time order: run_state[q],
+// run_start[q]; adjacent equal states merge, matching the run-length encoding of the trace (caller.py:58-60).
 // ------------------------------------------------------------------------------------------------
-// ENC = 1: bit-per-predecessor fields, row r of a word at bits PB*(R-1-r) (dtw_fill_fast);
-// ENC = 0: numeric pointer fields, row r at bits PB*r (dtw_fill_generic).
-template <int PB, int ENC>
-__global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
+template <int F, int FL>
+__global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
 {
+    const int lane = threadIdx.x & 63;
+    const int slot = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (slot >= a.n_launch) return;
+    const ReadGeom gm = geom(a, slot);
+    const int lr = rfl(gm.lr), T = rfl(gm.T);
+    const long long off = gm.off;
+    if (a.status[lr] != 0) {
+        if (lane == 0) a.n_runs[lr] = 0;
+        return;
+    }
+    const DevAutomaton &A = a.aut[a.aut_id[gm.r]];
+    const int m = a.m;
+    const int NM = F + (K - 1) * FL;
+    const uint64_t *bp = mask_rows(a, off, lr, NM);
+    const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
+    uint16_t *run_state = a.run_state + off;
+    int32_t *run_start = a.run_start + off;
+    uint64_t p4[WSX_MAX_K]; // this lane's position in slot k: positions of its state's predecessors, 16 bits each
+    int sidt[WSX_MAX_K];    // ... and the state id
+#pragma unroll
+    for (int k = 0; k < WSX_MAX_K; k++) {
+        p4[k] = k < K ? A.pred4[k * 64 + lane] : 0ull;
+        sidt[k] = k * 64 + lane;
+        if (k < K && A.state_at) sidt[k] = A.state_at[k * 64 + lane];
+    }
+    int q = rfl(A.pos ? A.pos[A.endstate] : A.endstate);
+    int i = T - 1;
+    int nr = 0;
+    // finished runs queue up one per lane and leave 64 at a time (coalesced)
+    int q_state = 0, q_start = 0;
+    int open_state = -1, open_start = 0;
+    auto push = [&](int state, int start) {
+        if (lane == (nr & 63)) {
+            q_state = state;
+            q_start = start;
+        }
+        nr++;
+        if ((nr & 63) == 0) {
+            run_state[nr - 64 + lane] = (uint16_t)q_state;
+            run_start[nr - 64 + lane] = q_start;
+        }
+    };
+    struct Block {
+        uint64_t mk[F];
+        uint32_t mw; // the sample-mask word of this lane's row
+    };
+    auto load = [&](Block &B, int b, int ks) {
+        const int row = b * 64 + lane;
+        const bool in = b >= 0 && row < T;
+        const int Fk = ks ? FL : F;
+        const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM + (ks ? F + (ks - 1) * FL : 0);
+#pragma unroll
+        for (int f = 0; f < F; f++) B.mk[f] = (in && row >= m && f < Fk) ? rp[f] : 0ull; // rows < m hold no pointers
+        B.mw = (maskw && in) ? maskw[row >> 5] : 0u;
+    };
+    Block cur, n1, n2; // block cb of slot cslot, and the two below it
+    int cb = 0, cslot = -1;
+    uint64_t cmasked = 0; // bit l: row 64*cb + l is a masked sample (back = m-1)
+    while (true) {
+        const int ks = q >> 6, bit = q & 63;
+        const int b = i >> 6;
+        if (ks != cslot) {
+            load(cur, b, ks);
+            load(n1, b - 1, ks);
+            load(n2, b - 2, ks);
+            cslot = ks;
+            cb = b;
+            cmasked = __ballot((cur.mw >> (lane & 31)) & 1u);
+        } else if (cb != b) { // one block down
+            cur = n1;
+            n1 = n2;
+            load(n2, b - 2, ks);
+            cb = b;
+            cmasked = __ballot((cur.mw >> (lane & 31)) & 1u);
+        }
+        uint32_t hit = 0; // highest candidate whose bit is set, plus one
+#pragma unroll
+        for (int f = 0; f < F; f++)
+            if ((cur.mk[f] >> bit) & 1ull) hit = f + 1;
+        uint64_t entered = __ballot(hit != 0);
+        const int top = i & 63;
+        if (top < 63) entered &= (2ull << top) - 1ull; // rows <= i
+        if (entered == 0 && cb * 64 > m) { // the run continues in the block below
+            i = cb * 64 - 1;
+            continue;
+        }
+        int start = 0, ptr = 0, l = 0;
+        if (entered != 0) {
+            l = 63 - __builtin_clzll(entered);
+            start = cb * 64 + l;
+            ptr = __builtin_amdgcn_readlane((int)hit, l);
+        }
+        int sv = sidt[0];
+        uint64_t pv = p4[0];
+#pragma unroll
+        for (int k = 1; k < WSX_MAX_K; k++)
+            if (ks == k) {
+                sv = sidt[k];
+                pv = p4[k];
+            }
+        const int j = __builtin_amdgcn_readlane(sv, bit);
+        if (j == open_state) {
+            open_start = start;
+        } else {
+            if (open_state >= 0) push(open_state, open_start);
+            open_state = j;
+            open_start = start;
+        }
+        if (entered == 0) break; // reached row 0 in this state
+        const int back = m - (int)((cmasked >> l) & 1ull);
+        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv, bit);
+        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv >> 32), bit);
+        const uint32_t pw = ptr > 2 ? phi : plo; // predecessor ptr-1: 16 bits each
+        q = (int)((pw >> (16 * ((ptr - 1) & 1))) & 0xffffu);
+        i = start - back;
+    }
+    if (open_state >= 0) push(open_state, open_start);
+    if (lane < (nr & 63)) {
+        run_state[(nr & ~63) + lane] = (uint16_t)q_state;
+        run_start[(nr & ~63) + lane] = q_start;
+    }
+    if (lane == 0) a.n_runs[lr] = nr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traceback over the mask layout for single-slot automata (K = 1, S <= 64): one THREAD per read.
+// With one slot the rows a walk touches do not depend on the states it visits: the walk reads row T-1, T-2, .. of the
+// read's masks, whatever the path.  Each thread therefore streams its read's rows downwards (RC rows = 96..128
+// contiguous bytes per step, two steps in flight), tests the bit of its current state in each row and, where it is
+// set, closes the run and moves to the predecessor.  Per row that is a handful of VALU instructions shared by 64
+// reads; the stream runs at HBM rate (scripts/exp_stream.hip: 5.4 TB/s for this access pattern).  Predecessor
+// positions come from a table in LDS (one 64-entry table per automaton of the handle); finished runs queue up in LDS
+// and are written 16 at a time.  Same outputs as traceback_mask_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_aut)
+{
+    constexpr int RC = F == 2 ? 8 : 4; // rows per step
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    extern __shared__ uint64_t tb_tab[]; // [automaton][position]: the positions of its state's predecessors
+    __shared__ uint16_t q_state[16][64];
+    __shared__ int32_t q_start[16][64];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < n_aut * 64; e += 64) {
+        const DevAutomaton &B = a.aut[e >> 6];
+        tb_tab[e] = B.n_states <= 64 ? B.pred4[e & 63] : 0ull;
+    }
+    __syncthreads();
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= a.n_launch) return;
+    const ReadGeom gm = geom(a, slot);
+    const int lr = gm.lr, T = gm.T;
+    const long long off = gm.off;
+    if (a.status[lr] != 0) {
+        a.n_runs[lr] = 0;
+        return;
+    }
+    const int aid = a.aut_id[gm.r];
+    const uint64_t *tab = tb_tab + aid * 64;
+    const int m = a.m;
+    const uint64_t *bp = mask_rows(a, off, lr, F);
+    const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
+    uint16_t *run_state = a.run_state + off;
+    int32_t *run_start = a.run_start + off;
+    int nr = 0;
+    auto push = [&](int state, int start) {
+        q_state[nr & 15][lane] = (uint16_t)state;
+        q_start[nr & 15][lane] = start;
+        nr++;
+        if ((nr & 15) == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) run_state[nr - 16 + e] = q_state[e][lane];
+#pragma unroll
+            for (int e = 0; e < 16; e++) run_start[nr - 16 + e] = q_start[e][lane];
+        }
+    };
+    int open_state = -1, open_start = 0;
+    auto close_run = [&](int state, int start) { // the walk leaves `state`, entered at row `start`
+        if (state == open_state) {
+            open_start = start;
+        } else {
+            if (open_state >= 0) push(open_state, open_start);
+            open_state = state;
+            open_start = start;
+        }
+    };
+    struct Step {
+        ull2 v[RC * F / 2]; // RC rows x F masks
+        uint32_t mw;        // the sample-mask word that covers these rows
+    };
+    auto load = [&](Step &S, int c) { // rows RC*c .. RC*c + RC-1 (c < 0: nothing)
+        const int cc = c < 0 ? 0 : c;
+        const ull2 *p = (const ull2 *)(bp + (size_t)cc * (RC * F));
+#pragma unroll
+        for (int e = 0; e < RC * F / 2; e++) S.v[e] = p[e];
+        S.mw = maskw ? maskw[(cc * RC) >> 5] : 0u;
+    };
+    int bit = a.aut[aid].endstate; // K = 1: position = state
+    int i = T - 1;                 // rows above i are not part of the walk
+    int c = i / RC;
+    Step cur, n1, n2;
+    load(cur, c);
+    load(n1, c - 1);
+    load(n2, c - 2);
+    for (; c >= 0; c--) {
+#pragma unroll
+        for (int rr = RC - 1; rr >= 0; rr--) {
+            const int r = c * RC + rr;
+            uint32_t e = 0; // bit f: predecessor f beat everything before it at (r, bit)
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const int idx = rr * F + f;
+                const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
+                e |= (uint32_t)((w >> bit) & 1ull) << f;
+            }
+            if (e != 0 && r <= i && r >= m) { // rows < m hold no pointers (and were never written)
+                close_run(bit, r);
+                const int ptr = 32 - __builtin_clz(e); // the arg-min is the highest set bit
+                const int back = m - (int)((cur.mw >> (r & 31)) & 1u);
+                bit = (int)((tab[bit] >> (16 * (ptr - 1))) & 0xffffull);
+                i = r - back;
+            }
+        }
+        cur = n1;
+        n1 = n2;
+        load(n2, c - 3);
+    }
+    close_run(bit, 0); // row 0 is reached in this state
+    if (open_state >= 0) push(open_state, open_start);
+    for (int e = nr & ~15; e < nr; e++) {
+        run_state[e] = q_state[e & 15][lane];
+        run_start[e] = q_start[e & 15][lane];
+    }
+    a.n_runs[lr] = nr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traceback over the word layout of dtw_fill_generic: one thread per read.
+//   bp words: word (wi, j) at bp[(wi*K + j/64)*64 + j%64], 4 bits per row (numeric pointer, row r at bits 4*r),
+//   8 rows per word.  Same outputs as above.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void traceback_generic_kernel(PassArgs a, int K)
+{
+    constexpr int PB = 4;
     constexpr int R = 32 / PB;
     constexpr uint32_t PM = (1u << PB) - 1u;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,66 +790,31 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
-    const uint64_t *pred4 = A.pred4;
     const size_t stride = (size_t)K * 64;
     int j = A.endstate;
     int i = T - 1;
     int nr = 0;
-    const uint16_t *pos = A.pos;
-    // Run records are written 16 at a time: a 2-byte and a 4-byte store per run, from 64 lanes that each own a
-    // different read, would miss in L2 on nearly every store (and turn into partial-sector HBM writes).  The open run
-    // stays in registers (its start moves while the walk stays in the same state); finished runs queue up in LDS.
-    __shared__ uint16_t q_state[16][64];
-    __shared__ int32_t q_start[16][64];
-    const int lane = threadIdx.x;
     int open_state = -1, open_start = 0;
     auto push = [&](int state, int start) {
-        q_state[nr & 15][lane] = (uint16_t)state;
-        q_start[nr & 15][lane] = start;
+        run_state[nr] = (uint16_t)state;
+        run_start[nr] = start;
         nr++;
-        if ((nr & 15) == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) run_state[nr - 16 + e] = q_state[e][lane];
-#pragma unroll
-            for (int e = 0; e < 16; e++) run_start[nr - 16 + e] = q_start[e][lane];
-        }
     };
     while (true) {
-        const int q = pos ? pos[j] : j; // where state j's pointer words live (slot q/64, lane q%64)
-        const uint32_t *col = bp + (size_t)(q >> 6) * 64 + (q & 63);
+        const uint32_t *col = bp + (size_t)(j >> 6) * 64 + (j & 63);
         int wi = i / R;
-        // two words per step (the current one and the one below) halve the dependent loads over runs of "stay"
         uint32_t wm = col[(size_t)wi * stride];
-        uint32_t wn = wi > 0 ? col[(size_t)(wi - 1) * stride] : 0u;
-        // keep rows <= i of this word
-        if (ENC) {
-            const int sh = (R - 1 - i % R) * PB; // bits below belong to later rows
-            wm = (wm >> sh) << sh;
-        } else {
-            const int sh = (i % R + 1) * PB;
-            if (sh < 32) wm &= (1u << sh) - 1u;
-        }
+        const int sh = (i % R + 1) * PB; // keep rows <= i of this word
+        if (sh < 32) wm &= (1u << sh) - 1u;
         while (wm == 0 && wi > 0) {
             wi--;
-            wm = wn;
-            if (wm == 0 && wi > 0) {
-                wi--;
-                wm = col[(size_t)wi * stride];
-                wn = wi > 0 ? col[(size_t)(wi - 1) * stride] : 0u;
-            }
+            wm = col[(size_t)wi * stride];
         }
         int start = 0, ptr = 0;
         if (wm != 0) {
-            if (ENC) {
-                const int fld = __builtin_ctz(wm) / PB;            // lowest non-zero field = latest row
-                const uint32_t bits = (wm >> (fld * PB)) & PM;
-                start = wi * R + (R - 1 - fld);
-                ptr = 32 - __builtin_clz(bits);                     // highest set bit + 1
-            } else {
-                const int rr = (31 - __builtin_clz(wm)) / PB;
-                start = wi * R + rr;
-                ptr = (int)((wm >> (rr * PB)) & PM);
-            }
+            const int rr = (31 - __builtin_clz(wm)) / PB;
+            start = wi * R + rr;
+            ptr = (int)((wm >> (rr * PB)) & PM);
         }
         if (j == open_state) {
             open_start = start;
@@ -602,16 +826,11 @@ __global__ __launch_bounds__(64) void traceback_kernel(PassArgs a, int K)
         if (wm == 0) break;
         int back = m;
         if (maskw) back = ((maskw[start >> 5] >> (start & 31)) & 1u) ? m - 1 : m;
-        if (ENC) j = (int)((pred4[j] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
-        else j = pred_idx[pred_ptr[j] + ptr - 1];
+        j = pred_idx[pred_ptr[j] + ptr - 1];
         i = start - back;
         if (i < 0) break; // cannot happen: pointers are only set on rows >= m
     }
     if (open_state >= 0) push(open_state, open_start);
-    for (int e = nr & ~15; e < nr; e++) {
-        run_state[e] = q_state[e & 15][lane];
-        run_start[e] = q_start[e & 15][lane];
-    }
     a.n_runs[lr] = nr;
 }
 
@@ -639,7 +858,7 @@ template <int M, int K, int F, int FL>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + 3) / 4;
-    size_t shmem = 4 * (2 * (K * 64 + 1) + 136) * sizeof(double);
+    size_t shmem = 4 * (2 * (K * 64 + 32)) * sizeof(double);
     // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
     // kernels of other chunks that run beside the fill on other streams.
     static const int cap_blocks = [] {
@@ -725,13 +944,37 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
 #endif
 }
 
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s)
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool generic, int n_aut, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;
-    const int blocks = (a.n_launch + 63) / 64;
-    if (generic) hipLaunchKernelGGL((traceback_kernel<4, 0>), dim3(blocks), dim3(64), 0, s, a, K);
-    else if (fast_f(F) <= 2) hipLaunchKernelGGL((traceback_kernel<2, 1>), dim3(blocks), dim3(64), 0, s, a, K);
-    else hipLaunchKernelGGL((traceback_kernel<4, 1>), dim3(blocks), dim3(64), 0, s, a, K);
+    const int wblocks = (a.n_launch + 3) / 4;
+    static const bool no_stream = getenv("WSX_NO_STREAM_TRACEBACK") != nullptr; // experiments: wave-per-read for K = 1 too
+    if (generic) {
+        hipLaunchKernelGGL(traceback_generic_kernel, dim3((a.n_launch + 63) / 64), dim3(64), 0, s, a, K);
+    } else if (K == 1 && n_aut <= 64 && !no_stream) { // thread per read; one 512-byte table per automaton in LDS
+        const int tblocks = (a.n_launch + 63) / 64;
+        const size_t shmem = (size_t)n_aut * 64 * sizeof(uint64_t);
+        switch (fast_f(F)) {
+        case 2: hipLaunchKernelGGL(traceback_stream_kernel<2>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
+        case 3: hipLaunchKernelGGL(traceback_stream_kernel<3>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
+        case 4: hipLaunchKernelGGL(traceback_stream_kernel<4>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        const int f = fast_f(F);
+#define WSX_TB(FF, LL)                                                                                              \
+    if (f == FF && FL == LL) hipLaunchKernelGGL((traceback_mask_kernel<FF, LL>), dim3(wblocks), dim3(256), 0, s, a, K)
+        WSX_TB(2, 2);
+        else WSX_TB(3, 3);
+        else WSX_TB(4, 4);
+        else WSX_TB(2, 1);
+        else WSX_TB(3, 1);
+        else WSX_TB(3, 2);
+        else WSX_TB(4, 1);
+        else WSX_TB(4, 2);
+        else return hipErrorInvalidValue;
+#undef WSX_TB
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace) return e;
     hipLaunchKernelGGL(expand_trace_kernel, dim3((a.n_launch + 3) / 4), dim3(256), 0, s, a);

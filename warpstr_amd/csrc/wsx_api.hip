@@ -38,8 +38,14 @@ struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
     int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
-    int PB() const { return generic ? 4 : (F <= 2 ? 2 : 4); }
-    int R() const { return 32 / PB(); }
+    // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
+    //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
+    //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
+    size_t bp_words(size_t samples, size_t reads) const
+    {
+        if (generic) return (samples / 8 + reads + 2) * (size_t)(K * 64);
+        return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2;
+    }
     bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL; }
 };
 
@@ -262,8 +268,8 @@ int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b)
 // bytes of workspace per sample / per read for a full call
 size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 {
-    int maxbp = 0;
-    for (auto &v : c->variant) maxbp = std::max(maxbp, v.K * 64 * 4 / v.R() + 1);
+    size_t maxbp = 0;
+    for (auto &v : c->variant) maxbp = std::max(maxbp, v.bp_words(4096, 1) * 4 / 4096 + 1);
     size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 24 /*scratch*/ +
                1 /*mask bits, rounded up*/ + maxbp;
     if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 1) : 0);
@@ -356,7 +362,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 return WSX_ERR_INVALID;
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
-                align_up(S * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S);
+                align_up((size_t)((S + 63) / 64) * 64 * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S) +
+                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -388,11 +395,6 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
         D.last_base = A.last_base ? (const uint8_t *)put(A.last_base, (size_t)S) : nullptr;
         if (!A.last_base) c->have_bases = false;
-        std::vector<uint64_t> p4(S, 0);
-        for (int j = 0; j < S; j++)
-            for (int e = A.pred_ptr[j], q = 0; e < A.pred_ptr[j + 1] && q < 4; e++, q++)
-                p4[j] |= (uint64_t)(uint16_t)A.pred_idx[e] << (16 * q);
-        D.pred4 = (const uint64_t *)put(p4.data(), (size_t)S * 8);
         Variant v;
         v.K = (S + 63) / 64;
         v.F = std::max(mf, 1);
@@ -414,8 +416,10 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             if (n_ge2 <= 64) v.FL = 1;
             else if (Fk > 2 && n_gt2 <= 64) v.FL = 2;
         }
+        std::vector<uint16_t> pos(S); // state -> position (identity unless split)
+        std::iota(pos.begin(), pos.end(), (uint16_t)0);
         if (v.FL < Fk) {
-            std::vector<uint16_t> pos(S), state_at((size_t)v.K * 64, 0xFFFF);
+            std::vector<uint16_t> state_at((size_t)v.K * 64, 0xFFFF);
             int q = 0; // positions 0..: the states with more than FL predecessors, then every other state, in state order
             for (int j = 0; j < S; j++)
                 if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) > v.FL) pos[j] = (uint16_t)q++;
@@ -424,6 +428,45 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             for (int j = 0; j < S; j++) state_at[pos[j]] = (uint16_t)j;
             D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
             D.state_at = (const uint16_t *)put(state_at.data(), state_at.size() * 2);
+        }
+        // pred4: the walk of the mask traceback runs in position space -- per position (slot*64 + lane) the positions of
+        // its state's first four predecessors, 16 bits each
+        {
+            std::vector<uint64_t> p4((size_t)v.K * 64, 0);
+            for (int j = 0; j < S; j++)
+                for (int e = A.pred_ptr[j], t = 0; e < A.pred_ptr[j + 1] && t < 4; e++, t++)
+                    p4[pos[j]] |= (uint64_t)pos[A.pred_idx[e]] << (16 * t);
+            D.pred4 = (const uint64_t *)put(p4.data(), p4.size() * 8);
+        }
+        // paddr: which LDS export slot (slot k, predecessor f, lane) reads in the register-resident fill.  A ds_read_b64
+        // serves lanes 0-31 and 32-63 in one cycle each when no two lanes of a group hit the same bank pair (slot mod 32)
+        // at different addresses; lanes without predecessor f all read the same +inf slot (a broadcast), picked among the
+        // 32 spare slots K*64.. so that its bank pair is one the group's real readers leave free.
+        if (!v.generic) {
+            std::vector<uint16_t> paddr((size_t)v.K * WSX_MAX_F * 64, (uint16_t)(v.K * 64));
+            std::vector<int> state_of((size_t)v.K * 64, -1);
+            for (int j = 0; j < S; j++) state_of[pos[j]] = j;
+            for (int k = 0; k < v.K; k++)
+                for (int f = 0; f < WSX_MAX_F; f++)
+                    for (int g = 0; g < 2; g++) {
+                        int used[32] = {0};
+                        for (int l = g * 32; l < g * 32 + 32; l++) {
+                            const int j = state_of[k * 64 + l];
+                            if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f) continue;
+                            const int pa = pos[A.pred_idx[A.pred_ptr[j] + f]];
+                            paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)pa;
+                            used[pa & 31]++;
+                        }
+                        int best = 0;
+                        for (int r = 1; r < 32; r++)
+                            if (used[r] < used[best]) best = r;
+                        for (int l = g * 32; l < g * 32 + 32; l++) {
+                            const int j = state_of[k * 64 + l];
+                            if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f)
+                                paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)(v.K * 64 + best);
+                        }
+                    }
+            D.paddr = (const uint16_t *)put(paddr.data(), paddr.size() * 2);
         }
         c->host_aut.push_back(D);
         if (v.generic) {
@@ -466,6 +509,7 @@ void wsx_caller_destroy(wsx_caller *c)
     (void)hipStreamSynchronize(c->stream);
     for (int w = 1; w < WSX_MAX_STREAMS; w++)
         if (c->aux[w]) (void)hipStreamSynchronize(c->aux[w]);
+
     c->ring_up.release();
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
@@ -676,8 +720,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         max_smp = std::max<size_t>(max_smp, ch.samples);
         max_cnt = std::max<size_t>(max_cnt, ch.count);
     }
-    int maxbpw = 0; // bp words per sample (upper bound)
-    for (auto &v : c->variant) maxbpw = std::max(maxbpw, (v.K * 64 + v.R() - 1) / v.R());
     const size_t S1 = max_smp + 64; // per-sample capacity
     const size_t R1 = max_cnt + 8;
     // per-sample arrays
@@ -691,7 +733,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         if (full && c->prm.reps_as_one)
             HIPCHK(c->work[w].reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
     }
-    // back-pointer scratch: one region per distinct DP kernel variant ((off/R + lr + 1) * K*64 words each), so that
+    // back-pointer scratch: one region per distinct DP kernel variant, so that
     // launch groups of one chunk never share words (their fills and tracebacks may then be issued in any order)
     std::vector<Variant> uvar;
     std::vector<size_t> uoff;
@@ -702,7 +744,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         if (seen) continue;
         uvar.push_back(v);
         uoff.push_back(bp_words);
-        bp_words += align_up((size_t)(S1 / v.R() + R1 + 2) * (size_t)(v.K * 64), 64);
+        bp_words += align_up(v.bp_words(S1, R1), 64);
     }
     auto bp_offset = [&](const Variant &v) -> size_t {
         for (size_t u = 0; u < uvar.size(); u++)
@@ -945,7 +987,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.maskbits = maskbits;
             pa.trace = trace;
             pa.status = status;
-            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].generic, nA, s));
         }
         return WSX_SUCCESS;
     };

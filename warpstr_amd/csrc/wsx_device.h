@@ -5,7 +5,7 @@
 //                                                                         alignment records)
 //   per-read arrays by                 lr   = r - first_read
 //   packed per-sample bit masks by     loff/32 + lr                       (32 samples per word, one spare word/read)
-//   DP back-pointer scratch by         (loff/R + lr) * K*64 words         (R = samples per 32-bit word, K = states/lane)
+//   DP back-pointer scratch by         loff * NM 64-bit wave masks        (NM masks per sample; dtw_kernels.hip)
 // so no extra prefix sums are needed besides the caller's own offsets[].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,9 +29,12 @@ struct DevAutomaton {
     const int32_t *pred_idx;
     const uint8_t *repeat_mask;
     const uint8_t *last_base; // ASCII of the k-mer's last base, or NULL
+    const uint16_t *paddr;    // register-resident fill: LDS export slot read by (slot k, predecessor f, lane), at
+                              // [(k*WSX_MAX_F + f)*64 + lane]; absent predecessors read one of the 32 +inf slots K*64..
     const uint16_t *pos;      // state -> position (slot*64 + lane) in the register-resident fill; NULL = identity
     const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
-    const uint64_t *pred4;  // per state: its first four predecessors, 16 bits each (one load in the traceback)
+    const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
+                            // predecessors, 16 bits each (mask traceback)
 };
 
 struct DevParams {
@@ -141,7 +144,7 @@ struct EvalArgs {
 
 // Host-side launchers (defined next to the kernels).
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s);
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, bool generic, hipStream_t s);
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool generic, int n_aut, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
