@@ -438,6 +438,65 @@ def test_baseline_full_size_recovers_planted_alleles():
         assert_close_rel(r0['dtw_end_cost2'][i], o.dtw_end_cost2, COST_REL)
 
 
+def test_mixed_locus_batch_at_per_gpu_size():
+    """BASELINE configs[4] at one GPU's share of it (8 loci x 50k reads over 8 GPUs = 6 250 reads per locus and GPU): eight
+    loci, both strands, squiggles of 500..5000 samples, automata of ~85..135 states at flank 40 (several kernel variants
+    in ONE handle and ONE call).  Checked through properties: deterministic bit for bit; reads that are copies of one
+    clean template agree on the allele up to noise; and a random sample of every locus equals the oracle."""
+    pats = ['((CAGG){CAGM})(CAGA)(CA)', '(NGC)', '(AAAT)', '(CTG)', '(GGCCCC)', '(CCTG)(TG)', '(AGC)AACAGCCGCCAC(CGC)',
+            '(CAG)CAACAG(CCG)']
+    fl, per_locus, n_tpl = 40, 6250, 48
+    rng = np.random.default_rng(404)
+    tables, oauts, sig_parts, lens, aid, tpl_of = [], [], [], [], [], []
+    for li, pat in enumerate(pats):
+        locus = synth.make_locus(pat, fl, 900 + li)
+        tables += [locus.template, locus.reverse]
+        oauts += [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+        tpls = []
+        for t in range(n_tpl):
+            T = int(rng.integers(500, 5001))
+            rev = bool(rng.random() < 0.5)
+            hi = max(2, min(30, (T // 4 - 2 * fl - 12) // 14))
+            s, _ = synth.squiggle(locus, rev, T, rng, lo=1, hi=hi, sigma=0.0)
+            tpls.append((s, rev))
+        pick = rng.integers(0, n_tpl, size=per_locus)
+        for t in pick:
+            s, rev = tpls[t]
+            sig_parts.append(s)
+            lens.append(len(s))
+            aid.append(2 * li + int(rev))
+            tpl_of.append(li * n_tpl + int(t))
+    perm = rng.permutation(len(lens))
+    lens = np.array(lens, dtype=np.int64)[perm]
+    aid = np.array(aid, dtype=np.int32)[perm]
+    tpl_of = np.array(tpl_of)[perm]
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    sig = np.concatenate([sig_parts[i] for i in perm])
+    sig += 0.25 * rng.standard_normal(sig.shape[0])
+    hip = HipCaller(tables, [fl] * len(tables), workspace_limit=64 << 30)
+    assert len({hip.kernel_name(a) for a in range(len(tables))}) >= 2      # several kernel variants in one call
+    r0, _ = hip.call(sig, off, aid)
+    r1, _ = hip.call(sig, off, aid)
+    assert r0.tobytes() == r1.tobytes()
+    ok = r0['status'] == 0
+    assert ok.mean() > 0.98
+    # copies of one clean template: the called allele is the same up to a repeat unit or two for nearly all of them
+    agree = []
+    for t in np.unique(tpl_of)[::7]:
+        l2 = r0['len2'][(tpl_of == t) & ok]
+        if len(l2) > 8:
+            agree.append(np.mean(np.abs(l2 - np.median(l2)) <= 6))
+    assert np.mean(agree) > 0.9
+    for i in rng.integers(0, len(lens), size=40):
+        o = oracle.call_read(oauts[aid[i]], sig[off[i]:off[i + 1]])
+        assert r0['status'][i] == o.status
+        if o.status == 0:
+            assert (r0['len1'][i], r0['len2'][i], r0['n_trans2'][i]) == (o.len1, o.len2, o.n_trans2)
+            assert_close_rel(r0['cost2'][i], o.cost2, COST_REL)
+            assert_close_rel(r0['dtw_end_cost2'][i], o.dtw_end_cost2, COST_REL)
+
+
 def test_upstream_test_case_real_reads(tmp_path):
     """The upstream test case end to end (README.md section 2; test/test_caller_only): example.csv + the multi-read
     VBZ fast5 -> caller-only overview -> int16 reads prepared on the GPU -> both passes -> overview.csv -> genotype.
@@ -528,6 +587,22 @@ def test_two_kernel_segmentation_fallback():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
                           'test_call_matches_golden or test_upstream_test_case_real_reads'],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout
+
+
+def test_wave_per_read_traceback_for_single_slot_automata():
+    """Automata of up to 64 states normally take the thread-per-read streaming traceback; a handle with more than 64
+    automata (no room for their tables in LDS) takes the wave-per-read one instead.  The knob forces that path for the
+    single-slot golden and seeded cases (own process: the knob is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, WSX_NO_STREAM_TRACEBACK='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
+                          'test_call_matches_golden or test_call_matches_oracle_seeded or test_warp_matches_golden'],
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert ' passed' in out.stdout

@@ -640,23 +640,28 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
     for (int kb = 0; kb < mfit; kb += 64) {
         const int k = kb + lane;
         const double xk = (k < mfit) ? cx[k] : 0.0;
-        // rank = #(x_q < x_k) + #(x_q == x_k, q < k).  Exact ties between run means are practically absent, so the hot
-        // loop only counts "<" and "<="; a lane that sees any tie besides itself recounts with the index tie-break.
-        int n_lt = 0, n_le = 0;
+        // rank = #(x_q < x_k) + #(x_q == x_k, q < k).  Both k and q advance in aligned blocks of 64, so a block of q
+        // lies entirely before the lanes' k (count "<="), entirely after (count "<"), or is the lanes' own block (the
+        // index decides ties): one compare and one add-with-carry per (q, k) pair except on the diagonal.
+        int rank = 0;
         for (int qb = 0; qb < mfit; qb += 512) {
             const int cnt = (mfit - qb) < 512 ? (mfit - qb) : 512;
             __builtin_amdgcn_wave_barrier();
             for (int q = lane; q < cnt; q += 64) xs[q] = cx[qb + q];
             __builtin_amdgcn_wave_barrier();
-            for (int q = 0; q < cnt; q++) {
-                const double xq = xs[q]; // LDS broadcast
-                n_lt += (xq < xk) ? 1 : 0;
-                n_le += (xq <= xk) ? 1 : 0;
+            for (int q0 = 0; q0 < cnt; q0 += 64) {
+                const int q1 = (q0 + 64 < cnt) ? q0 + 64 : cnt;
+                if (qb + q0 < kb) {
+                    for (int q = q0; q < q1; q++) rank += (xs[q] <= xk) ? 1 : 0; // LDS broadcast
+                } else if (qb + q0 > kb) {
+                    for (int q = q0; q < q1; q++) rank += (xs[q] < xk) ? 1 : 0;
+                } else {
+                    for (int q = q0; q < q1; q++) {
+                        const double xq = xs[q];
+                        rank += (xq < xk || (xq == xk && q - q0 < lane)) ? 1 : 0;
+                    }
+                }
             }
-        }
-        int rank = n_lt;
-        if (k < mfit && n_le - n_lt > 1) { // ties: stable order by original position
-            for (int q = 0; q < k; q++) rank += (cx[q] == xk) ? 1 : 0;
         }
         if (k < mfit) {
             fx[rank] = xk;
