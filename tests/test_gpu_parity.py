@@ -592,14 +592,15 @@ def test_two_kernel_segmentation_fallback():
     assert ' passed' in out.stdout
 
 
-def test_wave_per_read_traceback_for_single_slot_automata():
-    """Automata of up to 64 states normally take the thread-per-read streaming traceback; a handle with more than 64
-    automata (no room for their tables in LDS) takes the wave-per-read one instead.  The knob forces that path for the
-    single-slot golden and seeded cases (own process: the knob is read once)."""
+def test_streaming_traceback_on_small_batches():
+    """Automata of up to 64 states have two traceback kernels: wave per read (small launches; also when a handle holds
+    more than 64 automata) and the thread-per-read streaming one (launches of 8192 reads and more: the full-size tests
+    run it).  The knob lowers that threshold so that the golden and seeded single-slot cases go through the streaming
+    kernel too (own process: the knob is read once)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, WSX_NO_STREAM_TRACEBACK='1')
+    env = dict(os.environ, WSX_STREAM_TRACEBACK_MIN='1')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
                           'test_call_matches_golden or test_call_matches_oracle_seeded or test_warp_matches_golden'],

@@ -948,10 +948,17 @@ hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool ge
 {
     if (a.n_launch <= 0) return hipSuccess;
     const int wblocks = (a.n_launch + 3) / 4;
-    static const bool no_stream = getenv("WSX_NO_STREAM_TRACEBACK") != nullptr; // experiments: wave-per-read for K = 1 too
+    static const int stream_min = [] { // smallest launch that takes the streaming traceback (tests and experiments override)
+        const char *e = getenv("WSX_STREAM_TRACEBACK_MIN");
+        return e ? atoi(e) : 8192;
+    }();
     if (generic) {
         hipLaunchKernelGGL(traceback_generic_kernel, dim3((a.n_launch + 63) / 64), dim3(64), 0, s, a, K);
-    } else if (K == 1 && n_aut <= 64 && !no_stream) { // thread per read; one 512-byte table per automaton in LDS
+    } else if (K == 1 && n_aut <= 64 && a.n_launch >= stream_min) {
+        // thread per read; one 512-byte table per automaton in LDS.  Fewest instructions per read, but a launch lasts as
+        // long as one thread needs for its whole read (~0.3 ms): small launches take the wave-per-read kernel instead
+        // (measured: 1k reads 0.77 vs 1.45 ms per call, 16k reads 2.7 vs 3.2 ms; from 12.5k reads per launch on,
+        // inside a 100k-read batch, the streaming kernel wins)
         const int tblocks = (a.n_launch + 63) / 64;
         const size_t shmem = (size_t)n_aut * 64 * sizeof(uint64_t);
         switch (fast_f(F)) {
