@@ -521,8 +521,8 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 // history of the state and count-leading-zeros finds the latest entry at or below the current row.  Successive states
 // that live in the same slot are walked without touching memory (with K = 1 a block serves every transition inside
 // its 64 rows), and the two blocks below are already in flight while a block is walked.  The walk runs in position
-// space (slot*64 + lane): per lane the wave keeps its position's predecessor positions (pred4) and state id, read
-// with v_readlane -- no memory access per transition.  Runs are appended in reverse time order: run_state[q],
+// space (slot*64 + lane); predecessor positions (pred4) and state ids come through the scalar cache, so a transition
+// costs the vector ALU two instructions per candidate.  Runs are appended in reverse time order: run_state[q],
 // run_start[q]; adjacent equal states merge, matching the run-length encoding of the trace (caller.py:58-60).
 // ------------------------------------------------------------------------------------------------
 template <int F, int FL>
@@ -545,15 +545,10 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
-    uint64_t p4[WSX_MAX_K]; // this lane's position in slot k: positions of its state's predecessors, 16 bits each
-    int sidt[WSX_MAX_K];    // ... and the state id
-#pragma unroll
-    for (int k = 0; k < WSX_MAX_K; k++) {
-        p4[k] = k < K ? A.pred4[k * 64 + lane] : 0ull;
-        sidt[k] = k * 64 + lane;
-        if (k < K && A.state_at) sidt[k] = A.state_at[k * 64 + lane];
-    }
-    int q = rfl(A.pos ? A.pos[A.endstate] : A.endstate);
+    // predecessor positions and state ids by position: scalar loads (uniform index), no vector instruction
+    const WSX_AS4 uint64_t *pred4 = (const WSX_AS4 uint64_t *)A.pred4;
+    const WSX_AS4 uint16_t *state_at = (const WSX_AS4 uint16_t *)A.state_at;
+    int q = A.pos ? (int)((const WSX_AS4 uint16_t *)A.pos)[A.endstate] : A.endstate;
     int i = T - 1;
     int nr = 0;
     // finished runs queue up one per lane and leave 64 at a time (coalesced)
@@ -571,7 +566,7 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
         }
     };
     struct Block {
-        uint64_t mk[F];
+        uint32_t lo[F], hi[F];
         uint32_t mw; // the sample-mask word of this lane's row
     };
     auto load = [&](Block &B, int b, int ks) {
@@ -580,7 +575,11 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
         const int Fk = ks ? FL : F;
         const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM + (ks ? F + (ks - 1) * FL : 0);
 #pragma unroll
-        for (int f = 0; f < F; f++) B.mk[f] = (in && row >= m && f < Fk) ? rp[f] : 0ull; // rows < m hold no pointers
+        for (int f = 0; f < F; f++) {
+            const uint64_t w = (in && row >= m && f < Fk) ? rp[f] : 0ull; // rows < m hold no pointers
+            B.lo[f] = (uint32_t)w;
+            B.hi[f] = (uint32_t)(w >> 32);
+        }
         B.mw = (maskw && in) ? maskw[row >> 5] : 0u;
     };
     Block cur, n1, n2; // block cb of slot cslot, and the two below it
@@ -603,14 +602,19 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
             cb = b;
             cmasked = __ballot((cur.mw >> (lane & 31)) & 1u);
         }
-        uint32_t hit = 0; // highest candidate whose bit is set, plus one
+        // won[f] bit l: predecessor f beat everything before it at row 64*cb + l -- one AND and one compare per
+        // candidate on the vector ALU, everything after that is scalar
+        const uint32_t m32 = 1u << (bit & 31);
+        uint64_t won[F];
+        uint64_t entered = 0;
 #pragma unroll
-        for (int f = 0; f < F; f++)
-            if ((cur.mk[f] >> bit) & 1ull) hit = f + 1;
-        uint64_t entered = __ballot(hit != 0);
+        for (int f = 0; f < F; f++) {
+            won[f] = bit < 32 ? __ballot((cur.lo[f] & m32) != 0u) : __ballot((cur.hi[f] & m32) != 0u);
+            entered |= won[f];
+        }
         const int top = i & 63;
         if (top < 63) entered &= (2ull << top) - 1ull; // rows <= i
-        if (entered == 0 && cb * 64 > m) { // the run continues in the block below
+        if (entered == 0 && cb * 64 > m) {             // the run continues in the block below
             i = cb * 64 - 1;
             continue;
         }
@@ -618,17 +622,11 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
         if (entered != 0) {
             l = 63 - __builtin_clzll(entered);
             start = cb * 64 + l;
-            ptr = __builtin_amdgcn_readlane((int)hit, l);
-        }
-        int sv = sidt[0];
-        uint64_t pv = p4[0];
 #pragma unroll
-        for (int k = 1; k < WSX_MAX_K; k++)
-            if (ks == k) {
-                sv = sidt[k];
-                pv = p4[k];
-            }
-        const int j = __builtin_amdgcn_readlane(sv, bit);
+            for (int f = 0; f < F; f++)
+                if ((won[f] >> l) & 1ull) ptr = f + 1; // the arg-min is the highest candidate whose bit is set
+        }
+        const int j = state_at ? (int)state_at[q] : q;
         if (j == open_state) {
             open_start = start;
         } else {
@@ -638,10 +636,7 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
         }
         if (entered == 0) break; // reached row 0 in this state
         const int back = m - (int)((cmasked >> l) & 1ull);
-        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv, bit);
-        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv >> 32), bit);
-        const uint32_t pw = ptr > 2 ? phi : plo; // predecessor ptr-1: 16 bits each
-        q = (int)((pw >> (16 * ((ptr - 1) & 1))) & 0xffffu);
+        q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
         i = start - back;
     }
     if (open_state >= 0) push(open_state, open_start);
