@@ -11,6 +11,6 @@ run "stream tb, chunks=8" X=1
 run "stream tb, chunks=4" WSX_CHUNKS=4
 run "wave tb, chunks=8" WSX_STREAM_TRACEBACK_MIN=100000000
 run "wave tb, chunks=4" WSX_STREAM_TRACEBACK_MIN=100000000 WSX_CHUNKS=4
+run "wave tb, chunks=6 streams=3" WSX_STREAM_TRACEBACK_MIN=100000000 WSX_CHUNKS=6 WSX_STREAMS=3
 run "wave tb, chunks=16" WSX_STREAM_TRACEBACK_MIN=100000000 WSX_CHUNKS=16
-run "wave tb, chunks=12 streams=6" WSX_STREAM_TRACEBACK_MIN=100000000 WSX_CHUNKS=12 WSX_STREAMS=6
 done

@@ -30,7 +30,7 @@
 //       4-bit numeric pointers packed 8 rows per 32-bit word per state.
 //   traceback_stream_kernel<F>  mask layout, K = 1: one THREAD per read streams the read's mask rows downwards (the
 //       rows visited do not depend on the path when there is one slot), tests its current state's bit per row.
-//   traceback_mask_kernel<F,FL> mask layout, K > 1: one wavefront per read, 64 rows of one slot per load, ballots.
+//   traceback_mask_kernel<K,F,FL> mask layout: one wavefront per read, 64 rows (all slots) per load, ballots.
 //   traceback_generic_kernel    word layout of dtw_fill_generic, one thread per read.
 //       All three emit the run-length state list in reverse time order.
 //   expand_trace_kernel         optional: per-sample state ids from the run list (coalesced, wave per read).
@@ -516,17 +516,18 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 // ------------------------------------------------------------------------------------------------
 // Traceback over the mask layout of dtw_fill_fast: one wavefront per read.
 //   row i of the read holds NM 64-bit masks at bp[i*NM + mask_index(k, f)]; bit = lane of the state in slot k.
-// A block is 64 consecutive rows (64b .. 64b+63) of ONE slot, one row per lane: a coalesced load.  Whether the state
-// at (slot, bit) was entered at a row is that row's lane testing bit `bit`; a ballot turns the block into a 64-row
-// history of the state and count-leading-zeros finds the latest entry at or below the current row.  Successive states
-// that live in the same slot are walked without touching memory (with K = 1 a block serves every transition inside
-// its 64 rows), and the two blocks below are already in flight while a block is walked.  The walk runs in position
+// A block is 64 consecutive rows (64b .. 64b+63), one row per lane with ALL its NM masks: a coalesced load.  Whether
+// the state at (slot, bit) was entered at a row is that row's lane testing bit `bit` of the slot's masks; a ballot turns
+// the block into a 64-row history of the state and count-leading-zeros finds the latest entry at or below the current
+// row.  Every transition inside the block's 64 rows is walked without touching memory, whichever slots the path visits
+// (loop entries and other states with several predecessors sit in slot 0, so paths through long automata change slot at
+// every repeat unit), and the two blocks below are already in flight while a block is walked.  The walk runs in position
 // space (slot*64 + lane); predecessor positions (pred4) and state ids come through the scalar cache, so a transition
 // costs the vector ALU two instructions per candidate.  Runs are appended in reverse time order: run_state[q],
 // run_start[q]; adjacent equal states merge, matching the run-length encoding of the trace (caller.py:58-60).
 // ------------------------------------------------------------------------------------------------
-template <int F, int FL>
-__global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
+template <int K, int F, int FL>
+__global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int slot = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -540,110 +541,121 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a, int K)
     }
     const DevAutomaton &A = a.aut[a.aut_id[gm.r]];
     const int m = a.m;
-    const int NM = F + (K - 1) * FL;
+    constexpr int NM = F + (K - 1) * FL;
     const uint64_t *bp = mask_rows(a, off, lr, NM);
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
-    // predecessor positions and state ids by position: scalar loads (uniform index), no vector instruction
+    // predecessor positions by position: scalar loads (uniform index), no vector instruction
     const WSX_AS4 uint64_t *pred4 = (const WSX_AS4 uint64_t *)A.pred4;
-    const WSX_AS4 uint16_t *state_at = (const WSX_AS4 uint16_t *)A.state_at;
-    int q = A.pos ? (int)((const WSX_AS4 uint16_t *)A.pos)[A.endstate] : A.endstate;
+    const uint16_t *state_at = A.state_at;
+    int q = rfl(A.pos ? (int)A.pos[A.endstate] : A.endstate);
     int i = T - 1;
     int nr = 0;
-    // finished runs queue up one per lane and leave 64 at a time (coalesced)
-    int q_state = 0, q_start = 0;
-    int open_state = -1, open_start = 0;
-    auto push = [&](int state, int start) {
+    // finished runs (position, start row) queue up one per lane and leave 64 at a time (coalesced); positions turn into
+    // state ids on the way out
+    int q_pos = 0, q_start = 0;
+    int open_pos = -1, open_start = 0;
+    auto flush = [&](int first, int count) {
+        if (lane < count) {
+            run_state[first + lane] = state_at ? state_at[q_pos] : (uint16_t)q_pos;
+            run_start[first + lane] = q_start;
+        }
+    };
+    auto push = [&](int pos, int start) {
         if (lane == (nr & 63)) {
-            q_state = state;
+            q_pos = pos;
             q_start = start;
         }
         nr++;
-        if ((nr & 63) == 0) {
-            run_state[nr - 64 + lane] = (uint16_t)q_state;
-            run_start[nr - 64 + lane] = q_start;
-        }
+        if ((nr & 63) == 0) flush(nr - 64, 64);
     };
     struct Block {
-        uint32_t lo[F], hi[F];
-        uint32_t mw; // the sample-mask word of this lane's row
+        uint64_t w[NM]; // the row's masks, index mask_index(k, f)
+        uint32_t mw;    // the sample-mask word of this lane's row
     };
-    auto load = [&](Block &B, int b, int ks) {
+    auto load = [&](Block &B, int b) {
         const int row = b * 64 + lane;
         const bool in = b >= 0 && row < T;
-        const int Fk = ks ? FL : F;
-        const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM + (ks ? F + (ks - 1) * FL : 0);
+        const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM;
 #pragma unroll
-        for (int f = 0; f < F; f++) {
-            const uint64_t w = (in && row >= m && f < Fk) ? rp[f] : 0ull; // rows < m hold no pointers
-            B.lo[f] = (uint32_t)w;
-            B.hi[f] = (uint32_t)(w >> 32);
-        }
+        for (int e = 0; e < NM; e++) B.w[e] = (in && row >= m) ? rp[e] : 0ull; // rows < m hold no pointers
         B.mw = (maskw && in) ? maskw[row >> 5] : 0u;
     };
-    Block cur, n1, n2; // block cb of slot cslot, and the two below it
-    int cb = 0, cslot = -1;
-    uint64_t cmasked = 0; // bit l: row 64*cb + l is a masked sample (back = m-1)
+    // Walks every transition inside block cb (rows 64*cb ..), starting at row i in position q.  Returns true when the
+    // walk has reached row 0, false when it continues in the block below.
+    auto walk = [&](const Block &cur, int cb) -> bool {
+        const uint64_t cmasked = __ballot((cur.mw >> (lane & 31)) & 1u); // bit l: row 64*cb + l is masked (back = m-1)
+        while (true) {
+            const int ks = q >> 6, bit = q & 63;
+            // won[f] bit l: predecessor f beat everything before it at row 64*cb + l -- a shift, an AND and a compare
+            // per candidate on the vector ALU (the slot's masks are picked by a uniform register index); the rest is scalar
+            uint64_t won[F];
+            uint64_t entered = 0;
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                if (f < FL) {
+                    uint64_t w = cur.w[f]; // the slot's mask f: a chain of selects on the uniform slot number
+#pragma unroll
+                    for (int k = 1; k < K; k++) {
+                        uint64_t wk = cur.w[mask_index<F, FL>(k, f)];
+                        asm("" : "+v"(wk)); // keeps the select on values: as a select of addresses it would send w[] to scratch
+                        w = (ks == k) ? wk : w;
+                    }
+                    won[f] = __ballot((w >> bit) & 1ull);
+                } else { // candidates FL.. exist in slot 0 only
+                    const uint64_t t = __ballot((cur.w[f] >> bit) & 1ull);
+                    won[f] = ks == 0 ? t : 0ull;
+                }
+                entered |= won[f];
+            }
+            const int top = i & 63;
+            if (top < 63) entered &= (2ull << top) - 1ull; // rows <= i
+            if (entered == 0 && cb * 64 > m) {             // the run continues in the block below
+                i = cb * 64 - 1;
+                return false;
+            }
+            int start = 0, ptr = 0, l = 0;
+            if (entered != 0) {
+                l = 63 - __builtin_clzll(entered);
+                start = cb * 64 + l;
+#pragma unroll
+                for (int f = 0; f < F; f++)
+                    if ((won[f] >> l) & 1ull) ptr = f + 1; // the arg-min is the highest candidate whose bit is set
+            }
+            if (q == open_pos) {
+                open_start = start;
+            } else {
+                if (open_pos >= 0) push(open_pos, open_start);
+                open_pos = q;
+                open_start = start;
+            }
+            if (entered == 0) return true; // reached row 0 in this state
+            const int back = m - (int)((cmasked >> l) & 1ull);
+            q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
+            i = start - back;
+            if ((i >> 6) != cb) return false; // a step never skips a block: back <= m rows
+        }
+    };
+    // three blocks in registers, roles rotating statically: while one is walked the two below it are in flight
+    Block b0, b1, b2;
+    int cb = i >> 6;
+    load(b0, cb);
+    load(b1, cb - 1);
+    load(b2, cb - 2);
     while (true) {
-        const int ks = q >> 6, bit = q & 63;
-        const int b = i >> 6;
-        if (ks != cslot) {
-            load(cur, b, ks);
-            load(n1, b - 1, ks);
-            load(n2, b - 2, ks);
-            cslot = ks;
-            cb = b;
-            cmasked = __ballot((cur.mw >> (lane & 31)) & 1u);
-        } else if (cb != b) { // one block down
-            cur = n1;
-            n1 = n2;
-            load(n2, b - 2, ks);
-            cb = b;
-            cmasked = __ballot((cur.mw >> (lane & 31)) & 1u);
-        }
-        // won[f] bit l: predecessor f beat everything before it at row 64*cb + l -- one AND and one compare per
-        // candidate on the vector ALU, everything after that is scalar
-        const uint32_t m32 = 1u << (bit & 31);
-        uint64_t won[F];
-        uint64_t entered = 0;
-#pragma unroll
-        for (int f = 0; f < F; f++) {
-            won[f] = bit < 32 ? __ballot((cur.lo[f] & m32) != 0u) : __ballot((cur.hi[f] & m32) != 0u);
-            entered |= won[f];
-        }
-        const int top = i & 63;
-        if (top < 63) entered &= (2ull << top) - 1ull; // rows <= i
-        if (entered == 0 && cb * 64 > m) {             // the run continues in the block below
-            i = cb * 64 - 1;
-            continue;
-        }
-        int start = 0, ptr = 0, l = 0;
-        if (entered != 0) {
-            l = 63 - __builtin_clzll(entered);
-            start = cb * 64 + l;
-#pragma unroll
-            for (int f = 0; f < F; f++)
-                if ((won[f] >> l) & 1ull) ptr = f + 1; // the arg-min is the highest candidate whose bit is set
-        }
-        const int j = state_at ? (int)state_at[q] : q;
-        if (j == open_state) {
-            open_start = start;
-        } else {
-            if (open_state >= 0) push(open_state, open_start);
-            open_state = j;
-            open_start = start;
-        }
-        if (entered == 0) break; // reached row 0 in this state
-        const int back = m - (int)((cmasked >> l) & 1ull);
-        q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
-        i = start - back;
+        if (walk(b0, cb)) break;
+        cb--;
+        load(b0, cb - 2);
+        if (walk(b1, cb)) break;
+        cb--;
+        load(b1, cb - 2);
+        if (walk(b2, cb)) break;
+        cb--;
+        load(b2, cb - 2);
     }
-    if (open_state >= 0) push(open_state, open_start);
-    if (lane < (nr & 63)) {
-        run_state[(nr & ~63) + lane] = (uint16_t)q_state;
-        run_start[(nr & ~63) + lane] = q_start;
-    }
+    if (open_pos >= 0) push(open_pos, open_start);
+    flush(nr & ~63, nr & 63);
     if (lane == 0) a.n_runs[lr] = nr;
 }
 
@@ -964,17 +976,27 @@ hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool ge
         }
     } else {
         const int f = fast_f(F);
-#define WSX_TB(FF, LL)                                                                                              \
-    if (f == FF && FL == LL) hipLaunchKernelGGL((traceback_mask_kernel<FF, LL>), dim3(wblocks), dim3(256), 0, s, a, K)
-        WSX_TB(2, 2);
-        else WSX_TB(3, 3);
-        else WSX_TB(4, 4);
-        else WSX_TB(2, 1);
-        else WSX_TB(3, 1);
-        else WSX_TB(3, 2);
-        else WSX_TB(4, 1);
-        else WSX_TB(4, 2);
+#define WSX_TB(KK, FF, LL)                                                                                          \
+    if (K == KK && f == FF && FL == LL)                                                                             \
+    hipLaunchKernelGGL((traceback_mask_kernel<KK, FF, LL>), dim3(wblocks), dim3(256), 0, s, a)
+#define WSX_TB_SPLIT(KK)                                                                                            \
+    WSX_TB(KK, 2, 2);                                                                                               \
+    else WSX_TB(KK, 3, 3);                                                                                          \
+    else WSX_TB(KK, 4, 4);                                                                                          \
+    else WSX_TB(KK, 2, 1);                                                                                          \
+    else WSX_TB(KK, 3, 1);                                                                                          \
+    else WSX_TB(KK, 3, 2);                                                                                          \
+    else WSX_TB(KK, 4, 1);                                                                                          \
+    else WSX_TB(KK, 4, 2)
+        WSX_TB(1, 2, 2);
+        else WSX_TB(1, 3, 3);
+        else WSX_TB(1, 4, 4);
+        else WSX_TB_SPLIT(2);
+        else WSX_TB_SPLIT(3);
+        else WSX_TB_SPLIT(4);
+        else WSX_TB_SPLIT(5);
         else return hipErrorInvalidValue;
+#undef WSX_TB_SPLIT
 #undef WSX_TB
     }
     hipError_t e = hipGetLastError();
