@@ -171,12 +171,42 @@ __device__ __attribute__((noinline)) double np_median(const double *a, int n)
     return (select_rank(a, n, n / 2 - 1) + select_rank(a, n, n / 2)) / 2.0;
 }
 
+// ---- fp64 division by a denominator that many divisions share ---------------------------------
+// The compiler expands x / d into v_div_scale (x2), v_rcp_f64, four FMAs that refine the reciprocal, a multiply, a
+// residual FMA, v_div_fmas and v_div_fixup.  Everything up to the refined reciprocal depends on d alone whenever
+// v_div_scale leaves its operands unscaled, i.e. for d and x far from the ends of the exponent range (and x = 0) --
+// which holds for every use below: d is 3.0 or the span of a read's run means, x a sum of O(1) signal terms or a
+// B-spline weight of at least 2^-160 in magnitude.  wsx_div_by() then performs the remaining three operations of that
+// very expansion, so the quotient is bit-identical to x / d (checked bit for bit against the plain form on 100k reads:
+// scripts/exp_bitcmp.py) at a quarter of the instructions.
+__device__ __forceinline__ double wsx_recip_refined(double d)
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    const double f0 = __builtin_fma(-d, r, 1.0);
+    const double f1 = __builtin_fma(r, f0, r);
+    const double f2 = __builtin_fma(-d, f1, 1.0);
+    return __builtin_fma(f1, f2, f1);
+}
+__device__ __forceinline__ double wsx_div_by(double x, double d, double r)
+{
+#ifdef WSX_PLAIN_DIVISIONS // experiment builds: the compiler's full expansion
+    return x / d;
+#else
+    const double q = x * r;
+    const double e = __builtin_fma(-d, q, x);
+    return __builtin_fma(e, r, q);
+#endif
+}
+
 // ---- sliding t-test segmentation (caller.py:347-378) ------------------------------------------
-__device__ __forceinline__ double mean3v(double a0, double a1, double a2) { return (((0.0 + a0) + a1) + a2) / 3.0; }
-__device__ __forceinline__ double std3v(double a0, double a1, double a2, double mu)
+__device__ __forceinline__ double mean3v(double a0, double a1, double a2, double r3)
+{
+    return wsx_div_by(((0.0 + a0) + a1) + a2, 3.0, r3);
+}
+__device__ __forceinline__ double std3v(double a0, double a1, double a2, double mu, double r3)
 {
     const double d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu;
-    return sqrt((((0.0 + d0 * d0) + d1 * d1) + d2 * d2) / 3.0);
+    return sqrt(wsx_div_by(((0.0 + d0 * d0) + d1 * d1) + d2 * d2, 3.0, r3));
 }
 
 // Python slice bounds [a:b] on a sequence of length n
@@ -464,14 +494,15 @@ __global__ __launch_bounds__(256) void tstat_kernel(MidArgs a)
     const MidRec rec = a.rec[lr];
     if (rec.nsel <= 1 || p0 + 256 <= rec.p_lo || p0 >= rec.p_hi) return;
     const double *sig = a.signal + v.off;
+    const double r3 = wsx_recip_refined(3.0);
     // window statistics for positions p0-3 .. p0+255 (those inside [p_lo, p_hi-2))
     for (int q = tid; q < 259; q += 256) {
         const int p = p0 - 3 + q;
         double mu = 0.0, ss = 0.0;
         if (p >= rec.p_lo && p + 2 < rec.p_hi) {
             const double a0 = sig[p], a1 = sig[p + 1], a2 = sig[p + 2];
-            mu = mean3v(a0, a1, a2);
-            const double sd = std3v(a0, a1, a2, mu);
+            mu = mean3v(a0, a1, a2, r3);
+            const double sd = std3v(a0, a1, a2, mu, r3);
             ss = sd * sd;
         }
         wm[q] = mu;
@@ -480,7 +511,7 @@ __global__ __launch_bounds__(256) void tstat_kernel(MidArgs a)
     __syncthreads();
     const int p = p0 + tid;
     if (p >= rec.p_lo + 3 && p + 2 < rec.p_hi) {
-        double sd = sqrt((ws[tid] + ws[tid + 3]) / 3.0);
+        double sd = sqrt(wsx_div_by(ws[tid] + ws[tid + 3], 3.0, r3));
         if (sd == 0.0) sd = sd + 0.0000001;
         a.scr2[v.off + p] = (wm[tid] - wm[tid + 3]) / sd;
     }
@@ -554,6 +585,7 @@ __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
         if (c < nch) cnt[c] = 0;
     }
     const double *sig = a.signal + v.off;
+    const double r3 = wsx_recip_refined(3.0);
     for (int p0 = rec.p_lo + 3; p0 + 2 < rec.p_hi; p0 += 256) { // positions p0 .. p0+255 (t exists on [p_lo+3, p_hi-2))
         const double carry = (tid < 2 && p0 > rec.p_lo + 3) ? tl[256 + tid] : 0.0; // t[p0-2], t[p0-1] of the last tile
         for (int q = tid; q < 259; q += 256) { // window statistics at p0-3 .. p0+255
@@ -561,8 +593,8 @@ __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
             double mu = 0.0, ss = 0.0;
             if (p >= rec.p_lo && p + 2 < rec.p_hi) {
                 const double a0 = sig[p], a1 = sig[p + 1], a2 = sig[p + 2];
-                mu = mean3v(a0, a1, a2);
-                const double sd = std3v(a0, a1, a2, mu);
+                mu = mean3v(a0, a1, a2, r3);
+                const double sd = std3v(a0, a1, a2, mu, r3);
                 ss = sd * sd;
             }
             wm[q] = mu;
@@ -573,7 +605,7 @@ __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
         const bool valid = p + 2 < rec.p_hi;
         double t = 0.0;
         if (valid) {
-            double sd = sqrt((ws[tid] + ws[tid + 3]) / 3.0);
+            double sd = sqrt(wsx_div_by(ws[tid] + ws[tid + 3], 3.0, r3));
             if (sd == 0.0) sd = sd + 0.0000001;
             t = (wm[tid] - wm[tid + 3]) / sd;
         }
@@ -673,7 +705,13 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
 
 // ---- FITPACK pieces ---------------------------------------------------------------------------
 // fpbspl for the 8-knot cubic (knots xb x4, xe x4; interval l = 4): the 4 non-zero B-splines at x.
-__device__ __forceinline__ void bspl4(double xb, double xe, double x, double h[5])
+// den = xe - xb is the same for every point of a read; rden = wsx_recip_refined(den), or 0 where den is so close to the
+// ends of the exponent range that the plain division might scale its operands (wsx_bspl_rden).
+__device__ __forceinline__ double wsx_bspl_rden(double den)
+{
+    return (den > 0x1p-100 && den < 0x1p100) ? wsx_recip_refined(den) : 0.0;
+}
+__device__ __forceinline__ void bspl4(double xb, double xe, double den, double rden, double x, double h[5])
 {
     double hh[4];
     h[1] = 1.0;
@@ -685,7 +723,7 @@ __device__ __forceinline__ void bspl4(double xb, double xe, double x, double h[5
 #pragma unroll
         for (int i = 1; i <= j; i++) {
             // t(l+i) = xe, t(l+i-j) = xb for l = 4
-            const double f = hh[i] / (xe - xb);
+            const double f = rden != 0.0 ? wsx_div_by(hh[i], den, rden) : hh[i] / den;
             h[i] = h[i] + f * (xe - x);
             h[i + 1] = f * (x - xb);
         }
@@ -730,12 +768,13 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
         a.status[lr] = WSX_READ_FIT_ORDER;
         return;
     }
+    const double den = xe - xb, rden = wsx_bspl_rden(den);
     // banded upper-triangular A (4x4, row j: a[j][1..4]) and right-hand side z
     double A11 = 0, A12 = 0, A13 = 0, A14 = 0, A21 = 0, A22 = 0, A23 = 0, A31 = 0, A32 = 0, A41 = 0;
     double z1 = 0, z2 = 0, z3 = 0, z4 = 0, fp = 0.0;
     for (int it = 0; it < m; it++) {
         double h[5];
-        bspl4(xb, xe, x[it], h);
+        bspl4(xb, xe, den, rden, x[it], h);
         double yi = y[it] * 1.0;
         h[1] = h[1] * 1.0;
         h[2] = h[2] * 1.0;
@@ -802,9 +841,10 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
     const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
     const double *co = a.coef + (size_t)lr * 6;
     const double xb = co[0], xe = co[1], c1 = co[2], c2 = co[3], c3 = co[4], c4 = co[5];
+    const double den = xe - xb, rden = wsx_bspl_rden(den);
     for (int i = threadIdx.x; i < T; i += 256) {
         double h[5];
-        bspl4(xb, xe, a.signal[off + i], h);
+        bspl4(xb, xe, den, rden, a.signal[off + i], h);
         double sp = 0.0;
         sp = sp + c1 * h[1];
         sp = sp + c2 * h[2];
