@@ -272,15 +272,21 @@ __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
     // (a grid with one block per possible group, T/(m-1)/64 of them, is mostly empty blocks: runs last ~9 samples)
     for (int k0 = blockIdx.y * 64; k0 < v.n; k0 += RS_GROUPS * 64) {
         const int klast = (k0 + 64 < v.n ? k0 + 64 : v.n) - 1;
-        const int s_lo = v.fstart(k0), s_hi = v.fend(klast);
+        // Every thread fetches its own run first (start, end, state: three independent loads) and the group's span comes
+        // from the first and the last lane -- the staging loads and the expected levels then go out together, so a group
+        // costs three dependent memory round trips instead of five.
+        const int k = k0 + tid;
+        const bool mine = k <= klast;
+        const int s0 = mine ? v.fstart(k) : 0, s1 = mine ? v.fend(k) : 0, st = mine ? v.fstate(k) : 0;
+        const int s_lo = __builtin_amdgcn_readfirstlane(s0), s_hi = __builtin_amdgcn_readlane(s1, klast - k0);
+        const double expd = mine ? A.value[st] : 0.0;
         const bool staged = (s_hi - s_lo) <= RS_CAP;
         if (staged) {
             for (int q = tid; q < s_hi - s_lo; q += 64) buf[q] = sig[s_lo + q];
             __syncthreads();
         }
-        const int k = k0 + tid;
-        if (k <= klast) {
-            const int s0 = v.fstart(k), len = v.fend(k) - s0;
+        if (mine) {
+            const int len = s1 - s0;
             double val, sd;
             if (staged && len <= 128) { // common case: straight-line LDS reads
                 const double *p = buf + (s0 - s_lo);
@@ -290,7 +296,6 @@ __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
                 run_mean_std(sig, s0, len, val, sd);
             }
             if (a.prm.method_median) val = np_median(sig + s0, len);
-            const double expd = A.value[v.fstate(k)];
             const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
             a.al_value[v.off + k] = val;
             a.al_expected[v.off + k] = expd;
@@ -772,10 +777,16 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     // banded upper-triangular A (4x4, row j: a[j][1..4]) and right-hand side z
     double A11 = 0, A12 = 0, A13 = 0, A14 = 0, A21 = 0, A22 = 0, A23 = 0, A31 = 0, A32 = 0, A41 = 0;
     double z1 = 0, z2 = 0, z3 = 0, z4 = 0, fp = 0.0;
+    double xn = x[0], yn = y[0]; // the next point is fetched while the current one goes through its four rotations
     for (int it = 0; it < m; it++) {
+        const double xc = xn, yc = yn;
+        if (it + 1 < m) {
+            xn = x[it + 1];
+            yn = y[it + 1];
+        }
         double h[5];
-        bspl4(xb, xe, den, rden, x[it], h);
-        double yi = y[it] * 1.0;
+        bspl4(xb, xe, den, rden, xc, h);
+        double yi = yc * 1.0;
         h[1] = h[1] * 1.0;
         h[2] = h[2] * 1.0;
         h[3] = h[3] * 1.0;
