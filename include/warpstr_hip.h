@@ -13,6 +13,11 @@
  *                             _backtracking 247-301)
  *   wsx_prepare_signals  <->  Fast5.get_data_processed for every `saved` read (get_workload),
  *                             src/schemas/fast5.py:45-57, src/caller/wrapper.py:44-54
+ *   wsx_locate_flanks    <->  find_sequence(text, pattern) for a batch of (basecalled window, flank) pairs,
+ *                             src/extractor/tr_extractor.py:196-250 (align_seq 253-274 calls it twice per read);
+ *                             the alignment itself is Bio.pairwise2.align.localms (biopython ==1.75, absent here:
+ *                             parity of this entry point is UNPINNED, see oracle/flank_oracle.c)
+ *   wsx_moves_to_raw     <->  transform_moves + extract_from_moves, tr_extractor.py:147-193
  *   wsx_caller_create    <->  CallerWrapper.__init__ / init_pool: automata + config made
  *                             available to the workers, src/caller/wrapper.py:63-70,92-102
  *   wsx_automaton        <->  StateAutomata(states, endstate, mask), src/caller/automata.py:36-48
@@ -42,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 2
+#define WSX_ABI_VERSION 3
 
 /* function return codes */
 enum {
@@ -194,6 +199,50 @@ int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_laun
 
 /* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<1, 2, false>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);
+
+/* ---- flank localisation (upstream step 1) -------------------------------------------------------- */
+
+/* alignment_config, src/config.py:135-141 (upstream: 2, -3, -3, -3).  gap_open must equal gap_extend. */
+typedef struct wsx_align_scores {
+    int32_t match, mismatch, gap_open, gap_extend;
+} wsx_align_scores;
+
+/* One find_sequence result (Alignment, tr_extractor.py:45-63, before the accuracy/identity gate of __post_init__). */
+typedef struct wsx_flank_hit {
+    int32_t status;       /* 0 found; 1 no positive-scoring alignment (upstream: IndexError on pairwise2's empty list) */
+    int32_t score;        /* pairwise2 score + find_sequence's correction (tr_extractor.py:243-245) */
+    int32_t start, end;   /* Position(real_start, end) before origin_offset: text coordinates of the whole flank */
+    int32_t matches;      /* identity = matches / span (tr_extractor.py:234-246) */
+    int32_t span;         /* len(ref) */
+    int32_t row0, col0;   /* text / pattern bases in front of the local alignment */
+    int32_t row1, col1;   /* text / pattern bases up to its end */
+    int32_t gaps_text;    /* '-' in the aligned text inside the local region (nums_gaps) */
+    int32_t gaps_pattern; /* '-' in the aligned pattern inside the local region (nums_gaps2) */
+    int32_t raw_score;    /* the alignment's own score */
+    int32_t n_ops;        /* length of the local region */
+} wsx_flank_hit;
+
+/*
+ * Locates pattern r (pattern[pattern_offsets[r] .. pattern_offsets[r+1]), 1..256 bases) in text r for r = 0..n-1.
+ * text / pattern / hits / ops live where `mem` says; the offset arrays are host memory.  ops (optional): per pair
+ * ops_stride bytes, ops_stride >= 2 * (longest pattern) + 8, filled with the local region's operations in text order
+ * ('M' base against base, 'U' text base against a gap, 'L' pattern base against a gap), zero-padded -- enough to
+ * rebuild upstream's Mapping(ref, mapping, query) strings.  Blocks until the results are written.
+ */
+int wsx_locate_flanks(int device, void *stream, int mem, const uint8_t *text, const int64_t *text_offsets,
+                      const uint8_t *pattern, const int64_t *pattern_offsets, int64_t n, const wsx_align_scores *scores,
+                      wsx_flank_hit *hits, uint8_t *ops, int32_t ops_stride);
+
+/*
+ * Raw-signal positions of basecalled positions through Guppy's move table: for read r with moves
+ * moves[move_offsets[r] .. move_offsets[r+1]) (one byte per block), raw_start = strand_start + block_stride * (first block
+ * whose context index equals pos_start), raw_end = strand_start + block_stride * (last block whose context index equals
+ * pos_end); -1 where no block has that index.  moves / raw_start / raw_end live where `mem` says; the per-read
+ * parameter arrays are host memory.
+ */
+int wsx_moves_to_raw(int device, void *stream, int mem, const uint8_t *moves, const int64_t *move_offsets,
+                     const int32_t *pos_start, const int32_t *pos_end, const int64_t *strand_start,
+                     const int32_t *block_stride, int64_t n, int64_t *raw_start, int64_t *raw_end);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_ord
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
            'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize',
-           'wsx_caller_last_timing', 'wsx_caller_kernel_name']
+           'wsx_caller_last_timing', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
 
 
 class WsxAutomaton(C.Structure):
@@ -42,6 +42,16 @@ RESULT_DTYPE = np.dtype([('status', np.int32), ('len1', np.int32), ('len2', np.i
                          ('n_trans2', np.int32), ('reserved', np.int32), ('cost1', np.float64), ('cost2', np.float64),
                          ('dtw_end_cost1', np.float64), ('dtw_end_cost2', np.float64)], align=True)
 assert RESULT_DTYPE.itemsize == 56
+
+
+class WsxAlignScores(C.Structure):
+    _fields_ = [('match', C.c_int32), ('mismatch', C.c_int32), ('gap_open', C.c_int32), ('gap_extend', C.c_int32)]
+
+
+# numpy view of wsx_flank_hit
+FLANK_HIT_DTYPE = np.dtype([(n, np.int32) for n in ('status', 'score', 'start', 'end', 'matches', 'span', 'row0', 'col0', 'row1',
+                                                    'col1', 'gaps_text', 'gaps_pattern', 'raw_score', 'n_ops')])
+assert FLANK_HIT_DTYPE.itemsize == 56
 
 
 class HipLibraryMissing(RuntimeError):
@@ -77,6 +87,10 @@ def load():
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.wsx_caller_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_double)]
+    lib.wsx_locate_flanks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.wsx_moves_to_raw.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
