@@ -13,9 +13,10 @@
 // Kernels
 //   flank_score_kernel<CPL>   one wavefront per (read, flank) pair.  Lane L owns pattern columns L*CPL+1 .. L*CPL+CPL
 //       (CPL = 1, 2, 4: flanks up to 256 bases); the wave sweeps the text along anti-diagonals: at step t lane L is on
-//       text row t - L, so the value it needs from its left neighbour was produced one step earlier and arrives with a
-//       single cross-lane shuffle that also carries the text base (packed beside the score).  No matrix is stored:
-//       only the best cell survives.  Integer max-plus work, VALU-bound (7 VALU per cell); HBM traffic is the text once.
+//       text row t - L, so the value it needs from its left neighbour was produced one step earlier and arrives with one
+//       DPP move (wave_shr:1; lane 0 receives the zero of column 0).  Each lane fetches the eight text bases of its next
+//       eight rows with one load.  No matrix is stored: only the best cell survives.  Integer max-plus work, VALU-bound
+//       (7 VALU per cell + 3 per step); HBM traffic is the text once.
 //   flank_trace_kernel<CPL>   one wavefront per pair: the same sweep over the last WR rows before the best cell with a
 //       2-bit direction per cell parked in LDS (one byte per lane and row), then one lane walks back and evaluates
 //       find_sequence's string arithmetic.  Tiny next to the score pass (WR <= 5p/3 + 2 rows).
@@ -27,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/warpstr_hip.h"
@@ -62,8 +64,8 @@ struct FlankArgs {
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// One anti-diagonal step of the sweep for this lane's CPL columns.  `in` = packed word from the left neighbour:
-// bits 0..15 its last column's score on the row this lane is on now, bits 16..23 the text base of that row.
+// One anti-diagonal step of the sweep for this lane's CPL columns.  left_in = the left neighbour's last column on the
+// row this lane is on now (produced one step earlier), tc = the text base of that row.
 template <int CPL, bool TRACE>
 __device__ __forceinline__ void sweep_cell(const int (&pc)[CPL], int (&up)[CPL], int &diag_in, int left_in, int tc, bool valid,
                                            int match, int mismatch, int gap, int (&h_out)[CPL], uint32_t &dirs)
@@ -89,6 +91,9 @@ __device__ __forceinline__ void sweep_cell(const int (&pc)[CPL], int (&up)[CPL],
     diag_in = left_in; // the neighbour's value on this row is the diagonal input of the next row
 }
 
+// lane L receives lane L-1's value, lane 0 receives 0 (= column 0 of the matrix): one DPP move, no LDS round trip
+__device__ __forceinline__ int from_left_lane(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+
 template <int CPL>
 __global__ __launch_bounds__(256) void flank_score_kernel(FlankArgs a)
 {
@@ -105,31 +110,63 @@ __global__ __launch_bounds__(256) void flank_score_kernel(FlankArgs a)
         pc[c] = j < p ? (int)pat[j] : 0x100; // never equals a text base
         up[c] = 0;
     }
-    int diag_in = 0, out_word = 0;
-    int best = 0, bi = 0, bj = 0;
-    int tbuf = 0;
-    const int steps = n + 63;
-    for (int t = 1; t <= steps; t++) {
-        if (((t - 1) & 63) == 0) tbuf = (t - 1 + lane) < n ? (int)text[t - 1 + lane] : 0; // 64 text bases per load
-        const int t0c = __builtin_amdgcn_readlane(tbuf, (t - 1) & 63);                        // text base of row t (lane 0's row)
-        // neighbour's packed word from the previous step; lane 0 sits on row t: column 0 is all zeros
-        int in = __shfl_up(out_word, 1);
-        if (lane == 0) in = t0c << 16;
-        const int tc = (in >> 16) & 0xff;
-        const int i = t - lane; // this lane's text row (1-based)
-        const bool valid = i >= 1 && i <= n;
-        uint32_t dirs;
-        sweep_cell<CPL, false>(pc, up, diag_in, in & 0xffff, tc, valid, a.match, a.mismatch, a.gap, h, dirs);
+    int vmatch = a.match, vmismatch = a.mismatch; // kept in vector registers: v_cndmask cannot take two scalar operands
+    asm volatile("" : "+v"(vmatch), "+v"(vmismatch));
+    int best = 0, bi = 0, bj = 0; // this lane's latest cell that reached the wave's best score
+    int wbest = 1;                // best score of the whole wave so far (uniform), at least 1: zeros never count
+    int diag_in = 0, hlast = 0;
+    // Eight steps of the sweep: steps t0 .. t0+7, this lane on text rows t0 - lane .. t0 - lane + 7, whose bases arrive
+    // as one 8-byte load.  EDGE: groups in which some lane is above or below the text.
+    auto group = [&](int t0, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
+        uint32_t cw[2] = {0, 0};
+        const int first = t0 - lane - 1; // 0-based text index of this lane's row at step t0
+        if (!EDGE) {
+            __builtin_memcpy(cw, text + first, 8);
+        } else {
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int j = lane * CPL + c + 1;
-            if (valid && j <= p && h[c] > 0 && h[c] >= best) { // later cells win ties within a lane
-                best = h[c];
-                bi = i;
-                bj = j;
+            for (int k = 0; k < 8; k++) {
+                const int idx = first + k;
+                const uint32_t b = (idx >= 0 && idx < n) ? text[idx] : 0u;
+                cw[k >> 2] |= b << (8 * (k & 3));
             }
         }
-        out_word = (h[CPL - 1] & 0xffff) | (tc << 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int tc = (int)((cw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+            const int in = from_left_lane(hlast); // the neighbour's last column on this lane's row
+            const int i = t0 + k - lane;          // this lane's text row (1-based)
+            const bool valid = !EDGE || (i >= 1 && i <= n);
+            uint32_t dirs;
+            sweep_cell<CPL, false>(pc, up, diag_in, in, tc, valid, vmatch, vmismatch, a.gap, h, dirs);
+            // best cell: only a cell that reaches the best score of the whole wave so far can be (or tie with) the final
+            // best cell, and such cells are rare -- the bookkeeping sits behind one compare per column and a branch
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) any |= h[c] >= wbest;
+            if (__ballot(any) != 0ull) {
+                int hm = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int j = lane * CPL + c + 1;
+                    if (valid && j <= p && h[c] > 0 && h[c] >= wbest && h[c] >= best) { // later cells win ties within a lane
+                        best = h[c];
+                        bi = i;
+                        bj = j;
+                        hm = h[c];
+                    }
+                }
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) hm = max(hm, __shfl_xor(hm, sft));
+                wbest = max(wbest, rfl(hm));
+            }
+            hlast = h[CPL - 1];
+        }
+    };
+    const int steps = n + 63;
+    for (int t0 = 1; t0 <= steps; t0 += 8) {
+        if (t0 >= 64 && t0 + 7 <= n) group(t0, std::false_type{});
+        else group(t0, std::true_type{});
     }
     // best over the lanes: score, then text index, then pattern index
     unsigned long long key = ((unsigned long long)(unsigned)best << 48) | ((unsigned long long)(unsigned)bi << 16) | (unsigned)bj;
@@ -176,18 +213,16 @@ __global__ __launch_bounds__(64) void flank_trace_kernel(FlankArgs a, int max_ro
         pc[c] = j < p ? (int)pat[j] : 0x100;
         up[c] = 0;
     }
-    int diag_in = 0, out_word = 0;
+    int diag_in = 0, hlast = 0;
     for (int t = 1; t <= rows + 63; t++) {
-        const int t0c = (t <= rows) ? (int)text[i0 + t - 1] : 0; // uniform load
-        int in = __shfl_up(out_word, 1);
-        if (lane == 0) in = t0c << 16;
-        const int tc = (in >> 16) & 0xff;
         const int r = t - lane; // window row 1..rows
         const bool valid = r >= 1 && r <= rows;
+        const int tc = valid ? (int)text[i0 + r - 1] : 0;
+        const int in = from_left_lane(hlast);
         uint32_t dirs;
-        sweep_cell<CPL, true>(pc, up, diag_in, in & 0xffff, tc, valid, a.match, a.mismatch, a.gap, h, dirs);
+        sweep_cell<CPL, true>(pc, up, diag_in, in, tc, valid, a.match, a.mismatch, a.gap, h, dirs);
         if (valid) dirs_lds[r * 64 + lane] = (uint8_t)dirs;
-        out_word = (h[CPL - 1] & 0xffff) | (tc << 16);
+        hlast = h[CPL - 1];
     }
     __syncthreads();
     if (lane != 0) return;
