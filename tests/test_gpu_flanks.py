@@ -88,3 +88,43 @@ def test_moves_to_raw_matches_oracle():
     got = extractor.extract_from_moves_batch(moves, pos, ss, bs)
     for m, p, s, b, g in zip(moves, pos, ss, bs, got):
         assert (g.start, g.end) == flank.extract_from_moves(m, p.start, p.end, s, b)
+
+
+def test_extract_tr_batch_end_to_end():
+    """extract_tr's flow on synthetic basecalled reads: window around the mapped location, both flanks, raw positions
+    through the move table, repeat sequence (reverse-complemented for reverse-strand reads)."""
+    rng = np.random.default_rng(31)
+    tpl = extractor.Flank(left=''.join('ACGT'[k] for k in rng.integers(0, 4, 110)), right=''.join('ACGT'[k] for k in rng.integers(0, 4, 110)))
+    comp = str.maketrans('ACGT', 'TGCA')
+    rev = extractor.Flank(left=tpl.right.translate(comp)[::-1], right=tpl.left.translate(comp)[::-1])
+    reads, truth = [], []
+    for k in range(10):
+        is_rev = bool(k % 2)
+        fl = rev if is_rev else tpl
+        n0 = int(rng.integers(2000, 60000))
+        head = ''.join('ACGT'[q] for q in rng.integers(0, 4, n0))
+        rep = 'AGC' * int(rng.integers(8, 40))
+        tail = ''.join('ACGT'[q] for q in rng.integers(0, 4, int(rng.integers(500, 8000))))
+        fasta = head + fl.left + rep + fl.right + tail
+        stride = 5
+        moves = np.zeros(len(fasta) * 2 + 3, dtype=np.uint8)   # every base lasts two blocks
+        moves[::2][:len(fasta)] = 1
+        reads.append(extractor.BasecalledRead(f'r{k}', is_rev, fasta, moves, strand_start=100 + k, block_stride=stride,
+                                              approx_location=n0 + 50 if k % 3 else None))
+        truth.append((n0, n0 + 110, n0 + 110 + len(rep), n0 + 220 + len(rep), rep))
+    res = extractor.extract_tr_batch(reads, tpl, rev)
+    for rd, r, (ls, le, rs_, re_, rep) in zip(reads, res, truth):
+        assert r.valid == 1 and r.read_id == rd.name
+        assert (r.l_alignment.position.start, r.l_alignment.position.end) == (ls, le)
+        assert (r.r_alignment.position.start, r.r_alignment.position.end) == (rs_, re_)
+        assert r.l_alignment.identity == 1.0 and r.l_alignment.score == 220
+        want_seq = rep.translate(comp)[::-1] if rd.reverse else rep
+        assert r.sequence == want_seq
+        # base b occupies blocks 2b and 2b+1: context index b first appears at block 2b, last at 2b+1
+        assert r.lflank_raw.start == rd.strand_start + 2 * ls * rd.block_stride
+        assert r.lflank_raw.end == rd.strand_start + (2 * le + 1) * rd.block_stride
+        assert r.rflank_raw.start == rd.strand_start + 2 * rs_ * rd.block_stride
+    # a read that does not contain the flanks
+    junk = extractor.BasecalledRead('junk', False, 'ACGT' * 500, np.ones(100, np.uint8), 0, 5)
+    bad = extractor.extract_tr_batch([junk], tpl, rev)[0]
+    assert bad.valid == 0 and bad.sequence is None and bad.lflank_raw.start == -1

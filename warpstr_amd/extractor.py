@@ -177,3 +177,77 @@ def extract_from_moves_batch(moves: Sequence[np.ndarray], positions: Sequence[Po
     _lib.check(lib.wsx_moves_to_raw(device, None, _lib.WSX_MEM_HOST, _lib.ptr(buf), _lib.ptr(off), _lib.ptr(ps), _lib.ptr(pe),
                                     _lib.ptr(ss), _lib.ptr(bs), n, _lib.ptr(rs), _lib.ptr(re)), 'wsx_moves_to_raw')
     return [Position(int(a), int(b)) for a, b in zip(rs, re)]
+
+
+@dataclass
+class BasecalledRead:
+    """What extract_tr reads from an annotated fast5 (Fast5.get_tr_extract_reqs, src/schemas/fast5.py:35-45)."""
+    name: str
+    reverse: bool
+    fasta: str
+    moves: np.ndarray
+    strand_start: int
+    block_stride: int
+    approx_location: Optional[int] = None
+
+
+@dataclass
+class FlankInRead:                                           # tr_extractor.py:76-100
+    read_id: str
+    lflank_raw: Position
+    rflank_raw: Position
+    l_alignment: Alignment
+    r_alignment: Alignment
+    sequence: Optional[str]
+
+    @property
+    def valid(self) -> int:
+        return int(self.l_alignment.found and self.r_alignment.found and self.lflank_raw.valid and self.rflank_raw.valid)
+
+
+_COMPLEMENT = str.maketrans('ACGTacgt', 'TGCAtgca')
+
+
+def extract_tr_batch(reads: Sequence[BasecalledRead], template: Flank, reverse: Flank,
+                     config: Optional[AlignmentConfig] = None, device: int = 0) -> List[FlankInRead]:
+    """extract_tr (tr_extractor.py:277-340) for a batch of basecalled reads, without the file handling: the search
+    window around the mapped location, both flank alignments, the move-table mapping to raw positions and the
+    basecalled repeat sequence."""
+    cfg = config or AlignmentConfig()
+    windows, starts, flanks = [], [], []
+    for rd in reads:
+        n = len(rd.fasta)
+        if not rd.approx_location:
+            start, end = 0, n - 1
+        else:
+            loc = min(max(rd.approx_location, 0), n)
+            start = max(int(loc - 0.05 * n - 5000), 0)
+            end = min(int(loc + 0.05 * n + 5000), n - 1)
+        windows.append(rd.fasta[start:end])
+        starts.append(start)
+        flanks.append(reverse if rd.reverse else template)
+    pairs = align_seqs(windows, flanks, cfg, device=device)
+    out: List[Optional[FlankInRead]] = [None] * len(reads)
+    idx, mv, pos_l, pos_r, ss, bs = [], [], [], [], [], []
+    for r, (rd, (la, ra)) in enumerate(zip(reads, pairs)):
+        if not la.found or not ra.found:
+            out[r] = FlankInRead(rd.name, Position(-1, -1), Position(-1, -1), la, ra, None)
+            continue
+        for al in (la, ra):
+            al.position.start += starts[r]
+            al.position.end += starts[r]
+        idx.append(r)
+        mv += [rd.moves, rd.moves]
+        pos_l.append(la.position)
+        pos_r.append(ra.position)
+        ss += [rd.strand_start, rd.strand_start]
+        bs += [rd.block_stride, rd.block_stride]
+    if idx:
+        raw = extract_from_moves_batch(mv, [p for pair in zip(pos_l, pos_r) for p in pair], ss, bs, device=device)
+        for k, r in enumerate(idx):
+            rd, (la, ra) = reads[r], pairs[r]
+            seq = rd.fasta[la.position.end:ra.position.start]
+            if seq and rd.reverse:
+                seq = seq.translate(_COMPLEMENT)[::-1]       # get_reverse_strand
+            out[r] = FlankInRead(rd.name, raw[2 * k], raw[2 * k + 1], la, ra, seq)
+    return out  # type: ignore[return-value]
