@@ -13,7 +13,7 @@
 // used by the parity tests.
 //
 // Parallelisation: flat kernels, no serialised phases (see the kernel list further down):
-//   run_stats_kernel   thread per run             borders_kernel   thread per read
+//   run_stats_kernel   thread per run             borders_kernel   wavefront per read
 //   tstat_kernel       thread per sample          chunk_kernel     thread per (read, chunk)
 //   sort_kernel        wavefront per read         fit_kernel       thread per read (sequential Givens recurrence)
 //   eval_kernel        thread per sample (de Boor evaluation, 6 divisions)
@@ -225,7 +225,7 @@ __device__ void py_slice(long long a, long long b, long long n, int *lo, int *hi
 // ------------------------------------------------------------------------------------------------
 // The stage between the DTW passes as FLAT kernels (each massively parallel, no serialised phases):
 //   run_stats_kernel   one thread per run            : alignment records (mean/std/good/cost)
-//   borders_kernel     one thread per read           : find_event_borders, status, cost, allele length
+//   borders_kernel     one wavefront per read        : find_event_borders, status, cost, allele length
 //   tstat_kernel       one thread per sample         : sliding-window statistics and t-statistic; zeroes the mask
 //   chunk_kernel       one thread per (read, chunk)  : segment() peak scan -> bad-repeat mask
 //   sort_kernel        one wavefront per read        : stable sort of the accepted (value, expected) pairs
@@ -351,8 +351,160 @@ __global__ __launch_bounds__(64) void reps_stats_kernel(MidArgs a)
     a.n_align[lr] = u;
 }
 
-// (2,3,5) per read: allele length, find_event_borders, chunk range checks, state-wise cost, results
-__global__ __launch_bounds__(64) void borders_kernel(MidArgs a)
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// NumPy's pairwise sum of a[0..n) (n <= 128) with the eight partial sums on lanes 0..7: the same additions in the same
+// order as pw_block, the strided accumulations side by side.  Every lane returns the result.
+__device__ __forceinline__ double pw_block_wave(const double *a, int n, int lane)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r = lane < 8 ? a[lane] : 0.0;
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        if (lane < 8) r += a[i + lane];
+    const double r0 = readlane_f64(r, 0), r1 = readlane_f64(r, 1), r2 = readlane_f64(r, 2), r3 = readlane_f64(r, 3),
+                 r4 = readlane_f64(r, 4), r5 = readlane_f64(r, 5), r6 = readlane_f64(r, 6), r7 = readlane_f64(r, 7);
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// (2,3,5) per read: allele length, find_event_borders, chunk range checks, state-wise cost, results.  One wavefront per
+// read: the scans over the run list (good records, first/last repeat state, the run that closes the last chunk, the
+// chunk range checks) are lane-parallel with wave reductions, the state-wise cost keeps NumPy's summation order.
+__global__ __launch_bounds__(256) void borders_kernel(MidArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int lr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lr >= a.n_reads) return;
+    wsx_result *res = (wsx_result *)a.results + lr;
+    MidRec rec{};
+    int status = a.status[lr];
+    if (status != 0) {
+        if (lane == 0) {
+            res->status = status;
+            if (a.pass == 1) {
+                res->len1 = res->len2 = res->n_trans1 = res->n_trans2 = 0;
+                res->reserved = 0;
+                res->cost1 = res->cost2 = __builtin_nan("");
+                res->dtw_end_cost1 = res->dtw_end_cost2 = kInf;
+            }
+            a.rec[lr] = rec;
+        }
+        return;
+    }
+    const ReadView v = view(a, lr);
+    const DevAutomaton &A = a.aut[a.aut_id[v.r]];
+    const int n = v.n, T = v.T, sis = a.prm.states_in_segment;
+    const uint8_t *alg = a.al_good + v.off;
+    const double *alc = a.al_cost + v.off;
+
+    int slo, shi;
+    py_slice((long long)A.flank_length - A.seq_idx[v.fstate(0)], -(long long)A.flank_length, n, &slo, &shi);
+    const int seqlen = shi - slo;
+
+    const int na = a.n_align ? a.n_align[lr] : n; // alignment records: one per run, or per distinct state
+    // 64 runs per step, one per lane; ballots turn the flags into wave masks: counts and first/last positions are scalar
+    int n_good = 0, start = -1, end = -1;
+    for (int k0 = 0; k0 < na; k0 += 64) n_good += __builtin_popcountll(__ballot(k0 + lane < na && alg[k0 + lane]));
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const unsigned long long rep = __ballot(k0 + lane < n && A.repeat_mask[v.fstate(k0 + lane)]);
+        if (rep) {
+            if (start < 0) start = k0 + __builtin_ctzll(rep);
+            end = k0 + 63 - __builtin_clzll(rep);
+        }
+    }
+    int nsel = 0, nb = 0;
+    if (n_good < 4) {
+        status = WSX_READ_FIT_POINTS; // rescale_signal runs (and fails) before mask_bad_repeats upstream
+    } else if (start < 0) {
+        status = WSX_READ_NO_REPEAT;
+    } else {
+        nb = end - start;
+        const int add = (((nb - 1) % sis) + sis) % sis;
+        if (add > 0) {
+            end = end + (sis - add);
+            if (end >= n) {
+                status = WSX_READ_SEGMENT_RANGE;
+            } else {
+                const int es = v.fstate(end);
+                int eR = end; // the last run in the same state after `end`, or `end` itself
+                for (int k0 = end + 1; k0 < n; k0 += 64) {
+                    const unsigned long long same = __ballot(k0 + lane < n && v.fstate(k0 + lane) == es);
+                    if (same) eR = k0 + 63 - __builtin_clzll(same);
+                }
+                nb = eR - start;
+            }
+        }
+        if (status == 0) {
+            nsel = nb > 0 ? (nb + sis - 1) / sis : 0;
+            if (nsel == 0) status = WSX_READ_SEGMENT_RANGE;
+        }
+    }
+    if (status == 0) {
+        for (int c0 = 0; c0 < nsel - 1; c0 += 64) { // segment() would index an empty t_stats / wrap a negative slice
+            const int c = c0 + lane;
+            bool bad = false;
+            if (c < nsel - 1) {
+                const int lo = v.fend(start + c * sis) - 1 - 3;
+                int hi = v.fend(start + (c + 1) * sis) - 1 + 3;
+                if (hi > T) hi = T;
+                bad = lo < 0 || hi - lo - 5 <= 0;
+            }
+            if (__ballot(bad)) status = WSX_READ_SEGMENT_RANGE;
+        }
+    }
+    double cost = __builtin_nan("");
+    if (status == 0) {
+        int clo, chi;
+        py_slice(start, end, na, &clo, &chi);
+        if (chi > clo) {
+            const int len = chi - clo;
+            const double sum = len <= 128 ? pw_block_wave(alc + clo, len, lane) : np_pairwise_sum(LoadPlain{alc + clo}, len);
+            cost = sum / (double)len;
+        }
+        rec.start = start;
+        rec.nsel = nsel;
+        rec.p_lo = v.fend(start) - 1 - 3;
+        int p_hi = v.fend(start + (nsel - 1) * sis) - 1 + 3;
+        rec.p_hi = p_hi > T ? T : p_hi;
+        rec.n_good = n_good;
+    }
+    if (lane != 0) return;
+    a.rec[lr] = rec;
+    a.status[lr] = status;
+    res->status = status;
+    if (a.pass == 1) {
+        res->len1 = seqlen;
+        res->n_trans1 = n;
+        res->cost1 = cost;
+        res->len2 = 0;
+        res->n_trans2 = 0;
+        res->reserved = 0;
+        res->cost2 = __builtin_nan("");
+        res->dtw_end_cost1 = a.end_cost ? a.end_cost[lr] : kInf;
+        res->dtw_end_cost2 = kInf;
+    } else {
+        res->len2 = seqlen;
+        res->n_trans2 = n;
+        res->cost2 = cost;
+        if (a.end_cost) res->dtw_end_cost2 = a.end_cost[lr];
+    }
+}
+
+// (2,3,5) once more with one THREAD per read: per read it is a serial walk over the run list (every step a dependent
+// load), but 64 reads share each instruction -- less total work than a wavefront per read, so big launches take this one
+// (a launch lasts at least the ~50 us one thread needs).
+__global__ __launch_bounds__(64) void borders_thread_kernel(MidArgs a)
 {
     const int lr = blockIdx.x * blockDim.x + threadIdx.x;
     if (lr >= a.n_reads) return;
@@ -876,7 +1028,9 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
     if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, std::min((max_runs + 63) / 64, RS_GROUPS)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+    // small launches: a wavefront per read (latency); big ones: a thread per read (throughput)
+    if (a.n_reads < 8192) hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(borders_thread_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.seq_out) hipLaunchKernelGGL(sequence_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;
