@@ -352,6 +352,14 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
             dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext, mk, cutm);
             if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
         };
+        // the same, the masks handed back instead of stored (the caller stores a whole group at once)
+        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr bool FORCED = decltype(forced)::value;
+            constexpr bool CUT = decltype(cut)::value;
+            constexpr bool MROW = decltype(msk)::value;
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext, mk, cutm);
+        };
         // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
         // 64-byte scalar load; the rows before and after such groups load theirs one by one
         auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
@@ -368,14 +376,38 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
             for (; i + 8 <= phi && i + 8 < T; i += 8) {
                 const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
                 uint64_t *gp = bp + (size_t)(unsigned)i * NM;
-                row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
-                row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
-                row(P0{}, forced, cut, msk, std::integral_constant<int, 2>{}, gp, v[2]);
-                row(P1{}, forced, cut, msk, std::integral_constant<int, 3>{}, gp, v[3]);
-                row(P0{}, forced, cut, msk, std::integral_constant<int, 4>{}, gp, v[4]);
-                row(P1{}, forced, cut, msk, std::integral_constant<int, 5>{}, gp, v[5]);
-                row(P0{}, forced, cut, msk, std::integral_constant<int, 6>{}, gp, v[6]);
-                row(P1{}, forced, cut, msk, std::integral_constant<int, 7>{}, gp, v[7]);
+                if constexpr (NM <= 2 && !decltype(forced)::value) {
+                    // The scalar stores of the eight rows leave together after the group.  A scalar store counts on the
+                    // same counter as the LDS reads and completes out of order with them, so a store in flight makes
+                    // every counted LDS wait behind it a wait for the store as well -- invisible with eight waves
+                    // per SIMD, but it was most of a lone wave's time per row (small batches).
+                    uint64_t g0[NM], g1[NM], g2[NM], g3[NM], g4[NM], g5[NM], g6[NM], g7[NM];
+                    row_keep(P0{}, forced, cut, msk, v[0], g0);
+                    row_keep(P1{}, forced, cut, msk, v[1], g1);
+                    row_keep(P0{}, forced, cut, msk, v[2], g2);
+                    row_keep(P1{}, forced, cut, msk, v[3], g3);
+                    row_keep(P0{}, forced, cut, msk, v[4], g4);
+                    row_keep(P1{}, forced, cut, msk, v[5], g5);
+                    row_keep(P0{}, forced, cut, msk, v[6], g6);
+                    row_keep(P1{}, forced, cut, msk, v[7], g7);
+                    store_row_masks<NM, 0>(g0, gp);
+                    store_row_masks<NM, 1>(g1, gp);
+                    store_row_masks<NM, 2>(g2, gp);
+                    store_row_masks<NM, 3>(g3, gp);
+                    store_row_masks<NM, 4>(g4, gp);
+                    store_row_masks<NM, 5>(g5, gp);
+                    store_row_masks<NM, 6>(g6, gp);
+                    store_row_masks<NM, 7>(g7, gp);
+                } else {
+                    row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
+                    row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
+                    row(P0{}, forced, cut, msk, std::integral_constant<int, 2>{}, gp, v[2]);
+                    row(P1{}, forced, cut, msk, std::integral_constant<int, 3>{}, gp, v[3]);
+                    row(P0{}, forced, cut, msk, std::integral_constant<int, 4>{}, gp, v[4]);
+                    row(P1{}, forced, cut, msk, std::integral_constant<int, 5>{}, gp, v[5]);
+                    row(P0{}, forced, cut, msk, std::integral_constant<int, 6>{}, gp, v[6]);
+                    row(P1{}, forced, cut, msk, std::integral_constant<int, 7>{}, gp, v[7]);
+                }
             }
             for (; i < phi; i++) one(i);
         };
