@@ -152,6 +152,16 @@ __device__ __forceinline__ void store_row_masks(const uint64_t (&mk)[NM], uint64
     }
 }
 
+// the masks of G consecutive rows (group rows RBASE .. RBASE+G-1), kept in SGPRs until now
+template <int NM, int G, int RBASE, int Q = 0>
+__device__ __forceinline__ void store_row_group(const uint64_t (&gm)[G][NM], uint64_t *base)
+{
+    if constexpr (Q < G) {
+        store_row_masks<NM, RBASE + Q>(gm[Q], base);
+        store_row_group<NM, G, RBASE, Q + 1>(gm, base);
+    }
+}
+
 // masks per row: slot 0 holds F, every further slot FL; mask (k, f) is entry mask_index(k, f) of the row record
 template <int F, int FL>
 __host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f : F + (k - 1) * FL + f; }
@@ -376,28 +386,25 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
             for (; i + 8 <= phi && i + 8 < T; i += 8) {
                 const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
                 uint64_t *gp = bp + (size_t)(unsigned)i * NM;
-                if constexpr (NM <= 2 && !decltype(forced)::value) {
-                    // The scalar stores of the eight rows leave together after the group.  A scalar store counts on the
-                    // same counter as the LDS reads and completes out of order with them, so a store in flight makes
-                    // every counted LDS wait behind it a wait for the store as well -- invisible with eight waves
-                    // per SIMD, but it was most of a lone wave's time per row (small batches).
-                    uint64_t g0[NM], g1[NM], g2[NM], g3[NM], g4[NM], g5[NM], g6[NM], g7[NM];
-                    row_keep(P0{}, forced, cut, msk, v[0], g0);
-                    row_keep(P1{}, forced, cut, msk, v[1], g1);
-                    row_keep(P0{}, forced, cut, msk, v[2], g2);
-                    row_keep(P1{}, forced, cut, msk, v[3], g3);
-                    row_keep(P0{}, forced, cut, msk, v[4], g4);
-                    row_keep(P1{}, forced, cut, msk, v[5], g5);
-                    row_keep(P0{}, forced, cut, msk, v[6], g6);
-                    row_keep(P1{}, forced, cut, msk, v[7], g7);
-                    store_row_masks<NM, 0>(g0, gp);
-                    store_row_masks<NM, 1>(g1, gp);
-                    store_row_masks<NM, 2>(g2, gp);
-                    store_row_masks<NM, 3>(g3, gp);
-                    store_row_masks<NM, 4>(g4, gp);
-                    store_row_masks<NM, 5>(g5, gp);
-                    store_row_masks<NM, 6>(g6, gp);
-                    store_row_masks<NM, 7>(g7, gp);
+                if constexpr (NM <= 4 && !decltype(forced)::value) {
+                    // The scalar stores of G rows leave together (G = as many rows as fit ~32 SGPRs of masks; single-slot
+                    // automata: with more masks per row the grouping bought nothing).  A scalar
+                    // store counts on the same counter as the LDS reads and completes out of order with them, so a store
+                    // in flight turns every counted LDS wait behind it into a wait for the store as well.
+                    constexpr int G = NM <= 2 ? 8 : 4;
+                    uint64_t gm[G][NM];
+#define WSX_ROW(R)                                                                                                  \
+    row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], gm[(R) % G]);                            \
+    if constexpr (((R) % G) == G - 1) store_row_group<NM, G, (R) - (G - 1)>(gm, gp);
+                    WSX_ROW(0)
+                    WSX_ROW(1)
+                    WSX_ROW(2)
+                    WSX_ROW(3)
+                    WSX_ROW(4)
+                    WSX_ROW(5)
+                    WSX_ROW(6)
+                    WSX_ROW(7)
+#undef WSX_ROW
                 } else {
                     row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
                     row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
