@@ -774,14 +774,16 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
     int bit = a.aut[aid].endstate; // K = 1: position = state
     int i = T - 1;                 // rows above i are not part of the walk
     int c = i / RC;
-    Step cur, n1, n2;
-    load(cur, c);
-    load(n1, c - 1);
-    load(n2, c - 2);
-    for (; c >= 0; c--) {
+    // three steps in registers with statically rotating roles: one is processed while the loads of the other two are in
+    // flight (copying a step from one set of registers to another would wait for its load)
+    Step s0, s1, s2;
+    load(s0, c);
+    load(s1, c - 1);
+    load(s2, c - 2);
+    auto process = [&](const Step &cur, int cc) {
 #pragma unroll
         for (int rr = RC - 1; rr >= 0; rr--) {
-            const int r = c * RC + rr;
+            const int r = cc * RC + rr;
             uint32_t e = 0; // bit f: predecessor f beat everything before it at (r, bit)
 #pragma unroll
             for (int f = 0; f < F; f++) {
@@ -797,9 +799,15 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
                 i = r - back;
             }
         }
-        cur = n1;
-        n1 = n2;
-        load(n2, c - 3);
+    };
+    // (steps below row 0 are empty: their loads are clamped and `r <= i` is false for their rows)
+    for (; c >= 0; c -= 3) {
+        process(s0, c);
+        load(s0, c - 3);
+        process(s1, c - 1);
+        load(s1, c - 4);
+        process(s2, c - 2);
+        load(s2, c - 5);
     }
     close_run(bit, 0); // row 0 is reached in this state
     if (open_state >= 0) push(open_state, open_start);
