@@ -77,7 +77,7 @@ def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
             'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
 
 
-VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s3_pmc.json); the formulation's floor is 10
+VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s4_pmc.json); the formulation's floor is 10
 LDS_CYCLES_PER_ROW = 10.0    # 2 ds_read_b64 (2 cycles each) + 1 ds_write_b64 (~6): MI355X_MICROARCH.md, LDS table
 N_SIMD, N_CU, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 256, 2.4e9, 1.89e9
 
@@ -191,9 +191,9 @@ def main():
         algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         cells_per_s = reads_per_launch * T * S / (launch_ms * 1e-3)
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s3_traffic.json), same workload only
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s4_traffic.json), same workload only
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01s3_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01s4_traffic.json')) as f:
                 tj = json.load(f)
             if tj['workload']['samples'] == T:
                 traffic = tj['hbm_bytes_per_launch'] / tj['workload']['reads'] * reads_per_launch
