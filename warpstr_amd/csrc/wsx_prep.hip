@@ -33,7 +33,8 @@ struct PrepArgs {
     const int64_t *seg_lo; // device, [n] l_start_raw
     const int64_t *seg_hi; // device, [n] r_end_raw (inclusive)
     const int64_t *ooff;   // device, [n+1] output offsets (chunk-relative)
-    uint32_t *hist;        // [n][65536]
+    uint32_t *hist;        // [n][65536]; bin = value - (smallest value of the read); only the occupied range is touched
+    int32_t *mm;           // [n][2]: smallest and largest raw value of the read
     double *shift_scale;   // [n][2]
     double *out;
     int n;
@@ -46,12 +47,39 @@ __device__ __forceinline__ bool is_outlier(const int16_t *raw, long long i)
     return i > 2 && (v > 1000 || v < 250);
 }
 
+#define PREP_CHUNK 16384 // samples per block in the histogram pass (one private LDS histogram per block)
+#define PREP_STREAM 4096 // samples per block in the copy and spike passes (latency-bound: many small blocks)
+
+// copy + smallest / largest value of the read (spike removal writes medians of neighbours, so the range stays valid)
 __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
     const long long len = a.roff[r + 1] - a.roff[r];
-    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256)
-        a.clean[a.roff[r] + i] = a.raw[a.roff[r] + i];
+    const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
+    int lo = 32767, hi = -32768;
+    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
+        const int16_t v = a.raw[a.roff[r] + i];
+        a.clean[a.roff[r] + i] = v;
+        lo = min(lo, (int)v);
+        hi = max(hi, (int)v);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        lo = min(lo, __shfl_xor(lo, s));
+        hi = max(hi, __shfl_xor(hi, s));
+    }
+    if ((threadIdx.x & 63) == 0 && c0 < c1) {
+        atomicMin(&a.mm[2 * r], lo);
+        atomicMax(&a.mm[2 * r + 1], hi);
+    }
+}
+
+// zeroes the occupied range of every read's histogram
+__global__ __launch_bounds__(256) void zero_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const int range = a.mm[2 * r + 1] - a.mm[2 * r] + 1;
+    uint32_t *h = a.hist + (size_t)r * 65536;
+    for (int b = blockIdx.y * 256 + threadIdx.x; b < range; b += gridDim.y * 256) h[b] = 0u;
 }
 
 // np.median of 2..5 int16 values, stored back into int16 (truncation toward zero)
@@ -78,7 +106,8 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
     const long long len = a.roff[r + 1] - a.roff[r];
     const int16_t *raw = a.raw + a.roff[r];
     int16_t *out = a.clean + a.roff[r];
-    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256) {
+    const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
+    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
         if (!is_outlier(raw, i)) continue;
         // head of a chain: neither of the two previous samples is an outlier
         if ((i >= 1 && is_outlier(raw, i - 1)) || (i >= 2 && is_outlier(raw, i - 2))) continue;
@@ -95,23 +124,42 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
     }
 }
 
+#define PREP_LDS_BINS 8192
+// Counts one PREP_CHUNK of a read.  A raw read occupies a few thousand of the 65536 possible values, so the block counts
+// into a private LDS histogram over [smallest value, +PREP_LDS_BINS) and adds only its non-zero bins to the read's
+// histogram in HBM (a global atomic per SAMPLE serialises on the few hundred hot bins: it was half of the loader's
+// time); reads with a wider range count straight into HBM.
 __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
 {
+    __shared__ uint32_t lh[PREP_LDS_BINS];
     const int r = blockIdx.x;
     const long long len = a.roff[r + 1] - a.roff[r];
+    const long long c0 = (long long)blockIdx.y * PREP_CHUNK, c1 = c0 + PREP_CHUNK < len ? c0 + PREP_CHUNK : len;
+    if (c0 >= c1) return;
     const int16_t *x = a.clean + a.roff[r];
+    const int vmin = a.mm[2 * r], range = a.mm[2 * r + 1] - vmin + 1;
     uint32_t *h = a.hist + (size_t)r * 65536;
-    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256)
-        atomicAdd(&h[(int)x[i] + 32768], 1u);
+    if (range <= PREP_LDS_BINS) {
+        for (int b = threadIdx.x; b < range; b += 256) lh[b] = 0u;
+        __syncthreads();
+        for (long long i = c0 + threadIdx.x; i < c1; i += 256) atomicAdd(&lh[(int)x[i] - vmin], 1u);
+        __syncthreads();
+        for (int b = threadIdx.x; b < range; b += 256) {
+            const uint32_t c = lh[b];
+            if (c) atomicAdd(&h[b], c);
+        }
+    } else {
+        for (long long i = c0 + threadIdx.x; i < c1; i += 256) atomicAdd(&h[(int)x[i] - vmin], 1u);
+    }
 }
 
 // value of the order statistic of rank k (0-based) given the histogram: smallest v with cum(v) > k
 // wave-cooperative; returns the same value in every lane
-__device__ int order_stat(const uint32_t *h, long long k, int lane)
+__device__ int order_stat(const uint32_t *h, int vmin, int range, long long k, int lane)
 {
     long long before = 0;
-    for (int base = 0; base < 65536; base += 64) {
-        const unsigned c = h[base + lane];
+    for (int base = 0; base < range; base += 64) {
+        const unsigned c = base + lane < range ? h[base + lane] : 0u;
         if (__ballot(c != 0) == 0ull) continue; // empty 64-bin group (most of the int16 range)
         // inclusive scan over the wave
         unsigned long long inc = c;
@@ -122,11 +170,11 @@ __device__ int order_stat(const uint32_t *h, long long k, int lane)
         const unsigned long long total = __shfl(inc, 63);
         if (before + (long long)total > k) {
             const unsigned long long hit = __ballot(before + (long long)inc > k);
-            return base + __builtin_ctzll(hit) - 32768;
+            return base + __builtin_ctzll(hit) + vmin;
         }
         before += (long long)total;
     }
-    return 32767;
+    return vmin + range - 1;
 }
 
 __device__ double np_lerp(double a, double b, double t)
@@ -143,6 +191,7 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
     const int lane = threadIdx.x;
     const long long n = a.roff[r + 1] - a.roff[r];
     const uint32_t *h = a.hist + (size_t)r * 65536;
+    const int vmin = a.mm[2 * r], vmax = a.mm[2 * r + 1], range = vmax - vmin + 1;
     if (n <= 0) {
         if (lane == 0) {
             a.shift_scale[2 * r] = 0.0;
@@ -159,7 +208,7 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
         if (vi >= (double)(n - 1)) prev = next = n - 1;
         if (vi < 0) prev = next = 0;
         const double gamma = vi - floor(vi);
-        const double xa = (double)order_stat(h, prev, lane), xb = (double)order_stat(h, next, lane);
+        const double xa = (double)order_stat(h, vmin, range, prev, lane), xb = (double)order_stat(h, vmin, range, next, lane);
         pct[t] = np_lerp(xa, xb, gamma);
     }
     const double shift = ((0.0 + pct[0]) + pct[1]) / 2.0;
@@ -168,14 +217,14 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
     if (lane == 0) {
         long long need_hi = n / 2, need_lo = (n % 2) ? n / 2 : n / 2 - 1; // ranks of the middle order statistics
         int lo = (int)floor(shift), hi = lo + 1;                          // lo <= shift < hi
-        if (lo > 32767) { lo = 32767; hi = 32768; }
-        if (lo < -32769) { lo = -32769; hi = -32768; }
+        if (lo > vmax) { lo = vmax; hi = vmax + 1; }
+        if (lo < vmin - 1) { lo = vmin - 1; hi = vmin; }
         long long seen = 0;
         double d_lo = 0.0, d_hi = 0.0;
         bool got_lo = false, got_hi = false;
-        while (!got_hi && (lo >= -32768 || hi <= 32767)) {
-            const double dl = lo >= -32768 ? fabs((double)lo - shift) : __builtin_huge_val();
-            const double dh = hi <= 32767 ? fabs((double)hi - shift) : __builtin_huge_val();
+        while (!got_hi && (lo >= vmin || hi <= vmax)) {
+            const double dl = lo >= vmin ? fabs((double)lo - shift) : __builtin_huge_val();
+            const double dh = hi <= vmax ? fabs((double)hi - shift) : __builtin_huge_val();
             int v;
             double d;
             if (dl <= dh) {
@@ -185,7 +234,7 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
                 v = hi++;
                 d = dh;
             }
-            const long long c = h[v + 32768];
+            const long long c = h[v - vmin];
             if (c == 0) continue;
             if (!got_lo && seen + c > need_lo) {
                 d_lo = d;
@@ -320,14 +369,29 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         PCHK(hipMemcpyAsync(d_ooff, h_ooff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, st));
         PCHK(hipMemcpyAsync(d_lo, seg_start + f, cnt * 8, hipMemcpyHostToDevice, st));
         PCHK(hipMemcpyAsync(d_hi, seg_end + f, cnt * 8, hipMemcpyHostToDevice, st));
-        PCHK(hipMemsetAsync(d_hist, 0, (size_t)cnt * 65536 * 4, st));
-        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_ss, d_out, (int)cnt, (int)max_len};
-        const unsigned gy = (unsigned)std::min<int64_t>(std::max<int64_t>((max_len + 255) / 256, 1), 4096);
-        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
-        if (spike_removal == 1) hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        int32_t *d_mm = nullptr;
+        PCHK(alloc((void **)&d_mm, (size_t)cnt * 8));
+        {
+            std::vector<int32_t> mm0((size_t)cnt * 2);
+            for (int64_t r = 0; r < cnt; r++) {
+                mm0[2 * r] = 32767;      // empty reads keep an empty (negative) range
+                mm0[2 * r + 1] = -32768;
+            }
+            PCHK(hipMemcpyAsync(d_mm, mm0.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+            PCHK(hipStreamSynchronize(st)); // mm0 goes out of scope
+        }
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len};
+        int64_t max_out = 0;
+        for (int64_t r = 0; r < cnt; r++) max_out = std::max(max_out, h_ooff[r + 1] - h_ooff[r]);
+        const unsigned gn = (unsigned)std::min<int64_t>(std::max<int64_t>((max_out + 255) / 256, 1), 4096);
+        const unsigned gc = (unsigned)std::max<int64_t>((max_len + PREP_CHUNK - 1) / PREP_CHUNK, 1);
+        const unsigned gs = (unsigned)std::max<int64_t>((max_len + PREP_STREAM - 1) / PREP_STREAM, 1);
+        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, 8), dim3(256), 0, st, a);
+        if (spike_removal == 1) hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)cnt, gc), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_kernel, dim3((unsigned)cnt), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(norm_kernel, dim3((unsigned)cnt, gy), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(norm_kernel, dim3((unsigned)cnt, gn), dim3(256), 0, st, a);
         PCHK(hipGetLastError());
         if (host) PCHK(hipMemcpyAsync(signal_out + obase, d_out, (size_t)osz * 8, hipMemcpyDeviceToHost, st));
         if (shift_scale) {
