@@ -222,6 +222,7 @@ struct wsx_caller {
     std::vector<hipEvent_t> sched_events;
     size_t sched_used = 0;
     PinRing ring_up, ring_down; // host-buffer calls only (allocated on first use)
+    DeviceBuf prep_pool[8];     // wsx_prepare_signals: histograms and per-chunk buffers, kept between calls
     void *pinned_res = nullptr; // host-buffer calls: the batch's result records land here first
     size_t pinned_res_cap = 0;
 };
@@ -514,6 +515,7 @@ void wsx_caller_destroy(wsx_caller *c)
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
+    for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
     for (int w = 1; w < WSX_MAX_STREAMS; w++) {
@@ -576,6 +578,13 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 int wsx_internal_device(wsx_caller *c) { return c->device; }
 hipStream_t wsx_internal_stream(wsx_caller *c) { return c->stream; }
 void wsx_internal_set_error(const char *msg) { g_err = msg; }
+// buffer `slot` of the signal loader's pool, at least `bytes` large (grown when needed, freed with the handle)
+hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p)
+{
+    hipError_t e = c->prep_pool[slot].ensure(bytes);
+    *p = c->prep_pool[slot].p;
+    return e;
+}
 
 namespace {
 

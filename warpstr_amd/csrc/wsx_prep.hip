@@ -39,12 +39,31 @@ struct PrepArgs {
     double *out;
     int n;
     int max_len;
+    int vec; // raw and clean are 16-byte aligned: the streaming passes load eight samples per lane
 };
 
 __device__ __forceinline__ bool is_outlier(const int16_t *raw, long long i)
 {
     const int v = raw[i];
     return i > 2 && (v > 1000 || v < 250);
+}
+
+// The streaming passes move eight samples (16 bytes) per lane and load: groups of eight are aligned in BUFFER
+// coordinates (the staging buffers are 256-byte aligned; a caller's device buffer is checked by the launcher), so a
+// read that starts anywhere has a partial first and last group -- `first`/`count` say which of the eight belong to the
+// piece [s0, s1) being processed.  vec = 0 falls back to one sample per lane.
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+template <class Fn>
+__device__ __forceinline__ void for_each_sample8(const int16_t *buf, long long s0, long long s1, int tid, int nthreads, const Fn &fn)
+{
+    for (long long g = (s0 >> 3) + tid; (g << 3) < s1; g += nthreads) {
+        const short8 v = *(const short8 *)(buf + (g << 3));
+        const long long base = g << 3;
+        const int first = base < s0 ? (int)(s0 - base) : 0;
+        const int last = base + 8 > s1 ? (int)(s1 - base) : 8; // exclusive
+        fn(v, base, first, last);
+    }
 }
 
 #define PREP_CHUNK 16384 // samples per block in the histogram pass (one private LDS histogram per block)
@@ -57,11 +76,27 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
     int lo = 32767, hi = -32768;
-    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
-        const int16_t v = a.raw[a.roff[r] + i];
-        a.clean[a.roff[r] + i] = v;
-        lo = min(lo, (int)v);
-        hi = max(hi, (int)v);
+    if (a.vec) {
+        for_each_sample8(a.raw, a.roff[r] + c0, a.roff[r] + c1, threadIdx.x, 256, [&](short8 v, long long base, int first, int last) {
+            if (first == 0 && last == 8) {
+                *(short8 *)(a.clean + base) = v;
+            } else {
+                for (int e = first; e < last; e++) a.clean[base + e] = v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (e >= first && e < last) {
+                    lo = min(lo, (int)v[e]);
+                    hi = max(hi, (int)v[e]);
+                }
+        });
+    } else {
+        for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
+            const int16_t v = a.raw[a.roff[r] + i];
+            a.clean[a.roff[r] + i] = v;
+            lo = min(lo, (int)v);
+            hi = max(hi, (int)v);
+        }
     }
     for (int s = 32; s >= 1; s >>= 1) {
         lo = min(lo, __shfl_xor(lo, s));
@@ -107,10 +142,8 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
     const int16_t *raw = a.raw + a.roff[r];
     int16_t *out = a.clean + a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
-    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
-        if (!is_outlier(raw, i)) continue;
-        // head of a chain: neither of the two previous samples is an outlier
-        if ((i >= 1 && is_outlier(raw, i - 1)) || (i >= 2 && is_outlier(raw, i - 2))) continue;
+    auto fix_chain_from = [&](long long i) { // i is an outlier: if it heads a chain, fix the whole chain serially
+        if ((i >= 1 && is_outlier(raw, i - 1)) || (i >= 2 && is_outlier(raw, i - 2))) return;
         long long j = i;
         while (true) {
             int w[5];
@@ -121,6 +154,19 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
             else if (j + 2 < len && is_outlier(raw, j + 2)) j = j + 2;
             else break;
         }
+    };
+    if (a.vec) {
+        const long long ro = a.roff[r];
+        for_each_sample8(a.raw, ro + c0, ro + c1, threadIdx.x, 256, [&](short8 v, long long base, int first, int last) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const long long i = base + e - ro; // index in the read
+                if (e >= first && e < last && i > 2 && (v[e] > 1000 || v[e] < 250)) fix_chain_from(i);
+            }
+        });
+    } else {
+        for (long long i = c0 + threadIdx.x; i < c1; i += 256)
+            if (is_outlier(raw, i)) fix_chain_from(i);
     }
 }
 
@@ -142,7 +188,15 @@ __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
     if (range <= PREP_LDS_BINS) {
         for (int b = threadIdx.x; b < range; b += 256) lh[b] = 0u;
         __syncthreads();
-        for (long long i = c0 + threadIdx.x; i < c1; i += 256) atomicAdd(&lh[(int)x[i] - vmin], 1u);
+        if (a.vec) {
+            for_each_sample8(a.clean, a.roff[r] + c0, a.roff[r] + c1, threadIdx.x, 256, [&](short8 v, long long, int first, int last) {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (e >= first && e < last) atomicAdd(&lh[(int)v[e] - vmin], 1u);
+            });
+        } else {
+            for (long long i = c0 + threadIdx.x; i < c1; i += 256) atomicAdd(&lh[(int)x[i] - vmin], 1u);
+        }
         __syncthreads();
         for (int b = threadIdx.x; b < range; b += 256) {
             const uint32_t c = lh[b];
@@ -276,6 +330,7 @@ __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
 int wsx_internal_device(wsx_caller *c);
 hipStream_t wsx_internal_stream(wsx_caller *c);
 void wsx_internal_set_error(const char *msg);
+hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p);
 
 #define PCHK(expr)                                                                                       \
     do {                                                                                                 \
@@ -284,7 +339,6 @@ void wsx_internal_set_error(const char *msg);
             char b_[512];                                                                                \
             snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             wsx_internal_set_error(b_);                                                                  \
-            for (void *p_ : to_free) (void)hipFree(p_);                                                  \
             return WSX_ERR_HIP;                                                                          \
         }                                                                                                \
     } while (0)
@@ -293,7 +347,6 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
                                    const int64_t *seg_start, const int64_t *seg_end, int64_t n_reads, int32_t spike_removal,
                                    double *signal_out, const int64_t *out_offsets, double *shift_scale)
 {
-    std::vector<void *> to_free;
     if (!c || !raw_offsets || !seg_start || !seg_end || !out_offsets || n_reads < 0 || (n_reads > 0 && (!raw || !signal_out))) {
         wsx_internal_set_error("wsx_prepare_signals: null argument");
         return WSX_ERR_INVALID;
@@ -328,8 +381,9 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
     const bool host = mem == WSX_MEM_HOST;
     const int64_t chunk_reads = 4096; // 1 GiB of histograms
     uint32_t *d_hist = nullptr;
-    PCHK(hipMalloc((void **)&d_hist, (size_t)std::min<int64_t>(n_reads, chunk_reads) * 65536 * 4));
-    to_free.push_back(d_hist);
+    // every device buffer of this function lives in the handle's pool (slot 0: histograms, 1..: per-chunk buffers): a
+    // fresh hipMalloc / hipFree of ~1.5 GB per call cost a third of the call
+    PCHK(wsx_internal_prep_buffer(c, 0, (size_t)std::min<int64_t>(n_reads, chunk_reads) * 65536 * 4, (void **)&d_hist));
     for (int64_t f = 0; f < n_reads; f += chunk_reads) {
         const int64_t cnt = std::min(chunk_reads, n_reads - f);
         const int64_t rbase = raw_offsets[f], rsz = raw_offsets[f + cnt] - rbase;
@@ -344,24 +398,19 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         int16_t *d_raw = nullptr, *d_clean = nullptr;
         int64_t *d_meta = nullptr;
         double *d_ss = nullptr, *d_out = nullptr;
-        std::vector<void *> chunk_free;
+        int next_slot = 1;
         auto alloc = [&](void **p, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
-            if (e == hipSuccess) {
-                chunk_free.push_back(*p);
-                to_free.push_back(*p);
-            }
-            return e;
+            return wsx_internal_prep_buffer(c, next_slot++, std::max<size_t>(bytes, 256), p);
         };
         if (host) {
-            PCHK(alloc((void **)&d_raw, (size_t)rsz * 2));
+            PCHK(alloc((void **)&d_raw, (size_t)rsz * 2 + 16));
             PCHK(hipMemcpyAsync(d_raw, raw + rbase, (size_t)rsz * 2, hipMemcpyHostToDevice, st));
             PCHK(alloc((void **)&d_out, (size_t)osz * 8));
         } else {
             d_raw = const_cast<int16_t *>(raw) + rbase;
             d_out = signal_out + obase;
         }
-        PCHK(alloc((void **)&d_clean, (size_t)rsz * 2));
+        PCHK(alloc((void **)&d_clean, (size_t)rsz * 2 + 16));
         PCHK(alloc((void **)&d_meta, (size_t)(4 * cnt + 2) * 8));
         PCHK(alloc((void **)&d_ss, (size_t)cnt * 16));
         int64_t *d_roff = d_meta, *d_ooff = d_meta + cnt + 1, *d_lo = d_ooff + cnt + 1, *d_hi = d_lo + cnt;
@@ -380,7 +429,11 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
             PCHK(hipMemcpyAsync(d_mm, mm0.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, st));
             PCHK(hipStreamSynchronize(st)); // mm0 goes out of scope
         }
-        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len};
+        // eight-sample loads need 16-byte aligned buffers (groups of eight are aligned in buffer coordinates, reads may start
+        // anywhere) and must not run past the allocation: the staging buffers are padded, a caller's device buffer is only
+        // read in whole groups when it is aligned and the last group ends inside the chunk
+        const int vec = ((uintptr_t)d_raw % 16 == 0 && (uintptr_t)d_clean % 16 == 0 && (host || rsz % 8 == 0)) ? 1 : 0;
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec};
         int64_t max_out = 0;
         for (int64_t r = 0; r < cnt; r++) max_out = std::max(max_out, h_ooff[r + 1] - h_ooff[r]);
         const unsigned gn = (unsigned)std::min<int64_t>(std::max<int64_t>((max_out + 255) / 256, 1), 4096);
@@ -398,11 +451,6 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
             PCHK(hipMemcpyAsync(shift_scale + 2 * f, d_ss, (size_t)cnt * 16, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         }
         PCHK(hipStreamSynchronize(st)); // chunk buffers are freed below
-        for (void *p : chunk_free) {
-            (void)hipFree(p);
-            to_free.erase(std::find(to_free.begin(), to_free.end(), p));
-        }
     }
-    (void)hipFree(d_hist);
     return WSX_SUCCESS;
 }
