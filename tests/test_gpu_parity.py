@@ -327,6 +327,35 @@ def test_signal_loader_matches_reference_and_host():
             assert len(got) == len(ref) and np.array_equal(got, ref), (mode, i)
     out, ooff, _ = hip.prepare_signals([z['raw']], [(0, len(z['raw']) - 1)], 'Brute')
     assert np.array_equal(out, z['norm'])              # bit-identical to upstream normalize_signal_mad(brute_remove(raw))
+    # device-resident raw reads: a 16-byte aligned buffer takes the eight-samples-per-load passes, a buffer that starts
+    # two bytes later the one-sample-per-lane ones; both equal the host-buffer result.  (Device memory straight from the
+    # HIP runtime the library itself is linked against: a second runtime in the process, e.g. torch's, is not needed.)
+    import ctypes as C
+    from warpstr_amd import _lib
+    rt = C.CDLL('libamdhip64.so')
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    n = len(raws)
+    lens = np.array([len(r) for r in raws], np.int64)
+    roff = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=roff[1:])
+    pad = (-int(roff[-1])) % 8                          # whole groups of eight to the end of the buffer
+    flat = np.ascontiguousarray(np.concatenate(raws + [np.zeros(pad, np.int16)]))
+    lo = np.array([p[0] for p in pos], np.int64)
+    hi = np.array([p[1] for p in pos], np.int64)
+    want, want_off, _ = hip.prepare_signals(raws, pos, 'Brute')
+    d_raw, d_out = C.c_void_p(), C.c_void_p()
+    assert rt.hipMalloc(C.byref(d_raw), flat.nbytes + 64) == 0 and rt.hipMalloc(C.byref(d_out), want.nbytes + 64) == 0
+    for shift in (0, 1):
+        assert rt.hipMemcpy(C.c_void_p(d_raw.value + 2 * shift), _lib.ptr(flat), flat.nbytes, 1) == 0   # host -> device
+        _lib.check(hip.lib.wsx_prepare_signals(hip.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(d_raw.value + 2 * shift), _lib.ptr(roff),
+                                               _lib.ptr(lo), _lib.ptr(hi), n, 1, d_out, _lib.ptr(want_off), None), 'wsx_prepare_signals')
+        got = np.zeros_like(want)
+        assert rt.hipMemcpy(_lib.ptr(got), d_out, want.nbytes, 2) == 0                                   # device -> host
+        assert np.array_equal(got, want), shift
+    rt.hipFree(d_raw)
+    rt.hipFree(d_out)
 
 
 def test_large_automaton_and_long_read():

@@ -61,11 +61,37 @@ class HipLibraryMissing(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A process that initialises the system runtime first (through
+    this library) and imports torch afterwards ends up with two runtimes and torch sees no GPU; with torch imported first
+    this library simply binds to torch's copy (same soname) and both work.  Make the second order the only one: if torch
+    is installed but not imported yet, load its runtime libraries before ours.  WARPSTR_HIP_SYSTEM_RUNTIME=1 disables it."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules or os.environ.get('WARPSTR_HIP_SYSTEM_RUNTIME'):
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load the HIP library; raises HipLibraryMissing if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(f'{LIB_PATH} not found: build it with `python -m warpstr_amd.build` '
                                 '(the caller has no CPU path)')
