@@ -636,3 +636,43 @@ def test_streaming_traceback_on_small_batches():
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert ' passed' in out.stdout
+
+
+def test_long_reads_many_automata_and_degenerate_reads():
+    """Shapes away from the benchmark: reads of 20-60 kSample (masks and run lists of that length; the fused
+    segmentation kernel's LDS tables), a handle with 70 automata (more than the streaming traceback's LDS table holds: every
+    launch takes the wave-per-read traceback), and empty / too-short reads mixed into the batch."""
+    rng = np.random.default_rng(808)
+    tables, fls, oauts = [], [], []
+    for li in range(35):                                             # 35 loci x 2 strands = 70 automata
+        pat = ['(AGC)', '(CTG)', '(AAAT)', '(GGCCCC)', '(AGC)AACAGCCGCCAC(CGC)'][li % 5]
+        locus = synth.make_locus(pat, 16 + li % 7, 4000 + li)
+        tables += [locus.template, locus.reverse]
+        fls += [16 + li % 7] * 2
+        oauts += [oracle.Automaton.from_table(locus.template, 16 + li % 7), oracle.Automaton.from_table(locus.reverse, 16 + li % 7)]
+    sigs, aid = [], []
+    for k in range(24):
+        li = int(rng.integers(0, 35))
+        rev = bool(rng.random() < 0.5)
+        T = int(rng.choice([1500, 3000, 20000, 60000])) if k < 6 else int(rng.integers(600, 4000))
+        locus = synth.make_locus(['(AGC)', '(CTG)', '(AAAT)', '(GGCCCC)', '(AGC)AACAGCCGCCAC(CGC)'][li % 5], 16 + li % 7, 4000 + li)
+        s, _ = synth.squiggle(locus, rev, T, rng, lo=2, hi=max(3, min(30, T // 200)), sigma=0.25)
+        sigs.append(s)
+        aid.append(2 * li + int(rev))
+    sigs += [np.zeros(0), np.zeros(2), np.zeros(4), rng.normal(size=5)]
+    aid += [0, 1, 2, 3]
+    aid = np.array(aid, dtype=np.int32)
+    hip = HipCaller(tables, fls)
+    sig, off = pack_signals(sigs)
+    res, ex = hip.call(sig, off, aid, want_traces=True)
+    n_ok = 0
+    for i, s in enumerate(sigs):
+        o = oracle.call_read(oauts[aid[i]], s)
+        assert int(res['status'][i]) == o.status, (i, len(s), int(res['status'][i]), o.status)
+        if o.status == 0:
+            n_ok += 1
+            assert np.array_equal(ex['trace1'][off[i]:off[i + 1]], o.trace1), i
+            assert np.array_equal(ex['trace2'][off[i]:off[i + 1]], o.trace2), i
+            assert (res['len1'][i], res['len2'][i]) == (o.len1, o.len2)
+            assert_close_rel(res['cost2'][i], o.cost2, COST_REL)
+    assert n_ok >= 16 and (res['status'][-4:] != 0).all()
