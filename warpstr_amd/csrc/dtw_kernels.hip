@@ -648,9 +648,8 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
                 }
                 entered |= won[f];
             }
-            const int top = i & 63;
-            if (top < 63) entered &= (2ull << top) - 1ull; // rows <= i
-            if (entered == 0 && cb * 64 > m) {             // the run continues in the block below
+            entered &= ~0ull >> (63 - (i & 63)); // rows <= i
+            if (entered == 0 && cb * 64 > m) {   // the run continues in the block below
                 i = cb * 64 - 1;
                 return false;
             }
@@ -658,9 +657,9 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
             if (entered != 0) {
                 l = 63 - __builtin_clzll(entered);
                 start = cb * 64 + l;
+                ptr = 1; // the arg-min is the highest candidate whose bit is set
 #pragma unroll
-                for (int f = 0; f < F; f++)
-                    if ((won[f] >> l) & 1ull) ptr = f + 1; // the arg-min is the highest candidate whose bit is set
+                for (int f = 1; f < F; f++) ptr = ((won[f] >> l) & 1ull) ? f + 1 : ptr;
             }
             if (q == open_pos) {
                 open_start = start;
