@@ -125,11 +125,19 @@ def main():
     local = local % torch.cuda.device_count() if backend != 'nccl' else local
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    # WARPSTR_BENCH_SELF_GATHER=1: a one-rank RCCL group on a 1-GPU box, to exercise the collective path of N > 1
+    self_gather = world == 1 and bool(os.environ.get('WARPSTR_BENCH_SELF_GATHER'))
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            # no device_id: binding the group to the device at init (eager communicator) cost every later step 2.3 ms on
+            # this stack (measured with a one-rank group: 19.4 vs 17.3 ms per step); the communicator is created by the
+            # first collective of the warm-up instead, on the device set above
+            dist.init_process_group('nccl')
         else:
             dist.init_process_group(backend)
+    elif self_gather:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1)
+    collective = (world > 1 and backend == 'nccl') or self_gather
 
     from warpstr_amd import _lib
     from warpstr_amd.caller import HipCaller
@@ -140,14 +148,35 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     hip = HipCaller([locus.template, locus.reverse], [FLANK, FLANK], device=local, stream=stream,
                     workspace_limit=96 << 30)
-    results = torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device)
+    # Two result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
+    # other buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
+    res_bufs = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(2)]
+    gather_stream = torch.cuda.Stream(device=device) if collective else None
+    gather_done = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        results = res_bufs[k]
+        if gather_done[k] is not None:  # the gather that read this buffer two steps ago
+            torch.cuda.current_stream().wait_event(gather_done[k])
         hip.call_device(signal.data_ptr(), offsets, aut, results.data_ptr())
-        if world > 1 and backend != 'nccl':  # test path: CPU collective
+        if collective:
+            ready = torch.cuda.Event()
+            ready.record()                      # the handle's stream: every kernel of this step is ahead of it
+            gather_stream.wait_event(ready)
+            with torch.cuda.stream(gather_stream):
+                out = torch.empty((dist.get_world_size() * n, results.shape[1]), dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(out, results)
+                done = torch.cuda.Event()
+                done.record()
+            gather_done[k] = done
+            return out
+        if world > 1:  # test path (gloo): CPU collective
             torch.cuda.synchronize()
             return gather_results(results.cpu(), world)
-        return gather_results(results, world)
+        return results
 
     for _ in range(args.warmup):
         step()
@@ -206,7 +235,8 @@ def main():
             'config': {'workload': f'BASELINE configs[2]: {n} reads/GPU x {T} samples, {PATTERN} flank {FLANK}, '
                                    f'S={locus.template.n_states}/{locus.reverse.n_states} states, both passes',
                        'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
-                       'results_gather': (f'{backend} all_gather' if world > 1 else 'none (1 GPU)')},
+                       'results_gather': (f'{backend} all_gather of 56-B records per step, overlapped with the next step' if world > 1
+                                          else ('one-rank nccl group (self test)' if self_gather else 'none (1 GPU)'))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
@@ -223,7 +253,7 @@ def main():
             sample = signal[: min(n, 4096) * T].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(locus, sample, T, aut[: min(n, 4096)])
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or self_gather:
         dist.destroy_process_group()
 
 
