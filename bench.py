@@ -110,6 +110,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # Exactly one line on stdout: native libraries print there too (RCCL's start-up banner: version, hostname, library
+    # path), so file descriptor 1 points at stderr until the JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -252,7 +258,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sample = signal[: min(n, 4096) * T].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(locus, sample, T, aut[: min(n, 4096)])
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or self_gather:
         dist.destroy_process_group()
 
