@@ -27,5 +27,5 @@ for rep in range(3):
                'wsx_prepare_signals')
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f'{n} reads x {L} raw samples -> {T}-sample segments: {dt*1e3:.2f} ms per call, {n/dt:.3g} reads/s, '
-      f'{n*L*2/dt/1e9:.0f} GB/s of raw int16 in (each sample is read by the spike pass and the histogram pass)', flush=True)
+      f'{n*L*2/dt/1e9:.0f} GB/s of raw int16 in (every sample is read twice and written once)', flush=True)
 print('shift/scale of read 0:', ss[0].cpu().numpy(), 'segment mean/std:', float(out[:T].mean()), float(out[:T].std()))

@@ -319,6 +319,11 @@ def test_signal_loader_matches_reference_and_host():
         raws.append(raw)
         a = int(rng.integers(0, n))
         pos.append((a, int(rng.integers(a, n + 50))))   # r_end may exceed the read (python slices clamp)
+    # a read made mostly of outliers: its outlier list overflows and the spike pass scans it sample by sample instead
+    noisy = rng.normal(520, 70, size=20000).astype(np.int16)
+    noisy[rng.random(20000) < 0.4] = 1800
+    raws.append(noisy)
+    pos.append((500, 15000))
     for mode in ('Brute', 'None'):
         out, ooff, ss = hip.prepare_signals(raws, pos, mode)
         for i, (raw, p) in enumerate(zip(raws, pos)):
@@ -332,7 +337,9 @@ def test_signal_loader_matches_reference_and_host():
     # HIP runtime the library itself is linked against: a second runtime in the process, e.g. torch's, is not needed.)
     import ctypes as C
     from warpstr_amd import _lib
-    rt = C.CDLL('libamdhip64.so')
+    rt = C.CDLL(None)                                   # the HIP runtime already in the process (loaded globally by _lib)
+    if not hasattr(rt, 'hipMalloc'):
+        rt = C.CDLL('libamdhip64.so')
     rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     rt.hipFree.argtypes = [C.c_void_p]

@@ -40,7 +40,15 @@ struct PrepArgs {
     int n;
     int max_len;
     int vec; // raw and clean are 16-byte aligned: the streaming passes load eight samples per lane
+    // outliers found by the copy pass (spike removal): per read a list of sample indices (segment of read r: entries
+    // roff[r]/16 + 64 r .., capacity len/16 + 64) and a counter; a read whose list overflows is scanned sample by sample
+    long long *ol_list;
+    unsigned int *ol_count; // [n]
 };
+
+__device__ __forceinline__ long long ol_base(const PrepArgs &a, int r) { return a.roff[r] / 16 + 64ll * r; }
+__device__ __forceinline__ unsigned int ol_cap(const PrepArgs &a, int r) { return (unsigned int)((a.roff[r + 1] - a.roff[r]) / 16 + 64); }
+#define OL_OVERFLOW 0x80000000u
 
 __device__ __forceinline__ bool is_outlier(const int16_t *raw, long long i)
 {
@@ -76,6 +84,15 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
     int lo = 32767, hi = -32768;
+    // the block's outliers collect in LDS and join the read's list with one atomic per block
+    __shared__ long long bl_list[256];
+    __shared__ unsigned int bl_count, bl_base;
+    if (threadIdx.x == 0) bl_count = 0;
+    __syncthreads();
+    auto note_outlier = [&](long long i) {
+        const unsigned int q = atomicAdd(&bl_count, 1u);
+        if (q < 256) bl_list[q] = i;
+    };
     if (a.vec) {
         for_each_sample8(a.raw, a.roff[r] + c0, a.roff[r] + c1, threadIdx.x, 256, [&](short8 v, long long base, int first, int last) {
             if (first == 0 && last == 8) {
@@ -88,6 +105,8 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
                 if (e >= first && e < last) {
                     lo = min(lo, (int)v[e]);
                     hi = max(hi, (int)v[e]);
+                    const long long i = base + e - a.roff[r];
+                    if (a.ol_list && i > 2 && (v[e] > 1000 || v[e] < 250)) note_outlier(i); // is_outlier: rare
                 }
         });
     } else {
@@ -96,6 +115,7 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
             a.clean[a.roff[r] + i] = v;
             lo = min(lo, (int)v);
             hi = max(hi, (int)v);
+            if (a.ol_list && i > 2 && (v > 1000 || v < 250)) note_outlier(i);
         }
     }
     for (int s = 32; s >= 1; s >>= 1) {
@@ -105,6 +125,16 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
     if ((threadIdx.x & 63) == 0 && c0 < c1) {
         atomicMin(&a.mm[2 * r], lo);
         atomicMax(&a.mm[2 * r + 1], hi);
+    }
+    if (a.ol_list) {
+        __syncthreads();
+        const unsigned int nb = bl_count;
+        if (nb == 0) return;
+        if (threadIdx.x == 0) // more than 256 outliers in one block: the read is scanned sample by sample instead
+            bl_base = nb > 256 ? atomicOr(&a.ol_count[r], OL_OVERFLOW) : atomicAdd(&a.ol_count[r], nb);
+        __syncthreads();
+        if (nb <= 256 && bl_base + nb <= ol_cap(a, r))
+            for (unsigned int q = threadIdx.x; q < nb; q += 256) a.ol_list[ol_base(a, r) + bl_base + q] = bl_list[q];
     }
 }
 
@@ -155,6 +185,7 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
             else break;
         }
     };
+    if (a.ol_list && a.ol_count[r] <= ol_cap(a, r)) return; // the listed outliers are handled by spike_list_kernel
     if (a.vec) {
         const long long ro = a.roff[r];
         for_each_sample8(a.raw, ro + c0, ro + c1, threadIdx.x, 256, [&](short8 v, long long base, int first, int last) {
@@ -167,6 +198,33 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
     } else {
         for (long long i = c0 + threadIdx.x; i < c1; i += 256)
             if (is_outlier(raw, i)) fix_chain_from(i);
+    }
+}
+
+// Spike removal from the copy pass's outlier lists: one block per read, one thread per listed outlier; the one that heads
+// a chain (neither of the two samples before it is an outlier) repairs the whole chain serially, exactly as spike_kernel.
+__global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    const unsigned int total = a.ol_count[r];
+    if (total > ol_cap(a, r)) return; // overflow: spike_kernel scans this read
+    const long long len = a.roff[r + 1] - a.roff[r];
+    const int16_t *raw = a.raw + a.roff[r];
+    int16_t *out = a.clean + a.roff[r];
+    const long long *list = a.ol_list + ol_base(a, r);
+    for (unsigned int t = threadIdx.x; t < total; t += 256) {
+        const long long i = list[t];
+        if ((i >= 1 && is_outlier(raw, i - 1)) || (i >= 2 && is_outlier(raw, i - 2))) continue;
+        long long j = i;
+        while (true) {
+            int w[5];
+            int cnt = 0;
+            for (long long q = j - 2; q < j + 3 && q < len; q++) w[cnt++] = out[q];
+            out[j] = median_small(w, cnt);
+            if (j + 1 < len && is_outlier(raw, j + 1)) j = j + 1;
+            else if (j + 2 < len && is_outlier(raw, j + 2)) j = j + 2;
+            else break;
+        }
     }
 }
 
@@ -433,7 +491,16 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         // anywhere) and must not run past the allocation: the staging buffers are padded, a caller's device buffer is only
         // read in whole groups when it is aligned and the last group ends inside the chunk
         const int vec = ((uintptr_t)d_raw % 16 == 0 && (uintptr_t)d_clean % 16 == 0 && (host || rsz % 8 == 0)) ? 1 : 0;
-        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec};
+        // outlier lists for the spike pass: per read room for one sample in 16 (real reads: a fraction of a percent)
+        long long *d_ol = nullptr;
+        unsigned int *d_olc = nullptr;
+        if (spike_removal == 1) {
+            const size_t entries = (size_t)(rsz / 16 + 64 * cnt + 64);
+            PCHK(alloc((void **)&d_ol, entries * 8 + (size_t)cnt * 4 + 16));
+            d_olc = (unsigned int *)(d_ol + entries);
+            PCHK(hipMemsetAsync(d_olc, 0, (size_t)cnt * 4, st));
+        }
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec, d_ol, d_olc};
         int64_t max_out = 0;
         for (int64_t r = 0; r < cnt; r++) max_out = std::max(max_out, h_ooff[r + 1] - h_ooff[r]);
         const unsigned gn = (unsigned)std::min<int64_t>(std::max<int64_t>((max_out + 255) / 256, 1), 4096);
@@ -441,7 +508,10 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         const unsigned gs = (unsigned)std::max<int64_t>((max_len + PREP_STREAM - 1) / PREP_STREAM, 1);
         hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
         hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, 8), dim3(256), 0, st, a);
-        if (spike_removal == 1) hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        if (spike_removal == 1) {
+            if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3((unsigned)cnt), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a); // returns at once unless the list overflowed
+        }
         hipLaunchKernelGGL(hist_kernel, dim3((unsigned)cnt, gc), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_kernel, dim3((unsigned)cnt), dim3(64), 0, st, a);
         hipLaunchKernelGGL(norm_kernel, dim3((unsigned)cnt, gn), dim3(256), 0, st, a);
