@@ -9,12 +9,15 @@
 // NumPy semantics restated: percentile 'linear' (virtual index (n-1)q, lerp a + (b-a)g, or b - (b-a)(1-g) for g >= 0.5),
 // median = mean of the middle one/two order statistics, float -> int16 store truncates toward zero.
 //
-// Parallelisation
-//   copy_kernel       thread per sample
-//   spike_kernel      thread per sample; the thread at the head of a chain of outliers (gaps <= 2) fixes the whole chain
-//                     serially -- chains further apart than 2 samples never touch each other's windows
-//   hist_kernel       thread per sample: 65536-bin histogram per read (int16 has only 2^16 values, so every order
-//                     statistic of the read comes from counting; no sort)
+// Parallelisation (the three passes over the raw read are HBM streams: eight samples per 16-byte load)
+//   copy_kernel       block per 4096 samples: raw -> working copy, smallest / largest value of the read, and the read's
+//                     OUTLIER LIST (collected per block in LDS, appended with one atomic per block)
+//   spike_list_kernel block per read, thread per listed outlier: the outlier at the head of a chain (gaps <= 2) repairs
+//                     the whole chain serially -- chains further apart than 2 samples never touch each other's windows
+//   spike_kernel      fallback for reads whose list overflowed (more than one outlier in 16 samples): every sample again
+//   zero_kernel / hist_kernel   histogram per read over its occupied value range (int16 has only 2^16 values, so every
+//                     order statistic comes from counting; no sort): a private LDS histogram per 16384-sample block,
+//                     flushed bin by bin
 //   stats_kernel      wavefront per read: cumulative walk -> percentiles -> shift; two-sided merge around shift
 //                     -> median absolute deviation -> scale
 //   norm_kernel       thread per output sample: (x - shift) / scale of the requested slice
