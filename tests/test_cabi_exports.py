@@ -41,6 +41,8 @@ def test_struct_layouts():
     assert _lib.RESULT_DTYPE.itemsize == 56
     assert [_lib.RESULT_DTYPE.fields[k][1] for k in ('status', 'len1', 'len2', 'cost1', 'dtw_end_cost2')] == \
         [0, 4, 8, 24, 48]
+    assert C.sizeof(_lib.WsxAlignScores) == 16
+    assert _lib.FLANK_HIT_DTYPE.itemsize == 56 and _lib.FLANK_HIT_DTYPE.fields['n_ops'][1] == 52
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -61,6 +63,12 @@ def test_no_gpu_fails_loudly(lib):
     p = _lib.WsxParams(4, 6, 0.5, 0.5, 0, 0)
     rc = lib.wsx_caller_create(C.byref(h), 0, C.byref(a), 1, C.byref(p), None)
     assert rc == -2 and b'no HIP device' in lib.wsx_last_error()
+    # the flank entry points likewise
+    from warpstr_amd import extractor
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        extractor.locate(['ACGTACGT'], ['ACGT'])
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        extractor.extract_from_moves_batch([np.ones(8, np.uint8)], [extractor.Position(1, 2)], [0], [5])
 
 
 def test_product_never_imports_oracle():
@@ -69,4 +77,5 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, f), errors='ignore').read()
-                assert 'libwarpstr_oracle' not in text and 'from oracle' not in text and 'import oracle' not in text, f
+                assert 'libwarpstr_oracle' not in text and 'libflank_oracle' not in text and 'from oracle' not in text \
+                    and 'import oracle' not in text, f
