@@ -222,6 +222,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
         st.acur[k] = an;
         // row i+2 masked (back = M-1): successors need the (M-2)-deep sum, else the (M-1)-deep one
         ex[wbuf + k * 64 + lane] = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
+
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
     const int wib = threadIdx.x >> 6;
     const int slot = rfl(blockIdx.x * 4 + wib);
     if (slot >= a.n_launch) return;
+    // the fill is the resource everything else waits for: its waves win issue arbitration against the latency-bound
+    // stages of other chunks that share the SIMD (-1.5 % per step)
+    __builtin_amdgcn_s_setprio(3);
     ReadGeom gm = geom(a, slot);
     const int lr = rfl(gm.lr), T = rfl(gm.T);
     const long long off = gm.off;
