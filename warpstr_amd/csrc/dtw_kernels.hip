@@ -234,7 +234,10 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
 #endif
 
 template <int M, int K, int F, int FL>
-__global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
+#ifndef WSX_FILL_WPB
+#define WSX_FILL_WPB 4 // wavefronts (= reads) per workgroup
+#endif
+__global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
 
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int slot = rfl(blockIdx.x * 4 + wib);
+    const int slot = rfl(blockIdx.x * WSX_FILL_WPB + wib);
     if (slot >= a.n_launch) return;
     // the fill is the resource everything else waits for: its waves win issue arbitration against the latency-bound
     // stages of other chunks that share the SIMD (-1.5 % per step)
@@ -914,8 +917,8 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
 template <int M, int K, int F, int FL>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
-    const int blocks = (a.n_launch + 3) / 4;
-    size_t shmem = 4 * (2 * (K * 64 + 32)) * sizeof(double);
+    const int blocks = (a.n_launch + WSX_FILL_WPB - 1) / WSX_FILL_WPB;
+    size_t shmem = WSX_FILL_WPB * (2 * (K * 64 + 32)) * sizeof(double);
     // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
     // kernels of other chunks that run beside the fill on other streams.
     static const int cap_blocks = [] {
@@ -924,7 +927,7 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     }();
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
-    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL>), dim3(blocks), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL>), dim3(blocks), dim3(64 * WSX_FILL_WPB), shmem, s, a);
     return hipGetLastError();
 }
 
