@@ -703,9 +703,17 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         }
     }
     // Big single-chunk batches are split so that chunks can overlap on the two streams (the latency-bound stages of
-    // one chunk run under the VALU-bound fill of another).  WSX_CHUNKS overrides the split count (tuning knob).
+    // one chunk run under the VALU-bound fill of another).  The thread-per-read stages want launches of ~25k reads, so
+    // a second round of chunks per stream only pays from ~200k reads on, or when reads are long (their serial stages
+    // then last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.
+    // WSX_CHUNKS overrides the split count (tuning knob).
     if (chunks.size() == 1 && n >= 4096) {
-        int want = n >= 32768 ? 2 * c->n_streams : (n >= 8192 ? c->n_streams : 2);
+        int want = n >= 8192 ? c->n_streams : 2;
+        if (n >= 32768) {
+            const bool long_reads = chunks[0].samples / n >= 4096;
+            const int64_t per_round = (int64_t)25000 * c->n_streams;
+            want = c->n_streams * ((long_reads || 2 * n >= 3 * per_round) ? 2 : 1);
+        }
         if (c->n_streams == 1) want = 1;
         if (const char *e = getenv("WSX_CHUNKS")) want = std::max(1, atoi(e));
         const ChunkPlan whole = chunks[0];
