@@ -77,7 +77,7 @@ def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
             'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
 
 
-VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s4_pmc.json); the formulation's floor is 10
+VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s5_pmc.json); the formulation's floor is 10
 LDS_CYCLES_PER_ROW = 10.0    # 2 ds_read_b64 (2 cycles each) + 1 ds_write_b64 (~6): MI355X_MICROARCH.md, LDS table
 N_SIMD, N_CU, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 256, 2.4e9, 1.89e9
 
@@ -160,6 +160,9 @@ def main():
     gather_stream = torch.cuda.Stream(device=device) if collective else None
     gather_done = [None, None]
     step_no = [0]
+    # back-to-back steps: a call no longer drains into the handle's stream, the next step's chunks follow on every
+    # internal stream (wsx_caller_set_pipelined); consumers are ordered after a step with join()
+    hip.set_pipelined(True)
 
     def step():
         k = step_no[0] & 1
@@ -169,9 +172,7 @@ def main():
             torch.cuda.current_stream().wait_event(gather_done[k])
         hip.call_device(signal.data_ptr(), offsets, aut, results.data_ptr())
         if collective:
-            ready = torch.cuda.Event()
-            ready.record()                      # the handle's stream: every kernel of this step is ahead of it
-            gather_stream.wait_event(ready)
+            hip.join(gather_stream.cuda_stream)  # every kernel of this step is ahead of the gather
             with torch.cuda.stream(gather_stream):
                 out = torch.empty((dist.get_world_size() * n, results.shape[1]), dtype=torch.uint8, device=device)
                 dist.all_gather_into_tensor(out, results)
@@ -180,7 +181,7 @@ def main():
             gather_done[k] = done
             return out
         if world > 1:  # test path (gloo): CPU collective
-            torch.cuda.synchronize()
+            hip.synchronize()
             return gather_results(results.cpu(), world)
         return results
 
@@ -194,6 +195,7 @@ def main():
     dp_ms, dp_launches = 0.0, 0
     for _ in range(args.steps):
         allres = step()
+    hip.synchronize()        # pipelined calls end on the library's own streams
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -226,9 +228,9 @@ def main():
         algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         cells_per_s = reads_per_launch * T * S / (launch_ms * 1e-3)
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s4_traffic.json), same workload only
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s5_traffic.json), same workload only
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01s4_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01s5_traffic.json')) as f:
                 tj = json.load(f)
             if tj['workload']['samples'] == T:
                 traffic = tj['hbm_bytes_per_launch'] / tj['workload']['reads'] * reads_per_launch
@@ -253,7 +255,9 @@ def main():
                      'note': 'PMC: SQ_INSTS_VALU = 10.51 per row per wave (floor of this formulation: 10 = 6 adds, 2 '
                              'compares, 2 mins); the fill launches overlap other chunks\' kernels on 4 streams, so '
                              'launch_ms is a co-scheduled duration (5.3-5.4 ms per 100k reads when the kernel runs alone)'},
-            'dp_kernel_ms_per_step': tm['dp_kernel_ms'], 'device_ms_per_step': tm['total_ms'],
+            'dp_kernel_ms_per_step': tm['dp_kernel_ms'],
+            # enqueue-to-finish of the last step; steps are pipelined, so it overlaps the step before it
+            'last_step_latency_ms': tm['total_ms'],
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = signal[: min(n, 4096) * T].cpu().numpy()

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 3
+#define WSX_ABI_VERSION 4
 
 /* function return codes */
 enum {
@@ -143,6 +143,23 @@ int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
 
 /* Number of HIP streams big batches are spread over (1..8, default 4; 1 = everything on the handle's stream). */
 int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
+
+/*
+ * Pipelined calls (device buffers only; host-buffer calls stay synchronous).  Upstream calls one locus after the
+ * other (WarpSTR.py:66-76, main_wrapper per locus); a caller that has the next batch ready does not want the GPU to
+ * drain in between.  With `on` != 0 a wsx_call_batch / wsx_warp_batch on WSX_MEM_DEVICE buffers still reads its inputs
+ * in the order of the handle's stream, but no longer makes that stream wait for its end: the next call's chunks then
+ * follow this call's on every internal stream without a gap (at most two calls are in flight; a third blocks the host
+ * until the first has finished).  Outputs may be consumed only after wsx_caller_join (stream order) or
+ * wsx_caller_synchronize / wsx_caller_last_timing (host).  Turning the mode off joins the handle's stream.
+ */
+int wsx_caller_set_pipelined(wsx_caller *c, int32_t on);
+
+/*
+ * Make `stream` (a hipStream_t; NULL = the handle's stream) wait for every call enqueued on this handle so far.
+ * Does not block the host.  A no-op outside pipelined mode, where calls already end on the handle's stream.
+ */
+int wsx_caller_join(wsx_caller *c, void *stream);
 
 /*
  * Call a batch of reads: both alignments, rescaling and bad-repeat masking, per read.

@@ -1,0 +1,81 @@
+"""Pipelined device-buffer calls (wsx_caller_set_pipelined / wsx_caller_join): same bytes as stream-ordered calls."""
+import numpy as np
+import pytest
+
+from warpstr_amd import _lib, synth
+from warpstr_amd.caller import HipCaller, pack_signals
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(locus):
+    out = []
+    for seed, n, T in ((1, 8500, (500, 1100)), (2, 4200, 800), (3, 300, (400, 2500)), (4, 8200, 600)):
+        sigs, revs, _ = synth.batch(locus, n, T, seed)
+        sig, off = pack_signals(sigs)
+        out.append((sig, off, np.array([1 if x else 0 for x in revs], dtype=np.int32)))
+    return out
+
+
+def test_pipelined_calls_match_stream_ordered_calls():
+    import torch
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    batches = _batches(locus)
+    hip = HipCaller([locus.template, locus.reverse], [19, 19], stream=torch.cuda.current_stream().cuda_stream)
+    want = [hip.call(sig, off, aut, want_traces=True) for sig, off, aut in batches]
+    dev = torch.device('cuda:0')
+    d_sig = [torch.from_numpy(sig).to(dev) for sig, _, _ in batches]
+
+    def outputs():
+        return [(torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                 torch.zeros(len(sig), dtype=torch.int16, device=dev)) for sig, _, aut in batches]
+
+    def check(outs):
+        for (res, tr2), (w_res, w_extra) in zip(outs, want):
+            got = res.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+            assert got.tobytes() == w_res.tobytes()
+            assert np.array_equal(tr2.cpu().numpy().view(np.uint16), w_extra['trace2'])
+
+    hip.set_pipelined(True)
+    rounds = [outputs() for _ in range(3)]  # 12 calls back to back, four of them in every slot parity
+    for outs in rounds:
+        for (sig, off, aut), ds, (res, tr2) in zip(batches, d_sig, outs):
+            hip.call_device(ds.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+    # (a) a side stream ordered after the calls with join() sees finished outputs
+    side = torch.cuda.Stream(device=dev)
+    hip.join(side.cuda_stream)
+    with torch.cuda.stream(side):
+        copies = [[(res.clone(), tr2.clone()) for res, tr2 in outs] for outs in rounds]
+    side.synchronize()
+    for outs in copies:
+        check(outs)
+    # (b) host-side wait
+    hip.synchronize()
+    for outs in rounds:
+        check(outs)
+    # (c) a host-buffer call in between stays synchronous and correct
+    r, e = hip.call(*batches[1], want_traces=True)
+    assert r.tobytes() == want[1][0].tobytes() and np.array_equal(e['trace2'], want[1][1]['trace2'])
+    # (d) turning the mode off restores stream order: the handle's (= torch's current) stream is enough
+    outs = outputs()
+    (sig, off, aut), ds, (res, tr2) = batches[0], d_sig[0], outs[0]
+    hip.call_device(ds.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+    hip.set_pipelined(False)
+    (sig, off, aut), ds, (res, tr2) = batches[3], d_sig[3], outs[3]
+    hip.call_device(ds.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+    torch.cuda.current_stream().synchronize()
+    for k in (0, 3):
+        got = outs[k][0].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+        assert got.tobytes() == want[k][0].tobytes()
+        assert np.array_equal(outs[k][1].cpu().numpy().view(np.uint16), want[k][1]['trace2'])
+
+
+def test_join_before_any_call_is_a_no_op():
+    import torch
+    locus = synth.make_locus('(AGC)', 16, 1)
+    hip = HipCaller([locus.template, locus.reverse], [16, 16], stream=torch.cuda.current_stream().cuda_stream)
+    hip.join()
+    hip.set_pipelined(True)
+    hip.join()
+    hip.synchronize()
+    hip.set_pipelined(False)

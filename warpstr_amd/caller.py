@@ -226,6 +226,15 @@ class HipCaller:
     def set_streams(self, n: int):
         _lib.check(self.lib.wsx_caller_set_streams(self.handle, n), 'wsx_caller_set_streams')
 
+    def set_pipelined(self, on: bool = True):
+        """Device-buffer calls stop joining the handle's stream at their end, so that back-to-back calls overlap
+        (include/warpstr_hip.h: wsx_caller_set_pipelined); consume outputs after join() or synchronize()."""
+        _lib.check(self.lib.wsx_caller_set_pipelined(self.handle, int(bool(on))), 'wsx_caller_set_pipelined')
+
+    def join(self, stream: int = 0):
+        """Order `stream` (a hipStream_t value; 0 = the handle's stream) after every call enqueued so far."""
+        _lib.check(self.lib.wsx_caller_join(self.handle, C.c_void_p(stream or None)), 'wsx_caller_join')
+
     def synchronize(self):
         _lib.check(self.lib.wsx_caller_synchronize(self.handle), 'wsx_caller_synchronize')
 

@@ -208,10 +208,15 @@ struct wsx_caller {
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
     int n_streams = 4;
-    DeviceBuf meta;
-    void *pinned = nullptr; // host staging of offsets / automaton ids / launch order (caller buffers are not kept)
-    size_t pinned_cap = 0;
-    hipEvent_t ev_meta = nullptr; // recorded after the last metadata upload of a call
+    // offsets / automaton ids / launch order of a call: device copy + pinned staging (caller buffers are not kept).
+    // Two slots: pipelined calls alternate, so that call k+1 is prepared and enqueued while call k still runs.
+    DeviceBuf meta[2];
+    void *pinned[2] = {nullptr, nullptr};
+    size_t pinned_cap[2] = {0, 0};
+    hipEvent_t ev_meta[2] = {nullptr, nullptr}; // recorded when the call that used the slot has finished
+    bool pipelined = false;                     // wsx_caller_set_pipelined
+    uint64_t call_seq = 0;
+    hipStream_t join_st = nullptr; // pipelined calls end here instead of on the handle's stream
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
@@ -492,8 +497,9 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&c->ev_begin));
     HIPCHK(hipEventCreate(&c->ev_end));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
+    for (auto &e : c->ev_meta) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_joins[0], hipEventDisableTiming));
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     for (int w = 1; w < c->n_streams; w++) {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
@@ -510,11 +516,14 @@ void wsx_caller_destroy(wsx_caller *c)
     (void)hipStreamSynchronize(c->stream);
     for (int w = 1; w < WSX_MAX_STREAMS; w++)
         if (c->aux[w]) (void)hipStreamSynchronize(c->aux[w]);
-
+    if (c->join_st) {
+        (void)hipStreamSynchronize(c->join_st);
+        (void)hipStreamDestroy(c->join_st);
+    }
     c->ring_up.release();
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
-    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta}) b->release();
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta[0], &c->meta[1]}) b->release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
@@ -522,8 +531,11 @@ void wsx_caller_destroy(wsx_caller *c)
         if (c->aux[w]) (void)hipStreamDestroy(c->aux[w]);
         if (c->ev_joins[w]) (void)hipEventDestroy(c->ev_joins[w]);
     }
-    if (c->pinned) (void)hipHostFree(c->pinned);
-    if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
+    for (void *p : c->pinned)
+        if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : c->ev_meta)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_joins[0]) (void)hipEventDestroy(c->ev_joins[0]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -561,7 +573,27 @@ int wsx_caller_synchronize(wsx_caller *c)
 {
     if (!c) return WSX_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
+    if (c->join_st) HIPCHK(hipStreamSynchronize(c->join_st)); // pipelined calls end there
     HIPCHK(hipStreamSynchronize(c->stream));
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_join(wsx_caller *c, void *stream)
+{
+    if (!c) return WSX_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    // a never-recorded event is complete: joining before the first call is a no-op
+    HIPCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, c->ev_end, 0));
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_set_pipelined(wsx_caller *c, int32_t on)
+{
+    if (!c) return WSX_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    if (on && !c->join_st) HIPCHK(hipStreamCreateWithFlags(&c->join_st, hipStreamNonBlocking));
+    if (!on && c->pipelined) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_end, 0)); // back to stream order
+    c->pipelined = on != 0;
     return WSX_SUCCESS;
 }
 
@@ -647,6 +679,11 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     if (n == 0) return WSX_SUCCESS;
     hipStream_t st = c->stream;
     const bool host = io.mem == WSX_MEM_HOST;
+    // Pipelined (device buffers only): the call does not join the handle's stream at its end, so the next call's
+    // chunks follow this call's on every internal stream without a gap; wsx_caller_join orders a consumer after it.
+    const bool pipe = c->pipelined && !host;
+    if (c->pipelined && host) HIPCHK(hipStreamWaitEvent(st, c->ev_end, 0));
+    const int slot = pipe ? (int)(c->call_seq++ & 1) : 0;
     const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
                                       io.traces.seq1 || io.traces.seq2);
     if (full && (io.traces.seq1 || io.traces.seq2) && !c->have_bases) {
@@ -656,23 +693,25 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     // ---- metadata on the device: offsets, automaton ids, launch order ---------------------------
     // order: reads grouped by DP kernel variant, longest first inside a group (load balance)
-    HIPCHK(c->meta.ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
-    Carver mc(c->meta.p);
+    // the call that used this slot last (the previous one; in pipelined mode the one before that) has to be over:
+    // its kernels read the device copy, its uploads the pinned one (no-op if never recorded)
+    HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
+    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
+    Carver mc(c->meta[slot].p);
     int64_t *d_offsets = mc.take<int64_t>(n + 1);
     int32_t *d_autid = mc.take<int32_t>(n);
     int32_t *d_order = mc.take<int32_t>(n);
     // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
     // caller's arrays are not referenced after this function returns
     const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4);
-    HIPCHK(hipEventSynchronize(c->ev_meta)); // previous call's uploads (no-op if never recorded)
-    if (pin_bytes > c->pinned_cap) {
-        if (c->pinned) (void)hipHostFree(c->pinned);
-        c->pinned = nullptr;
-        c->pinned_cap = 0;
-        HIPCHK(hipHostMalloc(&c->pinned, pin_bytes + pin_bytes / 4, hipHostMallocDefault));
-        c->pinned_cap = pin_bytes + pin_bytes / 4;
+    if (pin_bytes > c->pinned_cap[slot]) {
+        if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
+        c->pinned[slot] = nullptr;
+        c->pinned_cap[slot] = 0;
+        HIPCHK(hipHostMalloc(&c->pinned[slot], pin_bytes + pin_bytes / 4, hipHostMallocDefault));
+        c->pinned_cap[slot] = pin_bytes + pin_bytes / 4;
     }
-    Carver pc(c->pinned);
+    Carver pc(c->pinned[slot]);
     int64_t *h_offsets = pc.take<int64_t>(n + 1);
     int32_t *h_autid = pc.take<int32_t>(n);
     int32_t *h_order = pc.take<int32_t>(n);
@@ -1121,13 +1160,19 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             }
             if ((rc = stage_m1(x, st)) || (rc = stage_f2(x, st)) || (rc = stage_m2(x, st))) return rc;
         }
-        for (int w = 1; w < n_work; w++) { // join: the handle's stream continues only after the internal ones drained
-            HIPCHK(hipEventRecord(c->ev_joins[w], c->aux[w]));
-            HIPCHK(hipStreamWaitEvent(main_st, c->ev_joins[w], 0));
+        // join: the handle's stream (pipelined: the join stream) continues only after the internal ones drained
+        const hipStream_t end_st = pipe ? c->join_st : main_st;
+        if (pipe) {
+            HIPCHK(hipEventRecord(c->ev_joins[0], main_st));
+            HIPCHK(hipStreamWaitEvent(end_st, c->ev_joins[0], 0));
         }
+        for (int w = 1; w < n_work; w++) {
+            HIPCHK(hipEventRecord(c->ev_joins[w], c->aux[w]));
+            HIPCHK(hipStreamWaitEvent(end_st, c->ev_joins[w], 0));
+        }
+        HIPCHK(hipEventRecord(c->ev_meta[slot], end_st));
+        HIPCHK(hipEventRecord(c->ev_end, end_st));
     }
-    HIPCHK(hipEventRecord(c->ev_meta, main_st));
-    HIPCHK(hipEventRecord(c->ev_end, main_st));
     c->timing_valid = true;
     if (host) {
         HIPCHK(hipStreamSynchronize(main_st));
