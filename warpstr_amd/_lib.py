@@ -61,6 +61,17 @@ class HipLibraryMissing(RuntimeError):
 _lib = None
 
 
+def _raise_hw_queue_limit():
+    """The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A wsx_caller uses up to
+    five streams and the application has its own; streams that share a queue serialise behind each other's event waits,
+    which undoes the chunk overlap of pipelined calls.  Only effective before the runtime initialises, and
+    an explicit setting of the user's is kept."""
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
+_raise_hw_queue_limit()
+
+
 def _share_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A process that initialises the system runtime first (through
     this library) and imports torch afterwards ends up with two runtimes and torch sees no GPU; with torch imported first
