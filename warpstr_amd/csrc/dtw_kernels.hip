@@ -786,20 +786,41 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
     load(s0, c);
     load(s1, c - 1);
     load(s2, c - 2);
+    // A step is walked transition by transition, not row by row: for the walk's current position every lane gathers, for
+    // each candidate f, the RC rows' bits into a small vector (three VALU ops per row and candidate), keeps the rows the
+    // walk can still reach (<= i, >= m) and takes the highest one.  With ~12 rows per run nearly every ROW sees some
+    // lane of the wave change state, so a per-row branch made every lane pay the transition code RC times per step; this
+    // way it runs as often as the busiest lane changes state inside the step (two or three times).
     auto process = [&](const Step &cur, int cc) {
-#pragma unroll
-        for (int rr = RC - 1; rr >= 0; rr--) {
-            const int r = cc * RC + rr;
-            uint32_t e = 0; // bit f: predecessor f beat everything before it at (r, bit)
+        const int base = cc * RC;
+        while (true) {
+            const int top = i - base; // rows base .. base+top are still part of the walk
+            uint32_t reach = top >= RC - 1 ? (1u << RC) - 1u : (top < 0 ? 0u : (2u << top) - 1u);
+            if (base < m) reach &= ~((1u << (m - base)) - 1u); // rows < m hold no pointers (and were never written)
+            const uint32_t sh = (uint32_t)bit & 31u;
+            const bool upper = bit >= 32;
+            uint32_t hf[F], h = 0;
 #pragma unroll
             for (int f = 0; f < F; f++) {
-                const int idx = rr * F + f;
-                const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
-                e |= (uint32_t)((w >> bit) & 1ull) << f;
+                hf[f] = 0;
+#pragma unroll
+                for (int rr = 0; rr < RC; rr++) {
+                    const int idx = rr * F + f;
+                    const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
+                    const uint32_t d = upper ? (uint32_t)(w >> 32) : (uint32_t)w;
+                    hf[f] |= ((d >> sh) & 1u) << rr;
+                }
+                h |= hf[f];
             }
-            if (e != 0 && r <= i && r >= m) { // rows < m hold no pointers (and were never written)
+            h &= reach;
+            if (__ballot(h != 0) == 0) break;
+            if (h != 0) {
+                const int rr = 31 - __builtin_clz(h); // the latest reachable row where the state was entered
+                const int r = base + rr;
                 close_run(bit, r);
-                const int ptr = 32 - __builtin_clz(e); // the arg-min is the highest set bit
+                int ptr = 1; // the arg-min is the highest candidate whose bit is set
+#pragma unroll
+                for (int f = 1; f < F; f++) ptr = ((hf[f] >> rr) & 1u) ? f + 1 : ptr;
                 const int back = m - (int)((cur.mw >> (r & 31)) & 1u);
                 bit = (int)((tab[bit] >> (16 * (ptr - 1))) & 0xffffull);
                 i = r - back;
