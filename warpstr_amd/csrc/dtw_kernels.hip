@@ -713,6 +713,8 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 // reads; the stream runs at HBM rate (scripts/exp_stream.hip: 5.4 TB/s for this access pattern).  Predecessor
 // positions come from a table in LDS (one 64-entry table per automaton of the handle); finished runs queue up in LDS
 // and are written 16 at a time.  Same outputs as traceback_mask_kernel.
+// (Tried: eight lanes fetching one read's 128-byte step together and trading pieces through LDS -- whole-line loads
+// instead of 64 lines per instruction.  7 % faster alone, 4 % slower per step: the fill it runs beside is LDS-bound.)
 // ------------------------------------------------------------------------------------------------
 template <int F>
 __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_aut)
@@ -770,12 +772,20 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
         ull2 v[RC * F / 2]; // RC rows x F masks
         uint32_t mw;        // the sample-mask word that covers these rows
     };
+    uint32_t mw_word = 0u;
+    int mw_at = -1;
     auto load = [&](Step &S, int c) { // rows RC*c .. RC*c + RC-1 (c < 0: nothing)
         const int cc = c < 0 ? 0 : c;
         const ull2 *p = (const ull2 *)(bp + (size_t)cc * (RC * F));
 #pragma unroll
         for (int e = 0; e < RC * F / 2; e++) S.v[e] = p[e];
-        S.mw = maskw ? maskw[(cc * RC) >> 5] : 0u;
+        // the sample-mask word changes every 32 / RC steps only (steps are loaded in descending order)
+        const int wi = (cc * RC) >> 5;
+        if (maskw && wi != mw_at) {
+            mw_word = maskw[wi];
+            mw_at = wi;
+        }
+        S.mw = mw_word;
     };
     int bit = a.aut[aid].endstate; // K = 1: position = state
     int i = T - 1;                 // rows above i are not part of the walk
