@@ -722,8 +722,9 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
     constexpr int RC = F == 2 ? 8 : 4; // rows per step
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     extern __shared__ uint64_t tb_tab[]; // [automaton][position]: the positions of its state's predecessors
-    __shared__ uint16_t q_state[16][64];
-    __shared__ int32_t q_start[16][64];
+    constexpr int QD = 32; // queue depth per lane: a 16-entry chunk waiting to leave + what three steps can add (<= 3 * RC / 2)
+    __shared__ uint16_t q_state[QD][64];
+    __shared__ int32_t q_start[QD][64];
     const int lane = threadIdx.x;
     for (int e = lane; e < n_aut * 64; e += 64) {
         const DevAutomaton &B = a.aut[e >> 6];
@@ -747,15 +748,22 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
     int nr = 0;
+    int nf = 0; // runs already written out (a multiple of 16)
     auto push = [&](int state, int start) {
-        q_state[nr & 15][lane] = (uint16_t)state;
-        q_start[nr & 15][lane] = start;
+        q_state[nr & (QD - 1)][lane] = (uint16_t)state;
+        q_start[nr & (QD - 1)][lane] = start;
         nr++;
-        if ((nr & 15) == 0) {
+    };
+    // Full 16-entry chunks leave the queue here -- called between steps, not from push(): the lanes of a wave fill their
+    // queues at different times, so a test inside the transition code made nearly every transition of the WAVE run the
+    // (long) write-out for some lane.
+    auto drain = [&]() {
+        if (nr - nf >= 16) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) run_state[nr - 16 + e] = q_state[e][lane];
+            for (int e = 0; e < 16; e++) run_state[nf + e] = q_state[(nf + e) & (QD - 1)][lane];
 #pragma unroll
-            for (int e = 0; e < 16; e++) run_start[nr - 16 + e] = q_start[e][lane];
+            for (int e = 0; e < 16; e++) run_start[nf + e] = q_start[(nf + e) & (QD - 1)][lane];
+            nf += 16;
         }
     };
     int open_state = -1, open_start = 0;
@@ -818,7 +826,11 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
                     const int idx = rr * F + f;
                     const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
                     const uint32_t d = upper ? (uint32_t)(w >> 32) : (uint32_t)w;
-                    hf[f] |= ((d >> sh) & 1u) << rr;
+                    // bit `sh` of d lands at bit rr: one bit-field extract and one shift-or (the compiler's own choice
+                    // was shift, shift, and, or)
+                    uint32_t t;
+                    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(t) : "v"(d), "v"(sh));
+                    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(hf[f]) : "v"(t), "n"(rr), "v"(hf[f]));
                 }
                 h |= hf[f];
             }
@@ -845,12 +857,14 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
         load(s1, c - 4);
         process(s2, c - 2);
         load(s2, c - 5);
+        drain();
     }
     close_run(bit, 0); // row 0 is reached in this state
     if (open_state >= 0) push(open_state, open_start);
-    for (int e = nr & ~15; e < nr; e++) {
-        run_state[e] = q_state[e & 15][lane];
-        run_start[e] = q_start[e & 15][lane];
+    drain();
+    for (int e = nf; e < nr; e++) {
+        run_state[e] = q_state[e & (QD - 1)][lane];
+        run_start[e] = q_start[e & (QD - 1)][lane];
     }
     a.n_runs[lr] = nr;
 }
