@@ -248,7 +248,8 @@ def main():
             'config': {'workload': f'BASELINE configs[2]: {n} reads/GPU x {T} samples, {PATTERN} flank {FLANK}, '
                                    f'S={locus.template.n_states}/{locus.reverse.n_states} states, both passes',
                        'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
-                       'results_gather': (f'{backend} all_gather of 56-B records per step, overlapped with the next step' if world > 1
+                       'results_gather': ((f'{backend} all_gather of 56-B records per step' +
+                                          (', overlapped with the next step' if collective else ' (CPU test path, synchronous)')) if world > 1
                                           else ('one-rank nccl group (self test)' if self_gather else 'none (1 GPU)'))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,

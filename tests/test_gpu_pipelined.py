@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 def _batches(locus):
     out = []
-    for seed, n, T in ((1, 8500, (500, 1100)), (2, 4200, 800), (3, 300, (400, 2500)), (4, 8200, 600)):
+    # growing sizes: the work sets are re-allocated while earlier calls are still in flight
+    for seed, n, T in ((3, 300, (400, 2500)), (2, 4200, 800), (1, 8500, (500, 1100)), (4, 8200, 600)):
         sigs, revs, _ = synth.batch(locus, n, T, seed)
         sig, off = pack_signals(sigs)
         out.append((sig, off, np.array([1 if x else 0 for x in revs], dtype=np.int32)))
@@ -22,7 +23,8 @@ def test_pipelined_calls_match_stream_ordered_calls():
     locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
     batches = _batches(locus)
     hip = HipCaller([locus.template, locus.reverse], [19, 19], stream=torch.cuda.current_stream().cuda_stream)
-    want = [hip.call(sig, off, aut, want_traces=True) for sig, off, aut in batches]
+    ref = HipCaller([locus.template, locus.reverse], [19, 19])  # its own handle: `hip` starts the pipelined calls cold
+    want = [ref.call(sig, off, aut, want_traces=True) for sig, off, aut in batches]
     dev = torch.device('cuda:0')
     d_sig = [torch.from_numpy(sig).to(dev) for sig, _, _ in batches]
 
