@@ -19,6 +19,12 @@ __global__ __launch_bounds__(256) void k(const double *x, double *out, const int
         if (MODE == 0) {
             n0 = lds[w][1 - par][a0];
             n1 = lds[w][1 - par][a1];
+        } else if (MODE == 3) { // one read only
+            n0 = lds[w][1 - par][a0];
+        } else if (MODE == 4) { // second read for the four lanes that have a second predecessor
+            n0 = lds[w][1 - par][a0];
+            if (a1 != 63) n1 = lds[w][1 - par][a1];
+        } else if (MODE == 5) { // write only
         } else if (MODE == 1) {
             const long long b = __double_as_longlong(g3);
             const int lo = (int)b, hi = (int)(b >> 32);
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(256) void k(const double *x, double *out, const int
         g2 = g1 + fabs(an);
         g1 = best + fabs(an);
         d = best;
-        if (MODE == 0) lds[w][par][lane] = g3;
+        if (MODE == 0 || MODE >= 3) lds[w][par][lane] = g3;
         e0 = n0;
         e1 = n1;
         __builtin_amdgcn_wave_barrier();
@@ -84,6 +90,9 @@ int main()
         printf("lds write+2 reads : %.3f ms\n", run<0>(dx, dout, s0, s1, waves, rows));
         printf("4 x ds_bpermute   : %.3f ms\n", run<1>(dx, dout, s0, s1, waves, rows));
         printf("no exchange       : %.3f ms\n", run<2>(dx, dout, s0, s1, waves, rows));
+        printf("write + 1 read    : %.3f ms\n", run<3>(dx, dout, s0, s1, waves, rows));
+        printf("write + 1 read + 4-lane read : %.3f ms\n", run<4>(dx, dout, s0, s1, waves, rows));
+        printf("write only        : %.3f ms\n", run<5>(dx, dout, s0, s1, waves, rows));
     }
     return 0;
 }
