@@ -9,6 +9,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(const double *x, double *out, const int *src0, const int *src1, int rows)
 {
     __shared__ double lds[4][2][96];
+    __shared__ __attribute__((aligned(16))) double lds2[4][192];
+    double keep0 = 0.5, keep1 = 0.25;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double d = x[lane], g1 = d + 1.0, g2 = d + 2.0, g3 = d + 3.0, e0 = 0.5, e1 = 0.25;
     const double v = x[(lane * 7) & 63];
@@ -24,6 +26,17 @@ __global__ __launch_bounds__(256) void k(const double *x, double *out, const int
         } else if (MODE == 4) { // second read for the four lanes that have a second predecessor
             n0 = lds[w][1 - par][a0];
             if (a1 != 63) n1 = lds[w][1 - par][a1];
+        } else if (MODE == 6) { // pairs of rows: 16-byte reads every other row
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            if (par) {
+                const d2 p0 = *(const d2 *)&lds2[w][a0 * 2];
+                const d2 p1 = *(const d2 *)&lds2[w][a1 * 2];
+                n0 = p0.x; keep0 = p0.y;
+                n1 = p1.x; keep1 = p1.y;
+            } else {
+                n0 = keep0;
+                n1 = keep1;
+            }
         } else if (MODE == 5) { // write only
         } else if (MODE == 1) {
             const long long b = __double_as_longlong(g3);
@@ -43,7 +56,12 @@ __global__ __launch_bounds__(256) void k(const double *x, double *out, const int
         g2 = g1 + fabs(an);
         g1 = best + fabs(an);
         d = best;
-        if (MODE == 0 || MODE >= 3) lds[w][par][lane] = g3;
+        if (MODE == 0 || (MODE >= 3 && MODE != 6)) lds[w][par][lane] = g3;
+        if (MODE == 6 && !par) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 pr = {g3, g2 + 1e-3};
+            *(d2 *)&lds2[w][lane * 2] = pr;
+        }
         e0 = n0;
         e1 = n1;
         __builtin_amdgcn_wave_barrier();
@@ -93,6 +111,7 @@ int main()
         printf("write + 1 read    : %.3f ms\n", run<3>(dx, dout, s0, s1, waves, rows));
         printf("write + 1 read + 4-lane read : %.3f ms\n", run<4>(dx, dout, s0, s1, waves, rows));
         printf("write only        : %.3f ms\n", run<5>(dx, dout, s0, s1, waves, rows));
+        printf("16-byte write + 2 reads every other row : %.3f ms\n", run<6>(dx, dout, s0, s1, waves, rows));
     }
     return 0;
 }
