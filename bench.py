@@ -108,8 +108,8 @@ def valu_roofline(tm1, n, T):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=100000)
     ap.add_argument('--samples', type=int, default=2000)
     ap.add_argument('--no-cpu-baseline', action='store_true')

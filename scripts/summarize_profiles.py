@@ -14,7 +14,7 @@ with open(os.path.join(prof, f'{name}_kernel_stats.csv'), 'w', newline='') as f:
     w.writeheader()
     w.writerows(keep)
 
-# the dominant kernel's launches by size: bench.py times K steps of 4 chunks x 2 passes (25 000 reads per launch at the default
+# the dominant kernel's launches by size: bench.py times K = 20 steps (after 2 warm-up steps) of 4 chunks x 2 passes (25 000 reads per launch at the default
 # size) and then runs one extra untimed single-stream step (2 launches of all reads) for the VALU roofline; rocprofv3's
 # per-kernel average above mixes the two, bench.py's roofline.launch_ms is the first kind
 tr = list(csv.DictReader(open(os.path.join(src, 'trace', 'p_kernel_trace.csv'))))
