@@ -196,8 +196,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    hip.timing_window(True)   # the fill kernels' HIP events of ALL timed steps are kept (roofline.launch_ms)
     t0 = time.perf_counter()
-    dp_ms, dp_launches = 0.0, 0
     for _ in range(args.steps):
         allres = step()
     hip.synchronize()        # pipelined calls end on the library's own streams
@@ -206,7 +206,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tm = hip.last_timing()  # HIP events on the launch streams, last step
+    tm = hip.last_timing()  # HIP events on the launch streams, every fill launch of the timed region
+    hip.timing_window(False)
     # untimed extra step on ONE stream: the fill kernel's duration when nothing runs beside it (VALU roofline)
     hip.set_streams(1)
     step()
@@ -227,8 +228,9 @@ def main():
         # dominant kernel = the DTW fill.  One step = 2 passes over n reads, issued as `launches` kernel launches
         # (the library splits big batches into chunks that overlap on two streams); durations are HIP events
         # recorded on the launch streams around each fill launch.
-        launches = max(tm['dp_launches'], 1)
-        launch_ms = tm['dp_kernel_ms'] / launches
+        launches_total = max(tm['dp_launches'], 1)
+        launches = launches_total / args.steps            # per step
+        launch_ms = tm['dp_kernel_ms'] / launches_total   # average over every fill launch of the timed region
         reads_per_launch = 2.0 * n / launches
         algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
         achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
@@ -261,9 +263,9 @@ def main():
                      'note': 'PMC: SQ_INSTS_VALU = 10.51 per row per wave (floor of this formulation: 10 = 6 adds, 2 '
                              'compares, 2 mins); the fill launches overlap other chunks\' kernels on 4 streams, so '
                              'launch_ms is a co-scheduled duration (5.3-5.4 ms per 100k reads when the kernel runs alone)'},
-            'dp_kernel_ms_per_step': tm['dp_kernel_ms'],
-            # enqueue-to-finish of the last step; steps are pipelined, so it overlaps the step before it
-            'last_step_latency_ms': tm['total_ms'],
+            'dp_kernel_ms_per_step': tm['dp_kernel_ms'] / args.steps,
+            # first enqueue to last finish of the timed region on the device clock (HIP events), per step
+            'device_ms_per_step': tm['total_ms'] / args.steps,
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = signal[: min(n, 4096) * T].cpu().numpy()

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 4
+#define WSX_ABI_VERSION 5
 
 /* function return codes */
 enum {
@@ -213,6 +213,14 @@ int wsx_caller_synchronize(wsx_caller *c);
  * milliseconds of the whole enqueue..finish region.  Blocks until the work has finished.
  */
 int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms);
+
+/*
+ * With `on` != 0 the figures of wsx_caller_last_timing cover every call from now on instead of the most recent one
+ * (the fill kernels' events of successive calls are kept, total_ms runs from the first call's start to the last
+ * call's end); calling it again, with either value, starts afresh.  For measurements over several pipelined calls
+ * (helpers.print_time_duration brackets whole steps upstream, src/helpers.py:16-29).
+ */
+int wsx_caller_timing_window(wsx_caller *c, int32_t on);
 
 /* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<1, 2, false>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);

@@ -81,3 +81,29 @@ def test_join_before_any_call_is_a_no_op():
     hip.join()
     hip.synchronize()
     hip.set_pipelined(False)
+
+
+def test_timing_window_covers_every_call():
+    import torch
+    locus = synth.make_locus('(AGC)', 16, 1)
+    sigs, revs, _ = synth.batch(locus, 9000, 700, 3)
+    sig, off = pack_signals(sigs)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    dev = torch.device('cuda:0')
+    dsig = torch.from_numpy(sig).to(dev)
+    res = torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    hip = HipCaller([locus.template, locus.reverse], [16, 16], stream=torch.cuda.current_stream().cuda_stream)
+    hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
+    one = hip.last_timing()
+    assert one['dp_launches'] >= 2 and one['dp_kernel_ms'] > 0 and one['total_ms'] >= one['dp_kernel_ms'] / one['dp_launches']
+    hip.set_pipelined(True)
+    hip.timing_window(True)
+    for _ in range(5):
+        hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
+    five = hip.last_timing()
+    assert five['dp_launches'] == 5 * one['dp_launches']
+    assert five['dp_kernel_ms'] > 2.5 * one['dp_kernel_ms'] and five['total_ms'] > 2.5 * one['total_ms']
+    hip.timing_window(False)
+    hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
+    again = hip.last_timing()
+    assert again['dp_launches'] == one['dp_launches']

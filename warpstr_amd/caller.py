@@ -238,6 +238,10 @@ class HipCaller:
     def synchronize(self):
         _lib.check(self.lib.wsx_caller_synchronize(self.handle), 'wsx_caller_synchronize')
 
+    def timing_window(self, on: bool = True):
+        """last_timing() covers every call from now on (on) or the most recent call only (off)."""
+        _lib.check(self.lib.wsx_caller_timing_window(self.handle, int(bool(on))), 'wsx_caller_timing_window')
+
     def last_timing(self):
         dp, nl, tot = C.c_double(), C.c_int32(), C.c_double()
         _lib.check(self.lib.wsx_caller_last_timing(self.handle, C.byref(dp), C.byref(nl), C.byref(tot)),

@@ -222,6 +222,9 @@ struct wsx_caller {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
     size_t dp_events_used = 0;
     bool timing_valid = false;
+    bool timing_window = false; // wsx_caller_timing_window: the fill events of successive calls accumulate
+    hipEvent_t ev_window = nullptr; // start of the window (the first call's begin)
+    bool window_open = false;
     int max_states = 0;
     bool have_bases = true; // every automaton came with last_base
     std::vector<hipEvent_t> sched_events;
@@ -538,6 +541,7 @@ void wsx_caller_destroy(wsx_caller *c)
     if (c->ev_joins[0]) (void)hipEventDestroy(c->ev_joins[0]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 
+    if (c->ev_window) (void)hipEventDestroy(c->ev_window);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto &e : c->sched_events) (void)hipEventDestroy(e);
@@ -584,6 +588,18 @@ int wsx_caller_join(wsx_caller *c, void *stream)
     HIPCHK(hipSetDevice(c->device));
     // a never-recorded event is complete: joining before the first call is a no-op
     HIPCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, c->ev_end, 0));
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_timing_window(wsx_caller *c, int32_t on)
+{
+    if (!c) return WSX_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    if (on && !c->ev_window) HIPCHK(hipEventCreate(&c->ev_window));
+    c->timing_window = on != 0;
+    c->window_open = false;
+    c->dp_events_used = 0;
+    c->timing_valid = false;
     return WSX_SUCCESS;
 }
 
@@ -675,7 +691,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int rc = set_device(c);
     if (rc) return rc;
     c->timing_valid = false;
-    c->dp_events_used = 0;
+    if (!c->timing_window) c->dp_events_used = 0;
     if (n == 0) return WSX_SUCCESS;
     hipStream_t st = c->stream;
     const bool host = io.mem == WSX_MEM_HOST;
@@ -817,6 +833,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     const hipStream_t main_st = c->stream;
     HIPCHK(hipEventRecord(c->ev_begin, main_st));
+    if (c->timing_window && !c->window_open) {
+        HIPCHK(hipEventRecord(c->ev_window, main_st));
+        c->window_open = true;
+    }
     const int m = c->prm.min_values_per_state;
     int32_t *order = h_order;
 
@@ -1236,7 +1256,7 @@ int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_laun
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(c->ev_end));
     float tot = 0.f;
-    HIPCHK(hipEventElapsedTime(&tot, c->ev_begin, c->ev_end));
+    HIPCHK(hipEventElapsedTime(&tot, (c->timing_window && c->window_open) ? c->ev_window : c->ev_begin, c->ev_end));
     double dp = 0.0;
     for (size_t i = 0; i < c->dp_events_used; i++) {
         float ms = 0.f;
