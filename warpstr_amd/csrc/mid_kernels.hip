@@ -256,7 +256,9 @@ __device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
 // (1) alignment records: one per run (create_alignment, reps_as_one = False), caller.py:17-43,65-96.
 // A block handles 64 consecutive runs, i.e. one contiguous span of the signal: the span is loaded coalesced into LDS
 // (when it fits) and every thread then walks its own run there.
+#ifndef RS_CAP
 #define RS_CAP 1024
+#endif
 #ifndef RS_GROUPS
 #define RS_GROUPS 4
 #endif //// grid.y: a read's 64-run groups are dealt round-robin to this many single-wave blocks
