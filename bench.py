@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/s of the HIP caller on BASELINE.json's headline workload.
+"""bench.py -- reads/s of the HIP caller on BASELINE.json's workloads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--samples T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload headline|cfg1|cfg5]
+                    [--reads R] [--samples T]
 
-Workload (config.workload): BASELINE.json configs[2] -- 100k synthetic reads, 2 kSample squiggles, HD-style
-interrupted automaton `(AGC)AACAGCCGCCAC(CGC)` with <= 64 states -- per GPU (weak scaling: reads shard with
-no exchange on the data path; one RCCL all-gather collects the per-read result records each step).
+Workloads (config.workload)
+  headline  BASELINE.json configs[2]: 100k synthetic reads, 2 kSample squiggles, HD-style interrupted automaton
+            `(AGC)AACAGCCGCCAC(CGC)` with <= 64 states.  --scaling weak (default): that many reads PER GPU;
+            --scaling strong = configs[3]: the SAME 100k-read workload sharded over the N GPUs
+            (warpstr_amd.dist.shard_reads), one RCCL all-gather of the result records per step.
+  cfg1      the shape of the upstream test case / every flank-110 locus: `(AAAT)` flank 110, S = 225 states,
+            T in [2271, 3701] samples, 20k reads per GPU (kernel dtw_fill_fast<4, 4, 2, 1>).
+  cfg5      BASELINE.json configs[4] at one GPU's share: 8 loci x 2 strands, ~128-state automata, T in [500, 5000],
+            50k reads per GPU.
 A "step" is one full call of the batch: both DTW passes, rescaling fit, bad-repeat masking, allele lengths.
-Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.  The results of the timed
+steps are compared with the CPU oracle on a sample of the reads ("verified"); a mismatch exits non-zero.
 """
 import argparse
 import json
@@ -20,89 +28,215 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The HIP runtime multiplexes a process's streams onto 4 hardware queues by default.  The batch call uses five streams,
-# the result gather a sixth; a stream that shares a queue with the gather's wait-for-step-k barrier cannot start its
+# The HIP runtime multiplexes a process's streams onto 4 hardware queues by default.  The batch call uses up to ten streams,
+# the result gather another; a stream that shares a queue with the gather's wait-for-step-k barrier cannot start its
 # step k+1 work behind it (measured: +0.8 ms per step on the collective path).  Has to be set before HIP initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-PATTERN = '(AGC)AACAGCCGCCAC(CGC)'
-FLANK = 19
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP64_VALU_PEAK = 78.6e12 / 2  # fp64 vector adds/s: 78.6 TFLOP/s counts FMA as 2
+N_SIMD, N_CU, CLK_MAX_HZ = 1024, 256, 2.4e9
+N_BUF = int(os.environ.get('WSX_INFLIGHT', '2'))  # result buffers = pipelined calls in flight
+
+HEADLINE = ('(AGC)AACAGCCGCCAC(CGC)', 19)
+CFG1 = ('(AAAT)', 110, (2271, 3701))
+CFG5_PATTERNS = ['((CAGG){CAGM})(CAGA)(CA)', '(CAG)CAACAG(CCG)', '(GGCCCC)', '(CTG)CTA(CTG)', '(AAGGG)(AAAGG)', '(CCTG)(TCTG)',
+                 '(GAA)', '(CAG)(CAA)(CAG)']
 
 
-def make_workload(n_reads, T, seed, device):
-    """Clean level sequences on the host (seeded), noise added on the device (seeded)."""
+class Workload:
+    """Automata + device-resident reads of one rank."""
+
+    def __init__(self, name, desc, tables, flanks, signal, offsets, aut, oracle_automata):
+        self.name, self.desc = name, desc
+        self.tables, self.flanks = tables, flanks
+        self.signal, self.offsets, self.aut = signal, offsets, aut
+        self.oracle_automata = oracle_automata  # () -> list of oracle.Automaton (built lazily: the oracle is the checker)
+
+    @property
+    def n(self):
+        return len(self.aut)
+
+
+def _noisy(clean_rows, lens, idx, seed, device):
+    """signal = clean template read + N(0, 0.25) noise, on the device (seeded): ragged rows -> one flat f64 tensor."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    flat = torch.from_numpy(np.concatenate([clean_rows[i] for i in idx])).to(device)
+    flat += 0.25 * torch.randn(flat.shape, generator=g, device=device, dtype=torch.float64)
+    offsets = np.zeros(len(idx) + 1, np.int64)
+    np.cumsum(lens[idx], out=offsets[1:])
+    return flat.contiguous(), offsets
+
+
+def make_headline(n_local, T, seed, device, picks=None):
+    """configs[2].  `picks` (strong scaling): template index of each of this rank's reads, drawn from the global
+    workload; else n_local reads drawn with this rank's seed."""
     import torch
 
     from warpstr_amd import synth
-    locus = synth.make_locus(PATTERN, FLANK, 2024, max_states=64)
-    rng = np.random.default_rng(seed)
-    n_tpl = min(n_reads, 2048)
+    pattern, fl = HEADLINE
+    locus = synth.make_locus(pattern, fl, 2024, max_states=64)
+    rng = np.random.default_rng(1000)  # templates are the same on every rank
+    n_tpl = 2048
     pm_sigs, revs = [], []
     for _ in range(n_tpl):
         rev = bool(rng.random() < 0.5)
         s, _ = synth.squiggle(locus, rev, T, rng, sigma=0.0)
         pm_sigs.append(s)
         revs.append(rev)
+    if picks is None:
+        picks = np.random.default_rng(seed).integers(0, n_tpl, size=n_local)
     clean = torch.from_numpy(np.stack(pm_sigs)).to(device)
-    idx = torch.from_numpy(rng.integers(0, n_tpl, size=n_reads)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    signal = clean[idx] + 0.25 * torch.randn((n_reads, T), generator=g, device=device, dtype=torch.float64)
+    idx = torch.from_numpy(picks).to(device)
+    signal = clean[idx] + 0.25 * torch.randn((len(picks), T), generator=g, device=device, dtype=torch.float64)
     signal = signal.reshape(-1).contiguous()
-    aut = np.array(revs, dtype=np.int32)[idx.cpu().numpy()]
-    offsets = np.arange(n_reads + 1, dtype=np.int64) * T
-    return locus, signal, offsets, aut
+    aut = np.array(revs, dtype=np.int32)[picks]
+    offsets = np.arange(len(picks) + 1, dtype=np.int64) * T
+
+    def oa():
+        from oracle import oracle
+        return [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+    desc = (f'{pattern} flank {fl}, S={locus.template.n_states}/{locus.reverse.n_states} states, {T} samples per read')
+    return Workload('headline', desc, [locus.template, locus.reverse], [fl, fl], signal, offsets, aut, oa)
 
 
-def cpu_baseline(locus, signal_host, T, aut, budget_s=15.0):
-    """The CPU oracle (a C port of the reference algorithm; the Python reference cannot travel) on this
-    box's host cores, on a bounded sample of the same workload."""
+def make_ragged(name, loci_spec, n_local, seed, device):
+    """cfg1 / cfg5: loci_spec = [(pattern, flank, (Tmin, Tmax), locus seed, max_states or None)]; reads are dealt evenly
+    over the loci and strands; 96 clean template reads per locus, noise added on the device."""
+    from warpstr_amd import synth
+    rng = np.random.default_rng(seed)
+    tables, flanks, clean, clean_aut = [], [], [], []
+    for li, (pattern, fl, (tmin, tmax), lseed, max_states) in enumerate(loci_spec):
+        locus = synth.make_locus(pattern, fl, lseed, max_states=max_states)
+        tables += [locus.template, locus.reverse]
+        flanks += [fl, fl]
+        trng = np.random.default_rng(7000 + li)
+        for _ in range(96):
+            rev = bool(trng.random() < 0.5)
+            t = int(trng.integers(tmin, tmax + 1))
+            hi = max(1, min(30, (t // 4 - 2 * fl - 12) // 14))
+            clean.append(synth.squiggle(locus, rev, t, trng, lo=1, hi=hi, sigma=0.0)[0])
+            clean_aut.append(2 * li + int(rev))
+    lens = np.array([len(c) for c in clean], np.int64)
+    idx = rng.integers(0, len(clean), size=n_local)
+    signal, offsets = _noisy(clean, lens, idx, seed, device)
+    aut = np.array(clean_aut, np.int32)[idx]
+
+    def oa():
+        from oracle import oracle
+        return [oracle.Automaton.from_table(t, f) for t, f in zip(tables, flanks)]
+    S = [t.n_states for t in tables]
+    desc = (f'{len(loci_spec)} loci x 2 strands ({", ".join(p for p, *_ in loci_spec[:3])}{", ..." if len(loci_spec) > 3 else ""}), '
+            f'S={min(S)}..{max(S)} states, T in [{loci_spec[0][2][0]}, {loci_spec[0][2][1]}] samples')
+    return Workload(name, desc, tables, flanks, signal, offsets, aut, oa)
+
+
+def cfg5_flank(pattern, seed):
+    """configs[4] asks for 128-state automata: the longest flank with which both strands' automata have <= 128 states."""
+    from warpstr_amd import synth
+    for fl in range(64, 20, -1):
+        locus = synth.make_locus(pattern, fl, seed)
+        if max(locus.template.n_states, locus.reverse.n_states) <= 128:
+            return fl
+    raise RuntimeError(f'no flank length gives <= 128 states for {pattern}')
+
+
+def oracle_sample(wl, signal_host, n_max, budget_s):
+    """The CPU oracle (a C port of the reference algorithm; the Python reference cannot travel) on this box's host
+    cores, on the first reads of the workload: returns (results per read, cpu_baseline record)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle
     cores = os.cpu_count() or 1
-    oa = [oracle.Automaton.from_table(locus.template, FLANK), oracle.Automaton.from_table(locus.reverse, FLANK)]
+    oa = wl.oracle_automata()
     oracle.lib()
+    off, aut = wl.offsets, wl.aut
 
     def one(i):
-        return oracle.call_read(oa[aut[i]], signal_host[i * T:(i + 1) * T], debug=False).len2
+        return oracle.call_read(oa[aut[i]], signal_host[off[i]:off[i + 1]], debug=False)
 
     t0 = time.perf_counter()
-    one(0)
+    first = one(0)
     t1 = time.perf_counter() - t0
-    n = int(max(cores, min(len(aut), budget_s * cores / max(t1, 1e-4))))
-    n = min(n, len(aut))
+    n = int(max(min(cores, n_max), min(n_max, budget_s * cores / max(t1, 1e-4))))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the call
-        list(ex.map(one, range(n)))
+        res = list(ex.map(one, range(n)))
     dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'reads/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} reads of the same workload (T={T}), C oracle, {cores} threads'}
+    res[0] = first
+    base = {'value': n / dt, 'unit': 'reads/s', 'cores': cores, 'kind': 'port',
+            'sample': f'the first {n} reads of the same workload ({wl.name}), C oracle, {cores} threads'}
+    return res, base
 
 
-VALU_INSTS_PER_ROW = 10.51   # SQ_INSTS_VALU per DP row per wave (profiles/r01s5_pmc.json); the formulation's floor is 10
-LDS_CYCLES_PER_ROW = 10.0    # 2 ds_read_b64 (2 cycles each) + 1 ds_write_b64 (~6): MI355X_MICROARCH.md, LDS table
-N_SIMD, N_CU, CLK_MAX_HZ, CLK_OBSERVED_HZ = 1024, 256, 2.4e9, 1.89e9
+def verify(gpu_records, oracle_results):
+    """Result records of the timed run against the oracle, read by read: status and both allele lengths identical, both
+    state-wise costs within 1e-5 relative (north_star's tolerance)."""
+    bad = []
+    for i, o in enumerate(oracle_results):
+        g = gpu_records[i]
+        ok = int(g['status']) == o.status
+        if ok and o.status == 0:
+            ok = (int(g['len1']), int(g['len2'])) == (o.len1, o.len2)
+            for a, b in ((float(g['cost1']), o.cost1), (float(g['cost2']), o.cost2)):
+                ok = ok and abs(a - b) <= 1e-5 * max(abs(b), 1e-300)
+        if not ok:
+            bad.append(i)
+    return {'reads': len(oracle_results), 'mismatches': len(bad), 'first_mismatches': bad[:5],
+            'fields': 'status, len1, len2 identical; cost1, cost2 within 1e-5 relative', 'against': 'oracle/ (CPU)'}
 
 
-def valu_roofline(tm1, n, T):
+def union_ms(begin, end):
+    """Total length of the union of intervals."""
+    order = np.argsort(begin)
+    tot, cs, ce = 0.0, None, None
+    for i in order:
+        b, e = float(begin[i]), float(end[i])
+        if cs is None or b > ce:
+            if cs is not None:
+                tot += ce - cs
+            cs, ce = b, e
+        else:
+            ce = max(ce, e)
+    return tot + ((ce - cs) if cs is not None else 0.0)
+
+
+def fill_profile(kernel):
+    """Counters of the fill kernel from the committed rocprofv3 PMC passes (profiles/fill_pmc.json, written by
+    scripts/summarize_profiles.py).  The bench refuses to quote counters of a different kernel."""
+    path = os.path.join(ROOT, 'profiles', 'fill_pmc.json')
+    with open(path) as f:
+        table = json.load(f)
+    if kernel not in table:
+        if os.environ.get('WARPSTR_BENCH_PROFILING'):  # scripts/profile_round.sh: the run that produces the entry
+            return None
+        raise SystemExit(f'bench.py: profiles/fill_pmc.json holds no PMC profile of {kernel} (has: {sorted(table)}); '
+                         're-run scripts/profile_round.sh for this workload')
+    return table[kernel]
+
+
+def valu_roofline(prof, alone_ms, wave_rows, kernel):
     """What actually bounds the fill: wave-level VALU instruction issue (every VALU op, fp64 or 32-bit, occupies a
-    SIMD for 4 cycles per wave64).  Measured on an extra single-stream step (HIP events around the fill launches)."""
-    launches = max(tm1['dp_launches'], 1)
-    ms = tm1['dp_kernel_ms'] / launches
-    rows = 2.0 * n * T / launches                      # wave-rows per launch (one wave per read)
-    achieved = rows * VALU_INSTS_PER_ROW / (ms * 1e-3)  # wave-instructions per second
+    SIMD for 4 cycles per wave64) together with the LDS pipe.  alone_ms: one fill launch with nothing beside it."""
+    import re
+    m = re.match(r'dtw_fill_fast<(\d+), (\d+), (\d+), (\d+)', kernel)
+    K, F, FL = (int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (1, 2, 2)
+    lds_cycles = 6.0 * K + 2.0 * (F + (K - 1) * FL)  # ds_write_b64 ~6, ds_read_b64 2 (MI355X_MICROARCH.md, LDS table)
+    vpr, clk = prof['valu_insts_per_wave_row'], prof['clock_hz_observed']
+    achieved = wave_rows * vpr / (alone_ms * 1e-3)
     peak = N_SIMD * CLK_MAX_HZ / 4.0
-    lds = rows * LDS_CYCLES_PER_ROW / (ms * 1e-3)       # LDS-pipe cycles per second, all CUs
+    lds = wave_rows * lds_cycles / (alone_ms * 1e-3)
     return {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'wave64 VALU instr/s',
-            'frac': achieved / peak, 'frac_at_observed_clock': achieved / (N_SIMD * CLK_OBSERVED_HZ / 4.0),
-            'launch_ms_alone': ms, 'launches': launches,
-            'lds_pipe': {'cycles_per_row': LDS_CYCLES_PER_ROW, 'frac': lds / (N_CU * CLK_MAX_HZ),
-                         'frac_at_observed_clock': lds / (N_CU * CLK_OBSERVED_HZ)},
-            'note': 'peak = 1024 SIMDs x 2.4 GHz / 4 cycles; the chip holds ~1.89 GHz under this fp64 load '
-                    '(GRBM_GUI_ACTIVE); the LDS pipe (one per CU: predecessor exchange) is loaded as heavily as the VALU'}
+            'frac': achieved / peak, 'frac_at_observed_clock': achieved / (N_SIMD * clk / 4.0),
+            'launch_ms_alone': alone_ms, 'valu_insts_per_wave_row': vpr, 'clock_hz_observed': clk,
+            'counters_from': prof['source'],
+            'lds_pipe': {'cycles_per_row': lds_cycles, 'frac': lds / (N_CU * CLK_MAX_HZ),
+                         'frac_at_observed_clock': lds / (N_CU * clk)},
+            'note': 'peak = 1024 SIMDs x 2.4 GHz / 4 cycles; clock_hz_observed = GRBM_GUI_ACTIVE / launch time under this '
+                    'fp64 load; the LDS pipe (one per CU: predecessor exchange) is loaded as heavily as the VALU'}
 
 
 def main():
@@ -110,9 +244,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--reads', type=int, default=100000)
-    ap.add_argument('--samples', type=int, default=2000)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['headline', 'cfg1', 'cfg5'], default='headline')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--reads', type=int, default=0, help='reads per GPU (weak) / in total (strong); default by workload')
+    ap.add_argument('--samples', type=int, default=2000, help='samples per read (headline workload)')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the 15 s CPU baseline (a 256-read check remains)')
+    ap.add_argument('--no-verify', action='store_true')
     args = ap.parse_args()
 
     # Exactly one line on stdout: native libraries print there too (RCCL's start-up banner: version, hostname, library
@@ -152,34 +289,57 @@ def main():
 
     from warpstr_amd import _lib
     from warpstr_amd.caller import HipCaller
-    from warpstr_amd.dist import gather_results
+    from warpstr_amd.dist import gather_results, shard_reads
 
-    n, T = args.reads, args.samples
-    locus, signal, offsets, aut = make_workload(n, T, 1000 + rank, device)
+    # ---- the workload of this rank ------------------------------------------------------------------------------
+    default_reads = {'headline': 100000, 'cfg1': 20000, 'cfg5': 50000}[args.workload]
+    n_arg = args.reads or default_reads
+    strong = args.scaling == 'strong'
+    shards = None
+    if strong:
+        # configs[3]: ONE workload of n_arg reads; rank r calls the reads shard_reads() gives it (all ranks compute the
+        # same partition from the same seeded global description), the all-gather returns every record to every rank
+        n_total = n_arg
+        if args.workload != 'headline':
+            raise SystemExit('--scaling strong is defined for the headline workload (configs[3])')
+        gpicks = np.random.default_rng(1000).integers(0, 2048, size=n_total)
+        shards = shard_reads(np.full(n_total, args.samples, np.int64), world)
+        wl = make_headline(len(shards[rank]), args.samples, 1000 + rank, device, picks=gpicks[shards[rank]])
+    else:
+        n_total = n_arg * world
+        if args.workload == 'headline':
+            wl = make_headline(n_arg, args.samples, 1000 + rank, device)
+        elif args.workload == 'cfg1':
+            pat, fl, tr = CFG1
+            wl = make_ragged('cfg1', [(pat, fl, tr, 1, None)], n_arg, 1000 + rank, device)
+        else:
+            wl = make_ragged('cfg5', [(p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i, None) for i, p in enumerate(CFG5_PATTERNS)],
+                             n_arg, 1000 + rank, device)
+    n = wl.n
+    n_pad = (n_total + world - 1) // world if strong else n  # all_gather_into_tensor wants equal shards
     stream = torch.cuda.current_stream().cuda_stream
-    hip = HipCaller([locus.template, locus.reverse], [FLANK, FLANK], device=local, stream=stream,
-                    workspace_limit=96 << 30)
-    # Two result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
-    # other buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
-    res_bufs = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(2)]
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream, workspace_limit=96 << 30)
+    # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
+    # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
+    res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
     gather_stream = torch.cuda.Stream(device=device) if collective else None
-    gather_done = [None, None]
+    gather_done = [None] * N_BUF
     step_no = [0]
-    # back-to-back steps: a call no longer drains into the handle's stream, the next step's chunks follow on every
-    # internal stream (wsx_caller_set_pipelined); consumers are ordered after a step with join()
+    # back-to-back steps: a call no longer drains into the handle's stream, the next step's chunks follow on the
+    # library's internal streams (wsx_caller_set_pipelined); consumers are ordered after a step with join()
     hip.set_pipelined(True)
 
     def step():
-        k = step_no[0] & 1
+        k = step_no[0] % N_BUF
         step_no[0] += 1
         results = res_bufs[k]
-        if gather_done[k] is not None:  # the gather that read this buffer two steps ago
+        if gather_done[k] is not None:  # the gather that read this buffer N_BUF steps ago
             torch.cuda.current_stream().wait_event(gather_done[k])
-        hip.call_device(signal.data_ptr(), offsets, aut, results.data_ptr())
+        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, results.data_ptr())
         if collective:
             hip.join(gather_stream.cuda_stream)  # every kernel of this step is ahead of the gather
             with torch.cuda.stream(gather_stream):
-                out = torch.empty((world * n, results.shape[1]), dtype=torch.uint8, device=device)
+                out = torch.empty((world * n_pad, results.shape[1]), dtype=torch.uint8, device=device)
                 dist.all_gather_into_tensor(out, results)
                 done = torch.cuda.Event()
                 done.record()
@@ -192,11 +352,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    hip.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    hip.timing_window(True)   # the fill kernels' HIP events of ALL timed steps are kept (roofline.launch_ms)
+    hip.timing_window(True)   # the fill kernels' HIP events of ALL timed steps are kept
     t0 = time.perf_counter()
     for _ in range(args.steps):
         allres = step()
@@ -207,73 +368,94 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = hip.last_timing()  # HIP events on the launch streams, every fill launch of the timed region
+    fb, fe, fr = hip.fill_intervals()
     hip.timing_window(False)
     # untimed extra step on ONE stream: the fill kernel's duration when nothing runs beside it (VALU roofline)
     hip.set_streams(1)
     step()
+    hip.synchronize()
     torch.cuda.synchronize()
-    tm1 = hip.last_timing()
-    hip.set_streams(4)
+    ab, ae, _ = hip.fill_intervals()
+    hip.set_streams(8)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    rc = 0
     if rank == 0:
-        res = allres.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
-        ok = int((res['status'] == 0).sum())
-        S = max(locus.template.n_states, locus.reverse.n_states)
-        total_reads = n * world * args.steps
-        reads_per_s = total_reads / dt
-        # dominant kernel = the DTW fill.  One step = 2 passes over n reads, issued as `launches` kernel launches
-        # (the library splits big batches into chunks that overlap on two streams); durations are HIP events
-        # recorded on the launch streams around each fill launch.
-        launches_total = max(tm['dp_launches'], 1)
-        launches = launches_total / args.steps            # per step
-        launch_ms = tm['dp_kernel_ms'] / launches_total   # average over every fill launch of the timed region
-        reads_per_launch = 2.0 * n / launches
-        algo_bytes_per_launch = reads_per_launch * (12 * T + 32) / 2.0   # 12T+32 B/read for both passes
-        achieved = algo_bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        cells_per_s = reads_per_launch * T * S / (launch_ms * 1e-3)
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01s5_traffic.json), same workload only
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01s5_traffic.json')) as f:
-                tj = json.load(f)
-            if tj['workload']['samples'] == T:
-                traffic = tj['hbm_bytes_per_launch'] / tj['workload']['reads'] * reads_per_launch
-        except (OSError, KeyError, ValueError):
-            pass
+        table = allres.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(world, n_pad)
+        mine = table[0][:n]
+        ok_all = int(sum((table[r][:(len(shards[r]) if strong else n)]['status'] == 0).sum() for r in range(world)))
+        S = max(t.n_states for t in wl.tables)
+        samples = float(wl.offsets[-1])
+        reads_per_s = (n_total if strong else n * world) * args.steps / dt
+        # dominant kernel = the DTW fill.  One launch = one pass over a chunk's reads of one kernel variant; durations are
+        # HIP events recorded around each launch on its stream.  Launches of different chunks overlap (they run on
+        # different streams), so the time the device spent filling is the UNION of the intervals, not their sum.
+        launches_total = max(len(fb), 1)
+        fill_union = union_ms(fb, fe)
+        fill_sum = float((fe - fb).sum())
+        # algorithmic bytes: 12T+32 B per read for both passes = 6T+16 per read and pass
+        algo_bytes_total = samples * 6.0 * 2 * args.steps + 16.0 * float(fr.sum())
+        achieved = algo_bytes_total / (fill_union * 1e-3) / 1e9
+        kernel = hip.kernel_name(0)
+        kernels = sorted({hip.kernel_name(a) for a in range(len(wl.tables))})
+        prof = fill_profile(kernel)
+        traffic = None
+        if prof is not None and prof.get('hbm_bytes_per_sample') is not None:  # HBM bytes per launch from the PMC passes, scaled to this launch size
+            traffic = prof['hbm_bytes_per_sample'] * samples * 2 * args.steps / launches_total
+        alone_ms = float((ae - ab).sum()) / max(len(ab), 1)
+        alone_rows = samples * 2 / max(len(ab), 1)
+        cells_per_s = samples * 2 * args.steps * S / (fill_union * 1e-3)
+        if wl.name == 'headline':
+            head = f'BASELINE configs[{3 if strong else 2}]: '
+        elif wl.name == 'cfg5':
+            head = 'BASELINE configs[4] at one GPU\'s share: '
+        else:
+            head = 'shape of the upstream test case (every flank-110 locus): '
         out = {
             'metric': 'reads/s (STR segments aligned)', 'value': reads_per_s, 'unit': 'reads/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[2]: {n} reads/GPU x {T} samples, {PATTERN} flank {FLANK}, '
-                                   f'S={locus.template.n_states}/{locus.reverse.n_states} states, both passes',
-                       'reads_per_gpu': n, 'samples_per_read': T, 'states': S, 'called_ok': ok,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': head + (f'{n_total} reads in total sharded over {world} GPU(s)' if strong else f'{n} reads/GPU') +
+                                   f', {wl.desc}, both passes',
+                       'name': wl.name, 'reads_per_gpu': n, 'reads_total': n_total, 'mean_samples_per_read': samples / n,
+                       'states': S, 'called_ok': ok_all,
                        'results_gather': ((f'{backend} all_gather of 56-B records per step' +
                                           (', overlapped with the next step' if collective else ' (CPU test path, synchronous)')) if world > 1
                                           else ('one-rank nccl group (self test)' if self_gather else 'none (1 GPU)'))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'kernel': hip.kernel_name(0), 'launch_ms': launch_ms, 'launches_per_step': launches,
-                         'reads_per_launch': reads_per_launch,
-                         'note': 'min-plus recurrence: bound by fp64 VALU issue, not HBM (see valu)'},
-            'valu_roofline': valu_roofline(tm1, n, T),
-            'valu': {'dp_cells_per_s': cells_per_s, 'valu_insts_per_row_per_wave': VALU_INSTS_PER_ROW,
-                     'note': 'PMC: SQ_INSTS_VALU = 10.51 per row per wave (floor of this formulation: 10 = 6 adds, 2 '
-                             'compares, 2 mins); the fill launches overlap other chunks\' kernels on 4 streams, so '
-                             'launch_ms is a co-scheduled duration (5.3-5.4 ms per 100k reads when the kernel runs alone)'},
-            'dp_kernel_ms_per_step': tm['dp_kernel_ms'] / args.steps,
+                         'kernel': kernel, 'kernels': kernels,
+                         'launch_ms': fill_union / launches_total, 'launches_per_step': launches_total / args.steps,
+                         'reads_per_launch': float(fr.sum()) / launches_total,
+                         'fill_union_ms_per_step': fill_union / args.steps,
+                         'launch_ms_mean_overlapping': fill_sum / launches_total,
+                         'note': 'achieved = algorithmic bytes of every fill launch of the timed region / union of the '
+                                 'launches\' HIP-event intervals (launches of different chunks overlap on different streams; '
+                                 'launch_ms_mean_overlapping is the plain per-launch mean, what rocprofv3 --stats averages). '
+                                 'min-plus recurrence: bound by fp64 VALU issue and the LDS pipe, not HBM (see valu_roofline)'},
+            'valu_roofline': valu_roofline(prof, alone_ms, alone_rows, kernel) if prof is not None else {'launch_ms_alone': alone_ms},
+            'valu': {'dp_cells_per_s': cells_per_s},
             # first enqueue to last finish of the timed region on the device clock (HIP events), per step
             'device_ms_per_step': tm['total_ms'] / args.steps,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = signal[: min(n, 4096) * T].cpu().numpy()
-            out['cpu_baseline'] = cpu_baseline(locus, sample, T, aut[: min(n, 4096)])
+        if not args.no_verify:
+            nv = min(n, 4096 if not args.no_cpu_baseline else 256)
+            sample = wl.signal[: int(wl.offsets[nv])].cpu().numpy()
+            ores, base = oracle_sample(wl, sample, nv, 15.0 if not args.no_cpu_baseline else 2.0)
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = base
+            out['verified'] = verify(mine, ores)
+            if out['verified']['mismatches']:
+                rc = 3
+                print(f"bench.py: {out['verified']['mismatches']} of {len(ores)} reads differ from the oracle", file=sys.stderr)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or self_gather:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == '__main__':

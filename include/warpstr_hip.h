@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 5
+#define WSX_ABI_VERSION 6
 
 /* function return codes */
 enum {
@@ -141,7 +141,11 @@ void wsx_caller_destroy(wsx_caller *c);
 /* Upper bound, in bytes, of the device workspace the handle may allocate (default 16 GiB). */
 int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
 
-/* Number of HIP streams big batches are spread over (1..8, default 4; 1 = everything on the handle's stream). */
+/*
+ * Number of HIP streams (and workspace sets) the handle may use (1..8, default 8; 1 = everything on the handle's
+ * stream).  One call spreads its chunks over at most four of them; pipelined calls of small batches take turns on the
+ * rest, so that two calls run side by side.
+ */
 int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
 
 /*
@@ -222,7 +226,16 @@ int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_laun
  */
 int wsx_caller_timing_window(wsx_caller *c, int32_t on);
 
-/* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<1, 2, false>". */
+/*
+ * The fill launches behind wsx_caller_last_timing, one by one: begin/end of launch i in milliseconds since the start of
+ * the timed call (or of the timing window), and the number of reads it covered.  Launches on different streams overlap,
+ * so their union -- not their sum -- is the time the device spent with a fill kernel in flight.  At most `capacity`
+ * entries are written (any array may be NULL); *n_out receives the number of launches.  Blocks like last_timing.
+ */
+int wsx_caller_fill_intervals(wsx_caller *c, double *begin_ms, double *end_ms, int32_t *reads, int32_t capacity,
+                              int32_t *n_out);
+
+/* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<4, 1, 2, 2>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);
 
 /* ---- flank localisation (upstream step 1) -------------------------------------------------------- */

@@ -1,6 +1,8 @@
-"""bench.py prints exactly one JSON line with the fields the driver reads (small workload, one GPU)."""
+"""bench.py prints exactly one JSON line with the fields the driver reads (small workloads, one GPU), checks its own
+results against the oracle, and its N > 1 path runs as the driver launches it (two ranks on the one GPU, gloo)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -8,18 +10,25 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _one_line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    return d
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--reads', '9000', '--samples', '900', '--steps', '3',
                           '--warmup', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
-        assert k in d, k
+    d = _one_line(out)
+    assert 'cpu_baseline' in d
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
     assert d['unit'] == 'reads/s' and d['scaling'] == 'weak' and d['dtype'] == 'f64' and d['vs_baseline'] is None
     assert 'workload' in d['config'] and d['config']['called_ok'] == 9000
@@ -28,5 +37,51 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 'traffic' in r
     assert r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert r['launches_per_step'] >= 2 and r['launch_ms'] > 0
+    # no reported kernel time exceeds the step: the fill figure is a union of launch intervals
+    assert r['fill_union_ms_per_step'] <= d['ms_per_step'] * 1.001
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'reads/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
+    v = d['verified']
+    assert v['reads'] >= 256 and v['mismatches'] == 0
+    assert d['valu_roofline']['counters_from'].startswith('profiles/')
+
+
+@pytest.mark.parametrize('workload', ['cfg1', 'cfg5'])
+def test_bench_other_workloads_keep_the_contract(workload):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--reads', '1500', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    d = _one_line(out)
+    assert d['config']['name'] == workload and d['config']['called_ok'] == 1500
+    assert d['verified']['mismatches'] == 0 and d['verified']['reads'] > 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_two_ranks_as_the_driver_launches_it(scaling):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: fresh child processes (this process never
+    touches the GPU), both ranks on the one card, gloo instead of RCCL (one GPU cannot host two RCCL ranks)."""
+    env = dict(os.environ, WARPSTR_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    reads = 6000 if scaling == 'weak' else 9001  # strong: an odd total, so the shards differ in size
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--reads', str(reads), '--samples', '900', '--scaling', scaling, '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _one_line(out)
+    assert d['n_gpus'] == 2 and d['scaling'] == scaling
+    assert 'all_gather' in d['config']['results_gather']
+    if scaling == 'weak':
+        assert d['config']['reads_per_gpu'] == reads and d['config']['called_ok'] == 2 * reads
+        assert abs(d['value'] - 2 * reads / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    else:
+        assert d['config']['reads_total'] == reads and d['config']['called_ok'] == reads
+        assert d['config']['reads_per_gpu'] in (reads // 2, reads // 2 + 1)
+        assert 'configs[3]' in d['config']['workload']
+        assert abs(d['value'] - reads / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert d['verified']['mismatches'] == 0

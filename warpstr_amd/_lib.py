@@ -18,7 +18,7 @@ READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_ord
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
            'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
-           'wsx_caller_last_timing', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
+           'wsx_caller_last_timing', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
 
 
 class WsxAutomaton(C.Structure):
@@ -63,13 +63,17 @@ _lib = None
 
 def _raise_hw_queue_limit():
     """The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A wsx_caller uses up to
-    five streams and the application has its own; streams that share a queue serialise behind each other's event waits,
-    which undoes the chunk overlap of pipelined calls.  Only effective before the runtime initialises, and
-    an explicit setting of the user's is kept."""
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
-
-_raise_hw_queue_limit()
+    ten streams and the application has its own; streams that share a queue serialise behind each other's event waits,
+    which undoes the chunk overlap of pipelined calls.  Called from load(), i.e. when a caller is first
+    created -- importing the package changes nothing.  Only effective before the HIP runtime initialises (nothing is
+    touched once torch has initialised it); an explicit setting of the user's is kept; WARPSTR_KEEP_HW_QUEUES=1 opts out."""
+    import sys
+    if 'GPU_MAX_HW_QUEUES' in os.environ or os.environ.get('WARPSTR_KEEP_HW_QUEUES'):
+        return
+    torch = sys.modules.get('torch')
+    if torch is not None and getattr(torch, 'cuda', None) is not None and torch.cuda.is_initialized():
+        return
+    os.environ['GPU_MAX_HW_QUEUES'] = '8'
 
 
 def _share_torch_hip_runtime():
@@ -102,6 +106,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    _raise_hw_queue_limit()
     _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(f'{LIB_PATH} not found: build it with `python -m warpstr_amd.build` '
@@ -127,6 +132,7 @@ def load():
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.wsx_caller_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_double)]
+    lib.wsx_caller_fill_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.wsx_locate_flanks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.wsx_moves_to_raw.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

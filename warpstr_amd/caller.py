@@ -248,6 +248,15 @@ class HipCaller:
                    'wsx_caller_last_timing')
         return dict(dp_kernel_ms=dp.value, dp_launches=nl.value, total_ms=tot.value)
 
+    def fill_intervals(self):
+        """(begin_ms, end_ms, reads) of every fill launch behind last_timing(), relative to the start of the timed region."""
+        n = C.c_int32()
+        _lib.check(self.lib.wsx_caller_fill_intervals(self.handle, None, None, None, 0, C.byref(n)), 'wsx_caller_fill_intervals')
+        b, e, r = np.zeros(n.value), np.zeros(n.value), np.zeros(n.value, np.int32)
+        _lib.check(self.lib.wsx_caller_fill_intervals(self.handle, _lib.ptr(b), _lib.ptr(e), _lib.ptr(r), n.value, C.byref(n)),
+                   'wsx_caller_fill_intervals')
+        return b, e, r
+
 
 def sequence_from_trace(table: AutomatonTable, flank_length: int, trace: np.ndarray, reverse: bool) -> str:
     """WarpSTR._get_sequence (src/caller/caller.py:178-187): last base of every visited state, flanks

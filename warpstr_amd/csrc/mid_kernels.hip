@@ -15,7 +15,7 @@
 // Parallelisation: flat kernels, no serialised phases (see the kernel list further down):
 //   run_stats_kernel   thread per run             borders_kernel   wavefront per read
 //   tstat_kernel       thread per sample          chunk_kernel     thread per (read, chunk)
-//   sort_kernel        wavefront per read         fit_kernel       thread per read (sequential Givens recurrence)
+//   sort_kernel        wavefront per read         fit_kernel       quad of lanes per read (pipelined Givens recurrence)
 //   eval_kernel        thread per sample (de Boor evaluation, 6 divisions)
 #include <algorithm>
 #include <cstdlib>
@@ -912,11 +912,31 @@ __device__ __forceinline__ void rota(double c, double s, double &x, double &y)
     x = c * stor1 - s * stor2;
 }
 
+// A double from another lane of the same quad (DPP quad_perm: no LDS, two 32-bit moves).
+template <int CTRL>
+__device__ __forceinline__ double quad_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kQuadFromLeft = 0x90; // quad_perm [0,0,1,2]: lane j takes lane j-1's value (lane 0 keeps its own)
+#define WSX_QUAD_BCAST(k) ((k) * 0x55)
+
 // fpcurf (iopt = 0, k = 3, s = m, unit weights) restricted to its first iteration, + fpback.
+// The observation rows go through the 4x4 banded triangle one after the other, and a row is rotated into triangle row
+// 1, then 2, 3, 4 -- but rotating into row j touches nothing except row j of the triangle and the observation row itself.
+// So the four rotations are a PIPELINE: lane j of a quad owns triangle row j+1 (diagonal, up to three off-diagonals,
+// right-hand side) and at step t rotates point t-j into it, then hands the point's remaining entries to lane j+1 (DPP).
+// Every value sees the same operations in the same order as in the one-thread recurrence (bit-identical results); the
+// dependent chain per point shrinks from four Givens set-ups (each a division, a square root and two more divisions) to
+// one, and a read takes 4 lanes instead of 1 thread, so small launches spread over four times as many wavefronts.
 __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 {
-    const int lr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lr >= a.n_reads) return;
+    const int j = threadIdx.x & 3;
+    const int lr = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (lr >= a.n_reads) return; // whole quads leave together
     if (a.status[lr] != 0) return;
     const int r = a.first_read + lr;
     const long long off = a.offsets[r] - a.base_off;
@@ -924,58 +944,61 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     const double *x = a.fit_x + off, *y = a.fit_y + off;
     const double xb = x[0], xe = x[m - 1];
     if (!(xb < xe)) {
-        a.status[lr] = WSX_READ_FIT_ORDER;
+        if (j == 0) a.status[lr] = WSX_READ_FIT_ORDER;
         return;
     }
     const double den = xe - xb, rden = wsx_bspl_rden(den);
-    // banded upper-triangular A (4x4, row j: a[j][1..4]) and right-hand side z
-    double A11 = 0, A12 = 0, A13 = 0, A14 = 0, A21 = 0, A22 = 0, A23 = 0, A31 = 0, A32 = 0, A41 = 0;
-    double z1 = 0, z2 = 0, z3 = 0, z4 = 0, fp = 0.0;
-    double xn = x[0], yn = y[0]; // the next point is fetched while the current one goes through its four rotations
-    for (int it = 0; it < m; it++) {
+    // this lane's triangle row: diagonal, off-diagonals (absent ones stay 0: rotating zeros gives zeros), right-hand side
+    double dg = 0, o0 = 0, o1 = 0, o2 = 0, z = 0, fp = 0.0;
+    // what the lane to the left handed over at the end of the previous step
+    double piv_in = 0, h0_in = 0, h1_in = 0, h2_in = 0, yi_in = 0;
+    double xn = x[0], yn = y[0]; // the next point is fetched while the current one is in the pipeline
+    for (int t = 0; t < m + 3; t++) {
         const double xc = xn, yc = yn;
-        if (it + 1 < m) {
-            xn = x[it + 1];
-            yn = y[it + 1];
+        if (t + 1 < m) {
+            xn = x[t + 1];
+            yn = y[t + 1];
         }
         double h[5];
-        bspl4(xb, xe, den, rden, xc, h);
-        double yi = yc * 1.0;
-        h[1] = h[1] * 1.0;
-        h[2] = h[2] * 1.0;
-        h[3] = h[3] * 1.0;
-        h[4] = h[4] * 1.0;
-        double c, s;
-        // i = 1 -> row 1
-        if (h[1] != 0.0) {
-            givens(h[1], A11, c, s);
-            rota(c, s, yi, z1);
-            rota(c, s, h[2], A12);
-            rota(c, s, h[3], A13);
-            rota(c, s, h[4], A14);
+        bspl4(xb, xe, den, rden, xc, h); // (used by lane 0 only)
+        double piv = piv_in, h0 = h0_in, h1 = h1_in, h2 = h2_in, yi = yi_in;
+        if (j == 0) {
+            yi = yc * 1.0; // unit weights
+            piv = h[1] * 1.0;
+            h0 = h[2] * 1.0;
+            h1 = h[3] * 1.0;
+            h2 = h[4] * 1.0;
         }
-        if (h[2] != 0.0) {
-            givens(h[2], A21, c, s);
-            rota(c, s, yi, z2);
-            rota(c, s, h[3], A22);
-            rota(c, s, h[4], A23);
+        const bool valid = t - j >= 0 && t - j < m;
+        if (valid && piv != 0.0) {
+            double c, s;
+            givens(piv, dg, c, s);
+            rota(c, s, yi, z);
+            rota(c, s, h0, o0);
+            rota(c, s, h1, o1);
+            rota(c, s, h2, o2);
         }
-        if (h[3] != 0.0) {
-            givens(h[3], A31, c, s);
-            rota(c, s, yi, z3);
-            rota(c, s, h[4], A32);
-        }
-        if (h[4] != 0.0) {
-            givens(h[4], A41, c, s);
-            rota(c, s, yi, z4);
-        }
-        fp = fp + yi * yi;
+        if (valid && j == 3) fp = fp + yi * yi;
+        piv_in = quad_f64<kQuadFromLeft>(h0);
+        h0_in = quad_f64<kQuadFromLeft>(h1);
+        h1_in = quad_f64<kQuadFromLeft>(h2);
+        h2_in = 0.0;
+        yi_in = quad_f64<kQuadFromLeft>(yi);
     }
+    fp = quad_f64<WSX_QUAD_BCAST(3)>(fp);
     if (!(fp < (double)m)) {
-        a.status[lr] = WSX_READ_FIT_SMOOTH;
+        if (j == 0) a.status[lr] = WSX_READ_FIT_SMOOTH;
         return;
     }
-    // fpback (n = 4, bandwidth 4)
+    // fpback (n = 4, bandwidth 4): every lane of the quad evaluates it on the gathered triangle
+    const double A11 = quad_f64<WSX_QUAD_BCAST(0)>(dg), A12 = quad_f64<WSX_QUAD_BCAST(0)>(o0),
+                 A13 = quad_f64<WSX_QUAD_BCAST(0)>(o1), A14 = quad_f64<WSX_QUAD_BCAST(0)>(o2),
+                 z1 = quad_f64<WSX_QUAD_BCAST(0)>(z);
+    const double A21 = quad_f64<WSX_QUAD_BCAST(1)>(dg), A22 = quad_f64<WSX_QUAD_BCAST(1)>(o0),
+                 A23 = quad_f64<WSX_QUAD_BCAST(1)>(o1), z2 = quad_f64<WSX_QUAD_BCAST(1)>(z);
+    const double A31 = quad_f64<WSX_QUAD_BCAST(2)>(dg), A32 = quad_f64<WSX_QUAD_BCAST(2)>(o0),
+                 z3 = quad_f64<WSX_QUAD_BCAST(2)>(z);
+    const double A41 = quad_f64<WSX_QUAD_BCAST(3)>(dg), z4 = quad_f64<WSX_QUAD_BCAST(3)>(z);
     const double c4 = z4 / A41;
     const double c3 = (z3 - c4 * A32) / A31;
     double st = z2;
@@ -987,6 +1010,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     st = st - c3 * A13;
     st = st - c4 * A14;
     const double c1 = st / A11;
+    if (j != 0) return;
     double *co = a.coef + (size_t)lr * 6;
     co[0] = xb;
     co[1] = xe;
@@ -1052,7 +1076,7 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s)
 {
     if (a.n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fit_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(fit_kernel, dim3((a.n_reads + 15) / 16), dim3(64), 0, s, a); // a quad of lanes per read
     return hipGetLastError();
 }
 

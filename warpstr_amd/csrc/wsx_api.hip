@@ -207,19 +207,24 @@ struct wsx_caller {
     } work[WSX_MAX_STREAMS];
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
-    int n_streams = 4;
+    int n_streams = 8;        // streams / work sets the handle may use
+    int streams_per_call = 4; // chunks of one call that run side by side
     // offsets / automaton ids / launch order of a call: device copy + pinned staging (caller buffers are not kept).
     // Two slots: pipelined calls alternate, so that call k+1 is prepared and enqueued while call k still runs.
-    DeviceBuf meta[2];
-    void *pinned[2] = {nullptr, nullptr};
-    size_t pinned_cap[2] = {0, 0};
-    hipEvent_t ev_meta[2] = {nullptr, nullptr}; // recorded when the call that used the slot has finished
+    static constexpr int kMetaSlots = 4;
+    DeviceBuf meta[kMetaSlots];
+    void *pinned[kMetaSlots] = {};
+    size_t pinned_cap[kMetaSlots] = {};
+    hipEvent_t ev_meta[kMetaSlots] = {}; // recorded when the call that used the slot has finished
+    int in_flight = 2;                    // pipelined calls the host may run ahead of the device (<= kMetaSlots)
     bool pipelined = false;                     // wsx_caller_set_pipelined
     uint64_t call_seq = 0;
+    int rot = 0; // pipelined calls with fewer chunks than streams: the first work set / stream of the next call
     hipStream_t join_st = nullptr; // pipelined calls end here instead of on the handle's stream
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_events;
+    std::vector<int32_t> dp_reads; // reads of the fill launch between the pair
     size_t dp_events_used = 0;
     bool timing_valid = false;
     bool timing_window = false; // wsx_caller_timing_window: the fill events of successive calls accumulate
@@ -260,16 +265,18 @@ struct ChunkPlan {
     int max_T;
 };
 
-int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b)
+int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b, int32_t reads)
 {
     if (c->dp_events_used == c->dp_events.size()) {
         hipEvent_t x, y;
         HIPCHK(hipEventCreate(&x));
         HIPCHK(hipEventCreate(&y));
         c->dp_events.push_back({x, y});
+        c->dp_reads.push_back(0);
     }
     *a = c->dp_events[c->dp_events_used].first;
     *b = c->dp_events[c->dp_events_used].second;
+    c->dp_reads[c->dp_events_used] = reads;
     c->dp_events_used++;
     return WSX_SUCCESS;
 }
@@ -504,6 +511,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_joins[0], hipEventDisableTiming));
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
+    if (const char *e = getenv("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
+    if (const char *e = getenv("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
     for (int w = 1; w < c->n_streams; w++) {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
@@ -526,7 +535,8 @@ void wsx_caller_destroy(wsx_caller *c)
     c->ring_up.release();
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
-    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->meta[0], &c->meta[1]}) b->release();
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
+    for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
         for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
@@ -699,7 +709,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // chunks follow this call's on every internal stream without a gap; wsx_caller_join orders a consumer after it.
     const bool pipe = c->pipelined && !host;
     if (c->pipelined && host) HIPCHK(hipStreamWaitEvent(st, c->ev_end, 0));
-    const int slot = pipe ? (int)(c->call_seq++ & 1) : 0;
+    const int slot = pipe ? (int)(c->call_seq++ % (uint64_t)c->in_flight) : 0;
     const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
                                       io.traces.seq1 || io.traces.seq2);
     if (full && (io.traces.seq1 || io.traces.seq2) && !c->have_bases) {
@@ -762,14 +772,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // a second round of chunks per stream only pays from ~200k reads on, or when reads are long (their serial stages
     // then last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.
     // WSX_CHUNKS overrides the split count (tuning knob).
+    const int spc = std::min(c->n_streams, c->streams_per_call);
     if (chunks.size() == 1 && n >= 4096) {
-        int want = n >= 8192 ? c->n_streams : 2;
+        int want = n >= 8192 ? spc : 2;
         if (n >= 32768) {
             const bool long_reads = chunks[0].samples / n >= 4096;
-            const int64_t per_round = (int64_t)25000 * c->n_streams;
-            want = c->n_streams * ((long_reads || 2 * n >= 3 * per_round) ? 2 : 1);
+            const int64_t per_round = (int64_t)25000 * spc;
+            want = spc * ((long_reads || 2 * n >= 3 * per_round) ? 2 : 1);
         }
-        if (c->n_streams == 1) want = 1;
+        if (spc == 1) want = 1;
         if (const char *e = getenv("WSX_CHUNKS")) want = std::max(1, atoi(e));
         const ChunkPlan whole = chunks[0];
         chunks.clear();
@@ -798,8 +809,18 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
                        3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
-    const int n_work = (int)std::min<size_t>(chunks.size(), (size_t)c->n_streams);
-    for (int w = 0; w < n_work; w++) {
+    const int n_work = (int)std::min<size_t>(chunks.size(), (size_t)spc);
+    // Work set (and stream) of chunk ci: (rot + ci) mod n_streams.  A pipelined call with fewer chunks than the handle has
+    // streams starts where the previous call ended, so that two back-to-back calls run on disjoint streams side by side
+    // (small batches: one call's kernels are too few wavefronts to fill the chip, and its stages depend on each other).
+    // (big calls fill the chip by themselves and stay on the first streams_per_call sets: measured in
+    // profiles/r02_stream_share_sweep.log)
+    const bool small_call = (io.offsets[n] - io.offsets[0]) < (int64_t)80 << 20;
+    const int rot = (pipe && small_call && n_work < c->n_streams) ? c->rot % c->n_streams : 0;
+    if (pipe) c->rot = (rot + n_work) % c->n_streams;
+    auto wset = [&](size_t ci) -> int { return (rot + (int)(ci % n_work)) % c->n_streams; };
+    for (int k = 0; k < n_work; k++) {
+        const int w = wset(k);
         HIPCHK(c->work[w].samples.ensure(smp_bytes));
         HIPCHK(c->work[w].reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
         if (full && c->prm.reps_as_one)
@@ -823,8 +844,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             if (uvar[u].same(v)) return uoff[u];
         return 0;
     };
-    for (int w = 0; w < n_work; w++) HIPCHK(c->work[w].bp.ensure(bp_words * 4));
-    for (int w = 0; w < n_work && host; w++) {
+    for (int k = 0; k < n_work; k++) HIPCHK(c->work[wset(k)].bp.ensure(bp_words * 4));
+    for (int k = 0; k < n_work && host; k++) {
+        const int w = wset(k);
         HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
         size_t so = align_up(S1 * 2) * 2 + align_up(S1 * 8) + 3 * align_up(S1) + align_up(R1 * 8) + align_up(R1 * 4) +
                     align_up(R1 * (size_t)std::max(io.last_row_stride, 1) * 8);
@@ -892,7 +914,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     auto prepare = [&](size_t ci, hipStream_t s) -> int {
         Ctx &x = ctxs[ci];
         x.ch = chunks[ci];
-        x.W = &c->work[ci % n_work];
+        x.W = &c->work[wset(ci)];
         wsx_caller::Work &W = *x.W;
         const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
         Carver sc(W.samples.p);
@@ -1046,7 +1068,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.status = status;
             pa.check_status = check_status;
             hipEvent_t e0, e1;
-            int rc2 = get_event_pair(c, &e0, &e1);
+            int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
             HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].generic, s));
@@ -1157,13 +1179,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     {
         // ---- chunks rotate over the streams, each chunk's stages in order on its stream, staggered by one fill --------
-        if (n_work > 1) {
+        auto stream_of = [&](int w) -> hipStream_t { return w ? c->aux[w] : main_st; };
+        if (n_work > 1 || rot != 0) {
             HIPCHK(hipEventRecord(c->ev_fork, main_st));
-            for (int w = 1; w < n_work; w++) HIPCHK(hipStreamWaitEvent(c->aux[w], c->ev_fork, 0));
+            for (int k = 0; k < n_work; k++)
+                if (wset(k) != 0) HIPCHK(hipStreamWaitEvent(c->aux[wset(k)], c->ev_fork, 0));
         }
         for (size_t ci = 0; ci < chunks.size(); ci++) {
             Ctx &x = ctxs[ci];
-            st = (ci % n_work) ? c->aux[ci % n_work] : main_st;
+            st = stream_of(wset(ci));
             // this work set's staging buffers were last used n_work chunks ago on the same stream (host copies)
             if (host && ci >= (size_t)n_work) HIPCHK(hipStreamSynchronize(st));
             if ((rc = prepare(ci, st))) return rc;
@@ -1176,7 +1200,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 hipEvent_t e;
                 if ((rc = sched_event(&e))) return rc;
                 HIPCHK(hipEventRecord(e, st));
-                HIPCHK(hipStreamWaitEvent(c->aux[ci + 1], e, 0));
+                HIPCHK(hipStreamWaitEvent(stream_of(wset(ci + 1)), e, 0));
             }
             if ((rc = stage_m1(x, st)) || (rc = stage_f2(x, st)) || (rc = stage_m2(x, st))) return rc;
         }
@@ -1186,7 +1210,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             HIPCHK(hipEventRecord(c->ev_joins[0], main_st));
             HIPCHK(hipStreamWaitEvent(end_st, c->ev_joins[0], 0));
         }
-        for (int w = 1; w < n_work; w++) {
+        for (int k = 0; k < n_work; k++) {
+            const int w = wset(k);
+            if (w == 0) continue; // the handle's stream: joined above (pipelined) or the end stream itself
             HIPCHK(hipEventRecord(c->ev_joins[w], c->aux[w]));
             HIPCHK(hipStreamWaitEvent(end_st, c->ev_joins[w], 0));
         }
@@ -1266,6 +1292,29 @@ int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_laun
     if (dp_kernel_ms) *dp_kernel_ms = dp;
     if (dp_launches) *dp_launches = (int32_t)c->dp_events_used;
     if (total_ms) *total_ms = tot;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_fill_intervals(wsx_caller *c, double *begin_ms, double *end_ms, int32_t *reads, int32_t capacity,
+                              int32_t *n_out)
+{
+    if (!c || !n_out || capacity < 0) return WSX_ERR_INVALID;
+    if (!c->timing_valid) {
+        g_err = "no completed batch to time";
+        return WSX_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_end));
+    const hipEvent_t origin = (c->timing_window && c->window_open) ? c->ev_window : c->ev_begin;
+    *n_out = (int32_t)c->dp_events_used;
+    for (size_t i = 0; i < c->dp_events_used && (int32_t)i < capacity; i++) {
+        float b = 0.f, e = 0.f;
+        HIPCHK(hipEventElapsedTime(&b, origin, c->dp_events[i].first));
+        HIPCHK(hipEventElapsedTime(&e, origin, c->dp_events[i].second));
+        if (begin_ms) begin_ms[i] = b;
+        if (end_ms) end_ms[i] = e;
+        if (reads) reads[i] = c->dp_reads[i];
+    }
     return WSX_SUCCESS;
 }
 
