@@ -376,7 +376,7 @@ def main():
     hip.synchronize()
     torch.cuda.synchronize()
     ab, ae, _ = hip.fill_intervals()
-    hip.set_streams(8)
+    hip.set_streams(4)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -142,9 +142,9 @@ void wsx_caller_destroy(wsx_caller *c);
 int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
 
 /*
- * Number of HIP streams (and workspace sets) the handle may use (1..8, default 8; 1 = everything on the handle's
- * stream).  One call spreads its chunks over at most four of them; pipelined calls of small batches take turns on the
- * rest, so that two calls run side by side.
+ * Number of HIP streams (and workspace sets) the handle may use (1..8, default 4; 1 = everything on the handle's
+ * stream).  A big call spreads its chunks over four of them; small pipelined calls take two each and alternate, so that
+ * consecutive calls run side by side.
  */
 int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
 

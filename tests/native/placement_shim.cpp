@@ -1,0 +1,20 @@
+// Test shim: exposes warpstr_amd/csrc/wsx_place.h (host-only C++) to the CPU test suite through a C function.
+#include "../../warpstr_amd/csrc/wsx_place.h"
+
+extern "C" int wsx_test_place(int S, const int32_t *pred_ptr, const int32_t *pred_idx, int K, int F, int FL, int want_low8,
+                              uint16_t *pos, uint16_t *state_at, uint16_t *wslot, int *low8, int *identity, int *plain_conflicts)
+{
+    const WsxPlacement p = wsx_place_states(S, pred_ptr, pred_idx, K, F, FL, want_low8 != 0);
+    for (int j = 0; j < S; j++) pos[j] = p.pos[j];
+    for (int q = 0; q < K * 64; q++) {
+        state_at[q] = p.state_at[q];
+        wslot[q] = p.wslot[q];
+    }
+    *low8 = p.low8;
+    *identity = p.identity;
+    std::vector<uint16_t> ipos(S), iat(K * 64, 0xFFFF), iw(K * 64);
+    for (int j = 0; j < S; j++) ipos[j] = iat[j] = (uint16_t)j;
+    for (int q = 0; q < K * 64; q++) iw[q] = (uint16_t)q;
+    *plain_conflicts = wsx_place_detail::conflict_cycles(S, pred_ptr, pred_idx, K, F, F, ipos, iat, iw);
+    return p.conflict_cycles;
+}

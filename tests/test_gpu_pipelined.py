@@ -93,10 +93,12 @@ def test_timing_window_covers_every_call():
     dsig = torch.from_numpy(sig).to(dev)
     res = torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     hip = HipCaller([locus.template, locus.reverse], [16, 16], stream=torch.cuda.current_stream().cuda_stream)
+    hip.set_pipelined(True)  # (a small pipelined call is cut into fewer chunks than a stream-ordered one)
     hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
     one = hip.last_timing()
     assert one['dp_launches'] >= 2 and one['dp_kernel_ms'] > 0 and one['total_ms'] >= one['dp_kernel_ms'] / one['dp_launches']
-    hip.set_pipelined(True)
+    b, e, r = hip.fill_intervals()
+    assert len(b) == one['dp_launches'] and (e > b).all() and r.sum() == 2 * len(aut)  # two passes over every read
     hip.timing_window(True)
     for _ in range(5):
         hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())

@@ -1,0 +1,99 @@
+"""The state placement of the register-resident fill (warpstr_amd/csrc/wsx_place.h, host-only C++): compiled here with
+g++ and checked for validity (a permutation; states with many predecessors in slot 0 / lanes 0..7; distinct LDS slots)
+and for what it is for -- LDS bank conflicts per DP row, counted by an independent Python model."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from warpstr_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def shim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp('place') / 'libplace.so')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-Wall', '-Werror', '-shared', '-fPIC', '-o', so,
+                           os.path.join(ROOT, 'tests', 'native', 'placement_shim.cpp')])
+    return C.CDLL(so)
+
+
+def place(lib, t, K, F, FL, low8):
+    S = t.n_states
+    pp, pi = np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32)
+    pos, sa, ws = np.zeros(S, np.uint16), np.zeros(K * 64, np.uint16), np.zeros(K * 64, np.uint16)
+    l8, idn, plain = C.c_int(), C.c_int(), C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    c = lib.wsx_test_place(S, p(pp), p(pi), K, F, FL, int(low8), p(pos), p(sa), p(ws), C.byref(l8), C.byref(idn), C.byref(plain))
+    return c, pos, sa, ws, bool(l8.value), plain.value
+
+
+def model_conflicts(t, K, F, FL, pos, sa, ws):
+    """Extra LDS passes per row under the rule measured on gfx950 (scripts/exp_ldsbank.hip, profiles/r02_lds_bank_rule.log):
+    ds_read_b64 -- per slot, candidate and half-wave the largest number of distinct export slots that share a bank pair
+    (slot mod 32), minus one; ds_write_b64 -- the same per 16 lanes with slots taken modulo 16 (idle lanes write too)."""
+    pp, pi = t.pred_ptr, t.pred_idx
+    total = 0
+    for k in range(K):
+        for q in range(4):
+            on = {}
+            for lane in range(q * 16, q * 16 + 16):
+                slot = int(ws[k * 64 + lane])
+                on.setdefault(slot & 15, set()).add(slot)
+            total += max(len(v) for v in on.values()) - 1
+        for g in range(2):
+            for f in range(F if k == 0 else FL):
+                on = {}
+                for lane in range(g * 32, g * 32 + 32):
+                    j = int(sa[k * 64 + lane])
+                    if j != 0xFFFF and pp[j + 1] - pp[j] > f:
+                        slot = int(ws[pos[pi[pp[j] + f]]])
+                        on.setdefault(slot & 31, set()).add(slot)
+                total += max([len(v) for v in on.values()] or [1]) - 1
+    return total
+
+
+CASES = [('(AAAT)', 110, 1, None), ('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, 64), ('(AGC)', 16, 11, None), ('(GGCCCC)', 61, 13, None),
+         ('((CAGG){CAGM})(CAGA)(CA)', 40, 11, None), ('(CAG)CAACAG(CCG)', 54, 12, None), ('(NGC)', 24, 1, None),
+         ('(CAG)', 30, 5, None), ('(CTG)CTA(CTG)', 18, 9, None), ('(GAA)', 61, 17, None)]
+
+
+@pytest.mark.parametrize('pattern,fl,seed,max_states', CASES)
+def test_placement_is_valid_and_not_worse_than_the_natural_order(shim, pattern, fl, seed, max_states):
+    locus = synth.make_locus(pattern, fl, seed, max_states=max_states)
+    for t in (locus.template, locus.reverse):
+        S = t.n_states
+        K = (S + 63) // 64
+        fan = np.diff(t.pred_ptr)
+        F = max(2, int(fan.max()))
+        FL = F
+        if K > 1:  # as wsx_caller_create chooses it
+            FL = 1 if (fan >= 2).sum() <= 64 else (2 if F > 2 and (fan > 2).sum() <= 64 else F)
+        c, pos, sa, ws, low8, plain = place(shim, t, K, F, FL, K == 1 and F == 2)
+        assert len(set(pos.tolist())) == S and all(sa[pos[j]] == j for j in range(S))
+        assert (sa != 0xFFFF).sum() == S
+        assert len(set(ws.tolist())) == K * 64 and ws.max() < K * 64          # every lane owns an export slot
+        if K > 1:
+            assert all(ws[q] == q for q in range(K * 64))                       # several slots: export slot = position
+            assert all(pos[j] < 64 for j in range(S) if fan[j] > FL)            # many predecessors: slot 0
+        if low8:
+            assert all(pos[j] < 8 for j in range(S) if fan[j] >= 2)             # packed rows: their bits form one byte
+        assert c == model_conflicts(t, K, F, FL, pos, sa, ws)
+        assert model_conflicts(t, K, F, FL, pos, sa, ws) <= 3
+        if FL == F:
+            assert c <= plain
+
+
+def test_headline_and_upstream_test_case_are_conflict_free(shim):
+    """configs[2] (packed rows) and the (AAAT) flank-110 automaton of the upstream test case: no bank conflict at all."""
+    head = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    for t in (head.template, head.reverse):
+        c, pos, sa, ws, low8, _ = place(shim, t, 1, 2, 2, True)
+        assert c == 0 and low8
+    aaat = synth.make_locus('(AAAT)', 110, 1)
+    for t in (aaat.template, aaat.reverse):
+        c, *_ = place(shim, t, 4, 2, 1, False)
+        assert c == 0

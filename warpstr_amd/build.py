@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['wsx_api.hip', 'dtw_kernels.hip', 'mid_kernels.hip', 'wsx_prep.hip', 'flank_kernels.hip']
-HEADERS = ['wsx_device.h', os.path.join('..', '..', 'include', 'warpstr_hip.h')]
+HEADERS = ['wsx_device.h', 'wsx_place.h', os.path.join('..', '..', 'include', 'warpstr_hip.h')]
 LIB = os.path.join(HERE, 'libwarpstr_hip.so')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fgpu-rdc' if False else '-fno-gpu-rdc']

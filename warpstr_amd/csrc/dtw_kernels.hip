@@ -84,6 +84,15 @@ __device__ __forceinline__ uint64_t *mask_rows(const PassArgs &a, long long off,
     return (uint64_t *)a.bp + ((((size_t)off + (size_t)lr) * (size_t)NM + 1) & ~(size_t)1);
 }
 
+// Packed mask rows (PK; single-slot automata with two candidates whose states with two predecessors all sit in lanes 0..7,
+// wsx_place.h): the second candidate's mask of a row is then one byte.  A read's rows are stored in groups of 16: sixteen
+// 64-bit first-candidate masks followed by two 64-bit words that hold the sixteen bytes (row r of the group in byte r) --
+// 144 bytes, so groups stay 16-byte aligned; 9 bytes per row instead of 16.
+__device__ __forceinline__ uint64_t *mask_rows_pk(const PassArgs &a, long long off, int lr)
+{
+    return (uint64_t *)a.bp + ((size_t)(off / 16) + (size_t)lr) * 18;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident fill (see file header), for min_values_per_state M in {3, 4, 5}.
 // ------------------------------------------------------------------------------------------------
@@ -176,7 +185,7 @@ __host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f :
 // FL < F ("split"): only slot 0 considers F predecessors per state, the other slots FL (the host places every state
 // with more than FL predecessors in slot 0; such states are few: loop entries, IUPAC alternatives).  FL == F: uniform.
 template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT>
-__device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int lane, double snext,
+__device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int wl, double snext,
                                        uint64_t (&mk)[F + (K - 1) * FL], const uint64_t (&cutm)[K])
 {
     constexpr int EXW = K * 64 + 32;
@@ -221,7 +230,8 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
         st.d[k] = best;
         st.acur[k] = an;
         // row i+2 masked (back = M-1): successors need the (M-2)-deep sum, else the (M-1)-deep one
-        ex[wbuf + k * 64 + lane] = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
+        // (wl: the lane's export slot -- its lane number, or for single-slot automata the slot wsx_place.h gave its state)
+        ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
 
     }
     __builtin_amdgcn_wave_barrier();
@@ -233,13 +243,14 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int l
 #define WSX_FILL_OCC
 #endif
 
-template <int M, int K, int F, int FL>
+template <int M, int K, int F, int FL, bool PK>
 #ifndef WSX_FILL_WPB
 #define WSX_FILL_WPB 4 // wavefronts (= reads) per workgroup
 #endif
 __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
+    static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
     static_assert(M >= 3, "the one-row-ahead export needs min_values_per_state >= 3");
     constexpr int NM = F + (K - 1) * FL; // back-pointer masks per row
     constexpr int EXW = K * 64 + 32; // export slots per buffer (+32 slots that hold +inf, one per bank pair)
@@ -268,7 +279,8 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
     }
     const double *sig = a.signal + off;
     double *ex = lds + wib * WLDS;
-    uint64_t *bp = mask_rows(a, off, lr, NM); // row i's masks at bp[i*NM ..]
+    uint64_t *bp = PK ? mask_rows_pk(a, off, lr) : mask_rows(a, off, lr, NM); // row i's masks at bp[i*NM ..] (PK: see above)
+    const int wl = K == 1 ? (int)A.wslot[lane] : lane; // export slot of this lane
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     const int nmw = cdiv(T, 32);
 
@@ -319,8 +331,8 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
         st.g[k][1] = d0 + fabs(st.acur[k]);
 #pragma unroll
         for (int q = 2; q < M; q++) st.g[k][q] = kInf;
-        ex[0 * EXW + k * 64 + lane] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
-        ex[1 * EXW + k * 64 + lane] = kInf;
+        ex[0 * EXW + (K == 1 ? wl : k * 64 + lane)] = kInf; // E(2), E(1): never used (rows < M are forced to inf) but defined
+        ex[1 * EXW + (K == 1 ? wl : k * 64 + lane)] = kInf;
 #pragma unroll
         for (int f = 0; f < F; f++) {
             st.e0[k][f] = kInf;
@@ -339,6 +351,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
     auto sample = [&](int q) -> double { return cs[q < T ? q : last]; };
     auto clampi = [&](int x) { return x < T ? x : last; };
     double warm = sig[clampi(64 + lane)];
+    uint64_t acc = 0; // packed rows: the bytes of the current half group (rows 8h .. 8h+7) collected so far
 
     for (int b = 0; b * 64 <= last; b++) {
         asm volatile("" ::"v"(warm)); // the previous block's warm-up load has landed long ago: no stall
@@ -366,8 +379,27 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
             uint64_t mk[NM];
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext, mk, cutm);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, wl, snext, mk, cutm);
             if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
+        };
+        // packed rows, one row: the first mask goes to its place in the group of 16, the second one's byte joins `acc`,
+        // which leaves for HBM when the eighth row of its half group has been added
+        auto row_pk = [&](auto par, auto forced, auto cut, auto msk, int r, double snext) {
+            constexpr int PAR = decltype(par)::value;
+            constexpr bool FORCED = decltype(forced)::value;
+            constexpr bool CUT = decltype(cut)::value;
+            constexpr bool MROW = decltype(msk)::value;
+            uint64_t mk[NM];
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, wl, snext, mk, cutm);
+            uint64_t *g16 = bp + (size_t)((unsigned)r >> 4) * 18;
+            if (!FORCED) {
+                store_mask<0>(mk[0], g16 + (r & 15));
+                acc |= mk[NM - 1] << ((r & 7) * 8); // bits above 7 are never set: those lanes have one predecessor
+            }
+            if ((r & 7) == 7) {
+                store_mask<0>(acc, g16 + 16 + ((r >> 3) & 1));
+                acc = 0;
+            }
         };
         // the same, the masks handed back instead of stored (the caller stores a whole group at once)
         auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) {
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, lane, snext, mk, cutm);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT>(st, ex, wl, snext, mk, cutm);
         };
         // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
         // 64-byte scalar load; the rows before and after such groups load theirs one by one
@@ -384,16 +416,49 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
             using P1 = std::integral_constant<int, 1>;
             using R0 = std::integral_constant<int, 0>;
             auto one = [&](int r) {
-                uint64_t *gp = bp + (size_t)(unsigned)r * NM;
-                if (r & 1) row(P1{}, forced, cut, msk, R0{}, gp, sample(r + 1));
-                else row(P0{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+                if constexpr (PK) {
+                    if (r & 1) row_pk(P1{}, forced, cut, msk, r, sample(r + 1));
+                    else row_pk(P0{}, forced, cut, msk, r, sample(r + 1));
+                } else {
+                    uint64_t *gp = bp + (size_t)(unsigned)r * NM;
+                    if (r & 1) row(P1{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+                    else row(P0{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+                }
             };
             int i = plo;
             for (; i < phi && (i & 7); i++) one(i);
             for (; i + 8 <= phi && i + 8 < T; i += 8) {
                 const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
                 uint64_t *gp = bp + (size_t)(unsigned)i * NM;
-                if constexpr (NM <= 4 && !decltype(forced)::value) {
+                if constexpr (PK && !decltype(forced)::value) {
+                    // eight aligned rows (`acc` is empty here: it was flushed after row i-1): the first masks leave as four
+                    // 16-byte scalar stores, the eight bytes as one 8-byte store -- 72 bytes instead of 128
+                    uint64_t *g16 = bp + (size_t)((unsigned)i >> 4) * 18;
+                    uint64_t m0[4][2]; // rows 2q and 2q+1 side by side: one 16-byte store
+                    uint32_t b_lo = 0, b_hi = 0;
+#define WSX_ROW(R)                                                                                                  \
+    {                                                                                                               \
+        uint64_t mk[NM];                                                                                            \
+        row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], mk);                                 \
+        m0[(R) / 2][(R) % 2] = mk[0];                                                                               \
+        if constexpr ((R) < 4) b_lo |= (uint32_t)mk[1] << (8 * (R));                                                \
+        else b_hi |= (uint32_t)mk[1] << (8 * ((R)-4));                                                             \
+    }
+                    WSX_ROW(0)
+                    WSX_ROW(1)
+                    WSX_ROW(2)
+                    WSX_ROW(3)
+                    WSX_ROW(4)
+                    WSX_ROW(5)
+                    WSX_ROW(6)
+                    WSX_ROW(7)
+#undef WSX_ROW
+                    uint64_t *gp8 = g16 + (i & 8);
+                    store_row_group<2, 4, 0>(m0, gp8);
+                    store_mask<0>(((uint64_t)b_hi << 32) | b_lo, g16 + 16 + ((i >> 3) & 1));
+                } else if constexpr (PK) {
+                    for (int q = 0; q < 8; q++) one(i + q); // (forced rows: the first four rows of a read)
+                } else if constexpr (NM <= 4 && !decltype(forced)::value) {
                     // The scalar stores of G rows leave together (G = as many rows as fit ~32 SGPRs of masks; single-slot
                     // automata: with more masks per row the grouping bought nothing).  A scalar
                     // store counts on the same counter as the LDS reads and completes out of order with them, so a store
@@ -446,6 +511,9 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(
         phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, hi);
     }
 
+    if constexpr (PK) { // the last half group of the read, if it is not complete
+        if ((T & 7) != 0) store_mask<0>(acc, bp + (size_t)((unsigned)last >> 4) * 18 + 16 + ((last >> 3) & 1));
+    }
     // ---- outputs of the fill -----------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -572,9 +640,10 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 // costs the vector ALU two instructions per candidate.  Runs are appended in reverse time order: run_state[q],
 // run_start[q]; adjacent equal states merge, matching the run-length encoding of the trace (caller.py:58-60).
 // ------------------------------------------------------------------------------------------------
-template <int K, int F, int FL>
+template <int K, int F, int FL, bool PK>
 __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 {
+    static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
     const int lane = threadIdx.x & 63;
     const int slot = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (slot >= a.n_launch) return;
@@ -588,7 +657,7 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
     const DevAutomaton &A = a.aut[a.aut_id[gm.r]];
     const int m = a.m;
     constexpr int NM = F + (K - 1) * FL;
-    const uint64_t *bp = mask_rows(a, off, lr, NM);
+    const uint64_t *bp = PK ? mask_rows_pk(a, off, lr) : mask_rows(a, off, lr, NM);
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
@@ -623,9 +692,17 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
     auto load = [&](Block &B, int b) {
         const int row = b * 64 + lane;
         const bool in = b >= 0 && row < T;
-        const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM;
+        if constexpr (PK) { // groups of 16 rows: the row's first mask, and its byte of the second one
+            const int rw = in ? row : 0;
+            const uint64_t *g16 = bp + (size_t)(rw >> 4) * 18;
+            const bool has = in && row >= m;
+            B.w[0] = has ? g16[rw & 15] : 0ull;
+            B.w[1] = has ? ((g16[16 + ((rw >> 3) & 1)] >> ((rw & 7) * 8)) & 0xffull) : 0ull;
+        } else {
+            const uint64_t *rp = bp + (size_t)(in ? row : 0) * NM;
 #pragma unroll
-        for (int e = 0; e < NM; e++) B.w[e] = (in && row >= m) ? rp[e] : 0ull; // rows < m hold no pointers
+            for (int e = 0; e < NM; e++) B.w[e] = (in && row >= m) ? rp[e] : 0ull; // rows < m hold no pointers
+        }
         B.mw = (maskw && in) ? maskw[row >> 5] : 0u;
     };
     // Walks every transition inside block cb (rows 64*cb ..), starting at row i in position q.  Returns true when the
@@ -716,19 +793,23 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 // (Tried: eight lanes fetching one read's 128-byte step together and trading pieces through LDS -- whole-line loads
 // instead of 64 lines per instruction.  7 % faster alone, 4 % slower per step: the fill it runs beside is LDS-bound.)
 // ------------------------------------------------------------------------------------------------
-template <int F>
+template <int F, bool PK>
 __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_aut)
 {
+    static_assert(!PK || F == 2, "packed mask rows: two candidates");
     constexpr int RC = F == 2 ? 8 : 4; // rows per step
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-    extern __shared__ uint64_t tb_tab[]; // [automaton][position]: the positions of its state's predecessors
+    extern __shared__ uint64_t tb_tab[]; // [automaton][position]: the positions of its state's predecessors; then the state ids
     constexpr int QD = 32; // queue depth per lane: a 16-entry chunk waiting to leave + what three steps can add (<= 3 * RC / 2)
     __shared__ uint16_t q_state[QD][64];
     __shared__ int32_t q_start[QD][64];
     const int lane = threadIdx.x;
+    uint16_t *st_tab = (uint16_t *)(tb_tab + n_aut * 64); // [automaton][position] -> state id
     for (int e = lane; e < n_aut * 64; e += 64) {
         const DevAutomaton &B = a.aut[e >> 6];
-        tb_tab[e] = B.n_states <= 64 ? B.pred4[e & 63] : 0ull;
+        const bool one_slot = B.n_states <= 64;
+        tb_tab[e] = one_slot ? B.pred4[e & 63] : 0ull;
+        st_tab[e] = (one_slot && B.state_at) ? B.state_at[e & 63] : (uint16_t)(e & 63);
     }
     __syncthreads();
     const int slot = blockIdx.x * 64 + lane;
@@ -742,15 +823,16 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
     }
     const int aid = a.aut_id[gm.r];
     const uint64_t *tab = tb_tab + aid * 64;
+    const uint16_t *stab = st_tab + aid * 64;
     const int m = a.m;
-    const uint64_t *bp = mask_rows(a, off, lr, F);
+    const uint64_t *bp = PK ? mask_rows_pk(a, off, lr) : mask_rows(a, off, lr, F);
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;
     int nr = 0;
     int nf = 0; // runs already written out (a multiple of 16)
-    auto push = [&](int state, int start) {
-        q_state[nr & (QD - 1)][lane] = (uint16_t)state;
+    auto push = [&](int position, int start) {
+        q_state[nr & (QD - 1)][lane] = stab[position];
         q_start[nr & (QD - 1)][lane] = start;
         nr++;
     };
@@ -766,7 +848,7 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
             nf += 16;
         }
     };
-    int open_state = -1, open_start = 0;
+    int open_state = -1, open_start = 0; // (positions; they turn into state ids in push)
     auto close_run = [&](int state, int start) { // the walk leaves `state`, entered at row `start`
         if (state == open_state) {
             open_start = start;
@@ -777,16 +859,26 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
         }
     };
     struct Step {
-        ull2 v[RC * F / 2]; // RC rows x F masks
-        uint32_t mw;        // the sample-mask word that covers these rows
+        ull2 v[PK ? RC / 2 : RC * F / 2]; // RC rows x F masks (packed rows: RC first masks)
+        unsigned long long pk;           // packed rows: the RC bytes of the second mask
+        uint32_t mw;                     // the sample-mask word that covers these rows
     };
     uint32_t mw_word = 0u;
     int mw_at = -1;
     auto load = [&](Step &S, int c) { // rows RC*c .. RC*c + RC-1 (c < 0: nothing)
         const int cc = c < 0 ? 0 : c;
-        const ull2 *p = (const ull2 *)(bp + (size_t)cc * (RC * F));
+        if constexpr (PK) { // half of a 16-row group: 64 bytes of first masks + its 8 bytes of the word pair behind them
+            const uint64_t *g16 = bp + (size_t)(cc >> 1) * 18;
+            const ull2 *p = (const ull2 *)(g16 + (cc & 1) * 8);
 #pragma unroll
-        for (int e = 0; e < RC * F / 2; e++) S.v[e] = p[e];
+            for (int e = 0; e < RC / 2; e++) S.v[e] = p[e];
+            S.pk = g16[16 + (cc & 1)];
+        } else {
+            const ull2 *p = (const ull2 *)(bp + (size_t)cc * (RC * F));
+#pragma unroll
+            for (int e = 0; e < RC * F / 2; e++) S.v[e] = p[e];
+            S.pk = 0ull;
+        }
         // the sample-mask word changes every 32 / RC steps only (steps are loaded in descending order)
         const int wi = (cc * RC) >> 5;
         if (maskw && wi != mw_at) {
@@ -795,7 +887,7 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
         }
         S.mw = mw_word;
     };
-    int bit = a.aut[aid].endstate; // K = 1: position = state
+    int bit = a.aut[aid].pos ? (int)a.aut[aid].pos[a.aut[aid].endstate] : a.aut[aid].endstate; // the walk's position (= lane of the fill)
     int i = T - 1;                 // rows above i are not part of the walk
     int c = i / RC;
     // three steps in registers with statically rotating roles: one is processed while the loads of the other two are in
@@ -821,16 +913,27 @@ __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_
 #pragma unroll
             for (int f = 0; f < F; f++) {
                 hf[f] = 0;
+                if (PK && f == 1) {
+                    // the second candidate's bytes: bit `bit` of byte rr -> bit rr (positions >= 8 have one predecessor)
+                    if (bit < 8) {
+                        unsigned long long t = (cur.pk >> bit) & 0x0101010101010101ull;
+                        t |= t >> 7;
+                        t |= t >> 14;
+                        t |= t >> 28;
+                        hf[f] = (uint32_t)t & 0xffu;
+                    }
+                } else {
 #pragma unroll
-                for (int rr = 0; rr < RC; rr++) {
-                    const int idx = rr * F + f;
-                    const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
-                    const uint32_t d = upper ? (uint32_t)(w >> 32) : (uint32_t)w;
-                    // bit `sh` of d lands at bit rr: one bit-field extract and one shift-or (the compiler's own choice
-                    // was shift, shift, and, or)
-                    uint32_t t;
-                    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(t) : "v"(d), "v"(sh));
-                    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(hf[f]) : "v"(t), "n"(rr), "v"(hf[f]));
+                    for (int rr = 0; rr < RC; rr++) {
+                        const int idx = PK ? rr : rr * F + f;
+                        const unsigned long long w = (idx & 1) ? cur.v[idx / 2].y : cur.v[idx / 2].x;
+                        const uint32_t d = upper ? (uint32_t)(w >> 32) : (uint32_t)w;
+                        // bit `sh` of d lands at bit rr: one bit-field extract and one shift-or (the compiler's own choice
+                        // was shift, shift, and, or)
+                        uint32_t t;
+                        asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(t) : "v"(d), "v"(sh));
+                        asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(hf[f]) : "v"(t), "n"(rr), "v"(hf[f]));
+                    }
                 }
                 h |= hf[f];
             }
@@ -959,7 +1062,7 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
     }
 }
 
-template <int M, int K, int F, int FL>
+template <int M, int K, int F, int FL, bool PK = false>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + WSX_FILL_WPB - 1) / WSX_FILL_WPB;
@@ -972,12 +1075,12 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     }();
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
-    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL>), dim3(blocks), dim3(64 * WSX_FILL_WPB), shmem, s, a);
+    hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL, PK>), dim3(blocks), dim3(64 * WSX_FILL_WPB), shmem, s, a);
     return hipGetLastError();
 }
 
 template <int M, int K>
-hipError_t launch_fill_f(const PassArgs &a, int F, int FL, hipStream_t s)
+hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, hipStream_t s)
 {
     if constexpr (K >= 2 && M == 4) { // split variants (FL < F): several slots, default min_values_per_state
         if (F == 2 && FL == 1) return launch_fill<M, K, 2, 1>(a, s);
@@ -987,6 +1090,10 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, hipStream_t s)
         if (F == 4 && FL == 2) return launch_fill<M, K, 4, 2>(a, s);
     }
     if (FL != F) return hipErrorInvalidValue;
+    if constexpr (K == 1) {
+        if (pk && F == 2) return launch_fill<M, 1, 2, 2, true>(a, s);
+    }
+    if (pk) return hipErrorInvalidValue;
     switch (F) {
     case 2: return launch_fill<M, K, 2, 2>(a, s);
     case 3: return launch_fill<M, K, 3, 3>(a, s);
@@ -996,14 +1103,14 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, hipStream_t s)
 }
 
 template <int M>
-hipError_t launch_fill_k(const PassArgs &a, int K, int F, int FL, hipStream_t s)
+hipError_t launch_fill_k(const PassArgs &a, int K, int F, int FL, bool pk, hipStream_t s)
 {
     switch (K) {
-    case 1: return launch_fill_f<M, 1>(a, F, FL, s);
-    case 2: return launch_fill_f<M, 2>(a, F, FL, s);
-    case 3: return launch_fill_f<M, 3>(a, F, FL, s);
-    case 4: return launch_fill_f<M, 4>(a, F, FL, s);
-    case 5: return launch_fill_f<M, 5>(a, F, FL, s);
+    case 1: return launch_fill_f<M, 1>(a, F, FL, pk, s);
+    case 2: return launch_fill_f<M, 2>(a, F, FL, pk, s);
+    case 3: return launch_fill_f<M, 3>(a, F, FL, pk, s);
+    case 4: return launch_fill_f<M, 4>(a, F, FL, pk, s);
+    case 5: return launch_fill_f<M, 5>(a, F, FL, pk, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1019,18 +1126,18 @@ static int fast_f(int F) { return F <= 2 ? 2 : F; }
 
 bool wsx_split_supported(int m, int K) { return m == 4 && K >= 2; }
 
-const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool generic)
+const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, bool generic)
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d>", m, K, fast_f(F), FL);
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, %s>", m, K, fast_f(F), FL, pk ? "true" : "false"); // as rocprofv3 prints it
     return buf;
 }
 
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s)
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, bool generic, hipStream_t s)
 {
 #ifdef WSX_ONLY_DEFAULT // experiment builds: just the headline variant
-    if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return launch_fill<4, 1, 2, 2>(a, s);
+    if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return pk ? launch_fill<4, 1, 2, 2, true>(a, s) : launch_fill<4, 1, 2, 2>(a, s);
     return hipErrorInvalidValue;
 #else
     if (a.n_launch <= 0) return hipSuccess;
@@ -1041,15 +1148,15 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
     }
     const int f = fast_f(F);
     switch (m) {
-    case 3: return launch_fill_k<3>(a, K, f, FL, s);
-    case 4: return launch_fill_k<4>(a, K, f, FL, s);
-    case 5: return launch_fill_k<5>(a, K, f, FL, s);
+    case 3: return launch_fill_k<3>(a, K, f, FL, pk, s);
+    case 4: return launch_fill_k<4>(a, K, f, FL, pk, s);
+    case 5: return launch_fill_k<5>(a, K, f, FL, pk, s);
     }
     return hipErrorInvalidValue;
 #endif
 }
 
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool generic, int n_aut, hipStream_t s)
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;
     const int wblocks = (a.n_launch + 3) / 4;
@@ -1065,18 +1172,19 @@ hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool ge
         // (measured: 1k reads 0.77 vs 1.45 ms per call, 16k reads 2.7 vs 3.2 ms; from 12.5k reads per launch on,
         // inside a 100k-read batch, the streaming kernel wins)
         const int tblocks = (a.n_launch + 63) / 64;
-        const size_t shmem = (size_t)n_aut * 64 * sizeof(uint64_t);
-        switch (fast_f(F)) {
-        case 2: hipLaunchKernelGGL(traceback_stream_kernel<2>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
-        case 3: hipLaunchKernelGGL(traceback_stream_kernel<3>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
-        case 4: hipLaunchKernelGGL(traceback_stream_kernel<4>, dim3(tblocks), dim3(64), shmem, s, a, n_aut); break;
-        default: return hipErrorInvalidValue;
-        }
+        const size_t shmem = (size_t)n_aut * 64 * (sizeof(uint64_t) + sizeof(uint16_t));
+        const int f = fast_f(F);
+        if (pk && f != 2) return hipErrorInvalidValue;
+        if (pk) hipLaunchKernelGGL((traceback_stream_kernel<2, true>), dim3(tblocks), dim3(64), shmem, s, a, n_aut);
+        else if (f == 2) hipLaunchKernelGGL((traceback_stream_kernel<2, false>), dim3(tblocks), dim3(64), shmem, s, a, n_aut);
+        else if (f == 3) hipLaunchKernelGGL((traceback_stream_kernel<3, false>), dim3(tblocks), dim3(64), shmem, s, a, n_aut);
+        else if (f == 4) hipLaunchKernelGGL((traceback_stream_kernel<4, false>), dim3(tblocks), dim3(64), shmem, s, a, n_aut);
+        else return hipErrorInvalidValue;
     } else {
         const int f = fast_f(F);
 #define WSX_TB(KK, FF, LL)                                                                                          \
-    if (K == KK && f == FF && FL == LL)                                                                             \
-    hipLaunchKernelGGL((traceback_mask_kernel<KK, FF, LL>), dim3(wblocks), dim3(256), 0, s, a)
+    if (K == KK && f == FF && FL == LL && !pk)                                                                      \
+    hipLaunchKernelGGL((traceback_mask_kernel<KK, FF, LL, false>), dim3(wblocks), dim3(256), 0, s, a)
 #define WSX_TB_SPLIT(KK)                                                                                            \
     WSX_TB(KK, 2, 2);                                                                                               \
     else WSX_TB(KK, 3, 3);                                                                                          \
@@ -1086,7 +1194,9 @@ hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool ge
     else WSX_TB(KK, 3, 2);                                                                                          \
     else WSX_TB(KK, 4, 1);                                                                                          \
     else WSX_TB(KK, 4, 2)
-        WSX_TB(1, 2, 2);
+        if (K == 1 && f == 2 && FL == 2 && pk)
+            hipLaunchKernelGGL((traceback_mask_kernel<1, 2, 2, true>), dim3(wblocks), dim3(256), 0, s, a);
+        else WSX_TB(1, 2, 2);
         else WSX_TB(1, 3, 3);
         else WSX_TB(1, 4, 4);
         else WSX_TB_SPLIT(2);

@@ -18,6 +18,7 @@
 
 #include "../../include/warpstr_hip.h"
 #include "wsx_device.h"
+#include "wsx_place.h"
 
 namespace {
 
@@ -38,15 +39,17 @@ struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
     int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
+    bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
     // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
     //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
     //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
     size_t bp_words(size_t samples, size_t reads) const
     {
         if (generic) return (samples / 8 + reads + 2) * (size_t)(K * 64);
+        if (pk) return (samples / 16 + reads + 4) * 18 * 2; // 18 64-bit words per 16 rows, a read starts a new group
         return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2;
     }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk; }
 };
 
 struct DeviceBuf {
@@ -207,7 +210,7 @@ struct wsx_caller {
     } work[WSX_MAX_STREAMS];
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
-    int n_streams = 8;        // streams / work sets the handle may use
+    int n_streams = 4;        // streams / work sets the handle may use
     int streams_per_call = 4; // chunks of one call that run side by side
     // offsets / automaton ids / launch order of a call: device copy + pinned staging (caller buffers are not kept).
     // Two slots: pipelined calls alternate, so that call k+1 is prepared and enqueued while call k still runs.
@@ -379,7 +382,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
                 align_up((size_t)((S + 63) / 64) * 64 * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S) +
-                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2);
+                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -432,18 +435,25 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             if (n_ge2 <= 64) v.FL = 1;
             else if (Fk > 2 && n_gt2 <= 64) v.FL = 2;
         }
-        std::vector<uint16_t> pos(S); // state -> position (identity unless split)
+        // where the states live: position (slot, lane) and LDS export slot of every state (wsx_place.h)
+        std::vector<uint16_t> pos(S), wslot((size_t)v.K * 64);
         std::iota(pos.begin(), pos.end(), (uint16_t)0);
-        if (v.FL < Fk) {
-            std::vector<uint16_t> state_at((size_t)v.K * 64, 0xFFFF);
-            int q = 0; // positions 0..: the states with more than FL predecessors, then every other state, in state order
-            for (int j = 0; j < S; j++)
-                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) > v.FL) pos[j] = (uint16_t)q++;
-            for (int j = 0; j < S; j++)
-                if ((A.pred_ptr[j + 1] - A.pred_ptr[j]) <= v.FL) pos[j] = (uint16_t)q++;
-            for (int j = 0; j < S; j++) state_at[pos[j]] = (uint16_t)j;
-            D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
-            D.state_at = (const uint16_t *)put(state_at.data(), state_at.size() * 2);
+        std::iota(wslot.begin(), wslot.end(), (uint16_t)0);
+        if (!v.generic) {
+            const bool want_pk = v.K == 1 && Fk == 2 && !getenv("WSX_NO_PACK");
+            const WsxPlacement pl = getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
+                                        ? WsxPlacement{}
+                                        : wsx_place_states(S, A.pred_ptr, A.pred_idx, v.K, Fk, v.FL, want_pk);
+            if (!pl.pos.empty()) {
+                pos = pl.pos;
+                wslot = pl.wslot;
+                v.pk = want_pk && pl.low8;
+                if (!pl.identity) {
+                    D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
+                    D.state_at = (const uint16_t *)put(pl.state_at.data(), pl.state_at.size() * 2);
+                }
+            }
+            if (v.K == 1) D.wslot = (const uint16_t *)put(wslot.data(), wslot.size() * 2);
         }
         // pred4: the walk of the mask traceback runs in position space -- per position (slot*64 + lane) the positions of
         // its state's first four predecessors, 16 bits each
@@ -469,7 +479,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                         for (int l = g * 32; l < g * 32 + 32; l++) {
                             const int j = state_of[k * 64 + l];
                             if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f) continue;
-                            const int pa = pos[A.pred_idx[A.pred_ptr[j] + f]];
+                            const int pa = wslot[pos[A.pred_idx[A.pred_ptr[j] + f]]];
                             paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)pa;
                             used[pa & 31]++;
                         }
@@ -513,7 +523,11 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     if (const char *e = getenv("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     if (const char *e = getenv("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
-    for (int w = 1; w < c->n_streams; w++) {
+    // The streams one call spreads over exist from the start; the others (small pipelined calls taking turns) are created
+    // when first used: the runtime maps streams onto a few hardware queues in order of creation, streams that merely exist
+    // already cost big calls 2 % (profiles/r02_ab_streams.log), and creating these ones late, after work has been queued,
+    // cost 6 %.
+    for (int w = 1; w < std::min(c->n_streams, c->streams_per_call); w++) {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
     }
@@ -573,13 +587,7 @@ int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams)
 {
     if (!c || n_streams < 1 || n_streams > WSX_MAX_STREAMS) return WSX_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    for (int w = 1; w < n_streams; w++) {
-        if (!c->aux[w]) {
-            HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
-        }
-    }
-    c->n_streams = n_streams;
+    c->n_streams = n_streams; // (streams are created on first use)
     return WSX_SUCCESS;
 }
 
@@ -627,7 +635,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
-    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.generic);
+    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.pk, v.generic);
 }
 
 } // extern "C"
@@ -773,8 +781,11 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // then last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.
     // WSX_CHUNKS overrides the split count (tuning knob).
     const int spc = std::min(c->n_streams, c->streams_per_call);
+    // (small pipelined calls: two chunks, consecutive calls on alternating pairs of streams -- two calls side by side fill
+    // the chip better than one call cut into four; profiles/r02_small_call_sweep.log)
+    const bool small_call = (io.offsets[n] - io.offsets[0]) < (int64_t)80 << 20;
     if (chunks.size() == 1 && n >= 4096) {
-        int want = n >= 8192 ? spc : 2;
+        int want = (n >= 8192 && !(pipe && small_call)) ? spc : 2;
         if (n >= 32768) {
             const bool long_reads = chunks[0].samples / n >= 4096;
             const int64_t per_round = (int64_t)25000 * spc;
@@ -815,12 +826,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // (small batches: one call's kernels are too few wavefronts to fill the chip, and its stages depend on each other).
     // (big calls fill the chip by themselves and stay on the first streams_per_call sets: measured in
     // profiles/r02_stream_share_sweep.log)
-    const bool small_call = (io.offsets[n] - io.offsets[0]) < (int64_t)80 << 20;
     const int rot = (pipe && small_call && n_work < c->n_streams) ? c->rot % c->n_streams : 0;
     if (pipe) c->rot = (rot + n_work) % c->n_streams;
     auto wset = [&](size_t ci) -> int { return (rot + (int)(ci % n_work)) % c->n_streams; };
     for (int k = 0; k < n_work; k++) {
         const int w = wset(k);
+        if (w > 0 && !c->aux[w]) {
+            HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
+        }
         HIPCHK(c->work[w].samples.ensure(smp_bytes));
         HIPCHK(c->work[w].reads.ensure(R1 * 168 + align_up(R1 * sizeof(wsx_result)) + 8192));
         if (full && c->prm.reps_as_one)
@@ -1071,7 +1085,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;
@@ -1085,7 +1099,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.maskbits = maskbits;
             pa.trace = trace;
             pa.status = status;
-            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].generic, nA, s));
+            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, s));
         }
         return WSX_SUCCESS;
     };

@@ -31,6 +31,7 @@ struct DevAutomaton {
     const uint8_t *last_base; // ASCII of the k-mer's last base, or NULL
     const uint16_t *paddr;    // register-resident fill: LDS export slot read by (slot k, predecessor f, lane), at
                               // [(k*WSX_MAX_F + f)*64 + lane]; absent predecessors read one of the 32 +inf slots K*64..
+    const uint16_t *wslot;    // single-slot automata: the LDS export slot lane l writes (64 entries; wsx_place.h)
     const uint16_t *pos;      // state -> position (slot*64 + lane) in the register-resident fill; NULL = identity
     const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
     const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
@@ -143,11 +144,13 @@ struct EvalArgs {
 };
 
 // Host-side launchers (defined next to the kernels).
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool generic, hipStream_t s);
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool generic, int n_aut, hipStream_t s);
+// pk: packed mask rows (single-slot automata whose states with two predecessors sit in lanes 0..7): per 16 rows
+// 16 x 8 bytes of first-candidate masks + 2 x 8 bytes holding the second candidate's byte of every row
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, bool generic, hipStream_t s);
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
-const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool generic);
+const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, bool generic);
 bool wsx_split_supported(int m, int K);

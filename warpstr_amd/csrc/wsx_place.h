@@ -1,0 +1,372 @@
+// wsx_place.h -- where the states of an automaton live in the register-resident DP fill (dtw_kernels.hip): which
+// (slot, lane) holds a state ("position" = slot*64 + lane) and which LDS export slot it writes.  Plain C++ (no HIP), so the
+// CPU test suite can compile and check it (tests/test_placement.py).
+//
+// The fill exchanges predecessor values through LDS: state x writes its export to slot w(x), a successor reads it with a
+// ds_read_b64.  Measured on gfx950 (scripts/exp_ldsbank.hip, profiles/r02_lds_bank_rule.log): a ds_read_b64 serves the lanes
+// 0-31 and 32-63 of a wavefront in one pass each if no two lanes of a half hit the same bank pair (slot mod 32) at different
+// slots; a ds_write_b64 works on 16 lanes at a time and wants the 16 slots of lanes 16q..16q+15 distinct modulo 16.  Every
+// extra slot on a bank pair costs a pass, and the LDS pipe is as loaded as the vector ALU in this kernel.  Upstream numbers the states of a repeat unit in an order that
+// is not the order of the transitions (src/caller/automata.py: loops of k-mers interleave), so "state j in lane j" has
+// conflicts, and moving the states with several predecessors together (they must share slot 0, see the fill) adds more.
+//
+// Layout: follow the FIRST-predecessor links.  They form a forest; it is cut into chains (a state is followed by the
+// child with the longest tail), and the chains are laid out one after the other in LDS: w(x) = w(pred0(x)) + 1 inside a
+// chain, so the 32 lanes of a half read 32 consecutive slots.  A chain that starts at a side branch ("jump": its first
+// state reads a slot that is not the one before it) is moved up to the next slot that is congruent to w(pred0) + 1 modulo
+// 32 while unused slots last: its read then uses exactly the bank pair its lane's neighbours leave free.  The whole
+// sequence is rotated so that the states with many predecessors fall into slot 0; the ones that still do not
+// trade places with the slot-0 state of the same bank pair.  For single-slot automata the lane of a state is free inside
+// its half of the wavefront (writes and reads go through per-lane slot tables), which lets the states with two
+// predecessors sit in lanes 0..7 (their back-pointer bits then form one byte: packed mask rows).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+struct WsxPlacement {
+    std::vector<uint16_t> pos;      // state -> position (slot*64 + lane)
+    std::vector<uint16_t> state_at; // position -> state (0xFFFF = none), K*64 entries
+    std::vector<uint16_t> wslot;    // position -> LDS export slot (0 .. K*64-1), K*64 entries (unused positions: own index)
+    int conflict_cycles = 0;        // extra LDS cycles per DP row (reads of real predecessors + writes), all groups
+    bool identity = true;           // pos[j] == j and wslot[q] == q
+    bool low8 = false;              // every state with >= 2 predecessors sits in lanes 0..7 of slot 0
+};
+
+namespace wsx_place_detail {
+
+inline int fanin(const int32_t *pp, int j) { return pp[j + 1] - pp[j]; }
+
+// extra LDS cycles per row of a placement: for every slot k, candidate f and half g the largest number of distinct slots
+// on one bank pair, minus one; the same for the export writes
+inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, const std::vector<uint16_t> &pos,
+                           const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot)
+{
+    int total = 0;
+    for (int k = 0; k < K; k++) {
+        for (int q = 0; q < 4; q++) { // writes: 16 lanes at a time, slots distinct modulo 16 (idle lanes write as well)
+            std::vector<std::vector<int>> on(16);
+            for (int l = q * 16; l < q * 16 + 16; l++) {
+                const int slot = wslot[k * 64 + l];
+                auto &v = on[slot & 15];
+                if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+            }
+            size_t worst = 1;
+            for (auto &v : on) worst = std::max(worst, v.size());
+            total += (int)worst - 1;
+        }
+        for (int g = 0; g < 2; g++)
+            for (int f = 0; f < (k == 0 ? F : FL); f++) { // reads: 32 lanes at a time, slots distinct modulo 32
+                std::vector<std::vector<int>> on(32);
+                for (int l = g * 32; l < g * 32 + 32; l++) {
+                    const int j = state_at[k * 64 + l] == 0xFFFF ? -1 : state_at[k * 64 + l];
+                    if (j < 0 || fanin(pp, j) <= f) continue;
+                    const int slot = wslot[pos[pi[pp[j] + f]]];
+                    auto &v = on[slot & 31];
+                    if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+                }
+                size_t worst = 1;
+                for (auto &v : on) worst = std::max(worst, v.size());
+                total += (int)worst - 1;
+            }
+    }
+    return total;
+}
+
+} // namespace wsx_place_detail
+
+// K slots of 64 lanes; states with more than FL predecessors must lie in slot 0 (FL = F: no such constraint).
+// want_low8 (K == 1 only): put the states with >= 2 predecessors into lanes 0..7 if there are at most 8 of them.
+inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, bool want_low8, bool use_gaps)
+{
+    using namespace wsx_place_detail;
+    const int P = K * 64;
+    WsxPlacement out;
+    out.pos.resize(S);
+    std::iota(out.pos.begin(), out.pos.end(), (uint16_t)0);
+    out.state_at.assign(P, 0xFFFF);
+    for (int j = 0; j < S; j++) out.state_at[j] = (uint16_t)j;
+    out.wslot.resize(P);
+    std::iota(out.wslot.begin(), out.wslot.end(), (uint16_t)0);
+    auto finish_identity = [&]() {
+        out.identity = true;
+        out.conflict_cycles = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
+        return out;
+    };
+    if (S > P || S <= 0) return finish_identity();
+
+    // ---- first-predecessor forest, heights, chain order ------------------------------------------------------------------
+    std::vector<int> pred0(S, -1), depth(S, -1);
+    for (int j = 0; j < S; j++)
+        if (fanin(pp, j) > 0) pred0[j] = pi[pp[j]];
+    for (int j = 0; j < S; j++) { // depth by walking up; a cycle of first-predecessor links (never seen) -> identity layout
+        int steps = 0, x = j;
+        while (x >= 0 && depth[x] < 0 && steps <= S) {
+            x = pred0[x];
+            steps++;
+        }
+        if (steps > S) return finish_identity();
+        int d = (x >= 0 ? depth[x] : -1) + steps;
+        for (int y = j; y >= 0 && depth[y] < 0; y = pred0[y]) depth[y] = d--;
+    }
+    std::vector<std::vector<int>> kids(S);
+    std::vector<int> roots;
+    for (int j = 0; j < S; j++) {
+        if (pred0[j] >= 0) kids[pred0[j]].push_back(j);
+        else roots.push_back(j);
+    }
+    std::vector<int> by_depth(S), height(S, 0);
+    std::iota(by_depth.begin(), by_depth.end(), 0);
+    std::stable_sort(by_depth.begin(), by_depth.end(), [&](int a, int b) { return depth[a] > depth[b]; });
+    for (int x : by_depth)
+        if (pred0[x] >= 0) height[pred0[x]] = std::max(height[pred0[x]], height[x] + 1);
+    std::vector<int> seq;
+    seq.reserve(S);
+    {
+        std::vector<int> stack(roots.rbegin(), roots.rend());
+        while (!stack.empty()) {
+            int x = stack.back();
+            stack.pop_back();
+            // walk the chain: the child with the longest tail follows directly, the others wait on the stack
+            while (true) {
+                seq.push_back(x);
+                auto &c = kids[x];
+                if (c.empty()) break;
+                int heavy = c[0];
+                for (int y : c)
+                    if (height[y] > height[heavy]) heavy = y;
+                for (auto it = c.rbegin(); it != c.rend(); ++it)
+                    if (*it != heavy) stack.push_back(*it);
+                x = heavy;
+            }
+        }
+    }
+    if ((int)seq.size() != S) return finish_identity();
+
+    // ---- LDS slots: consecutive inside a chain, jumps aligned modulo 32 while unused slots last --------------------------
+    std::vector<int> w(S, -1);
+    int cur = 0, slack = use_gaps ? P - S : 0;
+    for (int i = 0; i < S; i++) {
+        const int x = seq[i];
+        const bool jump = pred0[x] >= 0 && (i == 0 || seq[i - 1] != pred0[x]);
+        if (jump) {
+            const int gap = (((w[pred0[x]] + 1 - cur) % 32) + 32) % 32;
+            if (gap <= slack) {
+                cur += gap;
+                slack -= gap;
+            }
+        }
+        w[x] = cur++;
+    }
+    // rotation: as many of the states that need slot 0 as possible into slots 0..63 (K > 1), or into 0..31 (low8)
+    std::vector<int> need;
+    for (int j = 0; j < S; j++)
+        if ((K > 1 && fanin(pp, j) > FL) || (want_low8 && K == 1 && fanin(pp, j) >= 2)) need.push_back(j);
+    if (!need.empty() && K > 1) {
+        int best_r = 0, best_n = -1;
+        for (int r = 0; r < P; r++) {
+            int n = 0;
+            for (int j : need) n += ((w[j] + r) % P) < 64;
+            if (n > best_n) {
+                best_n = n;
+                best_r = r;
+            }
+        }
+        for (int j = 0; j < S; j++) w[j] = (w[j] + best_r) % P;
+    }
+
+    std::vector<int> at_slot(P, -1); // slot -> state
+    for (int j = 0; j < S; j++) at_slot[w[j]] = j;
+    if (K > 1) {
+        // position = slot.  A state that needs slot 0 and still lies outside trades places with the slot-0 tenant of the
+        // same bank pair (both keep the banks their new neighbours leave free); failing that with any free slot-0 state.
+        std::vector<char> fixed(64, 0);
+        for (int j : need) {
+            if (w[j] < 64) {
+                fixed[w[j]] = 1;
+                continue;
+            }
+        }
+        for (int j : need) {
+            if (w[j] < 64) continue;
+            auto ok = [&](int c) { return !fixed[c] && (at_slot[c] < 0 || fanin(pp, at_slot[c]) <= FL); };
+            int dst = -1;
+            for (int c : {w[j] % 32, w[j] % 32 + 32})
+                if (dst < 0 && ok(c)) dst = c;
+            for (int c = 0; c < 64 && dst < 0; c++)
+                if (ok(c)) dst = c;
+            if (dst < 0) return finish_identity(); // more than 64 such states: the caller does not ask for this
+            const int other = at_slot[dst], src = w[j];
+            at_slot[dst] = j;
+            at_slot[src] = other;
+            w[j] = dst;
+            if (other >= 0) w[other] = src;
+            fixed[dst] = 1;
+        }
+        for (int q = 0; q < P; q++) {
+            out.state_at[q] = at_slot[q] < 0 ? 0xFFFF : (uint16_t)at_slot[q];
+            out.wslot[q] = (uint16_t)q;
+        }
+        for (int j = 0; j < S; j++) out.pos[j] = (uint16_t)w[j];
+    } else {
+        // one slot: LDS slot w(x) as computed; the lane is free inside a quarter of the wavefront (16 lanes: the unit of a
+        // ds_write_b64).  Quarter q = slots 16q..16q+15, except that a state that has to be in the low lanes trades quarters
+        // with the quarter-0 state of the same slot modulo 16 (its write keeps a bank pair of its own there).
+        std::vector<int> quarter(S);
+        for (int j = 0; j < S; j++) quarter[j] = w[j] / 16;
+        auto is_need = [&](int j) { return std::find(need.begin(), need.end(), j) != need.end(); };
+        bool low_ok = want_low8 && (int)need.size() <= 8;
+        if (low_ok) {
+            // two steps, each an exchange that leaves every bank rule intact: into the low HALF by trading places with the
+            // state 32 slots away (reads: both halves keep their sets of bank pairs), then into quarter 0 by trading with
+            // the state 16 slots away in the same half (writes: both quarters keep their sets modulo 16)
+            auto tenant = [&](int qt, int mod, int val, int not_j) {
+                for (int y = 0; y < S; y++)
+                    if (y != not_j && quarter[y] == qt && (w[y] & (mod - 1)) == val) return y;
+                return -1;
+            };
+            auto count = [&](int qt) { return (int)std::count(quarter.begin(), quarter.end(), qt); };
+            for (int j : need) {
+                if (quarter[j] >= 2) {
+                    const int dst = quarter[j] - 2;
+                    int u = tenant(dst, 32, w[j] & 31, j);
+                    if (u < 0) u = tenant(dst ^ 1, 32, w[j] & 31, j);
+                    if (u >= 0 && is_need(u)) low_ok = false;
+                    if (u >= 0) std::swap(quarter[u], quarter[j]);
+                    else if (count(dst) < 16) quarter[j] = dst;
+                    else low_ok = false;
+                }
+                if (low_ok && quarter[j] == 1) {
+                    const int t = tenant(0, 16, w[j] & 15, j);
+                    if (t >= 0 && is_need(t)) low_ok = false;
+                    if (t >= 0) std::swap(quarter[t], quarter[j]);
+                    else if (count(0) < 16) quarter[j] = 0;
+                    else low_ok = false;
+                }
+                if (!low_ok) break;
+            }
+        }
+        if (!low_ok)
+            for (int j = 0; j < S; j++) quarter[j] = w[j] / 16;
+        std::vector<int> lanes[4];
+        if (low_ok)
+            for (int j : need) lanes[0].push_back(j);
+        for (int s = 0; s < P; s++) {
+            const int j = at_slot[s];
+            if (j < 0 || (low_ok && is_need(j))) continue;
+            lanes[quarter[j]].push_back(j);
+        }
+        for (auto &v : lanes)
+            if (v.size() > 16) return finish_identity();
+        out.state_at.assign(P, 0xFFFF);
+        for (int q = 0; q < P; q++) out.wslot[q] = 0xFFFF;
+        std::vector<char> slot_used(P, 0);
+        for (int h = 0; h < 4; h++)
+            for (size_t i = 0; i < lanes[h].size(); i++) {
+                const int j = lanes[h][i], q = h * 16 + (int)i;
+                out.pos[j] = (uint16_t)q;
+                out.state_at[q] = (uint16_t)j;
+                out.wslot[q] = (uint16_t)w[j];
+                slot_used[w[j]] = 1;
+            }
+        // idle lanes write too (the row code has no branches): each gets a slot of its own, distinct modulo 16 in its quarter
+        for (int h = 0; h < 4; h++) {
+            std::vector<char> bank_used(16, 0);
+            for (int l = 0; l < 16; l++)
+                if (out.wslot[h * 16 + l] != 0xFFFF) bank_used[out.wslot[h * 16 + l] & 15] = 1;
+            for (int l = 0; l < 16; l++) {
+                const int q = h * 16 + l;
+                if (out.wslot[q] != 0xFFFF) continue;
+                int pick = -1;
+                for (int s = 0; s < P && pick < 0; s++)
+                    if (!slot_used[s] && !bank_used[s & 15]) pick = s;
+                for (int s = 0; s < P && pick < 0; s++)
+                    if (!slot_used[s]) pick = s;
+                out.wslot[q] = (uint16_t)pick;
+                slot_used[pick] = 1;
+                bank_used[pick & 15] = 1;
+            }
+        }
+        out.low8 = low_ok && !need.empty();
+        if (need.empty() && want_low8) out.low8 = true; // nothing to place: trivially packed
+    }
+    // ---- repair: two states whose export slots share a bank pair may trade places (their writes stay conflict-free); keep
+    // every trade that lowers the conflict count.  Covers what the construction above misses: jumps that found no slack,
+    // states that changed halves, colliding reads of second and third predecessors.
+    {
+        auto pinned_ok = [&](int j, int q) { // may state j live at position q?
+            if (j < 0) return true;
+            if (K > 1) return fanin(pp, j) <= FL || q < 64;
+            return !(out.low8 && fanin(pp, j) >= 2) || q < 8;
+        };
+        int cur_cost = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
+        for (int pass = 0; pass < 4 && cur_cost > 0; pass++) {
+            bool improved = false;
+            for (int a = 0; a < P && cur_cost > 0; a++)
+                for (int b = a + 1; b < P && cur_cost > 0; b++) {
+                    // a trade must not disturb the writes: equal slots modulo 32 (several slots: slot = position), or modulo
+                    // 16 and a quarter of its own for each (one slot)
+                    if (K > 1 ? ((a & 31) != (b & 31) || (a / 32) == (b / 32))
+                              : ((out.wslot[a] & 15) != (out.wslot[b] & 15) || (a / 16) == (b / 16)))
+                        continue;
+                    const int ja = out.state_at[a] == 0xFFFF ? -1 : out.state_at[a], jb = out.state_at[b] == 0xFFFF ? -1 : out.state_at[b];
+                    if ((ja < 0 && jb < 0) || !pinned_ok(ja, b) || !pinned_ok(jb, a)) continue;
+                    auto trade = [&]() {
+                        std::swap(out.state_at[a], out.state_at[b]);
+                        if (K == 1) std::swap(out.wslot[a], out.wslot[b]);
+                        if (out.state_at[a] != 0xFFFF) out.pos[out.state_at[a]] = (uint16_t)a;
+                        if (out.state_at[b] != 0xFFFF) out.pos[out.state_at[b]] = (uint16_t)b;
+                    };
+                    trade();
+                    const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
+                    if (c < cur_cost) {
+                        cur_cost = c;
+                        improved = true;
+                    } else {
+                        trade();
+                    }
+                }
+            if (!improved) break;
+        }
+    }
+    out.identity = true;
+    for (int j = 0; j < S; j++) out.identity = out.identity && out.pos[j] == j;
+    for (int q = 0; q < P; q++) out.identity = out.identity && out.wslot[q] == q;
+    out.conflict_cycles = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
+    // never worse than the plain layout when that one is admissible (no slot-0 constraint to satisfy, no packing asked for)
+    if ((K == 1 && !out.low8) || (K > 1 && FL >= F)) {
+        WsxPlacement plain;
+        plain.pos.resize(S);
+        std::iota(plain.pos.begin(), plain.pos.end(), (uint16_t)0);
+        plain.state_at.assign(P, 0xFFFF);
+        for (int j = 0; j < S; j++) plain.state_at[j] = (uint16_t)j;
+        plain.wslot.resize(P);
+        std::iota(plain.wslot.begin(), plain.wslot.end(), (uint16_t)0);
+        plain.conflict_cycles = conflict_cycles(S, pp, pi, K, F, FL, plain.pos, plain.state_at, plain.wslot);
+        if (plain.conflict_cycles <= out.conflict_cycles) return plain;
+    }
+    return out;
+}
+
+// The layout with and without moving side chains up to aligned slots (the gaps can put two states that both have to be in
+// the low lanes on one bank pair, or overfill a half), and the plain one where it is admissible: fewest conflict cycles
+// first (the LDS pipe is what the fill runs out of), packed rows second.
+inline WsxPlacement wsx_place_states(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, bool want_low8)
+{
+    WsxPlacement best = wsx_place_attempt(S, pp, pi, K, F, FL, want_low8, true);
+    auto better = [&](const WsxPlacement &x, const WsxPlacement &y) {
+        if (x.conflict_cycles != y.conflict_cycles) return x.conflict_cycles < y.conflict_cycles;
+        return want_low8 && x.low8 && !y.low8;
+    };
+    if (best.conflict_cycles == 0 && (best.low8 || !want_low8)) return best;
+    WsxPlacement b = wsx_place_attempt(S, pp, pi, K, F, FL, want_low8, false);
+    if (better(b, best)) best = b;
+    if (want_low8) { // the unpacked layouts compete too
+        for (bool gaps : {true, false}) {
+            WsxPlacement c = wsx_place_attempt(S, pp, pi, K, F, FL, false, gaps);
+            if (better(c, best)) best = c;
+        }
+    }
+    return best;
+}
