@@ -239,6 +239,89 @@ def valu_roofline(prof, alone_ms, wave_rows, kernel):
                     'fp64 load; the LDS pipe (one per CU: predecessor exchange) is loaded as heavily as the VALU'}
 
 
+def from_raw_leg(hip, wl, device, steps, warmup):
+    """north_star's "loads of raw-signal segments": the same reads as int16 DAC values -> wsx_prepare_signals (spike removal,
+    MAD normalisation, slice; Fast5.get_data_processed, src/schemas/fast5.py:45-57) -> wsx_call_batch with the called sequences
+    requested -> result records on the host.  Two variants: raw segments resident in HBM, and in pinned host memory (the
+    upload of step k+1 runs on a copy stream beside the kernels of step k).  Checked against the float64 path: the same
+    reads prepared by the host restatement of the loader and called through host buffers give identical records."""
+    import torch
+
+    from warpstr_amd import _lib
+    from warpstr_amd.signal_prep import process_raw
+    n, total = wl.n, int(wl.offsets[-1])
+    raw_dev = torch.clamp(torch.round(wl.signal * 70.0 + 500.0), 0, 2047).to(torch.int16).contiguous()
+    raw_host = raw_dev.cpu().pin_memory()
+    lens = np.diff(wl.offsets)
+    seg_lo, seg_hi = np.zeros(n, np.int64), lens - 1  # the whole uploaded segment (reads are cut to the STR region upstream)
+    raw_bufs = [torch.empty_like(raw_dev) for _ in range(2)]
+    sig_bufs = [torch.empty(total, dtype=torch.float64, device=device) for _ in range(2)]
+    seq_bufs = [[torch.zeros(total, dtype=torch.uint8, device=device) for _ in range(2)] for _ in range(2)]
+    res_bufs = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(2)]
+    res_host = [torch.empty((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    copy_stream, down_stream = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream()
+
+    def run(host_resident):
+        uploaded, downloaded = [None, None], [None, None]
+
+        def upload(k):
+            with torch.cuda.stream(copy_stream):  # (buffer k&1 was last read by the loader of step k-2, which has returned)
+                raw_bufs[k & 1].copy_(raw_host, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            uploaded[k & 1] = ev
+
+        def step(k):
+            b = k & 1
+            if downloaded[b] is not None:
+                main.wait_event(downloaded[b])  # step k-2 used these signal / sequence / result buffers
+            if host_resident:
+                main.wait_event(uploaded[b])
+            src = raw_bufs[b] if host_resident else raw_dev
+            hip.prepare_device(src.data_ptr(), wl.offsets, seg_lo, seg_hi, sig_bufs[b].data_ptr(), wl.offsets)
+            if host_resident:
+                upload(k + 1)  # beside this step's kernels
+            hip.call_device(sig_bufs[b].data_ptr(), wl.offsets, wl.aut, res_bufs[b].data_ptr(), seq1_ptr=seq_bufs[b][0].data_ptr(),
+                            seq2_ptr=seq_bufs[b][1].data_ptr())
+            hip.join(down_stream.cuda_stream)
+            with torch.cuda.stream(down_stream):
+                res_host[b].copy_(res_bufs[b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            downloaded[b] = ev
+
+        if host_resident:
+            upload(0)
+        for k in range(warmup):
+            step(k)
+        hip.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k)
+        hip.synchronize()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, (warmup + steps - 1) & 1
+
+    dt_hbm, last = run(False)
+    dt_host, last = run(True)
+    got = res_host[last].numpy().view(_lib.RESULT_DTYPE).reshape(-1).copy()
+    seq2 = seq_bufs[last][1].cpu().numpy()
+    # the float64 path on the same reads: host restatement of the loader, host-buffer call
+    nv = min(n, 512)
+    raws = raw_host.numpy()
+    f64 = np.concatenate([process_raw(raws[wl.offsets[i]:wl.offsets[i + 1]], (0, int(lens[i]) - 1), 'Brute') for i in range(nv)])
+    want, extra = hip.call(f64, wl.offsets[:nv + 1], wl.aut[:nv], want_seqs=True)
+    same = bool(got[:nv].tobytes() == want.tobytes()) and bool(np.array_equal(seq2[: len(f64)], extra['seq2']))
+    return {'reads_per_s_hbm_int16': n * steps / dt_hbm, 'ms_per_step_hbm_int16': dt_hbm / steps * 1e3,
+            'reads_per_s_host_int16': n * steps / dt_host, 'ms_per_step_host_int16': dt_host / steps * 1e3,
+            'h2d_bytes_per_step': int(total) * 2, 'd2h_bytes_per_step': n * _lib.RESULT_DTYPE.itemsize,
+            'steps': steps, 'identical_to_f64_path': {'reads': nv, 'identical': same},
+            'pipeline': 'int16 segments -> wsx_prepare_signals (Brute spike removal, MAD normalisation) -> wsx_call_batch with '
+                        'seq1/seq2 -> 56-B records to pinned host memory; host variant: upload of step k+1 on a copy stream'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -250,6 +333,9 @@ def main():
     ap.add_argument('--samples', type=int, default=2000, help='samples per read (headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the 15 s CPU baseline (a 256-read check remains)')
     ap.add_argument('--no-verify', action='store_true')
+    ap.add_argument('--from-raw', action='store_true',
+                    help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
+                         'called sequences requested; reported as from_raw next to the headline')
     args = ap.parse_args()
 
     # Exactly one line on stdout: native libraries print there too (RCCL's start-up banner: version, hostname, library
@@ -451,6 +537,11 @@ def main():
             if out['verified']['mismatches']:
                 rc = 3
                 print(f"bench.py: {out['verified']['mismatches']} of {len(ores)} reads differ from the oracle", file=sys.stderr)
+        if args.from_raw and world == 1:
+            out['from_raw'] = from_raw_leg(hip, wl, device, max(3, args.steps // 2), 2)
+            if not out['from_raw']['identical_to_f64_path']['identical']:
+                rc = 3
+                print('bench.py: the from-raw path and the float64 path disagree', file=sys.stderr)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or self_gather:

@@ -12,7 +12,8 @@ expected value below is computed by the reference's own functions:
   (src/caller/caller.py:198-301), WarpResult.create_alignment (65-96), rescale_signal (304-313),
   mask_bad_repeats (330-339), WarpSTR.run (117-149), CallerWrapper.break_into_units /
   collapse_repeats / reverse_uniq_sequence (src/caller/wrapper.py:78-84,162-248),
-  normalize_signal_mad / Fast5.brute_remove (src/schemas/fast5.py:90-114).
+  normalize_signal_mad / Fast5.brute_remove (src/schemas/fast5.py:90-114), CallerWrapper.check_high_similarity
+  (src/caller/wrapper.py:122-160).
 The files written are data only (arrays and strings): no reference source text is stored.
 """
 import argparse
@@ -222,6 +223,41 @@ def gen_negative(ns, outdir):
     return out
 
 
+SIMILARITY_SEQUENCES = ['(AGC)', '(AAAT)', '(AGC)AACAGCCGCCAC(CGC)', '((CAGG){CAGM})(CAGA)(CA)', '(NGC)', '(GGCCCC)', '(CAG)(CAA)(CAG)',
+                        '(A)', '(AAAAG)', '(CCTG)(TCTG)']
+
+
+def gen_similarity(ns, outdir):
+    """summaries/state_similarity.csv and the high-similarity warnings, produced by the reference's own
+    CallerWrapper.check_high_similarity (src/caller/wrapper.py:122-160; PoreModel.get_diffs_for_all,
+    src/squiggler/pore_model.py:49-71) -- called unbound on a stand-in object that only carries locus.path."""
+    import contextlib
+    import io
+    import tempfile
+    import types
+    W = ns.wrapper.CallerWrapper
+    out = {}
+    for seq in SIMILARITY_SEQUENCES:
+        tmp = tempfile.mkdtemp(prefix='warpstr_sim_')
+        os.makedirs(os.path.join(tmp, ns.templates.SUMMARY_SUBDIR))
+        fake = types.SimpleNamespace(locus=types.SimpleNamespace(path=tmp), reverse_uniq_sequence=W.reverse_uniq_sequence)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                tp, rp = W.check_high_similarity(fake, seq)
+        except Exception as e:  # noqa: BLE001 -- e.g. one-base units: the k-mer list runs past the repeated pattern
+            out[seq] = dict(error=type(e).__name__)
+            continue
+        with open(os.path.join(tmp, ns.templates.SUMMARY_SUBDIR, 'state_similarity.csv')) as f:
+            csv_text = f.read()
+        out[seq] = dict(csv=csv_text, stdout=buf.getvalue(),
+                        template_problems=[dict(pattern=p['pattern'], mean_diff=float(p['mean_diff']), median_diff=float(p['median_diff'])) for p in tp],
+                        reverse_problems=[dict(pattern=p['pattern'], mean_diff=float(p['mean_diff']), median_diff=float(p['median_diff'])) for p in rp])
+    with open(os.path.join(outdir, 'similarity.json'), 'w') as f:
+        json.dump(dict(min_state_similarity=float(ns.wrapper.caller_config.min_state_similarity), summary_subdir=ns.templates.SUMMARY_SUBDIR,
+                       cases=out), f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--alt', action='store_true')
@@ -251,6 +287,9 @@ def main():
     if not args.only or args.only == 'real_aaat':
         print('real_aaat')
         gen_real(ns, HERE)
+    if not args.only or args.only == 'similarity':
+        print('similarity')
+        gen_similarity(ns, HERE)
     if not args.only:
         gen_units(ns, HERE)
         gen_negative(ns, HERE)

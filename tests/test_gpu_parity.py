@@ -378,6 +378,62 @@ def test_large_automaton_and_long_read():
     assert n_ok == 2 and res['len2'].min() > 500
 
 
+def test_automaton_of_more_than_ten_slots():
+    """S > 640: more than ten 64-state slots in the general DP kernel, whose pointer words live in LDS (a per-thread
+    array sized for ten slots was overrun here before)."""
+    huge = synth.make_locus('(AGC)', 330, 5)
+    assert huge.template.n_states > 640
+    sigs, revs, _ = synth.batch(huge, 3, 3600, 6, lo=3, hi=10)
+    _, res, n_ok = _compare_with_oracle(huge, 330, sigs, revs)
+    assert n_ok >= 2
+
+
+def test_workspace_limit_is_honoured():
+    """wsx_caller_set_workspace_limit bounds everything a call allocates (all work sets together, include/warpstr_hip.h);
+    a batch that needs several times the limit is cut into more chunks and gives the same results."""
+    import torch
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    sigs, revs, _ = synth.batch(locus, 4000, 1000, 3)
+    sig, off = pack_signals(sigs)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    dev = torch.device('cuda:0')
+    dsig = torch.from_numpy(sig).to(dev)
+    res = torch.zeros((len(aut), 56), dtype=torch.uint8, device=dev)
+    ref_res = torch.zeros((len(aut), 56), dtype=torch.uint8, device=dev)
+    limit = 160 << 20  # the batch needs ~0.4 GB of workspace
+    small = HipCaller([locus.template, locus.reverse], [19, 19], workspace_limit=limit)
+    small.call_device(dsig.data_ptr(), off[:9], aut[:8], res.data_ptr())  # first launches: the runtime's own scratch allocation
+    small.synchronize()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    small.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
+    small.synchronize()
+    used = free1 - torch.cuda.mem_get_info()[0]
+    assert used <= limit, (used, limit)
+    assert small.last_timing()['dp_launches'] > 8              # more chunks than the four a roomy handle would use
+    small.close()
+    big = HipCaller([locus.template, locus.reverse], [19, 19])
+    big.call_device(dsig.data_ptr(), off, aut, ref_res.data_ptr())
+    big.synchronize()
+    assert big.last_timing()['dp_launches'] <= 8
+    assert torch.equal(res, ref_res)
+
+
+def test_long_runs_and_long_repeats_take_the_deep_pairwise_sum():
+    """NumPy's pairwise summation beyond 2048 elements (its recursion is then deeper than the five levels kept in
+    registers; the deeper partial sums go through global scratch): a state the path dwells in for ~3000 samples (mean and
+    standard deviation of that run), and a repeat of more than 2048 transitions (the state-wise cost)."""
+    loc = synth.make_locus('(AGC)', 16, 3)
+    rng = np.random.default_rng(8)
+    base, _ = synth.squiggle(loc, False, 1500, rng, lo=20, hi=20)
+    at = 40  # inside the left flank: hold the level there for 3000 more samples
+    level = float(np.mean(base[at - 2:at + 2]))
+    long_dwell = np.concatenate([base[:at], level + 0.05 * rng.standard_normal(3000), base[at:]])
+    many_runs, _ = synth.squiggle(loc, True, 30000, rng, lo=800, hi=800)
+    _, res, n_ok = _compare_with_oracle(loc, 16, [long_dwell, many_runs], [False, True])
+    assert n_ok == 2 and res['n_trans1'][1] > 2048
+
+
 def test_noise_free_reads_exercise_ties():
     """sigma = 0: repeated k-mers give runs with exactly equal means (the stable sort's tie-break), zero standard
     deviations (the t-test's 1e-7 guard) and exact ties between DP candidates (stay wins, first predecessor wins)."""
@@ -561,8 +617,12 @@ def test_upstream_test_case_real_reads(tmp_path):
     loc = prepare_caller_only(os.path.join(real, 'example.csv'), str(tmp_path / 'out'), base_dir=str(tmp_path))
     loc = loc['Human_STR_1108232']
     ov.store_flanks(loc, [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']])
-    df, dfc = main_wrapper(loc, fj['sequence'], fj['flank_length'])
+    # the reference's own call shape: main_wrapper(locus, threads) with a Locus-like object (src/caller/wrapper.py:17)
+    from warpstr_amd.wrapper import LocusPath
+    df, dfc = main_wrapper(LocusPath(loc, fj['sequence'], fj['flank_length']), 4)
     assert dfc is None
+    sim = open(os.path.join(loc, 'summaries', 'state_similarity.csv')).read().splitlines()
+    assert sim[0] == 'pattern,strand,mean_diff,median_diff' and sim[1] == 'AAAT,template,1.647,1.647' and sim[2] == 'ATTT,reverse,1.224,1.115'
     out = pd.read_csv(os.path.join(loc, 'overview.csv'))
     assert list(out['read_name']) == [str(n) for n in z['names']]
     for i in range(int(z['n_reads'])):

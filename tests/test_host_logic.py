@@ -132,3 +132,61 @@ def test_genotyper_two_alleles_and_homozygous(tmp_path):
     assert genotype_results(rec).alleles == (30, '-')
     p = store_predictions(gt, str(tmp_path))
     assert open(p).read().splitlines()[0].startswith('WarpSTR_allele1,')
+
+
+def test_state_similarity_matches_reference(tmp_path, capsys):
+    """summaries/state_similarity.csv, the warnings and the returned problem lists against what the reference's
+    CallerWrapper.check_high_similarity produced (tests/golden/similarity.json, generate_golden.py: gen_similarity)."""
+    import json
+    import os
+
+    import pytest
+
+    from warpstr_amd.caller import CallerConfig, CallerWrapper
+    from warpstr_amd.pore_model import default_pore_model
+    with open(os.path.join(GOLDEN, 'similarity.json')) as f:
+        fx = json.load(f)
+    assert CallerConfig().min_state_similarity == fx['min_state_similarity']
+    cw = CallerWrapper.__new__(CallerWrapper)  # no GPU: only the host-side check
+    cw.caller_config, cw.pore_model, cw.locus = CallerConfig(), default_pore_model(), None
+    for seq, want in fx['cases'].items():
+        out_dir = tmp_path / str(abs(hash(seq)))
+        if 'error' in want:
+            with pytest.raises(IndexError):
+                cw.check_high_similarity(seq, str(out_dir))
+            continue
+        capsys.readouterr()
+        tp, rp = cw.check_high_similarity(seq, str(out_dir))
+        assert capsys.readouterr().out == want['stdout']
+        assert (out_dir / 'state_similarity.csv').read_text() == want['csv']
+        for got, ref in ((tp, want['template_problems']), (rp, want['reverse_problems'])):
+            assert [p['pattern'] for p in got] == [p['pattern'] for p in ref]
+            for g, r in zip(got, ref):
+                assert abs(g['mean_diff'] - r['mean_diff']) < 1e-12 and abs(g['median_diff'] - r['median_diff']) < 1e-12
+
+
+def test_caller_results_are_lazy_and_list_like():
+    """CallerWrapper.run's return value: CallerResult objects (src/caller/caller.py:46-51) built on access from the batch's
+    records and ASCII buffers; failed reads raise (the reference loses the whole batch) or give NaN records."""
+    import pytest
+
+    from warpstr_amd import _lib
+    from warpstr_amd.caller import CallerResult, CallerResults, ReadCallError
+    rec = np.zeros(3, dtype=_lib.RESULT_DTYPE)
+    rec['len1'], rec['len2'] = [3, 2, 0], [4, 1, 0]
+    rec['cost1'], rec['cost2'] = [0.5, 0.25, np.nan], [0.4, 0.2, np.nan]
+    rec['status'] = [0, 0, 3]
+    seq1 = b'ACGxxxxxTTyyyyyyzzzz'
+    seq2 = b'ACGTxxxxGyyyyyyyzzzz'
+    offsets = np.array([0, 8, 16])
+    res = CallerResults(['a', 'b', 'c'], rec, offsets, seq1, seq2, 'nan')
+    assert len(res) == 3 and res[0] == CallerResult('ACG', 0.5, 'ACGT', 0.4) and res[1] == CallerResult('TT', 0.25, 'G', 0.2)
+    assert res[-1].seq == '' and np.isnan(res[2].resc_cost)
+    assert [r.resc_seq for r in res] == ['ACGT', 'G', ''] and [r.seq for r in res[0:2]] == ['ACG', 'TT']
+    assert res.lengths()[1].tolist() == [4, 1, 0]
+    strict = CallerResults(['a', 'b', 'c'], rec, offsets, seq1, seq2, 'raise')
+    with pytest.raises(ReadCallError):
+        strict.check()
+    with pytest.raises(ReadCallError):
+        strict[2]
+    assert strict[0].seq == 'ACG'

@@ -9,7 +9,9 @@ Mirrors (same names, argument meaning and result fields):
 All per-read arithmetic runs on the GPU (libwarpstr_hip.so); this module only packs buffers, and
 turns state paths into base strings (WarpSTR._get_sequence, src/caller/caller.py:178-187).
 """
+import collections.abc
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -77,10 +79,55 @@ def pack_signals(signals: Sequence[np.ndarray]):
     lens = np.fromiter((len(s) for s in signals), dtype=np.int64, count=len(signals))
     offsets = np.zeros(len(signals) + 1, dtype=np.int64)
     np.cumsum(lens, out=offsets[1:])
-    buf = np.empty(int(offsets[-1]), dtype=np.float64)
-    for s, o in zip(signals, offsets[:-1]):
-        buf[o:o + len(s)] = s
+    if len(signals) == 0:
+        return np.empty(0, dtype=np.float64), offsets
+    buf = np.concatenate(signals)  # one pass in C (a Python loop of slice assignments cost 78 ms per 50k reads)
+    if buf.dtype != np.float64:
+        buf = buf.astype(np.float64)
     return buf, offsets
+
+
+class CallerResults(collections.abc.Sequence):
+    """What CallerWrapper.run returns: a list-like of CallerResult (src/caller/caller.py:46-51) in workload order, backed by
+    the batch's result records and the two ASCII sequence buffers -- a CallerResult (two Python strings) is only built for
+    the reads that are looked at.  The records are also available as columns (`len2`, `cost2`, ...) for batch consumers."""
+
+    def __init__(self, names, records, offsets, seq1: bytes, seq2: bytes, on_error: str):
+        self.names, self.records, self.offsets = names, records, np.asarray(offsets)
+        self._seq1, self._seq2, self._on_error = seq1, seq2, on_error
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        rec = self.records[i]
+        st = int(rec['status'])
+        if st != 0:
+            if self._on_error == 'raise':
+                raise ReadCallError(f'read {self.names[i]}: caller status {_lib.READ_STATUS.get(st, st)}')
+            return CallerResult('', float('nan'), '', float('nan'))
+        o = int(self.offsets[i])
+        return CallerResult(seq=self._seq1[o:o + int(rec['len1'])].decode('ascii'), cost=float(rec['cost1']),
+                            resc_seq=self._seq2[o:o + int(rec['len2'])].decode('ascii'), resc_cost=float(rec['cost2']))
+
+    def check(self):
+        """Raise for the first read the reference would have failed on (on_error='raise'); cheap, vectorised."""
+        bad = np.flatnonzero(self.records['status'] != 0)
+        if len(bad) and self._on_error == 'raise':
+            st = int(self.records['status'][bad[0]])
+            raise ReadCallError(f'read {self.names[bad[0]]}: caller status {_lib.READ_STATUS.get(st, st)}')
+        return self
+
+    def lengths(self):
+        """(len(seq), len(resc_seq)) per read as two integer arrays: all that overview.csv stores of the sequences."""
+        return self.records['len1'].copy(), self.records['len2'].copy()
+
+    def costs(self):
+        return self.records['cost1'].copy(), self.records['cost2'].copy()
 
 
 class HipCaller:
@@ -211,14 +258,28 @@ class HipCaller:
                                                 _lib.ptr(ooff), _lib.ptr(ss)), 'wsx_prepare_signals')
         return out, ooff, ss
 
-    # ---- device-buffer entry point (pointers from torch tensors; asynchronous) -----------------
+    # ---- device-buffer entry points (pointers from torch tensors) ------------------------------
+    def prepare_device(self, raw_ptr: int, raw_offsets: np.ndarray, seg_start: np.ndarray, seg_end: np.ndarray, out_ptr: int,
+                       out_offsets: np.ndarray, spike_removal: str = 'Brute', shift_scale_ptr: int = 0):
+        """wsx_prepare_signals on device buffers: int16 raw reads in HBM -> normalised float64 segments in HBM, laid out
+        by out_offsets (ready for call_device with the same offsets).  Blocks until the segments are written."""
+        raw_offsets = np.ascontiguousarray(raw_offsets, np.int64)
+        seg_start, seg_end = np.ascontiguousarray(seg_start, np.int64), np.ascontiguousarray(seg_end, np.int64)
+        out_offsets = np.ascontiguousarray(out_offsets, np.int64)
+        _lib.check(self.lib.wsx_prepare_signals(self.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(raw_ptr), _lib.ptr(raw_offsets),
+                                                _lib.ptr(seg_start), _lib.ptr(seg_end), len(seg_start),
+                                                1 if spike_removal == 'Brute' else 0, C.c_void_p(out_ptr), _lib.ptr(out_offsets),
+                                                C.c_void_p(shift_scale_ptr or None)), 'wsx_prepare_signals')
+
     def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
-                    trace1_ptr: int = 0, trace2_ptr: int = 0):
+                    trace1_ptr: int = 0, trace2_ptr: int = 0, seq1_ptr: int = 0, seq2_ptr: int = 0):
+        """wsx_call_batch on device buffers; asynchronous (see set_pipelined / join / synchronize)."""
         offsets = np.ascontiguousarray(offsets, np.int64)
         automaton_id = np.ascontiguousarray(automaton_id, np.int32)
         tr = None
-        if trace1_ptr or trace2_ptr:
-            tr = _lib.WsxTraces(C.c_void_p(trace1_ptr or None), C.c_void_p(trace2_ptr or None), None, None, None, None)
+        if trace1_ptr or trace2_ptr or seq1_ptr or seq2_ptr:
+            tr = _lib.WsxTraces(C.c_void_p(trace1_ptr or None), C.c_void_p(trace2_ptr or None), None, None,
+                                C.c_void_p(seq1_ptr or None), C.c_void_p(seq2_ptr or None))
         _lib.check(self.lib.wsx_call_batch(self.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(signal_ptr), _lib.ptr(offsets),
                                            _lib.ptr(automaton_id), len(automaton_id), C.c_void_p(results_ptr),
                                            C.byref(tr) if tr is not None else None), 'wsx_call_batch')
@@ -273,32 +334,77 @@ def sequence_from_trace(table: AutomatonTable, flank_length: int, trace: np.ndar
 class CallerWrapper:
     """Step-3 driver for one locus (src/caller/wrapper.py:57-120).
 
-    ``flanks`` = (left_template, right_template, left_reverse, right_reverse), i.e. what the
-    squiggler step stores in expected_signals/sequences.csv and ``load_flanks`` reads back.
+    Two call shapes:
+      CallerWrapper(locus, threads)  -- the reference's own (wrapper.py:63-70): `locus` is any object with `.path`,
+          `.sequence` and `.flank_length` (src/schemas/locus.py); the flanks are read from
+          <locus.path>/expected_signals/sequences.csv and summaries/state_similarity.csv is written, as upstream does.
+      CallerWrapper(sequence, flanks, flank_length, threads=1, ...)  -- without a locus directory;
+          ``flanks`` = (left_template, right_template, left_reverse, right_reverse).
     ``threads`` is accepted for interface compatibility; reads are fanned out over GPU wavefronts.
     """
 
-    def __init__(self, sequence: str, flanks: Sequence[str], flank_length: int, threads: int = 1,
+    def __init__(self, locus_or_sequence, flanks_or_threads=None, flank_length: Optional[int] = None, threads: int = 1,
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
-                 device: int = 0, pore_model=None, on_error: str = 'raise'):
-        self.sequence = sequence.upper()
-        self.flank_length = int(flank_length)
-        self.threads = threads
+                 device: int = 0, pore_model=None, on_error: str = 'raise', flanks: Optional[Sequence[str]] = None):
+        from .pore_model import default_pore_model
+        self.caller_config = caller_config or CallerConfig()
+        self.pore_model = pore_model or default_pore_model()
+        if isinstance(locus_or_sequence, str):
+            self.locus = None
+            self.sequence = locus_or_sequence.upper()
+            flanks = flanks if flanks is not None else flanks_or_threads
+            self.flank_length = int(flank_length)
+            self.threads = threads
+        else:
+            from . import overview as ov
+            self.locus = locus_or_sequence
+            self.sequence = self.locus.sequence.upper()
+            self.flank_length = int(self.locus.flank_length)
+            self.threads = int(flanks_or_threads) if flanks_or_threads is not None else threads
+            flanks = ov.load_flanks(self.locus.path)
+            self.check_high_similarity(self.sequence)
         self.on_error = on_error
         lt, rt, lr, rr = flanks
         self.temp_sta, self.rev_sta = locus_automata(lt, rt, lr, rr, self.sequence, pore_model)
-        self.hip = HipCaller([self.temp_sta, self.rev_sta], [self.flank_length, self.flank_length], caller_config,
+        self.hip = HipCaller([self.temp_sta, self.rev_sta], [self.flank_length, self.flank_length], self.caller_config,
                              rescaler_config, device=device)
 
-    def run(self, workload: List[ReadSignal]) -> List[CallerResult]:
+    def check_high_similarity(self, sequence: str, out_dir: Optional[str] = None):
+        """Similarity of consecutive state levels per repeat unit (src/caller/wrapper.py:122-160): writes
+        <locus.path>/summaries/state_similarity.csv (same columns and %.3f formatting), prints upstream's warnings for
+        units whose mean or median level difference is below caller_config.min_state_similarity, and returns
+        (template_problems, reverse_problems)."""
+        from .automata import reverse_pattern
+        diffs_t = self.pore_model.get_diffs_for_all(sequence)
+        diffs_r = self.pore_model.get_diffs_for_all(reverse_pattern(sequence))
+        if out_dir is None and self.locus is not None:
+            out_dir = os.path.join(self.locus.path, 'summaries')
+        if out_dir is not None:
+            os.makedirs(out_dir, exist_ok=True)
+            with open(os.path.join(out_dir, 'state_similarity.csv'), 'w') as f:
+                f.write('pattern,strand,mean_diff,median_diff\n')
+                for k, (mean, med) in diffs_t.items():
+                    f.write(f'{k},template,{mean:.3f},{med:.3f}\n')
+                for k, (mean, med) in diffs_r.items():
+                    f.write(f'{k},reverse,{mean:.3f},{med:.3f}\n')
+        lim = self.caller_config.min_state_similarity
+        problems = [[dict(pattern=k, mean_diff=mean, median_diff=med) for k, (mean, med) in d.items() if lim > mean or lim > med]
+                    for d in (diffs_t, diffs_r)]
+        for p in problems[0]:
+            print('Warning: Template has repeat unit {} with high state similarity'.format(p['pattern']))
+        for p in problems[1]:
+            print('Warning: high similarity of state values in reverse pattern {}'.format(p['pattern']))
+        return problems[0], problems[1]
+
+    def run(self, workload: List[ReadSignal]) -> 'CallerResults':
         """Run the caller for each piece of signal in the workload; results align with the workload."""
         if not workload:
             return []
-        signal, offsets = pack_signals([np.asarray(w.signal, dtype=np.float64) for w in workload])
+        signal, offsets = pack_signals([np.asarray(w.signal) for w in workload])
         return self._run_packed([w.name for w in workload], [w.reverse for w in workload], signal, offsets)
 
     def run_raw(self, names: Sequence[str], reverses: Sequence[bool], raws: Sequence[np.ndarray],
-                positions: Sequence[Sequence[int]], spike_removal: str = 'Brute') -> List[CallerResult]:
+                positions: Sequence[Sequence[int]], spike_removal: str = 'Brute') -> 'CallerResults':
         """Same as run(), from raw DAC reads: spike removal, whole-read normalisation and the slice
         [l_start_raw, r_end_raw] (Fast5.get_data_processed, src/schemas/fast5.py:45-57) happen on the GPU."""
         if not names:
@@ -306,24 +412,8 @@ class CallerWrapper:
         signal, offsets, _ = self.hip.prepare_signals(raws, positions, spike_removal)
         return self._run_packed(list(names), list(reverses), signal, offsets)
 
-    def _run_packed(self, names, reverses, signal, offsets) -> List[CallerResult]:
-        aut = np.array([1 if r else 0 for r in reverses], dtype=np.int32)
+    def _run_packed(self, names, reverses, signal, offsets) -> 'CallerResults':
+        aut = np.fromiter((1 if r else 0 for r in reverses), dtype=np.int32, count=len(names))
         res, extra = self.hip.call(signal, offsets, aut, want_seqs=True)
-        out: List[CallerResult] = []
-        # plain Python lists and one bytes object per pass: per-read numpy scalar access would dominate big batches
-        status, offs = res['status'].tolist(), np.asarray(offsets).tolist()
-        len1, len2 = res['len1'].tolist(), res['len2'].tolist()
-        cost1, cost2 = res['cost1'].tolist(), res['cost2'].tolist()
-        b1, b2 = extra['seq1'].tobytes(), extra['seq2'].tobytes()
-        for i, name in enumerate(names):
-            st = status[i]
-            if st != 0:
-                msg = f'read {name}: caller status {_lib.READ_STATUS.get(st, st)}'
-                if self.on_error == 'raise':
-                    raise ReadCallError(msg)
-                out.append(CallerResult('', float('nan'), '', float('nan')))
-                continue
-            o = offs[i]
-            out.append(CallerResult(seq=b1[o:o + len1[i]].decode('ascii'), cost=cost1[i],
-                                    resc_seq=b2[o:o + len2[i]].decode('ascii'), resc_cost=cost2[i]))
-        return out
+        out = CallerResults(names, res, offsets[:-1], extra['seq1'].tobytes(), extra['seq2'].tobytes(), self.on_error)
+        return out.check()

@@ -237,17 +237,23 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
     __builtin_amdgcn_wave_barrier();
 }
 
-#ifdef WSX_FILL_MAX_WAVES
-#define WSX_FILL_OCC __attribute__((amdgpu_waves_per_eu(1, WSX_FILL_MAX_WAVES)))
+// Occupancy knob (experiment builds, -DWSX_FILL_FORCE_WAVES): wavefronts per SIMD the register allocator has to make room
+// for (512 VGPRs per SIMD lane: 5 waves = 96 registers each, 4 = 128, 3 = 168).  Left alone the compiler takes 116 registers
+// for two slots and 168 for four (4 and 3 waves per SIMD).  Forcing 5 and 4 waves keeps the instruction counts of the 8-row
+// blocks and spills 0-190 bytes per lane around them -- and was measured slower: two slots 2.44 vs 2.47 ms per launch (no
+// gain), four slots 6.0 vs 5.4 ms (profiles/r02_occupancy_forcing.log).  Not the lever; default off.
+__host__ __device__ constexpr int fill_min_waves(int K, int FL) { return (K <= 1 || FL != 1) ? 1 : K == 2 ? 5 : K <= 4 ? 4 : 3; }
+#ifdef WSX_FILL_FORCE_WAVES
+#define WSX_FILL_OCC(K, FL) __attribute__((amdgpu_waves_per_eu(fill_min_waves(K, FL))))
 #else
-#define WSX_FILL_OCC
+#define WSX_FILL_OCC(K, FL)
 #endif
 
 template <int M, int K, int F, int FL, bool PK>
 #ifndef WSX_FILL_WPB
 #define WSX_FILL_WPB 4 // wavefronts (= reads) per workgroup
 #endif
-__global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC void dtw_fill_fast(PassArgs a)
+__global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL) void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
@@ -563,13 +569,16 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
     const double v0 = A.value[0];
     const double start_val = fabs(sig[0] - v0);
     if (lane == 0) lds[0] = start_val;
-    if (lane >= 1 && lane <= m && lane < S) lds[lane] = start_val + fabs(sig[lane] - v0);
+    for (int j = lane; j <= m && j < S; j += 64) // (min_values_per_state may exceed the 64 lanes)
+        if (j >= 1) lds[j] = start_val + fabs(sig[j] - v0);
     const long long boundary = (long long)A.flank_length - 10;
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
     const long long first_threshold = 6 * boundary, second_threshold = (long long)T - 6 * boundary;
     __builtin_amdgcn_wave_barrier();
-    uint32_t bpw[WSX_MAX_K * 2];
-    for (int k = 0; k < K; k++) bpw[k] = 0;
+    // the pointer words being filled (8 rows x 4 bits per state) live in LDS behind the ring: K is a run-time value here
+    // (any number of slots the ring has room for), so a per-thread array would have no static size
+    uint32_t *bpw = (uint32_t *)(lds + (size_t)ring * SP);
+    for (int k = 0; k < K; k++) bpw[k * 64 + lane] = 0;
     for (int i = 1; i < T; i++) {
         const bool real = i >= m;
         int back = m;
@@ -605,15 +614,15 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
                     }
                 }
             }
-            bpw[k] |= ptr << ((i % R) * PB);
+            bpw[k * 64 + lane] |= ptr << ((i % R) * PB);
             // this row's inputs (rows i-1 and i-back) live in other ring rows
             row[j] = best;
         }
         if ((i % R) == R - 1 || i == T - 1) {
             const int wi = i / R;
             for (int k = 0; k < K; k++) {
-                bp[((size_t)wi * K + k) * 64 + lane] = bpw[k];
-                bpw[k] = 0;
+                bp[((size_t)wi * K + k) * 64 + lane] = bpw[k * 64 + lane];
+                bpw[k * 64 + lane] = 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1142,7 +1151,7 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
 #else
     if (a.n_launch <= 0) return hipSuccess;
     if (generic) {
-        const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double);
+        const size_t shmem = (size_t)(m + 1) * K * 64 * sizeof(double) + (size_t)K * 64 * sizeof(uint32_t);
         hipLaunchKernelGGL(dtw_fill_generic, dim3(a.n_launch), dim3(64), shmem, s, a, K);
         return hipGetLastError();
     }

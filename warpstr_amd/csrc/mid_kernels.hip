@@ -67,91 +67,76 @@ __device__ __forceinline__ double pw_block_inl(const L &ld, int o, int n) // n <
     return res;
 }
 
+// The recursion  sum(a,n) = sum(a,n2) + sum(a+n2,n-n2),  n2 = n/2 - (n/2)%8,  of NumPy's pairwise summation for n > 128,
+// walked leaf by leaf without a call and without a local array: `path` says, per depth, whether the walk is in a right
+// child; the finished left siblings wait in five registers (enough for 2048 elements: each half is at most n/2 + 7 long)
+// and, deeper down, in GLOBAL memory the caller points at (>= 27 doubles owned by the calling thread; only inputs of more
+// than 2048 elements -- a run of that many samples, that many runs in a repeat -- ever touch it).  A local stack array or a
+// non-inlined helper would give the whole kernel a private segment, and the runtime reserves that segment for every
+// wave slot of the device on every stream: 448 bytes made 0.9 GB of device memory disappear on the first call.
 template <class L>
-__device__ __attribute__((noinline)) double pw_block(const L &ld, int o, int n) // n <= 128
+__device__ __forceinline__ double pw_tree(const L &ld, int n, double *gstack)
 {
-    if (n < 8) {
-        double res = 0.0;
-        for (int i = 0; i < n; i++) res += ld(o + i);
-        return res;
-    }
-    double r0 = ld(o), r1 = ld(o + 1), r2 = ld(o + 2), r3 = ld(o + 3), r4 = ld(o + 4), r5 = ld(o + 5), r6 = ld(o + 6),
-           r7 = ld(o + 7);
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += ld(o + i);
-        r1 += ld(o + i + 1);
-        r2 += ld(o + i + 2);
-        r3 += ld(o + i + 3);
-        r4 += ld(o + i + 4);
-        r5 += ld(o + i + 5);
-        r6 += ld(o + i + 6);
-        r7 += ld(o + i + 7);
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += ld(o + i);
-    return res;
-}
-
-// Explicit-stack form of the recursion  sum(a,n) = sum(a,n2) + sum(a+n2,n-n2),  n2 = n/2 - (n/2)%8.
-template <class L>
-__device__ __attribute__((noinline)) double pw_big(const L &ld, int n)
-{
-    // post-order evaluation; depth <= 24 covers n up to 2^31
-    int so[26], sn[26];
-    double sv[26];
-    unsigned char st[26];
-    int sp = 0;
-    so[0] = 0;
-    sn[0] = n;
-    st[0] = 0;
-    double ret = 0.0;
-    while (sp >= 0) {
-        const int o = so[sp], nn = sn[sp];
-        if (nn <= 128) {
-            ret = pw_block(ld, o, nn);
-            sp--;
-            continue;
+    double l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0;
+    auto put = [&](int d, double v) {
+        if (d == 1) l1 = v;
+        else if (d == 2) l2 = v;
+        else if (d == 3) l3 = v;
+        else if (d == 4) l4 = v;
+        else if (d == 5) l5 = v;
+        else gstack[d] = v;
+    };
+    auto get = [&](int d) -> double { return d == 1 ? l1 : d == 2 ? l2 : d == 3 ? l3 : d == 4 ? l4 : d == 5 ? l5 : gstack[d]; };
+    unsigned int path = 0u;
+    int d = 0, o = 0, nn = n;
+    while (true) {
+        while (nn > 128) { // down to the leftmost leaf below this node
+            int n2 = nn / 2;
+            n2 -= n2 % 8;
+            d++;
+            path &= ~(1u << d);
+            nn = n2;
         }
-        int n2 = nn / 2;
-        n2 -= n2 % 8;
-        if (st[sp] == 0) {
-            st[sp] = 1;
-            sp++;
-            so[sp] = o;
-            sn[sp] = n2;
-            st[sp] = 0;
-        } else if (st[sp] == 1) {
-            sv[sp] = ret; // left result
-            st[sp] = 2;
-            sp++;
-            so[sp] = o + n2;
-            sn[sp] = nn - n2;
-            st[sp] = 0;
-        } else {
-            ret = sv[sp] + ret;
-            sp--;
+        double ret = pw_block_inl(ld, o, nn);
+        while (d > 0 && ((path >> d) & 1u)) { // a right child: left sibling + this, and up
+            ret = get(d) + ret;
+            d--;
+        }
+        if (d == 0) return ret;
+        put(d, ret); // a left child: wait for the right sibling
+        path |= 1u << d;
+        o = 0;
+        nn = n;
+        for (int e = 1; e <= d; e++) { // offset and length of that sibling: from the root along the path
+            int n2 = nn / 2;
+            n2 -= n2 % 8;
+            if ((path >> e) & 1u) {
+                o += n2;
+                nn -= n2;
+            } else {
+                nn = n2;
+            }
         }
     }
-    return ret;
 }
 
 template <class L>
-__device__ __forceinline__ double np_pairwise_sum(const L &ld, int n)
+__device__ __forceinline__ double np_pairwise_sum(const L &ld, int n, double *gstack)
 {
-    if (n <= 128) return pw_block(ld, 0, n);
-    return pw_big(ld, n); // rare: runs longer than 128 samples
+    if (n <= 128) return pw_block_inl(ld, 0, n);
+    return pw_tree(ld, n, gstack);
 }
 
 // mean and std of one run (np.average / np.std of the run's samples)
-__device__ __forceinline__ void run_mean_std(const double *sig, int s0, int len, double &mean, double &sd)
+// gstack: >= 27 doubles of global scratch for this thread, touched only for runs of more than 2048 samples
+__device__ __forceinline__ void run_mean_std(const double *sig, int s0, int len, double &mean, double &sd, double *gstack)
 {
-    mean = np_pairwise_sum(LoadPlain{sig + s0}, len) / (double)len;
-    sd = sqrt(np_pairwise_sum(LoadSqDev{sig + s0, mean}, len) / (double)len);
+    mean = np_pairwise_sum(LoadPlain{sig + s0}, len, gstack) / (double)len;
+    sd = sqrt(np_pairwise_sum(LoadSqDev{sig + s0, mean}, len, gstack) / (double)len);
 }
 
 // k-th order statistic (0-based) of a[0..n) by rank counting; ties broken by index.
-__device__ double select_rank(const double *a, int n, int kth)
+__device__ __forceinline__ double select_rank(const double *a, int n, int kth)
 {
     for (int i = 0; i < n; i++) {
         const double x = a[i];
@@ -165,7 +150,7 @@ __device__ double select_rank(const double *a, int n, int kth)
     return a[0];
 }
 
-__device__ __attribute__((noinline)) double np_median(const double *a, int n)
+__device__ __forceinline__ double np_median(const double *a, int n)
 {
     if (n & 1) return select_rank(a, n, n / 2);
     return (select_rank(a, n, n / 2 - 1) + select_rank(a, n, n / 2)) / 2.0;
@@ -295,7 +280,8 @@ __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
                 val = pw_block_inl(LoadPlain{p}, 0, len) / (double)len;
                 sd = sqrt(pw_block_inl(LoadSqDev{p, val}, 0, len) / (double)len);
             } else {
-                run_mean_std(sig, s0, len, val, sd);
+                // (a run of more than 2048 samples owns that many doubles of the per-sample scratch: room for the stack)
+                run_mean_std(sig, s0, len, val, sd, a.scr0 + v.off + s0);
             }
             if (a.prm.method_median) val = np_median(sig + s0, len);
             const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
@@ -340,7 +326,7 @@ __global__ __launch_bounds__(64) void reps_stats_kernel(MidArgs a)
         const int len = cnt[j];
         if (len == 0) continue;
         double val, sd;
-        run_mean_std(gs, stoff[j], len, val, sd);
+        run_mean_std(gs, stoff[j], len, val, sd, a.scr1 + v.off + stoff[j]);
         if (a.prm.method_median) val = np_median(gs + stoff[j], len);
         const double expd = A.value[j];
         const bool good = (len >= a.prm.m) && (sd < a.prm.max_std) && (fabs(expd - val) <= a.prm.threshold);
@@ -471,7 +457,15 @@ __global__ __launch_bounds__(256) void borders_kernel(MidArgs a)
         py_slice(start, end, na, &clo, &chi);
         if (chi > clo) {
             const int len = chi - clo;
-            const double sum = len <= 128 ? pw_block_wave(alc + clo, len, lane) : np_pairwise_sum(LoadPlain{alc + clo}, len);
+            // (more than 2048 records: the stack lives in the read's slice of the per-sample scratch; every lane computes
+            // the same sum, so only lane 0 may write there)
+            double sum;
+            if (len <= 128) sum = pw_block_wave(alc + clo, len, lane);
+            else if (len <= 2048) sum = np_pairwise_sum(LoadPlain{alc + clo}, len, nullptr);
+            else {
+                sum = lane == 0 ? np_pairwise_sum(LoadPlain{alc + clo}, len, a.scr1 + v.off) : 0.0;
+                sum = readlane_f64(sum, 0);
+            }
             cost = sum / (double)len;
         }
         rec.start = start;
@@ -583,7 +577,7 @@ __global__ __launch_bounds__(64) void borders_thread_kernel(MidArgs a)
     if (status == 0) {
         int clo, chi;
         py_slice(start, end, na, &clo, &chi);
-        if (chi > clo) cost = np_pairwise_sum(LoadPlain{alc + clo}, chi - clo) / (double)(chi - clo);
+        if (chi > clo) cost = np_pairwise_sum(LoadPlain{alc + clo}, chi - clo, a.scr1 + v.off) / (double)(chi - clo);
         rec.start = start;
         rec.nsel = nsel;
         rec.p_lo = v.fend(start) - 1 - 3;

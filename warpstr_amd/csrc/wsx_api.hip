@@ -223,6 +223,7 @@ struct wsx_caller {
     bool pipelined = false;                     // wsx_caller_set_pipelined
     uint64_t call_seq = 0;
     int rot = 0; // pipelined calls with fewer chunks than streams: the first work set / stream of the next call
+    int chunks_override = 0; // WSX_CHUNKS at creation: chunks per call (tuning knob)
     hipStream_t join_st = nullptr; // pipelined calls end here instead of on the handle's stream
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -284,15 +285,32 @@ int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b, int32_t reads)
     return WSX_SUCCESS;
 }
 
-// bytes of workspace per sample / per read for a full call
+// bytes of workspace per sample of ONE work set, as run_batch allocates it: the per-sample arrays, the back-pointer scratch
+// of every distinct kernel variant of the handle (each has a region of its own), and for host buffers the staging areas
 size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 {
-    size_t maxbp = 0;
-    for (auto &v : c->variant) maxbp = std::max(maxbp, v.bp_words(4096, 1) * 4 / 4096 + 1);
+    size_t bp = 0;
+    std::vector<Variant> seen;
+    for (auto &v : c->variant) {
+        bool dup = false;
+        for (auto &u : seen) dup = dup || u.same(v);
+        if (dup) continue;
+        seen.push_back(v);
+        bp += v.bp_words(4096, 0) * 4 / 4096 + 1;
+    }
     size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 24 /*scratch*/ +
-               1 /*mask bits, rounded up*/ + maxbp;
-    if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 1) : 0);
+               1 /*mask bits, rounded up*/ + bp;
+    if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 3) : 0);
     return b + 8; // alignment slack
+}
+// ... and per read: the per-read arrays, the spare rows of the back-pointer regions, reps_as_one scratch, staged rows
+size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
+{
+    size_t b = 168 + sizeof(wsx_result) + 64;
+    for (auto &v : c->variant) b += v.bp_words(0, 1) * 4;
+    if (c->prm.reps_as_one) b += 2 * (size_t)c->max_states * sizeof(int32_t);
+    if (host_mem) b += 16 + last_row_bytes;
+    return b;
 }
 
 __global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, int first_read, int64_t base_off, int n,
@@ -352,6 +370,10 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         return WSX_ERR_INVALID;
     }
     wsx_caller *c = new wsx_caller();
+    struct Guard { // every failure below releases what has been built so far (wsx_caller_destroy takes partial handles)
+        wsx_caller *c;
+        ~Guard() { if (c) wsx_caller_destroy(c); }
+    } guard{c};
     c->device = device;
     c->stream = (hipStream_t)stream;
     c->prm = *params;
@@ -364,20 +386,22 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         if (A.n_states <= 0 || A.n_states > 65535 || A.endstate < 0 || A.endstate >= A.n_states || !A.value ||
             !A.seq_idx || !A.pred_ptr || !A.pred_idx || !A.repeat_mask) {
             g_err = "wsx_caller_create: malformed automaton";
-            delete c;
             return WSX_ERR_INVALID;
         }
-        const int S = A.n_states, E = A.pred_ptr[S];
+        const int S = A.n_states;
+        if (A.pred_ptr[0] != 0) {
+            g_err = "wsx_caller_create: pred_ptr[0] must be 0";
+            return WSX_ERR_INVALID;
+        }
         for (int j = 0; j < S; j++)
             if (A.pred_ptr[j + 1] < A.pred_ptr[j]) {
                 g_err = "wsx_caller_create: pred_ptr not monotone";
-                delete c;
                 return WSX_ERR_INVALID;
             }
+        const int E = A.pred_ptr[S]; // (only now known to be >= 0)
         for (int e = 0; e < E; e++)
             if (A.pred_idx[e] < 0 || A.pred_idx[e] >= S) {
                 g_err = "wsx_caller_create: predecessor index out of range";
-                delete c;
                 return WSX_ERR_INVALID;
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
@@ -498,12 +522,10 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         if (v.generic) {
             if (mf > 15) {
                 g_err = "automaton fan-in > 15 is not supported";
-                delete c;
                 return WSX_ERR_UNSUPPORTED;
             }
-            if ((size_t)(c->prm.min_values_per_state + 1) * v.K * 64 * 8 > 150 * 1024) {
+            if ((size_t)(c->prm.min_values_per_state + 1) * v.K * 64 * 8 + (size_t)v.K * 64 * 4 > 150 * 1024) {
                 g_err = "automaton too large for the generic DP kernel's LDS ring";
-                delete c;
                 return WSX_ERR_UNSUPPORTED;
             }
         } else {
@@ -521,6 +543,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_joins[0], hipEventDisableTiming));
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
+    if (const char *e = getenv("WSX_CHUNKS")) c->chunks_override = std::max(1, atoi(e));
     if (const char *e = getenv("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     if (const char *e = getenv("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
     // The streams one call spreads over exist from the start; the others (small pipelined calls taking turns) are created
@@ -531,6 +554,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
     }
+    guard.c = nullptr;
     *out = c;
     return WSX_SUCCESS;
 }
@@ -644,6 +668,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 int wsx_internal_device(wsx_caller *c) { return c->device; }
 hipStream_t wsx_internal_stream(wsx_caller *c) { return c->stream; }
 void wsx_internal_set_error(const char *msg) { g_err = msg; }
+uint64_t wsx_internal_workspace_limit(wsx_caller *c) { return c->ws_limit; }
 // buffer `slot` of the signal loader's pool, at least `bytes` large (grown when needed, freed with the handle)
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p)
 {
@@ -756,17 +781,22 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     // ---- chunk plan -----------------------------------------------------------------------------
     const size_t psb = per_sample_bytes(c, host, want_traces || !full);
-    const size_t prb = 256 + (size_t)(io.last_row && host ? c->max_states * 8 : 0);
+    const size_t prb = per_read_bytes(c, host, io.last_row ? (size_t)std::max(io.last_row_stride, 0) * 8 : 0);
+    // The limit covers everything the call allocates: up to streams_per_call work sets exist side by side, and a buffer
+    // grows with 12.5 % headroom (DeviceBuf) -- so one chunk may take limit / sets / 1.125.
+    const size_t sets = (size_t)std::max(1, std::min(c->n_streams, c->streams_per_call));
+    const size_t chunk_limit = (size_t)((double)c->ws_limit / (double)sets / 1.125);
     std::vector<ChunkPlan> chunks;
-    {
+    auto chunk_need = [&](int64_t samples, int64_t reads) { return (size_t)samples * psb + (size_t)reads * prb; };
+    auto greedy_plan = [&]() { // as many reads per chunk as the limit allows (ragged batches, or when the even split fails)
+        chunks.clear();
         int64_t first = 0;
         while (first < n) {
             int64_t cnt = 0, smp = 0;
             int mt = 0;
             while (first + cnt < n) {
                 const int64_t T = io.offsets[first + cnt + 1] - io.offsets[first + cnt];
-                const size_t need = (size_t)(smp + T) * psb + (size_t)(cnt + 1) * prb;
-                if (cnt > 0 && need > c->ws_limit) break;
+                if (cnt > 0 && chunk_need(smp + T, cnt + 1) > chunk_limit) break;
                 smp += T;
                 cnt++;
                 mt = std::max<int>(mt, (int)T);
@@ -774,30 +804,36 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             chunks.push_back({first, cnt, io.offsets[first], smp, mt});
             first += cnt;
         }
-    }
-    // Big single-chunk batches are split so that chunks can overlap on the two streams (the latency-bound stages of
-    // one chunk run under the VALU-bound fill of another).  The thread-per-read stages want launches of ~25k reads, so
-    // a second round of chunks per stream only pays from ~200k reads on, or when reads are long (their serial stages
-    // then last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.
-    // WSX_CHUNKS overrides the split count (tuning knob).
+    };
+    // How many chunks: big batches are split so that chunks can overlap on the streams (the latency-bound stages of one
+    // chunk run under the VALU-bound fill of another).  The thread-per-read stages want launches of ~25k reads, so a
+    // second round of chunks per stream only pays from ~200k reads on, or when reads are long (their serial stages then
+    // last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.  Small
+    // pipelined calls: two chunks, consecutive calls on alternating pairs of streams -- two calls side by side fill the
+    // chip better than one call cut into four (profiles/r02_small_call_sweep.log).  WSX_CHUNKS (read when the handle is
+    // created) overrides the count.  The workspace limit may ask for more chunks than that.
     const int spc = std::min(c->n_streams, c->streams_per_call);
-    // (small pipelined calls: two chunks, consecutive calls on alternating pairs of streams -- two calls side by side fill
-    // the chip better than one call cut into four; profiles/r02_small_call_sweep.log)
-    const bool small_call = (io.offsets[n] - io.offsets[0]) < (int64_t)80 << 20;
-    if (chunks.size() == 1 && n >= 4096) {
-        int want = (n >= 8192 && !(pipe && small_call)) ? spc : 2;
+    const int64_t total_samples = io.offsets[n] - io.offsets[0];
+    const bool small_call = total_samples < (int64_t)80 << 20;
+    int want = 1;
+    if (n >= 4096) {
+        want = (n >= 8192 && !(pipe && small_call)) ? spc : 2;
         if (n >= 32768) {
-            const bool long_reads = chunks[0].samples / n >= 4096;
+            const bool long_reads = total_samples / n >= 4096;
             const int64_t per_round = (int64_t)25000 * spc;
             want = spc * ((long_reads || 2 * n >= 3 * per_round) ? 2 : 1);
         }
         if (spc == 1) want = 1;
-        if (const char *e = getenv("WSX_CHUNKS")) want = std::max(1, atoi(e));
-        const ChunkPlan whole = chunks[0];
-        chunks.clear();
+        if (c->chunks_override > 0) want = c->chunks_override;
+    }
+    {
+        const size_t by_limit = (chunk_need(total_samples, n) + chunk_limit - 1) / chunk_limit;
+        if (by_limit > (size_t)want) want = (int)((by_limit + spc - 1) / spc * spc); // whole rounds of the streams
+        want = (int)std::min<int64_t>(want, n);
         int64_t first = 0;
+        bool fits = true;
         for (int part = 0; part < want && first < n; part++) {
-            const int64_t target = whole.samples * (part + 1) / want; // cumulative samples at the end of this part
+            const int64_t target = total_samples * (part + 1) / want; // cumulative samples at the end of this part
             int64_t cnt = 0;
             int mt = 0;
             while (first + cnt < n && (io.offsets[first + cnt] - io.offsets[0] < target || part == want - 1)) {
@@ -805,9 +841,12 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 cnt++;
             }
             if (cnt == 0) continue;
-            chunks.push_back({first, cnt, io.offsets[first], io.offsets[first + cnt] - io.offsets[first], mt});
+            const int64_t smp = io.offsets[first + cnt] - io.offsets[first];
+            fits = fits && (cnt == 1 || chunk_need(smp, cnt) <= chunk_limit);
+            chunks.push_back({first, cnt, io.offsets[first], smp, mt});
             first += cnt;
         }
+        if (!fits) greedy_plan();
     }
     size_t max_smp = 0, max_cnt = 0;
     for (auto &ch : chunks) {

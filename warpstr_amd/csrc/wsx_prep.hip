@@ -392,6 +392,7 @@ int wsx_internal_device(wsx_caller *c);
 hipStream_t wsx_internal_stream(wsx_caller *c);
 void wsx_internal_set_error(const char *msg);
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p);
+uint64_t wsx_internal_workspace_limit(wsx_caller *c);
 
 #define PCHK(expr)                                                                                       \
     do {                                                                                                 \
@@ -440,7 +441,10 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
     PCHK(hipSetDevice(wsx_internal_device(c)));
     hipStream_t st = wsx_internal_stream(c);
     const bool host = mem == WSX_MEM_HOST;
-    const int64_t chunk_reads = 4096; // 1 GiB of histograms
+    // a histogram of 65 536 counters (256 KiB) per read, of which only the read's occupied value range is ever touched: half
+    // the handle's workspace limit goes to them (default 16 GiB -> 32 768 reads per chunk; 288 GB of HBM take 100k short
+    // reads in one go, where 4 096-read chunks spent most of a call on launches and synchronisation)
+    const int64_t chunk_reads = std::max<int64_t>(4096, (int64_t)(wsx_internal_workspace_limit(c) / 2 / (65536 * 4)));
     uint32_t *d_hist = nullptr;
     // every device buffer of this function lives in the handle's pool (slot 0: histograms, 1..: per-chunk buffers): a
     // fresh hipMalloc / hipFree of ~1.5 GB per call cost a third of the call

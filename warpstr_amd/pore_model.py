@@ -76,6 +76,36 @@ class PoreModel:
         return np.array([self.get_value(sequence[i:i + k]) for i in range(len(sequence) - k + 1)], dtype=np.float64)
 
 
+    def _get_consecutive_diff(self, pattern: str):
+        """Mean and median |difference| between the expected levels of consecutive k-mers of a repeated unit
+        (src/squiggler/pore_model.py:34-43).  Like upstream, a one-base unit runs past the repeated pattern
+        (IndexError there; here too)."""
+        rep = pattern * self.kmersize
+        kmers = [rep[i:self.kmersize + i] for i in range(len(pattern) + 1)]
+        if any(len(k) != self.kmersize for k in kmers):
+            raise IndexError(f'repeat unit {pattern!r} is too short for {self.kmersize}-mers')
+        pore_values = np.abs(np.diff([self.get_value(k) for k in kmers]))
+        return np.mean(pore_values), np.median(pore_values)
+
+    def get_diffs_for_all(self, sequence: str):
+        """{unit: (mean_diff, median_diff)} for every bracketed unit of a locus pattern, IUPAC codes expanded
+        (src/squiggler/pore_model.py:49-71; same insertion order, later duplicates overwrite earlier ones)."""
+        import re
+        iupac = {'R': 'AG', 'Y': 'CT', 'S': 'GC', 'W': 'AT', 'K': 'GT', 'M': 'AC', 'B': 'CGT', 'D': 'AGT', 'H': 'ACT', 'V': 'ACG',
+                 'N': 'ACGT'}  # src/templates.py:32-44
+        diffs = {}
+        for r in re.findall(r'[\(\{].*?[\)\}]', sequence):
+            patterns = ['']
+            for char in (c for c in r if c not in '(){}'):
+                if char not in iupac:
+                    patterns = [p + char for p in patterns]
+                else:
+                    patterns = [p + alt for alt in iupac[char] for p in patterns]
+            for p in patterns:
+                diffs[p] = self._get_consecutive_diff(p)
+        return diffs
+
+
 _default: Optional[PoreModel] = None
 
 

@@ -58,29 +58,49 @@ def get_raw_workload(df_overview, path: str, raw_reader: Callable[[str], np.ndar
     return names, reverses, raws, positions
 
 
-def main_wrapper(locus_path: str, sequence: str, flank_length: int, threads: int = 1,
+class LocusPath:
+    """The three attributes of upstream's Locus (src/schemas/locus.py) that step 3 reads."""
+
+    def __init__(self, path: str, sequence: str, flank_length: int, name: Optional[str] = None):
+        self.path, self.sequence, self.flank_length = path, sequence.upper(), int(flank_length)
+        self.name = name or os.path.basename(os.path.normpath(path))
+
+
+def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
-                 signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None, device: int = 0):
+                 signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None, device: int = 0, **kwargs):
+    """Load data for calling and handle results (src/caller/wrapper.py:17-41).
+
+    main_wrapper(locus, threads) -- the reference's call: `locus` is any object with `.path`, `.sequence`, `.flank_length`.
+    main_wrapper(locus_path, sequence, flank_length[, threads]) -- the same without a Locus object.
+    Returns (df_overview, df_collapsed) and writes what upstream writes except the plots: overview.csv columns,
+    predictions/sequences/*.fasta, summaries/state_similarity.csv, and for loci with several repeat units
+    predictions/complexSTR_analysis/complex_repeat_units.csv."""
+    if isinstance(locus, str):  # (locus_path, sequence, flank_length[, threads])
+        locus = LocusPath(locus, threads, flank_length)
+        threads = args[0] if args else kwargs.pop('threads', 1)
+    if kwargs:
+        raise TypeError(f'main_wrapper: unexpected arguments {sorted(kwargs)}')
     caller_config = caller_config or CallerConfig()
-    overview_path, df_overview = ov.load_overview(locus_path)
-    cw = CallerWrapper(sequence, ov.load_flanks(locus_path), flank_length, threads, caller_config, rescaler_config,
-                       device=device)
+    overview_path, df_overview = ov.load_overview(locus.path)
+    cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device)
     if signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
         # default: int16 reads straight from the .fast5 files, prepared on the GPU
-        names, reverses, raws, positions = get_raw_workload(df_overview, locus_path)
+        names, reverses, raws, positions = get_raw_workload(df_overview, locus.path)
         results = cw.run_raw(names, reverses, raws, positions, caller_config.spike_removal)
     else:
-        workload = get_workload(df_overview, locus_path, signal_loader or _fast5_loader(caller_config.spike_removal))
+        workload = get_workload(df_overview, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
         reverses = [w.reverse for w in workload]
         results = cw.run(workload)
     seq_results = [(r.seq, r.resc_seq) for r in results]
     cost_results = [(r.cost, r.resc_cost) for r in results]
-    df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus_path)
+    df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus.path)
     df_collapsed = None
-    units, repeat_units, offsets = break_into_units(sequence.upper())
+    units, repeat_units, offsets = break_into_units(locus.sequence.upper())
     if len(units) > 1:
+        print(f'Running complex genotyping as complex repeat units present: {units}')
         collapsed = [collapse_repeats(s[1], repeat_units, offsets) for s in seq_results]
-        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus_path)
+        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus.path)
     return df_overview, df_collapsed
 
 
