@@ -92,7 +92,8 @@ class CallerResults(collections.abc.Sequence):
     the batch's result records and the two ASCII sequence buffers -- a CallerResult (two Python strings) is only built for
     the reads that are looked at.  The records are also available as columns (`len2`, `cost2`, ...) for batch consumers."""
 
-    def __init__(self, names, records, offsets, seq1: bytes, seq2: bytes, on_error: str):
+    def __init__(self, names, records, offsets, seq1, seq2, on_error: str):
+        """seq1 / seq2: the batch's ASCII buffers (bytes or uint8 arrays; read r starts at offsets[r])."""
         self.names, self.records, self.offsets = names, records, np.asarray(offsets)
         self._seq1, self._seq2, self._on_error = seq1, seq2, on_error
 
@@ -111,8 +112,8 @@ class CallerResults(collections.abc.Sequence):
                 raise ReadCallError(f'read {self.names[i]}: caller status {_lib.READ_STATUS.get(st, st)}')
             return CallerResult('', float('nan'), '', float('nan'))
         o = int(self.offsets[i])
-        return CallerResult(seq=self._seq1[o:o + int(rec['len1'])].decode('ascii'), cost=float(rec['cost1']),
-                            resc_seq=self._seq2[o:o + int(rec['len2'])].decode('ascii'), resc_cost=float(rec['cost2']))
+        return CallerResult(seq=bytes(self._seq1[o:o + int(rec['len1'])]).decode('ascii'), cost=float(rec['cost1']),
+                            resc_seq=bytes(self._seq2[o:o + int(rec['len2'])]).decode('ascii'), resc_cost=float(rec['cost2']))
 
     def check(self):
         """Raise for the first read the reference would have failed on (on_error='raise'); cheap, vectorised."""
@@ -415,5 +416,5 @@ class CallerWrapper:
     def _run_packed(self, names, reverses, signal, offsets) -> 'CallerResults':
         aut = np.fromiter((1 if r else 0 for r in reverses), dtype=np.int32, count=len(names))
         res, extra = self.hip.call(signal, offsets, aut, want_seqs=True)
-        out = CallerResults(names, res, offsets[:-1], extra['seq1'].tobytes(), extra['seq2'].tobytes(), self.on_error)
+        out = CallerResults(names, res, offsets[:-1], extra['seq1'], extra['seq2'], self.on_error)
         return out.check()
