@@ -134,7 +134,11 @@ __device__ __forceinline__ uint64_t lt_mask(double cand, double best)
 template <int BYTE_OFF>
 __device__ __forceinline__ void store_mask(uint64_t m, uint64_t *base)
 {
+#ifdef WSX_EXP_NO_MASK_STORES // timing experiment only (results are garbage): what do the scalar stores cost?  Nothing.
+    asm volatile("" ::"s"(m), "s"(base));
+#else
     asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(base), "n"(BYTE_OFF) : "memory");
+#endif
 }
 
 template <int BYTE_OFF> // two masks, 16-byte aligned destination
@@ -142,7 +146,11 @@ __device__ __forceinline__ void store_mask_pair(uint64_t m0, uint64_t m1, uint64
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)};
+#ifdef WSX_EXP_NO_MASK_STORES
+    asm volatile("" ::"s"(v), "s"(base));
+#else
     asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(base), "n"(BYTE_OFF) : "memory");
+#endif
 }
 
 // the NM masks of group row R, at base + R*NM (base = the group's first row); pairs go out as one 16-byte store when
@@ -200,6 +208,9 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
             if (PAR) st.e0[k][f] = e;
             else st.e1[k][f] = e;
         }
+#ifdef WSX_PIN_READS // experiment: keep these reads at the top of the row for K >= WSX_PIN_READS (no gain: DESIGN 4b)
+    if constexpr (K >= WSX_PIN_READS) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double best = st.g[k][1];
