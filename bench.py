@@ -263,10 +263,12 @@ def from_raw_leg(hip, wl, device, steps, warmup):
     main = torch.cuda.current_stream()
 
     def run(host_resident):
-        uploaded, downloaded = [None, None], [None, None]
+        uploaded, downloaded, prepared = [None, None], [None, None], [None, None]
 
         def upload(k):
-            with torch.cuda.stream(copy_stream):  # (buffer k&1 was last read by the loader of step k-2, which has returned)
+            with torch.cuda.stream(copy_stream):
+                if prepared[k & 1] is not None:
+                    copy_stream.wait_event(prepared[k & 1])  # the loader of step k-2 has read this buffer
                 raw_bufs[k & 1].copy_(raw_host, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -280,6 +282,8 @@ def from_raw_leg(hip, wl, device, steps, warmup):
                 main.wait_event(uploaded[b])
             src = raw_bufs[b] if host_resident else raw_dev
             hip.prepare_device(src.data_ptr(), wl.offsets, seg_lo, seg_hi, sig_bufs[b].data_ptr(), wl.offsets)
+            prepared[b] = torch.cuda.Event()
+            prepared[b].record(main)
             if host_resident:
                 upload(k + 1)  # beside this step's kernels
             hip.call_device(sig_bufs[b].data_ptr(), wl.offsets, wl.aut, res_bufs[b].data_ptr(), seq1_ptr=seq_bufs[b][0].data_ptr(),

@@ -203,7 +203,9 @@ int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
  *   signal_out     float64 output, concatenated by out_offsets (host int64[n_reads+1], lengths must equal the slice
  *                  lengths); can be passed straight to wsx_call_batch with the same offsets
  *   shift_scale    optional float64[2*n_reads] (shift, scale per read), in `mem`
- * Synchronous.
+ * Synchronous for WSX_MEM_HOST.  For WSX_MEM_DEVICE the work is enqueued on the handle's stream and the call returns
+ * without waiting (the host metadata arrays are copied before it returns); a wsx_call_batch on the same handle that
+ * follows reads signal_out in stream order.
  */
 int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_t *raw_offsets, const int64_t *seg_start,
                         const int64_t *seg_end, int64_t n_reads, int32_t spike_removal, double *signal_out,

@@ -324,6 +324,12 @@ def test_signal_loader_matches_reference_and_host():
     noisy[rng.random(20000) < 0.4] = 1800
     raws.append(noisy)
     pos.append((500, 15000))
+    # short reads go through the one-block-per-read kernel; one whose values span more than its histogram (4096 values)
+    # is handed back to the general kernels, like the long reads of this batch
+    wide = rng.normal(520, 70, size=1500).astype(np.int16)
+    wide[[7, 300, 301, 1499]] = [6000, -2500, 6100, -2600]
+    raws.append(wide)
+    pos.append((0, 1499))
     for mode in ('Brute', 'None'):
         out, ooff, ss = hip.prepare_signals(raws, pos, mode)
         for i, (raw, p) in enumerate(zip(raws, pos)):

@@ -263,7 +263,8 @@ class HipCaller:
     def prepare_device(self, raw_ptr: int, raw_offsets: np.ndarray, seg_start: np.ndarray, seg_end: np.ndarray, out_ptr: int,
                        out_offsets: np.ndarray, spike_removal: str = 'Brute', shift_scale_ptr: int = 0):
         """wsx_prepare_signals on device buffers: int16 raw reads in HBM -> normalised float64 segments in HBM, laid out
-        by out_offsets (ready for call_device with the same offsets).  Blocks until the segments are written."""
+        by out_offsets (ready for call_device with the same offsets).  Asynchronous: enqueued on the handle's stream, a
+        call_device that follows reads the segments in stream order."""
         raw_offsets = np.ascontiguousarray(raw_offsets, np.int64)
         seg_start, seg_end = np.ascontiguousarray(seg_start, np.int64), np.ascontiguousarray(seg_end, np.int64)
         out_offsets = np.ascontiguousarray(out_offsets, np.int64)

@@ -239,7 +239,10 @@ struct wsx_caller {
     std::vector<hipEvent_t> sched_events;
     size_t sched_used = 0;
     PinRing ring_up, ring_down; // host-buffer calls only (allocated on first use)
-    DeviceBuf prep_pool[8];     // wsx_prepare_signals: histograms and per-chunk buffers, kept between calls
+    DeviceBuf prep_pool[12];    // wsx_prepare_signals: histograms and per-chunk buffers, kept between calls
+    void *prep_pinned = nullptr; // ... and its metadata staging (pinned), with the event recorded after the last use
+    size_t prep_pinned_cap = 0;
+    hipEvent_t ev_prep = nullptr;
     void *pinned_res = nullptr; // host-buffer calls: the batch's result records land here first
     size_t pinned_res_cap = 0;
 };
@@ -573,6 +576,8 @@ void wsx_caller_destroy(wsx_caller *c)
     c->ring_up.release();
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
+    if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
+    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
@@ -669,6 +674,22 @@ int wsx_internal_device(wsx_caller *c) { return c->device; }
 hipStream_t wsx_internal_stream(wsx_caller *c) { return c->stream; }
 void wsx_internal_set_error(const char *msg) { g_err = msg; }
 uint64_t wsx_internal_workspace_limit(wsx_caller *c) { return c->ws_limit; }
+hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEvent_t *last_use)
+{
+    hipError_t e = hipSuccess;
+    if (!c->ev_prep && (e = hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming)) != hipSuccess) return e;
+    if (bytes > c->prep_pinned_cap) {
+        if ((e = hipEventSynchronize(c->ev_prep)) != hipSuccess) return e; // uploads from the old buffer
+        if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
+        c->prep_pinned = nullptr;
+        c->prep_pinned_cap = 0;
+        if ((e = hipHostMalloc(&c->prep_pinned, bytes + bytes / 4, hipHostMallocDefault)) != hipSuccess) return e;
+        c->prep_pinned_cap = bytes + bytes / 4;
+    }
+    *p = c->prep_pinned;
+    *last_use = c->ev_prep;
+    return hipSuccess;
+}
 // buffer `slot` of the signal loader's pool, at least `bytes` large (grown when needed, freed with the handle)
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p)
 {

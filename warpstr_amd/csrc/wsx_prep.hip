@@ -22,6 +22,8 @@
 //                     -> median absolute deviation -> scale
 //   norm_kernel       thread per output sample: (x - shift) / scale of the requested slice
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/warpstr_hip.h"
@@ -47,6 +49,7 @@ struct PrepArgs {
     // roff[r]/16 + 64 r .., capacity len/16 + 64) and a counter; a read whose list overflows is scanned sample by sample
     long long *ol_list;
     unsigned int *ol_count; // [n]
+    uint8_t *done;          // [n]: 1 = the read went through short_read_kernel, the general kernels skip it
 };
 
 __device__ __forceinline__ long long ol_base(const PrepArgs &a, int r) { return a.roff[r] / 16 + 64ll * r; }
@@ -84,6 +87,7 @@ __device__ __forceinline__ void for_each_sample8(const int16_t *buf, long long s
 __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
     int lo = 32767, hi = -32768;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
 __global__ __launch_bounds__(256) void zero_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const int range = a.mm[2 * r + 1] - a.mm[2 * r] + 1;
     uint32_t *h = a.hist + (size_t)r * 65536;
     for (int b = blockIdx.y * 256 + threadIdx.x; b < range; b += gridDim.y * 256) h[b] = 0u;
@@ -171,6 +176,7 @@ __device__ int16_t median_small(int *w, int cnt)
 __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const long long len = a.roff[r + 1] - a.roff[r];
     const int16_t *raw = a.raw + a.roff[r];
     int16_t *out = a.clean + a.roff[r];
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
 __global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const unsigned int total = a.ol_count[r];
     if (total > ol_cap(a, r)) return; // overflow: spike_kernel scans this read
     const long long len = a.roff[r + 1] - a.roff[r];
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
 {
     __shared__ uint32_t lh[PREP_LDS_BINS];
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_CHUNK, c1 = c0 + PREP_CHUNK < len ? c0 + PREP_CHUNK : len;
     if (c0 >= c1) return;
@@ -300,20 +308,11 @@ __device__ double np_lerp(double a, double b, double t)
     return r;
 }
 
-__global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
+// shift and scale of a read from its histogram (normalize_signal_mad, src/schemas/fast5.py:104-114): wave-cooperative;
+// shift is valid in every lane, scale in lane 0.  n > 0.
+__device__ __forceinline__ void read_stats(const uint32_t *h, int vmin, int vmax, long long n, int lane, double &shift_out, double &scale_out)
 {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    const long long n = a.roff[r + 1] - a.roff[r];
-    const uint32_t *h = a.hist + (size_t)r * 65536;
-    const int vmin = a.mm[2 * r], vmax = a.mm[2 * r + 1], range = vmax - vmin + 1;
-    if (n <= 0) {
-        if (lane == 0) {
-            a.shift_scale[2 * r] = 0.0;
-            a.shift_scale[2 * r + 1] = 1.0;
-        }
-        return;
-    }
+    const int range = vmax - vmin + 1;
     // np.percentile(x, (46.5, 53.5)), method 'linear'
     double pct[2];
     const double qs[2] = {46.5 / 100.0, 53.5 / 100.0};
@@ -362,14 +361,213 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
             seen += c;
         }
         scale = (n % 2) ? (0.0 + d_hi) / 1.0 : ((0.0 + d_lo) + d_hi) / 2.0;
+    }
+    shift_out = shift;
+    scale_out = scale;
+}
+
+__global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
+{
+    const int r = blockIdx.x;
+    if (a.done[r]) return;
+    const int lane = threadIdx.x;
+    const long long n = a.roff[r + 1] - a.roff[r];
+    const uint32_t *h = a.hist + (size_t)r * 65536;
+    if (n <= 0) {
+        if (lane == 0) {
+            a.shift_scale[2 * r] = 0.0;
+            a.shift_scale[2 * r + 1] = 1.0;
+        }
+        return;
+    }
+    double shift, scale;
+    read_stats(h, a.mm[2 * r], a.mm[2 * r + 1], n, lane, shift, scale);
+    if (lane == 0) {
         a.shift_scale[2 * r] = shift;
         a.shift_scale[2 * r + 1] = scale;
     }
 }
 
+// Short reads (the STR segments themselves: a few thousand samples): the whole loader in ONE wavefront per read, everything
+// in LDS -- working copy, outlier bits, histogram over the occupied value range -- and one pass over HBM (2 bytes in,
+// 8 bytes out per sample).  The general kernels above are built for whole reads of 10^4..10^6 samples; on 2000-sample
+// segments their per-read blocks spent 4.3 ms per 100k reads on launch granularity and serial walks.  Same arithmetic, same
+// results: outlier chains are repaired serially by the lane that finds their head; the histogram becomes its own prefix
+// sum, so an order statistic is a search and the median absolute deviation a search over candidate distances -- the k-th
+// smallest of the multiset {|v - shift|} does not depend on the order in which equal distances are visited, so the
+// two-sided walk of read_stats and this search give the same double.  A read that is longer than `cap` samples or spans more
+// than PREP_SHORT_BINS values is left to the general kernels (done[r] = 0).
+#define PREP_SHORT_BINS 2048
+__global__ __launch_bounds__(64) void short_read_kernel(PrepArgs a, int cap)
+{
+    extern __shared__ int16_t s_x[];          // cap samples (cap is a multiple of 64)
+    uint32_t *s_ol = (uint32_t *)(s_x + cap); // cap / 32 outlier bits (by the RAW values)
+    uint32_t *P = s_ol + cap / 32;            // PREP_SHORT_BINS counters, then their inclusive prefix sums
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const long long len_ll = a.roff[r + 1] - a.roff[r];
+    if (len_ll > cap || len_ll <= 0) {
+        if (lane == 0) a.done[r] = 0;
+        return;
+    }
+    const int len = (int)len_ll;
+    const int16_t *raw = a.raw + a.roff[r];
+    const bool brute = a.ol_list != nullptr;
+    int lo = 32767, hi = -32768;
+    for (int w = lane; w < cap / 32; w += 64) s_ol[w] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    auto take = [&](int i, int v) { // sample i of the read
+        s_x[i] = (int16_t)v;
+        lo = min(lo, v);
+        hi = max(hi, v);
+        if (brute && i > 2 && (v > 1000 || v < 250)) atomicOr(&s_ol[i >> 5], 1u << (i & 31)); // rare
+    };
+    if (a.vec) { // eight samples per 16-byte load, groups aligned in buffer coordinates (as the streaming passes above)
+        const long long ro = a.roff[r];
+        for_each_sample8(a.raw, ro, ro + len, lane, 64, [&](short8 v, long long base, int first, int last) {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (e >= first && e < last) take((int)(base + e - ro), (int)v[e]);
+        });
+    } else {
+        for (int i = lane; i < len; i += 64) take(i, (int)raw[i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    const int vmin = lo, vmax = hi, range = vmax - vmin + 1;
+    if (range > PREP_SHORT_BINS) {
+        if (lane == 0) a.done[r] = 0;
+        return;
+    }
+    for (int b = lane; b < range; b += 64) P[b] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // spike removal: the outlier that heads a chain (neither of the two samples before it is one) repairs the chain
+    auto is_ol = [&](int i) { return i >= 0 && ((s_ol[i >> 5] >> (i & 31)) & 1u); };
+    bool any_ol = false;
+    for (int w = lane; w < (len + 31) / 32; w += 64) any_ol = any_ol || s_ol[w] != 0u;
+    if (brute && __ballot(any_ol)) {
+        for (int i = lane; i < len; i += 64) {
+            if (!is_ol(i) || is_ol(i - 1) || is_ol(i - 2)) continue;
+            int j = i;
+            while (true) {
+                int w[5];
+                int cnt = 0;
+                for (int q = j - 2; q < j + 3 && q < len; q++) w[cnt++] = s_x[q];
+                s_x[j] = median_small(w, cnt);
+                if (j + 1 < len && is_ol(j + 1)) j = j + 1;
+                else if (j + 2 < len && is_ol(j + 2)) j = j + 2;
+                else break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < len; i += 64) atomicAdd(&P[(int)s_x[i] - vmin], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // counters -> inclusive prefix sums, in place
+    {
+        unsigned int carry = 0u;
+        for (int base = 0; base < range; base += 64) {
+            unsigned int inc = base + lane < range ? P[base + lane] : 0u;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            inc += carry;
+            if (base + lane < range) P[base + lane] = inc;
+            carry = __shfl(inc, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto cum = [&](int v) -> long long { // samples with value <= v
+        return v < vmin ? 0ll : (long long)P[(v > vmax ? vmax : v) - vmin];
+    };
+    auto order_value = [&](long long k) -> int { // value of the order statistic of rank k (0-based); same in every lane
+        for (int base = 0; base < range; base += 64) {
+            const unsigned long long hit = __ballot(base + lane < range && (long long)P[base + lane] > k);
+            if (hit) return vmin + base + __builtin_ctzll(hit);
+        }
+        return vmax;
+    };
+    const long long n = len;
+    double pct[2];
+    const double qs[2] = {46.5 / 100.0, 53.5 / 100.0};
+    for (int t = 0; t < 2; t++) { // np.percentile(x, (46.5, 53.5)), method 'linear' (as read_stats)
+        const double vi = (double)(n - 1) * qs[t];
+        long long prev = (long long)floor(vi), next = prev + 1;
+        if (vi >= (double)(n - 1)) prev = next = n - 1;
+        if (vi < 0) prev = next = 0;
+        const double gamma = vi - floor(vi);
+        pct[t] = np_lerp((double)order_value(prev), (double)order_value(next), gamma);
+    }
+    const double shift = ((0.0 + pct[0]) + pct[1]) / 2.0;
+    // median(|x - shift|): the distance of rank k is the smallest candidate |v - shift| with more than k samples within it.
+    // Lanes try the candidates of one side, 64 at a time, nearest first; "within rho" is an interval of values whose ends
+    // are found arithmetically and corrected with the very comparison fabs((double)v - shift) <= rho.
+    int fl = (int)floor(shift); // fl <= shift < fl + 1
+    if (fl > vmax) fl = vmax;
+    if (fl < vmin - 1) fl = vmin - 1;
+    auto within = [&](double rho) -> long long { // samples with |v - shift| <= rho
+        int a0 = (int)ceil(shift - rho), b0 = (int)floor(shift + rho);
+        a0 = a0 < vmin - 1 ? vmin - 1 : (a0 > vmax + 1 ? vmax + 1 : a0);
+        b0 = b0 < vmin - 1 ? vmin - 1 : (b0 > vmax + 1 ? vmax + 1 : b0);
+        while (a0 - 1 >= vmin && fabs((double)(a0 - 1) - shift) <= rho) a0--;
+        while (a0 <= vmax && !(fabs((double)a0 - shift) <= rho)) a0++;
+        while (b0 + 1 <= vmax && fabs((double)(b0 + 1) - shift) <= rho) b0++;
+        while (b0 >= vmin && !(fabs((double)b0 - shift) <= rho)) b0--;
+        return b0 >= a0 ? cum(b0) - cum(a0 - 1) : 0ll;
+    };
+    auto dist_of_rank = [&](long long k) -> double {
+        double best = __builtin_huge_val();
+        for (int side = 0; side < 2; side++) {
+            const int first = side == 0 ? fl : fl + 1, count = side == 0 ? fl - vmin + 1 : vmax - fl; // candidates first, first -+ 1, ..
+            for (int j0 = 0; j0 < count; j0 += 64) {
+                const int j = j0 + lane;
+                const int v = side == 0 ? first - j : first + j;
+                const double rho = fabs((double)v - shift);
+                const bool ok = j < count && within(rho) > k;
+                const unsigned long long hit = __ballot(ok);
+                if (hit) {
+                    const int jj = j0 + __builtin_ctzll(hit);
+                    const int vv = side == 0 ? first - jj : first + jj;
+                    const double d = fabs((double)vv - shift);
+                    best = d < best ? d : best;
+                    break;
+                }
+            }
+        }
+        return best;
+    };
+    const double d_hi = dist_of_rank(n / 2), d_lo = (n % 2) ? d_hi : dist_of_rank(n / 2 - 1);
+    const double scale = (n % 2) ? (0.0 + d_hi) / 1.0 : ((0.0 + d_lo) + d_hi) / 2.0;
+    if (lane == 0) {
+        a.shift_scale[2 * r] = shift;
+        a.shift_scale[2 * r + 1] = scale;
+        a.done[r] = 1;
+    }
+    long long slo = a.seg_lo[r], shi = a.seg_hi[r] + 1; // python slice [lo:hi)
+    if (slo < 0) slo += len;
+    if (slo < 0) slo = 0;
+    if (slo > len) slo = len;
+    if (shi < 0) shi += len;
+    if (shi < 0) shi = 0;
+    if (shi > len) shi = len;
+    const int cnt = (int)(a.ooff[r + 1] - a.ooff[r]);
+    double *out = a.out + a.ooff[r];
+    for (int i = lane; i < cnt; i += 64) out[i] = ((double)s_x[slo + i] - shift) / scale;
+}
+
 __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
 {
     const int r = blockIdx.x;
+    if (a.done[r]) return;
     const long long len = a.roff[r + 1] - a.roff[r];
     long long lo = a.seg_lo[r], hi = a.seg_hi[r] + 1; // python slice [lo:hi)
     if (lo < 0) lo += len;
@@ -393,6 +591,8 @@ hipStream_t wsx_internal_stream(wsx_caller *c);
 void wsx_internal_set_error(const char *msg);
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p);
 uint64_t wsx_internal_workspace_limit(wsx_caller *c);
+// pinned host memory of the handle for this function's metadata (>= bytes), and the event recorded after its last use
+hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEvent_t *last_use);
 
 #define PCHK(expr)                                                                                       \
     do {                                                                                                 \
@@ -445,6 +645,15 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
     // the handle's workspace limit goes to them (default 16 GiB -> 32 768 reads per chunk; 288 GB of HBM take 100k short
     // reads in one go, where 4 096-read chunks spent most of a call on launches and synchronisation)
     const int64_t chunk_reads = std::max<int64_t>(4096, (int64_t)(wsx_internal_workspace_limit(c) / 2 / (65536 * 4)));
+    // Metadata (chunk-relative offsets, slice bounds, initial value ranges) goes through pinned memory owned by the handle, so
+    // that the uploads are asynchronous and nothing of the caller's is referenced after the return; device-buffer calls then
+    // return as soon as the work is enqueued on the handle's stream.
+    const int64_t n_chunks = (n_reads + chunk_reads - 1) / chunk_reads;
+    char *pin = nullptr;
+    hipEvent_t pin_event = nullptr;
+    PCHK(wsx_internal_prep_pinned(c, (size_t)(5 * n_reads + 2 * n_chunks) * 8 + 64, (void **)&pin, &pin_event));
+    PCHK(hipEventSynchronize(pin_event)); // the previous call's uploads have left the buffer (a no-op before the first call)
+    size_t pin_used = 0;
     uint32_t *d_hist = nullptr;
     // every device buffer of this function lives in the handle's pool (slot 0: histograms, 1..: per-chunk buffers): a
     // fresh hipMalloc / hipFree of ~1.5 GB per call cost a third of the call
@@ -453,7 +662,9 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         const int64_t cnt = std::min(chunk_reads, n_reads - f);
         const int64_t rbase = raw_offsets[f], rsz = raw_offsets[f + cnt] - rbase;
         const int64_t obase = out_offsets[f], osz = out_offsets[f + cnt] - obase;
-        std::vector<int64_t> h_roff(cnt + 1), h_ooff(cnt + 1);
+        int64_t *h_roff = (int64_t *)(pin + pin_used), *h_ooff = h_roff + cnt + 1, *h_lo = h_ooff + cnt + 1, *h_hi = h_lo + cnt;
+        int32_t *h_mm = (int32_t *)(h_hi + cnt);
+        pin_used += (size_t)(5 * cnt + 2) * 8;
         int64_t max_len = 0;
         for (int64_t r = 0; r <= cnt; r++) {
             h_roff[r] = raw_offsets[f + r] - rbase;
@@ -479,21 +690,17 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         PCHK(alloc((void **)&d_meta, (size_t)(4 * cnt + 2) * 8));
         PCHK(alloc((void **)&d_ss, (size_t)cnt * 16));
         int64_t *d_roff = d_meta, *d_ooff = d_meta + cnt + 1, *d_lo = d_ooff + cnt + 1, *d_hi = d_lo + cnt;
-        PCHK(hipMemcpyAsync(d_roff, h_roff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, st));
-        PCHK(hipMemcpyAsync(d_ooff, h_ooff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, st));
-        PCHK(hipMemcpyAsync(d_lo, seg_start + f, cnt * 8, hipMemcpyHostToDevice, st));
-        PCHK(hipMemcpyAsync(d_hi, seg_end + f, cnt * 8, hipMemcpyHostToDevice, st));
+        memcpy(h_lo, seg_start + f, (size_t)cnt * 8);
+        memcpy(h_hi, seg_end + f, (size_t)cnt * 8);
+        for (int64_t r = 0; r < cnt; r++) {
+            h_mm[2 * r] = 32767; // empty reads keep an empty (negative) range
+            h_mm[2 * r + 1] = -32768;
+        }
         int32_t *d_mm = nullptr;
         PCHK(alloc((void **)&d_mm, (size_t)cnt * 8));
-        {
-            std::vector<int32_t> mm0((size_t)cnt * 2);
-            for (int64_t r = 0; r < cnt; r++) {
-                mm0[2 * r] = 32767;      // empty reads keep an empty (negative) range
-                mm0[2 * r + 1] = -32768;
-            }
-            PCHK(hipMemcpyAsync(d_mm, mm0.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, st));
-            PCHK(hipStreamSynchronize(st)); // mm0 goes out of scope
-        }
+        // (offsets, offsets, bounds, bounds are contiguous in the pinned buffer and on the device: one copy)
+        PCHK(hipMemcpyAsync(d_roff, h_roff, (size_t)(4 * cnt + 2) * 8, hipMemcpyHostToDevice, st));
+        PCHK(hipMemcpyAsync(d_mm, h_mm, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
         // eight-sample loads need 16-byte aligned buffers (groups of eight are aligned in buffer coordinates, reads may start
         // anywhere) and must not run past the allocation: the staging buffers are padded, a caller's device buffer is only
         // read in whole groups when it is aligned and the last group ends inside the chunk
@@ -507,14 +714,29 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
             d_olc = (unsigned int *)(d_ol + entries);
             PCHK(hipMemsetAsync(d_olc, 0, (size_t)cnt * 4, st));
         }
-        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec, d_ol, d_olc};
+        uint8_t *d_done = nullptr;
+        PCHK(alloc((void **)&d_done, (size_t)cnt));
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec, d_ol, d_olc, d_done};
         int64_t max_out = 0;
         for (int64_t r = 0; r < cnt; r++) max_out = std::max(max_out, h_ooff[r + 1] - h_ooff[r]);
-        const unsigned gn = (unsigned)std::min<int64_t>(std::max<int64_t>((max_out + 255) / 256, 1), 4096);
+        // (a chunk of short reads: the general kernels mostly find done[r] set -- one block per read is enough for the rest)
+        const unsigned gn = max_len <= 8192 ? 1u : (unsigned)std::min<int64_t>(std::max<int64_t>((max_out + 255) / 256, 1), 4096);
         const unsigned gc = (unsigned)std::max<int64_t>((max_len + PREP_CHUNK - 1) / PREP_CHUNK, 1);
         const unsigned gs = (unsigned)std::max<int64_t>((max_len + PREP_STREAM - 1) / PREP_STREAM, 1);
+        {
+            // short reads first, one block each (the kernel decides per read and tells the general kernels what is left)
+            int64_t min_len = max_len;
+            for (int64_t r = 0; r < cnt; r++) min_len = std::min(min_len, h_roff[r + 1] - h_roff[r]);
+            const int cap = (int)std::min<int64_t>(((std::min<int64_t>(max_len, 8192) + 63) / 64) * 64, 8192);
+            const size_t lds = (size_t)cap * 2 + (size_t)cap / 8 + 8 + PREP_SHORT_BINS * 4;
+            if (min_len <= cap && !getenv("WSX_PREP_GENERAL")) {
+                hipLaunchKernelGGL(short_read_kernel, dim3((unsigned)cnt), dim3(64), lds, st, a, cap);
+            } else {
+                PCHK(hipMemsetAsync(d_done, 0, (size_t)cnt, st)); // no read of this chunk is short
+            }
+        }
         hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, 8), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, max_len <= 8192 ? 1 : 8), dim3(256), 0, st, a);
         if (spike_removal == 1) {
             if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3((unsigned)cnt), dim3(256), 0, st, a);
             hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a); // returns at once unless the list overflowed
@@ -527,7 +749,8 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         if (shift_scale) {
             PCHK(hipMemcpyAsync(shift_scale + 2 * f, d_ss, (size_t)cnt * 16, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         }
-        PCHK(hipStreamSynchronize(st)); // chunk buffers are freed below
+        if (host) PCHK(hipStreamSynchronize(st)); // the caller's host buffers are complete when the call returns
     }
+    PCHK(hipEventRecord(pin_event, st));
     return WSX_SUCCESS;
 }
