@@ -280,7 +280,11 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL) void dtw_fil
     if (slot >= a.n_launch) return;
     // the fill is the resource everything else waits for: its waves win issue arbitration against the latency-bound
     // stages of other chunks that share the SIMD (-1.5 % per step)
+#ifdef WSX_EXP_FILL_PRIO // experiment builds: another issue priority for the fill
+    __builtin_amdgcn_s_setprio(WSX_EXP_FILL_PRIO);
+#else
     __builtin_amdgcn_s_setprio(3);
+#endif
     ReadGeom gm = geom(a, slot);
     const int lr = rfl(gm.lr), T = rfl(gm.T);
     const long long off = gm.off;
@@ -663,6 +667,9 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 template <int K, int F, int FL, bool PK>
 __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 {
+#ifdef WSX_EXP_MID_PRIO
+    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
+#endif
     static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
     const int lane = threadIdx.x & 63;
     const int slot = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -816,6 +823,9 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 template <int F, bool PK>
 __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_aut)
 {
+#ifdef WSX_EXP_MID_PRIO
+    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
+#endif
     static_assert(!PK || F == 2, "packed mask rows: two candidates");
     constexpr int RC = F == 2 ? 8 : 4; // rows per step
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
