@@ -5,7 +5,8 @@
  * callables.  Each entry point below states the upstream interface it stands in for
  * (paths relative to the upstream repository root):
  *
- *   wsx_call_batch       <->  CallerWrapper.run(workload) -> List[CallerResult]
+ *   wsx_call_batch, wsx_call_batch_reads
+ *                        <->  CallerWrapper.run(workload) -> List[CallerResult]
  *                             src/caller/wrapper.py:104-120 (Pool.map of warpstr_call_parallel,
  *                             251-289; WarpSTR.run, src/caller/caller.py:117-149)
  *   wsx_warp_batch       <->  WarpSTR.warp(signal, mask) -> WarpResult(trace)
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 6
+#define WSX_ABI_VERSION 7
 
 /* function return codes */
 enum {
@@ -178,6 +179,16 @@ int wsx_caller_join(wsx_caller *c, void *stream);
  */
 int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets,
                    const int32_t *automaton_id, int64_t n_reads, wsx_result *results, const wsx_traces *traces);
+
+/*
+ * The same for reads that live in separate host arrays -- the reference's workload is a list of ReadSignal objects, each
+ * with its own numpy array (src/schemas/readsignal.py:6-10; get_workload, src/caller/wrapper.py:44-54): reads[r] points at
+ * lengths[r] float64 samples.  The library gathers them into its pinned upload buffers with its copy threads while earlier
+ * pieces are already on their way to the device, so the caller need not build one 8-bytes-per-sample buffer first.  Host
+ * memory only; per-sample outputs in `traces` are laid out back to back by the running sum of `lengths`.  Synchronous.
+ */
+int wsx_call_batch_reads(wsx_caller *c, const double *const *reads, const int64_t *lengths, const int32_t *automaton_id,
+                         int64_t n_reads, wsx_result *results, const wsx_traces *traces);
 
 /*
  * One DP + traceback per read (WarpSTR.warp).

@@ -211,6 +211,32 @@ def test_caller_wrapper_interface():
     assert cw.run([]) == []
 
 
+def test_reads_in_separate_arrays_equal_the_packed_call():
+    """wsx_call_batch_reads (the library gathers a list of per-read arrays while it uploads) against wsx_call_batch on the
+    packed buffer: identical records and sequences; arrays that are not contiguous float64 are converted on the way; big
+    enough to span several pinned pieces and copy threads."""
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    sigs, revs, _ = synth.batch(locus, 6000, (600, 2600), 12)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    hip = HipCaller([locus.template, locus.reverse], [19, 19])
+    sig, off = pack_signals(sigs)
+    want, wextra = hip.call(sig, off, aut, want_seqs=True)
+    reads = list(sigs)
+    reads[3] = np.concatenate([sigs[3], sigs[3]])[::2][:len(sigs[3])] * 0 + sigs[3]   # a fresh (contiguous) copy
+    reads[5] = np.stack([sigs[5], sigs[5]], axis=1)[:, 0]                              # a strided view
+    reads[7] = sigs[7].astype(np.float32)                                             # another dtype
+    got, goff, gextra = hip.call_reads(reads, aut, want_seqs=True)
+    assert np.array_equal(goff, off)
+    keep = np.ones(len(sigs), bool)
+    keep[7] = False                                                                   # (float32 rounding changes that read)
+    assert got[keep].tobytes() == want[keep].tobytes()
+    for i in (0, 3, 5, 100, 5999):
+        o = off[i]
+        assert np.array_equal(gextra['seq2'][o:o + got['len2'][i]], wextra['seq2'][o:o + want['len2'][i]])
+    w32, _ = hip.call(np.concatenate([r.astype(np.float64) for r in reads]), off, aut)
+    assert got[7].tobytes() == w32[7].tobytes()
+
+
 def test_chunking_and_order_invariance():
     """Results do not depend on batch composition: tiny workspace limit (many chunks), permuted input."""
     locus = synth.make_locus('(AGC)', 16, 5)

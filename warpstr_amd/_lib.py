@@ -16,7 +16,7 @@ WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
                7: 'segment_range'}
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
-           'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_warp_batch', 'wsx_prepare_signals',
+           'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
            'wsx_caller_last_timing', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
 
@@ -126,6 +126,7 @@ def load():
     lib.wsx_caller_timing_window.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_call_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]
+    lib.wsx_call_batch_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.wsx_warp_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.wsx_prepare_signals.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -214,6 +214,34 @@ class HipCaller:
                                            C.byref(tr) if tr is not None else None), 'wsx_call_batch')
         return results, extra
 
+    def call_reads(self, reads: Sequence[np.ndarray], automaton_id: np.ndarray, want_seqs: bool = False):
+        """wsx_call_batch_reads: reads in separate float64 arrays (a workload of ReadSignal objects), gathered by the library
+        while it uploads -> (results, offsets, dict of optional per-sample outputs laid out by `offsets`)."""
+        n = len(reads)
+        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
+        ptrs = np.empty(n, np.uintp)
+        lens = np.empty(n, np.int64)
+        keep = []
+        for i, a in enumerate(reads):
+            if a.dtype != np.float64 or a.ndim != 1 or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, np.float64).reshape(-1)
+                keep.append(a)
+            ptrs[i] = a.__array_interface__['data'][0]
+            lens[i] = a.shape[0]
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        results = np.zeros(n, dtype=_lib.RESULT_DTYPE)
+        extra, tr = {}, None
+        if want_seqs:
+            extra['seq1'] = np.zeros(int(offsets[-1]), np.uint8)
+            extra['seq2'] = np.zeros(int(offsets[-1]), np.uint8)
+            tr = _lib.WsxTraces(None, None, None, None, _lib.ptr(extra['seq1']), _lib.ptr(extra['seq2']))
+        _lib.check(self.lib.wsx_call_batch_reads(self.handle, _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(automaton_id), n,
+                                                 _lib.ptr(results), C.byref(tr) if tr is not None else None),
+                   'wsx_call_batch_reads')
+        del keep
+        return results, offsets, extra
+
     def warp(self, signal: np.ndarray, offsets: np.ndarray, automaton_id: np.ndarray, mask: Optional[np.ndarray] = None,
              want_last_row: bool = False):
         """wsx_warp_batch on host buffers -> dict(trace, end_cost, status[, last_row])."""
@@ -402,8 +430,10 @@ class CallerWrapper:
         """Run the caller for each piece of signal in the workload; results align with the workload."""
         if not workload:
             return []
-        signal, offsets = pack_signals([np.asarray(w.signal) for w in workload])
-        return self._run_packed([w.name for w in workload], [w.reverse for w in workload], signal, offsets)
+        # (no packing on this side: the library gathers the reads' own arrays into its upload buffers)
+        aut = np.fromiter((1 if w.reverse else 0 for w in workload), dtype=np.int32, count=len(workload))
+        res, offsets, extra = self.hip.call_reads([np.asarray(w.signal) for w in workload], aut, want_seqs=True)
+        return CallerResults([w.name for w in workload], res, offsets[:-1], extra['seq1'], extra['seq2'], self.on_error).check()
 
     def run_raw(self, names: Sequence[str], reverses: Sequence[bool], raws: Sequence[np.ndarray],
                 positions: Sequence[Sequence[int]], spike_removal: str = 'Brute') -> 'CallerResults':

@@ -157,6 +157,47 @@ struct PinRing {
         }
         return hipSuccess;
     }
+    // The same from reads that live in separate host arrays (reads first .. first+count-1 of `ptrs`, laid out back to back
+    // by `offsets`): the copy threads gather straight into the pinned piece, no intermediate buffer on the caller's side.
+    hipError_t upload_gather(void *dev_dst, const double *const *ptrs, const int64_t *offsets, int64_t first, int64_t count,
+                             hipStream_t s)
+    {
+        const int64_t s0 = offsets[first], s1 = offsets[first + count]; // samples
+        const size_t bytes = (size_t)(s1 - s0) * 8;
+        for (size_t o = 0; o < bytes; o += kPiece) {
+            Slot &sl = slots[next++ % slots.size()];
+            hipError_t e = settle(sl);
+            if (e != hipSuccess) return e;
+            const size_t len = std::min(kPiece, bytes - o);
+            const int64_t a = s0 + (int64_t)(o / 8), b = a + (int64_t)(len / 8); // global sample range of this piece
+            auto part = [&](int64_t pa, int64_t pb) { // samples [pa, pb) into the piece
+                int64_t r = std::upper_bound(offsets + first, offsets + first + count + 1, pa) - offsets - 1;
+                while (pa < pb) {
+                    const int64_t e2 = std::min(pb, offsets[r + 1]);
+                    if (e2 > pa) memcpy((char *)sl.pin + (size_t)(pa - a) * 8, ptrs[r] + (pa - offsets[r]), (size_t)(e2 - pa) * 8);
+                    pa = e2;
+                    r++;
+                }
+            };
+            const int nt = len >= (4u << 20) ? copy_threads : 1;
+            if (nt <= 1) {
+                part(a, b);
+            } else {
+                std::vector<std::thread> th;
+                const int64_t step = (b - a + nt - 1) / nt;
+                for (int t = 1; t < nt; t++) {
+                    const int64_t pa = std::min(b, a + step * t), pb = std::min(b, a + step * (t + 1));
+                    if (pb > pa) th.emplace_back([=] { part(pa, pb); });
+                }
+                part(a, std::min(b, a + step));
+                for (auto &t : th) t.join();
+            }
+            if ((e = hipMemcpyAsync((char *)dev_dst + o, sl.pin, len, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+            if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return e;
+            sl.busy = true;
+        }
+        return hipSuccess;
+    }
     hipError_t download(void *host_dst, const void *dev_src, size_t bytes, hipStream_t s)
     {
         for (size_t o = 0; o < bytes; o += kPiece) {
@@ -707,6 +748,7 @@ struct BatchIO {
     const int64_t *offsets;
     const int32_t *aut_id;
     int64_t n;
+    const double *const *read_ptrs = nullptr; // host reads in separate arrays (instead of `signal`)
     // full call
     wsx_result *results = nullptr;
     wsx_traces traces{};
@@ -721,7 +763,7 @@ struct BatchIO {
 
 int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 {
-    if (!c || !io.offsets || !io.aut_id || io.n < 0 || (io.n > 0 && !io.signal)) {
+    if (!c || !io.offsets || !io.aut_id || io.n < 0 || (io.n > 0 && !io.signal && !io.read_ptrs)) {
         g_err = "null argument";
         return WSX_ERR_INVALID;
     }
@@ -959,7 +1001,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
     // Carve the work set of chunk ci, upload its launch order (and, for host buffers, its signal) on stream s.
     // caller-owned host buffers: big batches go through the pinned rings, small ones use plain (blocking) copies
-    const bool ringed = host && (size_t)(io.offsets[n] - io.offsets[0]) * 8 >= (16u << 20);
+    const bool ringed = host && ((size_t)(io.offsets[n] - io.offsets[0]) * 8 >= (16u << 20) || io.read_ptrs);
     wsx_result *res_dst = io.results;
     if (ringed) {
         HIPCHK(c->ring_up.init(4));
@@ -1011,7 +1053,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
 
         if (host) {
-            HIPCHK(h2d(W.stage_sig.p, io.signal + boff, (size_t)x.ch.samples * 8, s));
+            if (io.read_ptrs) HIPCHK(c->ring_up.upload_gather(W.stage_sig.p, io.read_ptrs, io.offsets, f, cnt, s));
+            else HIPCHK(h2d(W.stage_sig.p, io.signal + boff, (size_t)x.ch.samples * 8, s));
             x.d_sig = (const double *)W.stage_sig.p;
         } else {
             x.d_sig = io.signal + boff;
@@ -1316,6 +1359,33 @@ int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
     io.mem = mem;
     io.signal = signal;
     io.offsets = offsets;
+    io.aut_id = automaton_id;
+    io.n = n_reads;
+    io.results = results;
+    if (traces) io.traces = *traces;
+    return run_batch(c, io, true);
+}
+
+int wsx_call_batch_reads(wsx_caller *c, const double *const *reads, const int64_t *lengths, const int32_t *automaton_id,
+                         int64_t n_reads, wsx_result *results, const wsx_traces *traces)
+{
+    if (!reads || !lengths || n_reads < 0) {
+        g_err = "wsx_call_batch_reads: null argument";
+        return WSX_ERR_INVALID;
+    }
+    std::vector<int64_t> offsets((size_t)n_reads + 1, 0);
+    for (int64_t r = 0; r < n_reads; r++) {
+        if (lengths[r] < 0 || (lengths[r] > 0 && !reads[r])) {
+            g_err = "wsx_call_batch_reads: negative length or null read";
+            return WSX_ERR_INVALID;
+        }
+        offsets[r + 1] = offsets[r] + lengths[r];
+    }
+    BatchIO io{};
+    io.mem = WSX_MEM_HOST;
+    io.signal = nullptr;
+    io.read_ptrs = reads;
+    io.offsets = offsets.data();
     io.aut_id = automaton_id;
     io.n = n_reads;
     io.results = results;
