@@ -12,9 +12,10 @@
 // first predecessor wins ties) because the re-computation is exact.
 //
 // Kernels
-//   dtw_fill_fast<M,K,F,FL>     register-resident fill for min_values_per_state M in {3,4,5}: one 64-lane wavefront per
-//       read; state j lives in lane j%64, slot j/64 (K slots per lane); one row (= one signal sample) per
-//       step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
+//   dtw_fill_fast<M,K,F,FL,PK>  register-resident fill for min_values_per_state M in {3,4,5}: one 64-lane wavefront per
+//       read; a state lives in one (slot, lane) of K slots per lane -- which one is decided by wsx_place.h (chains of
+//       first-predecessor links, free of LDS bank conflicts; the natural "state j in lane j%64, slot j/64" when that is
+//       as good); one row (= one signal sample) per step, all states of a row are independent.  Per state the "dwell" partial sums are a shift register
 //       g_1..g_{M-1} that runs one row AHEAD of the DP:
 //             after row i   g_s = D[i-s+1,j] + |s_{i-s+2}-v_j| + .. + |s_{i+1}-v_j|
 //       so g_1 is the next row's stay candidate, and the value a successor needs at row i+2 is final at the end
@@ -25,12 +26,13 @@
 //       operands).  Back-pointers never touch the vector ALU beyond the compare itself: "candidate f beat everything
 //       before it" for the 64 states of a slot is one v_cmp_lt_f64 into an SGPR pair, and that pair -- one bit per
 //       state -- is stored as it is with a scalar store (s_store_dwordx2/x4).  Per row the read gets NM = F + (K-1)*FL
-//       64-bit masks in HBM.
+//       64-bit masks in HBM; PK (one slot, two candidates, the states with two predecessors in lanes 0..7): the second
+//       mask is one byte, 9 bytes per row in groups of 16 rows.
 //   dtw_fill_generic            any m >= 2, fan-in <= 15: last m+1 rows of D in an LDS ring, direct restatement;
 //       4-bit numeric pointers packed 8 rows per 32-bit word per state.
-//   traceback_stream_kernel<F>  mask layout, K = 1: one THREAD per read streams the read's mask rows downwards (the
+//   traceback_stream_kernel<F,PK>  mask layout, K = 1: one THREAD per read streams the read's mask rows downwards (the
 //       rows visited do not depend on the path when there is one slot), tests its current state's bit per row.
-//   traceback_mask_kernel<K,F,FL> mask layout: one wavefront per read, 64 rows (all slots) per load, ballots.
+//   traceback_mask_kernel<K,F,FL,PK> mask layout: one wavefront per read, 64 rows (all slots) per load, ballots.
 //   traceback_generic_kernel    word layout of dtw_fill_generic, one thread per read.
 //       All three emit the run-length state list in reverse time order.
 //   expand_trace_kernel         optional: per-sample state ids from the run list (coalesced, wave per read).
@@ -38,7 +40,7 @@
 // Roofline: min-plus recurrence, no MFMA.  Per row and 64 states (F = 2): 6 v_add_f64, 2 v_cmp_lt_f64, 2 v_min_f64 on the
 // vector ALU; 2 ds_read_b64 + 1 ds_write_b64 on the LDS pipe (10 LDS cycles on gfx950, as many as the VALU needs: the two
 // pipes are balanced); 1 scalar store.  HBM traffic per read and pass: 8T (signal) + 8*NM*T (masks, written once, read once
-// by the traceback) + 6*runs.
+// by the traceback) + 6*runs; 8T + 9T + 6*runs with packed rows.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>

@@ -1,9 +1,9 @@
 // wsx_api.hip -- C ABI of the MI355X-native WarpSTR caller (include/warpstr_hip.h): handle, HBM
 // workspace, chunking, launch sequence.  No compute happens on the host: every stage of the per-read
-// pipeline is a HIP kernel (dtw_kernels.hip, mid_kernels.hip); the host only sorts read ids by
-// length (load balance) and sizes the workspace.
+// pipeline is a HIP kernel (dtw_kernels.hip, mid_kernels.hip); the host only places the states of every automaton
+// (wsx_place.h, once per handle), sorts read ids by length (load balance), plans the chunks and sizes the workspace.
 //
-// Launch sequence per chunk of reads (all on the handle's stream):
+// Launch sequence per chunk of reads (each chunk on one of the handle's streams, chunks side by side):
 //   dtw_fill (unmasked) -> traceback -> mid(pass 1: run statistics, sort, borders, segmentation mask, cost1)
 //   -> fit (Givens LSQ cubic) -> eval (rescaled signal) -> dtw_fill (masked, rescaled signal) -> traceback
 //   -> mid(pass 2: run statistics, borders, cost2, allele length)
