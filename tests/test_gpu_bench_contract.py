@@ -86,3 +86,17 @@ def test_bench_two_ranks_as_the_driver_launches_it(scaling):
         assert 'configs[3]' in d['config']['workload']
         assert abs(d['value'] - reads / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
     assert d['verified']['mismatches'] == 0
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_rccl_collective_path_with_a_one_rank_group(scaling):
+    """The code path N > 1 takes on real hardware -- RCCL all_gather_into_tensor of the records on a side stream, ordered
+    after each step with wsx_caller_join, overlapped with the next step -- run with a one-rank RCCL group on the one GPU
+    (WARPSTR_BENCH_SELF_GATHER=1)."""
+    env = dict(os.environ, WARPSTR_BENCH_SELF_GATHER='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--reads', '7001', '--samples', '900', '--steps', '4',
+                          '--warmup', '1', '--scaling', scaling, '--no-cpu-baseline'], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    d = _one_line(out)
+    assert 'nccl' in d['config']['results_gather'] and d['scaling'] == scaling
+    assert d['config']['called_ok'] == 7001 and d['verified']['mismatches'] == 0
