@@ -97,3 +97,40 @@ def test_headline_and_upstream_test_case_are_conflict_free(shim):
     for t in (aaat.template, aaat.reverse):
         c, *_ = place(shim, t, 4, 2, 1, False)
         assert c == 0
+
+
+def test_random_loci_keep_the_invariants(shim):
+    """Seeded random locus patterns (nested loops, optional blocks, IUPAC codes, interruptions, flanks 12..150): whatever
+    the conflict count, the result is a valid placement and the reported count is the model's."""
+    rng = np.random.default_rng(0)
+    units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CTG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA', 'TTTTA', 'GCN', 'CGG']
+    placed, free = 0, 0
+    for _ in range(40):
+        pat = ''
+        for _u in range(int(rng.integers(1, 4))):
+            unit = units[int(rng.integers(len(units)))]
+            if rng.random() < 0.2:
+                unit = '(' + unit + '){' + units[int(rng.integers(len(units)))] + '}'
+            pat += '(' + unit + ')'
+            if rng.random() < 0.4:
+                pat += ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(1, 14))))
+        locus = synth.make_locus(pat, int(rng.integers(12, 150)), int(rng.integers(1_000_000)))
+        for t in (locus.template, locus.reverse):
+            S = t.n_states
+            K = (S + 63) // 64
+            fan = np.diff(t.pred_ptr)
+            F = max(2, int(fan.max()))
+            if K > 5 or F > 4:
+                continue
+            FL = F
+            if K > 1:
+                FL = 1 if (fan >= 2).sum() <= 64 else (2 if F > 2 and (fan > 2).sum() <= 64 else F)
+            c, pos, sa, ws, low8, _ = place(shim, t, K, F, FL, K == 1 and F == 2)
+            assert len(set(pos.tolist())) == S and all(sa[pos[j]] == j for j in range(S)), pat
+            assert len(set(ws.tolist())) == K * 64 and ws.max() < K * 64, pat
+            assert K == 1 or all(pos[j] < 64 for j in range(S) if fan[j] > FL), pat
+            assert not low8 or all(pos[j] < 8 for j in range(S) if fan[j] >= 2), pat
+            assert c == model_conflicts(t, K, F, FL, pos, sa, ws), pat
+            placed += 1
+            free += c == 0
+    assert placed >= 40 and free >= placed // 2
