@@ -35,6 +35,11 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, N_CU, CLK_MAX_HZ = 1024, 256, 2.4e9
+# Measured issue cost of the fill's instruction mix (6 v_add_f64, 2 v_cmp_lt_f64 -> SGPR pair, 2 v_min_f64, dependent as in the
+# kernel) with 8 waves per SIMD and nothing else to do: 4.29 SIMD cycles per wave-instruction (scripts/exp_valu_rate.hip under
+# rocprofv3 --pmc, profiles/r02_valu_rate.log; plain v_add/v_min 4.15, the compare into an SGPR pair 4.51) -- a property of
+# the hardware, not of the kernel: the nominal 4 cycles are not reachable for this mix.
+ROW_MIX_CYCLES_PER_INST = 4.29
 N_BUF = int(os.environ.get('WSX_INFLIGHT', '2'))  # result buffers = pipelined calls in flight
 
 HEADLINE = ('(AGC)AACAGCCGCCAC(CGC)', 19)
@@ -231,6 +236,7 @@ def valu_roofline(prof, alone_ms, wave_rows, kernel):
     lds = wave_rows * lds_cycles / (alone_ms * 1e-3)
     return {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'wave64 VALU instr/s',
             'frac': achieved / peak, 'frac_at_observed_clock': achieved / (N_SIMD * clk / 4.0),
+            'frac_of_measured_issue_rate_at_observed_clock': achieved / (N_SIMD * clk / ROW_MIX_CYCLES_PER_INST),
             'launch_ms_alone': alone_ms, 'valu_insts_per_wave_row': vpr, 'clock_hz_observed': clk,
             'counters_from': prof['source'],
             'lds_pipe': {'cycles_per_row': lds_cycles, 'frac': lds / (N_CU * CLK_MAX_HZ),
