@@ -231,10 +231,36 @@ def test_reads_in_separate_arrays_equal_the_packed_call():
     keep[7] = False                                                                   # (float32 rounding changes that read)
     assert got[keep].tobytes() == want[keep].tobytes()
     for i in (0, 3, 5, 100, 5999):
-        o = off[i]
-        assert np.array_equal(gextra['seq2'][o:o + got['len2'][i]], wextra['seq2'][o:o + want['len2'][i]])
+        o, g = off[i], gextra['seq2_pos'][i]   # (packed back to back when csrc/seam_helper.c is built, else at off[i])
+        assert np.array_equal(gextra['seq2'][g:g + got['len2'][i]], wextra['seq2'][o:o + want['len2'][i]])
     w32, _ = hip.call(np.concatenate([r.astype(np.float64) for r in reads]), off, aut)
     assert got[7].tobytes() == w32[7].tobytes()
+
+
+def test_workload_seam_with_and_without_the_c_helper(monkeypatch):
+    """CallerWrapper.run on ReadSignal objects: the C loops of csrc/seam_helper.c (pointer collection, packed sequences)
+    and the pure-Python path give the same CallerResults; a signal that is not a float64 array (here a list) sends the
+    whole workload down the Python path."""
+    from warpstr_amd import caller as caller_mod
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    sigs, revs, _ = synth.batch(locus, 700, (600, 2600), 5)
+    cw = CallerWrapper.__new__(CallerWrapper)
+    cw.hip = HipCaller([locus.template, locus.reverse], [19, 19])
+    cw.on_error = 'nan'
+    work = [ReadSignal(f'r{i}', bool(revs[i]), sigs[i]) for i in range(len(sigs))]
+    assert caller_mod._seam() is not None, 'warpstr_amd/_seam_helper.so is built by warpstr_amd.build'
+    fast = cw.run(work)
+    fast_all = [(r.seq, r.cost, r.resc_seq, r.resc_cost) for r in fast]
+    again = [(r.seq, r.resc_seq) for r in cw.run(work)]          # the landing buffers are reused, the results are not
+    assert again == [(a, c) for a, _, c, _ in fast_all]
+    assert [(r.seq, r.resc_seq) for r in fast] == again          # ... and the first call's results are still intact
+    listy = list(work)
+    listy[11] = ReadSignal('r11', bool(revs[11]), [float(x) for x in sigs[11]])
+    mixed = [(r.seq, r.cost, r.resc_seq, r.resc_cost) for r in cw.run(listy)]
+    monkeypatch.setattr(caller_mod, '_SEAM', None)
+    slow = [(r.seq, r.cost, r.resc_seq, r.resc_cost) for r in cw.run(work)]
+    assert fast_all == slow == mixed
+    assert fast.names[3] == 'r3' and len(fast.names) == len(work)
 
 
 def test_chunking_and_order_invariance():

@@ -190,3 +190,29 @@ def test_caller_results_are_lazy_and_list_like():
     with pytest.raises(ReadCallError):
         strict[2]
     assert strict[0].seq == 'ACG'
+
+
+def test_seam_helper_loops():
+    """csrc/seam_helper.c: pointers / lengths / strand flags of a workload of ReadSignal objects, refusal of anything that
+    is not a contiguous float64 1-d buffer (the caller then converts in Python), and the packing of called sequences."""
+    from warpstr_amd import _lib, caller
+    from warpstr_amd.caller import ReadSignal
+    seam = caller._seam()
+    assert seam is not None, 'python -m warpstr_amd.build builds warpstr_amd/_seam_helper.so'
+    rng = np.random.default_rng(1)
+    work = [ReadSignal(f'r{i}', bool(i % 3 == 0), rng.standard_normal(5 + i)) for i in range(40)]
+    ptrs, lens, aut = np.empty(40, np.uintp), np.empty(40, np.int64), np.empty(40, np.int32)
+    assert seam.wsx_seam_collect(work, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == 40
+    assert all(int(ptrs[i]) == work[i].signal.ctypes.data and lens[i] == 5 + i and aut[i] == (i % 3 == 0) for i in range(40))
+    assert seam.wsx_seam_collect(tuple(work), b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == 40
+    for bad in ([1.0, 2.0], np.zeros(4, np.float32), np.zeros(8)[::2], np.zeros((2, 2)), np.zeros(3, np.int64)):
+        w2 = list(work)
+        w2[9] = ReadSignal('x', False, bad)
+        assert seam.wsx_seam_collect(w2, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == -10
+    assert seam.wsx_seam_collect([], b'signal', b'reverse', None, None, None) == 0
+    src = np.frombuffer(b'AAAACCCCGGGGTTTT', np.uint8).copy()
+    off = np.array([0, 4, 8, 12, 16], np.int64)
+    ln = np.array([2, 0, 4, 1], np.int32)
+    pos, out = np.empty(5, np.int64), np.empty(7, np.uint8)
+    assert seam.wsx_seam_pack_sequences(_lib.ptr(src), _lib.ptr(off), _lib.ptr(ln), 4, 4, _lib.ptr(out), _lib.ptr(pos)) == 7
+    assert bytes(out) == b'AAGGGGT' and pos.tolist() == [0, 2, 2, 6, 7]

@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['wsx_api.hip', 'dtw_kernels.hip', 'mid_kernels.hip', 'wsx_prep.hip', 'flank_kernels.hip']
 HEADERS = ['wsx_device.h', 'wsx_place.h', os.path.join('..', '..', 'include', 'warpstr_hip.h')]
 LIB = os.path.join(HERE, 'libwarpstr_hip.so')
+SEAM_SRC = os.path.join(CSRC, 'seam_helper.c')  # CPython-API loops of the Python seam (no compute); optional at run time
+SEAM_LIB = os.path.join(HERE, '_seam_helper.so')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fgpu-rdc' if False else '-fno-gpu-rdc']
 
@@ -44,6 +46,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or _stale(SEAM_LIB, [SEAM_SRC]):
+        import sysconfig
+        cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I', sysconfig.get_paths()['include'], SEAM_SRC, '-o', SEAM_LIB]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

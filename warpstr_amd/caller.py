@@ -92,9 +92,11 @@ class CallerResults(collections.abc.Sequence):
     the batch's result records and the two ASCII sequence buffers -- a CallerResult (two Python strings) is only built for
     the reads that are looked at.  The records are also available as columns (`len2`, `cost2`, ...) for batch consumers."""
 
-    def __init__(self, names, records, offsets, seq1, seq2, on_error: str):
-        """seq1 / seq2: the batch's ASCII buffers (bytes or uint8 arrays; read r starts at offsets[r])."""
+    def __init__(self, names, records, offsets, seq1, seq2, on_error: str, offsets2=None):
+        """seq1 / seq2: the batch's ASCII buffers (bytes or uint8 arrays; read r's seq starts at offsets[r], its resc_seq at
+        offsets2[r] -- the same place in the library's per-sample layout, different ones once packed)."""
         self.names, self.records, self.offsets = names, records, np.asarray(offsets)
+        self.offsets2 = self.offsets if offsets2 is None else np.asarray(offsets2)
         self._seq1, self._seq2, self._on_error = seq1, seq2, on_error
 
     def __len__(self):
@@ -111,9 +113,9 @@ class CallerResults(collections.abc.Sequence):
             if self._on_error == 'raise':
                 raise ReadCallError(f'read {self.names[i]}: caller status {_lib.READ_STATUS.get(st, st)}')
             return CallerResult('', float('nan'), '', float('nan'))
-        o = int(self.offsets[i])
+        o, o2 = int(self.offsets[i]), int(self.offsets2[i])
         return CallerResult(seq=bytes(self._seq1[o:o + int(rec['len1'])]).decode('ascii'), cost=float(rec['cost1']),
-                            resc_seq=bytes(self._seq2[o:o + int(rec['len2'])]).decode('ascii'), resc_cost=float(rec['cost2']))
+                            resc_seq=bytes(self._seq2[o2:o2 + int(rec['len2'])]).decode('ascii'), resc_cost=float(rec['cost2']))
 
     def check(self):
         """Raise for the first read the reference would have failed on (on_error='raise'); cheap, vectorised."""
@@ -129,6 +131,42 @@ class CallerResults(collections.abc.Sequence):
 
     def costs(self):
         return self.records['cost1'].copy(), self.records['cost2'].copy()
+
+
+class _WorkloadNames(collections.abc.Sequence):
+    """names[i] = workload[i].name without building a 50 000-element list per call."""
+
+    def __init__(self, workload):
+        self._w = workload
+
+    def __len__(self):
+        return len(self._w)
+
+    def __getitem__(self, i):
+        return self._w[i].name
+
+
+_SEAM = False
+
+
+def _seam():
+    """warpstr_amd/_seam_helper.so (csrc/seam_helper.c: the two per-read loops of the Python seam in C), or None."""
+    global _SEAM
+    if _SEAM is False:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_seam_helper.so')
+        _SEAM = None
+        if os.path.exists(path) and not os.environ.get('WARPSTR_NO_SEAM_HELPER'):
+            try:
+                lib = C.PyDLL(path)
+                lib.wsx_seam_collect.restype = C.c_int64
+                lib.wsx_seam_collect.argtypes = [C.py_object, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                lib.wsx_seam_pack_sequences.restype = C.c_int64
+                lib.wsx_seam_pack_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                        C.c_void_p]
+                _SEAM = lib
+            except OSError:
+                pass
+    return _SEAM
 
 
 class HipCaller:
@@ -164,6 +202,7 @@ class HipCaller:
                              1 if self.rescaler_config.method == 'median' else 0,
                              1 if self.rescaler_config.reps_as_one else 0)
         self.handle = C.c_void_p()
+        self._seq_landing = None
         _lib.check(self.lib.wsx_caller_create(C.byref(self.handle), device, C.byref(arr), len(self.automata),
                                               C.byref(prm), C.c_void_p(stream)), 'wsx_caller_create')
         if workspace_limit:
@@ -214,11 +253,24 @@ class HipCaller:
                                            C.byref(tr) if tr is not None else None), 'wsx_call_batch')
         return results, extra
 
+    def call_workload(self, workload: Sequence, want_seqs: bool = True):
+        """call_reads for a workload of objects with `.signal` and `.reverse` (ReadSignal, src/schemas/readsignal.py:6-10):
+        the pointers and the strand flags are collected by csrc/seam_helper.c when that helper is built (22 ms -> 3 ms
+        per 50 000 reads); the automaton of a read is 1 for reverse-strand reads, else 0 (wrapper.py:115)."""
+        n = len(workload)
+        seam = _seam()
+        if seam is not None:
+            ptrs, lens, aut = np.empty(n, np.uintp), np.empty(n, np.int64), np.empty(n, np.int32)
+            rc = seam.wsx_seam_collect(workload, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut))
+            if rc == n:
+                return self._call_read_ptrs(ptrs, lens, aut, want_seqs, keep=None)
+        aut = np.fromiter((1 if w.reverse else 0 for w in workload), dtype=np.int32, count=n)
+        return self.call_reads([np.asarray(w.signal) for w in workload], aut, want_seqs)
+
     def call_reads(self, reads: Sequence[np.ndarray], automaton_id: np.ndarray, want_seqs: bool = False):
         """wsx_call_batch_reads: reads in separate float64 arrays (a workload of ReadSignal objects), gathered by the library
         while it uploads -> (results, offsets, dict of optional per-sample outputs laid out by `offsets`)."""
         n = len(reads)
-        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
         ptrs = np.empty(n, np.uintp)
         lens = np.empty(n, np.int64)
         keep = []
@@ -228,18 +280,42 @@ class HipCaller:
                 keep.append(a)
             ptrs[i] = a.__array_interface__['data'][0]
             lens[i] = a.shape[0]
+        return self._call_read_ptrs(ptrs, lens, automaton_id, want_seqs, keep)
+
+    def _call_read_ptrs(self, ptrs, lens, automaton_id, want_seqs, keep):
+        n = len(ptrs)
+        automaton_id = np.ascontiguousarray(automaton_id, np.int32)
         offsets = np.zeros(n + 1, np.int64)
         np.cumsum(lens, out=offsets[1:])
         results = np.zeros(n, dtype=_lib.RESULT_DTYPE)
         extra, tr = {}, None
+        seam = _seam() if want_seqs else None
         if want_seqs:
-            extra['seq1'] = np.zeros(int(offsets[-1]), np.uint8)
-            extra['seq2'] = np.zeros(int(offsets[-1]), np.uint8)
-            tr = _lib.WsxTraces(None, None, None, None, _lib.ptr(extra['seq1']), _lib.ptr(extra['seq2']))
+            total = int(offsets[-1])
+            if seam is not None:
+                # per-sample landing buffers that live with the handle (their pages are touched once, not per call); what
+                # the caller gets are packed copies: sum(len) bytes instead of one byte per sample
+                if self._seq_landing is None or len(self._seq_landing[0]) < total:
+                    self._seq_landing = (np.empty(total, np.uint8), np.empty(total, np.uint8))
+                s1, s2 = self._seq_landing
+            else:
+                s1, s2 = np.zeros(total, np.uint8), np.zeros(total, np.uint8)
+            tr = _lib.WsxTraces(None, None, None, None, _lib.ptr(s1), _lib.ptr(s2))
         _lib.check(self.lib.wsx_call_batch_reads(self.handle, _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(automaton_id), n,
                                                  _lib.ptr(results), C.byref(tr) if tr is not None else None),
                    'wsx_call_batch_reads')
         del keep
+        if want_seqs and seam is not None:
+            for key, src, field in (('seq1', s1, 'len1'), ('seq2', s2, 'len2')):
+                lens_f = np.where(results['status'] == 0, results[field], 0).astype(np.int32)  # failed reads: no sequence
+                pos = np.empty(n + 1, np.int64)
+                out = np.empty(int(lens_f.sum(dtype=np.int64)), np.uint8)
+                seam.wsx_seam_pack_sequences(_lib.ptr(src), _lib.ptr(offsets), _lib.ptr(lens_f), 4, n, _lib.ptr(out),
+                                             _lib.ptr(pos))
+                extra[key], extra[key + '_pos'] = out, pos
+        elif want_seqs:
+            extra['seq1'], extra['seq2'] = s1, s2
+            extra['seq1_pos'] = extra['seq2_pos'] = offsets
         return results, offsets, extra
 
     def warp(self, signal: np.ndarray, offsets: np.ndarray, automaton_id: np.ndarray, mask: Optional[np.ndarray] = None,
@@ -431,9 +507,9 @@ class CallerWrapper:
         if not workload:
             return []
         # (no packing on this side: the library gathers the reads' own arrays into its upload buffers)
-        aut = np.fromiter((1 if w.reverse else 0 for w in workload), dtype=np.int32, count=len(workload))
-        res, offsets, extra = self.hip.call_reads([np.asarray(w.signal) for w in workload], aut, want_seqs=True)
-        return CallerResults([w.name for w in workload], res, offsets[:-1], extra['seq1'], extra['seq2'], self.on_error).check()
+        res, offsets, extra = self.hip.call_workload(workload, want_seqs=True)
+        return CallerResults(_WorkloadNames(workload), res, extra['seq1_pos'][:-1], extra['seq1'], extra['seq2'], self.on_error,
+                             offsets2=extra['seq2_pos'][:-1]).check()
 
     def run_raw(self, names: Sequence[str], reverses: Sequence[bool], raws: Sequence[np.ndarray],
                 positions: Sequence[Sequence[int]], spike_removal: str = 'Brute') -> 'CallerResults':

@@ -1,0 +1,72 @@
+// seam_helper.c -- the Python side of CallerWrapper.run(List[ReadSignal]) (upstream src/caller/wrapper.py:104-120) spends
+// its time walking 50 000 Python objects.  These two loops do that walk with the CPython C API (loaded through
+// ctypes.PyDLL, so the GIL is held): no arithmetic happens here, the HIP library gets the same pointers as before.
+// Built by warpstr_amd/build.py into warpstr_amd/_seam_helper.so; caller.py falls back to its own loops if it is absent.
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+
+// For every item of `workload`: ptrs[i] / lens[i] = address and length of item.<sig_attr> (a C-contiguous 1-d float64
+// buffer), aut[i] = 1 if item.<rev_attr> is true else 0.  Returns n, or -(i+1) if item i does not qualify (the caller
+// then converts the arrays itself), or INT64_MIN on a Python error.
+int64_t wsx_seam_collect(PyObject *workload, const char *sig_attr, const char *rev_attr, uintptr_t *ptrs, int64_t *lens,
+                         int32_t *aut)
+{
+    PyObject *fast = PySequence_Fast(workload, "workload must be a sequence");
+    if (!fast) return INT64_MIN;
+    PyObject *sig_name = PyUnicode_InternFromString(sig_attr), *rev_name = PyUnicode_InternFromString(rev_attr);
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+    int64_t rc = n;
+    for (Py_ssize_t i = 0; i < n && rc == n; i++) {
+        PyObject *item = PySequence_Fast_GET_ITEM(fast, i);
+        PyObject *sig = PyObject_GetAttr(item, sig_name);
+        PyObject *rev = sig ? PyObject_GetAttr(item, rev_name) : NULL;
+        if (!sig || !rev) {
+            rc = INT64_MIN;
+        } else {
+            Py_buffer view;
+            if (PyObject_GetBuffer(sig, &view, PyBUF_FORMAT | PyBUF_ND | PyBUF_C_CONTIGUOUS) != 0) {
+                PyErr_Clear();
+                rc = -(int64_t)(i + 1);
+            } else {
+                const char *f = view.format ? view.format : "B";
+                if (*f == '@' || *f == '=' || *f == '<') f++;
+                if (view.ndim != 1 || view.itemsize != 8 || strcmp(f, "d") != 0) {
+                    rc = -(int64_t)(i + 1);
+                } else {
+                    ptrs[i] = (uintptr_t)view.buf; // the array outlives the call: the workload holds it
+                    lens[i] = (int64_t)view.shape[0];
+                }
+                PyBuffer_Release(&view);
+            }
+            const int t = PyObject_IsTrue(rev);
+            if (t < 0) rc = INT64_MIN;
+            aut[i] = t > 0;
+        }
+        Py_XDECREF(sig);
+        Py_XDECREF(rev);
+    }
+    Py_XDECREF(sig_name);
+    Py_XDECREF(rev_name);
+    Py_DECREF(fast);
+    return rc;
+}
+
+// Packs the called sequences of a batch: read r's bytes src[offsets[r] .. offsets[r] + len[r]) go to dst[pos[r] ..) with
+// pos = exclusive prefix sum of len (written to pos[0..n]); len is read with a byte stride (a field of the result
+// records).  dst must hold sum(len) bytes; returns that sum.
+int64_t wsx_seam_pack_sequences(const uint8_t *src, const int64_t *offsets, const void *len_field, int64_t len_stride,
+                                int64_t n, uint8_t *dst, int64_t *pos)
+{
+    int64_t total = 0;
+    for (int64_t r = 0; r < n; r++) {
+        int32_t len;
+        memcpy(&len, (const char *)len_field + r * len_stride, sizeof len);
+        if (len < 0) len = 0;
+        pos[r] = total;
+        if (dst) memcpy(dst + total, src + offsets[r], (size_t)len);
+        total += len;
+    }
+    pos[n] = total;
+    return total;
+}
