@@ -806,13 +806,18 @@ __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
 }
 
 // (6) rescaling input: accepted records, stably sorted by value (filter_alignment + list.sort, caller.py:304-318):
-// compact (order preserved), then rank = #(x_q < x_k) + #(x_q == x_k, q < k).  One wavefront per read.
+// compact (order preserved), then rank = #(x_q < x_k) + #(x_q == x_k, q < k) -- counted inside value buckets for the usual
+// 100-1000 records, directly for fewer or more.  One wavefront per read.
 __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
 {
 #ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
     __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
 #endif
-    __shared__ double xs[512];
+    constexpr int SORT_CAP = 1024, SORT_BUCKETS = 1024, SORT_DIRECT_MAX = 96; // (fewer than ~100 records: counting is cheaper)
+    __shared__ double xs[SORT_CAP]; // direct counting: a tile of the values; bucketed: the values grouped by bucket
+    __shared__ int sort_cnt[SORT_BUCKETS], sort_start[SORT_BUCKETS + 1];
+    __shared__ uint32_t sort_bs[SORT_CAP];  // per element: bucket | slot inside the bucket << 16
+    __shared__ uint16_t sort_idx[SORT_CAP]; // the elements' positions, grouped like xs
     const int lane = threadIdx.x & 63;
     const int lr = blockIdx.x;
     if (a.status[lr] != 0) return;
@@ -837,6 +842,84 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const int mfit = base;
+    if (mfit > SORT_DIRECT_MAX && mfit <= SORT_CAP) {
+        // Bucketed rank.  b(x) = int((x - min) * (SORT_BUCKETS - 1) / (max - min)) never decreases with x and is the same
+        // for equal values, so an element's rank is the number of elements in lower buckets plus its rank among the members
+        // of its own bucket -- a handful of comparisons instead of mfit.  The order is the same total order as below (value,
+        // then position), whatever the bucket boundaries are.
+        double mn = kInf, mx = -kInf;
+        for (int k = lane; k < mfit; k += 64) {
+            const double x = cx[k];
+            mn = x < mn ? x : mn;
+            mx = x > mx ? x : mx;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double m1 = __shfl_xor(mn, o), m2 = __shfl_xor(mx, o);
+            mn = m1 < mn ? m1 : mn;
+            mx = m2 > mx ? m2 : mx;
+        }
+        const double scale = mx > mn ? (double)(SORT_BUCKETS - 1) / (mx - mn) : 0.0;
+        auto bucket = [&](double x) {
+            const int b = (int)((x - mn) * scale);
+            return b < 0 ? 0 : (b > SORT_BUCKETS - 1 ? SORT_BUCKETS - 1 : b);
+        };
+        for (int b = lane; b < SORT_BUCKETS; b += 64) sort_cnt[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < mfit; k += 64) {
+            const int b = bucket(cx[k]);
+            const int slot = atomicAdd(&sort_cnt[b], 1);
+            sort_bs[k] = (uint32_t)b | ((uint32_t)slot << 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        { // exclusive prefix sum of the bucket counts: SORT_BUCKETS / 64 consecutive buckets per lane, then across the lanes
+            constexpr int PER = SORT_BUCKETS / 64;
+            int c[PER], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                c[q] = sort_cnt[lane * PER + q];
+                tot += c[q];
+            }
+            int incl = tot;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                sort_start[lane * PER + q] = run;
+                run += c[q];
+            }
+            if (lane == 63) sort_start[SORT_BUCKETS] = run;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < mfit; k += 64) {
+            const uint32_t p = sort_bs[k];
+            const int at = sort_start[p & 0xffffu] + (int)(p >> 16);
+            xs[at] = cx[k];
+            sort_idx[at] = (uint16_t)k;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int kb = 0; kb < mfit; kb += 64) {
+            const int k = kb + lane;
+            const bool valid = k < mfit;
+            const double xk = valid ? cx[k] : 0.0;
+            const int b = valid ? (int)(sort_bs[k] & 0xffffu) : 0;
+            const int j0 = sort_start[b], j1 = valid ? sort_start[b + 1] : j0;
+            int below = 0;
+            for (int j = j0; __any(j < j1); j++)
+                if (j < j1) {
+                    const double xq = xs[j];
+                    below += (xq < xk || (xq == xk && (int)sort_idx[j] < k)) ? 1 : 0;
+                }
+            if (valid) {
+                fx[j0 + below] = xk;
+                fy[j0 + below] = cy[k];
+            }
+        }
+        if (lane == 0) a.fit_m[lr] = mfit;
+        return;
+    }
     for (int kb = 0; kb < mfit; kb += 64) {
         const int k = kb + lane;
         const double xk = (k < mfit) ? cx[k] : 0.0;
