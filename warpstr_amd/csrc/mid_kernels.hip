@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
 #ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
     __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
 #endif
-    constexpr int SORT_CAP = 1024, SORT_BUCKETS = 1024, SORT_DIRECT_MAX = 96; // (fewer than ~100 records: counting is cheaper)
+    constexpr int SORT_CAP = 512, SORT_BUCKETS = 512, SORT_DIRECT_MAX = 96; // (fewer than ~100 records: counting is cheaper)
     __shared__ double xs[SORT_CAP]; // direct counting: a tile of the values; bucketed: the values grouped by bucket
     __shared__ int sort_cnt[SORT_BUCKETS], sort_start[SORT_BUCKETS + 1];
     __shared__ uint32_t sort_bs[SORT_CAP];  // per element: bucket | slot inside the bucket << 16
