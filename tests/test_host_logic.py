@@ -195,8 +195,13 @@ def test_caller_results_are_lazy_and_list_like():
 def test_seam_helper_loops():
     """csrc/seam_helper.c: pointers / lengths / strand flags of a workload of ReadSignal objects, refusal of anything that
     is not a contiguous float64 1-d buffer (the caller then converts in Python), and the packing of called sequences."""
-    from warpstr_amd import _lib, caller
+    from warpstr_amd import _lib, build, caller
     from warpstr_amd.caller import ReadSignal
+    if not os.path.exists(build.SEAM_LIB):  # (a clean clone: the helper is a few seconds of gcc, the HIP library minutes)
+        import subprocess
+        import sysconfig
+        subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-I', sysconfig.get_paths()['include'], build.SEAM_SRC, '-o', build.SEAM_LIB])
+        caller._SEAM = False
     seam = caller._seam()
     assert seam is not None, 'python -m warpstr_amd.build builds warpstr_amd/_seam_helper.so'
     rng = np.random.default_rng(1)
