@@ -1,0 +1,99 @@
+"""Randomised parity sweep over LOCI: many seeded random locus patterns (nested units, optional blocks, IUPAC codes,
+interruptions, flanks 12..150 -> automata of 30..320+ states, fan-in 2..4, every fill variant and the generic kernel), a
+few dozen reads each, HIP caller vs the CPU oracle on all outputs incl. both state paths.  One line per kernel variant and a
+final tally; exit code 1 on any mismatch.  (Test infrastructure: uses oracle/.)   Usage: fuzz_loci.py [n_loci] [reads_per_locus]"""
+import sys, os, time, collections
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle
+from warpstr_amd import synth
+from warpstr_amd.caller import HipCaller, pack_signals
+
+def run(n_loci, per, seed=2026, verbose=True):
+    """-> (reads compared, mismatches, {kernel name: reads})"""
+    units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CTG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA', 'TTTTA', 'GCN', 'CGG', 'AT', 'ATTCT']
+    rng = np.random.default_rng(seed)
+    oracle.lib()
+    tot = bad = skipped = 0
+    by_kernel = collections.Counter()
+    bad_by_kernel = collections.Counter()
+    t00 = time.time()
+    for li in range(n_loci):
+        pat = ''
+        for _u in range(int(rng.integers(1, 4))):
+            unit = units[int(rng.integers(len(units)))]
+            if rng.random() < 0.2:
+                unit = '(' + unit + '){' + units[int(rng.integers(len(units)))] + '}'
+            pat += '(' + unit + ')'
+            if rng.random() < 0.4:
+                pat += ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(1, 14))))
+        fl = int(rng.integers(12, 150))
+        try:
+            locus = synth.make_locus(pat, fl, int(rng.integers(1_000_000)))
+        except Exception:  # (patterns the automaton compiler refuses, as upstream does)
+            skipped += 1
+            continue
+        S = max(locus.template.n_states, locus.reverse.n_states)
+        try:
+            hip = HipCaller([locus.template, locus.reverse], [fl, fl])
+        except Exception as e:
+            skipped += 1
+            if verbose:
+                print(f'{pat} fl={fl} S={S}: not accepted by wsx_caller_create ({str(e)[:80]})', flush=True)
+            continue
+        sigs, revs = [], []
+        for i in range(per):
+            rev = bool(rng.random() < 0.5)
+            t = int(rng.integers(max(6 * S, 400), max(6 * S, 400) + 2500))
+            hi = max(2, min(30, (t // 4 - 2 * fl - 12) // 14))
+            s, _ = synth.squiggle(locus, rev, t, rng, lo=1, hi=hi, sigma=float(rng.choice([0.15, 0.25, 0.4])))
+            sigs.append(s)
+            revs.append(rev)
+        sig, off = pack_signals(sigs)
+        aut = np.array(revs, dtype=np.int32)
+        res, ex = hip.call(sig, off, aut, want_traces=True)
+        oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+
+        def check(i):
+            o = oracle.call_read(oa[aut[i]], sigs[i])
+            if int(res['status'][i]) != o.status:
+                return f'read {i}: status {res["status"][i]} vs {o.status}'
+            if o.status:
+                return None
+            sl = slice(off[i], off[i + 1])
+            if not np.array_equal(ex['trace1'][sl], o.trace1):
+                return f'read {i}: trace1'
+            if not np.array_equal(ex['trace2'][sl], o.trace2):
+                return f'read {i}: trace2'
+            if (res['len1'][i], res['len2'][i], res['n_trans1'][i], res['n_trans2'][i]) != (o.len1, o.len2, o.n_trans1, o.n_trans2):
+                return f'read {i}: lengths'
+            for a, b in ((res['cost1'][i], o.cost1), (res['cost2'][i], o.cost2), (res['dtw_end_cost1'][i], o.dtw_end_cost1),
+                         (res['dtw_end_cost2'][i], o.dtw_end_cost2)):
+                if not (a == b or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-9 * max(abs(a), abs(b))):
+                    return f'read {i}: cost {a} vs {b}'
+            return None
+        with ThreadPoolExecutor(os.cpu_count()) as pool:
+            errs = [e for e in pool.map(check, range(per)) if e]
+        for k in (0, 1):
+            by_kernel[hip.kernel_name(k)] += int((aut == k).sum())
+        tot += per
+        bad += len(errs)
+        if errs:
+            bad_by_kernel[hip.kernel_name(0)] += len(errs)
+            print(f'MISMATCH {pat} fl={fl} S={locus.template.n_states}/{locus.reverse.n_states} {hip.kernel_name(0)} / '
+                  f'{hip.kernel_name(1)}: {errs[:3]}', flush=True)
+        if verbose and li % 100 == 99:
+            print(f'... {li + 1} loci, {tot} reads, {bad} mismatches, {time.time() - t00:.0f} s', flush=True)
+        hip.close()
+    if verbose:
+        for k, n in sorted(by_kernel.items()):
+            print(f'{k:40s} {n:7d} reads  {bad_by_kernel.get(k, 0)} mismatching')
+        print(f'TOTAL {n_loci - skipped} loci ({skipped} skipped), {tot} reads, {bad} mismatches, {time.time()-t00:.0f} s')
+    return tot, bad, dict(by_kernel)
+
+
+if __name__ == '__main__':
+    n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+    sys.exit(1 if run(n_loci, per)[1] else 0)

@@ -1,5 +1,7 @@
 """Parity of the HIP caller (through the C ABI) with the CPU oracle and the golden vectors.
 Everything here needs an MI355X: `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from warpstr_amd.caller import (CallerConfig, CallerWrapper, HipCaller, ReadSign
                                 sequence_from_trace)
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COST_REL = 1e-5  # north_star tolerance on DTW cost; integer outputs must be identical
 
@@ -801,3 +804,18 @@ def test_long_reads_many_automata_and_degenerate_reads():
             assert (res['len1'][i], res['len2'][i]) == (o.len1, o.len2)
             assert_close_rel(res['cost2'][i], o.cost2, COST_REL)
     assert n_ok >= 16 and (res['status'][-4:] != 0).all()
+
+
+def test_random_loci_reach_every_kind_of_fill_kernel():
+    """Seeded random locus patterns (scripts/fuzz_loci.py: nested units, optional blocks, IUPAC codes, interruptions,
+    flanks 12..150): 60 loci x 16 reads against the oracle on every output incl. both state paths -- single- and multi-slot
+    fills, split and uniform candidate counts, packed rows and the generic kernel all occur."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fuzz_loci', os.path.join(ROOT, 'scripts', 'fuzz_loci.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    reads, mismatches, kernels = mod.run(60, 16, seed=7, verbose=False)
+    assert reads >= 800 and mismatches == 0
+    names = ' '.join(kernels)
+    assert 'dtw_fill_generic' in names and '<4, 1, 2, 2, true>' in names
+    assert sum(1 for k in kernels if k.startswith('dtw_fill_fast<4, ') and not k.startswith('dtw_fill_fast<4, 1,')) >= 6
