@@ -1,7 +1,7 @@
 """Randomised parity sweep over LOCI: many seeded random locus patterns (nested units, optional blocks, IUPAC codes,
 interruptions, flanks 12..150 -> automata of 30..320+ states, fan-in 2..4, every fill variant and the generic kernel), a
 few dozen reads each, HIP caller vs the CPU oracle on all outputs incl. both state paths.  One line per kernel variant and a
-final tally; exit code 1 on any mismatch.  (Test infrastructure: uses oracle/.)   Usage: fuzz_loci.py [n_loci] [reads_per_locus]"""
+final tally; exit code 1 on any mismatch.  (Test infrastructure: uses oracle/.)   Usage: fuzz_loci.py [n_loci] [reads_per_locus] [--configs]"""
 import sys, os, time, collections
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,15 @@ from oracle import oracle
 from warpstr_amd import synth
 from warpstr_amd.caller import HipCaller, pack_signals
 
-def run(n_loci, per, seed=2026, verbose=True):
+# caller / rescaler settings a locus may be called with (config.py:91-119 upstream); `configs=True` cycles through them
+CONFIGS = [dict(), dict(min_values_per_state=3), dict(min_values_per_state=5), dict(min_values_per_state=2),
+           dict(method='median'), dict(reps_as_one=True), dict(states_in_segment=4), dict(min_values_per_state=3, method='median'),
+           dict(threshold=0.8, max_std=0.3)]
+
+
+def run(n_loci, per, seed=2026, verbose=True, configs=False):
     """-> (reads compared, mismatches, {kernel name: reads})"""
+    from warpstr_amd.caller import CallerConfig, RescalerConfig
     units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CTG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA', 'TTTTA', 'GCN', 'CGG', 'AT', 'ATTCT']
     rng = np.random.default_rng(seed)
     oracle.lib()
@@ -35,8 +42,13 @@ def run(n_loci, per, seed=2026, verbose=True):
             skipped += 1
             continue
         S = max(locus.template.n_states, locus.reverse.n_states)
+        cfg = CONFIGS[li % len(CONFIGS)] if configs else {}
+        cc = CallerConfig(**{k: v for k, v in cfg.items() if k in ('min_values_per_state', 'states_in_segment')})
+        rc = RescalerConfig(**{k: v for k, v in cfg.items() if k in ('method', 'reps_as_one', 'threshold', 'max_std')})
+        prm = oracle.Params(min_values_per_state=cc.min_values_per_state, states_in_segment=cc.states_in_segment,
+                            threshold=rc.threshold, max_std=rc.max_std, method=rc.method, reps_as_one=rc.reps_as_one)
         try:
-            hip = HipCaller([locus.template, locus.reverse], [fl, fl])
+            hip = HipCaller([locus.template, locus.reverse], [fl, fl], caller_config=cc, rescaler_config=rc)
         except Exception as e:
             skipped += 1
             if verbose:
@@ -56,7 +68,7 @@ def run(n_loci, per, seed=2026, verbose=True):
         oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
 
         def check(i):
-            o = oracle.call_read(oa[aut[i]], sigs[i])
+            o = oracle.call_read(oa[aut[i]], sigs[i], prm)
             if int(res['status'][i]) != o.status:
                 return f'read {i}: status {res["status"][i]} vs {o.status}'
             if o.status:
@@ -76,11 +88,11 @@ def run(n_loci, per, seed=2026, verbose=True):
         with ThreadPoolExecutor(os.cpu_count()) as pool:
             errs = [e for e in pool.map(check, range(per)) if e]
         for k in (0, 1):
-            by_kernel[hip.kernel_name(k)] += int((aut == k).sum())
+            by_kernel[hip.kernel_name(k) + (' ' + str(cfg) if cfg else '')] += int((aut == k).sum())
         tot += per
         bad += len(errs)
         if errs:
-            bad_by_kernel[hip.kernel_name(0)] += len(errs)
+            bad_by_kernel[hip.kernel_name(0) + (' ' + str(cfg) if cfg else '')] += len(errs)
             print(f'MISMATCH {pat} fl={fl} S={locus.template.n_states}/{locus.reverse.n_states} {hip.kernel_name(0)} / '
                   f'{hip.kernel_name(1)}: {errs[:3]}', flush=True)
         if verbose and li % 100 == 99:
@@ -96,4 +108,4 @@ def run(n_loci, per, seed=2026, verbose=True):
 if __name__ == '__main__':
     n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 48
-    sys.exit(1 if run(n_loci, per)[1] else 0)
+    sys.exit(1 if run(n_loci, per, configs='--configs' in sys.argv)[1] else 0)
