@@ -56,6 +56,19 @@ def test_bench_other_workloads_keep_the_contract(workload):
     assert d['verified']['mismatches'] == 0 and d['verified']['reads'] > 0
 
 
+def test_bench_from_raw_leg_reports_both_variants_and_checks_them():
+    """--from-raw: int16 segments -> wsx_prepare_signals -> wsx_call_batch with both sequences -> records, from HBM and
+    from pinned host memory, as a secondary field of the same one line; the leg compares its records and sequences with the
+    float64 path."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--reads', '6000', '--samples', '900', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline', '--from-raw'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    d = _one_line(out)
+    f = d['from_raw']
+    assert f['reads_per_s_hbm_int16'] > 0 and f['reads_per_s_host_int16'] > 0
+    assert f['identical_to_f64_path']['identical'] is True and f['identical_to_f64_path']['reads'] > 0
+    assert f['h2d_bytes_per_step'] == 6000 * 900 * 2
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
