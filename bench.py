@@ -40,7 +40,7 @@ N_SIMD, N_CU, CLK_MAX_HZ = 1024, 256, 2.4e9
 # rocprofv3 --pmc, profiles/r02_valu_rate.log; plain v_add/v_min 4.15, the compare into an SGPR pair 4.51) -- a property of
 # the hardware, not of the kernel: the nominal 4 cycles are not reachable for this mix.
 ROW_MIX_CYCLES_PER_INST = 4.29
-N_BUF = int(os.environ.get('WSX_INFLIGHT', '2'))  # result buffers = pipelined calls in flight
+N_BUF = 4  # result buffers >= pipelined calls in flight (two for big batches, four for small ones: include/warpstr_hip.h)
 
 HEADLINE = ('(AGC)AACAGCCGCCAC(CGC)', 19)
 CFG1 = ('(AAAT)', 110, (2271, 3701))

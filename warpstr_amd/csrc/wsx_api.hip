@@ -261,6 +261,7 @@ struct wsx_caller {
     size_t pinned_cap[kMetaSlots] = {};
     hipEvent_t ev_meta[kMetaSlots] = {}; // recorded when the call that used the slot has finished
     int in_flight = 2;                    // pipelined calls the host may run ahead of the device (<= kMetaSlots)
+    int in_flight_small = kMetaSlots;     // ... for small batches (one chunk each; WSX_INFLIGHT_SMALL)
     bool pipelined = false;                     // wsx_caller_set_pipelined
     uint64_t call_seq = 0;
     int rot = 0; // pipelined calls with fewer chunks than streams: the first work set / stream of the next call
@@ -590,6 +591,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     if (const char *e = getenv("WSX_CHUNKS")) c->chunks_override = std::max(1, atoi(e));
     if (const char *e = getenv("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     if (const char *e = getenv("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
+    if (const char *e = getenv("WSX_INFLIGHT_SMALL")) c->in_flight_small = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
     // The streams one call spreads over exist from the start; the others (small pipelined calls taking turns) are created
     // when first used: the runtime maps streams onto a few hardware queues in order of creation, streams that merely exist
     // already cost big calls 2 % (profiles/r02_ab_streams.log), and creating these ones late, after work has been queued,
@@ -805,7 +807,13 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // chunks follow this call's on every internal stream without a gap; wsx_caller_join orders a consumer after it.
     const bool pipe = c->pipelined && !host;
     if (c->pipelined && host) HIPCHK(hipStreamWaitEvent(st, c->ev_end, 0));
-    const int slot = pipe ? (int)(c->call_seq++ % (uint64_t)c->in_flight) : 0;
+    // The host may run this many pipelined calls ahead of the device: two for batches that fill the chip by themselves, up
+    // to kMetaSlots for small ones (each takes one stream, consecutive calls rotate over the streams: four side by side;
+    // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
+    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) < ((int64_t)80 << 20) && n < 32768;
+    const int depth = small_pipe ? c->in_flight_small : c->in_flight;
+    const uint64_t seq = pipe ? c->call_seq++ : 0;
+    const int slot = pipe ? (int)(seq % (uint64_t)wsx_caller::kMetaSlots) : 0;
     const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
                                       io.traces.seq1 || io.traces.seq2);
     if (full && (io.traces.seq1 || io.traces.seq2) && !c->have_bases) {
@@ -818,6 +826,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // the call that used this slot last (the previous one; in pipelined mode the one before that) has to be over:
     // its kernels read the device copy, its uploads the pinned one (no-op if never recorded)
     HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
+    if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
+        HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
     HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
     Carver mc(c->meta[slot].p);
     int64_t *d_offsets = mc.take<int64_t>(n + 1);
@@ -872,15 +882,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // chunk run under the VALU-bound fill of another).  The thread-per-read stages want launches of ~25k reads, so a
     // second round of chunks per stream only pays from ~200k reads on, or when reads are long (their serial stages then
     // last long enough to need another chunk's fill to hide under); measured in profiles/r01s5_chunk_sweep.log.  Small
-    // pipelined calls: two chunks, consecutive calls on alternating pairs of streams -- two calls side by side fill the
-    // chip better than one call cut into four (profiles/r02_small_call_sweep.log).  WSX_CHUNKS (read when the handle is
+    // pipelined calls: one chunk, consecutive calls on consecutive streams -- four calls side by side fill the chip better
+    // than one call cut into four (profiles/r02_small_call_sweep.log).  WSX_CHUNKS (read when the handle is
     // created) overrides the count.  The workspace limit may ask for more chunks than that.
     const int spc = std::min(c->n_streams, c->streams_per_call);
     const int64_t total_samples = io.offsets[n] - io.offsets[0];
     const bool small_call = total_samples < (int64_t)80 << 20;
     int want = 1;
     if (n >= 4096) {
-        want = (n >= 8192 && !(pipe && small_call)) ? spc : 2;
+        want = (pipe && small_call) ? (c->in_flight_small > 2 ? 1 : 2) : (n >= 8192 ? spc : 2);
         if (n >= 32768) {
             const bool long_reads = total_samples / n >= 4096;
             const int64_t per_round = (int64_t)25000 * spc;
