@@ -155,7 +155,7 @@ int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
  * drain in between.  With `on` != 0 a wsx_call_batch / wsx_warp_batch on WSX_MEM_DEVICE buffers still reads its inputs
  * in the order of the handle's stream, but no longer makes that stream wait for its end: the next call's chunks then
  * follow this call's on every internal stream without a gap (at most two calls are in flight, four if they are small --
- * fewer than 32 768 reads and 80 M samples --; the next one blocks the host until the oldest has finished: keep that many
+ * fewer than 32 768 reads and at most 52 M samples --; the next one blocks the host until the oldest has finished: keep that many
  * sets of output buffers).  Outputs may be consumed only after wsx_caller_join (stream order) or
  * wsx_caller_synchronize / wsx_caller_last_timing (host).  Turning the mode off joins the handle's stream.
  */

@@ -256,6 +256,7 @@ struct wsx_caller {
     // offsets / automaton ids / launch order of a call: device copy + pinned staging (caller buffers are not kept).
     // Two slots: pipelined calls alternate, so that call k+1 is prepared and enqueued while call k still runs.
     static constexpr int kMetaSlots = 4;
+    static constexpr int64_t kSmallPipeSamples = (int64_t)52 << 20; // pipelined calls up to this size: one chunk, four in flight
     DeviceBuf meta[kMetaSlots];
     void *pinned[kMetaSlots] = {};
     size_t pinned_cap[kMetaSlots] = {};
@@ -810,7 +811,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // The host may run this many pipelined calls ahead of the device: two for batches that fill the chip by themselves, up
     // to kMetaSlots for small ones (each takes one stream, consecutive calls rotate over the streams: four side by side;
     // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
-    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) < ((int64_t)80 << 20) && n < 32768;
+    // (up to 50 M samples per call; at 60 M -- 30 000 reads of 2 000 samples, 20 000 of 3 000 -- four whole calls side by
+    // side ran at half the speed of two calls of two chunks each: the bound below keeps to what was measured)
+    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= wsx_caller::kSmallPipeSamples && n < 32768;
     const int depth = small_pipe ? c->in_flight_small : c->in_flight;
     const uint64_t seq = pipe ? c->call_seq++ : 0;
     const int slot = pipe ? (int)(seq % (uint64_t)wsx_caller::kMetaSlots) : 0;
@@ -890,7 +893,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     const bool small_call = total_samples < (int64_t)80 << 20;
     int want = 1;
     if (n >= 4096) {
-        want = (pipe && small_call) ? (c->in_flight_small > 2 ? 1 : 2) : (n >= 8192 ? spc : 2);
+        want = (pipe && small_call) ? ((c->in_flight_small > 2 && total_samples <= wsx_caller::kSmallPipeSamples) ? 1 : 2) : (n >= 8192 ? spc : 2);
         if (n >= 32768) {
             const bool long_reads = total_samples / n >= 4096;
             const int64_t per_round = (int64_t)25000 * spc;
