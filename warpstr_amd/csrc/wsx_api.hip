@@ -813,7 +813,11 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
     // (up to 50 M samples per call; at 60 M -- 30 000 reads of 2 000 samples, 20 000 of 3 000 -- four whole calls side by
     // side ran at half the speed of two calls of two chunks each: the bound below keeps to what was measured)
-    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= wsx_caller::kSmallPipeSamples && n < 32768;
+    static const int64_t small_pipe_samples = [] { // (experiments: another bound for the one-chunk policy, in samples)
+        const char *e = getenv("WSX_SMALL_PIPE_SAMPLES");
+        return e ? (int64_t)atoll(e) : wsx_caller::kSmallPipeSamples;
+    }();
+    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= small_pipe_samples && n < 32768;
     const int depth = small_pipe ? c->in_flight_small : c->in_flight;
     const uint64_t seq = pipe ? c->call_seq++ : 0;
     const int slot = pipe ? (int)(seq % (uint64_t)wsx_caller::kMetaSlots) : 0;
@@ -893,7 +897,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     const bool small_call = total_samples < (int64_t)80 << 20;
     int want = 1;
     if (n >= 4096) {
-        want = (pipe && small_call) ? ((c->in_flight_small > 2 && total_samples <= wsx_caller::kSmallPipeSamples) ? 1 : 2) : (n >= 8192 ? spc : 2);
+        want = (pipe && small_call) ? ((c->in_flight_small > 2 && total_samples <= small_pipe_samples) ? 1 : 2) : (n >= 8192 ? spc : 2);
         if (n >= 32768) {
             const bool long_reads = total_samples / n >= 4096;
             const int64_t per_round = (int64_t)25000 * spc;
@@ -944,8 +948,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     const int rot = (pipe && small_call && n_work < c->n_streams) ? c->rot % c->n_streams : 0;
     if (pipe) c->rot = (rot + n_work) % c->n_streams;
     auto wset = [&](size_t ci) -> int { return (rot + (int)(ci % n_work)) % c->n_streams; };
-    for (int k = 0; k < n_work; k++) {
-        const int w = wset(k);
+    // A pipelined call that rotates over the streams sizes the work sets of ALL of them, not only its own: the next calls
+    // land on the other sets, and a multi-gigabyte hipMalloc in the middle of a pipelined sequence stalls every stream
+    // (seen as 8 instead of 4.6 ms per step over 30 steps of 30 000 reads, 26-33 instead of 11.5 ms for the flank-110 shape,
+    // when the benchmark's two warm-up calls had touched only two of the four sets: profiles/r02_small_call_sweep.log).
+    const bool rotates = pipe && small_call && n_work < c->n_streams;
+    const int n_sized = rotates ? c->n_streams : n_work;
+    auto sized_set = [&](int k) -> int { return rotates ? k : wset(k); };
+    for (int k = 0; k < n_sized; k++) {
+        const int w = sized_set(k);
         if (w > 0 && !c->aux[w]) {
             HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
@@ -973,7 +984,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             if (uvar[u].same(v)) return uoff[u];
         return 0;
     };
-    for (int k = 0; k < n_work; k++) HIPCHK(c->work[wset(k)].bp.ensure(bp_words * 4));
+    for (int k = 0; k < n_sized; k++) HIPCHK(c->work[sized_set(k)].bp.ensure(bp_words * 4));
     for (int k = 0; k < n_work && host; k++) {
         const int w = wset(k);
         HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
