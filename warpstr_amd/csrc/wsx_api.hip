@@ -836,6 +836,20 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
         HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
     HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
+    if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
+        for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
+            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+            if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
+            HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
+            HIPCHK(c->meta[q].ensure(need));
+            if (need > c->pinned_cap[q]) {
+                if (c->pinned[q]) (void)hipHostFree(c->pinned[q]);
+                c->pinned[q] = nullptr;
+                c->pinned_cap[q] = 0;
+                HIPCHK(hipHostMalloc(&c->pinned[q], need + need / 4, hipHostMallocDefault));
+                c->pinned_cap[q] = need + need / 4;
+            }
+        }
     Carver mc(c->meta[slot].p);
     int64_t *d_offsets = mc.take<int64_t>(n + 1);
     int32_t *d_autid = mc.take<int32_t>(n);
