@@ -87,6 +87,29 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
             return None
         with ThreadPoolExecutor(os.cpu_count()) as pool:
             errs = [e for e in pool.map(check, range(per)) if e]
+        # WarpSTR.warp on its own (wsx_warp_batch): a random bad-repeat mask on half of the reads, the whole last DP row
+        nw = min(per, 8)
+        wmask = np.zeros(int(off[nw]), np.uint8)
+        for i in range(0, nw, 2):
+            a0 = int(off[i] + rng.integers(0, len(sigs[i]) // 2))
+            wmask[a0:a0 + int(rng.integers(1, len(sigs[i]) // 2))] = 1
+        wr = hip.warp(sig[:off[nw]], off[:nw + 1], aut[:nw], mask=wmask, want_last_row=True)
+        m_ = cc.min_values_per_state
+        for i in range(nw):
+            sl = slice(int(off[i]), int(off[i + 1]))
+            a_ = oa[aut[i]]
+            try:
+                D = oracle.dtw_fill(a_, sigs[i], wmask[sl], m_)
+                otr = oracle.backtrack(a_, D, sigs[i], wmask[sl], m_)
+            except RuntimeError:
+                if wr['status'][i] == 0:
+                    errs.append(f'warp read {i}: oracle refused, status 0')
+                continue
+            lr = wr['last_row'][i, :a_.n_states]
+            same = (lr == D[-1]) | (np.isinf(lr) & np.isinf(D[-1]))
+            if wr['status'][i] != 0 or not same.all() or not np.array_equal(wr['trace'][sl], otr):
+                errs.append(f'warp read {i}: status {wr["status"][i]}, last row equal {bool(same.all())}, '
+                            f'trace equal {np.array_equal(wr["trace"][sl], otr)}')
         for k in (0, 1):
             by_kernel[hip.kernel_name(k) + (' ' + str(cfg) if cfg else '')] += int((aut == k).sum())
         tot += per
