@@ -207,14 +207,23 @@ def test_seam_helper_loops():
     rng = np.random.default_rng(1)
     work = [ReadSignal(f'r{i}', bool(i % 3 == 0), rng.standard_normal(5 + i)) for i in range(40)]
     ptrs, lens, aut = np.empty(40, np.uintp), np.empty(40, np.int64), np.empty(40, np.int32)
-    assert seam.wsx_seam_collect(work, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == 40
+    assert seam.wsx_seam_collect(work, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut), None) == 40
     assert all(int(ptrs[i]) == work[i].signal.ctypes.data and lens[i] == 5 + i and aut[i] == (i % 3 == 0) for i in range(40))
-    assert seam.wsx_seam_collect(tuple(work), b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == 40
+    assert seam.wsx_seam_collect(tuple(work), b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut), None) == 40
     for bad in ([1.0, 2.0], np.zeros(4, np.float32), np.zeros(8)[::2], np.zeros((2, 2)), np.zeros(3, np.int64)):
         w2 = list(work)
         w2[9] = ReadSignal('x', False, bad)
-        assert seam.wsx_seam_collect(w2, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut)) == -10
-    assert seam.wsx_seam_collect([], b'signal', b'reverse', None, None, None) == 0
+        assert seam.wsx_seam_collect(w2, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut), None) == -10
+    assert seam.wsx_seam_collect([], b'signal', b'reverse', None, None, None, None) == 0
+    class Fresh:  # a workload whose `signal` is built per access: the keep-alive list holds what the pointers refer to
+        reverse = False
+
+        @property
+        def signal(self):
+            return np.full(7, 3.5)
+    keep = []
+    assert seam.wsx_seam_collect([Fresh(), Fresh()], b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut), keep) == 2
+    assert len(keep) == 2 and all(int(ptrs[i]) == keep[i].ctypes.data and lens[i] == 7 for i in range(2))
     src = np.frombuffer(b'AAAACCCCGGGGTTTT', np.uint8).copy()
     off = np.array([0, 4, 8, 12, 16], np.int64)
     ln = np.array([2, 0, 4, 1], np.int32)

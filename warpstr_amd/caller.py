@@ -159,7 +159,7 @@ def _seam():
             try:
                 lib = C.PyDLL(path)
                 lib.wsx_seam_collect.restype = C.c_int64
-                lib.wsx_seam_collect.argtypes = [C.py_object, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                lib.wsx_seam_collect.argtypes = [C.py_object, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.py_object]
                 lib.wsx_seam_pack_sequences.restype = C.c_int64
                 lib.wsx_seam_pack_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                         C.c_void_p]
@@ -261,9 +261,10 @@ class HipCaller:
         seam = _seam()
         if seam is not None:
             ptrs, lens, aut = np.empty(n, np.uintp), np.empty(n, np.int64), np.empty(n, np.int32)
-            rc = seam.wsx_seam_collect(workload, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut))
+            keep = []  # the signal objects themselves: alive until the call has returned
+            rc = seam.wsx_seam_collect(workload, b'signal', b'reverse', _lib.ptr(ptrs), _lib.ptr(lens), _lib.ptr(aut), keep)
             if rc == n:
-                return self._call_read_ptrs(ptrs, lens, aut, want_seqs, keep=None)
+                return self._call_read_ptrs(ptrs, lens, aut, want_seqs, keep=keep)
         aut = np.fromiter((1 if w.reverse else 0 for w in workload), dtype=np.int32, count=n)
         return self.call_reads([np.asarray(w.signal) for w in workload], aut, want_seqs)
 

@@ -9,8 +9,10 @@
 // For every item of `workload`: ptrs[i] / lens[i] = address and length of item.<sig_attr> (a C-contiguous 1-d float64
 // buffer), aut[i] = 1 if item.<rev_attr> is true else 0.  Returns n, or -(i+1) if item i does not qualify (the caller
 // then converts the arrays itself), or INT64_MIN on a Python error.
+// `keep` (a list, or NULL): every signal object is appended to it, so that the addresses stay valid for as long as the caller
+// holds the list even if item.<sig_attr> is a property that builds a new array per access.
 int64_t wsx_seam_collect(PyObject *workload, const char *sig_attr, const char *rev_attr, uintptr_t *ptrs, int64_t *lens,
-                         int32_t *aut)
+                         int32_t *aut, PyObject *keep)
 {
     PyObject *fast = PySequence_Fast(workload, "workload must be a sequence");
     if (!fast) return INT64_MIN;
@@ -34,8 +36,9 @@ int64_t wsx_seam_collect(PyObject *workload, const char *sig_attr, const char *r
                 if (view.ndim != 1 || view.itemsize != 8 || strcmp(f, "d") != 0) {
                     rc = -(int64_t)(i + 1);
                 } else {
-                    ptrs[i] = (uintptr_t)view.buf; // the array outlives the call: the workload holds it
+                    ptrs[i] = (uintptr_t)view.buf;
                     lens[i] = (int64_t)view.shape[0];
+                    if (keep && keep != Py_None && PyList_Append(keep, sig) != 0) rc = INT64_MIN;
                 }
                 PyBuffer_Release(&view);
             }
