@@ -2,7 +2,7 @@
 instead of a state per lane -- no LDS exchange; the code is generated for ONE automaton (straight-line, unrolled over the
 positions).  Writes a .hip file with the kernel and a small C driver (run_fill_t).
 
-    python scripts/exp_transposed_gen.py headline 4 build/exp/fill_t.hip
+    python scripts/exp_transposed_gen.py headline 4 build/exp/fill_t.hip [--masked]   (--masked: the second pass, a bad-repeat mask per read)
 """
 import os
 import sys
@@ -61,7 +61,7 @@ def dpp_ctrl(G, d):
     return (0x110 + d) if d > 0 else (0x100 - d)
 
 
-def generate(values, preds, endstate, G, out, M=4):
+def generate(values, preds, endstate, G, out, M=4, masked=False):
     S = len(values)
     n = (S + G - 1) // G
     L = linearize(S, preds)
@@ -135,8 +135,12 @@ def generate(values, preds, endstate, G, out, M=4):
                         w(f'    const uint64_t w{wi} = grp(best_{k}, {src}, a_{k}, 0x{mask:016x}ull);')
                     n_valu += 3
                 n_groups += 1
-        w(f'    c3_{k} = add_abs(c2_{k}, a_{k}); c2_{k} = add_abs(c1_{k}, a_{k}); c1_{k} = stay_{k}; D_{k} = best_{k};')
-        n_valu += 2
+        if masked:  # c3 is only ever read as the export of the NEXT row: (that row masked for this read ? c1 : c2) + a
+            w(f'    c3_{k} = add_abs(c2_{k}, a_{k}); c3_{k} = add_abs_masked(c3_{k}, c1_{k}, a_{k}, mnext); c2_{k} = add_abs(c1_{k}, a_{k}); c1_{k} = stay_{k}; D_{k} = best_{k};')
+            n_valu += 3
+        else:
+            w(f'    c3_{k} = add_abs(c2_{k}, a_{k}); c2_{k} = add_abs(c1_{k}, a_{k}); c1_{k} = stay_{k}; D_{k} = best_{k};')
+            n_valu += 2
     NW = len(words)
     NWP = (NW + 1) & ~1
     for i in range(0, NW, 2):
@@ -158,10 +162,17 @@ def generate(values, preds, endstate, G, out, M=4):
 namespace {{
 constexpr double kInf = __builtin_huge_val();
 constexpr int G = {G}, N = {n}, RPW = {RPW}, NW = {NW}, NWP = {NWP}, M = {M};
+constexpr bool MASKED = {'true' if masked else 'false'};
 __device__ const double vtab[G][N] = {{{', '.join('{' + ', '.join(repr(x) for x in row) + '}' for row in vtab)}}};
 __device__ const int jtab[G][N] = {{{', '.join('{' + ', '.join(str(x) for x in row) + '}' for row in jtab)}}};
 __device__ __forceinline__ double add_abs(double x, double a) {{ double r; asm("v_add_f64 %0, %1, |%2|" : "=v"(r) : "v"(x), "v"(a)); return r; }}
 __device__ __forceinline__ double min_f64(double a, double b) {{ double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }}
+// keep, except in the lanes of `mask`: x + |a|  (the per-read choice of the export under the bad-repeat mask)
+__device__ __forceinline__ double add_abs_masked(double keep, double x, double a, uint64_t mask)
+{{
+    asm("s_mov_b64 exec, %3\\n\\tv_add_f64 %0, %1, |%2|\\n\\ts_mov_b64 exec, -1" : "+v"(keep) : "v"(x), "v"(a), "s"(mask));
+    return keep;
+}}
 template <int CTRL> __device__ __forceinline__ double shift(double x)
 {{
     long long b = __double_as_longlong(x);
@@ -198,7 +209,7 @@ template <int OFF> __device__ __forceinline__ void store2(uint64_t m0, uint64_t 
     asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(p), "n"(OFF) : "memory");
 }}
 
-__global__ __launch_bounds__(64) void fill_t(const double *sig, int n_reads, int T, uint64_t *bp, double *last_row, int stride)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void fill_t(const double *sig, int n_reads, int T, uint64_t *bp, double *last_row, int stride, const unsigned char *mask)
 {{
     const int lane = threadIdx.x, q = lane % G, g = lane / G;
     const int wave = blockIdx.x;
@@ -214,35 +225,47 @@ __global__ __launch_bounds__(64) void fill_t(const double *sig, int n_reads, int
         init.append(f'    v_{k} = vtab[q][{k}]; {{ const int j = jtab[q][{k}]; double d0 = kInf; if (j == 0) d0 = start; else if (j > 0 && j <= M) d0 = start + fabs(sp[j] - v0); D_{k} = d0; }} c1_{k} = kInf; c2_{k} = kInf; c3_{k} = kInf;')
     adv = []
     for k in range(n):
-        adv.append(f'        {{ const double a = s - v_{k}; c3_{k} = add_abs(c2_{k}, a); c2_{k} = add_abs(c1_{k}, a); c1_{k} = add_abs(D_{k}, a); D_{k} = kInf; }}')
+        adv.append(f'        {{ const double a = s - v_{k}; c3_{k} = add_abs(c2_{k}, a); if (MASKED) c3_{k} = add_abs_masked(c3_{k}, c1_{k}, a, mrow(i + 1)); c2_{k} = add_abs(c1_{k}, a); c1_{k} = add_abs(D_{k}, a); D_{k} = kInf; }}')
     outp = []
     for k in range(n):
         outp.append(f'        {{ const int j = jtab[q][{k}]; if (j >= 0) last_row[(size_t)read * stride + j] = D_{k}; }}')
     src += f'''    const double v0 = vtab[0][0];
     const double start = fabs(sp[0] - v0);
 {chr(10).join(init)}
+    const unsigned char *mp = mask ? mask + (size_t)read * T : nullptr;
+    auto mrow = [&](int r) -> uint64_t {{ return MASKED ? __ballot(r < T && mp[r] != 0) : 0ull; }}; // the reads masked at row r
     for (int i = 1; i < M; i++) {{
         const double s = sp[i];
 {chr(10).join(adv)}
     }}
     typedef double d2 __attribute__((ext_vector_type(2)));
-    auto row = [&](double s, uint64_t *rowp) __attribute__((always_inline)) {{
+    auto row = [&](double s, uint64_t *rowp, uint64_t mnext) __attribute__((always_inline)) {{
 {body}
     }};
     int i = M;
-    for (; i < T && (i & 7); i++) row(sp[i], wbp + (size_t)i * NWP);
-    d2 nx[4];
-    if (i + 8 <= T) for (int u = 0; u < 4; u++) nx[u] = *(const d2 *)(sp + i + 2 * u);
+    for (; i < T && (i & 7); i++) row(sp[i], wbp + (size_t)i * NWP, mrow(i + 1));
+    // eight rows per round; the samples arrive two at a time, two loads in flight (8 VGPRs instead of 32 for whole rounds)
+    auto pair = [&](int r) -> d2 {{ const int c = r + 2 <= T ? r : T - 2; return *(const d2 *)(sp + c); }};
+    d2 p0 = pair(i), p1 = pair(i + 2);
     for (; i + 8 <= T; i += 8) {{
-        d2 cur[4];
-        for (int u = 0; u < 4; u++) cur[u] = nx[u];
-        const int ni = i + 16 <= T ? i + 8 : i;
-        for (int u = 0; u < 4; u++) nx[u] = *(const d2 *)(sp + ni + 2 * u);
+        uint64_t mm[8];
+        if (MASKED) {{
+            const int c = i + 9 <= T ? i + 1 : T - 8; // rows i+1 .. i+8 (clamped at the end of the read)
+            const uint64_t bytes = *(const uint64_t *)(mp + c);
+            const int sh = i + 1 - c;
+#pragma unroll
+            for (int u = 0; u < 8; u++) mm[u] = __ballot(u + sh < 8 && ((bytes >> (8 * ((u + sh) & 7))) & 0xffull) != 0);
+        }} else {{
+#pragma unroll
+            for (int u = 0; u < 8; u++) mm[u] = 0;
+        }}
         uint64_t *rp = wbp + (size_t)i * NWP;
-        row(cur[0].x, rp); row(cur[0].y, rp + NWP); row(cur[1].x, rp + 2 * NWP); row(cur[1].y, rp + 3 * NWP);
-        row(cur[2].x, rp + 4 * NWP); row(cur[2].y, rp + 5 * NWP); row(cur[3].x, rp + 6 * NWP); row(cur[3].y, rp + 7 * NWP);
+        row(p0.x, rp, mm[0]); row(p0.y, rp + NWP, mm[1]); p0 = pair(i + 4);
+        row(p1.x, rp + 2 * NWP, mm[2]); row(p1.y, rp + 3 * NWP, mm[3]); p1 = pair(i + 6);
+        row(p0.x, rp + 4 * NWP, mm[4]); row(p0.y, rp + 5 * NWP, mm[5]); p0 = pair(i + 8);
+        row(p1.x, rp + 6 * NWP, mm[6]); row(p1.y, rp + 7 * NWP, mm[7]); p1 = pair(i + 10);
     }}
-    for (; i < T; i++) row(sp[i], wbp + (size_t)i * NWP);
+    for (; i < T; i++) row(sp[i], wbp + (size_t)i * NWP, mrow(i + 1));
     if (live && last_row) {{
 {chr(10).join(outp)}
     }}
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(64) void fill_t(const double *sig, int n_reads, int
 
 extern "C" int fill_t_words() {{ return NWP; }}
 extern "C" int fill_t_rpw() {{ return RPW; }}
-extern "C" float run_fill_t(const double *sig, int n_reads, int T, unsigned long long *bp, double *last_row, int stride, int reps)
+extern "C" float run_fill_t(const double *sig, int n_reads, int T, unsigned long long *bp, double *last_row, int stride, int reps, const unsigned char *mask)
 {{
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -260,7 +283,7 @@ extern "C" float run_fill_t(const double *sig, int n_reads, int T, unsigned long
     float best = 1e30f;
     for (int r = 0; r < reps; r++) {{
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(fill_t, dim3(waves), dim3(64), 0, 0, sig, n_reads, T, (uint64_t *)bp, last_row, stride);
+        hipLaunchKernelGGL(fill_t, dim3(waves), dim3(64), 0, 0, sig, n_reads, T, (uint64_t *)bp, last_row, stride, mask);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -300,4 +323,4 @@ def automaton(name):
 if __name__ == '__main__':
     name, G, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     _, values, preds, end = automaton(name)
-    generate(values, preds, end, G, out)
+    generate(values, preds, end, G, out, masked='--masked' in sys.argv)
