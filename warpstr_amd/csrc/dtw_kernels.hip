@@ -1098,6 +1098,7 @@ template <int M, int K, int F, int FL, bool PK = false>
 hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 {
     const int blocks = (a.n_launch + WSX_FILL_WPB - 1) / WSX_FILL_WPB;
+    static_assert(WSX_FILL_WPB * (2 * (K * 64 + 32)) * sizeof(double) <= 64 * 1024, "export buffers of a workgroup: at most 64 KB of LDS");
     size_t shmem = WSX_FILL_WPB * (2 * (K * 64 + 32)) * sizeof(double);
     // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
     // kernels of other chunks that run beside the fill on other streams.
