@@ -40,6 +40,7 @@ struct Variant { // which DP kernel an automaton uses
     bool generic = false;
     int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
+    int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 2 = every slot
     // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
     //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
     //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
@@ -49,7 +50,7 @@ struct Variant { // which DP kernel an automaton uses
         if (pk) return (samples / 16 + reads + 4) * 18 * 2; // 18 64-bit words per 16 rows, a read starts a new group
         return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2;
     }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm; }
 };
 
 struct DeviceBuf {
@@ -452,7 +453,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
                 align_up((size_t)((S + 63) / 64) * 64 * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S) +
-                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2);
+                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2) +
+                align_up((size_t)((S + 63) / 64) * 2 * 4);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -511,7 +513,20 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         std::iota(wslot.begin(), wslot.end(), (uint16_t)0);
         if (!v.generic) {
             const bool want_pk = v.K == 1 && Fk == 2 && !getenv("WSX_NO_PACK");
-            const WsxPlacement pl = getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
+            // several slots: the lane-major layout (chains along the slots of a lane, LDS only for slot 0) where it fits
+            WsxLanePlacement lp;
+            static const int lm_mode = [] {
+                const char *e = getenv("WSX_FILL_LM");
+                return e ? atoi(e) : 1; // 0: off; 1: on; 2: on, every slot exports
+            }();
+            if (lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K))
+                lp = wsx_place_lane_major(S, A.pred_ptr, A.pred_idx, v.K);
+            if (lp.lm != 0) {
+                v.FL = 1;
+                v.lm = lm_mode == 2 ? 2 : lp.lm;
+            }
+            const WsxPlacement pl = lp.lm != 0 ? lp.pl
+                                    : getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
                                         ? WsxPlacement{}
                                         : wsx_place_states(S, A.pred_ptr, A.pred_idx, v.K, Fk, v.FL, want_pk);
             if (!pl.pos.empty()) {
@@ -533,6 +548,31 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 for (int e = A.pred_ptr[j], t = 0; e < A.pred_ptr[j + 1] && t < 4; e++, t++)
                     p4[pos[j]] |= (uint64_t)pos[A.pred_idx[e]] << (16 * t);
             D.pred4 = (const uint64_t *)put(p4.data(), p4.size() * 8);
+        }
+        // slot_hops: when a slot of the several-slot fill can sleep (dtw_fill_wg) -- per slot the fewest transitions from
+        // the states row 0 initialises (0..m, caller.py:201-208) to any of its states, and from any of its states to the end
+        if (!v.generic) {
+            const int kUnreach = 1 << 20;
+            const int mm = c->prm.min_values_per_state;
+            std::vector<int> hs(S, kUnreach), he(S, kUnreach);
+            for (int j = 0; j <= mm && j < S; j++) hs[j] = 0;
+            he[A.endstate] = 0;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int j = 0; j < S; j++)
+                    for (int e = A.pred_ptr[j]; e < A.pred_ptr[j + 1]; e++) {
+                        const int p = A.pred_idx[e];
+                        if (hs[p] + 1 < hs[j]) hs[j] = hs[p] + 1, changed = true;
+                        if (he[j] + 1 < he[p]) he[p] = he[j] + 1, changed = true;
+                    }
+            }
+            std::vector<int32_t> sh((size_t)v.K * 2, kUnreach);
+            for (int j = 0; j < S; j++) {
+                const int k = pos[j] / 64;
+                sh[2 * k] = std::min(sh[2 * k], hs[j]);
+                sh[2 * k + 1] = std::min(sh[2 * k + 1], he[j]);
+            }
+            D.slot_hops = (const int32_t *)put(sh.data(), sh.size() * 4);
         }
         // paddr: which LDS export slot (slot k, predecessor f, lane) reads in the register-resident fill.  A ds_read_b64
         // serves lanes 0-31 and 32-63 in one cycle each when no two lanes of a group hit the same bank pair (slot mod 32)
@@ -708,7 +748,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
-    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.pk, v.generic);
+    return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.pk, v.lm, v.generic);
 }
 
 } // extern "C"
@@ -1226,7 +1266,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;

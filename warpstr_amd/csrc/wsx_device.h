@@ -34,6 +34,8 @@ struct DevAutomaton {
     const uint16_t *wslot;    // single-slot automata: the LDS export slot lane l writes (64 entries; wsx_place.h)
     const uint16_t *pos;      // state -> position (slot*64 + lane) in the register-resident fill; NULL = identity
     const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
+    const int32_t *slot_hops; // per slot k: [2k] fewest transitions from the states row 0 initialises (0..m) to a state of the
+                              // slot, [2k+1] fewest from a state of the slot to the end state (dtw_fill_wg: when a slot sleeps)
     const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
                             // predecessors, 16 bits each (mask traceback)
 };
@@ -146,11 +148,13 @@ struct EvalArgs {
 // Host-side launchers (defined next to the kernels).
 // pk: packed mask rows (single-slot automata whose states with two predecessors sit in lanes 0..7): per 16 rows
 // 16 x 8 bytes of first-candidate masks + 2 x 8 bytes holding the second candidate's byte of every row
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, bool generic, hipStream_t s);
+// lm: lane-major placement (0 = no; 1 = slots 0 and K-1 export to LDS; 2 = every slot does), dtw_kernels.hip: dp_row
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
-const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, bool generic);
+const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, bool generic);
+bool wsx_lane_major_supported(int m, int K);
 bool wsx_split_supported(int m, int K);

@@ -370,3 +370,113 @@ inline WsxPlacement wsx_place_states(int S, const int32_t *pp, const int32_t *pi
     }
     return best;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Lane-major placement (dtw_kernels.hip: dp_row with LM != 0).  The automata of real loci are almost chains: two long
+// flanks and a few short loops.  Laid along the SLOTS of a lane -- position (slot r, lane l) holds the state after the one
+// in (slot r-1, lane l) -- a state above slot 0 finds its one predecessor's value in a register of its own lane, and only
+// the states in slot 0 exchange through LDS: heads of chains (states with no, or several, predecessors, and side branches),
+// and the first state of every further K-state piece of a long chain, which reads the top slot of the lane before it.
+//
+// Chains: every state with exactly one predecessor may continue that predecessor's chain; a state keeps the child with the
+// longest tail.  A chain is cut behind every state that has a successor outside the chain ("source": somebody reads it
+// through LDS), so that such a state ends a piece.  A piece of L = q*K + rem states takes q full lanes; its last rem states
+// either take one more lane (slots 0..rem-1: every slot may then have to export, LM = 2) or one lane EACH, in slot 0 -- then
+// everything a slot-0 state reads sits in slot 0 or slot K-1 and only those two slots write to LDS (LM = 1).  The second
+// form is used while 64 lanes suffice; otherwise the pieces with the largest remainders change to the first form.
+// Returns an empty placement when the automaton does not fit the K*64 positions this way.
+// ------------------------------------------------------------------------------------------------------------------
+struct WsxLanePlacement {
+    WsxPlacement pl;   // pos, state_at, wslot (identity)
+    int lm = 0;        // 0: does not fit; 1: slots 0 and K-1 export; 2: every slot exports
+    int lanes = 0;
+};
+
+inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int32_t *pi, int K)
+{
+    using namespace wsx_place_detail;
+    WsxLanePlacement out;
+    if (K < 2 || S > K * 64) return out;
+    std::vector<std::vector<int>> succ(S);
+    for (int j = 0; j < S; j++)
+        for (int e = pp[j]; e < pp[j + 1]; e++) succ[pi[e]].push_back(j);
+    // tail[j]: states in the longest run of single-predecessor states that starts at j
+    std::vector<int> tail(S, 1);
+    for (int it = 0; it <= S; it++) {
+        bool changed = false;
+        for (int j = S - 1; j >= 0; j--) {
+            int best = 0;
+            for (int c : succ[j])
+                if (fanin(pp, c) == 1) best = std::max(best, tail[c]);
+            if (1 + best != tail[j]) tail[j] = 1 + best, changed = true;
+        }
+        if (!changed) break;
+        if (it == S) return out; // a loop of single-predecessor states: not an automaton this layout is for
+    }
+    std::vector<int> child(S, -1), parent(S, -1);
+    for (int p = 0; p < S; p++) {
+        for (int c : succ[p])
+            if (fanin(pp, c) == 1 && (child[p] < 0 || tail[c] > tail[child[p]])) child[p] = c;
+        if (child[p] >= 0) parent[child[p]] = p;
+    }
+    // pieces: maximal runs head -> child -> .. that end at a source or at the end of the chain
+    std::vector<std::vector<int>> pieces;
+    for (int h = 0; h < S; h++) {
+        if (parent[h] >= 0) continue;
+        std::vector<int> cur;
+        for (int j = h; j >= 0; j = child[j]) {
+            cur.push_back(j);
+            bool source = false;
+            for (int c : succ[j]) source |= c != child[j];
+            if (source || child[j] < 0) {
+                pieces.push_back(cur);
+                cur.clear();
+            }
+            if ((int)pieces.size() > S) return out;
+        }
+    }
+    // lanes: every piece q full lanes + rem single-state lanes; change the largest remainders to one lane until it fits
+    std::vector<char> packed(pieces.size(), 0);
+    int lanes = 0;
+    for (auto &p : pieces) lanes += (int)p.size() / K + (int)p.size() % K;
+    out.lm = 1;
+    while (lanes > 64) {
+        int best = -1;
+        for (size_t q = 0; q < pieces.size(); q++)
+            if (!packed[q] && (int)pieces[q].size() % K >= 2 &&
+                (best < 0 || pieces[q].size() % K > pieces[best].size() % K))
+                best = (int)q;
+        if (best < 0) return WsxLanePlacement{};
+        packed[best] = 1;
+        lanes -= (int)pieces[best].size() % K - 1;
+        out.lm = 2;
+    }
+    out.lanes = lanes;
+    WsxPlacement &pl = out.pl;
+    pl.pos.assign(S, 0);
+    pl.state_at.assign((size_t)K * 64, 0xFFFF);
+    pl.wslot.resize((size_t)K * 64);
+    std::iota(pl.wslot.begin(), pl.wslot.end(), (uint16_t)0);
+    int lane = 0;
+    auto put = [&](int state, int slot, int l) {
+        pl.pos[state] = (uint16_t)(slot * 64 + l);
+        pl.state_at[slot * 64 + l] = (uint16_t)state;
+    };
+    for (size_t q = 0; q < pieces.size(); q++) {
+        const auto &p = pieces[q];
+        const int full = (int)p.size() / K, rem = (int)p.size() % K;
+        for (int s = 0; s < full * K; s++) put(p[s], s % K, lane + s / K);
+        lane += full;
+        if (packed[q]) {
+            for (int s = 0; s < rem; s++) put(p[full * K + s], s, lane);
+            lane += rem ? 1 : 0;
+        } else {
+            for (int s = 0; s < rem; s++) put(p[full * K + s], 0, lane + s);
+            lane += rem;
+        }
+    }
+    pl.identity = false;
+    pl.low8 = false;
+    pl.conflict_cycles = 0; // (not modelled: this layout leaves the LDS pipe mostly idle)
+    return out;
+}
