@@ -10,7 +10,7 @@ Workloads (config.workload)
             --scaling strong = configs[3]: the SAME 100k-read workload sharded over the N GPUs
             (warpstr_amd.dist.shard_reads), one RCCL all-gather of the result records per step.
   cfg1      the shape of the upstream test case / every flank-110 locus: `(AAAT)` flank 110, S = 225 states,
-            T in [2271, 3701] samples, 20k reads per GPU (kernel dtw_fill_fast<4, 4, 2, 1>).
+            T in [2271, 3701] samples, 20k reads per GPU (kernel dtw_fill_fast<4, 4, 2, 1, false, 1>: lane-major).
   cfg5      BASELINE.json configs[4] at one GPU's share: 8 loci x 2 strands, ~128-state automata, T in [500, 5000],
             50k reads per GPU.
 A "step" is one full call of the batch: both DTW passes, rescaling fit, bad-repeat masking, allele lengths.
@@ -215,6 +215,10 @@ def fill_profile(kernel):
     path = os.path.join(ROOT, 'profiles', 'fill_pmc.json')
     with open(path) as f:
         table = json.load(f)
+    if kernel not in table and kernel.endswith(', 0>'):  # profiles taken before the kernel grew its last template parameter
+        legacy = kernel[:-len(', 0>')] + '>'
+        if legacy in table:
+            return table[legacy]
     if kernel not in table:
         if os.environ.get('WARPSTR_BENCH_PROFILING'):  # scripts/profile_round.sh: the run that produces the entry
             return None
@@ -227,9 +231,12 @@ def valu_roofline(prof, alone_ms, wave_rows, kernel):
     """What actually bounds the fill: wave-level VALU instruction issue (every VALU op, fp64 or 32-bit, occupies a
     SIMD for 4 cycles per wave64) together with the LDS pipe.  alone_ms: one fill launch with nothing beside it."""
     import re
-    m = re.match(r'dtw_fill_fast<(\d+), (\d+), (\d+), (\d+)', kernel)
+    m = re.match(r'dtw_fill_(?:fast|wg)<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false), (\d+))?', kernel)
     K, F, FL = (int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (1, 2, 2)
-    lds_cycles = 6.0 * K + 2.0 * (F + (K - 1) * FL)  # ds_write_b64 ~6, ds_read_b64 2 (MI355X_MICROARCH.md, LDS table)
+    lm = int(m.group(5)) if m and m.group(5) else 0
+    # ds_write_b64 ~6 cycles, ds_write2_b64 ~10, ds_read_b64 2 (MI355X_MICROARCH.md, LDS table).  Lane-major placement
+    # (lm): only slot 0 reads LDS (F reads); slots 0 and K-1 (lm = 1: one ds_write2_b64) or all slots (lm = 2) write
+    lds_cycles = (6.0 * K + 2.0 * (F + (K - 1) * FL)) if lm == 0 else ((10.0 if lm == 1 else 6.0 * K) + 2.0 * F)
     vpr, clk = prof['valu_insts_per_wave_row'], prof['clock_hz_observed']
     achieved = wave_rows * vpr / (alone_ms * 1e-3)
     peak = N_SIMD * CLK_MAX_HZ / 4.0

@@ -18,3 +18,15 @@ extern "C" int wsx_test_place(int S, const int32_t *pred_ptr, const int32_t *pre
     *plain_conflicts = wsx_place_detail::conflict_cycles(S, pred_ptr, pred_idx, K, F, F, ipos, iat, iw);
     return p.conflict_cycles;
 }
+
+// lane-major placement: returns lm (0 = does not fit, 1 = slots 0 and K-1 export, 2 = every slot), fills pos / state_at
+extern "C" int wsx_test_place_lane_major(int S, const int32_t *pred_ptr, const int32_t *pred_idx, int K, uint16_t *pos,
+                                         uint16_t *state_at, int *lanes)
+{
+    const WsxLanePlacement p = wsx_place_lane_major(S, pred_ptr, pred_idx, K);
+    *lanes = p.lanes;
+    if (p.lm == 0) return 0;
+    for (int j = 0; j < S; j++) pos[j] = p.pl.pos[j];
+    for (int q = 0; q < K * 64; q++) state_at[q] = p.pl.state_at[q];
+    return p.lm;
+}

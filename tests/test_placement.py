@@ -134,3 +134,63 @@ def test_random_loci_keep_the_invariants(shim):
             placed += 1
             free += c == 0
     assert placed >= 40 and free >= placed // 2
+
+
+def place_lane_major(lib, t, K):
+    S = t.n_states
+    pp, pi = np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32)
+    pos, sa = np.zeros(S, np.uint16), np.zeros(K * 64, np.uint16)
+    lanes = C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lm = lib.wsx_test_place_lane_major(S, p(pp), p(pi), K, p(pos), p(sa), C.byref(lanes))
+    return lm, pos, sa, lanes.value
+
+
+def check_lane_major(t, K, lm, pos, sa):
+    """The contract dp_row<.., LM> relies on (dtw_kernels.hip): a permutation; a state above slot 0 has exactly one predecessor
+    and it sits right below it in the same lane; what a slot-0 state reads through LDS sits in an exporting slot."""
+    S = t.n_states
+    assert len(set(int(x) for x in pos)) == S and all(int(sa[int(pos[j])]) == j for j in range(S))
+    assert sum(1 for q in sa if q != 0xFFFF) == S
+    for j in range(S):
+        slot, lane = int(pos[j]) // 64, int(pos[j]) % 64
+        inc = t.incoming(j)
+        if slot > 0:
+            assert len(inc) == 1 and int(pos[inc[0]]) == (slot - 1) * 64 + lane, (j, slot, lane, inc)
+        elif lm == 1:
+            assert all(int(pos[p]) // 64 in (0, K - 1) for p in inc), (j, inc)
+    for lane in range(64):  # a lane is filled from slot 0 upwards
+        filled = [sa[k * 64 + lane] != 0xFFFF for k in range(K)]
+        assert filled == sorted(filled, reverse=True)
+
+
+@pytest.mark.parametrize('pattern,fl,seed', [('(AAAT)', 110, 1), ('(AGC)', 110, 3), ('(GGCCCC)', 110, 2), ('(AGC)', 126, 5),
+                                             ('(CCTG)(TCTG)', 110, 4), ('(AAGGG)(AAAGG)', 110, 6), ('(AGC)', 40, 1)])
+def test_lane_major_placement_of_simple_loci(shim, pattern, fl, seed):
+    """Flank-110 automata of simple repeats fit the lane-major layout (chains along the slots of a lane)."""
+    locus = synth.make_locus(pattern, fl, seed)
+    for t in (locus.template, locus.reverse):
+        K = (t.n_states + 63) // 64
+        lm, pos, sa, lanes = place_lane_major(shim, t, K)
+        assert lm in (1, 2) and lanes <= 64, (pattern, t.n_states, lm, lanes)
+        check_lane_major(t, K, lm, pos, sa)
+
+
+def test_lane_major_placement_on_random_loci(shim):
+    """Whatever the automaton: either the layout is refused, or it keeps the contract."""
+    rng = np.random.default_rng(5)
+    units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA']
+    fits = 0
+    for it in range(60):
+        pat = ''.join('(' + units[int(rng.integers(len(units)))] + ')' + ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(0, 6))))
+                      for _ in range(int(rng.integers(1, 4))))
+        locus = synth.make_locus(pat, int(rng.integers(30, 150)), int(rng.integers(1 << 20)))
+        for t in (locus.template, locus.reverse):
+            K = (t.n_states + 63) // 64
+            if K < 2 or K > 5:
+                continue
+            lm, pos, sa, lanes = place_lane_major(shim, t, K)
+            if lm:
+                fits += 1
+                check_lane_major(t, K, lm, pos, sa)
+    assert fits >= 20

@@ -1385,21 +1385,25 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// Several slots: one slot per wave, a workgroup per read (dtw_fill_wg), unless WSX_FILL_WG=0 asks for the one-wave kernel.
+// Several slots, no lane-major placement: one slot per wave, a workgroup per read (dtw_fill_wg), where that measured
+// faster than the one-wave kernel -- three and four slots (20 k reads x 2 000 samples, whole call: 6.66 vs 6.81 ms at 192
+// states, 8.31 vs 8.68 ms at 256; two slots 5.10 vs 4.93, five 13.5 vs 11.9: profiles/r03_state_staircase.log).
+// WSX_FILL_WG: 0 = never, 1 = where it wins (default), 2 = same with wave w fixed to slot w, 3 = for every K >= 2.
 static int fill_wg_mode()
 {
     static const int mode = [] {
         const char *e = getenv("WSX_FILL_WG");
-        return e ? atoi(e) : 1; // 0: off, 1: on, slots rotate over the waves, 2: on, wave w takes slot w
+        return e ? atoi(e) : 1;
     }();
     return mode;
 }
+static bool fill_wg_wanted(int K) { return fill_wg_mode() == 3 ? K >= 2 : (fill_wg_mode() != 0 && (K == 3 || K == 4)); }
 
 template <int M, int K, int F, int FL>
 hipError_t launch_fill_wg(const PassArgs &a, hipStream_t s)
 {
     const size_t shmem = 2 * (K * 64 + 32) * sizeof(double);
-    hipLaunchKernelGGL((dtw_fill_wg<M, K, F, FL>), dim3(a.n_launch), dim3(64 * K), shmem, s, a, fill_wg_mode() == 1 ? 1 : 0);
+    hipLaunchKernelGGL((dtw_fill_wg<M, K, F, FL>), dim3(a.n_launch), dim3(64 * K), shmem, s, a, fill_wg_mode() != 2 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1421,7 +1425,7 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipS
         return hipErrorInvalidValue;
     }
     if constexpr (K >= 2) {
-        if (fill_wg_mode() != 0 && !pk) {
+        if (fill_wg_wanted(K) && !pk) {
             if constexpr (M == 4) {
                 if (F == 2 && FL == 1) return launch_fill_wg<M, K, 2, 1>(a, s);
                 if (F == 3 && FL == 1) return launch_fill_wg<M, K, 3, 1>(a, s);
@@ -1489,9 +1493,8 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, b
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else if (lm != 0) snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, false, %d>", m, K, fast_f(F), FL, lm);
-    else if (K >= 2 && fill_wg_mode() != 0) snprintf(buf, sizeof(buf), "dtw_fill_wg<%d, %d, %d, %d>", m, K, fast_f(F), FL);
-    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, %s>", m, K, fast_f(F), FL, pk ? "true" : "false"); // as rocprofv3 prints it
+    else if (fill_wg_wanted(K)) snprintf(buf, sizeof(buf), "dtw_fill_wg<%d, %d, %d, %d>", m, K, fast_f(F), FL);
+    else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, %s, %d>", m, K, fast_f(F), FL, pk ? "true" : "false", lm); // as rocprofv3 prints it
     return buf;
 }
 
