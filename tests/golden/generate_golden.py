@@ -258,6 +258,122 @@ def gen_similarity(ns, outdir):
                        cases=out), f, indent=1)
 
 
+def _genotype_length_sets():
+    """Seeded per-read allele-length sets for the step-4 fixtures: (name, numpy seed for the mixture, values)."""
+    rng = np.random.default_rng(77)
+    two = lambda a, na, b, nb, sd: [int(v) for v in np.concatenate([np.round(rng.normal(a, sd, na)), np.round(rng.normal(b, sd, nb))])]
+    sets = [
+        ('two_far_alleles', 1, two(30, 22, 50, 19, 0.8)),
+        ('two_close_alleles', 2, two(44, 30, 40, 26, 0.7)),
+        ('homozygous_noisy', 3, [int(v) for v in np.round(rng.normal(60, 1.0, 48))]),
+        ('single_value', 4, [40] * 12),
+        ('five_values_no_filter', 5, [21, 22, 21, 90, 22]),
+        ('six_values', 6, [21, 22, 21, 35, 22, 36]),
+        ('outliers_filtered', 7, two(35, 25, 47, 25, 0.9) + [200, 2]),
+        ('minor_component_below_min_weight', 8, two(30, 46, 50, 4, 0.6)),
+        ('two_values_only', 9, [17, 23]),
+        ('shuffled_two_alleles', 10, None),
+    ]
+    v = two(25, 18, 33, 21, 1.1)
+    rng.shuffle(v)
+    sets[-1] = ('shuffled_two_alleles', 10, [int(x) for x in v])
+    return sets
+
+
+def _complex_tables():
+    """Per-read repeat-unit count tables (the columns store_collapsed writes, src/caller/overview.py:11-34)."""
+    rng = np.random.default_rng(78)
+    def table(n1, c1, n2, c2, sd, names, extra=()):
+        rows = [np.round(rng.normal(c1, sd)).astype(int) for _ in range(n1)] + [np.round(rng.normal(c2, sd)).astype(int) for _ in range(n2)]
+        rows += [np.array(e) for e in extra]
+        order = rng.permutation(len(rows))
+        d = {name: [int(rows[i][k]) for i in order] for k, name in enumerate(names)}
+        d['reverse'] = [bool(rng.integers(0, 2)) for _ in order]
+        return d
+    return [
+        ('two_alleles_two_units', 11, table(20, (12, 30), 18, (20, 22), 0.7, ['AGC', 'CGC'])),
+        ('two_alleles_three_units', 12, table(16, (10, 5, 14), 16, (18, 5, 9), 0.8, ['main_CAGG', 'CAGA', 'CA'])),
+        ('homozygous_two_units', 13, table(40, (15, 8), 0, (0, 0), 0.8, ['AAGGG', 'AAAGG'])),
+        ('five_rows', 14, table(3, (7, 9), 2, (12, 4), 0.5, ['CCTG', 'TCTG'])),
+        ('outlier_rows_dropped_two_alleles', 15, table(20, (12, 30), 20, (22, 18), 0.7, ['AGC', 'CGC'], extra=[(90, 30), (12, 2)])),
+        ('outlier_rows_dropped_homozygous', 16, table(30, (15, 8), 0, (0, 0), 0.7, ['AAGGG', 'AAAGG'], extra=[(60, 8), (15, 40)])),
+        ('one_unit_only', 17, {'AGC': [5, 6, 7, 5, 6, 7, 8], 'reverse': [False] * 7}),
+        ('homozygous_nothing_dropped', 18, {'AGC': [15, 16] * 9, 'CGC': [8, 8, 9] * 6, 'reverse': [False, True] * 9}),
+        ('homozygous_identical_rows', 19, {'AGC': [15] * 10, 'CGC': [8] * 10, 'reverse': [True] * 10}),
+        ('homozygous_early_row_dropped', 20, {'AGC': [40] + [15, 16] * 10, 'CGC': [8] + [8, 9] * 10, 'reverse': [False] * 21}),
+    ]
+
+
+def gen_genotype(outdir):
+    """Step 4 (src/genotyper/genotyping.py): the reference's own run_genotyping / run_genotyping_overview (incl. the basecall
+    alleles of load_predictions 95-103) / run_genotyping_complex on seeded inputs.  scikit-learn's mixture draws from numpy's
+    global generator, so each case seeds it (np.random.seed) right before the call; the plots are switched off."""
+    import contextlib
+    import io
+    import tempfile
+    import pandas as pd
+    from _ref_import import REFERENCE_ROOT
+    old = os.getcwd()
+    os.chdir(REFERENCE_ROOT)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        from src.genotyper import genotyping
+    finally:
+        os.chdir(old)
+        sys.path.remove(REFERENCE_ROOT)
+    genotyping.genotyping_config.visualize = False
+    genotyping.plot_complex_repeats = lambda *a, **k: None
+    out = dict(min_weight=float(genotyping.genotyping_config.min_weight), std_filter=float(genotyping.genotyping_config.std_filter),
+               simple=[], overview=[], complex=[])
+    for name, seed, vals in _genotype_length_sets():
+        np.random.seed(seed)
+        gt = genotyping.run_genotyping(list(vals))
+        out['simple'].append(dict(name=name, seed=seed, values=vals, group1=[int(v) for v in gt.group1], group2=[int(v) for v in gt.group2],
+                                  predictions=[int(v) for v in gt.predictions], alleles=[gt.first_allele, gt.second_allele],
+                                  sizes=[gt.first_allele_sz, gt.second_allele_sz]))
+    # overview tables: with and without the basecall columns; rows that were not `saved` are skipped
+    sets = {n: v for n, _, v in _genotype_length_sets()}
+    rng = np.random.default_rng(79)
+    for name, seed, vals, with_bc in (('warpstr_only', 21, sets['two_far_alleles'], False), ('with_basecalls', 22, sets['two_close_alleles'], True),
+                                      ('with_basecalls_homozygous', 23, sets['homozygous_noisy'], True)):
+        n = len(vals)
+        saved = [bool(rng.random() < 0.85) for _ in range(n)]
+        cols = dict(read_name=[f'read{i:03d}' for i in range(n)], saved=saved, results=[v if s else -1 for v, s in zip(vals, saved)])
+        if with_bc:
+            l_end = [int(rng.integers(200, 400)) for _ in range(n)]
+            cols['l_seq_end'] = l_end
+            cols['r_seq_start'] = [le + 3 * v + int(rng.integers(-4, 5)) for le, v in zip(l_end, vals)]
+        df = pd.DataFrame(cols).set_index('read_name')
+        tmp = tempfile.mkdtemp(prefix='warpstr_gt_')
+        os.makedirs(os.path.join(tmp, 'predictions'))
+        buf = io.StringIO()
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(buf):
+            genotyping.run_genotyping_overview(df, tmp, None)
+        with open(os.path.join(tmp, 'predictions', 'alleles.csv')) as f:
+            text = f.read()
+        out['overview'].append(dict(name=name, seed=seed, columns={k: v for k, v in cols.items()}, alleles_csv=text, stdout=buf.getvalue()))
+    for name, seed, table in _complex_tables():
+        df = pd.DataFrame.from_dict(table)
+        tmp = tempfile.mkdtemp(prefix='warpstr_gtc_')
+        os.makedirs(os.path.join(tmp, 'predictions', 'complexSTR_analysis'))
+        os.makedirs(os.path.join(tmp, 'summaries'))
+        buf = io.StringIO()
+        np.random.seed(seed)
+        rec = dict(name=name, seed=seed, table=table)
+        try:
+            with contextlib.redirect_stdout(buf):
+                genotyping.run_genotyping_complex(tmp, df)
+        except Exception as e:  # noqa: BLE001 -- e.g. the label lookup of find_nearest on a table that lost rows
+            rec['error'] = type(e).__name__
+        path = os.path.join(tmp, 'predictions', 'complexSTR_analysis', 'complex_alleles.csv')
+        rec['complex_alleles_csv'] = open(path).read() if os.path.exists(path) else None
+        rec['stdout'] = buf.getvalue()
+        out['complex'].append(rec)
+    with open(os.path.join(outdir, 'genotype.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--alt', action='store_true')
@@ -290,6 +406,9 @@ def main():
     if not args.only or args.only == 'similarity':
         print('similarity')
         gen_similarity(ns, HERE)
+    if not args.only or args.only == 'genotype':
+        print('genotype')
+        gen_genotype(HERE)
     if not args.only:
         gen_units(ns, HERE)
         gen_negative(ns, HERE)

@@ -9,7 +9,7 @@ import pytest
 
 from tests.helpers import GOLDEN, load_case
 from warpstr_amd import fast5, overview as ov
-from warpstr_amd.genotyper import run_genotyping
+from warpstr_amd.genotyper import call_alleles
 from warpstr_amd.signal_prep import process_raw
 from warpstr_amd.wrapper import get_raw_workload, prepare_caller_only
 
@@ -99,5 +99,5 @@ def test_upstream_known_answer_from_golden_lengths():
     z = load_case('real_aaat')
     lens = [len(str(z[f'r{i}_seq'][1])) for i in range(int(z['n_reads']))]
     assert sorted(set(lens)) == [40, 44]
-    gt = run_genotyping(lens, random_state=0)
-    assert gt.is_hetero and sorted(gt.alleles, reverse=True) == [44, 40]
+    gt = call_alleles(lens, random_state=0)
+    assert gt.heterozygous and sorted(gt.alleles, reverse=True) == [44, 40]

@@ -549,8 +549,8 @@ def test_main_wrapper_end_to_end(tmp_path):
     assert first[0] == '>read00' and len(first[1]) == out['results'][0]
     assert dfc is not None and list(dfc.columns) == ['AGC', 'CGC', 'reverse']
     assert collapse_repeats(first[1], ru, offs) == [[int(dfc['AGC'][0])], [int(dfc['CGC'][0])]]
-    gt = run_genotyping_overview(str(loc), random_state=0)
-    assert (loc / 'predictions' / 'alleles.csv').exists() and gt.first_allele > 0
+    gt = run_genotyping_overview(None, str(loc), random_state=0)
+    assert (loc / 'predictions' / 'alleles.csv').exists() and gt.allele(0) > 0
 
 
 def test_baseline_full_size_recovers_planted_alleles():
@@ -693,8 +693,8 @@ def test_upstream_test_case_real_reads(tmp_path):
         assert_close_rel(out['dtw_cost2'][i], z[f'r{i}_cost'][1], COST_REL)
     fasta = open(os.path.join(loc, 'predictions', 'sequences', 'all.fasta')).read().split('\n\n')
     assert fasta[0].splitlines()[1] == str(z['r0_seq'][1])
-    gt = run_genotyping_overview(loc, random_state=0)
-    assert gt.is_hetero and sorted(gt.alleles, reverse=True) == [44, 40]
+    gt = run_genotyping_overview(None, loc, random_state=0)
+    assert gt.heterozygous and sorted(gt.alleles, reverse=True) == [44, 40]
 
 
 def test_host_buffer_transfer_rings():

@@ -116,21 +116,21 @@ def test_overview_outputs(tmp_path):
 
 def test_genotyper_two_alleles_and_homozygous(tmp_path):
     from warpstr_amd import _lib
-    from warpstr_amd.genotyper import filter_out, genotype_results, run_genotyping, store_predictions
+    from warpstr_amd.genotyper import call_alleles, genotype_results, trim_outliers, write_alleles_csv
     rng = np.random.default_rng(3)
     vals = list(np.round(rng.normal(44, 1.0, 40)).astype(int)) + list(np.round(rng.normal(120, 1.5, 35)).astype(int))
-    gt = run_genotyping(vals, random_state=0)
-    assert gt.is_hetero and sorted(abs(a - b) <= 2 for a, b in zip(sorted(gt.alleles), (44, 120))) == [True, True]
-    assert gt.first_allele_sz + gt.second_allele_sz == len(filter_out(vals, 2))
-    hom = run_genotyping([40] * 12, random_state=0)
-    assert not hom.is_hetero and hom.alleles == (40, '-')
-    near = run_genotyping(list(np.round(rng.normal(60, 0.8, 50)).astype(int)) + [200], random_state=0)
-    assert not near.is_hetero and abs(near.first_allele - 60) <= 1          # the outlier is filtered (+-2 sigma)
+    gt = call_alleles(vals, random_state=0)
+    assert gt.heterozygous and sorted(abs(a - b) <= 2 for a, b in zip(sorted(gt.alleles), (44, 120))) == [True, True]
+    assert gt.support(0) + gt.support(1) == len(trim_outliers(vals, 2))
+    hom = call_alleles([40] * 12, random_state=0)
+    assert not hom.heterozygous and hom.alleles == (40, '-')
+    near = call_alleles(list(np.round(rng.normal(60, 0.8, 50)).astype(int)) + [200], random_state=0)
+    assert not near.heterozygous and abs(near.allele(0) - 60) <= 1          # the outlier is set aside (+-2 sigma)
     rec = np.zeros(6, dtype=_lib.RESULT_DTYPE)
     rec['len2'] = [30, 30, 30, 30, 99, 30]
     rec['status'] = [0, 0, 0, 0, 7, 0]
     assert genotype_results(rec).alleles == (30, '-')
-    p = store_predictions(gt, str(tmp_path))
+    p = write_alleles_csv(str(tmp_path), gt)
     assert open(p).read().splitlines()[0].startswith('WarpSTR_allele1,')
 
 
