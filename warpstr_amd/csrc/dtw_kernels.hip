@@ -1493,7 +1493,7 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, b
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else if (fill_wg_wanted(K)) snprintf(buf, sizeof(buf), "dtw_fill_wg<%d, %d, %d, %d>", m, K, fast_f(F), FL);
+    else if (lm == 0 && !pk && fill_wg_wanted(K)) snprintf(buf, sizeof(buf), "dtw_fill_wg<%d, %d, %d, %d>", m, K, fast_f(F), FL);
     else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, %s, %d>", m, K, fast_f(F), FL, pk ? "true" : "false", lm); // as rocprofv3 prints it
     return buf;
 }
