@@ -333,7 +333,12 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
     long long cut_from_ll = 6 * boundary; // rows with i >= first_threshold and i > second_threshold
     if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
-    const int cut_from = cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll);
+    const int cut_from = rfl(cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll));
+    // The cut only has to be FORCED for M rows: every predecessor of a cut state is a cut state (the cut takes a prefix of the
+    // pattern: flank, repeat, the right flank's first bases; back edges stay inside the repeat), so once the values that were
+    // in flight when the cut began have drained -- an export made at row i rests on D[i+2-M] at the oldest -- stay and
+    // every candidate of a cut state are +inf by themselves, and so are its pointers ("inf < inf" is false).
+    const int cut_end = cut_from + M < T ? cut_from + M : T;
     int sid[K]; // state handled at position k*64 + lane (-1: none)
     uint64_t cutm[K]; // lanes of slot k that the corner cut removes
 #pragma unroll
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
         }
 
         // one row, everything wave-uniform except the per-lane state; snext = s_{i+1}
-        auto row = [&](auto par, auto forced, auto cut, auto msk, auto rc, uint64_t *gp, double snext) {
+        auto row = [&](auto par, auto forced, auto cut, auto msk, auto rc, uint64_t *gp, double snext) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             constexpr int R = decltype(rc)::value; // row R of the group whose first row's masks are at gp
             constexpr bool FORCED = decltype(forced)::value;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
         };
         // packed rows, one row: the first mask goes to its place in the group of 16, the second one's byte joins `acc`,
         // which leaves for HBM when the eighth row of its half group has been added
-        auto row_pk = [&](auto par, auto forced, auto cut, auto msk, int r, double snext) {
+        auto row_pk = [&](auto par, auto forced, auto cut, auto msk, int r, double snext) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
             }
         };
         // the same, the masks handed back instead of stored (the caller stores a whole group at once)
-        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) {
+        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
@@ -456,11 +461,11 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
         };
         // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
         // 64-byte scalar load; the rows before and after such groups load theirs one by one
-        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
+        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) __attribute__((always_inline)) {
             using P0 = std::integral_constant<int, 0>;
             using P1 = std::integral_constant<int, 1>;
             using R0 = std::integral_constant<int, 0>;
-            auto one = [&](int r) {
+            auto one = [&](int r) __attribute__((always_inline)) {
                 if constexpr (PK) {
                     if (r & 1) row_pk(P1{}, forced, cut, msk, r, sample(r + 1));
                     else row_pk(P0{}, forced, cut, msk, r, sample(r + 1));
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
             for (; i < phi; i++) one(i);
         };
         // a phase, split into maximal runs of equal mask bit so that the row code is branch-free
-        auto phase = [&](auto forced, auto cut, int plo, int phi) {
+        auto phase = [&](auto forced, auto cut, int plo, int phi) __attribute__((always_inline)) {
             int i = plo;
             while (i < phi) {
                 const unsigned long long rest = bm >> (i - base);
@@ -551,9 +556,11 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
         };
         const int e0 = hi < M ? hi : M;               // forced rows end
         const int e1 = hi < cut_from ? hi : cut_from; // plain rows end
+        const int e2 = hi < cut_end ? hi : cut_end;   // rows that force the cut end
         phase(std::true_type{}, std::false_type{}, lo, e0);
         phase(std::false_type{}, std::false_type{}, lo > M ? lo : M, e1);
-        phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, hi);
+        phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, e2);
+        phase(std::false_type{}, std::false_type{}, lo > cut_end ? lo : cut_end, hi);
     }
 
     if constexpr (PK) { // the last half group of the read, if it is not complete
@@ -627,7 +634,12 @@ __device__ __forceinline__ void fill_wg_slot(const PassArgs &a, const DevAutomat
     const long long after_repeat = (long long)A.seq_idx_last - boundary;
     long long cut_from_ll = 6 * boundary;
     if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
-    const int cut_from = cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll);
+    const int cut_from = rfl(cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll));
+    // The cut only has to be FORCED for M rows: every predecessor of a cut state is a cut state (the cut takes a prefix of the
+    // pattern: flank, repeat, the right flank's first bases; back edges stay inside the repeat), so once the values that were
+    // in flight when the cut began have drained -- an export made at row i rests on D[i+2-M] at the oldest -- stay and
+    // every candidate of a cut state are +inf by themselves, and so are its pointers ("inf < inf" is false).
+    const int cut_end = cut_from + M < T ? cut_from + M : T;
     int j = wl < S ? wl : -1; // state of this lane
     if (A.state_at) {
         const int t = A.state_at[wl];
@@ -718,17 +730,17 @@ __device__ __forceinline__ void fill_wg_slot(const PassArgs &a, const DevAutomat
             bm = ((m0 | (m1 << 32)) >> 2) | ((m2 & 3ull) << 62);
             bm = ((unsigned long long)(unsigned)rfl((int)(bm >> 32)) << 32) | (unsigned)rfl((int)bm);
         }
-        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[FX]) {
+        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[FX]) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
             dp_row<M, 1, FX, FX, MROW, PAR, FORCED, CUT, EXW, true>(st, ex, wl, snext, mk, cutm);
         };
-        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) {
+        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) __attribute__((always_inline)) {
             using P0 = std::integral_constant<int, 0>;
             using P1 = std::integral_constant<int, 1>;
-            auto one = [&](int r) {
+            auto one = [&](int r) __attribute__((always_inline)) {
                 uint64_t mk[FX];
                 if (r & 1) row_keep(P1{}, forced, cut, msk, sample(r + 1), mk);
                 else row_keep(P0{}, forced, cut, msk, sample(r + 1), mk);
@@ -761,7 +773,7 @@ __device__ __forceinline__ void fill_wg_slot(const PassArgs &a, const DevAutomat
             }
             for (; i < phi; i++) one(i);
         };
-        auto phase = [&](auto forced, auto cut, int plo, int phi) {
+        auto phase = [&](auto forced, auto cut, int plo, int phi) __attribute__((always_inline)) {
             int i = plo;
             while (i < phi) {
                 const unsigned long long rest = bm >> (i - base);
@@ -776,9 +788,11 @@ __device__ __forceinline__ void fill_wg_slot(const PassArgs &a, const DevAutomat
         };
         const int e0 = bhi < M ? bhi : M;               // forced rows end
         const int e1 = bhi < cut_from ? bhi : cut_from; // plain rows end
+        const int e2 = bhi < cut_end ? bhi : cut_end;   // rows that force the cut end
         phase(std::true_type{}, std::false_type{}, blo, e0);
         phase(std::false_type{}, std::false_type{}, blo > M ? blo : M, e1);
-        phase(std::false_type{}, std::true_type{}, blo > cut_from ? blo : cut_from, bhi);
+        phase(std::false_type{}, std::true_type{}, blo > cut_from ? blo : cut_from, e2);
+        phase(std::false_type{}, std::false_type{}, blo > cut_end ? blo : cut_end, bhi);
     }
     idle_rows(hi + 1, T);
 
