@@ -339,6 +339,38 @@ def from_raw_leg(hip, wl, device, steps, warmup):
                         'seq1/seq2 -> 56-B records to pinned host memory; host variant: upload of step k+1 on a copy stream'}
 
 
+def secondary_leg(wl, local, device, steps, warmup, n_verify):
+    """One more workload under the same clock rules (pipelined device-resident calls, K timed steps between two
+    synchronisations), its records checked against the oracle: the production shape (cfg1) and configs[4]'s share (cfg5)
+    ride along with the default run so that the driver's record holds them."""
+    import torch
+
+    from warpstr_amd import _lib
+    from warpstr_amd.caller import HipCaller
+    n = wl.n
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=torch.cuda.current_stream().cuda_stream, workspace_limit=96 << 30)
+    res = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+    hip.set_pipelined(True)
+    for k in range(warmup):
+        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
+    hip.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
+    hip.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    got = res[(steps - 1) % N_BUF].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+    nv = min(n, n_verify)
+    ores, _ = oracle_sample(wl, wl.signal[: int(wl.offsets[nv])].cpu().numpy(), nv, 2.0)
+    out = {'workload': wl.desc, 'reads_per_step': n, 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+           'value': n * steps / dt, 'unit': 'reads/s', 'kernels': sorted({hip.kernel_name(a) for a in range(len(wl.tables))}),
+           'called_ok': int((got['status'] == 0).sum()), 'verified': verify(got, ores)}
+    hip.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -350,6 +382,9 @@ def main():
     ap.add_argument('--samples', type=int, default=2000, help='samples per read (headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the 15 s CPU baseline (a 256-read check remains)')
     ap.add_argument('--no-verify', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='the default single-GPU headline run also times cfg1, cfg5 and the path from raw int16 segments '
+                         '(reported under "secondary"); this switch leaves them out')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
                          'called sequences requested; reported as from_raw next to the headline')
@@ -531,7 +566,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': kernel, 'kernels': kernels,
-                         'launch_ms': fill_union / launches_total, 'launches_per_step': launches_total / args.steps,
+                         'fill_union_ms_per_launch': fill_union / launches_total, 'launches_per_step': launches_total / args.steps,
                          'reads_per_launch': float(fr.sum()) / launches_total,
                          'fill_union_ms_per_step': fill_union / args.steps,
                          'launch_ms_mean_overlapping': fill_sum / launches_total,
@@ -554,11 +589,36 @@ def main():
             if out['verified']['mismatches']:
                 rc = 3
                 print(f"bench.py: {out['verified']['mismatches']} of {len(ores)} reads differ from the oracle", file=sys.stderr)
-        if args.from_raw and world == 1:
+        if 'cpu_baseline' in out:
+            # the reference's own Python caller cannot travel to the GPU box; its timing on this shape was taken in the
+            # development container (Pool(8), 8 vCPUs) and rides along as a constant
+            out['cpu_baseline']['reference_python'] = {'value': 12.1, 'unit': 'reads/s', 'cores': 8, 'kind': 'reference',
+                                                       'sample': 'upstream WarpSTR.run through Pool(8) on 2 kSample x 64-state '
+                                                                 'reads, development container (BASELINE.md section 2); a constant, '
+                                                                 'not measured in this run'}
+        secondary = (world == 1 and wl.name == 'headline' and args.reads == 0 and not args.no_secondary and not args.no_verify
+                     and not os.environ.get('WARPSTR_BENCH_PROFILING'))
+        if (args.from_raw or secondary) and world == 1:
             out['from_raw'] = from_raw_leg(hip, wl, device, max(3, args.steps // 2), 2)
             if not out['from_raw']['identical_to_f64_path']['identical']:
                 rc = 3
                 print('bench.py: the from-raw path and the float64 path disagree', file=sys.stderr)
+        if secondary:
+            # driver-timed numbers for the production shape and configs[4]'s share, each checked against the oracle
+            hip.close()
+            del hip
+            out['secondary'] = {}
+            pat, fl, tr = CFG1
+            legs = (('cfg1', lambda: make_ragged('cfg1', [(pat, fl, tr, 1, None)], 20000, 1000, device)),
+                    ('cfg5', lambda: make_ragged('cfg5', [(p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i, None)
+                                                          for i, p in enumerate(CFG5_PATTERNS)], 50000, 1000, device)))
+            for name, make in legs:
+                leg = secondary_leg(make(), local, device, max(4, args.steps // 2), 4, 256)
+                out['secondary'][name] = leg
+                if leg['verified']['mismatches']:
+                    rc = 3
+                    print(f"bench.py: secondary workload {name}: {leg['verified']['mismatches']} reads differ from the oracle", file=sys.stderr)
+            out['secondary']['from_raw'] = out['from_raw']
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or self_gather:

@@ -16,7 +16,7 @@ with open(os.path.join(prof, f'{name}_kernel_stats.csv'), 'w', newline='') as f:
 
 # the dominant kernel's launches by size: bench.py times K = 20 steps (after 2 warm-up steps) of 4 chunks x 2 passes (25 000 reads per launch at the default
 # size) and then runs one extra untimed single-stream step (2 launches of all reads) for the VALU roofline; rocprofv3's
-# per-kernel average above mixes the two, bench.py's roofline.launch_ms is the first kind
+# per-kernel average above mixes the two, bench.py's roofline.fill_union_ms_per_launch is the first kind
 tr = list(csv.DictReader(open(os.path.join(src, 'trace', 'p_kernel_trace.csv'))))
 by = collections.defaultdict(list)
 for r in tr:
@@ -28,7 +28,7 @@ with open(os.path.join(prof, f'{name}_fill_launches.txt'), 'w') as f:
         f.write(f'grid {g:9d} threads = {g // 64:6d} reads per launch: {len(v):3d} launches, average {sum(v) / len(v) / 1e6:.4f} ms, '
                 f'min {min(v) / 1e6:.4f}, max {max(v) / 1e6:.4f}\n')
     bj = json.load(open(os.path.join(src, 'bench_under_trace.json')))
-    f.write(f"bench.py under the trace: roofline.launch_ms = {bj['roofline']['launch_ms']:.4f} ms over {bj['roofline']['launches_per_step']} launches per step, "
+    f.write(f"bench.py under the trace: roofline.fill_union_ms_per_launch = {bj['roofline'].get('fill_union_ms_per_launch', bj['roofline'].get('launch_ms')):.4f} ms over {bj['roofline']['launches_per_step']} launches per step, "
             f"valu_roofline.launch_ms_alone = {bj['valu_roofline']['launch_ms_alone']:.4f} ms, fill_union_ms_per_step = {bj['roofline']['fill_union_ms_per_step']:.4f}\n")
 
 # PMC passes (WSX_STREAMS=1: kernels one at a time), mean per launch and kernel

@@ -36,7 +36,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 'traffic' in r
     assert r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['launches_per_step'] >= 2 and r['launch_ms'] > 0
+    assert r['launches_per_step'] >= 2 and r['fill_union_ms_per_launch'] > 0 and 'launch_ms' not in r
     # no reported kernel time exceeds the step: the fill figure is a union of launch intervals
     assert r['fill_union_ms_per_step'] <= d['ms_per_step'] * 1.001
     c = d['cpu_baseline']
@@ -67,6 +67,26 @@ def test_bench_from_raw_leg_reports_both_variants_and_checks_them():
     assert f['reads_per_s_hbm_int16'] > 0 and f['reads_per_s_host_int16'] > 0
     assert f['identical_to_f64_path']['identical'] is True and f['identical_to_f64_path']['reads'] > 0
     assert f['h2d_bytes_per_step'] == 6000 * 900 * 2
+
+
+def test_default_run_carries_the_secondary_workloads():
+    """The driver's command (no --reads, one GPU): besides the headline, ONE line also holds driver-timed, oracle-checked
+    numbers for the flank-110 shape (cfg1), configs[4]'s share (cfg5) and the path from raw int16 segments, and the
+    reference's own Python timing as a constant next to the CPU baseline."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1'], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT)
+    d = _one_line(out)
+    if os.environ.get('WARPSTR_BENCH_PROFILING'):
+        pytest.skip('profiling runs leave the secondary workloads out')
+    sec = d['secondary']
+    for name in ('cfg1', 'cfg5'):
+        leg = sec[name]
+        assert leg['ms_per_step'] > 0 and leg['value'] > 0 and leg['called_ok'] == leg['reads_per_step']
+        assert leg['verified']['reads'] >= 256 and leg['verified']['mismatches'] == 0 and leg['kernels']
+    assert sec['from_raw']['identical_to_f64_path']['identical'] is True and sec['from_raw']['ms_per_step_host_int16'] > 0
+    ref = d['cpu_baseline']['reference_python']
+    assert ref['kind'] == 'reference' and ref['value'] > 0 and ref['cores'] == 8
+    assert d['config']['name'] == 'headline' and d['verified']['mismatches'] == 0
 
 
 def _free_port():

@@ -179,6 +179,7 @@ class HipCaller:
         """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
         default: odd positions (template, reverse, template, reverse, ...)."""
         self.lib = _lib.load()
+        self.device = int(device)
         if self.lib.wsx_device_count() <= 0:
             raise RuntimeError('warpstr_amd: no HIP device visible; the caller has no CPU path')
         self.caller_config = caller_config or CallerConfig()
@@ -452,8 +453,11 @@ class CallerWrapper:
 
     def __init__(self, locus_or_sequence, flanks_or_threads=None, flank_length: Optional[int] = None, threads: int = 1,
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
-                 device: int = 0, pore_model=None, on_error: str = 'raise', flanks: Optional[Sequence[str]] = None):
+                 device: int = 0, pore_model=None, on_error: str = 'raise', flanks: Optional[Sequence[str]] = None,
+                 write_summaries: bool = True):
+        """write_summaries=False: the locus directory is left alone (ranks other than 0 of a multi-GPU job)."""
         from .pore_model import default_pore_model
+        self._write_summaries = bool(write_summaries)
         self.caller_config = caller_config or CallerConfig()
         self.pore_model = pore_model or default_pore_model()
         if isinstance(locus_or_sequence, str):
@@ -484,7 +488,7 @@ class CallerWrapper:
         from .automata import reverse_pattern
         diffs_t = self.pore_model.get_diffs_for_all(sequence)
         diffs_r = self.pore_model.get_diffs_for_all(reverse_pattern(sequence))
-        if out_dir is None and self.locus is not None:
+        if out_dir is None and self.locus is not None and self._write_summaries:
             out_dir = os.path.join(self.locus.path, 'summaries')
         if out_dir is not None:
             os.makedirs(out_dir, exist_ok=True)
@@ -518,8 +522,41 @@ class CallerWrapper:
         [l_start_raw, r_end_raw] (Fast5.get_data_processed, src/schemas/fast5.py:45-57) happen on the GPU."""
         if not names:
             return []
-        signal, offsets, _ = self.hip.prepare_signals(raws, positions, spike_removal)
-        return self._run_packed(list(names), list(reverses), signal, offsets)
+        if spike_removal not in ('None', 'Brute'):
+            raise ValueError('only spike_removal None / Brute run on the GPU (median3/median5: warpstr_amd.signal_prep)')
+        # The reads cross PCIe once, as int16 (2 bytes per sample of the WHOLE read go up, the records and the called
+        # sequences come down); the normalised float64 segments are produced and consumed in HBM.  torch is the device
+        # allocator here (pinned staging buffer, HBM buffers), nothing else.
+        import torch
+        dev = torch.device('cuda', self.hip.device)
+        n = len(names)
+        lens = np.fromiter((len(r) for r in raws), dtype=np.int64, count=n)
+        roff = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=roff[1:])
+        staged = torch.empty(int(roff[-1]), dtype=torch.int16, pin_memory=True)
+        raw_host = staged.numpy()
+        for r, o in zip(raws, roff[:-1]):
+            raw_host[o:o + len(r)] = r
+        lo = np.array([p[0] for p in positions], np.int64)
+        hi = np.array([p[1] for p in positions], np.int64)
+        seglen = np.array([len(range(*slice(int(a), int(b) + 1).indices(int(L)))) for a, b, L in zip(lo, hi, lens)], np.int64)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(seglen, out=offsets[1:])
+        total = int(offsets[-1])
+        aut = np.fromiter((1 if r else 0 for r in reverses), dtype=np.int32, count=n)
+        with torch.cuda.device(dev):
+            raw_dev = staged.to(dev, non_blocking=True)
+            signal = torch.empty(max(total, 1), dtype=torch.float64, device=dev)
+            records = torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            seq1 = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+            seq2 = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream(dev).synchronize()  # the handle's stream is not torch's: inputs are complete before it starts
+            self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, spike_removal)
+            self.hip.call_device(signal.data_ptr(), offsets, aut, records.data_ptr(), seq1_ptr=seq1.data_ptr(), seq2_ptr=seq2.data_ptr())
+            self.hip.synchronize()
+            res = records.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(n)
+            out = CallerResults(list(names), res, offsets[:-1], seq1[:total].cpu().numpy(), seq2[:total].cpu().numpy(), self.on_error)
+        return out.check()
 
     def _run_packed(self, names, reverses, signal, offsets) -> 'CallerResults':
         aut = np.fromiter((1 if r else 0 for r in reverses), dtype=np.int32, count=len(names))

@@ -1501,7 +1501,17 @@ static int fast_f(int F) { return F <= 2 ? 2 : F; }
 
 bool wsx_split_supported(int m, int K) { return m == 4 && K >= 2; }
 
-bool wsx_lane_major_supported(int m, int K) { return m == 4 && K >= 2 && K <= WSX_MAX_K; }
+// Lane-major placement from three slots on: with two it buys 2-4 % where it fits (4.30 vs 4.46 ms at 65 states, 4.71 vs 4.82
+// at 96: profiles/r03_state_staircase.log) and costs the mixed batch of configs[4] 4 % (more kernel variants per call:
+// 16.9 vs 16.2 ms per step).  WSX_FILL_LM=3 asks for it from two slots on.
+bool wsx_lane_major_supported(int m, int K)
+{
+    static const int lm_min_k = [] {
+        const char *e = getenv("WSX_FILL_LM");
+        return (e && atoi(e) == 3) ? 2 : 3;
+    }();
+    return m == 4 && K >= lm_min_k && K <= WSX_MAX_K;
+}
 
 const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, bool generic)
 {

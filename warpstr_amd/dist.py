@@ -3,23 +3,88 @@ path); the only collective is one all-gather of the fixed-size per-read result r
 rank (or rank 0) can genotype.  Backend 'nccl' is RCCL on ROCm; the same code
 runs on 'gloo' with CPU tensors for the world_size-2 tests.
 """
-from typing import List, Sequence, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
 
-def shard_reads(lengths: Sequence[int], world: int) -> List[np.ndarray]:
-    """Greedy longest-first partition of read indices by work (~ samples): returns, per rank, the sorted
-    array of read indices it owns.  Deterministic; every read appears exactly once."""
+# What a sample of a read costs, by the number of 64-state slots of its automaton, relative to one slot: the whole call on
+# 20 000 reads x 2 000 samples (scripts/exp_staircase.py, profiles/r03_state_staircase.log: 3.11 / 4.8 / 6.3 / 8.0 / 10.4 ms at
+# 1..5 slots, the mean over the layouts a slot count can get).  Beyond five slots the general kernel runs (LDS ring, one
+# wave per read); its cost per slot was measured once (S = 665: ~6x a register-resident slot).
+SLOT_COST = {1: 1.0, 2: 1.54, 3: 2.0, 4: 2.57, 5: 3.35}
+
+
+def slot_cost(n_states: int) -> float:
+    """Relative cost per sample of calling a read against an automaton of n_states states (see SLOT_COST)."""
+    k = (int(n_states) + 63) // 64
+    return SLOT_COST[k] if k in SLOT_COST else 6.0 * k
+
+
+def shard_reads(lengths: Sequence[int], world: int, cost_per_sample: Optional[Sequence[float]] = None) -> List[np.ndarray]:
+    """Greedy longest-first partition of read indices by work: returns, per rank, the sorted array of read indices it
+    owns.  Work = samples x cost_per_sample (slot_cost of the read's automaton: a read on a five-slot automaton costs 3.35 x
+    a single-slot one per sample; None = every read costs the same per sample).  Deterministic -- every rank derives the
+    same partition from the same description -- and every read appears exactly once."""
     lengths = np.asarray(lengths, dtype=np.int64)
-    order = np.argsort(-lengths, kind='stable')
-    load = np.zeros(world, dtype=np.int64)
+    work = lengths.astype(np.float64) if cost_per_sample is None else lengths * np.asarray(cost_per_sample, dtype=np.float64)
+    order = np.argsort(-work, kind='stable')
+    load = np.zeros(world, dtype=np.float64)
     owner = np.empty(len(lengths), dtype=np.int64)
     for i in order:
         r = int(np.argmin(load))
         owner[i] = r
-        load[r] += lengths[i]
+        load[r] += work[i]
     return [np.flatnonzero(owner == r) for r in range(world)]
+
+
+def force_collectives() -> bool:
+    """WARPSTR_DIST_SELF_GATHER=1: a single process still joins a (one-rank) process group and runs every collective -- how
+    the RCCL path is exercised on a one-GPU box."""
+    return bool(os.environ.get('WARPSTR_DIST_SELF_GATHER'))
+
+
+def process_group():
+    """(rank, world) of this process; joins the job's process group when it was started under torch.distributed.run
+    (RANK / WORLD_SIZE / MASTER_* in the environment) and none exists yet.  Backend: WARPSTR_DIST_BACKEND, else 'nccl'
+    (= RCCL) when a GPU is visible, else 'gloo'.  The group is created without binding it to a device: an eager
+    communicator slowed every later kernel launch on this stack."""
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env <= 1 and not force_collectives():
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if world_env <= 1:  # one-rank group outside torch.distributed.run
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+        backend = os.environ.get('WARPSTR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def gather_bytes_ragged(local: np.ndarray, world: int, device=None) -> List[np.ndarray]:
+    """All-gather one byte string of arbitrary length per rank (the called sequences of a shard): sizes first, then the
+    strings padded to the longest.  Returns the per-rank strings."""
+    local = np.ascontiguousarray(local, dtype=np.uint8).reshape(-1)
+    if world <= 1 and not force_collectives():
+        return [local]
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else 'cpu'
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([len(local)], dtype=torch.int64, device=dev))
+    sizes = sizes.cpu().numpy()
+    cap = max(int(sizes.max()), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    mine[:len(local)] = torch.from_numpy(local).to(dev)
+    everything = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(everything, mine)
+    everything = everything.cpu().numpy().reshape(world, cap)
+    return [everything[r, :int(sizes[r])].copy() for r in range(world)]
 
 
 def gather_results(local, world: int):
@@ -39,7 +104,7 @@ def gather_results_ragged(local_records: np.ndarray, owned: np.ndarray, n_total:
     import torch
     import torch.distributed as dist
     itemsize = local_records.dtype.itemsize
-    if world <= 1:
+    if world <= 1 and not force_collectives():
         out = np.zeros(n_total, dtype=local_records.dtype)
         out[owned] = local_records
         return out
@@ -63,14 +128,47 @@ def gather_results_ragged(local_records: np.ndarray, owned: np.ndarray, n_total:
     return out
 
 
-def call_sharded(caller, signals: Sequence[np.ndarray], automaton_id: Sequence[int], world: int, rank: int, device=None):
+def gather_called(local, owned: np.ndarray, shards: List[np.ndarray], n_total: int, world: int, device=None):
+    """Every rank's CallerResults (records + called sequences of its shard, in the order of its `owned` indices) -> the
+    complete table in the original read order, on every rank: (records, seq1, offsets1, seq2, offsets2) with the two
+    sequence buffers packed (read r's seq at seq1[offsets1[r] : offsets1[r] + len1[r]]).  Two collectives: the 56-byte
+    records (+ their read index), and one byte string of sequences per rank."""
+    records = gather_results_ragged(local.records, owned, n_total, world, device)
+    l1, l2 = local.records['len1'].astype(np.int64), local.records['len2'].astype(np.int64)
+    ok = local.records['status'] == 0
+    l1, l2 = np.where(ok, l1, 0), np.where(ok, l2, 0)
+    as_u8 = lambda b: np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray, memoryview)) else np.asarray(b, dtype=np.uint8)
+    s1, s2 = as_u8(local._seq1), as_u8(local._seq2)
+    pieces = [s1[int(o):int(o) + int(n)] for o, n in zip(local.offsets, l1)] + [s2[int(o):int(o) + int(n)] for o, n in zip(local.offsets2, l2)]
+    blob = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    blobs = gather_bytes_ragged(blob, world, device)
+    g1 = np.where(records['status'] == 0, records['len1'].astype(np.int64), 0)
+    g2 = np.where(records['status'] == 0, records['len2'].astype(np.int64), 0)
+    off1, off2 = np.zeros(n_total + 1, np.int64), np.zeros(n_total + 1, np.int64)
+    np.cumsum(g1, out=off1[1:])
+    np.cumsum(g2, out=off2[1:])
+    seq1, seq2 = np.zeros(int(off1[-1]), np.uint8), np.zeros(int(off2[-1]), np.uint8)
+    for r in range(world):
+        idx = shards[r]
+        at = 0
+        for i in idx:  # a rank's string: the seqs of its reads in shard order, then their resc_seqs
+            seq1[off1[i]:off1[i + 1]] = blobs[r][at:at + g1[i]]
+            at += int(g1[i])
+        for i in idx:
+            seq2[off2[i]:off2[i + 1]] = blobs[r][at:at + g2[i]]
+            at += int(g2[i])
+    return records, seq1, off1[:-1], seq2, off2[:-1]
+
+
+def call_sharded(caller, signals: Sequence[np.ndarray], automaton_id: Sequence[int], world: int, rank: int, device=None,
+                 cost_per_sample: Optional[Sequence[float]] = None):
     """Call a whole workload across `world` ranks (one process per GPU): every rank passes the SAME full workload,
     calls only its own shard on its GPU (`caller` = this rank's HipCaller, or anything with a compatible `.call`),
     and receives the complete result table in the original read order (what step 4 / the genotyper consumes).
     The only communication is the all-gather of the 56-byte result records."""
     from .caller import pack_signals
     lengths = [len(s) for s in signals]
-    shards = shard_reads(lengths, world)
+    shards = shard_reads(lengths, world, cost_per_sample)
     mine = shards[rank]
     sig, off = pack_signals([signals[i] for i in mine])
     aut = np.asarray(automaton_id, dtype=np.int32)[mine]

@@ -80,20 +80,23 @@ def write_results_to_fasta(fasta, locus_path: str):
             f.writelines(f'>{rid}\n{seq}\n\n' for rid, seq, rev in fasta if strand is None or rev == strand)
 
 
-def store_results(overview_path, df_overview, seq_results, cost_results, locus_path: str):
+def store_results(overview_path, df_overview, seq_results, cost_results, locus_path: str, write: bool = True):
     """Write the FASTA files and the overview with (re)placed `results, orig, dtw_cost1, dtw_cost2` columns; any older
     column starting with 'result' is dropped first (src/caller/overview.py:48-54,103-115)."""
     cols, fasta = result_columns(df_overview, seq_results, cost_results)
-    write_results_to_fasta(fasta, locus_path)
+    if write:
+        write_results_to_fasta(fasta, locus_path)
     stale = [c for c in df_overview.columns if c.startswith('result')]
     df_overview = df_overview.drop(columns=stale)
     for name in ('results', 'orig', 'dtw_cost1', 'dtw_cost2'):
         df_overview[name] = cols[name]
-    df_overview.to_csv(overview_path)
+    if write:
+        df_overview.to_csv(overview_path)
     return df_overview
 
 
-def store_collapsed(results, units: List[str], rep_units: List[List[str]], reverse_lst: List[bool], locus_path: str):
+def store_collapsed(results, units: List[str], rep_units: List[List[str]], reverse_lst: List[bool], locus_path: str,
+                    write: bool = True):
     """predictions/complexSTR_analysis/complex_repeat_units.csv (src/caller/overview.py:11-34): one row per read;
     a unit with alternatives gives `main_<first>` (all its counts summed) plus one `inter_<suffix>` column per further
     alternative, a plain unit gives one column named after its bases; last column `reverse`."""
@@ -108,7 +111,8 @@ def store_collapsed(results, units: List[str], rep_units: List[List[str]], rever
             table[unit.strip('(').strip(')')] = counts[:, 0]
     table['reverse'] = list(reverse_lst)
     df = pd.DataFrame(table)
-    out = os.path.join(locus_path, PREDICTIONS_SUBDIR, COMPLEX_SUBDIR)
-    os.makedirs(out, exist_ok=True)
-    df.to_csv(os.path.join(out, 'complex_repeat_units.csv'))
+    if write:
+        out = os.path.join(locus_path, PREDICTIONS_SUBDIR, COMPLEX_SUBDIR)
+        os.makedirs(out, exist_ok=True)
+        df.to_csv(os.path.join(out, 'complex_repeat_units.csv'))
     return df

@@ -82,6 +82,10 @@ def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
     if kwargs:
         raise TypeError(f'main_wrapper: unexpected arguments {sorted(kwargs)}')
     caller_config = caller_config or CallerConfig()
+    from . import dist as wdist
+    rank, world = wdist.process_group()
+    if world > 1 or wdist.force_collectives():
+        return _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal_loader, rank, world)
     overview_path, df_overview = ov.load_overview(locus.path)
     cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device)
     if signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
@@ -92,16 +96,75 @@ def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
         workload = get_workload(df_overview, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
         reverses = [w.reverse for w in workload]
         results = cw.run(workload)
+    return _store_outputs(locus, overview_path, df_overview, results, reverses, write=True)
+
+
+def _store_outputs(locus, overview_path, df_overview, results, reverses, write: bool):
+    """The results of all `saved` reads (overview order) -> overview columns, FASTA files, complex-unit table
+    (src/caller/wrapper.py:24-41).  write=False: the tables are built and returned, the locus directory is not touched."""
     seq_results = [(r.seq, r.resc_seq) for r in results]
     cost_results = [(r.cost, r.resc_cost) for r in results]
-    df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus.path)
+    df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus.path, write=write)
     df_collapsed = None
     units, repeat_units, offsets = break_into_units(locus.sequence.upper())
     if len(units) > 1:
-        print(f'Running complex genotyping as complex repeat units present: {units}')
+        if write:
+            print(f'Running complex genotyping as complex repeat units present: {units}')
         collapsed = [collapse_repeats(s[1], repeat_units, offsets) for s in seq_results]
-        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus.path)
+        df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus.path, write=write)
     return df_overview, df_collapsed
+
+
+def _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal_loader, rank: int, world: int):
+    """main_wrapper under `python -m torch.distributed.run --nproc-per-node N` (one process per GPU; upstream's fan-out is
+    the Pool.map of src/caller/wrapper.py:104-120).  Every rank reads the overview, derives the same partition of the
+    `saved` reads -- by cost: samples of the STR segment x what a sample costs on the strand's automaton (dist.slot_cost) --,
+    opens ONLY its own reads' fast5 files and calls them on its GPU.  Two collectives (RCCL all-gathers over xGMI; gloo in
+    the CPU tests) return every read's 56-byte record and called sequences to every rank; rank 0 writes overview.csv, the
+    FASTA files and the complex-unit table exactly as the single-GPU path does, every rank returns the same two tables
+    (so step 4 may run anywhere)."""
+    import torch
+    import torch.distributed as tdist
+
+    from . import dist as wdist
+    from .caller import CallerResults
+    backend = tdist.get_backend()
+    local_gpu = int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1)
+    coll_device = torch.device('cuda', local_gpu) if backend == 'nccl' else None
+    if backend == 'nccl':
+        torch.cuda.set_device(local_gpu)
+    overview_path, df_overview = ov.load_overview(locus.path)
+    # a read the caller fails on must not leave the other ranks waiting in a collective: the shards are called without
+    # raising, the complete table is checked on every rank alike
+    cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=local_gpu,
+                       write_summaries=rank == 0, on_error='nan')
+    saved = df_overview[np.asarray(df_overview['saved']).astype(bool)]
+    n = len(saved)
+    reverses = [bool(v) for v in saved['reverse']]
+    span = (np.asarray(saved['r_end_raw'], np.int64) - np.asarray(saved['l_start_raw'], np.int64) + 1).clip(min=1)
+    per_sample = np.where(np.asarray(reverses), wdist.slot_cost(cw.rev_sta.n_states), wdist.slot_cost(cw.temp_sta.n_states))
+    shards = wdist.shard_reads(span, world, per_sample)
+    mine = shards[rank]
+    part = saved.iloc[mine]
+    if len(part) == 0:
+        local = CallerResults([], np.zeros(0, dtype=_RESULT_DTYPE()), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.uint8),
+                              'nan')
+    elif signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
+        names, revs, raws, positions = get_raw_workload(part, locus.path)
+        local = cw.run_raw(names, revs, raws, positions, caller_config.spike_removal)
+    else:
+        workload = get_workload(part, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
+        local = cw.run(workload)
+    records, seq1, off1, seq2, off2 = wdist.gather_called(local, mine, shards, n, world, coll_device)
+    results = CallerResults([str(x) for x in saved.index], records, off1, seq1, seq2, 'raise', offsets2=off2).check()
+    out = _store_outputs(locus, overview_path, df_overview, results, reverses, write=rank == 0)
+    tdist.barrier()  # the files are complete when any rank returns
+    return out
+
+
+def _RESULT_DTYPE():
+    from . import _lib
+    return _lib.RESULT_DTYPE
 
 
 def prepare_caller_only(csv_path: str, output: str, base_dir: str = '.'):
@@ -128,3 +191,41 @@ def prepare_caller_only(csv_path: str, output: str, base_dir: str = '.'):
         part.to_csv(os.path.join(locus_path, ov.OVERVIEW_NAME), index=False)
         out[locus] = locus_path
     return out
+
+
+def _npz_loader(path: str) -> Callable[[str, int, int], np.ndarray]:
+    """Already normalised STR segments from an .npz archive (read name -> float64 array) instead of fast5 files."""
+    archive = np.load(path)
+    return lambda fast5path, l_start_raw, r_end_raw: archive[os.path.basename(fast5path)[:-len('.fast5')]]
+
+
+def main(argv=None):
+    """Step 3 (and optionally step 4) for one locus from the command line; under `python -m torch.distributed.run
+    --nproc-per-node N -m warpstr_amd.wrapper ...` the reads are sharded over the N GPUs of the node."""
+    import argparse
+    ap = argparse.ArgumentParser(prog='python -m warpstr_amd.wrapper', description=main.__doc__)
+    ap.add_argument('locus_path')
+    ap.add_argument('sequence')
+    ap.add_argument('flank_length', type=int)
+    ap.add_argument('--segments-npz', dest='signals', help='.npz archive of normalised segments by read name (instead of the fast5 files)')
+    ap.add_argument('--genotype', action='store_true', help='also run step 4 on the results (rank 0)')
+    args = ap.parse_args(argv)
+    locus = LocusPath(args.locus_path, args.sequence, args.flank_length)
+    df_overview, df_collapsed = main_wrapper(locus, 1, signal_loader=_npz_loader(args.signals) if args.signals else None)
+    from . import dist as wdist
+    rank, _ = wdist.process_group()
+    if rank == 0:
+        called = int((np.asarray(df_overview['results']) >= 0).sum())
+        print(f'{locus.name}: {called} reads called')
+        if args.genotype:
+            from .genotyper import run_genotyping_complex, run_genotyping_overview
+            run_genotyping_overview(df_overview, locus.path, None)
+            run_genotyping_complex(locus.path, df_collapsed)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
