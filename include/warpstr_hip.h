@@ -67,7 +67,7 @@ enum {
     WSX_READ_BACKTRACK = 2,     /* upstream RuntimeError, caller.py:290-291 */
     WSX_READ_FIT_POINTS = 3,    /* < 4 states pass filter_alignment (upstream: splrep TypeError) */
     WSX_READ_FIT_ORDER = 4,     /* degenerate abscissae for the rescaling fit */
-    WSX_READ_FIT_SMOOTH = 5,    /* residual >= s: upstream FITPACK would add knots (threshold > 1) */
+    WSX_READ_FIT_SMOOTH = 5,    /* residual of the cubic >= 1.001 s: upstream FITPACK would add knots (needs threshold > 1) */
     WSX_READ_NO_REPEAT = 6,     /* no repeat state on the path (upstream IndexError, caller.py:384) */
     WSX_READ_SEGMENT_RANGE = 7, /* upstream IndexError in find_event_borders/segment (caller.py:395-397) */
 };
@@ -92,7 +92,7 @@ typedef struct wsx_automaton {
 typedef struct wsx_params {
     int32_t min_values_per_state; /* tr_calling_config.min_values_per_state, default 4 (> 1) */
     int32_t states_in_segment;    /* tr_calling_config.states_in_segment, default 6 (> 1) */
-    double threshold;             /* rescaling.threshold, default 0.5 (0 < . <= 1) */
+    double threshold;             /* rescaling.threshold, default 0.5 (> 0; above 1 a read may come back WSX_READ_FIT_SMOOTH) */
     double max_std;               /* rescaling.max_std, default 0.5 */
     int32_t method_median;        /* rescaling.method: 0 = mean, 1 = median */
     int32_t reps_as_one;          /* rescaling.reps_as_one (0/1) */
@@ -211,7 +211,8 @@ int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
  *   raw            concatenated int16 raw signals of whole reads, in `mem`
  *   raw_offsets    host int64[n_reads+1]
  *   seg_start/end  host int64[n_reads] (inclusive end, as upstream)
- *   spike_removal  0 = None, 1 = Brute (tr_calling_config.spike_removal; median3/median5 are not on the GPU)
+ *   spike_removal  0 = None, 1 = Brute, 2 = median3, 3 = median5 (tr_calling_config.spike_removal; remove_spikes,
+ *                  src/schemas/fast5.py:68-75; the median filters are scipy.signal.medfilt: zero padding at both ends)
  *   signal_out     float64 output, concatenated by out_offsets (host int64[n_reads+1], lengths must equal the slice
  *                  lengths); can be passed straight to wsx_call_batch with the same offsets
  *   shift_scale    optional float64[2*n_reads] (shift, scale per read), in `mem`

@@ -420,7 +420,8 @@ int wso_rescale_signal(const double *sig, long T, const double *value, const dou
     free(pr);
     free(x);
     if (rc != WSO_OK) return rc;
-    if (!(fp < (double)m)) return WSO_ERR_FIT_SMOOTH; /* would leave the ier=-2 branch: not restated */
+    /* fpcurf: fpms = fp - s; |fpms| < acc (= 0.001 s) or fpms < 0 keeps the polynomial (ier = -2) */
+    if (!(fp - (double)m < 0.001 * (double)m)) return WSO_ERR_FIT_SMOOTH; /* knots would be added: not restated */
     wso_eval_cubic(t, c, sig, T, out);
     if (tck_t) memcpy(tck_t, t, sizeof(t));
     if (tck_c) memcpy(tck_c, c, sizeof(c));
@@ -646,7 +647,15 @@ int wso_call_read(const wso_automaton *A, const wso_params *P, const double *sig
     R->n_trans2 = (int32_t)ntr;
 
     n2 = wso_create_alignment(A, P, trace2, resc, T, v2, e2, g2);
-    if ((rc = wso_rescale_signal(resc, T, v2, e2, g2, n2, resc2, NULL, NULL)) != WSO_OK) goto done;
+    /* caller.py:132-135: this second spline only feeds mask_bad_repeats, of which only the two indices are kept -- and those
+     * come from the state path alone.  If FITPACK leaves its polynomial branch HERE (possible with rescaling.threshold > 1)
+     * upstream goes on with a smoothing spline nobody looks at: not an error of the read. */
+    rc = wso_rescale_signal(resc, T, v2, e2, g2, n2, resc2, NULL, NULL);
+    if (rc == WSO_ERR_FIT_SMOOTH) {
+        memcpy(resc2, resc, sizeof(double) * (size_t)T);
+        rc = WSO_OK;
+    }
+    if (rc != WSO_OK) goto done;
     if (dbg && dbg->rescaled2) memcpy(dbg->rescaled2, resc2, sizeof(double) * (size_t)T);
     if ((rc = wso_mask_bad_repeats(A, P, resc2, T, trace2, &rstart, &rend, NULL)) != WSO_OK) goto done;
 

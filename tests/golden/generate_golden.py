@@ -46,6 +46,9 @@ ALT_CASES = [
     ('alt_m3_median', '(AGC)', 20, 21, 1500, 4, 201, (5, 30),
      dict(min_values_per_state=3, method='median', states_in_segment=5)),
     ('alt_repsasone', '(AGC)', 20, 22, 1500, 4, 202, (5, 30), dict(reps_as_one=True, max_std=0.6, threshold=0.4)),
+    # rescaling.threshold above 1 (src/config.py:97-100 allows any positive value): states up to 1.5 normalised units off
+    # their level enter the spline fit; FITPACK still stays on its polynomial branch (ier = -2) for these reads
+    ('alt_thr15', '(AGC)AACAGCCGCCAC(CGC)', 20, 23, 1700, 6, 203, (6, 20), dict(threshold=1.5, max_std=0.9)),
 ]
 
 

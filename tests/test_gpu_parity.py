@@ -134,7 +134,7 @@ def test_other_min_values_per_state():
                              oracle.Params(min_values_per_state=m, states_in_segment=sis, method=method))
 
 
-@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone'])
+@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone', 'alt_thr15'])
 def test_alternative_configs_match_golden(case):
     """Non-default settings recorded from the upstream caller: generic DP kernel (m = 3), median state values,
     5-state segments; reps_as_one with other thresholds."""
@@ -165,6 +165,30 @@ def test_alternative_configs_match_golden(case):
         assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
         assert_close_rel(res['cost1'][i], z[f'r{i}_cost'][0], COST_REL)
         assert_close_rel(res['cost2'][i], z[f'r{i}_cost'][1], COST_REL)
+
+
+def test_threshold_above_one_is_accepted_and_the_knot_branch_is_a_status():
+    """rescaling.threshold > 1 (src/config.py:97-100 allows it): the handle is created and reads are called exactly as the
+    oracle calls them (fixture alt_thr15: recorded from the upstream caller at threshold 1.5).  What would make FITPACK add
+    knots -- accepted states whose levels a cubic of their signal means cannot follow, residual >= 1.001 m -- does not
+    happen with pore-model levels (the DTW itself keeps means near levels), so the automaton here gets artificial levels
+    (+-amp, alternating) under a flat signal: those reads come back with the fit-smooth status, the same on both sides."""
+    import copy
+    pattern, fl = '(AGC)AACAGCCGCCAC(CGC)', 20
+    base = synth.make_locus(pattern, fl, 31)
+    rng = np.random.default_rng(1)
+    smooth = [k for k, v in oracle.STATUS.items() if v == 'fit_smooth'][0]
+    seen = set()
+    for amp in (1.2, 2.0, 3.0):
+        locus = copy.deepcopy(base)
+        for t in (locus.template, locus.reverse):
+            t.value = np.where(np.arange(t.n_states) % 2 == 0, amp, -amp).astype(np.float64)
+        sigs = [rng.normal(0.0, 0.05, size=1500 + 100 * i) for i in range(8)]
+        prm = oracle.Params(threshold=6.0, max_std=3.0)
+        _, res, _ = _compare_with_oracle(locus, fl, sigs, [bool(i & 1) for i in range(8)], None,
+                                         RescalerConfig(threshold=6.0, max_std=3.0), prm)
+        seen |= {int(x) for x in res['status']}
+    assert seen >= {0, smooth}
 
 
 def test_reps_as_one_matches_oracle():
@@ -385,12 +409,17 @@ def test_signal_loader_matches_reference_and_host():
     wide[[7, 300, 301, 1499]] = [6000, -2500, 6100, -2600]
     raws.append(wide)
     pos.append((0, 1499))
-    for mode in ('Brute', 'None'):
+    # a read of negative values only (the median filters pad with zeros: the padding brings a value the read does not have),
+    # reads shorter than the filter window
+    raws += [rng.normal(-300, 20, size=900).astype(np.int16), np.array([700], np.int16), np.array([400, 900], np.int16),
+             np.array([300, 800, 500, 100], np.int16)]
+    pos += [(0, 899), (0, 0), (0, 1), (0, 3)]
+    for mode in ('Brute', 'None', 'median3', 'median5'):  # (the median filters: scipy.signal.medfilt on the host side)
         out, ooff, ss = hip.prepare_signals(raws, pos, mode)
         for i, (raw, p) in enumerate(zip(raws, pos)):
             ref = process_raw(raw, p, mode)
             got = out[ooff[i]:ooff[i + 1]]
-            assert len(got) == len(ref) and np.array_equal(got, ref), (mode, i)
+            assert len(got) == len(ref) and np.array_equal(got, ref, equal_nan=True), (mode, i)  # (flat reads: 0/0 on both sides)
     out, ooff, _ = hip.prepare_signals([z['raw']], [(0, len(z['raw']) - 1)], 'Brute')
     assert np.array_equal(out, z['norm'])              # bit-identical to upstream normalize_signal_mad(brute_remove(raw))
     # device-resident raw reads: a 16-byte aligned buffer takes the eight-samples-per-load passes, a buffer that starts
@@ -421,7 +450,7 @@ def test_signal_loader_matches_reference_and_host():
                                                _lib.ptr(lo), _lib.ptr(hi), n, 1, d_out, _lib.ptr(want_off), None), 'wsx_prepare_signals')
         got = np.zeros_like(want)
         assert rt.hipMemcpy(_lib.ptr(got), d_out, want.nbytes, 2) == 0                                   # device -> host
-        assert np.array_equal(got, want), shift
+        assert np.array_equal(got, want, equal_nan=True), shift  # (the flat reads: 0/0)
     rt.hipFree(d_raw)
     rt.hipFree(d_out)
 

@@ -83,6 +83,33 @@ def test_fitpack_cubic_bitwise():
             assert np.array_equal(oracle.eval_cubic(t, c, q), interpolate.splev(q, tck))
 
 
+def test_fitpack_leaves_the_polynomial_branch_exactly_where_the_oracle_says():
+    """rescaling.threshold > 1 (accepted since round 3): curfit keeps the least-squares cubic (ier = -2) while its residual fp
+    stays below s + 0.001 s (fpcurf: |fp - s| < acc or fp < s, acc = tol * s, tol = 0.001) and adds knots beyond -- the one
+    case the caller answers with a per-read status (fit-smooth) instead of a spline.  Pinned against SciPy here: fp itself
+    bit for bit, and the branch on both sides of the boundary, including the band s <= fp < 1.001 s."""
+    from scipy import interpolate
+    rng = np.random.default_rng(11)
+    seen = set()
+    for m in (12, 60, 250):
+        x = np.sort(rng.normal(size=m))
+        noise = rng.normal(size=m)
+        for target in (0.5, 0.98, 1.0003, 1.0008, 1.0012, 1.01, 1.5, 3.0):
+            # scale the noise so that the residual of the fitted cubic is target * m (the fit is linear in y: residuals scale)
+            _, _, fp1 = oracle.fit_cubic(x, x + noise)
+            y = x + noise * np.sqrt(target * m / fp1)
+            (t_ref, c_ref, _), fp_ref, ier, _ = interpolate.splrep(x, y, s=m, full_output=1)
+            t, c, fp = oracle.fit_cubic(x, y)
+            keeps = fp - m < 0.001 * m
+            seen.add((keeps, fp >= m))
+            assert keeps == (ier == -2), (m, target, fp, ier)
+            if keeps:
+                assert fp == fp_ref and np.array_equal(t, t_ref) and np.array_equal(c, c_ref[:4])
+            else:
+                assert len(t_ref) > 8 and ier in (0, 1)
+    assert seen == {(True, False), (True, True), (False, True)}  # below s, inside the band, beyond it
+
+
 def test_segment_against_python_loop():
     # an independent, direct transcription of the published sliding t-test on tiny inputs
     from math import sqrt
@@ -138,7 +165,7 @@ def test_short_read_is_a_status_not_a_crash():
     assert oracle.STATUS[r.status] == 'shape'
 
 
-@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone'])
+@pytest.mark.parametrize('case', ['alt_m3_median', 'alt_repsasone', 'alt_thr15'])
 def test_alternative_configs(case):
     """Non-default tr_calling_config / rescaling settings (min_values_per_state=3 + median + 5-state segments;
     reps_as_one with other thresholds): the oracle follows the reference there too."""

@@ -169,6 +169,10 @@ def _seam():
     return _SEAM
 
 
+# caller_config.spike_removal (src/config.py, remove_spikes src/schemas/fast5.py:68-75) -> wsx_prepare_signals' code
+SPIKE_REMOVAL = {'None': 0, 'Brute': 1, 'median3': 2, 'median5': 3}
+
+
 class HipCaller:
     """One handle on one GPU holding the automata of one or more loci (include/warpstr_hip.h)."""
 
@@ -344,8 +348,7 @@ class HipCaller:
     def prepare_signals(self, raws: Sequence[np.ndarray], positions: Sequence[Sequence[int]], spike_removal: str = 'Brute'):
         """wsx_prepare_signals on host buffers: raw int16 reads + (l_start_raw, r_end_raw) ->
         (normalised float64 buffer, offsets) ready for call(); also returns the (shift, scale) table."""
-        if spike_removal not in ('None', 'Brute'):
-            raise ValueError('only spike_removal None / Brute run on the GPU (median3/median5: warpstr_amd.signal_prep)')
+        spike_code = SPIKE_REMOVAL[spike_removal]
         n = len(raws)
         lens = np.fromiter((len(r) for r in raws), dtype=np.int64, count=n)
         roff = np.zeros(n + 1, np.int64)
@@ -361,7 +364,7 @@ class HipCaller:
         out = np.empty(int(ooff[-1]), np.float64)
         ss = np.zeros((n, 2), np.float64)
         _lib.check(self.lib.wsx_prepare_signals(self.handle, _lib.WSX_MEM_HOST, _lib.ptr(raw), _lib.ptr(roff), _lib.ptr(lo),
-                                                _lib.ptr(hi), n, 1 if spike_removal == 'Brute' else 0, _lib.ptr(out),
+                                                _lib.ptr(hi), n, spike_code, _lib.ptr(out),
                                                 _lib.ptr(ooff), _lib.ptr(ss)), 'wsx_prepare_signals')
         return out, ooff, ss
 
@@ -376,7 +379,7 @@ class HipCaller:
         out_offsets = np.ascontiguousarray(out_offsets, np.int64)
         _lib.check(self.lib.wsx_prepare_signals(self.handle, _lib.WSX_MEM_DEVICE, C.c_void_p(raw_ptr), _lib.ptr(raw_offsets),
                                                 _lib.ptr(seg_start), _lib.ptr(seg_end), len(seg_start),
-                                                1 if spike_removal == 'Brute' else 0, C.c_void_p(out_ptr), _lib.ptr(out_offsets),
+                                                SPIKE_REMOVAL[spike_removal], C.c_void_p(out_ptr), _lib.ptr(out_offsets),
                                                 C.c_void_p(shift_scale_ptr or None)), 'wsx_prepare_signals')
 
     def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
@@ -522,8 +525,8 @@ class CallerWrapper:
         [l_start_raw, r_end_raw] (Fast5.get_data_processed, src/schemas/fast5.py:45-57) happen on the GPU."""
         if not names:
             return []
-        if spike_removal not in ('None', 'Brute'):
-            raise ValueError('only spike_removal None / Brute run on the GPU (median3/median5: warpstr_amd.signal_prep)')
+        if spike_removal not in SPIKE_REMOVAL:
+            raise ValueError(f'spike_removal must be one of {sorted(SPIKE_REMOVAL)}')
         # The reads cross PCIe once, as int16 (2 bytes per sample of the WHOLE read go up, the records and the called
         # sequences come down); the normalised float64 segments are produced and consumed in HBM.  torch is the device
         # allocator here (pinned staging buffer, HBM buffers), nothing else.

@@ -1081,7 +1081,11 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
         yi_in = quad_f64<kQuadFromLeft>(yi);
     }
     fp = quad_f64<WSX_QUAD_BCAST(3)>(fp);
-    if (!(fp < (double)m)) {
+    // fpcurf's test after the first least-squares fit (s = m, acc = tol * s, tol = 0.001): |fp - s| < acc or fp < s keeps the
+    // polynomial (ier = -2); anything else adds knots and smooths -- not restated: the read gets a status.  With
+    // rescaling.threshold <= 1 this cannot happen (the line y = x alone has residual <= m * threshold^2); above 1 it takes
+    // accepted states that are, on average, further than one normalised unit from their level.
+    if (!(fp - (double)m < 0.001 * (double)m)) {
         if (j == 0) a.status[lr] = WSX_READ_FIT_SMOOTH;
         return;
     }

@@ -403,10 +403,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         g_err = "wsx_caller_create: invalid parameters (src/config.py:91-119 asserts)";
         return WSX_ERR_INVALID;
     }
-    if (params->threshold > 1.0) {
-        g_err = "rescaling.threshold > 1 may leave FITPACK's polynomial branch; not implemented";
-        return WSX_ERR_UNSUPPORTED;
-    }
+    // (rescaling.threshold > 1 is accepted, as upstream accepts it, src/config.py:97-100: a read whose first least-squares fit
+    // leaves FITPACK's polynomial branch -- possible only then -- comes back with WSX_READ_FIT_SMOOTH)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_err = "no HIP device available";

@@ -145,6 +145,50 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
     }
 }
 
+// spike_removal median3 / median5 (remove_spikes, src/schemas/fast5.py:68-75): scipy.signal.medfilt of the raw integer read
+// with a window of W samples -- the middle order statistic of the window, the read padded with ZEROS beyond both ends --
+// instead of copy_kernel: raw -> filtered working copy, and the smallest / largest FILTERED value (the padding can bring a
+// zero into a read that has none).  A thread per sample; the W loads of neighbouring lanes overlap in L1.
+__device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
+template <int W>
+__global__ __launch_bounds__(256) void medfilt_kernel(PrepArgs a)
+{
+    static_assert(W == 3 || W == 5, "median3 / median5");
+    const int r = blockIdx.x;
+    if (a.done[r]) return;
+    const long long len = a.roff[r + 1] - a.roff[r];
+    const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
+    const int16_t *src = a.raw + a.roff[r];
+    int lo = 32767, hi = -32768;
+    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
+        int v[W];
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+            const long long q = i - W / 2 + e;
+            v[e] = (q >= 0 && q < len) ? (int)src[q] : 0;
+        }
+        int m;
+        if constexpr (W == 3) {
+            m = med3(v[0], v[1], v[2]);
+        } else { // median of five: drop the smaller of the two pair minima and the larger of the two pair maxima
+            const int a0 = min(v[0], v[1]), a1 = max(v[0], v[1]), b0 = min(v[2], v[3]), b1 = max(v[2], v[3]);
+            m = med3(max(a0, b0), min(a1, b1), v[4]);
+        }
+        a.clean[a.roff[r] + i] = (int16_t)m;
+        lo = min(lo, m);
+        hi = max(hi, m);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        lo = min(lo, __shfl_xor(lo, s));
+        hi = max(hi, __shfl_xor(hi, s));
+    }
+    if ((threadIdx.x & 63) == 0 && c0 < c1) {
+        atomicMin(&a.mm[2 * r], lo);
+        atomicMax(&a.mm[2 * r + 1], hi);
+    }
+}
+
 // zeroes the occupied range of every read's histogram
 __global__ __launch_bounds__(256) void zero_kernel(PrepArgs a)
 {
@@ -613,9 +657,9 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
         wsx_internal_set_error("wsx_prepare_signals: null argument");
         return WSX_ERR_INVALID;
     }
-    if (spike_removal != 0 && spike_removal != 1) {
-        wsx_internal_set_error("spike_removal: only None (0) and Brute (1) run on the GPU; median3/median5 are host-side");
-        return WSX_ERR_UNSUPPORTED;
+    if (spike_removal < 0 || spike_removal > 3) {
+        wsx_internal_set_error("spike_removal: 0 = None, 1 = Brute, 2 = median3, 3 = median5 (src/schemas/fast5.py:68-75)");
+        return WSX_ERR_INVALID;
     }
     if (mem != WSX_MEM_HOST && mem != WSX_MEM_DEVICE) {
         wsx_internal_set_error("mem must be WSX_MEM_HOST or WSX_MEM_DEVICE");
@@ -729,13 +773,15 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
             for (int64_t r = 0; r < cnt; r++) min_len = std::min(min_len, h_roff[r + 1] - h_roff[r]);
             const int cap = (int)std::min<int64_t>(((std::min<int64_t>(max_len, 8192) + 63) / 64) * 64, 8192);
             const size_t lds = (size_t)cap * 2 + (size_t)cap / 8 + 8 + PREP_SHORT_BINS * 4;
-            if (min_len <= cap && !getenv("WSX_PREP_GENERAL")) {
+            if (min_len <= cap && spike_removal <= 1 && !getenv("WSX_PREP_GENERAL")) {
                 hipLaunchKernelGGL(short_read_kernel, dim3((unsigned)cnt), dim3(64), lds, st, a, cap);
             } else {
                 PCHK(hipMemsetAsync(d_done, 0, (size_t)cnt, st)); // no read of this chunk is short
             }
         }
-        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        if (spike_removal == 2) hipLaunchKernelGGL(medfilt_kernel<3>, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        else if (spike_removal == 3) hipLaunchKernelGGL(medfilt_kernel<5>, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
         hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, max_len <= 8192 ? 1 : 8), dim3(256), 0, st, a);
         if (spike_removal == 1) {
             if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3((unsigned)cnt), dim3(256), 0, st, a);

@@ -20,7 +20,7 @@ FAST5_SUBDIR, ANNOT_SUBDIR = 'fast5', 'annot'
 
 
 def _fast5_loader(spike_removal: str) -> Callable[[str, int, int], np.ndarray]:
-    """Host-side loader (used for the median3/median5 spike filters, which have no GPU kernel)."""
+    """Host-side loader (the restatement of Fast5.get_data_processed in signal_prep; main_wrapper prepares on the GPU)."""
     def load(path: str, l_start_raw: int, r_end_raw: int) -> np.ndarray:
         return process_raw(read_raw_signal(path), (l_start_raw, r_end_raw), spike_removal)
     return load
@@ -88,7 +88,7 @@ def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
         return _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal_loader, rank, world)
     overview_path, df_overview = ov.load_overview(locus.path)
     cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device)
-    if signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
+    if signal_loader is None:
         # default: int16 reads straight from the .fast5 files, prepared on the GPU
         names, reverses, raws, positions = get_raw_workload(df_overview, locus.path)
         results = cw.run_raw(names, reverses, raws, positions, caller_config.spike_removal)
@@ -149,7 +149,7 @@ def _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal
     if len(part) == 0:
         local = CallerResults([], np.zeros(0, dtype=_RESULT_DTYPE()), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.uint8),
                               'nan')
-    elif signal_loader is None and caller_config.spike_removal in ('None', 'Brute'):
+    elif signal_loader is None:
         names, revs, raws, positions = get_raw_workload(part, locus.path)
         local = cw.run_raw(names, revs, raws, positions, caller_config.spike_removal)
     else:
