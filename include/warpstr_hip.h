@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 7
+#define WSX_ABI_VERSION 8
 
 /* function return codes */
 enum {
@@ -273,6 +273,11 @@ typedef struct wsx_flank_hit {
     int32_t gaps_pattern; /* '-' in the aligned pattern inside the local region (nums_gaps2) */
     int32_t raw_score;    /* the alignment's own score */
     int32_t n_ops;        /* length of the local region */
+    /* How much of this hit rests on a tie rule (upstream takes pairwise2's first alignment; Biopython's order among equally
+     * good alignments is not restated): both 0 = the optimal local alignment is UNIQUE, and every correct Smith-Waterman --
+     * pairwise2 included -- returns exactly this one. */
+    int32_t n_best_cells; /* cells of the whole matrix that reach the best score (1 = the end of the alignment is unique) */
+    int32_t tie_steps;    /* steps of the traceback where more than one predecessor reproduces the cell's score */
 } wsx_flank_hit;
 
 /*

@@ -19,7 +19,7 @@ class _Scores(C.Structure):
 
 class _Hit(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('status', 'score', 'start', 'end', 'matches', 'span', 'row0', 'col0', 'row1', 'col1',
-                                         'gaps_text', 'gaps_pattern', 'raw_score', 'n_ops')]
+                                         'gaps_text', 'gaps_pattern', 'raw_score', 'n_ops', 'n_best_cells', 'tie_steps')]
 
 
 HIT_FIELDS = [n for n, _ in _Hit._fields_]
@@ -54,6 +54,8 @@ class Hit:
     gaps_pattern: int
     raw_score: int
     n_ops: int
+    n_best_cells: int
+    tie_steps: int
     ops: bytes
 
 

@@ -44,6 +44,8 @@ typedef struct {
     int32_t gaps_pattern; /* '-' in the aligned pattern inside the local region (nums_gaps2) */
     int32_t raw_score;  /* the alignment's own score */
     int32_t n_ops;      /* operations of the local region */
+    int32_t n_best_cells; /* cells of the full matrix that reach the best score */
+    int32_t tie_steps;    /* traceback steps with more than one predecessor reproducing the score */
 } flo_hit;
 
 int32_t flo_window_rows(int32_t p, const flo_scores *sc) { return p + (sc->match * p) / (-sc->gap_open) + 2; }
@@ -62,7 +64,7 @@ int flo_find_sequence(const uint8_t *text, int32_t n, const uint8_t *pat, int32_
     const int32_t g = sc->gap_open;
     /* ---- stage 1: best cell of the full matrix (two rolling rows) ---- */
     int32_t *prev = (int32_t *)calloc((size_t)p + 1, sizeof(int32_t)), *cur = (int32_t *)calloc((size_t)p + 1, sizeof(int32_t));
-    int32_t best = 0, bi = 0, bj = 0;
+    int32_t best = 0, bi = 0, bj = 0, nbest = 0;
     for (int32_t i = 1; i <= n; i++) {
         cur[0] = 0;
         for (int32_t j = 1; j <= p; j++) {
@@ -72,6 +74,7 @@ int flo_find_sequence(const uint8_t *text, int32_t n, const uint8_t *pat, int32_
             if (h < 0) h = 0;
             cur[j] = h;
             if (h >= best && h > 0) { /* later cells win ties: largest i, then largest j */
+                nbest = h > best ? 1 : nbest + 1;
                 best = h;
                 bi = i;
                 bj = j;
@@ -101,10 +104,13 @@ int flo_find_sequence(const uint8_t *text, int32_t n, const uint8_t *pat, int32_
             if (h < 0) h = 0;
             HW(i, j) = h;
         }
-    int32_t i = bi, j = bj, nops = 0, g1 = 0, g2 = 0;
+    int32_t i = bi, j = bj, nops = 0, g1 = 0, g2 = 0, ties = 0;
     while (i > i0 && j > 0 && HW(i, j) > 0) {
         const int32_t h = HW(i, j);
         uint8_t op;
+        if ((h == HW(i - 1, j - 1) + (text[i - 1] == pat[j - 1] ? sc->match : sc->mismatch)) + (h == HW(i - 1, j) + g) +
+                (h == HW(i, j - 1) + g) > 1)
+            ties++;
         if (h == HW(i - 1, j - 1) + (text[i - 1] == pat[j - 1] ? sc->match : sc->mismatch)) {
             op = 'M';
             i--;
@@ -136,6 +142,8 @@ int flo_find_sequence(const uint8_t *text, int32_t n, const uint8_t *pat, int32_
     hit->gaps_pattern = g2;
     hit->raw_score = best;
     hit->n_ops = nops;
+    hit->n_best_cells = nbest;
+    hit->tie_steps = ties;
     /* ---- find_sequence's arithmetic on the aligned strings (tr_extractor.py:226-250) ----
      * aligned strings: lead = |row0 - col0| gap characters in front of the shorter unaligned prefix, then the prefixes,
      * the local region, the unaligned suffixes, and gap characters after the shorter suffix. */

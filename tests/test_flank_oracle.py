@@ -138,3 +138,44 @@ def test_extract_from_moves_matches_reference_statement():
         d1, d2 = np.where(mr == ps)[0], np.where(mr == pe)[0]
         want = (100 + d1[0] * 5 if len(d1) else -1, 100 + d2[-1] * 5 if len(d2) else -1)
         assert flank.extract_from_moves(m, ps, pe, 100, 5) == want
+
+
+def test_unique_optimum_is_pinned_and_ties_are_counted():
+    """Bounding what the absent Biopython leaves unpinned: an independent NumPy Smith-Waterman (tests/sw_enumerate.py, no tie
+    rule) enumerates every best end cell and every co-optimal traceback.  (i) Where the optimal alignment is unique, the
+    oracle's hit equals the arithmetic of find_sequence on that one alignment, field for field -- tie rules cannot matter
+    there, so this IS what pairwise2 returns; (ii) the hit says how much rests on a tie rule: n_best_cells = the number of
+    best end cells, tie_steps = 0 exactly when the traceback from the chosen end cell is the only one."""
+    from tests.sw_enumerate import hit_from_alignment, optimal_alignments
+    rng = np.random.default_rng(77)
+    unique = tied = 0
+    cases = []
+    for _ in range(120):                                    # short flanks in short texts: ties are common
+        n, p = int(rng.integers(30, 300)), int(rng.integers(5, 40))
+        cases.append(random_case(rng, n, p, float(rng.choice([0.0, 0.1, 0.25])), edge=rng.choice([None, 'head', 'tail'])))
+    for _ in range(10):                                     # the shape upstream runs: 110-base flanks, thousands of bases
+        n = int(rng.integers(2500, 5000))
+        cases.append(random_case(rng, n, 110, float(rng.choice([0.08, 0.12]))))
+    cases += [('ACGT' * 30, 'ACGTACGT'), ('ACACACACACAC', 'ACACGG'), ('TTTTTTTTTT', 'TTT')]  # periodic: many best cells
+    for text, pat in cases:
+        if not pat:
+            continue
+        best, ends, als = optimal_alignments(text, pat)
+        h = flank.find_sequence(text.encode(), pat.encode())
+        if best == 0:
+            assert h.status == 1
+            continue
+        assert h.status == 0 and h.raw_score == best and h.n_best_cells == len(ends)
+        assert (h.row1, h.col1) == max(ends)                # the documented rule: largest text index, then pattern index
+        from_chosen_end = [a for a in als if (a[2], a[3]) == (h.row1, h.col1)]
+        assert (h.tie_steps == 0) == (len(from_chosen_end) == 1)
+        if len(als) < 64:                                    # (the enumeration stops spelling alignments out at 64)
+            assert any(a[4].encode() == h.ops for a in from_chosen_end)  # the oracle's alignment is one of the optimal ones
+        if len(ends) == 1 and len(als) == 1:
+            unique += 1
+            want = hit_from_alignment(text, pat, *als[0][:4], als[0][4], best)
+            assert {k: getattr(h, k) for k in want} == want
+            assert (h.n_best_cells, h.tie_steps) == (1, 0)
+        else:
+            tied += 1
+    assert unique >= 40 and tied >= 10

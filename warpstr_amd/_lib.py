@@ -50,8 +50,9 @@ class WsxAlignScores(C.Structure):
 
 # numpy view of wsx_flank_hit
 FLANK_HIT_DTYPE = np.dtype([(n, np.int32) for n in ('status', 'score', 'start', 'end', 'matches', 'span', 'row0', 'col0', 'row1',
-                                                    'col1', 'gaps_text', 'gaps_pattern', 'raw_score', 'n_ops')])
-assert FLANK_HIT_DTYPE.itemsize == 56
+                                                    'col1', 'gaps_text', 'gaps_pattern', 'raw_score', 'n_ops', 'n_best_cells',
+                                                    'tie_steps')])
+assert FLANK_HIT_DTYPE.itemsize == 64
 
 
 class HipLibraryMissing(RuntimeError):

@@ -56,7 +56,7 @@ struct FlankArgs {
     int32_t n;
     int32_t match, mismatch, gap;
     // stage 1 -> stage 2
-    int32_t *best;           // [n][3]: score, i, j
+    int32_t *best;           // [n][4]: score, i, j, number of cells that reach the score
     wsx_flank_hit *hits;     // [n]
     uint8_t *ops;            // [n][ops_stride], ops_stride >= 2 * max pattern length + 8
     int32_t ops_stride;
@@ -82,6 +82,8 @@ __device__ __forceinline__ void sweep_cell(const int (&pc)[CPL], int (&up)[CPL],
         if (TRACE) { // diagonal first, then up (text base against a gap), then left; 3 = stop (score 0)
             const uint32_t d = h == 0 ? 3u : (h == hd ? 0u : (h == hu ? 1u : 2u));
             dirs |= d << (2 * c);
+            // bit 8 + c: more than one predecessor reproduces the score (wsx_flank_hit::tie_steps counts them on the path)
+            if (h != 0 && (int)(h == hd) + (int)(h == hu) + (int)(h == hl) > 1) dirs |= 0x100u << c;
         }
         diag = up[c];
         up[c] = h;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void flank_score_kernel(FlankArgs a)
     int vmatch = a.match, vmismatch = a.mismatch; // kept in vector registers: v_cndmask cannot take two scalar operands
     asm volatile("" : "+v"(vmatch), "+v"(vmismatch));
     int best = 0, bi = 0, bj = 0; // this lane's latest cell that reached the wave's best score
+    int nbest = 0;                // cells of this lane that reached `best`
     int wbest = 1;                // best score of the whole wave so far (uniform), at least 1: zeros never count
     int diag_in = 0, hlast = 0;
     // Eight steps of the sweep: steps t0 .. t0+7, this lane on text rows t0 - lane .. t0 - lane + 7, whose bases arrive
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256) void flank_score_kernel(FlankArgs a)
                 for (int c = 0; c < CPL; c++) {
                     const int j = lane * CPL + c + 1;
                     if (valid && j <= p && h[c] > 0 && h[c] >= wbest && h[c] >= best) { // later cells win ties within a lane
+                        nbest = h[c] > best ? 1 : nbest + 1;
                         best = h[c];
                         bi = i;
                         bj = j;
@@ -175,17 +179,24 @@ __global__ __launch_bounds__(256) void flank_score_kernel(FlankArgs a)
         const unsigned long long o = __shfl_xor(key, s);
         key = o > key ? o : key;
     }
+    // how many cells reach the best score (the lanes whose own best is the wave's)
+    int cells = best == (int)(key >> 48) ? nbest : 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) cells += __shfl_xor(cells, s);
     if (lane == 0) {
-        a.best[3 * w + 0] = (int)(key >> 48);
-        a.best[3 * w + 1] = (int)((key >> 16) & 0xffffffffull);
-        a.best[3 * w + 2] = (int)(key & 0xffffull);
+        a.best[4 * w + 3] = cells;
+        a.best[4 * w + 0] = (int)(key >> 48);
+        a.best[4 * w + 1] = (int)((key >> 16) & 0xffffffffull);
+        a.best[4 * w + 2] = (int)(key & 0xffffull);
     }
 }
 
 template <int CPL>
 __global__ __launch_bounds__(64) void flank_trace_kernel(FlankArgs a, int max_rows)
 {
-    extern __shared__ uint8_t dirs_lds[]; // [rows + 1][64]: byte of lane L on window row r = directions of its CPL cells
+    extern __shared__ uint8_t dirs_lds[]; // [rows + 1][64]: byte of lane L on window row r = directions of its CPL cells;
+                                          // then [rows + 1][64] again: bit c = cell c of the lane has tied predecessors
+    uint8_t *tie_lds = dirs_lds + (size_t)(max_rows + 1) * 64;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x;
     if (w >= a.n) return;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(64) void flank_trace_kernel(FlankArgs a, int max_ro
     const int n = (int)(a.text_off[w + 1] - to), p = (int)(a.pat_off[w + 1] - po);
     const uint8_t *text = a.text + to, *pat = a.pat + po;
     wsx_flank_hit *hit = a.hits + w;
-    const int best = a.best[3 * w], bi = a.best[3 * w + 1], bj = a.best[3 * w + 2];
+    const int best = a.best[4 * w], bi = a.best[4 * w + 1], bj = a.best[4 * w + 2];
     if (best <= 0) {
         if (lane == 0) {
             wsx_flank_hit z{};
@@ -221,19 +232,22 @@ __global__ __launch_bounds__(64) void flank_trace_kernel(FlankArgs a, int max_ro
         const int in = from_left_lane(hlast);
         uint32_t dirs;
         sweep_cell<CPL, true>(pc, up, diag_in, in, tc, valid, a.match, a.mismatch, a.gap, h, dirs);
-        if (valid) dirs_lds[r * 64 + lane] = (uint8_t)dirs;
+        if (valid) {
+            dirs_lds[r * 64 + lane] = (uint8_t)dirs;
+            tie_lds[r * 64 + lane] = (uint8_t)(dirs >> 8);
+        }
         hlast = h[CPL - 1];
     }
     __syncthreads();
     if (lane != 0) return;
     // ---- walk back from (bi, bj) ----
-    (void)max_rows;
-    int i = bi, j = bj, nops = 0, g1 = 0, g2 = 0;
+    int i = bi, j = bj, nops = 0, g1 = 0, g2 = 0, ties = 0;
     uint8_t *ops = a.ops + (size_t)w * a.ops_stride; // always present (the caller's buffer or a temporary), >= 2p + 8 bytes
     while (i > i0 && j > 0) {
         const int col = j - 1;
         const uint32_t d = (dirs_lds[(i - i0) * 64 + col / CPL] >> (2 * (col % CPL))) & 3u;
         if (d == 3u) break;
+        ties += (tie_lds[(i - i0) * 64 + col / CPL] >> (col % CPL)) & 1;
         uint8_t op;
         if (d == 0u) {
             op = 'M';
@@ -302,6 +316,8 @@ __global__ __launch_bounds__(64) void flank_trace_kernel(FlankArgs a, int max_ro
     out.gaps_pattern = g2;
     out.raw_score = best;
     out.n_ops = nops;
+    out.n_best_cells = a.best[4 * w + 3];
+    out.tie_steps = ties;
     *hit = out;
 }
 
@@ -450,7 +466,7 @@ int wsx_locate_flanks(int device, void *stream, int mem, const uint8_t *text, co
     }
     const int32_t stride = ops ? ops_stride : need_stride;
     if (host || !ops) FCHK(tmp.alloc((void **)&d_ops, (size_t)n * stride)); // identity needs the operations either way
-    FCHK(tmp.alloc((void **)&a.best, n * 3 * sizeof(int32_t)));
+    FCHK(tmp.alloc((void **)&a.best, n * 4 * sizeof(int32_t)));
     a.text = d_text;
     a.text_off = d_toff;
     a.pat = d_pat;
@@ -464,7 +480,7 @@ int wsx_locate_flanks(int device, void *stream, int mem, const uint8_t *text, co
     a.ops_stride = stride;
     const int cpl = max_p <= 64 ? 1 : (max_p <= 128 ? 2 : 4);
     const int max_rows = max_p + (scores->match * max_p) / (-scores->gap_open) + 2;
-    const size_t lds = (size_t)(max_rows + 1) * 64;
+    const size_t lds = (size_t)(max_rows + 1) * 64 * 2; // directions + tie bits
     const dim3 g1((unsigned)((n + 3) / 4)), g2((unsigned)n);
     switch (cpl) {
     case 1:
