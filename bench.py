@@ -578,6 +578,8 @@ def main():
             'valu': {'dp_cells_per_s': cells_per_s},
             # first enqueue to last finish of the timed region on the device clock (HIP events), per step
             'device_ms_per_step': tm['total_ms'] / args.steps,
+            # device memory the handle holds for this workload (all work sets of all streams), and per sample of a call
+            'workspace': hip.workspace(),
         }
         if not args.no_verify:
             nv = min(n, 4096 if not args.no_cpu_baseline else 256)

@@ -67,7 +67,9 @@ def test_call_matches_golden(case):
         assert res['status'][i] == 0
         assert np.array_equal(ex['trace1'][sl], z[f'r{i}_trace1'])
         assert np.array_equal(ex['badmask'][sl], z[f'r{i}_badmask'])
-        np.testing.assert_allclose(ex['rescaled'][sl], z[f'r{i}_rescaled'], rtol=1e-12, atol=1e-13)
+        # the rescaled signal bit for bit: FITPACK's Givens fit and de Boor evaluation restated operation for operation,
+        # device fp64 division and square root correctly rounded
+        assert np.array_equal(ex['rescaled'][sl], z[f'r{i}_rescaled'])
         assert np.array_equal(ex['trace2'][sl], z[f'r{i}_trace2'])
         seq, rseq = [str(s) for s in z[f'r{i}_seq']]
         assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
@@ -110,7 +112,7 @@ def _compare_with_oracle(locus, fl, sigs, revs, caller_config=None, rescaler_con
 
 
 @pytest.mark.parametrize('pattern,fl,T,n', [
-    ('(AGC)', 16, 1500, 48),                       # config 2 shape: K=1
+    ('(AGC)', 16, 1500, 1000),                     # BASELINE configs[1] at its size: 1 k reads x 1.5 kSample, ~35 states
     ('(AGC)AACAGCCGCCAC(CGC)', 19, 2000, 32),      # config 3 shape: S ~ 63
     ('((CAGG){CAGM})(CAGA)(CA)', 40, (500, 5000), 24),  # config 5 shape: S ~ 128, fan-in 3, ragged
     ('(AAAT)', 110, (2271, 3701), 10),             # config 1 shape (test_caller_only segment lengths), K=4

@@ -18,7 +18,7 @@ READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_ord
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
            'wsx_caller_set_workspace_limit', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
-           'wsx_caller_last_timing', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
+           'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
 
 
 class WsxAutomaton(C.Structure):
@@ -125,6 +125,7 @@ def load():
     lib.wsx_caller_set_pipelined.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_caller_join.argtypes = [C.c_void_p, C.c_void_p]
     lib.wsx_caller_timing_window.argtypes = [C.c_void_p, C.c_int32]
+    lib.wsx_caller_workspace.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     lib.wsx_call_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]
     lib.wsx_call_batch_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

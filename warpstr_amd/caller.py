@@ -420,6 +420,12 @@ class HipCaller:
                    'wsx_caller_last_timing')
         return dict(dp_kernel_ms=dp.value, dp_launches=nl.value, total_ms=tot.value)
 
+    def workspace(self):
+        """Device memory held by the handle, and per sample of the most recent call (wsx_caller_workspace)."""
+        total, per = C.c_uint64(), C.c_double()
+        _lib.check(self.lib.wsx_caller_workspace(self.handle, C.byref(total), C.byref(per)), 'wsx_caller_workspace')
+        return dict(bytes_allocated=int(total.value), bytes_per_sample=per.value)
+
     def fill_intervals(self):
         """(begin_ms, end_ms, reads) of every fill launch behind last_timing(), relative to the start of the timed region."""
         n = C.c_int32()

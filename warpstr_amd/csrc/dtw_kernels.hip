@@ -137,11 +137,7 @@ __device__ __forceinline__ uint64_t lt_mask(double cand, double best)
 template <int BYTE_OFF>
 __device__ __forceinline__ void store_mask(uint64_t m, uint64_t *base)
 {
-#ifdef WSX_EXP_NO_MASK_STORES // timing experiment only (results are garbage): what do the scalar stores cost?  Nothing.
-    asm volatile("" ::"s"(m), "s"(base));
-#else
     asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(base), "n"(BYTE_OFF) : "memory");
-#endif
 }
 
 template <int BYTE_OFF> // two masks, 16-byte aligned destination
@@ -149,11 +145,7 @@ __device__ __forceinline__ void store_mask_pair(uint64_t m0, uint64_t m1, uint64
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)};
-#ifdef WSX_EXP_NO_MASK_STORES
-    asm volatile("" ::"s"(v), "s"(base));
-#else
     asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(base), "n"(BYTE_OFF) : "memory");
-#endif
 }
 
 // the NM masks of group row R, at base + R*NM (base = the group's first row); pairs go out as one 16-byte store when
@@ -219,9 +211,6 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
             if (PAR) st.e0[k][f] = e;
             else st.e1[k][f] = e;
         }
-#ifdef WSX_PIN_READS // experiment: keep these reads at the top of the row for K >= WSX_PIN_READS (no gain: DESIGN 4b)
-    if constexpr (K >= WSX_PIN_READS) __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int kk = 0; kk < K; kk++) {
         const int k = LM != 0 ? K - 1 - kk : kk;
@@ -268,25 +257,14 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
     }
 }
 
-// Occupancy knob (experiment builds, -DWSX_FILL_FORCE_WAVES): wavefronts per SIMD the register allocator has to make room
-// for (512 VGPRs per SIMD lane: 5 waves = 96 registers each, 4 = 128, 3 = 168).  Left alone the compiler takes 116 registers
-// for two slots and 168 for four (4 and 3 waves per SIMD).  Forcing 5 and 4 waves keeps the instruction counts of the 8-row
-// blocks and spills 0-190 bytes per lane around them -- and was measured slower: two slots 2.44 vs 2.47 ms per launch (no
-// gain), four slots 6.0 vs 5.4 ms (profiles/r02_occupancy_forcing.log).  Not the lever; default off.
-__host__ __device__ constexpr int fill_min_waves(int K, int FL) { return (K <= 1 || FL != 1) ? 1 : K == 2 ? 5 : K <= 4 ? 4 : 3; }
-#ifdef WSX_FILL_FORCE_WAVES
-#define WSX_FILL_OCC(K, FL, LM) __attribute__((amdgpu_waves_per_eu(fill_min_waves(K, FL))))
-#elif defined(WSX_LM_WAVES) // experiment builds: register budget of the lane-major variants
-#define WSX_FILL_OCC(K, FL, LM) __attribute__((amdgpu_waves_per_eu((LM) != 0 ? WSX_LM_WAVES : 1)))
-#else
-#define WSX_FILL_OCC(K, FL, LM)
-#endif
-
+// (Register budgets: left to the compiler.  Forcing more waves per SIMD was measured slower every time -- two slots at 96
+// registers no gain, four slots at 128 registers 6.0 vs 5.4 ms per launch, the lane-major four-slot kernel at 128 / 96 / 80
+// registers 11.6 / 20.7 / 30.0 vs 10.35 ms per step: profiles/r02_occupancy_forcing.log, scripts/exp_round3_knobs.patch.)
 template <int M, int K, int F, int FL, bool PK, int LM = 0>
 #ifndef WSX_FILL_WPB
 #define WSX_FILL_WPB 4 // wavefronts (= reads) per workgroup
 #endif
-__global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw_fill_fast(PassArgs a)
+__global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
 {
     static_assert(FL >= 1 && FL <= F, "slots 1.. consider FL <= F predecessors");
     static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
@@ -302,11 +280,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) WSX_FILL_OCC(K, FL, LM) void dtw
     if (slot >= a.n_launch) return;
     // the fill is the resource everything else waits for: its waves win issue arbitration against the latency-bound
     // stages of other chunks that share the SIMD (-1.5 % per step)
-#ifdef WSX_EXP_FILL_PRIO // experiment builds: another issue priority for the fill
-    __builtin_amdgcn_s_setprio(WSX_EXP_FILL_PRIO);
-#else
     __builtin_amdgcn_s_setprio(3);
-#endif
     ReadGeom gm = geom(a, slot);
     const int lr = rfl(gm.lr), T = rfl(gm.T);
     const long long off = gm.off;
@@ -956,9 +930,6 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
 template <int K, int F, int FL, bool PK>
 __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     static_assert(!PK || (K == 1 && F == 2), "packed mask rows: one slot, two candidates");
     const int lane = threadIdx.x & 63;
     const int slot = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1112,9 +1083,6 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
 template <int F, bool PK>
 __global__ __launch_bounds__(64) void traceback_stream_kernel(PassArgs a, int n_aut)
 {
-#ifdef WSX_EXP_MID_PRIO
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     static_assert(!PK || F == 2, "packed mask rows: two candidates");
     constexpr int RC = F == 2 ? 8 : 4; // rows per step
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));

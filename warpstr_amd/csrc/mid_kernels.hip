@@ -174,13 +174,9 @@ __device__ __forceinline__ double wsx_recip_refined(double d)
 }
 __device__ __forceinline__ double wsx_div_by(double x, double d, double r)
 {
-#ifdef WSX_PLAIN_DIVISIONS // experiment builds: the compiler's full expansion
-    return x / d;
-#else
     const double q = x * r;
     const double e = __builtin_fma(-d, q, x);
     return __builtin_fma(e, r, q);
-#endif
 }
 
 // ---- sliding t-test segmentation (caller.py:347-378) ------------------------------------------
@@ -249,9 +245,6 @@ __device__ __forceinline__ ReadView view(const MidArgs &a, int lr)
 #endif //// grid.y: a read's 64-run groups are dealt round-robin to this many single-wave blocks
 __global__ __launch_bounds__(64) void run_stats_kernel(MidArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     __shared__ double buf[RS_CAP];
     const int lr = blockIdx.x;
     if (a.status[lr] != 0) return;
@@ -374,9 +367,6 @@ __device__ __forceinline__ double pw_block_wave(const double *a, int n, int lane
 // chunk range checks) are lane-parallel with wave reductions, the state-wise cost keeps NumPy's summation order.
 __global__ __launch_bounds__(256) void borders_kernel(MidArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     const int lane = threadIdx.x & 63;
     const int lr = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lr >= a.n_reads) return;
@@ -508,9 +498,6 @@ __global__ __launch_bounds__(256) void borders_kernel(MidArgs a)
 // (a launch lasts at least the ~50 us one thread needs).
 __global__ __launch_bounds__(64) void borders_thread_kernel(MidArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     const int lr = blockIdx.x * blockDim.x + threadIdx.x;
     if (lr >= a.n_reads) return;
     wsx_result *res = (wsx_result *)a.results + lr;
@@ -729,9 +716,6 @@ __global__ __launch_bounds__(64) void chunk_kernel(MidArgs a)
 // `started` before position p is exactly A(p-1), so  borders(chunk) = #{p in (b0, b1] : A(p-1) and not A(p)}.
 __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     extern __shared__ int seg_lds[]; // cb[max_chunks + 1]: first sample of every chunk; cnt[max_chunks]
     __shared__ double wm[256 + 3], ws[256 + 3], tl[256 + 2];
     int *cb = seg_lds, *cnt = seg_lds + (max_chunks + 1);
@@ -810,9 +794,6 @@ __global__ __launch_bounds__(256) void segment_kernel(MidArgs a, int max_chunks)
 // 100-1000 records, directly for fewer or more.  One wavefront per read.
 __global__ __launch_bounds__(64) void sort_kernel(MidArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     constexpr int SORT_CAP = 512, SORT_BUCKETS = 512, SORT_DIRECT_MAX = 96; // (fewer than ~100 records: counting is cheaper)
     __shared__ double xs[SORT_CAP]; // direct counting: a tile of the values; bucketed: the values grouped by bucket
     __shared__ int sort_cnt[SORT_BUCKETS], sort_start[SORT_BUCKETS + 1];
@@ -1026,9 +1007,6 @@ constexpr int kQuadFromLeft = 0x90; // quad_perm [0,0,1,2]: lane j takes lane j-
 // one, and a read takes 4 lanes instead of 1 thread, so small launches spread over four times as many wavefronts.
 __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     const int j = threadIdx.x & 3;
     const int lr = blockIdx.x * 16 + (threadIdx.x >> 2);
     if (lr >= a.n_reads) return; // whole quads leave together
@@ -1122,9 +1100,6 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 // splev (ext = 0) of the fitted cubic at every sample of the read.
 __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 {
-#ifdef WSX_EXP_MID_PRIO // experiment builds: issue priority of the stages between the fills
-    __builtin_amdgcn_s_setprio(WSX_EXP_MID_PRIO);
-#endif
     const int lr = blockIdx.x; // one block per read, striding over its samples
     if (a.status[lr] != 0) return;
     const int r = a.first_read + lr;

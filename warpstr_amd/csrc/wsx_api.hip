@@ -275,6 +275,7 @@ struct wsx_caller {
     std::vector<int32_t> dp_reads; // reads of the fill launch between the pair
     size_t dp_events_used = 0;
     bool timing_valid = false;
+    int64_t last_samples = 0; // samples of the most recent call (wsx_caller_workspace)
     bool timing_window = false; // wsx_caller_timing_window: the fill events of successive calls accumulate
     hipEvent_t ev_window = nullptr; // start of the window (the first call's begin)
     bool window_open = false;
@@ -1413,6 +1414,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         HIPCHK(hipEventRecord(c->ev_end, end_st));
     }
     c->timing_valid = true;
+    c->last_samples = io.offsets[n] - io.offsets[0];
     if (host) {
         HIPCHK(hipStreamSynchronize(main_st));
         if (ringed) {
@@ -1512,6 +1514,19 @@ int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_laun
     if (dp_kernel_ms) *dp_kernel_ms = dp;
     if (dp_launches) *dp_launches = (int32_t)c->dp_events_used;
     if (total_ms) *total_ms = tot;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_workspace(wsx_caller *c, uint64_t *bytes_allocated, double *bytes_per_sample)
+{
+    if (!c) return WSX_ERR_INVALID;
+    uint64_t total = c->aut_blob.cap + c->aut_table.cap;
+    for (auto &b : c->meta) total += b.cap;
+    for (auto &b : c->prep_pool) total += b.cap;
+    for (auto &w : c->work)
+        for (const DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) total += b->cap;
+    if (bytes_allocated) *bytes_allocated = total;
+    if (bytes_per_sample) *bytes_per_sample = c->last_samples > 0 ? (double)total / (double)c->last_samples : 0.0;
     return WSX_SUCCESS;
 }
 
