@@ -1,5 +1,5 @@
 """Throughput of the whole call against the number of states: the cost of a 64-state slot boundary.
-Usage: exp_staircase.py [n_reads] [samples]   (device-resident input, pipelined calls, simple repeats with flanks chosen so that the
+Usage: exp_staircase.py [n_reads] [samples] [S,S,...]   (device-resident input, pipelined calls, simple repeats with flanks chosen so that the
 larger of the two strands' automata has exactly S states)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,8 @@ def locus_with(S):
 
 
 print(f'{n} reads x {T} samples, both passes, device-resident, 8 pipelined calls', flush=True)
-for S in (48, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 257, 320):
+sizes = tuple(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else (48, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 257, 320)
+for S in sizes:
     loc, fl, pat = locus_with(S)
     rng = np.random.default_rng(S)
     base = []

@@ -53,9 +53,6 @@ out['_workload'] = bench['config']
 json.dump(out, open(os.path.join(prof, f'{name}_pmc.json'), 'w'), indent=1)
 
 fills = [k for k in out if k.startswith('dtw_fill')]
-for k in fills:  # dtw_fill_wg<M, K, ..>: K waves per read -- the bookkeeping below counts reads
-    if k.startswith('dtw_fill_wg<'):
-        out[k]['SQ_WAVES']['mean_per_launch'] /= int(k.split(',')[1])
 n = bench['config']['reads_per_gpu']
 samples_all = n * bench['config'].get('mean_samples_per_read', bench['config'].get('samples_per_read'))
 waves_all = sum(out[k]['SQ_WAVES']['mean_per_launch'] for k in fills)

@@ -187,19 +187,17 @@ __host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f :
 // before it in the reference's order (stay, pred 0, pred 1, ..); the arg-min is the highest f whose bit is set; none = stay.
 // FL < F ("split"): only slot 0 considers F predecessors per state, the other slots FL (the host places every state
 // with more than FL predecessors in slot 0; such states are few: loop entries, IUPAC alternatives).  FL == F: uniform.
-// EXW: export slots per LDS buffer (K*64 + 32 when the wave holds all K slots).  WG: the slots of the read are spread over
-// the waves of a workgroup (dtw_fill_wg: this wave holds ONE of them, K = 1 here, wl = its export slot) -- the row then
-// ends with the workgroup's barrier instead of the wave's.
 // LM ("lane-major", wsx_place.h: wsx_place_lane_major): the state in (slot k >= 1, lane l) has ONE predecessor and it sits
 // right below it, in (slot k-1, lane l) -- its candidate is a register of the same lane, two rows old (x[][]), not an LDS
 // read; only slot 0 (chain heads, states with several predecessors, continuations of a chain from the lane before) reads
 // LDS, and only the slots such states read from write it: slots 0 and K-1 (LM = 1) or all (LM = 2).  The slots are then
 // walked downwards, so that slot k takes slot k-1's export of two rows ago before slot k-1 replaces it.
-template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT, int EXW = K * 64 + 32, bool WG = false, int LM = 0>
+template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT, int LM = 0>
 __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int wl, double snext,
                                        uint64_t (&mk)[F + (K - 1) * FL], const uint64_t (&cutm)[K])
 {
-    static_assert(LM == 0 || (FL == 1 && K >= 2 && !WG), "lane-major: one in-lane predecessor per state above slot 0");
+    static_assert(LM == 0 || (FL == 1 && K >= 2), "lane-major: one in-lane predecessor per state above slot 0");
+    constexpr int EXW = K * 64 + 32;
     constexpr int wbuf = PAR * EXW;       // E(i+2) goes to the buffer of parity i
     constexpr int rbuf = (1 - PAR) * EXW; // E(i+1) lives in the buffer of parity i+1
 #pragma unroll
@@ -248,13 +246,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
         if (LM == 0 || LM == 2 || k == 0 || k == K - 1) ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = enew;
 
     }
-    if constexpr (WG) {
-        // every wave's exports of this row are in LDS (and its reads of the other buffer have returned) before any wave
-        // starts the next row: the next row's reads see them, the next row's writes replace values nobody reads any more
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-        __builtin_amdgcn_wave_barrier();
-    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // (Register budgets: left to the compiler.  Forcing more waves per SIMD was measured slower every time -- two slots at 96
@@ -403,7 +395,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
             uint64_t mk[NM];
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, K * 64 + 32, false, LM>(st, ex, wl, snext, mk, cutm);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
             if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
         };
         // packed rows, one row: the first mask goes to its place in the group of 16, the second one's byte joins `acc`,
@@ -414,7 +406,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
             uint64_t mk[NM];
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, K * 64 + 32, false, LM>(st, ex, wl, snext, mk, cutm);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
             uint64_t *g16 = bp + (size_t)((unsigned)r >> 4) * 18;
             if (!FORCED) {
                 store_mask<0>(mk[0], g16 + (r & 15));
@@ -431,7 +423,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
             constexpr bool FORCED = decltype(forced)::value;
             constexpr bool CUT = decltype(cut)::value;
             constexpr bool MROW = decltype(msk)::value;
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, K * 64 + 32, false, LM>(st, ex, wl, snext, mk, cutm);
+            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
         };
         // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
         // 64-byte scalar load; the rows before and after such groups load theirs one by one
@@ -549,264 +541,6 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
     }
     if (lane == 0 && !a.check_status) a.status[lr] = 0;
     asm volatile("s_dcache_wb" ::: "memory"); // scalar stores sit in the scalar data cache until written back
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-resident fill for automata of several slots (S > 64), one SLOT PER WAVEFRONT: the KW slots of a read are the KW
-// waves of a workgroup.  Each wave runs the single-slot row (7 VALU instructions for a slot that considers one predecessor,
-// 10 for two) out of ~60 registers, so eight waves share a SIMD -- the one-wave-per-read formulation above needs 168-202
-// registers for four or five slots and leaves a SIMD with two or three waves, too few to cover the round trip of the
-// predecessor exchange.  The exchange is the same (exports one row ahead through LDS, conflict-free slots from
-// wsx_place.h); what orders it is the workgroup barrier at the end of every row.
-//   Slots sleep while they cannot matter (exact).  A transition advances at least bmin = M rows (M-1 in a masked pass), so
-//   a state hs transitions away from the states row 0 initialises is +inf before row bmin*hs, and a cell from which the end
-//   state is more than the remaining rows away lies on no path to (T-1, endstate): a wave whose 64 states are all in that
-//   situation only keeps the barrier count (and stores zero masks, so the traceback of a read without any finite path still
-//   sees "stay").  It wakes one row before its first state can become finite and keeps exporting two rows past its last
-//   live row -- the export of row i feeds row i+2 -- so every value a live cell reads is the one the full sweep computes;
-//   dead cells only feed dead cells.  (With last_row requested nothing is cut at the end: that output is the whole row.)
-//   The per-slot hop counts come from the host (DevAutomaton::slot_hops).
-// Mask layout, traceback: as dtw_fill_fast<M, KW, F, FL, false>.
-// ------------------------------------------------------------------------------------------------
-template <int STRIDE, int N, int R, int Q = 0> // the N masks of this wave's slot for group row R (rows are STRIDE masks apart)
-__device__ __forceinline__ void store_slot_masks(const uint64_t (&mk)[N], uint64_t *base)
-{
-    if constexpr (Q < N) {
-        store_mask<(R * STRIDE + Q) * 8>(mk[Q], base);
-        store_slot_masks<STRIDE, N, R, Q + 1>(mk, base);
-    }
-}
-
-template <int STRIDE, int N, int G, int RBASE, int Q = 0>
-__device__ __forceinline__ void store_slot_group(const uint64_t (&gm)[G][N], uint64_t *base)
-{
-    if constexpr (Q < G) {
-        store_slot_masks<STRIDE, N, RBASE + Q>(gm[Q], base);
-        store_slot_group<STRIDE, N, G, RBASE, Q + 1>(gm, base);
-    }
-}
-
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int M, int KW, int F, int FL, int FX> // FX: predecessors this wave's slot considers (F in slot 0, FL elsewhere)
-__device__ __forceinline__ void fill_wg_slot(const PassArgs &a, const DevAutomaton &A, const int k, const int lane, double *ex,
-                                             const int lr, const int T, const long long off)
-{
-    constexpr int NM = F + (KW - 1) * FL; // back-pointer masks per row (all slots)
-    constexpr int EXW = KW * 64 + 32;
-    const int S = A.n_states;
-    const int moff = k == 0 ? 0 : F + (k - 1) * FL; // this slot's first mask inside a row
-    const double *sig = a.signal + off;
-    uint64_t *bp = mask_rows(a, off, lr, NM) + moff; // row i's masks of this slot at bp[i*NM + f]
-    const int wl = k * 64 + lane;                    // export slot of this lane
-    const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
-    const int nmw = cdiv(T, 32);
-
-    // ---- per-state constants -----------------------------------------------------------------
-    FillState<M, 1, FX> st;
-    const long long boundary = (long long)A.flank_length - 10;
-    const long long after_repeat = (long long)A.seq_idx_last - boundary;
-    long long cut_from_ll = 6 * boundary;
-    if ((long long)T - 6 * boundary + 1 > cut_from_ll) cut_from_ll = (long long)T - 6 * boundary + 1;
-    const int cut_from = rfl(cut_from_ll < M ? M : (cut_from_ll > T ? T : (int)cut_from_ll));
-    // The cut only has to be FORCED for M rows: every predecessor of a cut state is a cut state (the cut takes a prefix of the
-    // pattern: flank, repeat, the right flank's first bases; back edges stay inside the repeat), so once the values that were
-    // in flight when the cut began have drained -- an export made at row i rests on D[i+2-M] at the oldest -- stay and
-    // every candidate of a cut state are +inf by themselves, and so are its pointers ("inf < inf" is false).
-    const int cut_end = cut_from + M < T ? cut_from + M : T;
-    int j = wl < S ? wl : -1; // state of this lane
-    if (A.state_at) {
-        const int t = A.state_at[wl];
-        j = t == 0xFFFF ? -1 : t;
-    }
-    st.v[0] = j >= 0 ? A.value[j] : 0.0;
-    st.cutf[0] = j >= 0 && ((long long)A.seq_idx[j] < after_repeat);
-    const uint64_t cutm[1] = {__ballot(st.cutf[0])};
-#pragma unroll
-    for (int f = 0; f < FX; f++) st.paddr[0][f] = A.paddr[(k * WSX_MAX_F + f) * 64 + lane];
-
-    // ---- the rows this slot takes part in ------------------------------------------------------
-    const long long bmin = maskw ? M - 1 : M;
-    const long long hs = A.slot_hops[2 * k], he = A.slot_hops[2 * k + 1]; // transitions from the start / to the end (min over the slot)
-    long long lo_ll = hs == 0 ? 1 : bmin * hs - 1;                         // first row computed
-    long long hi_ll = a.last_row ? (long long)T - 1 : (long long)T - bmin * he + 1; // last row computed
-    if (hi_ll > T - 1) hi_ll = T - 1;
-    if (lo_ll > hi_ll) { // never
-        lo_ll = T;
-        hi_ll = T - 1;
-    }
-    const int lo = rfl((int)lo_ll), hi = rfl((int)hi_ll);
-
-    // ---- state at row lo - 1 ---------------------------------------------------------------------
-    ex[0 * EXW + wl] = kInf;
-    ex[1 * EXW + wl] = kInf;
-    if (k == 0 && lane < 32) {
-        ex[KW * 64 + lane] = kInf;
-        ex[EXW + KW * 64 + lane] = kInf;
-    }
-    {
-        double d0 = kInf;
-        if (hs == 0) { // row 0 (caller.py:201-208)
-            const double v0 = A.value[0];
-            const double start_val = fabs(sig[0] - v0);
-            if (j == 0) d0 = start_val;
-            else if (j > 0 && j <= M) d0 = start_val + fabs(sig[j] - v0);
-        }
-        st.d[0] = d0;
-        st.acur[0] = sig[lo < T ? lo : T - 1] - st.v[0];
-        st.g[0][1] = d0 + fabs(st.acur[0]);
-#pragma unroll
-        for (int q = 2; q < M; q++) st.g[0][q] = kInf;
-#pragma unroll
-        for (int f = 0; f < FX; f++) {
-            st.e0[0][f] = kInf;
-            st.e1[0][f] = kInf;
-        }
-    }
-    wg_barrier();
-
-    // rows without work for this slot: the pointers read "stay", the barrier count is kept
-    auto idle_rows = [&](int from, int to) { // [from, to)
-        for (int i = from; i < to; i++) {
-            if (i >= M) {
-                uint64_t *rp = bp + (size_t)(unsigned)i * NM;
-#pragma unroll
-                for (int f = 0; f < FX; f++) store_mask<0>(0ull, rp + f);
-            }
-            asm volatile("s_barrier" ::: "memory");
-        }
-    };
-    idle_rows(1, lo);
-
-    typedef double d8 __attribute__((ext_vector_type(8)));
-    typedef d8 d8u __attribute__((aligned(8)));
-    const WSX_AS4 double *cs = (const WSX_AS4 double *)sig;
-    const int last = T - 1;
-    auto sample = [&](int q) -> double { return cs[q < T ? q : last]; };
-    auto clampi = [&](int x) { return x < T ? x : last; };
-    double warm = 0.0;
-    if (k == 0) warm = sig[clampi(lo + 64 + lane)];
-
-    for (int b = lo >> 6; b * 64 <= hi; b++) {
-        if (k == 0) { // one wave of the workgroup warms L2 for everybody's scalar loads
-            asm volatile("" ::"v"(warm));
-            warm = sig[clampi((b + 2) * 64 + lane)];
-        }
-        const int base = b * 64;
-        const int blo = base > lo ? base : lo;
-        const int bhi = base + 64 < hi + 1 ? base + 64 : hi + 1; // rows [blo, bhi)
-
-        unsigned long long bm = 0; // bit t <=> row base+t exports for a MASKED row (mask bit of sample base+t+2)
-        if (maskw) {
-            const int w0 = 2 * b;
-            const unsigned long long m0 = w0 < nmw ? maskw[w0] : 0u, m1 = w0 + 1 < nmw ? maskw[w0 + 1] : 0u,
-                                     m2 = w0 + 2 < nmw ? maskw[w0 + 2] : 0u;
-            bm = ((m0 | (m1 << 32)) >> 2) | ((m2 & 3ull) << 62);
-            bm = ((unsigned long long)(unsigned)rfl((int)(bm >> 32)) << 32) | (unsigned)rfl((int)bm);
-        }
-        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[FX]) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;
-            constexpr bool FORCED = decltype(forced)::value;
-            constexpr bool CUT = decltype(cut)::value;
-            constexpr bool MROW = decltype(msk)::value;
-            dp_row<M, 1, FX, FX, MROW, PAR, FORCED, CUT, EXW, true>(st, ex, wl, snext, mk, cutm);
-        };
-        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) __attribute__((always_inline)) {
-            using P0 = std::integral_constant<int, 0>;
-            using P1 = std::integral_constant<int, 1>;
-            auto one = [&](int r) __attribute__((always_inline)) {
-                uint64_t mk[FX];
-                if (r & 1) row_keep(P1{}, forced, cut, msk, sample(r + 1), mk);
-                else row_keep(P0{}, forced, cut, msk, sample(r + 1), mk);
-                if (!decltype(forced)::value) store_slot_masks<NM, FX, 0>(mk, bp + (size_t)(unsigned)r * NM);
-            };
-            int i = plo;
-            for (; i < phi && (i & 7); i++) one(i);
-            for (; i + 8 <= phi && i + 8 < T; i += 8) {
-                const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
-                uint64_t *gp = bp + (size_t)(unsigned)i * NM;
-                if constexpr (!decltype(forced)::value) {
-                    // the scalar stores of G rows leave together (see dtw_fill_fast)
-                    constexpr int G = FX <= 2 ? 8 : 4;
-                    uint64_t gm[G][FX];
-#define WSX_ROW(R)                                                                                                  \
-    row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], gm[(R) % G]);                            \
-    if constexpr (((R) % G) == G - 1) store_slot_group<NM, FX, G, (R) - (G - 1)>(gm, gp);
-                    WSX_ROW(0)
-                    WSX_ROW(1)
-                    WSX_ROW(2)
-                    WSX_ROW(3)
-                    WSX_ROW(4)
-                    WSX_ROW(5)
-                    WSX_ROW(6)
-                    WSX_ROW(7)
-#undef WSX_ROW
-                } else {
-                    for (int q = 0; q < 8; q++) one(i + q);
-                }
-            }
-            for (; i < phi; i++) one(i);
-        };
-        auto phase = [&](auto forced, auto cut, int plo, int phi) __attribute__((always_inline)) {
-            int i = plo;
-            while (i < phi) {
-                const unsigned long long rest = bm >> (i - base);
-                const bool mv = rest & 1ull;
-                const unsigned long long x = mv ? ~rest : rest;
-                const int len = x ? __builtin_ctzll(x) : 64;
-                const int e = (i + len < phi) ? i + len : phi;
-                if (mv) span(forced, cut, std::true_type{}, i, e);
-                else span(forced, cut, std::false_type{}, i, e);
-                i = e;
-            }
-        };
-        const int e0 = bhi < M ? bhi : M;               // forced rows end
-        const int e1 = bhi < cut_from ? bhi : cut_from; // plain rows end
-        const int e2 = bhi < cut_end ? bhi : cut_end;   // rows that force the cut end
-        phase(std::true_type{}, std::false_type{}, blo, e0);
-        phase(std::false_type{}, std::false_type{}, blo > M ? blo : M, e1);
-        phase(std::false_type{}, std::true_type{}, blo > cut_from ? blo : cut_from, e2);
-        phase(std::false_type{}, std::false_type{}, blo > cut_end ? blo : cut_end, bhi);
-    }
-    idle_rows(hi + 1, T);
-
-    // ---- outputs of the fill -----------------------------------------------------------------
-    if (j == A.endstate && a.end_cost) a.end_cost[lr] = st.d[0];
-    if (a.last_row && j >= 0) a.last_row[(size_t)lr * a.last_row_stride + j] = lo < T ? st.d[0] : kInf;
-    if (k == 0 && lane == 0 && !a.check_status) a.status[lr] = 0;
-    asm volatile("s_dcache_wb" ::: "memory");
-}
-
-template <int M, int KW, int F, int FL>
-__global__ __launch_bounds__(64 * KW) void dtw_fill_wg(PassArgs a, int rotate)
-{
-    static_assert(KW >= 2 && FL >= 1 && FL <= F && M >= 3, "several slots, one per wave");
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x & 63;
-    const int wib = rfl(threadIdx.x >> 6);
-    const int slot = blockIdx.x; // one read per workgroup
-    __builtin_amdgcn_s_setprio(3);
-    ReadGeom gm = geom(a, slot);
-    const int lr = rfl(gm.lr), T = rfl(gm.T);
-    const long long off = gm.off;
-    const DevAutomaton A = a.aut[a.aut_id[gm.r]];
-    if (a.check_status && a.status[lr] != 0) return;
-    if (T <= M || A.n_states <= M) { // (uniform over the workgroup: no wave is left at a barrier)
-        if (threadIdx.x == 0) {
-            a.status[lr] = 1; // WSX_READ_SHAPE
-            if (a.end_cost) a.end_cost[lr] = kInf;
-        }
-        return;
-    }
-    // Which wave takes which slot rotates with the workgroup: slot 0 is the expensive one (F candidates), and the waves of a
-    // workgroup are dealt to the SIMDs of a CU in order.
-    const int k = rfl((wib + (rotate ? (int)(blockIdx.x % KW) : 0)) % KW);
-    if constexpr (FL == F) {
-        fill_wg_slot<M, KW, F, FL, F>(a, A, k, lane, lds, lr, T, off);
-    } else {
-        if (k == 0) fill_wg_slot<M, KW, F, FL, F>(a, A, k, lane, lds, lr, T, off);
-        else fill_wg_slot<M, KW, F, FL, FL>(a, A, k, lane, lds, lr, T, off);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,25 +734,31 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
             const int ks = q >> 6, bit = q & 63;
             // won[f] bit l: predecessor f beat everything before it at row 64*cb + l -- a shift, an AND and a compare
             // per candidate on the vector ALU (the slot's masks are picked by a uniform register index); the rest is scalar
+            // The slot is wave-uniform: a branch per slot picks that slot's masks by a STATIC register index (a shift, an AND
+            // and a compare per candidate; a chain of selects over the K slots cost 2 (K-1) more per candidate).
             uint64_t won[F];
+#pragma unroll
+            for (int f = 0; f < F; f++) won[f] = 0ull;
+            auto history = [&](uint64_t w) { return __ballot((w >> bit) & 1ull); };
+            if (ks == 0) {
+#pragma unroll
+                for (int f = 0; f < F; f++) won[f] = history(cur.w[f]);
+            }
+#define WSX_TB_SLOT(KK)                                                                                             \
+    if constexpr (K > KK) {                                                                                         \
+        if (ks == KK) {                                                                                             \
+            _Pragma("unroll") for (int f = 0; f < FL; f++) won[f] = history(cur.w[mask_index<F, FL>(KK, f)]);      \
+        }                                                                                                           \
+    }
+            WSX_TB_SLOT(1)
+            WSX_TB_SLOT(2)
+            WSX_TB_SLOT(3)
+            WSX_TB_SLOT(4)
+#undef WSX_TB_SLOT
+            static_assert(K <= 5, "one branch per slot");
             uint64_t entered = 0;
 #pragma unroll
-            for (int f = 0; f < F; f++) {
-                if (f < FL) {
-                    uint64_t w = cur.w[f]; // the slot's mask f: a chain of selects on the uniform slot number
-#pragma unroll
-                    for (int k = 1; k < K; k++) {
-                        uint64_t wk = cur.w[mask_index<F, FL>(k, f)];
-                        asm("" : "+v"(wk)); // keeps the select on values: as a select of addresses it would send w[] to scratch
-                        w = (ks == k) ? wk : w;
-                    }
-                    won[f] = __ballot((w >> bit) & 1ull);
-                } else { // candidates FL.. exist in slot 0 only
-                    const uint64_t t = __ballot((cur.w[f] >> bit) & 1ull);
-                    won[f] = ks == 0 ? t : 0ull;
-                }
-                entered |= won[f];
-            }
+            for (int f = 0; f < F; f++) entered |= won[f];
             entered &= ~0ull >> (63 - (i & 63)); // rows <= i
             if (entered == 0 && cb * 64 > m) {   // the run continues in the block below
                 i = cb * 64 - 1;
@@ -1041,7 +781,10 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
             }
             if (entered == 0) return true; // reached row 0 in this state
             const int back = m - (int)((cmasked >> l) & 1ull);
-            q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
+            // lane-major placement: the one predecessor of a position above slot 0 sits right below it -- no table look-up
+            // (a dependent scalar load per transition otherwise)
+            if (a.lane_major && ks > 0) q -= 64;
+            else q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
             i = start - back;
             if ((i >> 6) != cb) return false; // a step never skips a block: back <= m rows
         }
@@ -1367,28 +1110,6 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// Several slots, no lane-major placement: one slot per wave, a workgroup per read (dtw_fill_wg), where that measured
-// faster than the one-wave kernel -- three and four slots (20 k reads x 2 000 samples, whole call: 6.66 vs 6.81 ms at 192
-// states, 8.31 vs 8.68 ms at 256; two slots 5.10 vs 4.93, five 13.5 vs 11.9: profiles/r03_state_staircase.log).
-// WSX_FILL_WG: 0 = never, 1 = where it wins (default), 2 = same with wave w fixed to slot w, 3 = for every K >= 2.
-static int fill_wg_mode()
-{
-    static const int mode = [] {
-        const char *e = getenv("WSX_FILL_WG");
-        return e ? atoi(e) : 1;
-    }();
-    return mode;
-}
-static bool fill_wg_wanted(int K) { return fill_wg_mode() == 3 ? K >= 2 : (fill_wg_mode() != 0 && (K == 3 || K == 4)); }
-
-template <int M, int K, int F, int FL>
-hipError_t launch_fill_wg(const PassArgs &a, hipStream_t s)
-{
-    const size_t shmem = 2 * (K * 64 + 32) * sizeof(double);
-    hipLaunchKernelGGL((dtw_fill_wg<M, K, F, FL>), dim3(a.n_launch), dim3(64 * K), shmem, s, a, fill_wg_mode() != 2 ? 1 : 0);
-    return hipGetLastError();
-}
-
 template <int M, int K>
 hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipStream_t s)
 {
@@ -1405,25 +1126,6 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipS
             }
         }
         return hipErrorInvalidValue;
-    }
-    if constexpr (K >= 2) {
-        if (fill_wg_wanted(K) && !pk) {
-            if constexpr (M == 4) {
-                if (F == 2 && FL == 1) return launch_fill_wg<M, K, 2, 1>(a, s);
-                if (F == 3 && FL == 1) return launch_fill_wg<M, K, 3, 1>(a, s);
-                if (F == 3 && FL == 2) return launch_fill_wg<M, K, 3, 2>(a, s);
-                if (F == 4 && FL == 1) return launch_fill_wg<M, K, 4, 1>(a, s);
-                if (F == 4 && FL == 2) return launch_fill_wg<M, K, 4, 2>(a, s);
-            }
-            if (FL == F) {
-                switch (F) {
-                case 2: return launch_fill_wg<M, K, 2, 2>(a, s);
-                case 3: return launch_fill_wg<M, K, 3, 3>(a, s);
-                case 4: return launch_fill_wg<M, K, 4, 4>(a, s);
-                }
-            }
-            return hipErrorInvalidValue;
-        }
     }
     if constexpr (K >= 2 && M == 4) { // split variants (FL < F): several slots, default min_values_per_state
         if (F == 2 && FL == 1) return launch_fill<M, K, 2, 1>(a, s);
@@ -1485,7 +1187,6 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, b
 {
     static thread_local char buf[64];
     if (generic) snprintf(buf, sizeof(buf), "dtw_fill_generic");
-    else if (lm == 0 && !pk && fill_wg_wanted(K)) snprintf(buf, sizeof(buf), "dtw_fill_wg<%d, %d, %d, %d>", m, K, fast_f(F), FL);
     else snprintf(buf, sizeof(buf), "dtw_fill_fast<%d, %d, %d, %d, %s, %d>", m, K, fast_f(F), FL, pk ? "true" : "false", lm); // as rocprofv3 prints it
     return buf;
 }
@@ -1493,7 +1194,7 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, b
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, hipStream_t s)
 {
 #ifdef WSX_ONLY_WG // listing builds (hipcc -S): just the flank-110 variants of the several-slot fills
-    return lm ? launch_fill<4, 4, 2, 1, false, 1>(a, s) : launch_fill_wg<4, 4, 2, 1>(a, s);
+    return lm ? launch_fill<4, 4, 2, 1, false, 1>(a, s) : launch_fill<4, 4, 2, 1>(a, s);
 #elif defined(WSX_ONLY_DEFAULT) // experiment builds: just the headline variant
     if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return pk ? launch_fill<4, 1, 2, 2, true>(a, s) : launch_fill<4, 1, 2, 2>(a, s);
     return hipErrorInvalidValue;

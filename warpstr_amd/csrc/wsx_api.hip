@@ -452,8 +452,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
                 align_up((size_t)((S + 63) / 64) * 64 * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S) +
-                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2) +
-                align_up((size_t)((S + 63) / 64) * 2 * 4);
+                align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2);
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
@@ -547,31 +546,6 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 for (int e = A.pred_ptr[j], t = 0; e < A.pred_ptr[j + 1] && t < 4; e++, t++)
                     p4[pos[j]] |= (uint64_t)pos[A.pred_idx[e]] << (16 * t);
             D.pred4 = (const uint64_t *)put(p4.data(), p4.size() * 8);
-        }
-        // slot_hops: when a slot of the several-slot fill can sleep (dtw_fill_wg) -- per slot the fewest transitions from
-        // the states row 0 initialises (0..m, caller.py:201-208) to any of its states, and from any of its states to the end
-        if (!v.generic) {
-            const int kUnreach = 1 << 20;
-            const int mm = c->prm.min_values_per_state;
-            std::vector<int> hs(S, kUnreach), he(S, kUnreach);
-            for (int j = 0; j <= mm && j < S; j++) hs[j] = 0;
-            he[A.endstate] = 0;
-            for (bool changed = true; changed;) {
-                changed = false;
-                for (int j = 0; j < S; j++)
-                    for (int e = A.pred_ptr[j]; e < A.pred_ptr[j + 1]; e++) {
-                        const int p = A.pred_idx[e];
-                        if (hs[p] + 1 < hs[j]) hs[j] = hs[p] + 1, changed = true;
-                        if (he[j] + 1 < he[p]) he[p] = he[j] + 1, changed = true;
-                    }
-            }
-            std::vector<int32_t> sh((size_t)v.K * 2, kUnreach);
-            for (int j = 0; j < S; j++) {
-                const int k = pos[j] / 64;
-                sh[2 * k] = std::min(sh[2 * k], hs[j]);
-                sh[2 * k + 1] = std::min(sh[2 * k + 1], he[j]);
-            }
-            D.slot_hops = (const int32_t *)put(sh.data(), sh.size() * 4);
         }
         // paddr: which LDS export slot (slot k, predecessor f, lane) reads in the register-resident fill.  A ds_read_b64
         // serves lanes 0-31 and 32-63 in one cycle each when no two lanes of a group hit the same bank pair (slot mod 32)
@@ -1279,6 +1253,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.maskbits = maskbits;
             pa.trace = trace;
             pa.status = status;
+            pa.lane_major = x.gvar[g].lm != 0;
             HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, s));
         }
         return WSX_SUCCESS;

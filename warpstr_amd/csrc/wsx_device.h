@@ -34,8 +34,6 @@ struct DevAutomaton {
     const uint16_t *wslot;    // single-slot automata: the LDS export slot lane l writes (64 entries; wsx_place.h)
     const uint16_t *pos;      // state -> position (slot*64 + lane) in the register-resident fill; NULL = identity
     const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
-    const int32_t *slot_hops; // per slot k: [2k] fewest transitions from the states row 0 initialises (0..m) to a state of the
-                              // slot, [2k+1] fewest from a state of the slot to the end state (dtw_fill_wg: when a slot sleeps)
     const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
                             // predecessors, 16 bits each (mask traceback)
 };
@@ -71,6 +69,7 @@ struct PassArgs {
     int32_t *status;           // per read: written by pass 1, read (skip if != 0) by pass 2
     int32_t check_status;      // 1: skip reads whose status is already non-zero and do not write status
     int32_t m;
+    int32_t lane_major;        // the launch group's automata are placed lane-major (wsx_place.h): traceback shortcut
 };
 
 // Per-read record produced by borders_kernel for the segmentation kernels.
