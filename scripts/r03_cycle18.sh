@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, cycle 18: reads per workgroup x chunks per call, cfg1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+export WARPSTR_BENCH_PROFILING=1
+line() { python3 -c "import json,sys; d=json.load(open('$1')); print('$2', round(d['value']), round(d['ms_per_step'],3), 'fill union', round(d['roofline'].get('fill_union_ms_per_step',0),3))"; }
+for rep in 1 2; do for lib in wpb4 wpb2 wpb1; do for ch in 0 4 8; do
+  env=""; [ $ch != 0 ] && env="WSX_CHUNKS=$ch"
+  env $env WARPSTR_HIP_LIB=$R/build/exp/lib$lib.so timeout -k 10 300 python bench.py --workload cfg1 --no-cpu-baseline --no-verify > $O/r03c18_b.json 2> $O/r03c18_b.err || { tail $O/r03c18_b.err; exit 1; }
+  line $O/r03c18_b.json "cfg1 [$lib chunks=$ch]"
+done; done; done

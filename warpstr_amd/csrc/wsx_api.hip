@@ -777,7 +777,9 @@ struct BatchIO {
     int32_t *status = nullptr;
 };
 
-int run_batch(wsx_caller *c, const BatchIO &io, bool full)
+// ---- a call in three parts: validate_batch (the caller's arguments), plan_chunks (which reads go together: host logic
+// only, no HIP call), run_batch (workspace, per-chunk pointers, the launch sequence on the handle's streams) ----------------
+int validate_batch(wsx_caller *c, const BatchIO &io, bool full)
 {
     if (!c || !io.offsets || !io.aut_id || io.n < 0 || (io.n > 0 && !io.signal && !io.read_ptrs)) {
         g_err = "null argument";
@@ -795,10 +797,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         g_err = "trace is NULL";
         return WSX_ERR_INVALID;
     }
-    const int64_t n = io.n;
     const int nA = (int)c->variant.size();
-    int64_t max_T_all = 0;
-    for (int64_t r = 0; r < n; r++) {
+    for (int64_t r = 0; r < io.n; r++) {
         const int64_t T = io.offsets[r + 1] - io.offsets[r];
         if (T < 0 || T > (1 << 30)) {
             g_err = "offsets must be non-decreasing (read too long or negative length)";
@@ -808,87 +808,19 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             g_err = "automaton_id out of range";
             return WSX_ERR_INVALID;
         }
-        max_T_all = std::max(max_T_all, T);
     }
-    int rc = set_device(c);
-    if (rc) return rc;
-    c->timing_valid = false;
-    if (!c->timing_window) c->dp_events_used = 0;
-    if (n == 0) return WSX_SUCCESS;
-    hipStream_t st = c->stream;
-    const bool host = io.mem == WSX_MEM_HOST;
-    // Pipelined (device buffers only): the call does not join the handle's stream at its end, so the next call's
-    // chunks follow this call's on every internal stream without a gap; wsx_caller_join orders a consumer after it.
-    const bool pipe = c->pipelined && !host;
-    if (c->pipelined && host) HIPCHK(hipStreamWaitEvent(st, c->ev_end, 0));
-    // The host may run this many pipelined calls ahead of the device: two for batches that fill the chip by themselves, up
-    // to kMetaSlots for small ones (each takes one stream, consecutive calls rotate over the streams: four side by side;
-    // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
-    // (up to 50 M samples per call; at 60 M -- 30 000 reads of 2 000 samples, 20 000 of 3 000 -- four whole calls side by
-    // side ran at half the speed of two calls of two chunks each: the bound below keeps to what was measured)
-    static const int64_t small_pipe_samples = [] { // (experiments: another bound for the one-chunk policy, in samples)
-        const char *e = getenv("WSX_SMALL_PIPE_SAMPLES");
-        return e ? (int64_t)atoll(e) : wsx_caller::kSmallPipeSamples;
-    }();
-    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= small_pipe_samples && n < 32768;
-    const int depth = small_pipe ? c->in_flight_small : c->in_flight;
-    const uint64_t seq = pipe ? c->call_seq++ : 0;
-    const int slot = pipe ? (int)(seq % (uint64_t)wsx_caller::kMetaSlots) : 0;
-    const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
-                                      io.traces.seq1 || io.traces.seq2);
     if (full && (io.traces.seq1 || io.traces.seq2) && !c->have_bases) {
         g_err = "sequences requested but an automaton was created without last_base";
         return WSX_ERR_INVALID;
     }
+    return WSX_SUCCESS;
+}
 
-    // ---- metadata on the device: offsets, automaton ids, launch order ---------------------------
-    // order: reads grouped by DP kernel variant, longest first inside a group (load balance)
-    // the call that used this slot last (the previous one; in pipelined mode the one before that) has to be over:
-    // its kernels read the device copy, its uploads the pinned one (no-op if never recorded)
-    HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
-    if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
-        HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
-    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
-    if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
-        for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
-            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4);
-            if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
-            HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
-            HIPCHK(c->meta[q].ensure(need));
-            if (need > c->pinned_cap[q]) {
-                if (c->pinned[q]) (void)hipHostFree(c->pinned[q]);
-                c->pinned[q] = nullptr;
-                c->pinned_cap[q] = 0;
-                HIPCHK(hipHostMalloc(&c->pinned[q], need + need / 4, hipHostMallocDefault));
-                c->pinned_cap[q] = need + need / 4;
-            }
-        }
-    Carver mc(c->meta[slot].p);
-    int64_t *d_offsets = mc.take<int64_t>(n + 1);
-    int32_t *d_autid = mc.take<int32_t>(n);
-    int32_t *d_order = mc.take<int32_t>(n);
-    // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
-    // caller's arrays are not referenced after this function returns
-    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4);
-    if (pin_bytes > c->pinned_cap[slot]) {
-        if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
-        c->pinned[slot] = nullptr;
-        c->pinned_cap[slot] = 0;
-        HIPCHK(hipHostMalloc(&c->pinned[slot], pin_bytes + pin_bytes / 4, hipHostMallocDefault));
-        c->pinned_cap[slot] = pin_bytes + pin_bytes / 4;
-    }
-    Carver pc(c->pinned[slot]);
-    int64_t *h_offsets = pc.take<int64_t>(n + 1);
-    int32_t *h_autid = pc.take<int32_t>(n);
-    int32_t *h_order = pc.take<int32_t>(n);
-    memcpy(h_offsets, io.offsets, (n + 1) * 8);
-    memcpy(h_autid, io.aut_id, n * 4);
-    HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_autid, h_autid, n * 4, hipMemcpyHostToDevice, st));
-
-    // ---- chunk plan -----------------------------------------------------------------------------
-    const size_t psb = per_sample_bytes(c, host, want_traces || !full);
-    const size_t prb = per_read_bytes(c, host, io.last_row ? (size_t)std::max(io.last_row_stride, 0) * 8 : 0);
+// Which reads go together.  `pipe`: a pipelined device-buffer call; small_pipe_samples: up to this many samples such a
+// call stays in one chunk (four calls side by side).  psb / prb: workspace bytes per sample / per read.
+std::vector<ChunkPlan> plan_chunks(const wsx_caller *c, const BatchIO &io, bool pipe, int64_t small_pipe_samples, size_t psb, size_t prb)
+{
+    const int64_t n = io.n;
     // The limit covers everything the call allocates: up to streams_per_call work sets exist side by side, and a buffer
     // grows with 12.5 % headroom (DeviceBuf) -- so one chunk may take limit / sets / 1.125.
     const size_t sets = (size_t)std::max(1, std::min(c->n_streams, c->streams_per_call));
@@ -955,6 +887,93 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         }
         if (!fits) greedy_plan();
     }
+    return chunks;
+}
+
+int run_batch(wsx_caller *c, const BatchIO &io, bool full)
+{
+    int rc = validate_batch(c, io, full);
+    if (rc) return rc;
+    const int64_t n = io.n;
+    const int nA = (int)c->variant.size();
+    rc = set_device(c);
+    if (rc) return rc;
+    c->timing_valid = false;
+    if (!c->timing_window) c->dp_events_used = 0;
+    if (n == 0) return WSX_SUCCESS;
+    hipStream_t st = c->stream;
+    const bool host = io.mem == WSX_MEM_HOST;
+    // Pipelined (device buffers only): the call does not join the handle's stream at its end, so the next call's
+    // chunks follow this call's on every internal stream without a gap; wsx_caller_join orders a consumer after it.
+    const bool pipe = c->pipelined && !host;
+    if (c->pipelined && host) HIPCHK(hipStreamWaitEvent(st, c->ev_end, 0));
+    // The host may run this many pipelined calls ahead of the device: two for batches that fill the chip by themselves, up
+    // to kMetaSlots for small ones (each takes one stream, consecutive calls rotate over the streams: four side by side;
+    // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
+    // (up to 50 M samples per call; at 60 M -- 30 000 reads of 2 000 samples, 20 000 of 3 000 -- four whole calls side by
+    // side ran at half the speed of two calls of two chunks each: the bound below keeps to what was measured)
+    static const int64_t small_pipe_samples = [] { // (experiments: another bound for the one-chunk policy, in samples)
+        const char *e = getenv("WSX_SMALL_PIPE_SAMPLES");
+        return e ? (int64_t)atoll(e) : wsx_caller::kSmallPipeSamples;
+    }();
+    const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= small_pipe_samples && n < 32768;
+    const int depth = small_pipe ? c->in_flight_small : c->in_flight;
+    const uint64_t seq = pipe ? c->call_seq++ : 0;
+    const int slot = pipe ? (int)(seq % (uint64_t)wsx_caller::kMetaSlots) : 0;
+    const bool want_traces = full && (io.traces.trace1 || io.traces.trace2 || io.traces.rescaled || io.traces.badmask ||
+                                      io.traces.seq1 || io.traces.seq2);
+
+    // ---- metadata on the device: offsets, automaton ids, launch order ---------------------------
+    // order: reads grouped by DP kernel variant, longest first inside a group (load balance)
+    // the call that used this slot last (the previous one; in pipelined mode the one before that) has to be over:
+    // its kernels read the device copy, its uploads the pinned one (no-op if never recorded)
+    HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
+    if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
+        HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
+    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
+    if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
+        for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
+            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+            if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
+            HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
+            HIPCHK(c->meta[q].ensure(need));
+            if (need > c->pinned_cap[q]) {
+                if (c->pinned[q]) (void)hipHostFree(c->pinned[q]);
+                c->pinned[q] = nullptr;
+                c->pinned_cap[q] = 0;
+                HIPCHK(hipHostMalloc(&c->pinned[q], need + need / 4, hipHostMallocDefault));
+                c->pinned_cap[q] = need + need / 4;
+            }
+        }
+    Carver mc(c->meta[slot].p);
+    int64_t *d_offsets = mc.take<int64_t>(n + 1);
+    int32_t *d_autid = mc.take<int32_t>(n);
+    int32_t *d_order = mc.take<int32_t>(n);
+    // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
+    // caller's arrays are not referenced after this function returns
+    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+    if (pin_bytes > c->pinned_cap[slot]) {
+        if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
+        c->pinned[slot] = nullptr;
+        c->pinned_cap[slot] = 0;
+        HIPCHK(hipHostMalloc(&c->pinned[slot], pin_bytes + pin_bytes / 4, hipHostMallocDefault));
+        c->pinned_cap[slot] = pin_bytes + pin_bytes / 4;
+    }
+    Carver pc(c->pinned[slot]);
+    int64_t *h_offsets = pc.take<int64_t>(n + 1);
+    int32_t *h_autid = pc.take<int32_t>(n);
+    int32_t *h_order = pc.take<int32_t>(n);
+    memcpy(h_offsets, io.offsets, (n + 1) * 8);
+    memcpy(h_autid, io.aut_id, n * 4);
+    HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_autid, h_autid, n * 4, hipMemcpyHostToDevice, st));
+
+    // ---- chunk plan -----------------------------------------------------------------------------
+    const size_t psb = per_sample_bytes(c, host, want_traces || !full);
+    const size_t prb = per_read_bytes(c, host, io.last_row ? (size_t)std::max(io.last_row_stride, 0) * 8 : 0);
+    const std::vector<ChunkPlan> chunks = plan_chunks(c, io, pipe, small_pipe_samples, psb, prb);
+    const int spc = std::min(c->n_streams, c->streams_per_call);
+    const bool small_call = (io.offsets[n] - io.offsets[0]) < (int64_t)80 << 20;
     size_t max_smp = 0, max_cnt = 0;
     for (auto &ch : chunks) {
         max_smp = std::max<size_t>(max_smp, ch.samples);
