@@ -536,7 +536,12 @@ def main():
         fill_sum = float((fe - fb).sum())
         # algorithmic bytes: 12T+32 B per read for both passes = 6T+16 per read and pass
         algo_bytes_total = samples * 6.0 * 2 * args.steps + 16.0 * float(fr.sum())
-        achieved = algo_bytes_total / (fill_union * 1e-3) / 1e9
+        # roofline.achieved = algorithmic bytes of a launch / the kernel's average launch duration (HIP events around every
+        # fill launch of the timed region, on the launch's own stream): what `rocprofv3 --kernel-trace --stats` averages for
+        # the same command (profiles/r03_*_kernel_stats.csv).  Launches of different chunks overlap, so their sum exceeds
+        # the step; the figure over the UNION of the intervals rides along as achieved_over_union.
+        achieved = algo_bytes_total / (fill_sum * 1e-3) / 1e9
+        achieved_union = algo_bytes_total / (fill_union * 1e-3) / 1e9
         kernel = hip.kernel_name(0)
         kernels = sorted({hip.kernel_name(a) for a in range(len(wl.tables))})
         prof = fill_profile(kernel)
@@ -565,15 +570,17 @@ def main():
                                           else ('one-rank nccl group (self test)' if self_gather else 'none (1 GPU)'))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'launch_ms': fill_sum / launches_total, 'algorithmic_bytes_per_launch': algo_bytes_total / launches_total,
+                         'achieved_over_union': achieved_union, 'frac_over_union': achieved_union / HBM_PEAK_GBPS,
                          'kernel': kernel, 'kernels': kernels,
                          'fill_union_ms_per_launch': fill_union / launches_total, 'launches_per_step': launches_total / args.steps,
                          'reads_per_launch': float(fr.sum()) / launches_total,
                          'fill_union_ms_per_step': fill_union / args.steps,
-                         'launch_ms_mean_overlapping': fill_sum / launches_total,
-                         'note': 'achieved = algorithmic bytes of every fill launch of the timed region / union of the '
-                                 'launches\' HIP-event intervals (launches of different chunks overlap on different streams; '
-                                 'launch_ms_mean_overlapping is the plain per-launch mean, what rocprofv3 --stats averages). '
-                                 'min-plus recurrence: bound by fp64 VALU issue and the LDS pipe, not HBM (see valu_roofline)'},
+                         'note': 'achieved = algorithmic bytes per fill launch / launch_ms, the mean HIP-event duration of the '
+                                 'fill launches of the timed region (= what rocprofv3 --stats averages for this command); '
+                                 'launches of different chunks overlap on different streams, achieved_over_union divides by the '
+                                 'union of their intervals instead. min-plus recurrence: bound by fp64 VALU issue and the LDS '
+                                 'pipe, not HBM (see valu_roofline)'},
             'valu_roofline': valu_roofline(prof, alone_ms, alone_rows, kernel) if prof is not None else {'launch_ms_alone': alone_ms},
             'valu': {'dp_cells_per_s': cells_per_s},
             # first enqueue to last finish of the timed region on the device clock (HIP events), per step
@@ -615,7 +622,7 @@ def main():
                     ('cfg5', lambda: make_ragged('cfg5', [(p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i, None)
                                                           for i, p in enumerate(CFG5_PATTERNS)], 50000, 1000, device)))
             for name, make in legs:
-                leg = secondary_leg(make(), local, device, max(4, args.steps // 2), 4, 256)
+                leg = secondary_leg(make(), local, device, args.steps, max(args.warmup, 4), 256)
                 out['secondary'][name] = leg
                 if leg['verified']['mismatches']:
                     rc = 3

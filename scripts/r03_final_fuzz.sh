@@ -5,5 +5,5 @@ timeout -k 10 900 python scripts/fuzz_loci.py 4000 48 > $O/r03_fuzz_loci_4000.lo
 tail -1 $O/r03_fuzz_loci_4000.log
 timeout -k 10 900 python scripts/fuzz_parity.py 30 > $O/r03_fuzz_parity_945k_reads.log 2>&1 || { tail -30 $O/r03_fuzz_parity_945k_reads.log; exit 1; }
 tail -1 $O/r03_fuzz_parity_945k_reads.log
-timeout -k 10 900 python scripts/fuzz_loci.py 3000 48 --configs > $O/r03_fuzz_loci_configs_3000.log 2>&1 || { tail -30 $O/r03_fuzz_loci_configs_3000.log; exit 1; }
-tail -1 $O/r03_fuzz_loci_configs_3000.log
+timeout -k 10 900 python scripts/fuzz_loci.py 1500 48 --configs > $O/r03_fuzz_loci_configs_1500.log 2>&1 || { tail -30 $O/r03_fuzz_loci_configs_1500.log; exit 1; }
+tail -1 $O/r03_fuzz_loci_configs_1500.log
