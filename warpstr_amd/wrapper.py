@@ -155,6 +155,10 @@ def _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal
     else:
         workload = get_workload(part, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
         local = cw.run(workload)
+    if n == 0:  # nothing was saved for this locus: no collective has anything to carry
+        out = _store_outputs(locus, overview_path, df_overview, [], reverses, write=rank == 0)
+        tdist.barrier()
+        return out
     records, seq1, off1, seq2, off2 = wdist.gather_called(local, mine, shards, n, world, coll_device)
     results = CallerResults([str(x) for x in saved.index], records, off1, seq1, seq2, 'raise', offsets2=off2).check()
     out = _store_outputs(locus, overview_path, df_overview, results, reverses, write=rank == 0)
