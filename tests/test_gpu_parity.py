@@ -852,4 +852,5 @@ def test_random_loci_reach_every_kind_of_fill_kernel():
     multi = [k for k in kernels if k.startswith('dtw_fill_fast<4, ') and not k.startswith('dtw_fill_fast<4, 1,')]
     assert len(multi) >= 6
     # several slots: the lane-major layout where the automaton fits it (both export sets), the slot-major one elsewhere
-    assert any(k.endswith(', 1>') for k in multi) and any(k.endswith(', 2>') for k in multi) and any(k.endswith('false, 0>') for k in multi)
+    assert any(k.endswith(', 1>') for k in multi) and any(k.endswith(', 2>') or k.endswith(', 3>') for k in multi)
+    assert any(k.endswith('false, 0>') for k in multi)

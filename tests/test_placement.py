@@ -157,8 +157,9 @@ def check_lane_major(t, K, lm, pos, sa):
         inc = t.incoming(j)
         if slot > 0:
             assert len(inc) == 1 and int(pos[inc[0]]) == (slot - 1) * 64 + lane, (j, slot, lane, inc)
-        elif lm == 1:
-            assert all(int(pos[p]) // 64 in (0, K - 1) for p in inc), (j, inc)
+        elif lm in (1, 3):
+            allowed = (0, K - 1) if lm == 1 else (0, 1, K - 1)
+            assert all(int(pos[p]) // 64 in allowed for p in inc), (j, inc)
     for lane in range(64):  # a lane is filled from slot 0 upwards
         filled = [sa[k * 64 + lane] != 0xFFFF for k in range(K)]
         assert filled == sorted(filled, reverse=True)
@@ -172,7 +173,7 @@ def test_lane_major_placement_of_simple_loci(shim, pattern, fl, seed):
     for t in (locus.template, locus.reverse):
         K = (t.n_states + 63) // 64
         lm, pos, sa, lanes = place_lane_major(shim, t, K)
-        assert lm in (1, 2) and lanes <= 64, (pattern, t.n_states, lm, lanes)
+        assert lm in (1, 2, 3) and lanes <= 64, (pattern, t.n_states, lm, lanes)
         check_lane_major(t, K, lm, pos, sa)
 
 

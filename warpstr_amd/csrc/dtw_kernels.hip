@@ -190,7 +190,7 @@ __host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f :
 // LM ("lane-major", wsx_place.h: wsx_place_lane_major): the state in (slot k >= 1, lane l) has ONE predecessor and it sits
 // right below it, in (slot k-1, lane l) -- its candidate is a register of the same lane, two rows old (x[][]), not an LDS
 // read; only slot 0 (chain heads, states with several predecessors, continuations of a chain from the lane before) reads
-// LDS, and only the slots such states read from write it: slots 0 and K-1 (LM = 1) or all (LM = 2).  The slots are then
+// LDS, and only the slots such states read from write it: slots 0 and K-1 (LM = 1), 0, 1 and K-1 (LM = 3) or all (LM = 2).  The slots are then
 // walked downwards, so that slot k takes slot k-1's export of two rows ago before slot k-1 replaces it.
 template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT, int LM = 0>
 __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int wl, double snext,
@@ -243,7 +243,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
         // (wl: the lane's export slot -- its lane number, or for single-slot automata the slot wsx_place.h gave its state)
         const double enew = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
         if (LM != 0 && k < K - 1) st.x[PAR][k] = enew;
-        if (LM == 0 || LM == 2 || k == 0 || k == K - 1) ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = enew;
+        if (LM == 0 || LM == 2 || k == 0 || k == K - 1 || (LM == 3 && k == 1)) ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = enew;
 
     }
     __builtin_amdgcn_wave_barrier();
@@ -1115,8 +1115,15 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipS
 {
     if (lm != 0) { // lane-major placement: slots above 0 take their one predecessor from the lane's own registers
         if constexpr (K >= 2 && M == 4) {
-            if (FL != 1 || pk || lm > 2) return hipErrorInvalidValue;
-            switch (F * 10 + lm) {
+            if (FL != 1 || pk || lm > 3) return hipErrorInvalidValue;
+            if constexpr (K >= 4) {
+                switch (F * 10 + lm) {
+                case 23: return launch_fill<M, K, 2, 1, false, 3>(a, s);
+                case 33: return launch_fill<M, K, 3, 1, false, 3>(a, s);
+                case 43: return launch_fill<M, K, 4, 1, false, 3>(a, s);
+                }
+            }
+            switch (F * 10 + (lm == 3 ? 2 : lm)) {
             case 21: return launch_fill<M, K, 2, 1, false, 1>(a, s);
             case 22: return launch_fill<M, K, 2, 1, false, 2>(a, s);
             case 31: return launch_fill<M, K, 3, 1, false, 1>(a, s);

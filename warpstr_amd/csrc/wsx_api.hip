@@ -40,7 +40,7 @@ struct Variant { // which DP kernel an automaton uses
     bool generic = false;
     int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
-    int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 2 = every slot
+    int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot
     // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
     //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
     //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
@@ -521,7 +521,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                 lp = wsx_place_lane_major(S, A.pred_ptr, A.pred_idx, v.K);
             if (lp.lm != 0) {
                 v.FL = 1;
-                v.lm = lm_mode == 2 ? 2 : lp.lm;
+                v.lm = lm_mode == 2 ? 2 : (lp.lm == 3 && v.K < 4 ? 2 : lp.lm);
             }
             const WsxPlacement pl = lp.lm != 0 ? lp.pl
                                     : getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk

@@ -147,7 +147,7 @@ struct EvalArgs {
 // Host-side launchers (defined next to the kernels).
 // pk: packed mask rows (single-slot automata whose states with two predecessors sit in lanes 0..7): per 16 rows
 // 16 x 8 bytes of first-candidate masks + 2 x 8 bytes holding the second candidate's byte of every row
-// lm: lane-major placement (0 = no; 1 = slots 0 and K-1 export to LDS; 2 = every slot does), dtw_kernels.hip: dp_row
+// lm: lane-major placement (0 = no; 1 = slots 0 and K-1 export to LDS; 3 = slots 0, 1 and K-1; 2 = every slot), dtw_kernels.hip: dp_row
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);

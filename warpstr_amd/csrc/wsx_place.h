@@ -383,12 +383,13 @@ inline WsxPlacement wsx_place_states(int S, const int32_t *pp, const int32_t *pi
 // through LDS), so that such a state ends a piece.  A piece of L = q*K + rem states takes q full lanes; its last rem states
 // either take one more lane (slots 0..rem-1: every slot may then have to export, LM = 2) or one lane EACH, in slot 0 -- then
 // everything a slot-0 state reads sits in slot 0 or slot K-1 and only those two slots write to LDS (LM = 1).  The second
-// form is used while 64 lanes suffice; otherwise the pieces with the largest remainders change to the first form.
+// form is used while 64 lanes suffice; otherwise remainders go two states to a lane (slot 1 exports too: LM = 3), and if
+// that is still too many the pieces with the largest remainders change to the first form.
 // Returns an empty placement when the automaton does not fit the K*64 positions this way.
 // ------------------------------------------------------------------------------------------------------------------
 struct WsxLanePlacement {
     WsxPlacement pl;   // pos, state_at, wslot (identity)
-    int lm = 0;        // 0: does not fit; 1: slots 0 and K-1 export; 2: every slot exports
+    int lm = 0;        // 0: does not fit; 1: slots 0 and K-1 export; 3: slots 0, 1 and K-1; 2: every slot exports
     int lanes = 0;
 };
 
@@ -435,15 +436,35 @@ inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int
             if ((int)pieces.size() > S) return out;
         }
     }
-    // lanes: every piece q full lanes + rem single-state lanes; change the largest remainders to one lane until it fits
-    std::vector<char> packed(pieces.size(), 0);
+    // lanes: every piece q full lanes + rem single-state lanes (LM = 1).  Too many: the remainders go two states to a lane
+    // (slots 0 and 1: slot 1 exports as well, LM = 3), largest remainders first; still too many: a remainder takes one lane
+    // whatever its length (every slot may export, LM = 2).
+    std::vector<char> packed(pieces.size(), 0); // 0: singles, 1: one lane for the whole remainder, 2: pairs (+ a single)
     int lanes = 0;
     for (auto &p : pieces) lanes += (int)p.size() / K + (int)p.size() % K;
     out.lm = 1;
+    if (lanes > 64 && K >= 4) { // (K = 3: slots 0, 1, 2 are all there is)
+        std::vector<char> pairs(pieces.size(), 0);
+        int l3 = lanes;
+        while (l3 > 64) {
+            int best = -1;
+            for (size_t q = 0; q < pieces.size(); q++)
+                if (!pairs[q] && (int)pieces[q].size() % K >= 2 && (best < 0 || pieces[q].size() % K > pieces[best].size() % K))
+                    best = (int)q;
+            if (best < 0) break;
+            pairs[best] = 2;
+            l3 -= ((int)pieces[best].size() % K) / 2;
+        }
+        if (l3 <= 64) {
+            packed = pairs;
+            lanes = l3;
+            out.lm = 3;
+        }
+    }
     while (lanes > 64) {
         int best = -1;
         for (size_t q = 0; q < pieces.size(); q++)
-            if (!packed[q] && (int)pieces[q].size() % K >= 2 &&
+            if (packed[q] != 1 && (int)pieces[q].size() % K >= 2 &&
                 (best < 0 || pieces[q].size() % K > pieces[best].size() % K))
                 best = (int)q;
         if (best < 0) return WsxLanePlacement{};
@@ -467,9 +488,12 @@ inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int
         const int full = (int)p.size() / K, rem = (int)p.size() % K;
         for (int s = 0; s < full * K; s++) put(p[s], s % K, lane + s / K);
         lane += full;
-        if (packed[q]) {
+        if (packed[q] == 1) {
             for (int s = 0; s < rem; s++) put(p[full * K + s], s, lane);
             lane += rem ? 1 : 0;
+        } else if (packed[q] == 2) {
+            for (int s = 0; s < rem; s++) put(p[full * K + s], s % 2, lane + s / 2); // pairs in slots 0, 1; an odd last state alone
+            lane += (rem + 1) / 2;
         } else {
             for (int s = 0; s < rem; s++) put(p[full * K + s], 0, lane + s);
             lane += rem;
