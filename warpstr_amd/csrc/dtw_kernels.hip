@@ -369,164 +369,176 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
     double warm = sig[clampi(64 + lane)];
     uint64_t acc = 0; // packed rows: the bytes of the current half group (rows 8h .. 8h+7) collected so far
 
-    for (int b = 0; b * 64 <= last; b++) {
-        asm volatile("" ::"v"(warm)); // the previous block's warm-up load has landed long ago: no stall
-        warm = sig[clampi((b + 2) * 64 + lane)];
-        const int base = b * 64;
-        int lo = base, hi = base + 64; // rows [lo, hi)
-        if (lo < 1) lo = 1;
-        if (hi > T) hi = T;
-
-        // bm: bit t <=> row base+t exports for a MASKED row (mask bit of sample base+t+2)
-        unsigned long long bm = 0;
-        if (maskw) {
-            const int w0 = 2 * b;
-            const unsigned long long m0 = w0 < nmw ? maskw[w0] : 0u, m1 = w0 + 1 < nmw ? maskw[w0 + 1] : 0u,
-                                     m2 = w0 + 2 < nmw ? maskw[w0 + 2] : 0u;
-            bm = ((m0 | (m1 << 32)) >> 2) | ((m2 & 3ull) << 62);
-            bm = ((unsigned long long)(unsigned)rfl((int)(bm >> 32)) << 32) | (unsigned)rfl((int)bm);
+    // The sample-mask words come through the scalar cache too (read-only during the fill): bit q of the read's mask =
+    // sample q is masked; row r exports for row r+2, so its flag is bit r+2.
+    const WSX_AS4 uint32_t *cm = (const WSX_AS4 uint32_t *)maskw;
+    auto mask_word = [&](int w) -> uint32_t { return (cm && w < nmw) ? cm[w] : 0u; };
+    // rows [i, e) share the flag of row i (e <= phi): scanned a mask word at a time, all scalar
+    auto run_end = [&](int i, int phi, bool &mv) -> int {
+        if (!cm) {
+            mv = false;
+            return phi;
         }
-
-        // one row, everything wave-uniform except the per-lane state; snext = s_{i+1}
-        auto row = [&](auto par, auto forced, auto cut, auto msk, auto rc, uint64_t *gp, double snext) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;
-            constexpr int R = decltype(rc)::value; // row R of the group whose first row's masks are at gp
-            constexpr bool FORCED = decltype(forced)::value;
-            constexpr bool CUT = decltype(cut)::value;
-            constexpr bool MROW = decltype(msk)::value;
-            uint64_t mk[NM];
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
-            if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
-        };
-        // packed rows, one row: the first mask goes to its place in the group of 16, the second one's byte joins `acc`,
-        // which leaves for HBM when the eighth row of its half group has been added
-        auto row_pk = [&](auto par, auto forced, auto cut, auto msk, int r, double snext) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;
-            constexpr bool FORCED = decltype(forced)::value;
-            constexpr bool CUT = decltype(cut)::value;
-            constexpr bool MROW = decltype(msk)::value;
-            uint64_t mk[NM];
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
-            uint64_t *g16 = bp + (size_t)((unsigned)r >> 4) * 18;
-            if (!FORCED) {
-                store_mask<0>(mk[0], g16 + (r & 15));
-                acc |= mk[NM - 1] << ((r & 7) * 8); // bits above 7 are never set: those lanes have one predecessor
+        int q = i + 2; // the sample whose mask bit is row i's flag
+        uint32_t word = mask_word(q >> 5);
+        mv = (word >> (q & 31)) & 1u;
+        const int qend = phi + 2;
+        while (q < qend) {
+            const uint32_t x = (mv ? ~word : word) >> (q & 31); // bits that differ from the run's, from q on
+            if (x != 0u) {
+                q += __builtin_ctz(x);
+                break;
             }
-            if ((r & 7) == 7) {
-                store_mask<0>(acc, g16 + 16 + ((r >> 3) & 1));
-                acc = 0;
+            q = (q | 31) + 1;
+            word = mask_word(q >> 5);
+        }
+        return (q < qend ? q : qend) - 2;
+    };
+    // one row, everything wave-uniform except the per-lane state; snext = s_{i+1}
+    auto row = [&](auto par, auto forced, auto cut, auto msk, auto rc, uint64_t *gp, double snext) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr int R = decltype(rc)::value; // row R of the group whose first row's masks are at gp
+        constexpr bool FORCED = decltype(forced)::value;
+        constexpr bool CUT = decltype(cut)::value;
+        constexpr bool MROW = decltype(msk)::value;
+        uint64_t mk[NM];
+        dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
+        if (!FORCED) store_row_masks<NM, R>(mk, gp); // rows < M hold no pointers and are never read
+    };
+    // packed rows, one row: the first mask goes to its place in the group of 16, the second one's byte joins `acc`,
+    // which leaves for HBM when the eighth row of its half group has been added
+    auto row_pk = [&](auto par, auto forced, auto cut, auto msk, int r, double snext) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FORCED = decltype(forced)::value;
+        constexpr bool CUT = decltype(cut)::value;
+        constexpr bool MROW = decltype(msk)::value;
+        uint64_t mk[NM];
+        dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
+        uint64_t *g16 = bp + (size_t)((unsigned)r >> 4) * 18;
+        if (!FORCED) {
+            store_mask<0>(mk[0], g16 + (r & 15));
+            acc |= mk[NM - 1] << ((r & 7) * 8); // bits above 7 are never set: those lanes have one predecessor
+        }
+        if ((r & 7) == 7) {
+            store_mask<0>(acc, g16 + 16 + ((r >> 3) & 1));
+            acc = 0;
+        }
+    };
+    // the same, the masks handed back instead of stored (the caller stores a whole group at once)
+    auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FORCED = decltype(forced)::value;
+        constexpr bool CUT = decltype(cut)::value;
+        constexpr bool MROW = decltype(msk)::value;
+        dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
+    };
+    // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
+    // 64-byte scalar load; the rows before and after such groups load theirs one by one
+    auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) __attribute__((always_inline)) {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using R0 = std::integral_constant<int, 0>;
+        auto one = [&](int r) __attribute__((always_inline)) {
+            if constexpr (PK) {
+                if (r & 1) row_pk(P1{}, forced, cut, msk, r, sample(r + 1));
+                else row_pk(P0{}, forced, cut, msk, r, sample(r + 1));
+            } else {
+                uint64_t *gp = bp + (size_t)(unsigned)r * NM;
+                if (r & 1) row(P1{}, forced, cut, msk, R0{}, gp, sample(r + 1));
+                else row(P0{}, forced, cut, msk, R0{}, gp, sample(r + 1));
             }
         };
-        // the same, the masks handed back instead of stored (the caller stores a whole group at once)
-        auto row_keep = [&](auto par, auto forced, auto cut, auto msk, double snext, uint64_t (&mk)[NM]) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;
-            constexpr bool FORCED = decltype(forced)::value;
-            constexpr bool CUT = decltype(cut)::value;
-            constexpr bool MROW = decltype(msk)::value;
-            dp_row<M, K, F, FL, MROW, PAR, FORCED, CUT, LM>(st, ex, wl, snext, mk, cutm);
-        };
-        // rows [plo, phi) with constant compile-time flags: aligned groups of eight rows take their samples from one
-        // 64-byte scalar load; the rows before and after such groups load theirs one by one
-        auto span = [&](auto forced, auto cut, auto msk, int plo, int phi) __attribute__((always_inline)) {
-            using P0 = std::integral_constant<int, 0>;
-            using P1 = std::integral_constant<int, 1>;
-            using R0 = std::integral_constant<int, 0>;
-            auto one = [&](int r) __attribute__((always_inline)) {
-                if constexpr (PK) {
-                    if (r & 1) row_pk(P1{}, forced, cut, msk, r, sample(r + 1));
-                    else row_pk(P0{}, forced, cut, msk, r, sample(r + 1));
-                } else {
-                    uint64_t *gp = bp + (size_t)(unsigned)r * NM;
-                    if (r & 1) row(P1{}, forced, cut, msk, R0{}, gp, sample(r + 1));
-                    else row(P0{}, forced, cut, msk, R0{}, gp, sample(r + 1));
-                }
-            };
-            int i = plo;
-            for (; i < phi && (i & 7); i++) one(i);
-            for (; i + 8 <= phi && i + 8 < T; i += 8) {
-                const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
-                uint64_t *gp = bp + (size_t)(unsigned)i * NM;
-                if constexpr (PK && !decltype(forced)::value) {
-                    // eight aligned rows (`acc` is empty here: it was flushed after row i-1): the first masks leave as four
-                    // 16-byte scalar stores, the eight bytes as one 8-byte store -- 72 bytes instead of 128
-                    uint64_t *g16 = bp + (size_t)((unsigned)i >> 4) * 18;
-                    uint64_t m0[4][2]; // rows 2q and 2q+1 side by side: one 16-byte store
-                    uint32_t b_lo = 0, b_hi = 0;
+        int i = plo;
+        for (; i < phi && (i & 7); i++) one(i);
+        for (; i + 8 <= phi && i + 8 < T; i += 8) {
+            // once per 64 rows: the lines two blocks ahead, for the scalar loads (the earlier load has landed long ago: no
+            // stall).  Without it the step is 4 % slower; eight lanes fetching a line every group instead, 2 % slower.
+            if ((i & 63) == 0) {
+                asm volatile("" ::"v"(warm));
+                warm = sig[clampi(i + 128 + lane)];
+            }
+            const d8 v = *(const WSX_AS4 d8u *)(cs + i + 1);
+            uint64_t *gp = bp + (size_t)(unsigned)i * NM;
+            if constexpr (PK && !decltype(forced)::value) {
+                // eight aligned rows (`acc` is empty here: it was flushed after row i-1): the first masks leave as four
+                // 16-byte scalar stores, the eight bytes as one 8-byte store -- 72 bytes instead of 128
+                uint64_t *g16 = bp + (size_t)((unsigned)i >> 4) * 18;
+                uint64_t m0[4][2]; // rows 2q and 2q+1 side by side: one 16-byte store
+                uint32_t b_lo = 0, b_hi = 0;
 #define WSX_ROW(R)                                                                                                  \
-    {                                                                                                               \
-        uint64_t mk[NM];                                                                                            \
-        row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], mk);                                 \
-        m0[(R) / 2][(R) % 2] = mk[0];                                                                               \
-        if constexpr ((R) < 4) b_lo |= (uint32_t)mk[1] << (8 * (R));                                                \
-        else b_hi |= (uint32_t)mk[1] << (8 * ((R)-4));                                                             \
-    }
-                    WSX_ROW(0)
-                    WSX_ROW(1)
-                    WSX_ROW(2)
-                    WSX_ROW(3)
-                    WSX_ROW(4)
-                    WSX_ROW(5)
-                    WSX_ROW(6)
-                    WSX_ROW(7)
+{                                                                                                               \
+    uint64_t mk[NM];                                                                                            \
+    row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], mk);                                 \
+    m0[(R) / 2][(R) % 2] = mk[0];                                                                               \
+    if constexpr ((R) < 4) b_lo |= (uint32_t)mk[1] << (8 * (R));                                                \
+    else b_hi |= (uint32_t)mk[1] << (8 * ((R)-4));                                                             \
+}
+                WSX_ROW(0)
+                WSX_ROW(1)
+                WSX_ROW(2)
+                WSX_ROW(3)
+                WSX_ROW(4)
+                WSX_ROW(5)
+                WSX_ROW(6)
+                WSX_ROW(7)
 #undef WSX_ROW
-                    uint64_t *gp8 = g16 + (i & 8);
-                    store_row_group<2, 4, 0>(m0, gp8);
-                    store_mask<0>(((uint64_t)b_hi << 32) | b_lo, g16 + 16 + ((i >> 3) & 1));
-                } else if constexpr (PK) {
-                    for (int q = 0; q < 8; q++) one(i + q); // (forced rows: the first four rows of a read)
-                } else if constexpr (NM <= 4 && !decltype(forced)::value) {
-                    // The scalar stores of G rows leave together (G = as many rows as fit ~32 SGPRs of masks; single-slot
-                    // automata: with more masks per row the grouping bought nothing).  A scalar
-                    // store counts on the same counter as the LDS reads and completes out of order with them, so a store
-                    // in flight turns every counted LDS wait behind it into a wait for the store as well.
-                    constexpr int G = NM <= 2 ? 8 : 4;
-                    uint64_t gm[G][NM];
+                uint64_t *gp8 = g16 + (i & 8);
+                store_row_group<2, 4, 0>(m0, gp8);
+                store_mask<0>(((uint64_t)b_hi << 32) | b_lo, g16 + 16 + ((i >> 3) & 1));
+            } else if constexpr (PK) {
+                for (int q = 0; q < 8; q++) one(i + q); // (forced rows: the first four rows of a read)
+            } else if constexpr (NM <= 4 && !decltype(forced)::value) {
+                // The scalar stores of G rows leave together (G = as many rows as fit ~32 SGPRs of masks; single-slot
+                // automata: with more masks per row the grouping bought nothing).  A scalar
+                // store counts on the same counter as the LDS reads and completes out of order with them, so a store
+                // in flight turns every counted LDS wait behind it into a wait for the store as well.
+                constexpr int G = NM <= 2 ? 8 : 4;
+                uint64_t gm[G][NM];
 #define WSX_ROW(R)                                                                                                  \
-    row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], gm[(R) % G]);                            \
-    if constexpr (((R) % G) == G - 1) store_row_group<NM, G, (R) - (G - 1)>(gm, gp);
-                    WSX_ROW(0)
-                    WSX_ROW(1)
-                    WSX_ROW(2)
-                    WSX_ROW(3)
-                    WSX_ROW(4)
-                    WSX_ROW(5)
-                    WSX_ROW(6)
-                    WSX_ROW(7)
+row_keep(std::integral_constant<int, (R)&1>{}, forced, cut, msk, v[R], gm[(R) % G]);                            \
+if constexpr (((R) % G) == G - 1) store_row_group<NM, G, (R) - (G - 1)>(gm, gp);
+                WSX_ROW(0)
+                WSX_ROW(1)
+                WSX_ROW(2)
+                WSX_ROW(3)
+                WSX_ROW(4)
+                WSX_ROW(5)
+                WSX_ROW(6)
+                WSX_ROW(7)
 #undef WSX_ROW
-                } else {
-                    row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
-                    row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
-                    row(P0{}, forced, cut, msk, std::integral_constant<int, 2>{}, gp, v[2]);
-                    row(P1{}, forced, cut, msk, std::integral_constant<int, 3>{}, gp, v[3]);
-                    row(P0{}, forced, cut, msk, std::integral_constant<int, 4>{}, gp, v[4]);
-                    row(P1{}, forced, cut, msk, std::integral_constant<int, 5>{}, gp, v[5]);
-                    row(P0{}, forced, cut, msk, std::integral_constant<int, 6>{}, gp, v[6]);
-                    row(P1{}, forced, cut, msk, std::integral_constant<int, 7>{}, gp, v[7]);
-                }
+            } else {
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 0>{}, gp, v[0]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 1>{}, gp, v[1]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 2>{}, gp, v[2]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 3>{}, gp, v[3]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 4>{}, gp, v[4]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 5>{}, gp, v[5]);
+                row(P0{}, forced, cut, msk, std::integral_constant<int, 6>{}, gp, v[6]);
+                row(P1{}, forced, cut, msk, std::integral_constant<int, 7>{}, gp, v[7]);
             }
-            for (; i < phi; i++) one(i);
-        };
-        // a phase, split into maximal runs of equal mask bit so that the row code is branch-free
-        auto phase = [&](auto forced, auto cut, int plo, int phi) __attribute__((always_inline)) {
-            int i = plo;
-            while (i < phi) {
-                const unsigned long long rest = bm >> (i - base);
-                const bool mv = rest & 1ull;
-                const unsigned long long x = mv ? ~rest : rest;
-                const int len = x ? __builtin_ctzll(x) : 64;
-                const int e = (i + len < phi) ? i + len : phi;
-                if (mv) span(forced, cut, std::true_type{}, i, e);
-                else span(forced, cut, std::false_type{}, i, e);
-                i = e;
-            }
-        };
-        const int e0 = hi < M ? hi : M;               // forced rows end
-        const int e1 = hi < cut_from ? hi : cut_from; // plain rows end
-        const int e2 = hi < cut_end ? hi : cut_end;   // rows that force the cut end
-        phase(std::true_type{}, std::false_type{}, lo, e0);
-        phase(std::false_type{}, std::false_type{}, lo > M ? lo : M, e1);
-        phase(std::false_type{}, std::true_type{}, lo > cut_from ? lo : cut_from, e2);
-        phase(std::false_type{}, std::false_type{}, lo > cut_end ? lo : cut_end, hi);
+        }
+        for (; i < phi; i++) one(i);
+    };
+    // A phase (forced rows, plain rows, the rows that force the corner cut, plain rows again) is cut into maximal runs of equal
+    // mask flag, so that the row code is branch-free; a run is NOT cut at 64-row boundaries any more: every change from one
+    // run's code to another's costs a shuffle of the whole state between the registers the two loops were allocated (26 moves
+    // for four slots), which at one change per 64 rows was 0.5-1.1 vector instructions per row.
+    auto phase = [&](auto forced, auto cut, int plo, int phi) __attribute__((always_inline)) {
+        int i = plo;
+        while (i < phi) {
+            bool mv;
+            const int e = run_end(i, phi, mv);
+            if (mv) span(forced, cut, std::true_type{}, i, e);
+            else span(forced, cut, std::false_type{}, i, e);
+            i = e;
+        }
+    };
+    {
+        const int e0 = T < M ? T : M; // forced rows end
+        phase(std::true_type{}, std::false_type{}, 1, e0);
+        phase(std::false_type{}, std::false_type{}, M, cut_from);
+        phase(std::false_type{}, std::true_type{}, cut_from, cut_end);
+        phase(std::false_type{}, std::false_type{}, cut_end, T);
     }
 
     if constexpr (PK) { // the last half group of the read, if it is not complete
