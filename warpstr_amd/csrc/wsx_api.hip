@@ -594,6 +594,17 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         c->n_states.push_back(S);
         c->max_states = std::max(c->max_states, S);
     }
+    // Fewer launch groups per chunk: every kernel variant among a chunk's reads is a launch of its own on the chunk's stream, and
+    // a minority variant's few hundred wavefronts last as long as their longest read (configs[4]: the three- and four-candidate
+    // variants, 12 % of the reads, took 1.8 of a pass's 4.3 ms).  Variants that differ only in the number of candidates of slot
+    // 0 share the larger kernel where the difference is one candidate (three vector instructions per row for those reads).
+    // (Their launches on side streams instead: slower, 17.1-22 vs 16.4 ms per step -- more streams than the runtime's queues.)
+    if (!getenv("WSX_NO_VARIANT_MERGE"))
+        for (auto &v : c->variant) {
+            if (v.generic || v.pk || v.K < 2) continue;
+            for (const auto &u : c->variant)
+                if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == v.F + 1 && v.F >= 3) v.F = u.F;
+        }
     HIPCHK(hipMemcpy(c->aut_blob.p, hblob.data(), blob, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&c->ev_begin));
