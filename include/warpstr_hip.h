@@ -67,7 +67,7 @@ enum {
     WSX_READ_BACKTRACK = 2,     /* upstream RuntimeError, caller.py:290-291 */
     WSX_READ_FIT_POINTS = 3,    /* < 4 states pass filter_alignment (upstream: splrep TypeError) */
     WSX_READ_FIT_ORDER = 4,     /* degenerate abscissae for the rescaling fit */
-    WSX_READ_FIT_SMOOTH = 5,    /* residual of the cubic >= 1.001 s: upstream FITPACK would add knots (needs threshold > 1) */
+    WSX_READ_FIT_SMOOTH = 5,    /* FITPACK's smoothing spline (threshold > 1 only) has a coefficient that is not finite */
     WSX_READ_NO_REPEAT = 6,     /* no repeat state on the path (upstream IndexError, caller.py:384) */
     WSX_READ_SEGMENT_RANGE = 7, /* upstream IndexError in find_event_borders/segment (caller.py:395-397) */
 };
@@ -92,7 +92,7 @@ typedef struct wsx_automaton {
 typedef struct wsx_params {
     int32_t min_values_per_state; /* tr_calling_config.min_values_per_state, default 4 (> 1) */
     int32_t states_in_segment;    /* tr_calling_config.states_in_segment, default 6 (> 1) */
-    double threshold;             /* rescaling.threshold, default 0.5 (> 0; above 1 a read may come back WSX_READ_FIT_SMOOTH) */
+    double threshold;             /* rescaling.threshold, default 0.5 (> 0; above 1 FITPACK's smoothing branch can be taken) */
     double max_std;               /* rescaling.max_std, default 0.5 */
     int32_t method_median;        /* rescaling.method: 0 = mean, 1 = median */
     int32_t reps_as_one;          /* rescaling.reps_as_one (0/1) */

@@ -37,7 +37,7 @@ class _Result(C.Structure):
 
 class _Debug(C.Structure):
     _fields_ = [('trace1', C.c_void_p), ('trace2', C.c_void_p), ('rescaled', C.c_void_p), ('rescaled2', C.c_void_p),
-                ('badmask', C.c_void_p), ('dlast1', C.c_void_p), ('dlast2', C.c_void_p), ('idx', C.c_int64 * 4)]
+                ('badmask', C.c_void_p), ('dlast1', C.c_void_p), ('dlast2', C.c_void_p), ('idx', C.c_int64 * 4), ('fit_knots', C.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -163,6 +163,44 @@ def eval_cubic(t, c, x):
     return out
 
 
+def curfit(x, y, s=None):
+    """splrep(x, y, s=s) in full (k = 3, unit weights): knots, coefficients (n each, the last four zero), fp, ier."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    m = len(x)
+    t, c = np.zeros(m + 16), np.zeros(m + 16)
+    n, fp, ier = C.c_int(), C.c_double(), C.c_int()
+    rc = lib().wso_curfit(_p(x), _p(y), C.c_long(m), C.c_double(float(m if s is None else s)), _p(t), _p(c), C.byref(n),
+                          C.byref(fp), C.byref(ier))
+    if rc:
+        raise RuntimeError(f'oracle curfit: {STATUS[rc]}')
+    return t[:n.value].copy(), c[:n.value].copy(), fp.value, ier.value
+
+
+def splev(t, c, x):
+    """splev(x, (t, c, 3)), ext = 0."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().wso_splev(_p(t), C.c_int(len(t)), _p(c), _p(x), C.c_long(len(x)), _p(out))
+    return out
+
+
+def rescale_signal(sig, value, expected, good):
+    """rescale_signal over alignment records (value, expected, good_enough) -- caller.py:304-318."""
+    sig = np.ascontiguousarray(sig, dtype=np.float64)
+    value = np.ascontiguousarray(value, dtype=np.float64)
+    expected = np.ascontiguousarray(expected, dtype=np.float64)
+    good = np.ascontiguousarray(good, dtype=np.uint8)
+    out = np.empty_like(sig)
+    rc = lib().wso_rescale_signal(_p(sig), C.c_long(len(sig)), _p(value), _p(expected), _p(good), C.c_long(len(value)), _p(out),
+                                  None, None)
+    if rc:
+        raise RuntimeError(f'oracle rescale_signal: {STATUS[rc]}')
+    return out
+
+
 def segment(data, win=3):
     data = np.ascontiguousarray(data, dtype=np.float64)
     return lib().wso_segment(_p(data), C.c_long(len(data)), C.c_int(win))
@@ -187,6 +225,7 @@ class ReadCall:
     dlast1: Optional[np.ndarray] = None
     dlast2: Optional[np.ndarray] = None
     idx: Optional[tuple] = None
+    fit_knots: Optional[int] = None  # knots of the first pass's spline (8: the cubic; more: FITPACK's smoothing branch)
 
 
 def call_read(aut: Automaton, sig, params: Params = Params(), debug: bool = True) -> ReadCall:
@@ -201,7 +240,7 @@ def call_read(aut: Automaton, sig, params: Params = Params(), debug: bool = True
         dbg = _Debug(_p(b['trace1']), _p(b['trace2']), _p(b['rescaled']), _p(b['rescaled2']), _p(b['badmask']),
                      _p(b['dlast1']), _p(b['dlast2']))
         lib().wso_call_read(C.byref(aut.c), C.byref(pc), _p(sig), C.c_long(T), C.byref(res), C.byref(dbg))
-        extra = dict(b, idx=tuple(dbg.idx))
+        extra = dict(b, idx=tuple(dbg.idx), fit_knots=int(dbg.fit_knots))
     else:
         lib().wso_call_read(C.byref(aut.c), C.byref(pc), _p(sig), C.c_long(T), C.byref(res), None)
         extra = {}

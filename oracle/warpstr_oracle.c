@@ -382,6 +382,410 @@ void wso_eval_cubic(const double t[8], const double c[4], const double *x, long 
     }
 }
 
+/*
+ * splrep(x, y, s = s) in full: FITPACK curfit/fpcurf for k = 3, unit weights, iopt = 0, tol = 0.001, maxit = 20,
+ * nest = max(m + 4, 9) (scipy.interpolate.splrep's choices) -- src/caller/caller.py:311 whatever rescaling.threshold is.
+ * Part 1 (fpcurf's main loop): least-squares spline on the current knots by Givens rotations; while fp - s >= acc
+ * knots are added where the residual is largest (fpknot), their number per round following the decrease of fp.
+ * Part 2: the smoothing spline -- the rows of the third-derivative jumps (fpdisc) weighted 1/p are rotated into the
+ * triangle and p is iterated by rational interpolation (fprati) until |f(p) - s| < acc.
+ * Arrays are 1-based as in the published routines so that the index arithmetic reads the same.
+ * t, c: room for m + 4 (at least 9) doubles each.  *ier: FITPACK's ier (-2 polynomial, -1 interpolating, 0 smoothing, 1..3).
+ * Pinned bit for bit against SciPy's compiled FITPACK: tests/test_oracle_golden.py::test_fitpack_smoothing_bitwise.
+ */
+static void fpback_n(double *const *a, const double *z, int n, int k, double *c)
+{
+    const int k1 = k - 1;
+    c[n] = z[n] / a[n][1];
+    int i = n - 1;
+    if (i == 0) return;
+    for (int j = 2; j <= n; j++) {
+        double store = z[i];
+        int i1 = k1;
+        if (j <= k1) i1 = j - 1;
+        int mm = i;
+        for (int l = 1; l <= i1; l++) {
+            mm = mm + 1;
+            store = store - c[mm] * a[i][l + 1];
+        }
+        c[i] = store / a[i][1];
+        i = i - 1;
+    }
+}
+
+/* fpdisc: discontinuity jumps of the k-th derivative of the B-splines at the interior knots */
+static void fpdisc(const double *t, int n, int k2, double *const *b)
+{
+    double h[13];
+    const int k1 = k2 - 1, k = k1 - 1, nk1 = n - k1, nrint = nk1 - k;
+    const double an = (double)nrint;
+    const double fac = an / (t[nk1 + 1] - t[k1]);
+    for (int l = k2; l <= nk1; l++) {
+        const int lmk = l - k1;
+        for (int j = 1; j <= k1; j++) {
+            const int ik = j + k1, lj = l + j, lk = lj - k2;
+            h[j] = t[l] - t[lk];
+            h[ik] = t[l] - t[lj];
+        }
+        int lp = lmk;
+        for (int j = 1; j <= k2; j++) {
+            int jk = j;
+            double prod = h[j];
+            for (int i = 1; i <= k; i++) {
+                jk = jk + 1;
+                prod = prod * h[jk] * fac;
+            }
+            const int lk = lp + k1;
+            b[lmk][j] = (t[lk] - t[lp]) / prod;
+            lp = lp + 1;
+        }
+    }
+}
+
+/* fpknot: one more knot in the interval with the largest residual that still holds data points */
+static void fpknot(const double *x, double *t, int *n, double *fpint, int *nrdata, int *nrint, int istart)
+{
+    const int k = (*n - *nrint - 1) / 2;
+    double fpmax = 0.0;
+    int jbegin = istart, number = 0, maxpt = 0, maxbeg = 0;
+    for (int j = 1; j <= *nrint; j++) {
+        const int jpoint = nrdata[j];
+        if (!(fpmax >= fpint[j] || jpoint == 0)) {
+            fpmax = fpint[j];
+            number = j;
+            maxpt = jpoint;
+            maxbeg = jbegin;
+        }
+        jbegin = jbegin + jpoint + 1;
+    }
+    if (number == 0) return; /* (SciPy's copy leaves here too: no interval can take a knot) */
+    const int ihalf = maxpt / 2 + 1;
+    const int nrx = maxbeg + ihalf;
+    const int next = number + 1;
+    if (next <= *nrint)
+        for (int j = next; j <= *nrint; j++) {
+            const int jj = next + *nrint - j;
+            fpint[jj + 1] = fpint[jj];
+            nrdata[jj + 1] = nrdata[jj];
+            const int jk = jj + k;
+            t[jk + 1] = t[jk];
+        }
+    nrdata[number] = ihalf - 1;
+    nrdata[next] = maxpt - ihalf;
+    const double am = (double)maxpt;
+    double an = (double)nrdata[number];
+    fpint[number] = fpmax * an / am;
+    an = (double)nrdata[next];
+    fpint[next] = fpmax * an / am;
+    const int jk = next + k;
+    t[jk] = x[nrx];
+    *n = *n + 1;
+    *nrint = *nrint + 1;
+}
+
+static double fprati(double *p1, double *f1, double p2, double f2, double *p3, double *f3)
+{
+    double p;
+    if (*p3 > 0.0) {
+        const double h1 = *f1 * (f2 - *f3), h2 = f2 * (*f3 - *f1), h3 = *f3 * (*f1 - f2);
+        p = -(*p1 * p2 * h3 + p2 * *p3 * h1 + *p3 * *p1 * h2) / (*p1 * h1 + p2 * h2 + *p3 * h3);
+    } else {
+        p = (*p1 * (*f1 - *f3) * f2 - p2 * (f2 - *f3) * *f1) / ((*f1 - f2) * *f3);
+    }
+    if (f2 < 0.0) {
+        *p3 = p2;
+        *f3 = f2;
+    } else {
+        *p1 = p2;
+        *f1 = f2;
+    }
+    return p;
+}
+
+int wso_curfit(const double *x0, const double *y0, long m_, double s, double *t_out, double *c_out, int *n_out, double *fp_out,
+               int *ier_out)
+{
+    enum { K = 3, K1 = 4, K2 = 5, MAXIT = 20 };
+    const double tol = 0.001, con1 = 0.1, con9 = 0.9, con4 = 0.04, half = 0.5;
+    const int m = (int)m_;
+    if (m < K1) return WSO_ERR_FIT_POINTS;
+    for (int i = 1; i < m; i++)
+        if (x0[i - 1] > x0[i]) return WSO_ERR_FIT_ORDER;
+    if (!(x0[0] < x0[m - 1])) return WSO_ERR_FIT_ORDER;
+    const int nest = m + K1 > 2 * K + 3 ? m + K1 : 2 * K + 3;
+    const double *x = x0 - 1, *y = y0 - 1; /* 1-based views */
+    const double xb = x[1], xe = x[m];
+    /* work arrays */
+    size_t nd = (size_t)nest + 2;
+    double *t = (double *)calloc(nd, sizeof(double)), *c = (double *)calloc(nd, sizeof(double));
+    double *z = (double *)calloc(nd, sizeof(double)), *fpint = (double *)calloc(nd, sizeof(double));
+    int *nrdata = (int *)calloc(nd, sizeof(int));
+    double *abuf = (double *)calloc(nd * (K1 + 1), sizeof(double)), *bbuf = (double *)calloc(nd * (K2 + 1), sizeof(double));
+    double *gbuf = (double *)calloc(nd * (K2 + 1), sizeof(double)), *qbuf = (double *)calloc(((size_t)m + 1) * (K1 + 1), sizeof(double));
+    double **a = (double **)malloc(nd * sizeof(double *)), **b = (double **)malloc(nd * sizeof(double *));
+    double **g = (double **)malloc(nd * sizeof(double *)), **q = (double **)malloc(((size_t)m + 1) * sizeof(double *));
+    for (size_t i = 0; i < nd; i++) {
+        a[i] = abuf + i * (K1 + 1);
+        b[i] = bbuf + i * (K2 + 1);
+        g[i] = gbuf + i * (K2 + 1);
+    }
+    for (int i = 0; i <= m; i++) q[i] = qbuf + (size_t)i * (K1 + 1);
+    double h[8];
+    const int nmin = 2 * K1;
+    const double acc = tol * s;
+    const int nmax = m + K1;
+    int n = nmin, ier = 0, nplus = 0, nrint = 0, nk1 = 0;
+    double fp = 0.0, fp0 = 0.0, fpold = 0.0, fpms = 0.0;
+    nrdata[1] = m - 2;
+    int restart = 1;
+    while (restart) { /* label 60: re-entered once from "go to 10" (knots of the interpolating spline) */
+        restart = 0;
+        for (int iter = 1; iter <= m; iter++) {
+            if (n == nmin) ier = -2;
+            nrint = n - nmin + 1;
+            nk1 = n - K1;
+            int i = n;
+            for (int j = 1; j <= K1; j++) {
+                t[j] = xb;
+                t[i] = xe;
+                i = i - 1;
+            }
+            fp = 0.0;
+            for (i = 1; i <= nk1; i++) {
+                z[i] = 0.0;
+                for (int j = 1; j <= K1; j++) a[i][j] = 0.0;
+            }
+            int l = K1;
+            for (int it = 1; it <= m; it++) {
+                const double xi = x[it], wi = 1.0;
+                double yi = y[it] * wi;
+                while (!(xi < t[l + 1] || l == nk1)) l = l + 1;
+                fpbspl(t, K, xi, l, h);
+                for (i = 1; i <= K1; i++) {
+                    q[it][i] = h[i];
+                    h[i] = h[i] * wi;
+                }
+                int j = l - K1;
+                for (i = 1; i <= K1; i++) {
+                    j = j + 1;
+                    const double piv = h[i];
+                    if (piv == 0.0) continue;
+                    double cs, sn;
+                    fpgivs(piv, &a[j][1], &cs, &sn);
+                    fprota(cs, sn, &yi, &z[j]);
+                    if (i == K1) break;
+                    int i2 = 1;
+                    for (int i1 = i + 1; i1 <= K1; i1++) {
+                        i2 = i2 + 1;
+                        fprota(cs, sn, &h[i1], &a[j][i2]);
+                    }
+                }
+                fp = fp + yi * yi;
+            }
+            if (ier == -2) fp0 = fp;
+            fpint[n] = fp0;
+            fpint[n - 1] = fpold;
+            nrdata[n] = nplus;
+            fpback_n(a, z, nk1, K1, c);
+            fpms = fp - s;
+            if (fabs(fpms) < acc) goto done;
+            if (fpms < 0.0) goto part2;
+            if (n == nmax) {
+                ier = -1;
+                goto done;
+            }
+            if (n == nest) {
+                ier = 1;
+                goto done;
+            }
+            if (ier != 0) {
+                nplus = 1;
+                ier = 0;
+            } else {
+                int npl1 = nplus * 2;
+                const double rn = (double)nplus;
+                if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+                int mx = npl1 > nplus / 2 ? npl1 : nplus / 2;
+                if (mx < 1) mx = 1;
+                nplus = nplus * 2 < mx ? nplus * 2 : mx;
+            }
+            fpold = fp;
+            double fpart = 0.0;
+            i = 1;
+            l = K2;
+            int nw = 0;
+            for (int it = 1; it <= m; it++) {
+                if (!(x[it] < t[l] || l > nk1)) {
+                    nw = 1;
+                    l = l + 1;
+                }
+                double term = 0.0;
+                int l0 = l - K2;
+                for (int j = 1; j <= K1; j++) {
+                    l0 = l0 + 1;
+                    term = term + c[l0] * q[it][j];
+                }
+                term = (1.0 * (term - y[it])) * (1.0 * (term - y[it]));
+                fpart = fpart + term;
+                if (nw == 0) continue;
+                const double store = term * half;
+                fpint[i] = fpart - store;
+                i = i + 1;
+                fpart = store;
+                nw = 0;
+            }
+            fpint[nrint] = fpart;
+            int to_interp = 0;
+            for (l = 1; l <= nplus; l++) {
+                fpknot(x, t, &n, fpint, nrdata, &nrint, 1);
+                if (n == nmax) {
+                    to_interp = 1;
+                    break;
+                }
+                if (n == nest) break;
+            }
+            if (to_interp) { /* label 10: the knots of the interpolating spline, then the main loop from its start */
+                const int mk1 = m - K1;
+                int ii = K2, jj = K / 2 + 2;
+                for (l = 1; l <= mk1; l++) {
+                    t[ii] = x[jj];
+                    ii = ii + 1;
+                    jj = jj + 1;
+                }
+                restart = 1;
+                break;
+            }
+        }
+        if (restart) continue;
+        break;
+    }
+part2:
+    if (ier == -2) goto done;
+    {
+        fpdisc(t, n, K2, b);
+        double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 0.0;
+        for (int i = 1; i <= nk1; i++) p = p + a[i][1];
+        const double rn = (double)nk1;
+        p = rn / p;
+        int ich1 = 0, ich3 = 0;
+        const int n8 = n - nmin;
+        int iter;
+        for (iter = 1; iter <= MAXIT; iter++) {
+            const double pinv = 1.0 / p;
+            for (int i = 1; i <= nk1; i++) {
+                c[i] = z[i];
+                g[i][K2] = 0.0;
+                for (int j = 1; j <= K1; j++) g[i][j] = a[i][j];
+            }
+            for (int it = 1; it <= n8; it++) {
+                for (int i = 1; i <= K2; i++) h[i] = b[it][i] * pinv;
+                double yi = 0.0;
+                for (int j = it; j <= nk1; j++) {
+                    const double piv = h[1];
+                    double cs, sn;
+                    fpgivs(piv, &g[j][1], &cs, &sn);
+                    fprota(cs, sn, &yi, &c[j]);
+                    if (j == nk1) break;
+                    int i2 = K1;
+                    if (j > n8) i2 = nk1 - j;
+                    for (int i = 1; i <= i2; i++) {
+                        const int i1 = i + 1;
+                        fprota(cs, sn, &h[i1], &g[j][i1]);
+                        h[i] = h[i1];
+                    }
+                    h[i2 + 1] = 0.0;
+                }
+            }
+            fpback_n(g, c, nk1, K2, c);
+            fp = 0.0;
+            int l = K2;
+            for (int it = 1; it <= m; it++) {
+                if (!(x[it] < t[l] || l > nk1)) l = l + 1;
+                int l0 = l - K2;
+                double term = 0.0;
+                for (int j = 1; j <= K1; j++) {
+                    l0 = l0 + 1;
+                    term = term + c[l0] * q[it][j];
+                }
+                fp = fp + (1.0 * (term - y[it])) * (1.0 * (term - y[it]));
+            }
+            fpms = fp - s;
+            if (fabs(fpms) < acc) goto done;
+            if (iter == MAXIT) {
+                ier = 3;
+                goto done;
+            }
+            const double p2 = p, f2 = fpms;
+            if (ich3 == 0) {
+                if (!(f2 - f3 > acc)) { /* the initial choice of p is too large */
+                    p3 = p2;
+                    f3 = f2;
+                    p = p * con4;
+                    if (p <= p1) p = p1 * con9 + p2 * con1;
+                    continue;
+                }
+                if (f2 < 0.0) ich3 = 1;
+            }
+            if (ich1 == 0) {
+                if (!(f1 - f2 > acc)) { /* the initial choice of p is too small */
+                    p1 = p2;
+                    f1 = f2;
+                    p = p / con4;
+                    if (p3 < 0.0) continue;
+                    if (p >= p3) p = p2 * con1 + p3 * con9;
+                    continue;
+                }
+                if (f2 > 0.0) ich1 = 1;
+            }
+            if (f2 >= f1 || f2 <= f3) {
+                ier = 2;
+                goto done;
+            }
+            p = fprati(&p1, &f1, p2, f2, &p3, &f3);
+        }
+    }
+done:
+    for (int i = 1; i <= n; i++) {
+        t_out[i - 1] = t[i];
+        c_out[i - 1] = i <= n - K1 ? c[i] : 0.0;
+    }
+    *n_out = n;
+    if (fp_out) *fp_out = fp;
+    if (ier_out) *ier_out = ier;
+    free(t); free(c); free(z); free(fpint); free(nrdata); free(abuf); free(bbuf); free(gbuf); free(qbuf);
+    free(a); free(b); free(g); free(q);
+    return WSO_OK;
+}
+
+/* splev(x, (t, c, 3)) with ext = 0 for any knot vector: src/caller/caller.py:312. */
+void wso_splev(const double *t0, int n, const double *c0, const double *x, long cnt, double *out)
+{
+    enum { K1 = 4, K2 = 5 };
+    const double *t = t0 - 1, *c = c0 - 1;
+    const int nk1 = n - K1;
+    int l = K1, l1 = l + 1;
+    double h[8];
+    for (long i = 0; i < cnt; i++) {
+        const double arg = x[i];
+        while (!(arg >= t[l] || l1 == K2)) {
+            l1 = l;
+            l = l - 1;
+        }
+        while (!(arg < t[l1] || l == nk1)) {
+            l = l1;
+            l1 = l + 1;
+        }
+        fpbspl(t, 3, arg, l, h);
+        double sp = 0.0;
+        int ll = l - K1;
+        for (int j = 1; j <= K1; j++) {
+            ll = ll + 1;
+            sp = sp + c[ll] * h[j];
+        }
+        out[i] = sp;
+    }
+}
+
 typedef struct {
     double x, y;
     long k;
@@ -418,10 +822,32 @@ int wso_rescale_signal(const double *sig, long T, const double *value, const dou
     double t[8], c[4], fp;
     int rc = wso_fit_cubic(x, y, m, t, c, &fp);
     free(pr);
-    free(x);
-    if (rc != WSO_OK) return rc;
+    if (rc != WSO_OK) {
+        free(x);
+        return rc;
+    }
     /* fpcurf: fpms = fp - s; |fpms| < acc (= 0.001 s) or fpms < 0 keeps the polynomial (ier = -2) */
-    if (!(fp - (double)m < 0.001 * (double)m)) return WSO_ERR_FIT_SMOOTH; /* knots would be added: not restated */
+    if (!(fp - (double)m < 0.001 * (double)m)) {
+        /* possible with rescaling.threshold > 1 only: knots are added and the spline is smoothed (wso_curfit); ier 1..3 are
+         * warnings in splrep and upstream goes on.  A spline with a coefficient that is not finite (coinciding abscissae
+         * can do that) is refused on both sides of the parity tests: the second pass has nothing to align to. */
+        double *tk = (double *)malloc(sizeof(double) * (size_t)(2 * (m + 16)));
+        double *ck = tk + m + 16;
+        int n = 0, ier = 0, finite = 1;
+        rc = wso_curfit(x, y, m, (double)m, tk, ck, &n, NULL, &ier);
+        for (int i = 0; rc == WSO_OK && i < n - 4; i++) finite = finite && isfinite(ck[i]);
+        if (rc == WSO_OK && !finite) rc = WSO_ERR_FIT_SMOOTH;
+        if (rc == WSO_OK) wso_splev(tk, n, ck, sig, T, out);
+        free(tk);
+        free(x);
+        if (rc == WSO_OK && tck_t) { /* (the caller's 8 + 4 doubles cannot hold it: NaN marks the smoothing spline) */
+            for (int i = 0; i < 8; i++) tck_t[i] = NAN;
+            for (int i = 0; i < 4; i++) tck_c[i] = NAN;
+            tck_t[1] = (double)n; /* its number of knots */
+        }
+        return rc;
+    }
+    free(x);
     wso_eval_cubic(t, c, sig, T, out);
     if (tck_t) memcpy(tck_t, t, sizeof(t));
     if (tck_c) memcpy(tck_c, c, sizeof(c));
@@ -630,7 +1056,11 @@ int wso_call_read(const wso_automaton *A, const wso_params *P, const double *sig
     R->n_trans1 = (int32_t)ntr;
 
     n1 = wso_create_alignment(A, P, trace1, sig, T, v1, e1, g1);
-    if ((rc = wso_rescale_signal(sig, T, v1, e1, g1, n1, resc, NULL, NULL)) != WSO_OK) goto done;
+    {
+        double tk[8], ck[4];
+        if ((rc = wso_rescale_signal(sig, T, v1, e1, g1, n1, resc, tk, ck)) != WSO_OK) goto done;
+        if (dbg) dbg->fit_knots = isnan(tk[0]) ? (int64_t)tk[1] : 8;
+    }
     if (dbg && dbg->rescaled) memcpy(dbg->rescaled, resc, sizeof(double) * (size_t)T);
     if ((rc = wso_mask_bad_repeats(A, P, sig, T, trace1, &start, &end, bad)) != WSO_OK) goto done;
     if (dbg && dbg->badmask) memcpy(dbg->badmask, bad, (size_t)T);
@@ -651,7 +1081,7 @@ int wso_call_read(const wso_automaton *A, const wso_params *P, const double *sig
      * come from the state path alone.  If FITPACK leaves its polynomial branch HERE (possible with rescaling.threshold > 1)
      * upstream goes on with a smoothing spline nobody looks at: not an error of the read. */
     rc = wso_rescale_signal(resc, T, v2, e2, g2, n2, resc2, NULL, NULL);
-    if (rc == WSO_ERR_FIT_SMOOTH) {
+    if (rc == WSO_ERR_FIT_SMOOTH) { /* (a spline that is not finite: upstream goes on, nobody looks at it) */
         memcpy(resc2, resc, sizeof(double) * (size_t)T);
         rc = WSO_OK;
     }

@@ -17,7 +17,7 @@ enum {
     WSO_ERR_BACKTRACK = 2,     /* RuntimeError, caller.py:290-291 */
     WSO_ERR_FIT_POINTS = 3,    /* fewer than 4 states survive filter_alignment (splrep TypeError) */
     WSO_ERR_FIT_ORDER = 4,     /* degenerate abscissae (all equal) */
-    WSO_ERR_FIT_SMOOTH = 5,    /* fp >= s: FITPACK would add knots (rescaling.threshold > 1); not restated */
+    WSO_ERR_FIT_SMOOTH = 5,    /* FITPACK's smoothing spline (rescaling.threshold > 1) came out with a coefficient that is not finite */
     WSO_ERR_NO_REPEAT = 6,     /* no repeat state on the path (trues[0] IndexError, caller.py:384) */
     WSO_ERR_SEGMENT_RANGE = 7, /* IndexError in find_event_borders/segment (caller.py:395-397, 361) */
 };
@@ -57,6 +57,7 @@ typedef struct { /* optional per-read intermediates; any pointer may be NULL */
     uint8_t *badmask;           /* [T] */
     double *dlast1, *dlast2;    /* [S] last DP row of each pass */
     int64_t idx[4];             /* start, end, resc_start, resc_end */
+    int64_t fit_knots;          /* knots of the first pass's spline: 8 = the least-squares cubic, more = FITPACK's smoothing branch */
 } wso_debug;
 
 double wso_np_mean(const double *a, long n);
@@ -70,6 +71,9 @@ long wso_create_alignment(const wso_automaton *A, const wso_params *P, const int
                           long T, double *value, double *expected, uint8_t *good);
 int wso_fit_cubic(const double *x, const double *y, long m, double t[8], double c[4], double *fp_out);
 void wso_eval_cubic(const double t[8], const double c[4], const double *x, long n, double *out);
+int wso_curfit(const double *x, const double *y, long m, double s, double *t_out, double *c_out, int *n_out, double *fp_out,
+               int *ier_out);
+void wso_splev(const double *t, int n, const double *c, const double *x, long cnt, double *out);
 int wso_rescale_signal(const double *sig, long T, const double *value, const double *expected, const uint8_t *good,
                        long n_align, double *out, double tck_t[8], double tck_c[4]);
 long wso_segment(const double *data, long n, int win);

@@ -1,7 +1,10 @@
 """Randomised parity sweep over LOCI: many seeded random locus patterns (nested units, optional blocks, IUPAC codes,
 interruptions, flanks 12..150 -> automata of 30..320+ states, fan-in 2..4, every fill variant and the generic kernel), a
 few dozen reads each, HIP caller vs the CPU oracle on all outputs incl. both state paths.  One line per kernel variant and a
-final tally; exit code 1 on any mismatch.  (Test infrastructure: uses oracle/.)   Usage: fuzz_loci.py [n_loci] [reads_per_locus] [--configs]"""
+final tally; exit code 1 on any mismatch.  (Test infrastructure: uses oracle/.)   Usage: fuzz_loci.py [n_loci] [reads_per_locus] [--configs | --smooth]
+--smooth: rescaling.threshold in (1, 6] and the called automaton's levels perturbed per state (the signals follow the
+unperturbed ones), so that many reads leave FITPACK's polynomial branch: knots added, smoothing iterated (fit_smooth_kernel);
+the rescaled signal is compared bit for bit as well."""
 import sys, os, time, collections
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,13 +19,18 @@ CONFIGS = [dict(), dict(min_values_per_state=3), dict(min_values_per_state=5), d
            dict(threshold=0.8, max_std=0.3)]
 
 
-def run(n_loci, per, seed=2026, verbose=True, configs=False):
+SMOOTH = [dict(threshold=1.5, max_std=3.0), dict(threshold=3.0, max_std=3.0), dict(threshold=6.0, max_std=3.0),
+          dict(threshold=6.0, max_std=3.0, min_values_per_state=3), dict(threshold=4.0, max_std=2.0, method='median')]
+
+
+def run(n_loci, per, seed=2026, verbose=True, configs=False, smooth=False):
     """-> (reads compared, mismatches, {kernel name: reads})"""
     from warpstr_amd.caller import CallerConfig, RescalerConfig
     units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CTG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA', 'TTTTA', 'GCN', 'CGG', 'AT', 'ATTCT']
     rng = np.random.default_rng(seed)
     oracle.lib()
-    tot = bad = skipped = 0
+    tot = bad = skipped = n_smooth = 0
+    import copy
     by_kernel = collections.Counter()
     bad_by_kernel = collections.Counter()
     t00 = time.time()
@@ -42,13 +50,19 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
             skipped += 1
             continue
         S = max(locus.template.n_states, locus.reverse.n_states)
-        cfg = CONFIGS[li % len(CONFIGS)] if configs else {}
+        cfg = CONFIGS[li % len(CONFIGS)] if configs else (SMOOTH[li % len(SMOOTH)] if smooth else {})
+        called = locus
+        if smooth:  # the automaton the reads are called against: every level off by its own amount
+            called = copy.deepcopy(locus)
+            spread = float(rng.choice([0.8, 1.5, 2.5]))
+            for tb in (called.template, called.reverse):
+                tb.value = (tb.value + rng.normal(0.0, spread, size=tb.n_states)).astype(np.float64)
         cc = CallerConfig(**{k: v for k, v in cfg.items() if k in ('min_values_per_state', 'states_in_segment')})
         rc = RescalerConfig(**{k: v for k, v in cfg.items() if k in ('method', 'reps_as_one', 'threshold', 'max_std')})
         prm = oracle.Params(min_values_per_state=cc.min_values_per_state, states_in_segment=cc.states_in_segment,
                             threshold=rc.threshold, max_std=rc.max_std, method=rc.method, reps_as_one=rc.reps_as_one)
         try:
-            hip = HipCaller([locus.template, locus.reverse], [fl, fl], caller_config=cc, rescaler_config=rc)
+            hip = HipCaller([called.template, called.reverse], [fl, fl], caller_config=cc, rescaler_config=rc)
         except Exception as e:
             skipped += 1
             if verbose:
@@ -64,8 +78,9 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
             revs.append(rev)
         sig, off = pack_signals(sigs)
         aut = np.array(revs, dtype=np.int32)
-        res, ex = hip.call(sig, off, aut, want_traces=True)
-        oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+        res, ex = hip.call(sig, off, aut, want_traces=True, want_debug=smooth)
+        oa = [oracle.Automaton.from_table(called.template, fl), oracle.Automaton.from_table(called.reverse, fl)]
+        knots = [0] * per
 
         def check(i):
             o = oracle.call_read(oa[aut[i]], sigs[i], prm)
@@ -73,7 +88,10 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
                 return f'read {i}: status {res["status"][i]} vs {o.status}'
             if o.status:
                 return None
+            knots[i] = o.fit_knots
             sl = slice(off[i], off[i + 1])
+            if smooth and not np.array_equal(ex['rescaled'][sl], o.rescaled):
+                return f'read {i}: rescaled ({o.fit_knots} knots)'
             if not np.array_equal(ex['trace1'][sl], o.trace1):
                 return f'read {i}: trace1'
             if not np.array_equal(ex['trace2'][sl], o.trace2):
@@ -114,6 +132,7 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
             by_kernel[hip.kernel_name(k) + (' ' + str(cfg) if cfg else '')] += int((aut == k).sum())
         tot += per
         bad += len(errs)
+        n_smooth += sum(k > 8 for k in knots)
         if errs:
             bad_by_kernel[hip.kernel_name(0) + (' ' + str(cfg) if cfg else '')] += len(errs)
             print(f'MISMATCH {pat} fl={fl} S={locus.template.n_states}/{locus.reverse.n_states} {hip.kernel_name(0)} / '
@@ -124,11 +143,12 @@ def run(n_loci, per, seed=2026, verbose=True, configs=False):
     if verbose:
         for k, n in sorted(by_kernel.items()):
             print(f'{k:40s} {n:7d} reads  {bad_by_kernel.get(k, 0)} mismatching')
-        print(f'TOTAL {n_loci - skipped} loci ({skipped} skipped), {tot} reads, {bad} mismatches, {time.time()-t00:.0f} s')
+        print(f'TOTAL {n_loci - skipped} loci ({skipped} skipped), {tot} reads, {bad} mismatches, {time.time()-t00:.0f} s'
+              + (f'; {n_smooth} reads through FITPACK\'s smoothing branch' if smooth else ''))
     return tot, bad, dict(by_kernel)
 
 
 if __name__ == '__main__':
     n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 48
-    sys.exit(1 if run(n_loci, per, configs='--configs' in sys.argv)[1] else 0)
+    sys.exit(1 if run(n_loci, per, configs='--configs' in sys.argv, smooth='--smooth' in sys.argv)[1] else 0)

@@ -101,6 +101,7 @@ def _compare_with_oracle(locus, fl, sigs, revs, caller_config=None, rescaler_con
         sl = slice(off[i], off[i + 1])
         assert np.array_equal(ex['trace1'][sl], o.trace1), i
         assert np.array_equal(ex['badmask'][sl], o.badmask), i
+        assert np.array_equal(ex['rescaled'][sl], o.rescaled), i  # bit for bit
         assert np.array_equal(ex['trace2'][sl], o.trace2), i
         assert (res['len1'][i], res['len2'][i], res['n_trans1'][i], res['n_trans2'][i]) == \
             (o.len1, o.len2, o.n_trans1, o.n_trans2)
@@ -169,28 +170,34 @@ def test_alternative_configs_match_golden(case):
         assert_close_rel(res['cost2'][i], z[f'r{i}_cost'][1], COST_REL)
 
 
-def test_threshold_above_one_is_accepted_and_the_knot_branch_is_a_status():
-    """rescaling.threshold > 1 (src/config.py:97-100 allows it): the handle is created and reads are called exactly as the
-    oracle calls them (fixture alt_thr15: recorded from the upstream caller at threshold 1.5).  What would make FITPACK add
-    knots -- accepted states whose levels a cubic of their signal means cannot follow, residual >= 1.001 m -- does not
-    happen with pore-model levels (the DTW itself keeps means near levels), so the automaton here gets artificial levels
-    (+-amp, alternating) under a flat signal: those reads come back with the fit-smooth status, the same on both sides."""
+def test_threshold_above_one_takes_fitpacks_smoothing_branch():
+    """rescaling.threshold > 1 (src/config.py:97-100 allows it): reads are called exactly as the oracle calls them (fixture
+    alt_thr15: recorded from the upstream caller at threshold 1.5).  What makes FITPACK add knots -- accepted states whose
+    levels a cubic of their signal means cannot follow, residual >= 1.001 m -- does not happen with pore-model levels (the
+    DTW itself keeps means near levels), so the automaton here gets artificial levels (+-amp, alternating) under a noisy
+    signal: those reads go through fit_smooth_kernel (knots added, smoothing parameter iterated) and the general splev,
+    and everything downstream -- rescaled signal bit for bit, masks, second-pass paths, lengths -- equals the oracle,
+    whose FITPACK is pinned against SciPy's (tests/test_oracle_golden.py::test_fitpack_smoothing_bitwise)."""
     import copy
     pattern, fl = '(AGC)AACAGCCGCCAC(CGC)', 20
     base = synth.make_locus(pattern, fl, 31)
     rng = np.random.default_rng(1)
-    smooth = [k for k, v in oracle.STATUS.items() if v == 'fit_smooth'][0]
-    seen = set()
-    for amp in (1.2, 2.0, 3.0):
+    n_smooth = n_ok = 0
+    for amp, noise in ((1.2, 0.05), (3.0, 0.05), (4.0, 0.05), (3.0, 0.5), (5.0, 0.2)):
         locus = copy.deepcopy(base)
         for t in (locus.template, locus.reverse):
             t.value = np.where(np.arange(t.n_states) % 2 == 0, amp, -amp).astype(np.float64)
-        sigs = [rng.normal(0.0, 0.05, size=1500 + 100 * i) for i in range(8)]
+        sigs = [rng.normal(0.0, noise, size=1500 + 100 * i) for i in range(8)]
+        revs = [bool(i & 1) for i in range(8)]
         prm = oracle.Params(threshold=6.0, max_std=3.0)
-        _, res, _ = _compare_with_oracle(locus, fl, sigs, [bool(i & 1) for i in range(8)], None,
-                                         RescalerConfig(threshold=6.0, max_std=3.0), prm)
-        seen |= {int(x) for x in res['status']}
-    assert seen >= {0, smooth}
+        _, res, ok = _compare_with_oracle(locus, fl, sigs, revs, None, RescalerConfig(threshold=6.0, max_std=3.0), prm)
+        n_ok += ok
+        # which of them left the polynomial branch
+        oa = [oracle.Automaton.from_table(locus.template, fl), oracle.Automaton.from_table(locus.reverse, fl)]
+        for s_, rv in zip(sigs, revs):
+            o = oracle.call_read(oa[int(rv)], s_, prm)
+            n_smooth += int(o.status == 0 and o.fit_knots > 8)
+    assert n_ok >= 25 and n_smooth >= 15, (n_ok, n_smooth)
 
 
 def test_reps_as_one_matches_oracle():

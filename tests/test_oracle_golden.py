@@ -83,11 +83,69 @@ def test_fitpack_cubic_bitwise():
             assert np.array_equal(oracle.eval_cubic(t, c, q), interpolate.splev(q, tck))
 
 
+def test_fitpack_smoothing_bitwise():
+    """FITPACK beyond the polynomial (rescaling.threshold > 1): fpcurf's knot-adding loop (fpknot, the number of new knots
+    per round), the smoothing iteration (fpdisc, the rotation of the weighted jump rows, fprati) and splev on the resulting
+    knot vector, against SciPy's compiled FITPACK bit for bit -- knots, coefficients, fp and ier; s = m as the caller uses
+    it and a smaller s; noise levels on both sides of the accept test; abscissae with ties (ier = -1 / 3 and coefficients
+    that are not finite included: NaN compares as NaN)."""
+    import warnings
+    from scipy import interpolate
+    rng = np.random.default_rng(5)
+    seen = {}
+    for trial in range(900):
+        m = int(rng.integers(5, 400))
+        kind = trial % 6
+        x = np.sort(rng.normal(size=m))
+        if kind == 1:
+            x = np.sort(np.round(rng.normal(size=m), 1))
+        if kind == 5:
+            x = np.sort(np.round(rng.normal(size=m), 2))
+        if x[0] == x[-1]:
+            continue
+        y = x + rng.normal(size=m) * [0.5, 1.2, 1.6, 3.0, 1.05, 1.3][kind]
+        if kind == 3:
+            y = np.sin(3 * x) * 3 + rng.normal(size=m) * 0.9
+        s = m * (0.3 if kind == 3 else 1.0)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (t_ref, c_ref, _), fp_ref, ier_ref, _ = interpolate.splrep(x, y, s=s, full_output=1, quiet=1)
+        t, c, fp, ier = oracle.curfit(x, y, s)
+        seen[ier] = seen.get(ier, 0) + 1
+        assert ier == ier_ref and len(t) == len(t_ref), (trial, ier, ier_ref)
+        assert np.array_equal(t, t_ref) and np.array_equal(c, c_ref, equal_nan=True), trial
+        assert fp == fp_ref or (fp != fp and fp_ref != fp_ref), trial
+        if np.all(np.isfinite(c)):
+            q = np.concatenate([rng.normal(size=300) * 3, x[:50], t])
+            assert np.array_equal(oracle.splev(t, c, q), interpolate.splev(q, (t_ref, c_ref, 3))), trial
+    assert seen.get(0, 0) > 300 and seen.get(-2, 0) > 100 and seen.get(-1, 0) > 20 and seen.get(3, 0) > 20, seen
+
+
+def test_rescale_signal_takes_the_smoothing_branch_like_scipy():
+    """wso_rescale_signal end to end (filter, stable sort, splrep with s = m, splev of the signal) where the accepted pairs
+    are far from each other: the same numbers as SciPy's splrep + splev on the same pairs."""
+    from scipy import interpolate
+    rng = np.random.default_rng(8)
+    took = 0
+    for trial in range(60):
+        n = int(rng.integers(30, 300))
+        value = rng.normal(size=n)
+        expected = value + rng.normal(size=n) * (1.5 if trial % 3 else 0.4)
+        good = (rng.random(n) < 0.8).astype(np.uint8)
+        sig = rng.normal(size=2000) * 1.5
+        out = oracle.rescale_signal(sig, value, expected, good)
+        pairs = sorted([(v, e) for v, e, g in zip(value, expected, good) if g], key=lambda p: p[0])
+        tck = interpolate.splrep([p[0] for p in pairs], [p[1] for p in pairs], s=len(pairs))
+        took += len(tck[0]) > 8
+        assert np.array_equal(out, interpolate.splev(sig, tck)), trial
+    assert took >= 20
+
+
 def test_fitpack_leaves_the_polynomial_branch_exactly_where_the_oracle_says():
     """rescaling.threshold > 1 (accepted since round 3): curfit keeps the least-squares cubic (ier = -2) while its residual fp
-    stays below s + 0.001 s (fpcurf: |fp - s| < acc or fp < s, acc = tol * s, tol = 0.001) and adds knots beyond -- the one
-    case the caller answers with a per-read status (fit-smooth) instead of a spline.  Pinned against SciPy here: fp itself
-    bit for bit, and the branch on both sides of the boundary, including the band s <= fp < 1.001 s."""
+    stays below s + 0.001 s (fpcurf: |fp - s| < acc or fp < s, acc = tol * s, tol = 0.001) and adds knots beyond -- where the
+    caller switches from the cubic's fast kernel to the full routine.  Pinned against SciPy here: fp itself bit for bit, and
+    the branch on both sides of the boundary, including the band s <= fp < 1.001 s."""
     from scipy import interpolate
     rng = np.random.default_rng(11)
     seen = set()

@@ -1060,13 +1060,23 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     }
     fp = quad_f64<WSX_QUAD_BCAST(3)>(fp);
     // fpcurf's test after the first least-squares fit (s = m, acc = tol * s, tol = 0.001): |fp - s| < acc or fp < s keeps the
-    // polynomial (ier = -2); anything else adds knots and smooths -- not restated: the read gets a status.  With
-    // rescaling.threshold <= 1 this cannot happen (the line y = x alone has residual <= m * threshold^2); above 1 it takes
-    // accepted states that are, on average, further than one normalised unit from their level.
+    // polynomial (ier = -2); anything else adds knots and smooths: fit_smooth_kernel.  With rescaling.threshold <= 1 this
+    // cannot happen (the line y = x alone has residual <= m * threshold^2); above 1 it takes accepted states that are, on
+    // average, further than one normalised unit from their level.
     if (!(fp - (double)m < 0.001 * (double)m)) {
-        if (j == 0) a.status[lr] = WSX_READ_FIT_SMOOTH;
+        if (j == 0) {
+            if (a.smooth_list) { // (handles with rescaling.threshold > 1) the read goes to fit_smooth_kernel
+                const int slot = atomicAdd(a.smooth_count, 1);
+                atomicMax(a.smooth_count + 1, m);
+                a.smooth_list[slot] = lr;
+                a.smooth_slot[lr] = slot;
+            } else {
+                a.status[lr] = WSX_READ_FIT_SMOOTH;
+            }
+        }
         return;
     }
+    if (j == 0 && a.smooth_slot) a.smooth_slot[lr] = -1;
     // fpback (n = 4, bandwidth 4): every lane of the quad evaluates it on the gathered triangle
     const double A11 = quad_f64<WSX_QUAD_BCAST(0)>(dg), A12 = quad_f64<WSX_QUAD_BCAST(0)>(o0),
                  A13 = quad_f64<WSX_QUAD_BCAST(0)>(o1), A14 = quad_f64<WSX_QUAD_BCAST(0)>(o2),
@@ -1097,6 +1107,378 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     co[5] = c4;
 }
 
+// ---- FITPACK beyond the polynomial: fpcurf in full (rescaling.threshold > 1 only) ----------------------------------
+// One THREAD per read that failed fpcurf's first test; the read's arrays live in its slot of the handle's smoothing
+// workspace (global memory, 1-based like the published routines).  Operation for operation the oracle's wso_curfit,
+// which is pinned bit for bit against SciPy's compiled FITPACK.  A rare path: what matters is that it is exact.
+// Slot layout (doubles): [0] n (as int), then t, c, z, fpint (nest + 2 each), nrdata (ints), a (x5), b (x6), g (x6), q (x5).
+__host__ __device__ inline size_t smooth_slot_doubles(int nest) { return (size_t)27 * (nest + 2) + 8; }
+
+__device__ __forceinline__ void bspl_knots(const double *t, double x, int l, double h[6])
+{
+    double hh[4];
+    h[1] = 1.0;
+#pragma unroll
+    for (int j = 1; j <= 3; j++) {
+#pragma unroll
+        for (int i = 1; i <= j; i++) hh[i] = h[i];
+        h[1] = 0.0;
+#pragma unroll
+        for (int i = 1; i <= j; i++) {
+            const double tli = t[l + i], tlj = t[l + i - j];
+            if (tli == tlj) {
+                h[i + 1] = 0.0;
+            } else {
+                const double f = hh[i] / (tli - tlj);
+                h[i] = h[i] + f * (tli - x);
+                h[i + 1] = f * (x - tlj);
+            }
+        }
+    }
+}
+
+// fpback: a*c = z, a upper triangular with bandwidth k, rows of `a` `ld` doubles apart
+__device__ __forceinline__ void back_subst(const double *a, int ld, const double *z, int n, int k, double *c)
+{
+    const int k1 = k - 1;
+    c[n] = z[n] / a[n * ld + 1];
+    int i = n - 1;
+    if (i == 0) return;
+    for (int j = 2; j <= n; j++) {
+        double store = z[i];
+        int i1 = k1;
+        if (j <= k1) i1 = j - 1;
+        int mm = i;
+        for (int l = 1; l <= i1; l++) {
+            mm = mm + 1;
+            store = store - c[mm] * a[i * ld + l + 1];
+        }
+        c[i] = store / a[i * ld + 1];
+        i = i - 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void fit_smooth_kernel(FitArgs a, int count, int nest_cap, double *ws)
+{
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= count) return;
+    const int lr = a.smooth_list[slot];
+    const int r = a.first_read + lr;
+    const long long off = a.offsets[r] - a.base_off;
+    const int m = a.fit_m[lr];
+    const double *x = a.fit_x + off - 1, *y = a.fit_y + off - 1; // 1-based
+    constexpr int K = 3, K1 = 4, K2 = 5, MAXIT = 20;
+    const double s = (double)m, tol = 0.001, con1 = 0.1, con9 = 0.9, con4 = 0.04, half = 0.5;
+    const int nest = m + K1 > 2 * K + 3 ? m + K1 : 2 * K + 3;
+    double *base = ws + (size_t)slot * smooth_slot_doubles(nest_cap);
+    const size_t nd = (size_t)nest_cap + 2;
+    double *t = base + 8, *c = t + nd, *z = c + nd, *fpint = z + nd;
+    int *nrdata = (int *)(fpint + nd);
+    double *wa = fpint + nd + nd / 2 + 1, *wb = wa + nd * 5, *wg = wb + nd * 6, *wq = wg + nd * 6;
+#define A_(i, j) wa[(i) * 5 + (j)]
+#define B_(i, j) wb[(i) * 6 + (j)]
+#define G_(i, j) wg[(i) * 6 + (j)]
+#define Q_(i, j) wq[(i) * 5 + (j)]
+    const double xb = x[1], xe = x[m];
+    const int nmin = 2 * K1, nmax = m + K1;
+    const double acc = tol * s;
+    int n = nmin, ier = 0, nplus = 0, nrint = 0, nk1 = 0;
+    double fp = 0.0, fp0 = 0.0, fpold = 0.0, fpms = 0.0;
+    nrdata[1] = m - 2;
+    bool accepted = false, smoothing = false;
+    for (int entry = 0; entry < 2 && !accepted && !smoothing; entry++) { // (second entry: the interpolation knots)
+        bool again = false;
+        for (int iter = 1; iter <= m; iter++) {
+            if (n == nmin) ier = -2;
+            nrint = n - nmin + 1;
+            nk1 = n - K1;
+            {
+                int i = n;
+                for (int j = 1; j <= K1; j++) {
+                    t[j] = xb;
+                    t[i] = xe;
+                    i = i - 1;
+                }
+            }
+            fp = 0.0;
+            for (int i = 1; i <= nk1; i++) {
+                z[i] = 0.0;
+                for (int j = 1; j <= K1; j++) A_(i, j) = 0.0;
+            }
+            int l = K1;
+            for (int it = 1; it <= m; it++) {
+                const double xi = x[it];
+                double yi = y[it] * 1.0;
+                while (!(xi < t[l + 1] || l == nk1)) l = l + 1;
+                double h[6];
+                bspl_knots(t, xi, l, h);
+#pragma unroll
+                for (int i = 1; i <= K1; i++) {
+                    Q_(it, i) = h[i];
+                    h[i] = h[i] * 1.0;
+                }
+                bool last = false;
+#pragma unroll
+                for (int i = 1; i <= K1; i++) {
+                    const int j = l - K1 + i;
+                    const double piv = h[i];
+                    if (!last && piv != 0.0) {
+                        double cs, sn;
+                        givens(piv, A_(j, 1), cs, sn);
+                        rota(cs, sn, yi, z[j]);
+                        if (i == K1) {
+                            last = true;
+                        } else {
+#pragma unroll
+                            for (int i1 = i + 1; i1 <= K1; i1++) rota(cs, sn, h[i1], A_(j, i1 - i + 1));
+                        }
+                    }
+                }
+                fp = fp + yi * yi;
+            }
+            if (ier == -2) fp0 = fp;
+            fpint[n] = fp0;
+            fpint[n - 1] = fpold;
+            nrdata[n] = nplus;
+            back_subst(wa, 5, z, nk1, K1, c);
+            fpms = fp - s;
+            if (fabs(fpms) < acc) {
+                accepted = true;
+                break;
+            }
+            if (fpms < 0.0) {
+                smoothing = true;
+                break;
+            }
+            if (n == nmax) {
+                ier = -1;
+                accepted = true;
+                break;
+            }
+            if (n == nest) {
+                ier = 1;
+                accepted = true;
+                break;
+            }
+            if (ier != 0) {
+                nplus = 1;
+                ier = 0;
+            } else {
+                int npl1 = nplus * 2;
+                const double rn = (double)nplus;
+                if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+                int mx = npl1 > nplus / 2 ? npl1 : nplus / 2;
+                if (mx < 1) mx = 1;
+                nplus = nplus * 2 < mx ? nplus * 2 : mx;
+            }
+            fpold = fp;
+            double fpart = 0.0;
+            int i = 1, nw = 0;
+            l = K2;
+            for (int it = 1; it <= m; it++) {
+                if (!(x[it] < t[l] || l > nk1)) {
+                    nw = 1;
+                    l = l + 1;
+                }
+                double term = 0.0;
+#pragma unroll
+                for (int j = 1; j <= K1; j++) term = term + c[l - K2 + j] * Q_(it, j);
+                term = (1.0 * (term - y[it])) * (1.0 * (term - y[it]));
+                fpart = fpart + term;
+                if (nw == 0) continue;
+                const double store = term * half;
+                fpint[i] = fpart - store;
+                i = i + 1;
+                fpart = store;
+                nw = 0;
+            }
+            fpint[nrint] = fpart;
+            bool to_interp = false;
+            for (l = 1; l <= nplus; l++) {
+                // fpknot: one more knot in the interval with the largest residual that still holds data points
+                {
+                    const int k = (n - nrint - 1) / 2;
+                    double fpmax = 0.0;
+                    int jbegin = 1, number = 0, maxpt = 0, maxbeg = 0;
+                    for (int j = 1; j <= nrint; j++) {
+                        const int jpoint = nrdata[j];
+                        if (!(fpmax >= fpint[j] || jpoint == 0)) {
+                            fpmax = fpint[j];
+                            number = j;
+                            maxpt = jpoint;
+                            maxbeg = jbegin;
+                        }
+                        jbegin = jbegin + jpoint + 1;
+                    }
+                    if (number != 0) {
+                        const int ihalf = maxpt / 2 + 1, nrx = maxbeg + ihalf, next = number + 1;
+                        for (int j = next; j <= nrint; j++) {
+                            const int jj = next + nrint - j;
+                            fpint[jj + 1] = fpint[jj];
+                            nrdata[jj + 1] = nrdata[jj];
+                            t[jj + k + 1] = t[jj + k];
+                        }
+                        nrdata[number] = ihalf - 1;
+                        nrdata[next] = maxpt - ihalf;
+                        const double am = (double)maxpt;
+                        double an = (double)nrdata[number];
+                        fpint[number] = fpmax * an / am;
+                        an = (double)nrdata[next];
+                        fpint[next] = fpmax * an / am;
+                        t[next + k] = x[nrx];
+                        n = n + 1;
+                        nrint = nrint + 1;
+                    }
+                }
+                if (n == nmax) {
+                    to_interp = true;
+                    break;
+                }
+                if (n == nest) break;
+            }
+            if (to_interp) {
+                int ii = K2, jj = K / 2 + 2;
+                for (l = 1; l <= m - K1; l++) {
+                    t[ii] = x[jj];
+                    ii = ii + 1;
+                    jj = jj + 1;
+                }
+                again = true;
+                break;
+            }
+        }
+        if (!again) break;
+    }
+    if (!accepted && ier != -2) {
+        // part 2: the smoothing spline
+        {   // fpdisc
+            const int nrint2 = nk1 - K;
+            const double an = (double)nrint2;
+            const double fac = an / (t[nk1 + 1] - t[K1]);
+            for (int l = K2; l <= nk1; l++) {
+                const int lmk = l - K1;
+                double h[13];
+#pragma unroll
+                for (int j = 1; j <= K1; j++) {
+                    h[j] = t[l] - t[l + j - K2];
+                    h[j + K1] = t[l] - t[l + j];
+                }
+#pragma unroll
+                for (int j = 1; j <= K2; j++) {
+                    double prod = h[j];
+#pragma unroll
+                    for (int i = 1; i <= K; i++) prod = prod * h[j + i] * fac;
+                    const int lp = lmk + j - 1;
+                    B_(lmk, j) = (t[lp + K1] - t[lp]) / prod;
+                }
+            }
+        }
+        double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 0.0;
+        for (int i = 1; i <= nk1; i++) p = p + A_(i, 1);
+        p = (double)nk1 / p;
+        int ich1 = 0, ich3 = 0;
+        const int n8 = n - nmin;
+        for (int iter = 1; iter <= MAXIT; iter++) {
+            const double pinv = 1.0 / p;
+            for (int i = 1; i <= nk1; i++) {
+                c[i] = z[i];
+                G_(i, K2) = 0.0;
+                for (int j = 1; j <= K1; j++) G_(i, j) = A_(i, j);
+            }
+            for (int it = 1; it <= n8; it++) {
+                double h[7];
+#pragma unroll
+                for (int i = 1; i <= K2; i++) h[i] = B_(it, i) * pinv;
+                h[6] = 0.0;
+                double yi = 0.0;
+                for (int j = it; j <= nk1; j++) {
+                    const double piv = h[1];
+                    double cs, sn;
+                    givens(piv, G_(j, 1), cs, sn);
+                    rota(cs, sn, yi, c[j]);
+                    if (j == nk1) break;
+                    int i2 = K1;
+                    if (j > n8) i2 = nk1 - j;
+#pragma unroll
+                    for (int i = 1; i <= K1; i++)
+                        if (i <= i2) {
+                            rota(cs, sn, h[i + 1], G_(j, i + 1));
+                            h[i] = h[i + 1];
+                        }
+#pragma unroll
+                    for (int i = 1; i <= K2; i++)
+                        if (i == i2 + 1) h[i] = 0.0;
+                }
+            }
+            back_subst(wg, 6, c, nk1, K2, c);
+            fp = 0.0;
+            int l = K2;
+            for (int it = 1; it <= m; it++) {
+                if (!(x[it] < t[l] || l > nk1)) l = l + 1;
+                double term = 0.0;
+#pragma unroll
+                for (int j = 1; j <= K1; j++) term = term + c[l - K2 + j] * Q_(it, j);
+                fp = fp + (1.0 * (term - y[it])) * (1.0 * (term - y[it]));
+            }
+            fpms = fp - s;
+            if (fabs(fpms) < acc) break;
+            if (iter == MAXIT) {
+                ier = 3;
+                break;
+            }
+            const double p2 = p, f2 = fpms;
+            if (ich3 == 0) {
+                if (!(f2 - f3 > acc)) {
+                    p3 = p2;
+                    f3 = f2;
+                    p = p * con4;
+                    if (p <= p1) p = p1 * con9 + p2 * con1;
+                    continue;
+                }
+                if (f2 < 0.0) ich3 = 1;
+            }
+            if (ich1 == 0) {
+                if (!(f1 - f2 > acc)) {
+                    p1 = p2;
+                    f1 = f2;
+                    p = p / con4;
+                    if (p3 < 0.0) continue;
+                    if (p >= p3) p = p2 * con1 + p3 * con9;
+                    continue;
+                }
+                if (f2 > 0.0) ich1 = 1;
+            }
+            if (f2 >= f1 || f2 <= f3) {
+                ier = 2;
+                break;
+            }
+            // fprati
+            if (p3 > 0.0) {
+                const double h1 = f1 * (f2 - f3), h2 = f2 * (f3 - f1), h3 = f3 * (f1 - f2);
+                p = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3);
+            } else {
+                p = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3);
+            }
+            if (f2 < 0.0) {
+                p3 = p2;
+                f3 = f2;
+            } else {
+                p1 = p2;
+                f1 = f2;
+            }
+        }
+    }
+#undef A_
+#undef B_
+#undef G_
+#undef Q_
+    // a spline with a coefficient that is not finite (coinciding abscissae can do that) is of no use to the second pass
+    bool finite = true;
+    for (int i = 1; i <= n - K1; i++) finite = finite && (fabs(c[i]) <= 1.7976931348623157e308);
+    *(int *)base = n;
+    if (!finite) a.status[lr] = WSX_READ_FIT_SMOOTH;
+}
+
 // splev (ext = 0) of the fitted cubic at every sample of the read.
 __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 {
@@ -1105,6 +1487,29 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
     const int r = a.first_read + lr;
     const long long off = a.offsets[r] - a.base_off;
     const int T = (int)(a.offsets[r + 1] - a.offsets[r]);
+    if (a.smooth_slot && a.smooth_slot[lr] >= 0) { // a smoothing spline with interior knots: the interval by bisection
+        const double *base = a.smooth_ws + (size_t)a.smooth_slot[lr] * smooth_slot_doubles(a.smooth_nest);
+        const int n = *(const int *)base, nk1 = n - 4;
+        const double *t = base + 8, *c = t + (a.smooth_nest + 2);
+        for (int i = threadIdx.x; i < T; i += 256) {
+            const double arg = a.signal[off + i];
+            // splev's search ends at the largest l in [4, nk1] with t[l] <= arg (4 if there is none)
+            int lo = 4, hi = nk1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (t[mid] <= arg) lo = mid;
+                else hi = mid - 1;
+            }
+            double h[6];
+            bspl_knots(t, arg, lo, h);
+            double sp = 0.0;
+#pragma unroll
+            for (int j = 1; j <= 4; j++) sp = sp + c[lo - 4 + j] * h[j];
+            a.out[off + i] = sp;
+            if (a.out_user) a.out_user[off + i] = sp;
+        }
+        return;
+    }
     const double *co = a.coef + (size_t)lr * 6;
     const double xb = co[0], xe = co[1], c1 = co[2], c2 = co[3], c3 = co[4], c4 = co[5];
     const double den = xe - xb, rden = wsx_bspl_rden(den);
@@ -1154,6 +1559,15 @@ hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s)
 {
     if (a.n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(fit_kernel, dim3((a.n_reads + 15) / 16), dim3(64), 0, s, a); // a quad of lanes per read
+    return hipGetLastError();
+}
+
+size_t wsx_smooth_workspace_bytes(int count, int max_m) { return (size_t)count * smooth_slot_doubles(max_m + 4 > 9 ? max_m + 4 : 9) * 8; }
+
+hipError_t wsx_launch_fit_smooth(const FitArgs &a, int count, int max_m, double *ws, hipStream_t s)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fit_smooth_kernel, dim3((count + 63) / 64), dim3(64), 0, s, a, count, max_m + 4 > 9 ? max_m + 4 : 9, ws);
     return hipGetLastError();
 }
 

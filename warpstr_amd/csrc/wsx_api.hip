@@ -249,7 +249,9 @@ struct wsx_caller {
     // VALU-bound DP fill of others.
     struct Work {
         DeviceBuf samples, reads, bp, stage_sig, stage_out, reps;
+        DeviceBuf smooth; // fit_smooth_kernel's arrays (rescaling.threshold > 1, sized when a chunk has such reads)
     } work[WSX_MAX_STREAMS];
+    int32_t *smooth_host = nullptr; // pinned: per work set, the chunk's {reads for fit_smooth_kernel, most points among them}
     hipStream_t aux[WSX_MAX_STREAMS] = {};  // aux[0] unused (the handle's stream)
     hipEvent_t ev_joins[WSX_MAX_STREAMS] = {};
     int n_streams = 4;        // streams / work sets the handle may use
@@ -354,7 +356,7 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 // ... and per read: the per-read arrays, the spare rows of the back-pointer regions, reps_as_one scratch, staged rows
 size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
 {
-    size_t b = 168 + sizeof(wsx_result) + 64;
+    size_t b = 192 + sizeof(wsx_result) + 64;
     for (auto &v : c->variant) b += v.bp_words(0, 1) * 4;
     if (c->prm.reps_as_one) b += 2 * (size_t)c->max_states * sizeof(int32_t);
     if (host_mem) b += 16 + last_row_bytes;
@@ -405,7 +407,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
         return WSX_ERR_INVALID;
     }
     // (rescaling.threshold > 1 is accepted, as upstream accepts it, src/config.py:97-100: a read whose first least-squares fit
-    // leaves FITPACK's polynomial branch -- possible only then -- comes back with WSX_READ_FIT_SMOOTH)
+    // leaves FITPACK's polynomial branch -- possible only then -- takes fpcurf's knot-adding and smoothing branch in
+    // fit_smooth_kernel)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_err = "no HIP device available";
@@ -605,6 +608,7 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
             for (const auto &u : c->variant)
                 if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == v.F + 1 && v.F >= 3) v.F = u.F;
         }
+    if (c->prm.threshold > 1.0) HIPCHK(hipHostMalloc((void **)&c->smooth_host, 2 * WSX_MAX_STREAMS * sizeof(int32_t), hipHostMallocDefault));
     HIPCHK(hipMemcpy(c->aut_blob.p, hblob.data(), blob, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&c->ev_begin));
@@ -644,13 +648,14 @@ void wsx_caller_destroy(wsx_caller *c)
     c->ring_up.release();
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
+    if (c->smooth_host) (void)hipHostFree(c->smooth_host);
     if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
-        for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) b->release();
+        for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps, &w.smooth}) b->release();
     for (int w = 1; w < WSX_MAX_STREAMS; w++) {
         if (c->aux[w]) (void)hipStreamDestroy(c->aux[w]);
         if (c->ev_joins[w]) (void)hipEventDestroy(c->ev_joins[w]);
@@ -1065,6 +1070,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         wsx_caller::Work *W;
         const double *d_sig;
         double *d_resc, *d_resc_user, *d_endcost, *d_endcost_user, *d_lastrow, *d_coef;
+        int32_t *d_smooth_cnt;
         uint16_t *d_tr1, *d_tr2;
         uint8_t *d_badmask, *d_seq1, *d_seq2, *d_alg;
         int32_t *d_status, *d_status_user, *d_nruns;
@@ -1132,6 +1138,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         MidRec *d_rec = rcv.take<MidRec>(R1);
         int32_t *d_nalign = rcv.take<int32_t>(R1);
         wsx_result *d_results_ws = rcv.take<wsx_result>(R1);
+        int32_t *d_smooth_list = rcv.take<int32_t>(R1), *d_smooth_slot = rcv.take<int32_t>(R1);
+        x.d_smooth_cnt = rcv.take<int32_t>(4);
 
         if (host) {
             if (io.read_ptrs) HIPCHK(c->ring_up.upload_gather(W.stage_sig.p, io.read_ptrs, io.offsets, f, cnt, s));
@@ -1246,8 +1254,12 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.status = x.d_status;
         ma.end_cost = x.d_endcost;
         ma.results = x.d_results;
-        x.fa = FitArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, x.d_coef, x.d_status};
-        x.ea = EvalArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, x.d_sig, x.d_coef, x.d_status, x.d_resc, x.d_resc_user};
+        const bool may_smooth = c->prm.threshold > 1.0; // FITPACK can leave its polynomial branch only then
+        x.fa = FitArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, d_fx, d_fy, d_fitm, x.d_coef, x.d_status,
+                       may_smooth ? x.d_smooth_cnt : nullptr, may_smooth ? d_smooth_list : nullptr,
+                       may_smooth ? d_smooth_slot : nullptr};
+        x.ea = EvalArgs{d_offsets, (int32_t)cnt, (int32_t)f, boff, x.d_sig, x.d_coef, x.d_status, x.d_resc, x.d_resc_user,
+                        nullptr, nullptr, 0};
         return WSX_SUCCESS;
     };
 
@@ -1302,7 +1314,22 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.badmask_bytes = x.d_badmask;
         ma.seq_out = x.d_seq1;
         HIPCHK(wsx_launch_mid(ma, x.ch.max_T, s));
+        if (x.fa.smooth_list) HIPCHK(hipMemsetAsync(x.d_smooth_cnt, 0, 2 * sizeof(int32_t), s));
         HIPCHK(wsx_launch_fit(x.fa, s));
+        if (x.fa.smooth_list) {
+            // rescaling.threshold > 1: reads whose cubic fails fpcurf's test take FITPACK's knot-adding and smoothing
+            // branch (a thread per read, arrays in a workspace sized from the chunk's count: the host has to see it)
+            int32_t *hc = c->smooth_host + 2 * (x.W - c->work);
+            HIPCHK(hipMemcpyAsync(hc, x.d_smooth_cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (hc[0] > 0) {
+                HIPCHK(x.W->smooth.ensure(wsx_smooth_workspace_bytes(hc[0], hc[1])));
+                HIPCHK(wsx_launch_fit_smooth(x.fa, hc[0], hc[1], (double *)x.W->smooth.p, s));
+                x.ea.smooth_slot = x.fa.smooth_slot;
+                x.ea.smooth_ws = (const double *)x.W->smooth.p;
+                x.ea.smooth_nest = hc[1] + 4 > 9 ? hc[1] + 4 : 9;
+            }
+        }
         HIPCHK(wsx_launch_eval(x.ea, x.ch.max_T, s));
         return WSX_SUCCESS;
     };
@@ -1529,7 +1556,7 @@ int wsx_caller_workspace(wsx_caller *c, uint64_t *bytes_allocated, double *bytes
     for (auto &b : c->meta) total += b.cap;
     for (auto &b : c->prep_pool) total += b.cap;
     for (auto &w : c->work)
-        for (const DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps}) total += b->cap;
+        for (const DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps, &w.smooth}) total += b->cap;
     if (bytes_allocated) *bytes_allocated = total;
     if (bytes_per_sample) *bytes_per_sample = c->last_samples > 0 ? (double)total / (double)c->last_samples : 0.0;
     return WSX_SUCCESS;

@@ -130,6 +130,11 @@ struct FitArgs {
     const int32_t *fit_m;
     double *coef;              // per read: xb, xe, c0..c3 (6 doubles)
     int32_t *status;
+    // handles with rescaling.threshold > 1 (else NULL): reads whose least-squares cubic fails fpcurf's test queue up for
+    // fit_smooth_kernel -- smooth_count[0] reads (list), smooth_count[1] the largest number of points among them
+    int32_t *smooth_count;
+    int32_t *smooth_list;
+    int32_t *smooth_slot;      // per read: its slot of the smoothing workspace, -1 = the cubic in `coef`
 };
 
 struct EvalArgs {
@@ -142,6 +147,9 @@ struct EvalArgs {
     const int32_t *status;
     double *out;               // rescaled signal
     double *out_user;          // optional second copy (user-visible), may be NULL
+    const int32_t *smooth_slot; // see FitArgs; NULL unless rescaling.threshold > 1
+    const double *smooth_ws;    // smoothing workspace of the chunk's work set (slots of smooth_nest knots)
+    int32_t smooth_nest;
 };
 
 // Host-side launchers (defined next to the kernels).
@@ -152,6 +160,8 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
+size_t wsx_smooth_workspace_bytes(int count, int max_m);
+hipError_t wsx_launch_fit_smooth(const FitArgs &a, int count, int max_m, double *ws, hipStream_t s);
 hipError_t wsx_launch_eval(const EvalArgs &a, int max_T, hipStream_t s);
 bool wsx_fast_pass_supported(int m, int K, int F);
 const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, bool generic);
