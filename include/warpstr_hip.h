@@ -234,9 +234,10 @@ int wsx_caller_synchronize(wsx_caller *c);
 int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms);
 
 /*
- * Device memory the handle holds (automata, metadata, every work set of every stream, loader pool), and that figure per
- * sample of the most recent call: the workspace is sized per sample -- the read's normalised and rescaled signal, run
- * lists, alignment records, fit pairs, scratch and the DP back-pointers -- for every chunk in flight.
+ * Device memory the handle holds (automata, metadata, every work set of every stream, loader pool), and the caller's part
+ * of it (everything but the loader pool) per sample of the most recent call: the workspace is sized per sample -- the
+ * read's normalised and rescaled signal, run lists, alignment records, fit pairs, scratch and the DP back-pointers
+ *  -- for every chunk in flight.
  */
 int wsx_caller_workspace(wsx_caller *c, uint64_t *bytes_allocated, double *bytes_per_sample);
 

@@ -356,7 +356,7 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 // ... and per read: the per-read arrays, the spare rows of the back-pointer regions, reps_as_one scratch, staged rows
 size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
 {
-    size_t b = 192 + sizeof(wsx_result) + 64;
+    size_t b = 168 + sizeof(wsx_result) + 64;
     for (auto &v : c->variant) b += v.bp_words(0, 1) * 4;
     if (c->prm.reps_as_one) b += 2 * (size_t)c->max_states * sizeof(int32_t);
     if (host_mem) b += 16 + last_row_bytes;
@@ -1554,11 +1554,13 @@ int wsx_caller_workspace(wsx_caller *c, uint64_t *bytes_allocated, double *bytes
     if (!c) return WSX_ERR_INVALID;
     uint64_t total = c->aut_blob.cap + c->aut_table.cap;
     for (auto &b : c->meta) total += b.cap;
-    for (auto &b : c->prep_pool) total += b.cap;
     for (auto &w : c->work)
         for (const DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps, &w.smooth}) total += b->cap;
-    if (bytes_allocated) *bytes_allocated = total;
+    // (per sample of the most recent call: the caller's own buffers; the loader's pool -- wsx_prepare_signals, sized by its
+    // own calls -- counts towards the total only)
     if (bytes_per_sample) *bytes_per_sample = c->last_samples > 0 ? (double)total / (double)c->last_samples : 0.0;
+    for (auto &b : c->prep_pool) total += b.cap;
+    if (bytes_allocated) *bytes_allocated = total;
     return WSX_SUCCESS;
 }
 
