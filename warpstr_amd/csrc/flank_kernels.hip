@@ -34,6 +34,7 @@
 #include "../../include/warpstr_hip.h"
 
 void wsx_internal_set_error(const char *msg);
+extern "C" int wsx_internal_on_exception(void);
 
 namespace {
 
@@ -397,7 +398,7 @@ extern "C" {
 int wsx_locate_flanks(int device, void *stream, int mem, const uint8_t *text, const int64_t *text_offsets,
                       const uint8_t *pattern, const int64_t *pattern_offsets, int64_t n, const wsx_align_scores *scores,
                       wsx_flank_hit *hits, uint8_t *ops, int32_t ops_stride)
-{
+try {
     if (!text_offsets || !pattern_offsets || !scores || !hits || n < 0 || (n > 0 && (!text || !pattern))) {
         wsx_internal_set_error("wsx_locate_flanks: null argument");
         return WSX_ERR_INVALID;
@@ -503,12 +504,14 @@ int wsx_locate_flanks(int device, void *stream, int mem, const uint8_t *text, co
     }
     FCHK(hipStreamSynchronize(st)); // temporaries are freed on return
     return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 int wsx_moves_to_raw(int device, void *stream, int mem, const uint8_t *moves, const int64_t *move_offsets,
                      const int32_t *pos_start, const int32_t *pos_end, const int64_t *strand_start,
                      const int32_t *block_stride, int64_t n, int64_t *raw_start, int64_t *raw_end)
-{
+try {
     if (!move_offsets || !pos_start || !pos_end || !strand_start || !block_stride || !raw_start || !raw_end || n < 0 ||
         (n > 0 && !moves)) {
         wsx_internal_set_error("wsx_moves_to_raw: null argument");
@@ -572,6 +575,8 @@ int wsx_moves_to_raw(int device, void *stream, int mem, const uint8_t *moves, co
     }
     FCHK(hipStreamSynchronize(st));
     return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 } // extern "C"

@@ -382,6 +382,7 @@ __global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, in
 
 extern "C" {
 
+int wsx_internal_on_exception(void);
 int wsx_abi_version(void) { return WSX_ABI_VERSION; }
 
 int wsx_device_count(void)
@@ -395,7 +396,7 @@ const char *wsx_last_error(void) { return g_err.c_str(); }
 
 int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
                       const wsx_params *params, void *stream)
-{
+try {
     if (!out || !automata || n_automata <= 0 || !params) {
         g_err = "wsx_caller_create: null argument";
         return WSX_ERR_INVALID;
@@ -632,6 +633,8 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
     guard.c = nullptr;
     *out = c;
     return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 void wsx_caller_destroy(wsx_caller *c)
@@ -746,6 +749,22 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 int wsx_internal_device(wsx_caller *c) { return c->device; }
 hipStream_t wsx_internal_stream(wsx_caller *c) { return c->stream; }
 void wsx_internal_set_error(const char *msg) { g_err = msg; }
+// No C++ exception crosses the C ABI: the entry points that allocate host memory are function-try-blocks ending here.
+int wsx_internal_on_exception(void)
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of host memory";
+        return WSX_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        g_err = std::string("internal error: ") + e.what();
+        return WSX_ERR_INVALID;
+    } catch (...) {
+        g_err = "internal error (unknown exception)";
+        return WSX_ERR_INVALID;
+    }
+}
 uint64_t wsx_internal_workspace_limit(wsx_caller *c) { return c->ws_limit; }
 hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEvent_t *last_use)
 {
@@ -1464,7 +1483,7 @@ extern "C" {
 
 int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets, const int32_t *automaton_id,
                    int64_t n_reads, wsx_result *results, const wsx_traces *traces)
-{
+try {
     BatchIO io{};
     io.mem = mem;
     io.signal = signal;
@@ -1474,11 +1493,13 @@ int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
     io.results = results;
     if (traces) io.traces = *traces;
     return run_batch(c, io, true);
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 int wsx_call_batch_reads(wsx_caller *c, const double *const *reads, const int64_t *lengths, const int32_t *automaton_id,
                          int64_t n_reads, wsx_result *results, const wsx_traces *traces)
-{
+try {
     if (!reads || !lengths || n_reads < 0) {
         g_err = "wsx_call_batch_reads: null argument";
         return WSX_ERR_INVALID;
@@ -1501,12 +1522,14 @@ int wsx_call_batch_reads(wsx_caller *c, const double *const *reads, const int64_
     io.results = results;
     if (traces) io.traces = *traces;
     return run_batch(c, io, true);
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets, const int32_t *automaton_id,
                    int64_t n_reads, const uint8_t *mask, uint16_t *trace, double *end_cost, double *last_row,
                    int32_t last_row_stride, int32_t *status)
-{
+try {
     BatchIO io{};
     io.mem = mem;
     io.signal = signal;
@@ -1524,6 +1547,8 @@ int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
         return WSX_ERR_INVALID;
     }
     return run_batch(c, io, false);
+} catch (...) {
+    return wsx_internal_on_exception();
 }
 
 int wsx_caller_last_timing(wsx_caller *c, double *dp_kernel_ms, int32_t *dp_launches, double *total_ms)

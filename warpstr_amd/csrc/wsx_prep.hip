@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
 int wsx_internal_device(wsx_caller *c);
 hipStream_t wsx_internal_stream(wsx_caller *c);
 void wsx_internal_set_error(const char *msg);
+extern "C" int wsx_internal_on_exception(void);
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p);
 uint64_t wsx_internal_workspace_limit(wsx_caller *c);
 // pinned host memory of the handle for this function's metadata (>= bytes), and the event recorded after its last use
@@ -652,7 +653,7 @@ hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEv
 extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_t *raw_offsets,
                                    const int64_t *seg_start, const int64_t *seg_end, int64_t n_reads, int32_t spike_removal,
                                    double *signal_out, const int64_t *out_offsets, double *shift_scale)
-{
+try {
     if (!c || !raw_offsets || !seg_start || !seg_end || !out_offsets || n_reads < 0 || (n_reads > 0 && (!raw || !signal_out))) {
         wsx_internal_set_error("wsx_prepare_signals: null argument");
         return WSX_ERR_INVALID;
@@ -799,4 +800,6 @@ extern "C" int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, c
     }
     PCHK(hipEventRecord(pin_event, st));
     return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
 }
