@@ -51,6 +51,28 @@ def test_streamvbyte_and_vbz_chunk_round_trip(n):
         fast5.vbz_decode_chunk(chunk, 2, True, 1, 0)  # 1-bit-key variant: refused, not mis-decoded
 
 
+def test_c_decoder_equals_the_numpy_decoder(monkeypatch):
+    """csrc/seam_helper.c's StreamVByte / zig-zag / running-sum loop (what fast5.py uses when the helper is built) against
+    the NumPy decoder on random blocks: every code length, wrap-around of the int16 running sum, truncated blocks."""
+    if fast5._vbz_c() is None:
+        pytest.skip('warpstr_amd/_seam_helper.so is not built')
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 5, 64, 1000, 4097):
+        for zigzag in (True, False):
+            vals = rng.integers(0, 2 ** np.array([7, 8, 15, 16, 17, 24, 31, 32])[rng.integers(0, 8, size=n)], dtype=np.uint64)
+            chunk = struct.pack('<I', 2 * n) + svb_encode([int(v) for v in vals])
+            got = fast5.vbz_decode_chunk(chunk, 2, zigzag, 0, 0)
+            with monkeypatch.context() as mp:
+                mp.setattr(fast5, '_VBZ_C', None)
+                want = fast5.vbz_decode_chunk(chunk, 2, zigzag, 0, 0)
+            assert got.dtype == np.int16 and np.array_equal(got, want), (n, zigzag)
+            if n:
+                with pytest.raises(fast5.Fast5Error):
+                    fast5.vbz_decode_chunk(chunk[:-1], 2, zigzag, 0, 0)
+                with pytest.raises(fast5.Fast5Error):
+                    fast5.vbz_decode_chunk(chunk[:4 + (n + 3) // 4 - 1], 2, zigzag, 0, 0)
+
+
 @needs_hdf5
 def test_reader_on_upstream_multi_read_file():
     z = load_case('real_aaat')

@@ -102,6 +102,28 @@ def streamvbyte_decode(buf: np.ndarray, n: int) -> np.ndarray:
     return vals
 
 
+_VBZ_C = False
+
+
+def _vbz_c():
+    """csrc/seam_helper.c's decoder loop (warpstr_amd/_seam_helper.so, loaded without the GIL), or None: the NumPy decoder
+    below then does the same arithmetic.  Host-side file reading, not the caller's compute path."""
+    global _VBZ_C
+    if _VBZ_C is False:
+        _VBZ_C = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_seam_helper.so')
+        if os.path.exists(path) and not os.environ.get('WARPSTR_NO_SEAM_HELPER'):
+            try:
+                lib = C.CDLL(path)
+                fn = lib.wsx_seam_vbz_decode_i16
+                fn.restype = C.c_int64
+                fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+                _VBZ_C = fn
+            except (OSError, AttributeError):
+                _VBZ_C = None
+    return _VBZ_C
+
+
 def vbz_decode_chunk(chunk: bytes, int_size: int, zigzag: bool, version: int, zstd_level: int) -> np.ndarray:
     """One VBZ-filtered HDF5 chunk -> integer samples.  Layout: u32 uncompressed byte count, then (zstd_level != 0) a
     zstd frame holding the StreamVByte block of the delta-coded, optionally zig-zag-mapped, samples."""
@@ -124,6 +146,14 @@ def vbz_decode_chunk(chunk: bytes, int_size: int, zigzag: bool, version: int, zs
         if zs.ZSTD_isError(got) or got != size:
             raise Fast5Error('zstd decompression of a VBZ chunk failed')
         body = out.raw[:size]
+    fn = _vbz_c() if int_size == 2 else None
+    if fn is not None:
+        block = np.frombuffer(body, dtype=np.uint8)
+        out = np.empty(n, dtype=np.int16)
+        rc = fn(block.ctypes.data_as(C.c_void_p), block.size, n, int(bool(zigzag)), out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise Fast5Error('StreamVByte block shorter than its key area' if rc == -1 else 'StreamVByte block shorter than its keys say')
+        return out
     vals = streamvbyte_decode(np.frombuffer(body, dtype=np.uint8), n)
     if zigzag:
         delta = (vals >> np.uint32(1)).astype(np.int32) ^ -(vals & np.uint32(1)).astype(np.int32)
