@@ -1536,8 +1536,10 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     const int max_runs = max_T / (m - 1 > 0 ? m - 1 : 1) + 2;
     if (a.n_align) hipLaunchKernelGGL(reps_stats_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, std::min((max_runs + 63) / 64, RS_GROUPS)), dim3(64), 0, s, a);
-    // small launches: a wavefront per read (latency); big ones: a thread per read (throughput)
-    if (a.n_reads < 8192) hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
+    // small launches: a wavefront per read (latency); big ones: a thread per read (throughput; the wavefront form at 25 000
+    // reads per launch: 13.9 instead of 13.4 ms per 100 k-read step, scripts/r03_cycle33.sh)
+    static const int borders_wave_below = getenv("WSX_BORDERS_WAVE_BELOW") ? atoi(getenv("WSX_BORDERS_WAVE_BELOW")) : 8192;
+    if (a.n_reads < borders_wave_below) hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(borders_thread_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.seq_out) hipLaunchKernelGGL(sequence_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     if (a.pass == 1) {
