@@ -348,7 +348,7 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
         seen.push_back(v);
         bp += v.bp_words(4096, 0) * 4 / 4096 + 1;
     }
-    size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 24 /*scratch*/ +
+    size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 16 /*scratch*/ +
                1 /*mask bits, rounded up*/ + bp;
     if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 3) : 0);
     return b + 8; // alignment slack
@@ -1018,7 +1018,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     const size_t R1 = max_cnt + 8;
     // per-sample arrays
     size_t smp_bytes = align_up(S1 * 8) /*rescaled*/ + align_up(S1 * 2) + align_up(S1 * 4) /*runs*/ +
-                       3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 5 * align_up(S1 * 8) /*fit + scratch*/ +
+                       3 * align_up(S1 * 8) + align_up(S1) /*alignment*/ + 4 * align_up(S1 * 8) /*fit + scratch*/ +
                        align_up((S1 / 32 + R1 + 2) * 4) /*mask bits*/;
     const int n_work = (int)std::min<size_t>(chunks.size(), (size_t)spc);
     // Work set (and stream) of chunk ci: (rot + ci) mod n_streams.  A pipelined call with fewer chunks than the handle has
@@ -1146,7 +1146,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         double *d_alv = sc.take<double>(S1), *d_ale = sc.take<double>(S1), *d_alc = sc.take<double>(S1);
         x.d_alg = sc.take<uint8_t>(S1);
         double *d_fx = sc.take<double>(S1), *d_fy = sc.take<double>(S1);
-        double *d_scr0 = sc.take<double>(S1), *d_scr1 = sc.take<double>(S1), *d_scr2 = sc.take<double>(S1);
+        double *d_scr0 = sc.take<double>(S1), *d_scr1 = sc.take<double>(S1);
+        // the t-statistics of the two-kernel segmentation (reads beyond ~90 k samples) live where the rescaled signal will
+        // be: that stage runs in the first pass only, before eval_kernel writes the plane, and nothing reads it in between
+        double *d_scr2 = x.d_resc;
         x.d_maskbits = sc.take<uint32_t>(S1 / 32 + R1 + 2);
         Carver rcv(W.reads.p);
         x.d_nruns = rcv.take<int32_t>(R1);
