@@ -30,3 +30,15 @@ extern "C" int wsx_test_place_lane_major(int S, const int32_t *pred_ptr, const i
     for (int q = 0; q < K * 64; q++) state_at[q] = p.pl.state_at[q];
     return p.lm;
 }
+
+extern "C" int wsx_test_place_lane_stacked(int S, const int32_t *pred_ptr, const int32_t *pred_idx, int K, uint16_t *pos,
+                                           uint16_t *state_at, int *lanes, uint64_t *stack_mask)
+{
+    const WsxLanePlacement p = wsx_place_lane_stacked(S, pred_ptr, pred_idx, K);
+    *lanes = p.lanes;
+    *stack_mask = p.stack_mask;
+    if (p.lm == 0) return 0;
+    for (int j = 0; j < S; j++) pos[j] = p.pl.pos[j];
+    for (int q = 0; q < K * 64; q++) state_at[q] = p.pl.state_at[q];
+    return p.lm;
+}

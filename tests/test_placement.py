@@ -195,3 +195,72 @@ def test_lane_major_placement_on_random_loci(shim):
                 fits += 1
                 check_lane_major(t, K, lm, pos, sa)
     assert fits >= 20
+
+
+def place_lane_stacked(lib, t, K):
+    S = t.n_states
+    pp, pi = np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32)
+    pos, sa = np.zeros(S, np.uint16), np.zeros(K * 64, np.uint16)
+    lanes, mask = C.c_int(), C.c_uint64()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lm = lib.wsx_test_place_lane_stacked(S, p(pp), p(pi), K, p(pos), p(sa), C.byref(lanes), C.byref(mask))
+    return lm, pos, sa, lanes.value, mask.value
+
+
+def check_lane_stacked(t, K, pos, sa, mask):
+    """The contract dp_row<.., LM = 4> relies on: a permutation; a state above slot 0 has exactly one predecessor -- right
+    below it in the same lane, or anywhere if it sits in the stack slot (2) of a lane of the stack mask; slot-0 states may
+    have any predecessors (every slot exports)."""
+    S = t.n_states
+    assert len(set(int(x) for x in pos)) == S and all(int(sa[int(pos[j])]) == j for j in range(S))
+    assert sum(1 for q in sa if q != 0xFFFF) == S
+    for j in range(S):
+        slot, lane = int(pos[j]) // 64, int(pos[j]) % 64
+        inc = t.incoming(j)
+        if slot == 2 and (mask >> lane) & 1:
+            assert len(inc) == 1, (j, inc)
+        elif slot > 0:
+            assert len(inc) == 1 and int(pos[inc[0]]) == (slot - 1) * 64 + lane, (j, slot, lane, inc)
+    for lane in range(64):
+        if (mask >> lane) & 1:
+            assert sa[2 * 64 + lane] != 0xFFFF  # a stacked lane has a state in the stack slot
+
+
+@pytest.mark.parametrize('pattern,name', [('(AGC)AACAGCCGCCAC(CGC)', 'HD'), ('((CAGG){CAGM})(CAGA)(CA)', 'DM2')])
+def test_stacked_lane_major_takes_the_complex_example_loci(shim, pattern, name):
+    """HD and DM2 (upstream's example configuration) at flank 110: many short chains and little room -- the plain lane-major
+    layout refuses at least one strand of each; two pieces to a lane fit both strands of HD in four slots and DM2's
+    266-state strand in five.  (The caller uses the stacked layout for five slots only: with four it measured slower than
+    the slot-major kernel, profiles/r03_stacked_ab.log.)"""
+    locus = synth.make_locus(pattern, 110, 7)
+    plain_refused = fitted = 0
+    for t in (locus.template, locus.reverse):
+        K = (t.n_states + 63) // 64
+        lm, _, _, _ = place_lane_major(shim, t, K)
+        plain_refused += lm == 0
+        lm4, pos, sa, lanes, mask = place_lane_stacked(shim, t, K)
+        if lm4:
+            assert lm4 == 4 and lanes <= 64
+            check_lane_stacked(t, K, pos, sa, mask)
+            fitted += 1
+    assert plain_refused >= 1 and fitted >= (2 if name == 'HD' else 1)
+
+
+def test_stacked_lane_major_on_random_loci(shim):
+    rng = np.random.default_rng(9)
+    units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA']
+    fits = 0
+    for it in range(80):
+        pat = ''.join('(' + units[int(rng.integers(len(units)))] + ')' + ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(0, 6))))
+                      for _ in range(int(rng.integers(1, 4))))
+        locus = synth.make_locus(pat, int(rng.integers(60, 150)), int(rng.integers(1 << 20)))
+        for t in (locus.template, locus.reverse):
+            K = (t.n_states + 63) // 64
+            if K < 4 or K > 5:
+                continue
+            lm, pos, sa, lanes, mask = place_lane_stacked(shim, t, K)
+            if lm:
+                fits += 1
+                check_lane_stacked(t, K, pos, sa, mask)
+    assert fits >= 20
+

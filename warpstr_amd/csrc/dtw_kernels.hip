@@ -106,6 +106,7 @@ struct FillState {
     int paddr[K][F];                                  // LDS double index of predecessor f's export slot
     bool cutf[K];
     double x[2][K]; // lane-major placement (LM): x[i&1][k] = the export slot k made at row i, for the state above it in the lane
+    bool stk;       // LM = 4: this lane's slot WSX_DEV_STACK_SLOT starts a piece of its own (predecessor through LDS)
 };
 
 // x + |a| as ONE VALU op: the abs is a source modifier.  (Written as asm because the compiler otherwise
@@ -192,6 +193,9 @@ __host__ __device__ constexpr int mask_index(int k, int f) { return k == 0 ? f :
 // read; only slot 0 (chain heads, states with several predecessors, continuations of a chain from the lane before) reads
 // LDS, and only the slots such states read from write it: slots 0 and K-1 (LM = 1), 0, 1 and K-1 (LM = 3) or all (LM = 2).  The slots are then
 // walked downwards, so that slot k takes slot k-1's export of two rows ago before slot k-1 replaces it.
+// LM = 4 ("stacked", wsx_place_lane_stacked): as LM = 2, and in the lanes of the automaton's stack mask the state in slot
+// WSX_DEV_STACK_SLOT starts a piece of its own -- one predecessor, anywhere -- so that slot reads LDS as well and every lane
+// picks its source (two v_cndmask per row).
 template <int M, int K, int F, int FL, bool MROW, int PAR, bool FORCED, bool CUT, int LM = 0>
 __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int wl, double snext,
                                        uint64_t (&mk)[F + (K - 1) * FL], const uint64_t (&cutm)[K])
@@ -204,7 +208,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
     for (int k = 0; k < K; k++)
 #pragma unroll
         for (int f = 0; f < F; f++) {
-            if (k > 0 && (f >= FL || LM != 0)) continue;
+            if (k > 0 && (f >= FL || (LM != 0 && !(LM == 4 && k == WSX_DEV_STACK_SLOT)))) continue;
             const double e = ex[rbuf + st.paddr[k][f]];
             if (PAR) st.e0[k][f] = e;
             else st.e1[k][f] = e;
@@ -224,7 +228,9 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
 #pragma unroll
             for (int f = 0; f < F; f++) {
                 if (f < Fk) {
-                    const double cand = add_abs((LM != 0 && k > 0) ? st.x[PAR][k - 1] : (PAR ? st.e1[k][f] : st.e0[k][f]), st.acur[k]);
+                    double src = (LM != 0 && k > 0) ? st.x[PAR][k - 1] : (PAR ? st.e1[k][f] : st.e0[k][f]);
+                    if (LM == 4 && k == WSX_DEV_STACK_SLOT) src = st.stk ? (PAR ? st.e1[k][f] : st.e0[k][f]) : src;
+                    const double cand = add_abs(src, st.acur[k]);
                     uint64_t lt = lt_mask(cand, best);
                     if (CUT) lt &= ~cutm[k];
                     mk[mask_index<F, FL>(k, f)] = lt;
@@ -243,7 +249,7 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
         // (wl: the lane's export slot -- its lane number, or for single-slot automata the slot wsx_place.h gave its state)
         const double enew = MROW ? st.g[k][M - 2] : st.g[k][M - 1];
         if (LM != 0 && k < K - 1) st.x[PAR][k] = enew;
-        if (LM == 0 || LM == 2 || k == 0 || k == K - 1 || (LM == 3 && k == 1)) ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = enew;
+        if (LM == 0 || LM == 2 || LM == 4 || k == 0 || k == K - 1 || (LM == 3 && k == 1)) ex[wbuf + (K == 1 ? wl : k * 64 + wl)] = enew;
 
     }
     __builtin_amdgcn_wave_barrier();
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(64 * WSX_FILL_WPB) void dtw_fill_fast(PassArgs a)
         ex[K * 64 + lane] = kInf;
         ex[EXW + K * 64 + lane] = kInf;
     }
+    st.stk = LM == 4 && ((A.stack_mask >> lane) & 1ull);
 
     // ---- row 0 (caller.py:201-208) -----------------------------------------------------------
     const double v0 = A.value[0];
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(256) void traceback_mask_kernel(PassArgs a)
             const int back = m - (int)((cmasked >> l) & 1ull);
             // lane-major placement: the one predecessor of a position above slot 0 sits right below it -- no table look-up
             // (a dependent scalar load per transition otherwise)
-            if (a.lane_major && ks > 0) q -= 64;
+            if (a.lane_major && ks > 0 && !(ks == WSX_DEV_STACK_SLOT && ((A.stack_mask >> bit) & 1ull))) q -= 64;
             else q = (int)((pred4[q] >> (16 * (ptr - 1))) & 0xffffull); // fan-in <= 4 in the register-resident fill
             i = start - back;
             if ((i >> 6) != cb) return false; // a step never skips a block: back <= m rows
@@ -1127,7 +1134,7 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipS
 {
     if (lm != 0) { // lane-major placement: slots above 0 take their one predecessor from the lane's own registers
         if constexpr (K >= 2 && M == 4) {
-            if (FL != 1 || pk || lm > 3) return hipErrorInvalidValue;
+            if (FL != 1 || pk || lm > 4) return hipErrorInvalidValue;
             if constexpr (K >= 4) {
                 switch (F * 10 + lm) {
                 case 23: return launch_fill<M, K, 2, 1, false, 3>(a, s);
@@ -1135,6 +1142,14 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipS
                 case 43: return launch_fill<M, K, 4, 1, false, 3>(a, s);
                 }
             }
+            if constexpr (K >= 5) { // stacked placement: five slots only (four: measured slower than slot-major, wsx_api.hip)
+                switch (F * 10 + lm) {
+                case 24: return launch_fill<M, K, 2, 1, false, 4>(a, s);
+                case 34: return launch_fill<M, K, 3, 1, false, 4>(a, s);
+                case 44: return launch_fill<M, K, 4, 1, false, 4>(a, s);
+                }
+            }
+            if (lm == 4) return hipErrorInvalidValue;
             switch (F * 10 + (lm == 3 ? 2 : lm)) {
             case 21: return launch_fill<M, K, 2, 1, false, 1>(a, s);
             case 22: return launch_fill<M, K, 2, 1, false, 2>(a, s);

@@ -35,12 +35,15 @@ thread_local std::string g_err;
         }                                                                                                         \
     } while (0)
 
+static_assert(WSX_STACK_SLOT == WSX_DEV_STACK_SLOT, "placement and kernels agree on the stack slot");
+
 struct Variant { // which DP kernel an automaton uses
     int K = 1, F = 2;
     bool generic = false;
     int FL = 2; // predecessors considered by slots 1..: FL < F when the states with more sit in slot 0 ("split")
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
-    int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot
+    int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot,
+                     // 4 = every slot and two pieces to a lane (stacked)
     // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
     //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
     //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
@@ -523,9 +526,18 @@ try {
             }();
             if (lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K))
                 lp = wsx_place_lane_major(S, A.pred_ptr, A.pred_idx, v.K);
+            // ... and for five-slot automata with many short chains and little room (DM2 at flank 110: 266 states) its
+            // stacked form: two pieces to a lane, the upper one's first state reading LDS in slot 2, every slot exporting.
+            // 20 000 reads x 3 000 samples, same box (profiles/r03_stacked_ab.log): DM2 17.0 -> 16.5 ms per call; with four
+            // slots it LOSES to the slot-major kernel (HD, both strands: 12.1 vs 11.8 ms -- four exports and the extra read
+            // load the LDS pipe as much as the slot-major exchange does), so four-slot automata keep that one.
+            if (lp.lm == 0 && lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K) && v.K >= 5 &&
+                !getenv("WSX_NO_STACKED"))
+                lp = wsx_place_lane_stacked(S, A.pred_ptr, A.pred_idx, v.K);
             if (lp.lm != 0) {
                 v.FL = 1;
-                v.lm = lm_mode == 2 ? 2 : (lp.lm == 3 && v.K < 4 ? 2 : lp.lm);
+                v.lm = lp.lm == 4 ? 4 : lm_mode == 2 ? 2 : (lp.lm == 3 && v.K < 4 ? 2 : lp.lm);
+                D.stack_mask = lp.stack_mask;
             }
             const WsxPlacement pl = lp.lm != 0 ? lp.pl
                                     : getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk

@@ -16,6 +16,11 @@
 #define WSX_MAX_F 4
 #define WSX_MAX_STREAMS 8 // chunks of a batch rotate over this many HIP streams      // fan-in handled by the register-resident DP kernel
 
+#ifndef WSX_STACK_SLOT_DEFINED
+#define WSX_STACK_SLOT_DEFINED
+constexpr int WSX_DEV_STACK_SLOT = 2; // = WSX_STACK_SLOT of wsx_place.h (static_assert in wsx_api.hip)
+#endif
+
 struct DevAutomaton {
     int32_t n_states;
     int32_t endstate;
@@ -36,6 +41,7 @@ struct DevAutomaton {
     const uint16_t *state_at; // position -> state (0xFFFF = none); NULL = identity
     const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
                             // predecessors, 16 bits each (mask traceback)
+    uint64_t stack_mask;    // stacked lane-major placement (wsx_place.h, LM = 4): lanes whose slot WSX_STACK_SLOT reads LDS
 };
 
 struct DevParams {

@@ -389,9 +389,12 @@ inline WsxPlacement wsx_place_states(int S, const int32_t *pp, const int32_t *pi
 // ------------------------------------------------------------------------------------------------------------------
 struct WsxLanePlacement {
     WsxPlacement pl;   // pos, state_at, wslot (identity)
-    int lm = 0;        // 0: does not fit; 1: slots 0 and K-1 export; 3: slots 0, 1 and K-1; 2: every slot exports
+    int lm = 0;        // 0: does not fit; 1: slots 0 and K-1 export; 3: slots 0, 1 and K-1; 2: every slot exports;
+                       // 4: stacked (wsx_place_lane_stacked): every slot exports, lanes in stack_mask read LDS in slot 2 too
     int lanes = 0;
+    uint64_t stack_mask = 0; // lm = 4: lanes whose slot WSX_STACK_SLOT starts a piece of its own (one predecessor, through LDS)
 };
+constexpr int WSX_STACK_SLOT = 2;
 
 inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int32_t *pi, int K)
 {
@@ -502,5 +505,105 @@ inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int
     pl.identity = false;
     pl.low8 = false;
     pl.conflict_cycles = 0; // (not modelled: this layout leaves the LDS pipe mostly idle)
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stacked lane-major placement (LM = 4), for automata with many short chains and little room (HD, DM2 at flank 110): a
+// lane may hold TWO pieces -- one in slots 0..1, one from slot WSX_STACK_SLOT (= 2) upwards.  The state that starts the upper
+// piece has exactly one predecessor, somewhere else, and takes it through LDS (its own read and a per-lane select in
+// dp_row: +1 LDS read, +2 vector instructions per row); every slot exports.  Chains are NOT cut behind sources here (any
+// slot exports), only where the automaton branches; what is left of a chain after its full lanes (r < K states) becomes
+// a lower part (<= 2 states, any head) and/or an upper part (<= K-2 states; a cut inside a chain always leaves a state
+// with one predecessor).  Lanes = full lanes + max(lower parts, upper parts).
+// ------------------------------------------------------------------------------------------------------------------
+inline WsxLanePlacement wsx_place_lane_stacked(int S, const int32_t *pp, const int32_t *pi, int K)
+{
+    using namespace wsx_place_detail;
+    WsxLanePlacement out;
+    constexpr int SS = WSX_STACK_SLOT;
+    if (K < SS + 1 || S > K * 64) return out;
+    const int UP = K - SS; // capacity of an upper part
+    std::vector<std::vector<int>> succ(S);
+    for (int j = 0; j < S; j++)
+        for (int e = pp[j]; e < pp[j + 1]; e++) succ[pi[e]].push_back(j);
+    std::vector<int> tail(S, 1);
+    for (int it = 0; it <= S; it++) {
+        bool changed = false;
+        for (int j = S - 1; j >= 0; j--) {
+            int best = 0;
+            for (int c : succ[j])
+                if (fanin(pp, c) == 1) best = std::max(best, tail[c]);
+            if (1 + best != tail[j]) tail[j] = 1 + best, changed = true;
+        }
+        if (!changed) break;
+        if (it == S) return out;
+    }
+    std::vector<int> child(S, -1), parent(S, -1);
+    for (int p = 0; p < S; p++) {
+        for (int c : succ[p])
+            if (fanin(pp, c) == 1 && (child[p] < 0 || tail[c] > tail[child[p]])) child[p] = c;
+        if (child[p] >= 0) parent[child[p]] = p;
+    }
+    struct Part {
+        std::vector<int> states;
+        bool soft; // its first state has exactly one predecessor: may start at the stack slot
+    };
+    std::vector<std::vector<int>> full; // K states each: one lane
+    std::vector<Part> lower, upper, flexible;
+    for (int h = 0; h < S; h++) {
+        if (parent[h] >= 0) continue;
+        std::vector<int> chain;
+        for (int j = h; j >= 0; j = child[j]) {
+            chain.push_back(j);
+            if ((int)chain.size() > S) return out;
+        }
+        const int q = (int)chain.size() / K, r = (int)chain.size() % K;
+        for (int a = 0; a < q; a++) full.emplace_back(chain.begin() + a * K, chain.begin() + (a + 1) * K);
+        if (r == 0) continue;
+        std::vector<int> rem(chain.begin() + q * K, chain.end());
+        const bool soft = fanin(pp, rem[0]) == 1;
+        if (r <= SS && !(soft && r <= UP)) lower.push_back({rem, soft});
+        else if (r <= SS || (soft && r <= UP)) {
+            if (r <= SS) flexible.push_back({rem, soft}); // either half takes it
+            else upper.push_back({rem, soft});
+        } else { // longer than the lower half and not allowed (or too long) for the upper one: split behind slot 1
+            lower.push_back({std::vector<int>(rem.begin(), rem.begin() + SS), soft});
+            std::vector<int> rest(rem.begin() + SS, rem.end());
+            if ((int)rest.size() > UP) return out; // (cannot happen: r <= K-1 = SS + UP - 1)
+            upper.push_back({rest, true});
+        }
+    }
+    for (auto &f : flexible) (lower.size() <= upper.size() ? lower : upper).push_back(f);
+    const int lanes = (int)full.size() + (int)std::max(lower.size(), upper.size());
+    if (lanes > 64) return out;
+    out.lm = 4;
+    out.lanes = lanes;
+    WsxPlacement &pl = out.pl;
+    pl.pos.assign(S, 0);
+    pl.state_at.assign((size_t)K * 64, 0xFFFF);
+    pl.wslot.resize((size_t)K * 64);
+    std::iota(pl.wslot.begin(), pl.wslot.end(), (uint16_t)0);
+    auto put = [&](int state, int slot, int l) {
+        pl.pos[state] = (uint16_t)(slot * 64 + l);
+        pl.state_at[slot * 64 + l] = (uint16_t)state;
+    };
+    int lane = 0;
+    for (auto &f : full) {
+        for (int s2 = 0; s2 < K; s2++) put(f[s2], s2, lane);
+        lane++;
+    }
+    for (size_t q = 0; q < std::max(lower.size(), upper.size()); q++) {
+        if (q < lower.size())
+            for (size_t s2 = 0; s2 < lower[q].states.size(); s2++) put(lower[q].states[s2], (int)s2, lane);
+        if (q < upper.size()) {
+            for (size_t s2 = 0; s2 < upper[q].states.size(); s2++) put(upper[q].states[s2], SS + (int)s2, lane);
+            out.stack_mask |= 1ull << lane;
+        }
+        lane++;
+    }
+    pl.identity = false;
+    pl.low8 = false;
+    pl.conflict_cycles = 0;
     return out;
 }
