@@ -431,6 +431,25 @@ def test_signal_loader_matches_reference_and_host():
             assert len(got) == len(ref) and np.array_equal(got, ref, equal_nan=True), (mode, i)  # (flat reads: 0/0 on both sides)
     out, ooff, _ = hip.prepare_signals([z['raw']], [(0, len(z['raw']) - 1)], 'Brute')
     assert np.array_equal(out, z['norm'])              # bit-identical to upstream normalize_signal_mad(brute_remove(raw))
+    # a batch of segment-sized reads only: the one-wave-per-read kernel takes them, and the general kernels look at 256
+    # reads per block for what it left -- here every seventh read, whose values span more than its histogram; the
+    # stragglers sit at the start, in the middle and at the end of the 256-read groups, and the last group is partial
+    sraws, spos = [], []
+    for k in range(700):
+        n = int(rng.integers(40, 6000))
+        raw = rng.normal(520, 70, size=n).astype(np.int16)
+        raw[rng.integers(0, n, size=max(1, n // 150))] = rng.choice([100, 1200, 30, 2500], size=max(1, n // 150))
+        if k % 7 == 0 or k in (255, 256, 511, 699):
+            raw[[3, n // 2, n - 1]] = [6000, -2500, 6100]
+        sraws.append(raw)
+        a0 = int(rng.integers(0, n))
+        spos.append((a0, int(rng.integers(a0, n + 20))))
+    for mode in ('Brute', 'None'):
+        out, ooff, ss = hip.prepare_signals(sraws, spos, mode)
+        for i, (raw, p) in enumerate(zip(sraws, spos)):
+            ref = process_raw(raw, p, mode)
+            got = out[ooff[i]:ooff[i + 1]]
+            assert len(got) == len(ref) and np.array_equal(got, ref, equal_nan=True), (mode, i)
     # device-resident raw reads: a 16-byte aligned buffer takes the eight-samples-per-load passes, a buffer that starts
     # two bytes later the one-sample-per-lane ones; both equal the host-buffer result.  (Device memory straight from the
     # HIP runtime the library itself is linked against: a second runtime in the process, e.g. torch's, is not needed.)

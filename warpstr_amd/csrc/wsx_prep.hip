@@ -50,7 +50,26 @@ struct PrepArgs {
     long long *ol_list;
     unsigned int *ol_count; // [n]
     uint8_t *done;          // [n]: 1 = the read went through short_read_kernel, the general kernels skip it
+    int group;              // reads a block of the general kernels looks after (1; 256 for chunks short_read_kernel has been through)
 };
+
+// The general kernels, a block per read -- or, for a chunk short_read_kernel has been through, a block per `group` reads:
+// nearly all of them are done then, and finding that out a block per read cost 0.07-0.23 ms per kernel and 100 k reads
+// (0.85 ms of the 2.6 ms the loader added to a step).  The block looks at its reads' flags together and leaves if none is
+// left; what is left (a read that spans more than PREP_SHORT_BINS values) is done read by read.  Inside the braces `r` is the
+// read; `continue` leaves it (block-uniform conditions only: there are barriers inside).
+#define PREP_READS_BEGIN(a, r)                                                                                      \
+    const int prep_g_ = (a).group > 1 ? (a).group : 1;                                                              \
+    const int prep_r0_ = (int)blockIdx.x * prep_g_;                                                                 \
+    if (prep_g_ > 1) {                                                                                              \
+        int left_ = 0;                                                                                              \
+        for (int q_ = threadIdx.x; q_ < prep_g_ && prep_r0_ + q_ < (a).n; q_ += blockDim.x) left_ |= !(a).done[prep_r0_ + q_]; \
+        if (!__syncthreads_or(left_)) return;                                                                       \
+    }                                                                                                               \
+    for (int r = prep_r0_; r < prep_r0_ + prep_g_ && r < (a).n; r++) {                                              \
+        if (prep_g_ > 1 && r > prep_r0_) __syncthreads();                                                           \
+        if ((a).done[r]) continue;
+#define PREP_READS_END }
 
 __device__ __forceinline__ long long ol_base(const PrepArgs &a, int r) { return a.roff[r] / 16 + 64ll * r; }
 __device__ __forceinline__ unsigned int ol_cap(const PrepArgs &a, int r) { return (unsigned int)((a.roff[r + 1] - a.roff[r]) / 16 + 64); }
@@ -86,14 +105,13 @@ __device__ __forceinline__ void for_each_sample8(const int16_t *buf, long long s
 // copy + smallest / largest value of the read (spike removal writes medians of neighbours, so the range stays valid)
 __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    __shared__ long long bl_list[256];
+    __shared__ unsigned int bl_count, bl_base;
+    PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
     int lo = 32767, hi = -32768;
-    // the block's outliers collect in LDS and join the read's list with one atomic per block
-    __shared__ long long bl_list[256];
-    __shared__ unsigned int bl_count, bl_base;
+    // the block's outliers collect in LDS (bl_list, bl_count) and join the read's list with one atomic per block
     if (threadIdx.x == 0) bl_count = 0;
     __syncthreads();
     auto note_outlier = [&](long long i) {
@@ -136,13 +154,14 @@ __global__ __launch_bounds__(256) void copy_kernel(PrepArgs a)
     if (a.ol_list) {
         __syncthreads();
         const unsigned int nb = bl_count;
-        if (nb == 0) return;
+        if (nb == 0) continue;
         if (threadIdx.x == 0) // more than 256 outliers in one block: the read is scanned sample by sample instead
             bl_base = nb > 256 ? atomicOr(&a.ol_count[r], OL_OVERFLOW) : atomicAdd(&a.ol_count[r], nb);
         __syncthreads();
         if (nb <= 256 && bl_base + nb <= ol_cap(a, r))
             for (unsigned int q = threadIdx.x; q < nb; q += 256) a.ol_list[ol_base(a, r) + bl_base + q] = bl_list[q];
     }
+    PREP_READS_END
 }
 
 // spike_removal median3 / median5 (remove_spikes, src/schemas/fast5.py:68-75): scipy.signal.medfilt of the raw integer read
@@ -155,8 +174,7 @@ template <int W>
 __global__ __launch_bounds__(256) void medfilt_kernel(PrepArgs a)
 {
     static_assert(W == 3 || W == 5, "median3 / median5");
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_STREAM, c1 = c0 + PREP_STREAM < len ? c0 + PREP_STREAM : len;
     const int16_t *src = a.raw + a.roff[r];
@@ -187,16 +205,17 @@ __global__ __launch_bounds__(256) void medfilt_kernel(PrepArgs a)
         atomicMin(&a.mm[2 * r], lo);
         atomicMax(&a.mm[2 * r + 1], hi);
     }
+    PREP_READS_END
 }
 
 // zeroes the occupied range of every read's histogram
 __global__ __launch_bounds__(256) void zero_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const int range = a.mm[2 * r + 1] - a.mm[2 * r] + 1;
     uint32_t *h = a.hist + (size_t)r * 65536;
     for (int b = blockIdx.y * 256 + threadIdx.x; b < range; b += gridDim.y * 256) h[b] = 0u;
+    PREP_READS_END
 }
 
 // np.median of 2..5 int16 values, stored back into int16 (truncation toward zero)
@@ -219,8 +238,7 @@ __device__ int16_t median_small(int *w, int cnt)
 
 __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     const int16_t *raw = a.raw + a.roff[r];
     int16_t *out = a.clean + a.roff[r];
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
             else break;
         }
     };
-    if (a.ol_list && a.ol_count[r] <= ol_cap(a, r)) return; // the listed outliers are handled by spike_list_kernel
+    if (a.ol_list && a.ol_count[r] <= ol_cap(a, r)) continue; // the listed outliers are handled by spike_list_kernel
     if (a.vec) {
         const long long ro = a.roff[r];
         for_each_sample8(a.raw, ro + c0, ro + c1, threadIdx.x, 256, [&](short8 v, long long base, int first, int last) {
@@ -252,16 +270,16 @@ __global__ __launch_bounds__(256) void spike_kernel(PrepArgs a)
         for (long long i = c0 + threadIdx.x; i < c1; i += 256)
             if (is_outlier(raw, i)) fix_chain_from(i);
     }
+    PREP_READS_END
 }
 
 // Spike removal from the copy pass's outlier lists: one block per read, one thread per listed outlier; the one that heads
 // a chain (neither of the two samples before it is an outlier) repairs the whole chain serially, exactly as spike_kernel.
 __global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const unsigned int total = a.ol_count[r];
-    if (total > ol_cap(a, r)) return; // overflow: spike_kernel scans this read
+    if (total > ol_cap(a, r)) continue; // overflow: spike_kernel scans this read
     const long long len = a.roff[r + 1] - a.roff[r];
     const int16_t *raw = a.raw + a.roff[r];
     int16_t *out = a.clean + a.roff[r];
@@ -280,6 +298,7 @@ __global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
             else break;
         }
     }
+    PREP_READS_END
 }
 
 #define PREP_LDS_BINS 8192
@@ -290,11 +309,10 @@ __global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
 __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
 {
     __shared__ uint32_t lh[PREP_LDS_BINS];
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_CHUNK, c1 = c0 + PREP_CHUNK < len ? c0 + PREP_CHUNK : len;
-    if (c0 >= c1) return;
+    if (c0 >= c1) continue;
     const int16_t *x = a.clean + a.roff[r];
     const int vmin = a.mm[2 * r], range = a.mm[2 * r + 1] - vmin + 1;
     uint32_t *h = a.hist + (size_t)r * 65536;
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
     } else {
         for (long long i = c0 + threadIdx.x; i < c1; i += 256) atomicAdd(&h[(int)x[i] - vmin], 1u);
     }
+    PREP_READS_END
 }
 
 // value of the order statistic of rank k (0-based) given the histogram: smallest v with cum(v) > k
@@ -412,8 +431,7 @@ __device__ __forceinline__ void read_stats(const uint32_t *h, int vmin, int vmax
 
 __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const int lane = threadIdx.x;
     const long long n = a.roff[r + 1] - a.roff[r];
     const uint32_t *h = a.hist + (size_t)r * 65536;
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
             a.shift_scale[2 * r] = 0.0;
             a.shift_scale[2 * r + 1] = 1.0;
         }
-        return;
+        continue;
     }
     double shift, scale;
     read_stats(h, a.mm[2 * r], a.mm[2 * r + 1], n, lane, shift, scale);
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(64) void stats_kernel(PrepArgs a)
         a.shift_scale[2 * r] = shift;
         a.shift_scale[2 * r + 1] = scale;
     }
+    PREP_READS_END
 }
 
 // Short reads (the STR segments themselves: a few thousand samples): the whole loader in ONE wavefront per read, everything
@@ -610,8 +629,7 @@ __global__ __launch_bounds__(64) void short_read_kernel(PrepArgs a, int cap)
 
 __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
 {
-    const int r = blockIdx.x;
-    if (a.done[r]) return;
+    PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     long long lo = a.seg_lo[r], hi = a.seg_hi[r] + 1; // python slice [lo:hi)
     if (lo < 0) lo += len;
@@ -626,6 +644,7 @@ __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
     double *out = a.out + a.ooff[r];
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.y * 256)
         out[i] = ((double)x[i] - shift) / scale;
+    PREP_READS_END
 }
 
 } // namespace
@@ -761,7 +780,7 @@ try {
         }
         uint8_t *d_done = nullptr;
         PCHK(alloc((void **)&d_done, (size_t)cnt));
-        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec, d_ol, d_olc, d_done};
+        PrepArgs a{d_raw, d_clean, d_roff, d_lo, d_hi, d_ooff, d_hist, d_mm, d_ss, d_out, (int)cnt, (int)max_len, vec, d_ol, d_olc, d_done, 1};
         int64_t max_out = 0;
         for (int64_t r = 0; r < cnt; r++) max_out = std::max(max_out, h_ooff[r + 1] - h_ooff[r]);
         // (a chunk of short reads: the general kernels mostly find done[r] set -- one block per read is enough for the rest)
@@ -776,21 +795,24 @@ try {
             const size_t lds = (size_t)cap * 2 + (size_t)cap / 8 + 8 + PREP_SHORT_BINS * 4;
             if (min_len <= cap && spike_removal <= 1 && !getenv("WSX_PREP_GENERAL")) {
                 hipLaunchKernelGGL(short_read_kernel, dim3((unsigned)cnt), dim3(64), lds, st, a, cap);
+                // every read could go that way: what is left for the general kernels is the odd read with a wide value range
+                if (max_len <= cap && !getenv("WSX_PREP_NO_GROUPS")) a.group = 256;
             } else {
                 PCHK(hipMemsetAsync(d_done, 0, (size_t)cnt, st)); // no read of this chunk is short
             }
         }
-        if (spike_removal == 2) hipLaunchKernelGGL(medfilt_kernel<3>, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
-        else if (spike_removal == 3) hipLaunchKernelGGL(medfilt_kernel<5>, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)cnt, max_len <= 8192 ? 1 : 8), dim3(256), 0, st, a);
+        const unsigned gx = (unsigned)((cnt + a.group - 1) / a.group); // blocks along x: one per read, or per group of reads
+        if (spike_removal == 2) hipLaunchKernelGGL(medfilt_kernel<3>, dim3(gx, gs), dim3(256), 0, st, a);
+        else if (spike_removal == 3) hipLaunchKernelGGL(medfilt_kernel<5>, dim3(gx, gs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(copy_kernel, dim3(gx, gs), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(zero_kernel, dim3(gx, max_len <= 8192 ? 1 : 8), dim3(256), 0, st, a);
         if (spike_removal == 1) {
-            if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3((unsigned)cnt), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(spike_kernel, dim3((unsigned)cnt, gs), dim3(256), 0, st, a); // returns at once unless the list overflowed
+            if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3(gx), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(spike_kernel, dim3(gx, gs), dim3(256), 0, st, a); // returns at once unless the list overflowed
         }
-        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)cnt, gc), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(stats_kernel, dim3((unsigned)cnt), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(norm_kernel, dim3((unsigned)cnt, gn), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(hist_kernel, dim3(gx, gc), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stats_kernel, dim3(gx), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(norm_kernel, dim3(gx, gn), dim3(256), 0, st, a);
         PCHK(hipGetLastError());
         if (host) PCHK(hipMemcpyAsync(signal_out + obase, d_out, (size_t)osz * 8, hipMemcpyDeviceToHost, st));
         if (shift_scale) {
