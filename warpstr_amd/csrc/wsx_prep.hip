@@ -624,7 +624,24 @@ __global__ __launch_bounds__(64) void short_read_kernel(PrepArgs a, int cap)
     if (shi > len) shi = len;
     const int cnt = (int)(a.ooff[r + 1] - a.ooff[r]);
     double *out = a.out + a.ooff[r];
-    for (int i = lane; i < cnt; i += 64) out[i] = ((double)s_x[slo + i] - shift) / scale;
+    // (x - shift) / scale with the part of the compiler's fp64 division that depends on the denominator alone done once per
+    // read (mid_kernels.hip: wsx_div_by -- the same three last operations, bit-identical while v_div_scale would not rescale:
+    // |x - shift| is 0 or in [0.25, 2^17], scale in [0.25, 2^17]; a zero or non-finite scale takes the plain division)
+    if (scale >= 0.25 && scale <= 131072.0) {
+        const double r0 = __builtin_amdgcn_rcp(scale);
+        const double f0 = __builtin_fma(-scale, r0, 1.0);
+        const double r1 = __builtin_fma(r0, f0, r0);
+        const double f1 = __builtin_fma(-scale, r1, 1.0);
+        const double rr = __builtin_fma(r1, f1, r1);
+        for (int i = lane; i < cnt; i += 64) {
+            const double x = (double)s_x[slo + i] - shift;
+            const double q = x * rr;
+            const double e = __builtin_fma(-scale, q, x);
+            out[i] = __builtin_fma(e, rr, q);
+        }
+    } else {
+        for (int i = lane; i < cnt; i += 64) out[i] = ((double)s_x[slo + i] - shift) / scale;
+    }
 }
 
 __global__ __launch_bounds__(256) void norm_kernel(PrepArgs a)
