@@ -889,3 +889,16 @@ def test_random_loci_reach_every_kind_of_fill_kernel():
     # several slots: the lane-major layout where the automaton fits it (both export sets), the slot-major one elsewhere
     assert any(k.endswith(', 1>') for k in multi) and any(k.endswith(', 2>') or k.endswith(', 3>') for k in multi)
     assert any(k.endswith('false, 0>') for k in multi)
+
+
+def test_example_loci_at_the_default_flank_length():
+    """Upstream's example configuration (example/config.yaml): HD and DM2 at flank_length 110.  DM2's 266-state strand takes
+    the stacked lane-major kernel (two pieces to a lane, LM = 4: wsx_place_lane_stacked), its other strand and HD the
+    slot-major ones; every output equals the oracle."""
+    for pattern, want in (('((CAGG){CAGM})(CAGA)(CA)', ', 4>'), ('(AGC)AACAGCCGCCAC(CGC)', 'false, 0>')):
+        locus = synth.make_locus(pattern, 110, 7)
+        sigs, revs, _ = synth.batch(locus, 6, (2400, 3200), 21, lo=3, hi=14)
+        hip, _, n_ok = _compare_with_oracle(locus, 110, sigs, revs)
+        assert n_ok >= 5
+        names = [hip.kernel_name(0), hip.kernel_name(1)]
+        assert any(nm.endswith(want) for nm in names), names
