@@ -109,3 +109,56 @@ def test_timing_window_covers_every_call():
     hip.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
     again = hip.last_timing()
     assert again['dp_launches'] == one['dp_launches']
+
+
+def test_pipelined_calls_with_fitpacks_smoothing_branch():
+    """rescaling.threshold > 1: the one stage with a host decision in the middle of a chunk (how many reads take FITPACK's
+    knot-adding branch sizes their workspace).  Pipelined device-buffer calls on several streams, chunks with and without
+    such reads, growing counts (the workspace is re-allocated while other calls are in flight): same bytes as the
+    synchronous host-buffer calls of another handle."""
+    import copy
+
+    import torch
+    from warpstr_amd.caller import RescalerConfig
+    base = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 20, 31)
+    locus = copy.deepcopy(base)
+    for t in (locus.template, locus.reverse):
+        t.value = np.where(np.arange(t.n_states) % 2 == 0, 3.5, -3.5).astype(np.float64)
+    rc = RescalerConfig(threshold=6.0, max_std=3.0)
+    rng = np.random.default_rng(12)
+    batches = []
+    for n, noise in ((40, 0.05), (300, 0.3), (1200, 0.05), (700, 1.0)):
+        sigs = [rng.normal(0.0, noise, size=int(rng.integers(900, 2200))) for _ in range(n)]
+        sig, off = pack_signals(sigs)
+        batches.append((sig, off, (rng.random(n) < 0.5).astype(np.int32)))
+    hip = HipCaller([locus.template, locus.reverse], [20, 20], rescaler_config=rc, stream=torch.cuda.current_stream().cuda_stream)
+    ref = HipCaller([locus.template, locus.reverse], [20, 20], rescaler_config=rc)
+    want = [ref.call(sig, off, aut, want_debug=True) for sig, off, aut in batches]
+    assert sum(int((w[0]['status'] == 0).sum()) for w in want) > 1000
+    # ... and the batches do hold reads of that kind (the oracle says which: more than the cubic's eight knots)
+    from oracle import oracle
+    oa = [oracle.Automaton.from_table(locus.template, 20), oracle.Automaton.from_table(locus.reverse, 20)]
+    prm = oracle.Params(threshold=6.0, max_std=3.0)
+    sig0, off0, aut0 = batches[0]
+    knots = [oracle.call_read(oa[aut0[i]], sig0[off0[i]:off0[i + 1]], prm) for i in range(12)]
+    assert sum(1 for o in knots if o.status == 0 and o.fit_knots > 8) >= 4
+    for i, o in enumerate(knots):
+        assert want[0][0]['status'][i] == o.status
+        if o.status == 0:
+            assert np.array_equal(want[0][1]['trace2'][off0[i]:off0[i + 1]], o.trace2)
+    dev = torch.device('cuda:0')
+    d_sig = [torch.from_numpy(sig).to(dev) for sig, _, _ in batches]
+    hip.set_pipelined(True)
+    rounds = []
+    for _ in range(3):
+        outs = [(torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                 torch.zeros(len(sig), dtype=torch.int16, device=dev)) for sig, _, aut in batches]
+        for (sig, off, aut), ds, (res, tr2) in zip(batches, d_sig, outs):
+            hip.call_device(ds.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+        rounds.append(outs)
+    hip.synchronize()
+    for outs in rounds:
+        for (res, tr2), (w_res, w_extra) in zip(outs, want):
+            got = res.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+            assert got.tobytes() == w_res.tobytes()
+            assert np.array_equal(tr2.cpu().numpy().view(np.uint16), w_extra['trace2'])
