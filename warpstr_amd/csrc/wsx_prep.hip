@@ -308,7 +308,10 @@ __global__ __launch_bounds__(256) void spike_list_kernel(PrepArgs a)
 // time); reads with a wider range count straight into HBM.
 __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
 {
-    __shared__ uint32_t lh[PREP_LDS_BINS];
+    // (dynamic: PREP_LDS_BINS counters, or none when the block looks after a group of reads -- a block that asks for 32 KB of
+    // LDS waits for a CU with that much free, beside the fills 0.2 ms per launch, only to find its reads done; the odd read
+    // that is left then counts straight into HBM)
+    extern __shared__ uint32_t lh[];
     PREP_READS_BEGIN(a, r)
     const long long len = a.roff[r + 1] - a.roff[r];
     const long long c0 = (long long)blockIdx.y * PREP_CHUNK, c1 = c0 + PREP_CHUNK < len ? c0 + PREP_CHUNK : len;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void hist_kernel(PrepArgs a)
     const int16_t *x = a.clean + a.roff[r];
     const int vmin = a.mm[2 * r], range = a.mm[2 * r + 1] - vmin + 1;
     uint32_t *h = a.hist + (size_t)r * 65536;
-    if (range <= PREP_LDS_BINS) {
+    if (range <= PREP_LDS_BINS && a.group <= 1) {
         for (int b = threadIdx.x; b < range; b += 256) lh[b] = 0u;
         __syncthreads();
         if (a.vec) {
@@ -827,7 +830,7 @@ try {
             if (d_ol) hipLaunchKernelGGL(spike_list_kernel, dim3(gx), dim3(256), 0, st, a);
             hipLaunchKernelGGL(spike_kernel, dim3(gx, gs), dim3(256), 0, st, a); // returns at once unless the list overflowed
         }
-        hipLaunchKernelGGL(hist_kernel, dim3(gx, gc), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(hist_kernel, dim3(gx, gc), dim3(256), a.group > 1 ? 0 : PREP_LDS_BINS * sizeof(uint32_t), st, a);
         hipLaunchKernelGGL(stats_kernel, dim3(gx), dim3(64), 0, st, a);
         hipLaunchKernelGGL(norm_kernel, dim3(gx, gn), dim3(256), 0, st, a);
         PCHK(hipGetLastError());
