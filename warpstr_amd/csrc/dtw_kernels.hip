@@ -257,7 +257,10 @@ __device__ __forceinline__ void dp_row(FillState<M, K, F> &st, double *ex, int w
 
 // (Register budgets: left to the compiler.  Forcing more waves per SIMD was measured slower every time -- two slots at 96
 // registers no gain, four slots at 128 registers 6.0 vs 5.4 ms per launch, the lane-major four-slot kernel at 128 / 96 / 80
-// registers 11.6 / 20.7 / 30.0 vs 10.35 ms per step: profiles/r02_occupancy_forcing.log, scripts/exp_round3_knobs.patch.)
+// registers 11.6 / 20.7 / 30.0 vs 10.35 ms per step: profiles/r02_occupancy_forcing.log, scripts/exp_round3_knobs.patch.
+// Even a budget just below what the compiler takes buys nothing: the four-slot variants with three or four candidates use
+// 172-190 registers (two waves); at 168 (three waves) they spill 20-84 values, none inside the 8-row blocks, parity stays green
+// -- and DM2 at flank 110, whose 254-state strand runs <4,4,3,1>, takes 16.57 instead of 16.5-16.6 ms: profiles/r03_stacked_ab.log.)
 template <int M, int K, int F, int FL, bool PK, int LM = 0>
 #ifndef WSX_FILL_WPB
 #define WSX_FILL_WPB 4 // wavefronts (= reads) per workgroup
