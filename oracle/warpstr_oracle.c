@@ -604,7 +604,10 @@ int wso_curfit(const double *x0, const double *y0, long m_, double s, double *t_
             } else {
                 int npl1 = nplus * 2;
                 const double rn = (double)nplus;
-                if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+                if (fpold - fp > acc) { /* (Fortran's real -> integer assignment; out of range: what x86 gives, INT_MIN) */
+                    const double v = rn * fpms / (fpold - fp);
+                    npl1 = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1);
+                }
                 int mx = npl1 > nplus / 2 ? npl1 : nplus / 2;
                 if (mx < 1) mx = 1;
                 nplus = nplus * 2 < mx ? nplus * 2 : mx;

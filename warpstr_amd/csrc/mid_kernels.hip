@@ -1266,7 +1266,10 @@ __global__ __launch_bounds__(64) void fit_smooth_kernel(FitArgs a, int count, in
             } else {
                 int npl1 = nplus * 2;
                 const double rn = (double)nplus;
-                if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+                if (fpold - fp > acc) { // (out of the integer range: INT_MIN, as the host's conversion gives and the oracle restates)
+                    const double v = rn * fpms / (fpold - fp);
+                    npl1 = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1);
+                }
                 int mx = npl1 > nplus / 2 ? npl1 : nplus / 2;
                 if (mx < 1) mx = 1;
                 nplus = nplus * 2 < mx ? nplus * 2 : mx;
