@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 8
+#define WSX_ABI_VERSION 9
 
 /* function return codes */
 enum {
@@ -139,8 +139,30 @@ int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automat
                       const wsx_params *params, void *stream);
 void wsx_caller_destroy(wsx_caller *c);
 
-/* Upper bound, in bytes, of the device workspace the handle may allocate (default 16 GiB). */
+/*
+ * Upper bound, in bytes, of the device workspace the handle may allocate.  Default: 60 % of the device memory that is free
+ * when the handle is created (at least 2 GiB) -- the handle allocates what a call needs, the limit only decides when a call
+ * is cut into more chunks than its size asks for.  (Upstream has no counterpart: a Pool worker holds one T x S matrix.)
+ */
 int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes);
+int wsx_caller_get_workspace_limit(wsx_caller *c, uint64_t *bytes);
+
+/*
+ * Launch-policy knobs of a handle; the defaults are the measured ones.  Tests use them to force the
+ * fallback kernels; upstream's counterpart is the `threads` argument of CallerWrapper (src/caller/wrapper.py:63-70,104-109):
+ * how the work is spread, never what is computed.
+ */
+enum {
+    WSX_TUNE_STREAM_TRACEBACK_MIN = 1, /* smallest single-slot launch (reads) that takes the thread-per-read traceback; 8192 */
+    WSX_TUNE_BORDERS_WAVE_BELOW = 2,   /* launches of fewer reads take the wave-per-read borders stage; 8192 */
+    WSX_TUNE_SEGMENT_TWO_KERNELS = 3,  /* 1: always the two-kernel segmentation (otherwise only for reads beyond ~90 k samples); 0 */
+    WSX_TUNE_FILL_BLOCKS_PER_CU = 4,   /* > 0: cap the fill's workgroups per CU; 0 */
+    WSX_TUNE_CHUNKS = 5,               /* > 0: chunks per call instead of the built-in rule (also WSX_CHUNKS at creation); 0 */
+    WSX_TUNE_SMALL_PIPE_SAMPLES = 6,   /* pipelined calls up to this many samples stay in one chunk; 52 Mi */
+    WSX_TUNE_CALLS_IN_FLIGHT = 7,      /* pipelined calls the host may run ahead of the device, 2..4; 2 */
+    WSX_TUNE_SMALL_CALLS_IN_FLIGHT = 8 /* ... for one-chunk calls, 2..4; 4 */
+};
+int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value);
 
 /*
  * Number of HIP streams (and workspace sets) the handle may use (1..8, default 4; 1 = everything on the handle's

@@ -1,0 +1,123 @@
+"""Several loci through ONE handle (warpstr_amd/loci.py: main_wrapper_loci; `python -m warpstr_amd.wrapper --config`): mixed-locus
+batches, pipelined, against one main_wrapper call per locus -- every output file byte for byte.  In process (raw int16 reads
+through the GPU loader) and from the command line (a WarpSTR YAML; one rank and two gloo ranks on the one card)."""
+import filecmp
+import os
+import shutil
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from warpstr_amd import overview as ov, synth
+from warpstr_amd.wrapper import LocusPath, main_wrapper, main_wrapper_loci
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUTPUTS = ['overview.csv', 'predictions/sequences/all.fasta', 'predictions/sequences/sequences_template.fasta',
+           'predictions/sequences/sequences_reverse.fasta', 'summaries/state_similarity.csv']
+COMPLEX = 'predictions/complexSTR_analysis/complex_repeat_units.csv'
+# pattern, flank, reads, T: one to four slots, two to four candidates, a locus without saved reads, one with a single read
+LOCI = [('(AGC)', 16, 33, (900, 1600)), ('(AGC)AACAGCCGCCAC(CGC)', 20, 40, (1400, 2200)), ('(AAAT)', 110, 21, (2300, 3100)),
+        ('((CAGG){CAGM})(CAGA)(CA)', 40, 27, (1500, 3000)), ('(GGCCCC)', 30, 0, (900, 1000)), ('(NGC)', 24, 16, (1000, 1800)),
+        ('(CAG)CAACAG(CCG)', 70, 1, (2000, 2400)), ('(CCTG)(TCTG)', 110, 18, (2400, 3300))]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(root, tag):
+    """Locus directories (overview + flanks) under root/tag; returns (loci, raw reads by name, normalised segments by name)."""
+    loci, raws, segs = [], {}, {}
+    for li, (pattern, fl, n, T) in enumerate(LOCI):
+        locus = synth.make_locus(pattern, fl, 300 + li)
+        sigs, revs, _ = synth.batch(locus, n, T, 400 + li, lo=3, hi=10)
+        loc = os.path.join(root, tag, f'locus{li}')
+        ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+        names = [f'L{li}r{i:03d}' for i in range(n + 2)]
+        rng = np.random.default_rng(500 + li)
+        lo, hi = [], []
+        for nm, s in zip(names, sigs):  # the raw read: the segment with some signal on both sides, as DAC values
+            pre, post = int(rng.integers(50, 400)), int(rng.integers(50, 400))
+            whole = np.concatenate([rng.normal(0, 1, pre), s, rng.normal(0, 1, post)])
+            raws[nm] = np.clip(np.round(whole * 70.0 + 500.0), 0, 2047).astype(np.int16)
+            segs[nm] = s
+            lo.append(pre)
+            hi.append(pre + len(s) - 1)
+        pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': list(revs) + [False, True], 'saved': [1] * n + [0, 0],
+                      'l_start_raw': lo + [10, 10], 'r_end_raw': hi + [90, 90]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        loci.append(LocusPath(loc, pattern, fl))
+    return loci, raws, segs
+
+
+def _same(a, b):
+    for la, lb in zip(a, b):
+        rels = OUTPUTS + ([COMPLEX] if os.path.exists(os.path.join(la.path, COMPLEX)) else [])
+        for rel in rels:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), (la.path, rel)
+
+
+def test_eight_loci_in_one_handle_equal_eight_main_wrapper_calls(tmp_path):
+    """From raw int16 reads (the default path: loader kernels + caller, both called sequences packed on the device), cut into
+    batches of at most 30 reads so that several are in flight and loci straddle them."""
+    one, raws, _ = _make(str(tmp_path), 'one')
+    many, _, _ = _make(str(tmp_path), 'many')
+    reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
+    for locus in one:
+        main_wrapper(locus, 1, raw_reader=reader)
+    tm = {}
+    tables = main_wrapper_loci(many, 1, raw_reader=reader, batch_reads=30, timings=tm, quiet=True)
+    _same(one, many)
+    assert tm['n_loci'] == 8 and tm['n_reads'] == sum(n for _, _, n, _ in LOCI) and len(tm['kernels']) >= 4
+    assert os.path.exists(os.path.join(many[1].path, COMPLEX)) and os.path.exists(os.path.join(many[3].path, COMPLEX))
+    for (df, _), (_, _, n, _) in zip(tables, LOCI):
+        assert int((df['results'] >= 0).sum()) == n
+    # the same loci again, everything in one batch: nothing depends on where the list was cut
+    again, _, _ = _make(str(tmp_path), 'again')
+    main_wrapper_loci(again, 1, raw_reader=reader, quiet=True)
+    _same(one, again)
+
+
+def _cli(args, ranks, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    env.update(extra_env or {})
+    tail = ['-m', 'warpstr_amd.wrapper'] + args
+    if ranks == 1:
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port())] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_config_driven_run_on_one_and_two_ranks(tmp_path):
+    """`python -m warpstr_amd.wrapper --config cfg.yaml` (upstream: `python WarpSTR.py cfg.yaml` with tr_region_calling only):
+    one rank and two ranks (gloo collectives, both on the one card) write what eight per-locus command lines write."""
+    one, _, segs = _make(str(tmp_path), 'one')
+    npz = str(tmp_path / 'segments.npz')
+    np.savez(npz, **segs)
+    for locus in one:
+        _cli([locus.path, locus.sequence, str(locus.flank_length), '--segments-npz', npz], 1)
+    for tag, ranks, env in (('cfg1', 1, None), ('cfg2', 2, {'WARPSTR_DIST_BACKEND': 'gloo'})):
+        shutil.copytree(os.path.join(tmp_path, 'one'), os.path.join(tmp_path, tag),
+                        ignore=shutil.ignore_patterns('predictions', 'summaries'))
+        for li in range(len(LOCI)):  # (the copied overviews carry the first run's result columns: start from fresh ones)
+            df = pd.read_csv(os.path.join(tmp_path, tag, f'locus{li}', 'overview.csv'))
+            df.drop(columns=['results', 'orig', 'dtw_cost1', 'dtw_cost2']).to_csv(os.path.join(tmp_path, tag, f'locus{li}', 'overview.csv'), index=False)
+        cfg = tmp_path / f'{tag}.yaml'
+        cfg.write_text(f'output: {tmp_path / tag}\nthreads: 2\ntr_region_calling: True\ngenotyping: False\nloci:\n' + ''.join(
+            f'  - name: locus{li}\n    coord: chr1:1-2\n    sequence: {p}\n    flank_length: {fl}\n' for li, (p, fl, _, _) in enumerate(LOCI)))
+        out = _cli(['--config', str(cfg), '--segments-npz', npz], ranks, env)
+        for li, (_, _, n, _) in enumerate(LOCI):
+            assert f'locus{li}: {n} reads called' in out
+        _same(one, [LocusPath(os.path.join(tmp_path, tag, f'locus{li}'), p, fl) for li, (p, fl, _, _) in enumerate(LOCI)])

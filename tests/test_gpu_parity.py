@@ -162,7 +162,7 @@ def test_alternative_configs_match_golden(case):
         assert res['status'][i] == 0
         assert np.array_equal(ex['trace1'][sl], z[f'r{i}_trace1'])
         assert np.array_equal(ex['badmask'][sl], z[f'r{i}_badmask'])
-        np.testing.assert_allclose(ex['rescaled'][sl], z[f'r{i}_rescaled'], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(ex['rescaled'][sl], z[f'r{i}_rescaled'])  # bit for bit, as in the default cases
         assert np.array_equal(ex['trace2'][sl], z[f'r{i}_trace2'])
         seq, rseq = [str(s) for s in z[f'r{i}_seq']]
         assert (res['len1'][i], res['len2'][i]) == (len(seq), len(rseq))
@@ -800,36 +800,26 @@ def test_host_buffer_transfer_rings():
     assert int((r_big['status'] == 0).sum()) > 3000
 
 
-def test_two_kernel_segmentation_fallback():
+def test_two_kernel_segmentation_fallback(tmp_path, monkeypatch):
     """Reads too long for the fused segmentation kernel's LDS tables take the t-statistics through HBM and scan the
-    chunks one thread each; the knob forces that path for the golden cases (own process: the knob is read once)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, WSX_SEGMENT_TWO_KERNELS='1')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
-                          'test_call_matches_golden or test_upstream_test_case_real_reads'],
-                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert ' passed' in out.stdout
+    chunks one thread each; the handle knob (wsx_caller_set_tuning) forces that path for the golden cases."""
+    monkeypatch.setattr(HipCaller, 'default_tuning', {'segment_two_kernels': 1})
+    for case in DEFAULT_CASES:
+        test_call_matches_golden(case)
+    test_upstream_test_case_real_reads(tmp_path)
 
 
-def test_streaming_traceback_on_small_batches():
+def test_streaming_traceback_on_small_batches(monkeypatch):
     """Automata of up to 64 states have two traceback kernels: wave per read (small launches; also when a handle holds
     more than 64 automata) and the thread-per-read streaming one (launches of 8192 reads and more: the full-size tests
-    run it).  The knob lowers that threshold so that the golden and seeded single-slot cases go through the streaming
-    kernel too (own process: the knob is read once)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, WSX_STREAM_TRACEBACK_MIN='1')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-x', '-m', 'gpu', '-k',
-                          'test_call_matches_golden or test_call_matches_oracle_seeded or test_warp_matches_golden'],
-                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert ' passed' in out.stdout
+    run it).  The handle knob lowers that threshold so that the golden and seeded single-slot cases go through the
+    streaming kernel too."""
+    monkeypatch.setattr(HipCaller, 'default_tuning', {'stream_traceback_min': 1})
+    for case in DEFAULT_CASES:
+        test_call_matches_golden(case)
+        test_warp_matches_golden(case)
+    test_call_matches_oracle_seeded('(AGC)', 16, 1500, 1000)
+    test_call_matches_oracle_seeded('(AGC)AACAGCCGCCAC(CGC)', 19, 2000, 32)
 
 
 def test_long_reads_many_automata_and_degenerate_reads():

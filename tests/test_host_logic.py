@@ -80,6 +80,29 @@ def test_pore_model_tsv_roundtrip(tmp_path):
     assert pm2.get_value('ACGTAC') == pm.get_value('ACGTAC')
 
 
+def test_config_to_loci_like_upstreams_loop(tmp_path):
+    """A WarpSTR configuration with upstream's keys (test/config_template.yaml, example/config.yaml) -> the locus objects the
+    several-loci driver takes: <output>/<name> directories (src/schemas/locus.py:18-46), per-locus flank_length falling back to
+    the global one (WarpSTR.py:33-37 passes every locus dict to Locus)."""
+    from warpstr_amd.config import load_config
+    from warpstr_amd.wrapper import loci_from_config
+    p = tmp_path / 'cfg.yaml'
+    p.write_text('reference_path: /nowhere/GRCh38.fa\noutput: %s\ninputs:\n  - path: test/test_input\n    runs: test_run1\n'
+                 'tr_region_calling: True\ngenotyping: True\nthreads: 3\nrescaling:\n  threshold: 0.4\n'
+                 'guppy_config:\n  path: /x\nloci:\n  - name: Human_STR_1108232\n    coord: chr4:183178378-183178421\n'
+                 '    sequence: (aaat)\n  - name: DM2\n    coord: chr3:129,172,577-129,172,732\n'
+                 '    sequence: ((CAGG){CAGM})(CAGA)(CA)\n    flank_length: 90\n' % (tmp_path / 'out'))
+    cfg = load_config(str(p))
+    loci = loci_from_config(cfg)
+    assert [(l.name, l.sequence, l.flank_length) for l in loci] == [('Human_STR_1108232', '(AAAT)', 110), ('DM2', '((CAGG){CAGM})(CAGA)(CA)', 90)]
+    assert loci[1].path == str(tmp_path / 'out' / 'DM2')
+    assert cfg.threads == 3 and cfg.rescaler.threshold == 0.4 and cfg.rescaler.max_std == 0.5 and cfg.raw['genotyping'] is True
+    (tmp_path / 'nomotif.yaml').write_text('output: x\nloci:\n  - name: HD\n    motif: AGC,CGC\n')
+    import pytest
+    with pytest.raises(ValueError, match='explicit `sequence`'):
+        load_config(str(tmp_path / 'nomotif.yaml'))
+
+
 def test_config_defaults(tmp_path):
     from warpstr_amd.config import load_config
     p = tmp_path / 'cfg.yaml'

@@ -1,0 +1,221 @@
+"""Host logic of the several-loci step-3 driver (warpstr_amd/loci.py) on CPU: batching, cost sharding, the two all-gathers,
+per-locus outputs, error agreement across ranks -- with a stand-in for the GPU engine (a deterministic function of each
+read's samples; the product has no CPU engine).  world_size 1, 2 and 8 over gloo."""
+import filecmp
+import os
+import socket
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch.multiprocessing as mp
+
+from warpstr_amd import _lib, overview as ov, synth
+from warpstr_amd.caller import ReadCallError, ragged_index, slice_lengths
+from warpstr_amd.wrapper import LocusPath, main_wrapper_loci
+
+OUTPUTS = ['overview.csv', 'predictions/sequences/all.fasta', 'predictions/sequences/sequences_template.fasta',
+           'predictions/sequences/sequences_reverse.fasta', 'summaries/state_similarity.csv']
+LOCI = [('(AGC)', 16, 7), ('(AGC)AACAGCCGCCAC(CGC)', 20, 12), ('(AAAT)', 30, 1), ('(GGCCCC)', 24, 0), ('(CAG)CAACAG(CCG)', 20, 9)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class FakeEngine:
+    """Same four methods as loci.HipEngine; a read's record and sequences are a function of its samples and automaton."""
+
+    def __init__(self, tables, flank_lengths, caller_config, rescaler_config, device):
+        self.n_aut = len(tables)
+        self.batches = 0
+
+    def submit_signals(self, signals, aut):
+        self.batches += 1
+        n = len(signals)
+        rec = np.zeros(n, dtype=_lib.RESULT_DTYPE)
+        s1, s2 = [], []
+        for i, (x, a) in enumerate(zip(signals, aut)):
+            assert 0 <= a < self.n_aut
+            h = int(abs(float(np.sum(x))) * 1000) + int(a)
+            rec['status'][i] = 3 if x[0] > 90.0 else 0
+            rec['len1'][i], rec['len2'][i] = 4 + h % 9, 3 + h % 11
+            rec['cost1'][i], rec['cost2'][i] = float(np.mean(x)), float(np.max(x))
+            if rec['status'][i] == 0:
+                s1.append(('ACGT' * 5)[h % 4:][:rec['len1'][i]])
+                s2.append(('TTGCA' * 5)[h % 5:][:rec['len2'][i]])
+            else:
+                s1.append('')
+                s2.append('')
+        return rec, s1, s2
+
+    submit_raw = None
+
+    def collect(self, ticket):
+        rec, s1, s2 = ticket
+        pos = lambda ss: np.concatenate([[0], np.cumsum([len(x) for x in ss])]).astype(np.int64)
+        u8 = lambda ss: np.frombuffer(''.join(ss).encode(), np.uint8)
+        return rec, u8(s1), pos(s1), u8(s2), pos(s2)
+
+    def info(self):
+        return {'batches': self.batches}
+
+    def close(self):
+        pass
+
+
+def _make_loci(root, poison=None):
+    """Five synthetic locus directories (one without saved reads, one with a single read) + the normalised segments by read
+    name; returns (loci, {read name: signal})."""
+    signals, loci = {}, []
+    for li, (pattern, fl, n) in enumerate(LOCI):
+        locus = synth.make_locus(pattern, fl, 40 + li)
+        sigs, revs, _ = synth.batch(locus, n, (600, 1400), 50 + li, lo=3, hi=9)
+        loc = os.path.join(root, f'locus{li}')
+        ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+        names = [f'L{li}_read{i:03d}' for i in range(n + 2)]
+        lens = [len(s) for s in sigs] + [100, 100]
+        pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': list(revs) + [False, True], 'saved': [1] * n + [0, 0],
+                      'l_start_raw': 1000, 'r_end_raw': [1000 + L - 1 for L in lens]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        signals.update({nm: s for nm, s in zip(names, sigs)})
+        loci.append(LocusPath(loc, pattern, fl))
+    if poison:
+        signals[poison] = signals[poison].copy()
+        signals[poison][0] = 99.0
+    return loci, signals
+
+
+def _loader(signals, fail_on=None):
+    def load(fast5path, lo, hi):
+        name = os.path.basename(fast5path)[:-len('.fast5')]
+        if name == fail_on:
+            raise FileNotFoundError(f'{fast5path} is missing')
+        return signals[name]
+    return load
+
+
+def test_ragged_index_and_slice_lengths():
+    starts, lens = np.array([5, 0, 20, 9]), np.array([3, 0, 2, 1])
+    assert ragged_index(starts, lens).tolist() == [5, 6, 7, 20, 21, 9]
+    assert ragged_index(starts, np.zeros(4, int)).tolist() == []
+    rng = np.random.default_rng(0)
+    L = rng.integers(0, 50, 200)
+    lo, hi = rng.integers(0, 60, 200), rng.integers(-1, 70, 200)
+    want = [len(np.arange(n)[a:b + 1]) for a, b, n in zip(lo, hi, L)]
+    assert slice_lengths(lo, hi, L).tolist() == want
+    lo[::7] -= 30  # negative starts count from the end, as Python slices do
+    want = [len(np.arange(n)[a:b + 1]) for a, b, n in zip(lo, hi, L)]
+    assert slice_lengths(lo, hi, L).tolist() == want
+
+
+def test_one_rank_small_batches_equal_one_batch(tmp_path):
+    """The cut into batches does not show in the outputs (batch_reads = 4 against everything in one batch), and a locus
+    without saved reads / with one read gets its files like any other."""
+    a, sig = _make_loci(str(tmp_path / 'a'))
+    b, _ = _make_loci(str(tmp_path / 'b'))
+    tm = {}
+    ta = main_wrapper_loci(a, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, batch_reads=4, timings=tm)
+    tb = main_wrapper_loci(b, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+    assert tm['batches'] >= 7 and tm['n_loci'] == 5 and tm['n_reads'] == 29
+    for la, lb, (dfa, _), (dfb, _) in zip(a, b, ta, tb):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+        assert dfa.equals(dfb)
+    assert os.path.exists(os.path.join(a[1].path, 'predictions/complexSTR_analysis/complex_repeat_units.csv'))
+    df = pd.read_csv(os.path.join(a[3].path, 'overview.csv'))
+    assert (df['results'] == -1).all()  # nothing saved: every row -1, as upstream writes it
+
+
+def _rank(rank, world, port, root, mode, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    loci, sig = _make_loci(root) if rank == 0 else (None, None)
+    dist.barrier()
+    if rank != 0:  # the directories exist now; every rank derives the same signals
+        import tempfile
+        with tempfile.TemporaryDirectory() as scratch:
+            _, sig = _make_loci(scratch)
+        loci = [LocusPath(os.path.join(root, f'locus{li}'), p, fl) for li, (p, fl, _) in enumerate(LOCI)]
+    if mode == 'poison':
+        sig['L1_read004'] = sig['L1_read004'].copy()
+        sig['L1_read004'][0] = 99.0
+    msg = 'ok'
+    try:
+        main_wrapper_loci(loci, 1, signal_loader=_loader(sig, 'L4_read002' if mode == 'missing' else None), _engine=FakeEngine,
+                          quiet=True, shard=True, batch_reads=5)
+    except Exception as e:  # noqa: BLE001
+        msg = f'{type(e).__name__}: {e}'
+    with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
+        f.write(msg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_ranks_write_what_one_rank_writes(tmp_path, world):
+    """world 2 and world 8 (29 reads: shards of 3-4 reads, the single-read locus on one rank) against one rank."""
+    one, sig = _make_loci(str(tmp_path / 'one'))
+    main_wrapper_loci(one, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+    root = str(tmp_path / 'many')
+    mp.spawn(_rank, args=(world, _free_port(), root, 'plain', str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f'rank{r}.txt').read() == 'ok'
+    for li, l1 in enumerate(one):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(l1.path, rel), os.path.join(root, f'locus{li}', rel), shallow=False), (li, rel)
+
+
+def test_more_ranks_than_reads_leaves_empty_shards(tmp_path):
+    """Four reads on eight ranks: four ranks own nothing and still take part in both collectives."""
+    global LOCI
+    saved = LOCI
+    try:
+        LOCI = [('(AGC)', 16, 3), ('(AAAT)', 30, 1)]
+        one, sig = _make_loci(str(tmp_path / 'one'))
+        main_wrapper_loci(one, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+    finally:
+        LOCI = saved
+    root = str(tmp_path / 'many')
+    mp.spawn(_rank_few, args=(8, _free_port(), root, str(tmp_path)), nprocs=8, join=True)
+    for r in range(8):
+        assert open(tmp_path / f'rank{r}.txt').read() == 'ok'
+    for li, l1 in enumerate(one):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(l1.path, rel), os.path.join(root, f'locus{li}', rel), shallow=False), (li, rel)
+
+
+def _rank_few(rank, world, port, root, out_dir):
+    global LOCI
+    LOCI = [('(AGC)', 16, 3), ('(AAAT)', 30, 1)]
+    _rank(rank, world, port, root, 'plain', out_dir)
+
+
+def test_a_failing_read_raises_on_every_rank_alike(tmp_path):
+    """A read the caller fails on (status != 0) travels through the collectives like any other; every rank then raises
+    upstream's error for it -- nobody is left waiting -- and the loci before it are complete."""
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path / 'many'), 'poison', str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(tmp_path / f'rank{r}.txt').read()
+        assert msg.startswith('ReadCallError') and 'L1_read004' in msg and 'fit_points' in msg
+    assert os.path.exists(tmp_path / 'many' / 'locus0' / 'predictions' / 'sequences' / 'all.fasta')
+    assert not os.path.exists(tmp_path / 'many' / 'locus1' / 'predictions' / 'sequences' / 'all.fasta')
+
+
+def test_an_exception_on_one_rank_reaches_all(tmp_path):
+    """A missing file on ONE rank (before the collectives): the rank raises its own error, the others a RuntimeError naming
+    it, instead of waiting in the all-gather until the backend times out."""
+    world = 4
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path / 'many'), 'missing', str(tmp_path)), nprocs=world, join=True)
+    msgs = [open(tmp_path / f'rank{r}.txt').read() for r in range(world)]
+    assert sum(m.startswith('FileNotFoundError') for m in msgs) == 1
+    assert sum(m.startswith('RuntimeError') and 'failed on rank' in m and 'is missing' in m for m in msgs) == world - 1
+
+
+def test_one_rank_failing_read_raises(tmp_path):
+    loci, sig = _make_loci(str(tmp_path / 'a'), poison='L0_read001')
+    with pytest.raises(ReadCallError, match='L0_read001'):
+        main_wrapper_loci(loci, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)

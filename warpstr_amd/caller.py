@@ -176,6 +176,9 @@ SPIKE_REMOVAL = {'None': 0, 'Brute': 1, 'median3': 2, 'median5': 3}
 class HipCaller:
     """One handle on one GPU holding the automata of one or more loci (include/warpstr_hip.h)."""
 
+    # launch-policy knobs applied to every new handle (names: _lib.TUNING); the GPU tests set it to force fallback kernels
+    default_tuning: dict = {}
+
     def __init__(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
                  device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None,
@@ -214,6 +217,17 @@ class HipCaller:
             _lib.check(self.lib.wsx_caller_set_workspace_limit(self.handle, workspace_limit),
                        'wsx_caller_set_workspace_limit')
         self.max_states = max(t.n_states for t in self.automata)
+        for knob, value in self.default_tuning.items():
+            self.set_tuning(knob, value)
+
+    def set_tuning(self, knob: str, value: int):
+        """wsx_caller_set_tuning: how the work is spread over launches, never what is computed (knobs: _lib.TUNING)."""
+        _lib.check(self.lib.wsx_caller_set_tuning(self.handle, _lib.TUNING[knob], int(value)), 'wsx_caller_set_tuning')
+
+    def workspace_limit(self) -> int:
+        v = C.c_uint64()
+        _lib.check(self.lib.wsx_caller_get_workspace_limit(self.handle, C.byref(v)), 'wsx_caller_get_workspace_limit')
+        return int(v.value)
 
     def close(self):
         if getattr(self, 'handle', None) is not None and self.handle:
@@ -434,6 +448,146 @@ class HipCaller:
         _lib.check(self.lib.wsx_caller_fill_intervals(self.handle, _lib.ptr(b), _lib.ptr(e), _lib.ptr(r), n.value, C.byref(n)),
                    'wsx_caller_fill_intervals')
         return b, e, r
+
+
+def ragged_index(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Element indices of the ragged pieces [starts[k], starts[k] + lens[k]) laid end to end (one int64 per element)."""
+    lens = np.asarray(lens, np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    pos = np.cumsum(lens) - lens
+    return np.repeat(np.asarray(starts, np.int64) - pos, lens) + np.arange(total, dtype=np.int64)
+
+
+def slice_lengths(lo: np.ndarray, hi: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """len(signal[lo : hi + 1]) per read with Python's slice rules (Fast5.get_data_processed, src/schemas/fast5.py:56)."""
+    lo, hi, lens = np.asarray(lo, np.int64), np.asarray(hi, np.int64), np.asarray(lens, np.int64)
+    if len(lo) and (lo.min() < 0 or hi.min() < -1):  # negative indices count from the end: rare, keep Python's own arithmetic
+        return np.array([len(range(*slice(int(a), int(b) + 1).indices(int(L)))) for a, b, L in zip(lo, hi, lens)], np.int64)
+    return np.clip(np.minimum(hi + 1, lens) - np.minimum(lo, lens), 0, None)
+
+
+class BatchQueue:
+    """Back-to-back batches on one handle without draining the GPU in between: submit() enqueues the upload, the signal
+    loader and the caller of a batch and returns at once; collect() waits for that batch only and returns its records and
+    called sequences (packed on the device: what comes down is sum(len) bytes, not a byte per sample).  While batch k runs,
+    the host reads the files of batch k+1 -- upstream's per-locus loop (WarpSTR.py:33-76) has nothing to overlap, here the
+    loci of a run share the GPU.  torch is the device allocator and the stream owner, nothing else.
+
+    The handle must have been created on `stream` (a torch.cuda.Stream): inputs are uploaded there, and the library reads a
+    call's inputs in the order of the handle's stream (wsx_caller_set_pipelined)."""
+
+    def __init__(self, hip: 'HipCaller', stream, spike_removal: str = 'Brute'):
+        import torch
+        if spike_removal not in SPIKE_REMOVAL:
+            raise ValueError(f'spike_removal must be one of {sorted(SPIKE_REMOVAL)}')
+        self.torch, self.hip, self.stream, self.spike = torch, hip, stream, spike_removal
+        self.dev = torch.device('cuda', hip.device)
+        self.down = torch.cuda.Stream(device=self.dev)
+        self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
+        self._turn = 0
+        hip.set_pipelined(True)
+
+    def _stage(self, dtype, count: int):
+        """A pinned host buffer of `count` elements whose previous upload has left it (three take turns)."""
+        torch = self.torch
+        ring = self._staging.setdefault(dtype, [[None, None] for _ in range(3)])
+        slot = ring[self._turn % len(ring)]
+        self._turn += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < count:
+            slot[0] = torch.empty(max(count + count // 4, 1 << 16), dtype=dtype, pin_memory=True)
+        return slot
+
+    def _launch(self, n, offsets, aut, signal, keep):
+        torch = self.torch
+        total = int(offsets[-1])
+        with torch.cuda.stream(self.stream):
+            records = torch.zeros((max(n, 1), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=self.dev)
+            seq1 = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
+            seq2 = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
+        self.hip.call_device(signal.data_ptr(), offsets, aut, records.data_ptr(), seq1_ptr=seq1.data_ptr(), seq2_ptr=seq2.data_ptr())
+        self.hip.join(self.down.cuda_stream)
+        rec_host = torch.empty((max(n, 1), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, pin_memory=True)
+        with torch.cuda.stream(self.down):
+            rec_host.copy_(records, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return dict(n=n, offsets=offsets, records=records, seq1=seq1, seq2=seq2, rec_host=rec_host, done=done, keep=(signal, keep))
+
+    def submit_raw(self, raws: Sequence[np.ndarray], lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
+        """raws[r]: the whole raw read (int16 DAC values); [lo[r], hi[r]]: its STR segment (overview columns l_start_raw,
+        r_end_raw); aut[r]: automaton of the handle.  Spike removal, whole-read normalisation and the slice run on the GPU."""
+        torch = self.torch
+        n = len(raws)
+        lens = np.fromiter((len(r) for r in raws), dtype=np.int64, count=n)
+        roff = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=roff[1:])
+        total_raw = int(roff[-1])
+        slot = self._stage(torch.int16, total_raw)
+        if n:
+            np.concatenate([np.asarray(r, np.int16) for r in raws], out=slot[0].numpy()[:total_raw])
+        lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
+        with torch.cuda.stream(self.stream):
+            raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
+            raw_dev[:total_raw].copy_(slot[0][:total_raw], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+            signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
+        if n:
+            self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
+        return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+
+    def submit_signals(self, signals: Sequence[np.ndarray], aut: np.ndarray):
+        """Already normalised float64 segments (a `signal_loader`, or ReadSignal workloads)."""
+        torch = self.torch
+        n = len(signals)
+        lens = np.fromiter((len(x) for x in signals), dtype=np.int64, count=n)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        total = int(offsets[-1])
+        slot = self._stage(torch.float64, total)
+        if n:
+            np.concatenate([np.asarray(x, np.float64) for x in signals], out=slot[0].numpy()[:total])
+        with torch.cuda.stream(self.stream):
+            signal = torch.empty(max(total, 1), dtype=torch.float64, device=self.dev)
+            signal[:total].copy_(slot[0][:total], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, None)
+
+    def collect(self, ticket):
+        """-> (records, seq1, pos1, seq2, pos2): read r's seq is seq1[pos1[r] : pos1[r + 1]] (empty for a failed read)."""
+        torch = self.torch
+        n = ticket['n']
+        ticket['done'].synchronize()
+        rec = ticket['rec_host'].numpy().view(_lib.RESULT_DTYPE).reshape(-1)[:n].copy()
+        ok = rec['status'] == 0
+        out = [rec]
+        starts = torch.from_numpy(ticket['offsets'][:-1].copy())
+        packed = []
+        with torch.cuda.stream(self.down):
+            starts_d = starts.to(self.dev, non_blocking=True)
+            for field, key in (('len1', 'seq1'), ('len2', 'seq2')):
+                ln = np.where(ok, rec[field], 0).astype(np.int64)
+                pos = np.zeros(n + 1, np.int64)
+                np.cumsum(ln, out=pos[1:])
+                total = int(pos[-1])
+                host = torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=True)
+                if total:
+                    ln_d = torch.from_numpy(ln).to(self.dev, non_blocking=True)
+                    pos_d = torch.from_numpy(pos[:-1].copy()).to(self.dev, non_blocking=True)
+                    idx = torch.repeat_interleave(starts_d - pos_d, ln_d, output_size=total) + torch.arange(total, device=self.dev)
+                    host[:total].copy_(ticket[key][idx], non_blocking=True)
+                packed.append((host, pos, total))
+            self.down.synchronize()
+        for host, pos, total in packed:
+            out += [host.numpy()[:total].copy(), pos]
+        return tuple(out)
 
 
 def sequence_from_trace(table: AutomatonTable, flank_length: int, trace: np.ndarray, reverse: bool) -> str:

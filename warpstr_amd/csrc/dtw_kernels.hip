@@ -1115,17 +1115,14 @@ __global__ __launch_bounds__(256) void expand_trace_kernel(PassArgs a)
 }
 
 template <int M, int K, int F, int FL, bool PK = false, int LM = 0>
-hipError_t launch_fill(const PassArgs &a, hipStream_t s)
+hipError_t launch_fill(const PassArgs &a, const WsxTuning &tun, hipStream_t s)
 {
     const int blocks = (a.n_launch + WSX_FILL_WPB - 1) / WSX_FILL_WPB;
     static_assert(WSX_FILL_WPB * (2 * (K * 64 + 32)) * sizeof(double) <= 64 * 1024, "export buffers of a workgroup: at most 64 KB of LDS");
     size_t shmem = WSX_FILL_WPB * (2 * (K * 64 + 32)) * sizeof(double);
     // Occupancy cap (tuning knob): asking for more LDS per block leaves wave slots free for the latency-bound
     // kernels of other chunks that run beside the fill on other streams.
-    static const int cap_blocks = [] {
-        const char *e = getenv("WSX_FILL_BLOCKS_PER_CU");
-        return e ? atoi(e) : 0;
-    }();
+    const int cap_blocks = tun.fill_blocks_per_cu;
     if (cap_blocks > 0) shmem = std::max(shmem, (size_t)(160 * 1024 / cap_blocks) & ~(size_t)255);
     if (shmem > 64 * 1024) shmem = 64 * 1024;
     hipLaunchKernelGGL((dtw_fill_fast<M, K, F, FL, PK, LM>), dim3(blocks), dim3(64 * WSX_FILL_WPB), shmem, s, a);
@@ -1133,66 +1130,66 @@ hipError_t launch_fill(const PassArgs &a, hipStream_t s)
 }
 
 template <int M, int K>
-hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, hipStream_t s)
+hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, const WsxTuning &tun, hipStream_t s)
 {
     if (lm != 0) { // lane-major placement: slots above 0 take their one predecessor from the lane's own registers
         if constexpr (K >= 2 && M == 4) {
             if (FL != 1 || pk || lm > 4) return hipErrorInvalidValue;
             if constexpr (K >= 4) {
                 switch (F * 10 + lm) {
-                case 23: return launch_fill<M, K, 2, 1, false, 3>(a, s);
-                case 33: return launch_fill<M, K, 3, 1, false, 3>(a, s);
-                case 43: return launch_fill<M, K, 4, 1, false, 3>(a, s);
+                case 23: return launch_fill<M, K, 2, 1, false, 3>(a, tun, s);
+                case 33: return launch_fill<M, K, 3, 1, false, 3>(a, tun, s);
+                case 43: return launch_fill<M, K, 4, 1, false, 3>(a, tun, s);
                 }
             }
             if constexpr (K >= 5) { // stacked placement: five slots only (four: measured slower than slot-major, wsx_api.hip)
                 switch (F * 10 + lm) {
-                case 24: return launch_fill<M, K, 2, 1, false, 4>(a, s);
-                case 34: return launch_fill<M, K, 3, 1, false, 4>(a, s);
-                case 44: return launch_fill<M, K, 4, 1, false, 4>(a, s);
+                case 24: return launch_fill<M, K, 2, 1, false, 4>(a, tun, s);
+                case 34: return launch_fill<M, K, 3, 1, false, 4>(a, tun, s);
+                case 44: return launch_fill<M, K, 4, 1, false, 4>(a, tun, s);
                 }
             }
             if (lm == 4) return hipErrorInvalidValue;
             switch (F * 10 + (lm == 3 ? 2 : lm)) {
-            case 21: return launch_fill<M, K, 2, 1, false, 1>(a, s);
-            case 22: return launch_fill<M, K, 2, 1, false, 2>(a, s);
-            case 31: return launch_fill<M, K, 3, 1, false, 1>(a, s);
-            case 32: return launch_fill<M, K, 3, 1, false, 2>(a, s);
-            case 41: return launch_fill<M, K, 4, 1, false, 1>(a, s);
-            case 42: return launch_fill<M, K, 4, 1, false, 2>(a, s);
+            case 21: return launch_fill<M, K, 2, 1, false, 1>(a, tun, s);
+            case 22: return launch_fill<M, K, 2, 1, false, 2>(a, tun, s);
+            case 31: return launch_fill<M, K, 3, 1, false, 1>(a, tun, s);
+            case 32: return launch_fill<M, K, 3, 1, false, 2>(a, tun, s);
+            case 41: return launch_fill<M, K, 4, 1, false, 1>(a, tun, s);
+            case 42: return launch_fill<M, K, 4, 1, false, 2>(a, tun, s);
             }
         }
         return hipErrorInvalidValue;
     }
     if constexpr (K >= 2 && M == 4) { // split variants (FL < F): several slots, default min_values_per_state
-        if (F == 2 && FL == 1) return launch_fill<M, K, 2, 1>(a, s);
-        if (F == 3 && FL == 1) return launch_fill<M, K, 3, 1>(a, s);
-        if (F == 3 && FL == 2) return launch_fill<M, K, 3, 2>(a, s);
-        if (F == 4 && FL == 1) return launch_fill<M, K, 4, 1>(a, s);
-        if (F == 4 && FL == 2) return launch_fill<M, K, 4, 2>(a, s);
+        if (F == 2 && FL == 1) return launch_fill<M, K, 2, 1>(a, tun, s);
+        if (F == 3 && FL == 1) return launch_fill<M, K, 3, 1>(a, tun, s);
+        if (F == 3 && FL == 2) return launch_fill<M, K, 3, 2>(a, tun, s);
+        if (F == 4 && FL == 1) return launch_fill<M, K, 4, 1>(a, tun, s);
+        if (F == 4 && FL == 2) return launch_fill<M, K, 4, 2>(a, tun, s);
     }
     if (FL != F) return hipErrorInvalidValue;
     if constexpr (K == 1) {
-        if (pk && F == 2) return launch_fill<M, 1, 2, 2, true>(a, s);
+        if (pk && F == 2) return launch_fill<M, 1, 2, 2, true>(a, tun, s);
     }
     if (pk) return hipErrorInvalidValue;
     switch (F) {
-    case 2: return launch_fill<M, K, 2, 2>(a, s);
-    case 3: return launch_fill<M, K, 3, 3>(a, s);
-    case 4: return launch_fill<M, K, 4, 4>(a, s);
+    case 2: return launch_fill<M, K, 2, 2>(a, tun, s);
+    case 3: return launch_fill<M, K, 3, 3>(a, tun, s);
+    case 4: return launch_fill<M, K, 4, 4>(a, tun, s);
     }
     return hipErrorInvalidValue;
 }
 
 template <int M>
-hipError_t launch_fill_k(const PassArgs &a, int K, int F, int FL, bool pk, int lm, hipStream_t s)
+hipError_t launch_fill_k(const PassArgs &a, int K, int F, int FL, bool pk, int lm, const WsxTuning &tun, hipStream_t s)
 {
     switch (K) {
-    case 1: return launch_fill_f<M, 1>(a, F, FL, pk, lm, s);
-    case 2: return launch_fill_f<M, 2>(a, F, FL, pk, lm, s);
-    case 3: return launch_fill_f<M, 3>(a, F, FL, pk, lm, s);
-    case 4: return launch_fill_f<M, 4>(a, F, FL, pk, lm, s);
-    case 5: return launch_fill_f<M, 5>(a, F, FL, pk, lm, s);
+    case 1: return launch_fill_f<M, 1>(a, F, FL, pk, lm, tun, s);
+    case 2: return launch_fill_f<M, 2>(a, F, FL, pk, lm, tun, s);
+    case 3: return launch_fill_f<M, 3>(a, F, FL, pk, lm, tun, s);
+    case 4: return launch_fill_f<M, 4>(a, F, FL, pk, lm, tun, s);
+    case 5: return launch_fill_f<M, 5>(a, F, FL, pk, lm, tun, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1214,7 +1211,7 @@ bool wsx_split_supported(int m, int K) { return m == 4 && K >= 2; }
 bool wsx_lane_major_supported(int m, int K)
 {
     static const int lm_min_k = [] {
-        const char *e = getenv("WSX_FILL_LM");
+        const char *e = wsx_exp_env("WSX_FILL_LM");
         return (e && atoi(e) == 3) ? 2 : 3;
     }();
     return m == 4 && K >= lm_min_k && K <= WSX_MAX_K;
@@ -1228,12 +1225,12 @@ const char *wsx_pass_kernel_name(int m, int K, int F, int FL, bool pk, int lm, b
     return buf;
 }
 
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, hipStream_t s)
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, const WsxTuning &tun, hipStream_t s)
 {
 #ifdef WSX_ONLY_WG // listing builds (hipcc -S): just the flank-110 variants of the several-slot fills
-    return lm ? launch_fill<4, 4, 2, 1, false, 1>(a, s) : launch_fill<4, 4, 2, 1>(a, s);
+    return lm ? launch_fill<4, 4, 2, 1, false, 1>(a, tun, s) : launch_fill<4, 4, 2, 1>(a, tun, s);
 #elif defined(WSX_ONLY_DEFAULT) // experiment builds: just the headline variant
-    if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return pk ? launch_fill<4, 1, 2, 2, true>(a, s) : launch_fill<4, 1, 2, 2>(a, s);
+    if (!generic && m == 4 && K == 1 && fast_f(F) == 2) return pk ? launch_fill<4, 1, 2, 2, true>(a, tun, s) : launch_fill<4, 1, 2, 2>(a, tun, s);
     return hipErrorInvalidValue;
 #else
     if (a.n_launch <= 0) return hipSuccess;
@@ -1244,22 +1241,19 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
     }
     const int f = fast_f(F);
     switch (m) {
-    case 3: return launch_fill_k<3>(a, K, f, FL, pk, lm, s);
-    case 4: return launch_fill_k<4>(a, K, f, FL, pk, lm, s);
-    case 5: return launch_fill_k<5>(a, K, f, FL, pk, lm, s);
+    case 3: return launch_fill_k<3>(a, K, f, FL, pk, lm, tun, s);
+    case 4: return launch_fill_k<4>(a, K, f, FL, pk, lm, tun, s);
+    case 5: return launch_fill_k<5>(a, K, f, FL, pk, lm, tun, s);
     }
     return hipErrorInvalidValue;
 #endif
 }
 
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s)
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, const WsxTuning &tun, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;
     const int wblocks = (a.n_launch + 3) / 4;
-    static const int stream_min = [] { // smallest launch that takes the streaming traceback (tests and experiments override)
-        const char *e = getenv("WSX_STREAM_TRACEBACK_MIN");
-        return e ? atoi(e) : 8192;
-    }();
+    const int stream_min = tun.stream_traceback_min; // smallest launch that takes the streaming traceback
     if (generic) {
         hipLaunchKernelGGL(traceback_generic_kernel, dim3((a.n_launch + 63) / 64), dim3(64), 0, s, a, K);
     } else if (K == 1 && n_aut <= 64 && a.n_launch >= stream_min) {

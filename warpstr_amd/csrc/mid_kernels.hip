@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a)
 
 } // namespace
 
-hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
+hipError_t wsx_launch_mid(const MidArgs &a, int max_T, const WsxTuning &tun, hipStream_t s)
 {
     if (a.n_reads <= 0) return hipSuccess;
     const int m = a.prm.m;
@@ -1541,13 +1541,13 @@ hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s)
     else hipLaunchKernelGGL(run_stats_kernel, dim3(a.n_reads, std::min((max_runs + 63) / 64, RS_GROUPS)), dim3(64), 0, s, a);
     // small launches: a wavefront per read (latency); big ones: a thread per read (throughput; the wavefront form at 25 000
     // reads per launch: 13.9 instead of 13.4 ms per 100 k-read step, scripts/r03_cycle33.sh)
-    static const int borders_wave_below = getenv("WSX_BORDERS_WAVE_BELOW") ? atoi(getenv("WSX_BORDERS_WAVE_BELOW")) : 8192;
+    const int borders_wave_below = tun.borders_wave_below;
     if (a.n_reads < borders_wave_below) hipLaunchKernelGGL(borders_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(borders_thread_kernel, dim3((a.n_reads + 63) / 64), dim3(64), 0, s, a);
     if (a.seq_out) hipLaunchKernelGGL(sequence_kernel, dim3((a.n_reads + 3) / 4), dim3(256), 0, s, a);
     if (a.pass == 1) {
         const int max_chunks = max_runs / a.prm.states_in_segment + 2;
-        static const bool two_kernels = getenv("WSX_SEGMENT_TWO_KERNELS") != nullptr; // test knob for the fallback
+        const bool two_kernels = tun.segment_two_kernels != 0; // (tests force the fallback this way)
         const size_t seg_lds = (size_t)(2 * max_chunks + 1) * sizeof(int);
         if (seg_lds <= 40 * 1024 && !two_kernels) {
             hipLaunchKernelGGL(segment_kernel, dim3(a.n_reads), dim3(256), seg_lds, s, a, max_chunks);

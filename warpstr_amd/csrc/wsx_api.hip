@@ -244,8 +244,10 @@ struct wsx_caller {
     std::vector<DevAutomaton> host_aut; // device pointers inside
     std::vector<Variant> variant;
     std::vector<int> n_states;
+    std::vector<Variant> uvar; // the distinct kernel variants among `variant` (each has a back-pointer region of its own)
+    WsxTuning tun;             // launch-policy knobs (wsx_caller_set_tuning)
     DeviceBuf aut_blob, aut_table;
-    uint64_t ws_limit = 16ull << 30;
+    uint64_t ws_limit = 16ull << 30; // set from the device's free memory at creation (wsx_caller_set_workspace_limit overrides)
     // workspace
     // Up to WSX_MAX_STREAMS workspace sets: consecutive chunks rotate over the handle's stream and internal ones,
     // so that the latency/bandwidth-bound stages of some chunks (traceback, run statistics, fit, ...) run under the
@@ -268,7 +270,8 @@ struct wsx_caller {
     size_t pinned_cap[kMetaSlots] = {};
     hipEvent_t ev_meta[kMetaSlots] = {}; // recorded when the call that used the slot has finished
     int in_flight = 2;                    // pipelined calls the host may run ahead of the device (<= kMetaSlots)
-    int in_flight_small = kMetaSlots;     // ... for small batches (one chunk each; WSX_INFLIGHT_SMALL)
+    int in_flight_small = kMetaSlots;     // ... for small batches (one chunk each)
+    int64_t small_pipe_samples = kSmallPipeSamples; // where the one-chunk policy for small pipelined calls ends (WSX_TUNE_SMALL_PIPE_SAMPLES)
     bool pipelined = false;                     // wsx_caller_set_pipelined
     uint64_t call_seq = 0;
     int rot = 0; // pipelined calls with fewer chunks than streams: the first work set / stream of the next call
@@ -343,14 +346,7 @@ int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b, int32_t reads)
 size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 {
     size_t bp = 0;
-    std::vector<Variant> seen;
-    for (auto &v : c->variant) {
-        bool dup = false;
-        for (auto &u : seen) dup = dup || u.same(v);
-        if (dup) continue;
-        seen.push_back(v);
-        bp += v.bp_words(4096, 0) * 4 / 4096 + 1;
-    }
+    for (auto &v : c->uvar) bp += v.bp_words(4096, 0) * 4 / 4096 + 1;
     size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 16 /*scratch*/ +
                1 /*mask bits, rounded up*/ + bp;
     if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 3) : 0);
@@ -360,7 +356,7 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
 {
     size_t b = 168 + sizeof(wsx_result) + 64;
-    for (auto &v : c->variant) b += v.bp_words(0, 1) * 4;
+    for (auto &v : c->uvar) b += v.bp_words(0, 1) * 4; // (distinct variants: a handle may hold thousands of automata)
     if (c->prm.reps_as_one) b += 2 * (size_t)c->max_states * sizeof(int32_t);
     if (host_mem) b += 16 + last_row_bytes;
     return b;
@@ -502,7 +498,7 @@ try {
         D.state_at = nullptr;
         const int Fk = v.F <= 2 ? 2 : v.F;
         v.FL = Fk;
-        if (!v.generic && wsx_split_supported(c->prm.min_values_per_state, v.K) && !getenv("WSX_NO_SPLIT")) {
+        if (!v.generic && wsx_split_supported(c->prm.min_values_per_state, v.K) && !wsx_exp_env("WSX_NO_SPLIT")) {
             int n_ge2 = 0, n_gt2 = 0;
             for (int j = 0; j < S; j++) {
                 const int nf = A.pred_ptr[j + 1] - A.pred_ptr[j];
@@ -517,11 +513,11 @@ try {
         std::iota(pos.begin(), pos.end(), (uint16_t)0);
         std::iota(wslot.begin(), wslot.end(), (uint16_t)0);
         if (!v.generic) {
-            const bool want_pk = v.K == 1 && Fk == 2 && !getenv("WSX_NO_PACK");
+            const bool want_pk = v.K == 1 && Fk == 2 && !wsx_exp_env("WSX_NO_PACK");
             // several slots: the lane-major layout (chains along the slots of a lane, LDS only for slot 0) where it fits
             WsxLanePlacement lp;
             static const int lm_mode = [] {
-                const char *e = getenv("WSX_FILL_LM");
+                const char *e = wsx_exp_env("WSX_FILL_LM");
                 return e ? atoi(e) : 1; // 0: off; 1: on; 2: on, every slot exports
             }();
             if (lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K))
@@ -532,7 +528,7 @@ try {
             // slots it LOSES to the slot-major kernel (HD, both strands: 12.1 vs 11.8 ms -- four exports and the extra read
             // load the LDS pipe as much as the slot-major exchange does), so four-slot automata keep that one.
             if (lp.lm == 0 && lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K) && v.K >= 5 &&
-                !getenv("WSX_NO_STACKED"))
+                !wsx_exp_env("WSX_NO_STACKED"))
                 lp = wsx_place_lane_stacked(S, A.pred_ptr, A.pred_idx, v.K);
             if (lp.lm != 0) {
                 v.FL = 1;
@@ -540,7 +536,7 @@ try {
                 D.stack_mask = lp.stack_mask;
             }
             const WsxPlacement pl = lp.lm != 0 ? lp.pl
-                                    : getenv("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
+                                    : wsx_exp_env("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
                                         ? WsxPlacement{}
                                         : wsx_place_states(S, A.pred_ptr, A.pred_idx, v.K, Fk, v.FL, want_pk);
             if (!pl.pos.empty()) {
@@ -615,12 +611,25 @@ try {
     // variants, 12 % of the reads, took 1.8 of a pass's 4.3 ms).  Variants that differ only in the number of candidates of slot
     // 0 share the larger kernel where the difference is one candidate (three vector instructions per row for those reads).
     // (Their launches on side streams instead: slower, 17.1-22 vs 16.4 ms per step -- more streams than the runtime's queues.)
-    if (!getenv("WSX_NO_VARIANT_MERGE"))
+    if (!wsx_exp_env("WSX_NO_VARIANT_MERGE"))
         for (auto &v : c->variant) {
             if (v.generic || v.pk || v.K < 2) continue;
             for (const auto &u : c->variant)
                 if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == v.F + 1 && v.F >= 3) v.F = u.F;
         }
+    for (auto &v : c->variant) {
+        bool seen = false;
+        for (auto &u : c->uvar) seen = seen || u.same(v);
+        if (!seen) c->uvar.push_back(v);
+    }
+    // Workspace limit: what the device can give.  A fixed 16 GiB made a 100 000-read call of 2 kSample reads take eight
+    // chunks instead of four (more, smaller chunks lose: the serial per-read stages last as long for 6 000 reads as for
+    // 100 000); the handle only ever allocates what a call needs, the limit is an upper bound.
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+            c->ws_limit = std::max<uint64_t>(2ull << 30, (uint64_t)((double)free_b * 0.6));
+    }
     if (c->prm.threshold > 1.0) HIPCHK(hipHostMalloc((void **)&c->smooth_host, 2 * WSX_MAX_STREAMS * sizeof(int32_t), hipHostMallocDefault));
     HIPCHK(hipMemcpy(c->aut_blob.p, hblob.data(), blob, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
@@ -631,9 +640,15 @@ try {
     HIPCHK(hipEventCreateWithFlags(&c->ev_joins[0], hipEventDisableTiming));
     if (const char *e = getenv("WSX_STREAMS")) c->n_streams = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
     if (const char *e = getenv("WSX_CHUNKS")) c->chunks_override = std::max(1, atoi(e));
-    if (const char *e = getenv("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
-    if (const char *e = getenv("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
-    if (const char *e = getenv("WSX_INFLIGHT_SMALL")) c->in_flight_small = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
+    // (experiment builds only, -DWSX_EXPERIMENT: the A/B switches of scripts/)
+    if (const char *e = wsx_exp_env("WSX_STREAMS_PER_CALL")) c->streams_per_call = std::min(WSX_MAX_STREAMS, std::max(1, atoi(e)));
+    if (const char *e = wsx_exp_env("WSX_INFLIGHT")) c->in_flight = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
+    if (const char *e = wsx_exp_env("WSX_INFLIGHT_SMALL")) c->in_flight_small = std::min((int)wsx_caller::kMetaSlots, std::max(2, atoi(e)));
+    if (const char *e = wsx_exp_env("WSX_SMALL_PIPE_SAMPLES")) c->small_pipe_samples = (int64_t)atoll(e);
+    if (const char *e = wsx_exp_env("WSX_STREAM_TRACEBACK_MIN")) c->tun.stream_traceback_min = atoi(e);
+    if (const char *e = wsx_exp_env("WSX_BORDERS_WAVE_BELOW")) c->tun.borders_wave_below = atoi(e);
+    if (wsx_exp_env("WSX_SEGMENT_TWO_KERNELS")) c->tun.segment_two_kernels = 1;
+    if (const char *e = wsx_exp_env("WSX_FILL_BLOCKS_PER_CU")) c->tun.fill_blocks_per_cu = atoi(e);
     // The streams one call spreads over exist from the start; the others (small pipelined calls taking turns) are created
     // when first used: the runtime maps streams onto a few hardware queues in order of creation, streams that merely exist
     // already cost big calls 2 % (profiles/r02_ab_streams.log), and creating these ones late, after work has been queued,
@@ -697,6 +712,30 @@ int wsx_caller_set_workspace_limit(wsx_caller *c, uint64_t bytes)
 {
     if (!c || bytes < (64ull << 20)) return WSX_ERR_INVALID;
     c->ws_limit = bytes;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_get_workspace_limit(wsx_caller *c, uint64_t *bytes)
+{
+    if (!c || !bytes) return WSX_ERR_INVALID;
+    *bytes = c->ws_limit;
+    return WSX_SUCCESS;
+}
+
+int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value)
+{
+    if (!c) return WSX_ERR_INVALID;
+    switch (knob) {
+    case WSX_TUNE_STREAM_TRACEBACK_MIN: c->tun.stream_traceback_min = (int32_t)std::max<int64_t>(1, std::min<int64_t>(value, INT32_MAX)); break;
+    case WSX_TUNE_BORDERS_WAVE_BELOW: c->tun.borders_wave_below = (int32_t)std::max<int64_t>(0, std::min<int64_t>(value, INT32_MAX)); break;
+    case WSX_TUNE_SEGMENT_TWO_KERNELS: c->tun.segment_two_kernels = value != 0; break;
+    case WSX_TUNE_FILL_BLOCKS_PER_CU: c->tun.fill_blocks_per_cu = (int32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64)); break;
+    case WSX_TUNE_CHUNKS: c->chunks_override = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096)); break;
+    case WSX_TUNE_SMALL_PIPE_SAMPLES: c->small_pipe_samples = std::max<int64_t>(0, value); break;
+    case WSX_TUNE_CALLS_IN_FLIGHT: c->in_flight = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
+    case WSX_TUNE_SMALL_CALLS_IN_FLIGHT: c->in_flight_small = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
+    default: g_err = "wsx_caller_set_tuning: unknown knob"; return WSX_ERR_INVALID;
+    }
     return WSX_SUCCESS;
 }
 
@@ -959,10 +998,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // 12 500 reads: 1.96-2.02 ms per call against 2.10-2.14 with two calls of two chunks each, profiles/r02_small_call_sweep.log)
     // (up to 50 M samples per call; at 60 M -- 30 000 reads of 2 000 samples, 20 000 of 3 000 -- four whole calls side by
     // side ran at half the speed of two calls of two chunks each: the bound below keeps to what was measured)
-    static const int64_t small_pipe_samples = [] { // (experiments: another bound for the one-chunk policy, in samples)
-        const char *e = getenv("WSX_SMALL_PIPE_SAMPLES");
-        return e ? (int64_t)atoll(e) : wsx_caller::kSmallPipeSamples;
-    }();
+    const int64_t small_pipe_samples = c->small_pipe_samples;
     const bool small_pipe = pipe && n > 0 && (io.offsets[n] - io.offsets[0]) <= small_pipe_samples && n < 32768;
     const int depth = small_pipe ? c->in_flight_small : c->in_flight;
     const uint64_t seq = pipe ? c->call_seq++ : 0;
@@ -1061,14 +1097,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     }
     // back-pointer scratch: one region per distinct DP kernel variant, so that
     // launch groups of one chunk never share words (their fills and tracebacks may then be issued in any order)
-    std::vector<Variant> uvar;
+    const std::vector<Variant> &uvar = c->uvar;
     std::vector<size_t> uoff;
     size_t bp_words = 0;
-    for (auto &v : c->variant) {
-        bool seen = false;
-        for (auto &u : uvar) seen = seen || u.same(v);
-        if (seen) continue;
-        uvar.push_back(v);
+    for (auto &v : uvar) {
         uoff.push_back(bp_words);
         bp_words += align_up(v.bp_words(S1, R1), 64);
     }
@@ -1315,7 +1347,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, s));
+            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, c->tun, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;
@@ -1330,7 +1362,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.trace = trace;
             pa.status = status;
             pa.lane_major = x.gvar[g].lm != 0;
-            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, s));
+            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, c->tun, s));
         }
         return WSX_SUCCESS;
     };
@@ -1347,7 +1379,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.maskbits = x.d_maskbits;
         ma.badmask_bytes = x.d_badmask;
         ma.seq_out = x.d_seq1;
-        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, s));
+        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, c->tun, s));
         if (x.fa.smooth_list) HIPCHK(hipMemsetAsync(x.d_smooth_cnt, 0, 2 * sizeof(int32_t), s));
         HIPCHK(wsx_launch_fit(x.fa, s));
         if (x.fa.smooth_list) {
@@ -1379,7 +1411,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         ma.maskbits = nullptr;
         ma.badmask_bytes = nullptr;
         ma.seq_out = x.d_seq2;
-        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, s));
+        HIPCHK(wsx_launch_mid(ma, x.ch.max_T, c->tun, s));
         if (host) {
             const int64_t f = x.ch.first, cnt = x.ch.count, boff = x.ch.base_off;
             const size_t ns = (size_t)x.ch.samples;

@@ -16,6 +16,23 @@
 #define WSX_MAX_F 4
 #define WSX_MAX_STREAMS 8 // chunks of a batch rotate over this many HIP streams      // fan-in handled by the register-resident DP kernel
 
+// Launch-policy knobs of a handle (wsx_caller_set_tuning, include/warpstr_hip.h); the defaults are the measured ones.
+struct WsxTuning {
+    int32_t stream_traceback_min = 8192; // smallest single-slot launch that takes the thread-per-read traceback
+    int32_t borders_wave_below = 8192;   // launches of fewer reads take the wave-per-read form of the borders stage
+    int32_t segment_two_kernels = 0;     // 1: always the two-kernel segmentation (t-statistics through HBM)
+    int32_t fill_blocks_per_cu = 0;      // > 0: cap the fill's workgroups per CU through its LDS request
+};
+
+// A/B switches of the experiments under scripts/ are read from the environment only by builds made with -DWSX_EXPERIMENT
+// (scripts/build_exp.sh); the product library ignores them.
+#ifdef WSX_EXPERIMENT
+#include <cstdlib>
+inline const char *wsx_exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *wsx_exp_env(const char *) { return nullptr; }
+#endif
+
 #ifndef WSX_STACK_SLOT_DEFINED
 #define WSX_STACK_SLOT_DEFINED
 constexpr int WSX_DEV_STACK_SLOT = 2; // = WSX_STACK_SLOT of wsx_place.h (static_assert in wsx_api.hip)
@@ -162,9 +179,9 @@ struct EvalArgs {
 // pk: packed mask rows (single-slot automata whose states with two predecessors sit in lanes 0..7): per 16 rows
 // 16 x 8 bytes of first-candidate masks + 2 x 8 bytes holding the second candidate's byte of every row
 // lm: lane-major placement (0 = no; 1 = slots 0 and K-1 export to LDS; 3 = slots 0, 1 and K-1; 2 = every slot), dtw_kernels.hip: dp_row
-hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, hipStream_t s);
-hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, hipStream_t s);
-hipError_t wsx_launch_mid(const MidArgs &a, int max_T, hipStream_t s);
+hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, const WsxTuning &tun, hipStream_t s);
+hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, const WsxTuning &tun, hipStream_t s);
+hipError_t wsx_launch_mid(const MidArgs &a, int max_T, const WsxTuning &tun, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);
 size_t wsx_smooth_workspace_bytes(int count, int max_m);
 hipError_t wsx_launch_fit_smooth(const FitArgs &a, int count, int max_m, double *ws, hipStream_t s);

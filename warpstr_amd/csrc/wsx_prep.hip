@@ -728,7 +728,8 @@ try {
     // a histogram of 65 536 counters (256 KiB) per read, of which only the read's occupied value range is ever touched: half
     // the handle's workspace limit goes to them (default 16 GiB -> 32 768 reads per chunk; 288 GB of HBM take 100k short
     // reads in one go, where 4 096-read chunks spent most of a call on launches and synchronisation)
-    const int64_t chunk_reads = std::max<int64_t>(4096, (int64_t)(wsx_internal_workspace_limit(c) / 2 / (65536 * 4)));
+    // (at most 32 GiB of them: 131 072 reads per chunk)
+    const int64_t chunk_reads = std::max<int64_t>(4096, (int64_t)(std::min<uint64_t>(wsx_internal_workspace_limit(c) / 2, 32ull << 30) / (65536 * 4)));
     // Metadata (chunk-relative offsets, slice bounds, initial value ranges) goes through pinned memory owned by the handle, so
     // that the uploads are asynchronous and nothing of the caller's is referenced after the return; device-buffer calls then
     // return as soon as the work is enqueued on the handle's stream.
@@ -813,10 +814,10 @@ try {
             for (int64_t r = 0; r < cnt; r++) min_len = std::min(min_len, h_roff[r + 1] - h_roff[r]);
             const int cap = (int)std::min<int64_t>(((std::min<int64_t>(max_len, 8192) + 63) / 64) * 64, 8192);
             const size_t lds = (size_t)cap * 2 + (size_t)cap / 8 + 8 + PREP_SHORT_BINS * 4;
-            if (min_len <= cap && spike_removal <= 1 && !getenv("WSX_PREP_GENERAL")) {
+            if (min_len <= cap && spike_removal <= 1 && !wsx_exp_env("WSX_PREP_GENERAL")) {
                 hipLaunchKernelGGL(short_read_kernel, dim3((unsigned)cnt), dim3(64), lds, st, a, cap);
                 // every read could go that way: what is left for the general kernels is the odd read with a wide value range
-                if (max_len <= cap && !getenv("WSX_PREP_NO_GROUPS")) a.group = 256;
+                if (max_len <= cap && !wsx_exp_env("WSX_PREP_NO_GROUPS")) a.group = 256;
             } else {
                 PCHK(hipMemsetAsync(d_done, 0, (size_t)cnt, st)); // no read of this chunk is short
             }

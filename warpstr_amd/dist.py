@@ -58,7 +58,11 @@ def process_group():
     if not dist.is_initialized():
         if world_env <= 1:  # one-rank group outside torch.distributed.run
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29533')
+            if 'MASTER_PORT' not in os.environ:  # any free port: concurrent one-rank runs on a box must not collide
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('WARPSTR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -98,19 +102,49 @@ def gather_results(local, world: int):
     return out
 
 
+def gather_counts(value: int, world: int, device=None) -> np.ndarray:
+    """One int64 per rank -> the array of all of them (a fixed-size all-gather: nothing is pickled)."""
+    if world <= 1 and not force_collectives():
+        return np.array([int(value)], np.int64)
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else 'cpu'
+    out = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, torch.tensor([int(value)], dtype=torch.int64, device=dev))
+    return out.cpu().numpy()
+
+
+def agree_or_raise(error, world: int, device=None, what: str = 'rank-local work'):
+    """Every rank calls this after its rank-local part (error: the exception it caught, or None).  If any rank failed,
+    every rank raises -- the failing rank its own exception, the others a RuntimeError naming the first failing rank and
+    its message -- instead of some ranks waiting in the next collective for one that never comes."""
+    if world <= 1 and not force_collectives():
+        if error is not None:
+            raise error
+        return
+    msg = (f'{type(error).__name__}: {error}' if error is not None else '').encode('utf-8', 'replace')[:500]
+    flags = gather_counts(len(msg), world, device)
+    if not flags.any():
+        return
+    texts = gather_bytes_ragged(np.frombuffer(msg, np.uint8), world, device)
+    if error is not None:
+        raise error
+    first = int(np.flatnonzero(flags)[0])
+    raise RuntimeError(f'{what} failed on rank {first}: {texts[first].tobytes().decode("utf-8", "replace")}')
+
+
 def gather_results_ragged(local_records: np.ndarray, owned: np.ndarray, n_total: int, world: int, device=None):
     """All-gather unequal shards and un-permute to the original read order.
     local_records: structured array (RESULT_DTYPE) of this rank's reads, in the order of `owned`."""
-    import torch
-    import torch.distributed as dist
     itemsize = local_records.dtype.itemsize
     if world <= 1 and not force_collectives():
         out = np.zeros(n_total, dtype=local_records.dtype)
         out[owned] = local_records
         return out
-    counts = [None] * world
-    dist.all_gather_object(counts, int(len(owned)))
-    cap = max(counts)
+    import torch
+    import torch.distributed as dist
+    counts = gather_counts(len(owned), world, device)
+    cap = max(int(counts.max()), 1)
     buf = np.zeros((cap, itemsize + 8), dtype=np.uint8)
     buf[:len(owned), :itemsize] = local_records.view(np.uint8).reshape(len(owned), itemsize)
     buf[:len(owned), itemsize:] = np.asarray(owned, dtype=np.int64).view(np.uint8).reshape(len(owned), 8)
@@ -122,7 +156,7 @@ def gather_results_ragged(local_records: np.ndarray, owned: np.ndarray, n_total:
     g = g.cpu().numpy().reshape(world, cap, itemsize + 8)
     out = np.zeros(n_total, dtype=local_records.dtype)
     for r in range(world):
-        k = counts[r]
+        k = int(counts[r])
         idx = np.ascontiguousarray(g[r, :k, itemsize:]).view(np.int64).reshape(-1)
         out[idx] = np.ascontiguousarray(g[r, :k, :itemsize]).view(local_records.dtype).reshape(-1)
     return out
@@ -132,31 +166,29 @@ def gather_called(local, owned: np.ndarray, shards: List[np.ndarray], n_total: i
     """Every rank's CallerResults (records + called sequences of its shard, in the order of its `owned` indices) -> the
     complete table in the original read order, on every rank: (records, seq1, offsets1, seq2, offsets2) with the two
     sequence buffers packed (read r's seq at seq1[offsets1[r] : offsets1[r] + len1[r]]).  Two collectives: the 56-byte
-    records (+ their read index), and one byte string of sequences per rank."""
+    records (+ their read index), and one byte string of sequences per rank.  No per-read Python on either side: the pieces
+    move with one fancy-index copy per rank and buffer (400 k reads: a few milliseconds)."""
+    from .caller import ragged_index
     records = gather_results_ragged(local.records, owned, n_total, world, device)
-    l1, l2 = local.records['len1'].astype(np.int64), local.records['len2'].astype(np.int64)
     ok = local.records['status'] == 0
-    l1, l2 = np.where(ok, l1, 0), np.where(ok, l2, 0)
+    l1 = np.where(ok, local.records['len1'], 0).astype(np.int64)
+    l2 = np.where(ok, local.records['len2'], 0).astype(np.int64)
     as_u8 = lambda b: np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray, memoryview)) else np.asarray(b, dtype=np.uint8)
     s1, s2 = as_u8(local._seq1), as_u8(local._seq2)
-    pieces = [s1[int(o):int(o) + int(n)] for o, n in zip(local.offsets, l1)] + [s2[int(o):int(o) + int(n)] for o, n in zip(local.offsets2, l2)]
-    blob = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    # a rank's string: the seqs of its reads in shard order, then their resc_seqs
+    blob = np.concatenate([s1[ragged_index(local.offsets, l1)], s2[ragged_index(local.offsets2, l2)]])
     blobs = gather_bytes_ragged(blob, world, device)
-    g1 = np.where(records['status'] == 0, records['len1'].astype(np.int64), 0)
-    g2 = np.where(records['status'] == 0, records['len2'].astype(np.int64), 0)
+    g1 = np.where(records['status'] == 0, records['len1'], 0).astype(np.int64)
+    g2 = np.where(records['status'] == 0, records['len2'], 0).astype(np.int64)
     off1, off2 = np.zeros(n_total + 1, np.int64), np.zeros(n_total + 1, np.int64)
     np.cumsum(g1, out=off1[1:])
     np.cumsum(g2, out=off2[1:])
     seq1, seq2 = np.zeros(int(off1[-1]), np.uint8), np.zeros(int(off2[-1]), np.uint8)
     for r in range(world):
-        idx = shards[r]
-        at = 0
-        for i in idx:  # a rank's string: the seqs of its reads in shard order, then their resc_seqs
-            seq1[off1[i]:off1[i + 1]] = blobs[r][at:at + g1[i]]
-            at += int(g1[i])
-        for i in idx:
-            seq2[off2[i]:off2[i + 1]] = blobs[r][at:at + g2[i]]
-            at += int(g2[i])
+        idx = np.asarray(shards[r], np.int64)
+        n1 = int(g1[idx].sum())
+        seq1[ragged_index(off1[idx], g1[idx])] = blobs[r][:n1]
+        seq2[ragged_index(off2[idx], g2[idx])] = blobs[r][n1:n1 + int(g2[idx].sum())]
     return records, seq1, off1[:-1], seq2, off2[:-1]
 
 

@@ -68,35 +68,45 @@ class LocusPath:
 
 def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
-                 signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None, device: int = 0, **kwargs):
+                 signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
+                 raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False, **kwargs):
     """Load data for calling and handle results (src/caller/wrapper.py:17-41).
 
     main_wrapper(locus, threads) -- the reference's call: `locus` is any object with `.path`, `.sequence`, `.flank_length`.
     main_wrapper(locus_path, sequence, flank_length[, threads]) -- the same without a Locus object.
     Returns (df_overview, df_collapsed) and writes what upstream writes except the plots: overview.csv columns,
     predictions/sequences/*.fasta, summaries/state_similarity.csv, and for loci with several repeat units
-    predictions/complexSTR_analysis/complex_repeat_units.csv."""
+    predictions/complexSTR_analysis/complex_repeat_units.csv.
+
+    shard=True: this process is one rank of a `python -m torch.distributed.run` job whose ranks ALL call main_wrapper for
+    the same locus; the reads are dealt over the ranks (main_wrapper_loci).  It is an explicit argument -- a job whose ranks
+    work on different loci calls with shard=False and no collective is entered."""
     if isinstance(locus, str):  # (locus_path, sequence, flank_length[, threads])
         locus = LocusPath(locus, threads, flank_length)
         threads = args[0] if args else kwargs.pop('threads', 1)
     if kwargs:
         raise TypeError(f'main_wrapper: unexpected arguments {sorted(kwargs)}')
     caller_config = caller_config or CallerConfig()
-    from . import dist as wdist
-    rank, world = wdist.process_group()
-    if world > 1 or wdist.force_collectives():
-        return _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal_loader, rank, world)
+    if shard:
+        return main_wrapper_loci([locus], threads, caller_config=caller_config, rescaler_config=rescaler_config,
+                                 signal_loader=signal_loader, raw_reader=raw_reader, device=device, shard=True)[0]
     overview_path, df_overview = ov.load_overview(locus.path)
     cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device)
     if signal_loader is None:
         # default: int16 reads straight from the .fast5 files, prepared on the GPU
-        names, reverses, raws, positions = get_raw_workload(df_overview, locus.path)
+        names, reverses, raws, positions = get_raw_workload(df_overview, locus.path, raw_reader)
         results = cw.run_raw(names, reverses, raws, positions, caller_config.spike_removal)
     else:
         workload = get_workload(df_overview, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
         reverses = [w.reverse for w in workload]
         results = cw.run(workload)
     return _store_outputs(locus, overview_path, df_overview, results, reverses, write=True)
+
+
+def main_wrapper_loci(loci, threads=1, **kwargs):
+    """main_wrapper for every locus of a run through ONE handle (mixed-locus batches): warpstr_amd/loci.py."""
+    from .loci import main_wrapper_loci as impl
+    return impl(loci, threads, **kwargs)
 
 
 def _store_outputs(locus, overview_path, df_overview, results, reverses, write: bool):
@@ -113,62 +123,6 @@ def _store_outputs(locus, overview_path, df_overview, results, reverses, write: 
         collapsed = [collapse_repeats(s[1], repeat_units, offsets) for s in seq_results]
         df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus.path, write=write)
     return df_overview, df_collapsed
-
-
-def _main_wrapper_sharded(locus, threads, caller_config, rescaler_config, signal_loader, rank: int, world: int):
-    """main_wrapper under `python -m torch.distributed.run --nproc-per-node N` (one process per GPU; upstream's fan-out is
-    the Pool.map of src/caller/wrapper.py:104-120).  Every rank reads the overview, derives the same partition of the
-    `saved` reads -- by cost: samples of the STR segment x what a sample costs on the strand's automaton (dist.slot_cost) --,
-    opens ONLY its own reads' fast5 files and calls them on its GPU.  Two collectives (RCCL all-gathers over xGMI; gloo in
-    the CPU tests) return every read's 56-byte record and called sequences to every rank; rank 0 writes overview.csv, the
-    FASTA files and the complex-unit table exactly as the single-GPU path does, every rank returns the same two tables
-    (so step 4 may run anywhere)."""
-    import torch
-    import torch.distributed as tdist
-
-    from . import dist as wdist
-    from .caller import CallerResults
-    backend = tdist.get_backend()
-    local_gpu = int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1)
-    coll_device = torch.device('cuda', local_gpu) if backend == 'nccl' else None
-    if backend == 'nccl':
-        torch.cuda.set_device(local_gpu)
-    overview_path, df_overview = ov.load_overview(locus.path)
-    # a read the caller fails on must not leave the other ranks waiting in a collective: the shards are called without
-    # raising, the complete table is checked on every rank alike
-    cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=local_gpu,
-                       write_summaries=rank == 0, on_error='nan')
-    saved = df_overview[np.asarray(df_overview['saved']).astype(bool)]
-    n = len(saved)
-    reverses = [bool(v) for v in saved['reverse']]
-    span = (np.asarray(saved['r_end_raw'], np.int64) - np.asarray(saved['l_start_raw'], np.int64) + 1).clip(min=1)
-    per_sample = np.where(np.asarray(reverses), wdist.slot_cost(cw.rev_sta.n_states), wdist.slot_cost(cw.temp_sta.n_states))
-    shards = wdist.shard_reads(span, world, per_sample)
-    mine = shards[rank]
-    part = saved.iloc[mine]
-    if len(part) == 0:
-        local = CallerResults([], np.zeros(0, dtype=_RESULT_DTYPE()), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.uint8),
-                              'nan')
-    elif signal_loader is None:
-        names, revs, raws, positions = get_raw_workload(part, locus.path)
-        local = cw.run_raw(names, revs, raws, positions, caller_config.spike_removal)
-    else:
-        workload = get_workload(part, locus.path, signal_loader or _fast5_loader(caller_config.spike_removal))
-        local = cw.run(workload)
-    if n == 0:  # nothing was saved for this locus: no collective has anything to carry
-        out = _store_outputs(locus, overview_path, df_overview, [], reverses, write=rank == 0)
-        tdist.barrier()
-        return out
-    records, seq1, off1, seq2, off2 = wdist.gather_called(local, mine, shards, n, world, coll_device)
-    results = CallerResults([str(x) for x in saved.index], records, off1, seq1, seq2, 'raise', offsets2=off2).check()
-    out = _store_outputs(locus, overview_path, df_overview, results, reverses, write=rank == 0)
-    tdist.barrier()  # the files are complete when any rank returns
-    return out
-
-
-def _RESULT_DTYPE():
-    from . import _lib
-    return _lib.RESULT_DTYPE
 
 
 def prepare_caller_only(csv_path: str, output: str, base_dir: str = '.'):
@@ -203,32 +157,68 @@ def _npz_loader(path: str) -> Callable[[str, int, int], np.ndarray]:
     return lambda fast5path, l_start_raw, r_end_raw: archive[os.path.basename(fast5path)[:-len('.fast5')]]
 
 
+def loci_from_config(cfg) -> list:
+    """The loci of a parsed configuration (config.load_config) as LocusPath objects under <output>/<name>, the directory
+    layout of upstream's Locus (src/schemas/locus.py:18-46)."""
+    return [LocusPath(os.path.join(cfg.output, lc.name), lc.sequence, lc.flank_length, lc.name) for lc in cfg.loci]
+
+
+def under_torchrun() -> bool:
+    from . import dist as wdist
+    return int(os.environ.get('WORLD_SIZE', '1')) > 1 or wdist.force_collectives()
+
+
 def main(argv=None):
-    """Step 3 (and optionally step 4) for one locus from the command line; under `python -m torch.distributed.run
-    --nproc-per-node N -m warpstr_amd.wrapper ...` the reads are sharded over the N GPUs of the node."""
+    """Step 3 (and optionally step 4) from the command line.
+
+      python -m warpstr_amd.wrapper --config cfg.yaml             every locus of a WarpSTR configuration (WarpSTR.py:33-76)
+      python -m warpstr_amd.wrapper LOCUS_PATH SEQUENCE FLANK     one locus directory
+
+    Under `python -m torch.distributed.run --nproc-per-node N -m warpstr_amd.wrapper ...` the reads are sharded over the N
+    GPUs of the node."""
     import argparse
-    ap = argparse.ArgumentParser(prog='python -m warpstr_amd.wrapper', description=main.__doc__)
-    ap.add_argument('locus_path')
-    ap.add_argument('sequence')
-    ap.add_argument('flank_length', type=int)
+    ap = argparse.ArgumentParser(prog='python -m warpstr_amd.wrapper', description=main.__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('locus_path', nargs='?')
+    ap.add_argument('sequence', nargs='?')
+    ap.add_argument('flank_length', type=int, nargs='?')
+    ap.add_argument('--config', help="a WarpSTR YAML configuration (upstream's keys: output, loci, flank_length, threads, "
+                                     'tr_calling_config, rescaling, tr_region_calling, genotyping)')
     ap.add_argument('--segments-npz', dest='signals', help='.npz archive of normalised segments by read name (instead of the fast5 files)')
     ap.add_argument('--genotype', action='store_true', help='also run step 4 on the results (rank 0)')
     args = ap.parse_args(argv)
-    locus = LocusPath(args.locus_path, args.sequence, args.flank_length)
-    df_overview, df_collapsed = main_wrapper(locus, 1, signal_loader=_npz_loader(args.signals) if args.signals else None)
+    shard = under_torchrun()
+    loader = _npz_loader(args.signals) if args.signals else None
+    if args.config:
+        from .config import load_config
+        cfg = load_config(args.config)
+        loci = loci_from_config(cfg)
+        genotype = args.genotype or bool(cfg.raw.get('genotyping', False))
+        tables = []
+        if cfg.tr_region_calling:
+            tables = main_wrapper_loci(loci, cfg.threads, caller_config=cfg.caller, rescaler_config=cfg.rescaler, signal_loader=loader,
+                                       shard=shard)
+    else:
+        if args.locus_path is None or args.sequence is None or args.flank_length is None:
+            ap.error('either --config or LOCUS_PATH SEQUENCE FLANK_LENGTH')
+        loci = [LocusPath(args.locus_path, args.sequence, args.flank_length)]
+        genotype = args.genotype
+        tables = [main_wrapper(loci[0], 1, signal_loader=loader, shard=shard)]
     from . import dist as wdist
-    rank, _ = wdist.process_group()
+    rank, _ = wdist.process_group() if shard else (0, 1)
     if rank == 0:
-        called = int((np.asarray(df_overview['results']) >= 0).sum())
-        print(f'{locus.name}: {called} reads called')
-        if args.genotype:
-            from .genotyper import run_genotyping_complex, run_genotyping_overview
-            run_genotyping_overview(df_overview, locus.path, None)
-            run_genotyping_complex(locus.path, df_collapsed)
-    import torch.distributed as tdist
-    if tdist.is_available() and tdist.is_initialized():
-        tdist.barrier()
-        tdist.destroy_process_group()
+        for locus, (df_overview, df_collapsed) in zip(loci, tables):
+            called = int((np.asarray(df_overview['results']) >= 0).sum())
+            print(f'{locus.name}: {called} reads called')
+            if genotype:
+                from .genotyper import run_genotyping_complex, run_genotyping_overview
+                run_genotyping_overview(df_overview, locus.path, None)
+                run_genotyping_complex(locus.path, df_collapsed)
+    if shard:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            tdist.barrier()
+            tdist.destroy_process_group()
 
 
 if __name__ == '__main__':
