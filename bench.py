@@ -209,12 +209,28 @@ def union_ms(begin, end):
     return tot + ((ce - cs) if cs is not None else 0.0)
 
 
+def kernel_source_hash():
+    """What the committed counters are valid for: the text of the fill kernels and of the state placement."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ('warpstr_amd/csrc/dtw_kernels.hip', 'warpstr_amd/csrc/wsx_place.h'):
+        with open(os.path.join(ROOT, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def fill_profile(kernel):
     """Counters of the fill kernel from the committed rocprofv3 PMC passes (profiles/fill_pmc.json, written by
-    scripts/summarize_profiles.py).  The bench refuses to quote counters of a different kernel."""
+    scripts/summarize_profiles.py).  The bench refuses to quote counters of a different kernel: an entry is keyed by the
+    kernel's name AND carries the hash of the sources it was measured on (kernel_source_hash); an entry taken from other
+    sources is not quoted (returns {'stale': ...}: the line then says so instead of carrying its numbers)."""
     path = os.path.join(ROOT, 'profiles', 'fill_pmc.json')
     with open(path) as f:
         table = json.load(f)
+    entry = table.get(kernel)
+    if entry is not None and entry.get('kernel_source_hash') != kernel_source_hash() and not os.environ.get('WARPSTR_BENCH_PROFILING'):
+        return {'stale': f"profiles/fill_pmc.json: the counters of {kernel} were taken on other kernel sources "
+                         f"(hash {entry.get('kernel_source_hash')}, now {kernel_source_hash()}); re-run scripts/profile_round.sh"}
     if kernel not in table and kernel.endswith(', 0>'):  # profiles taken before the kernel grew its last template parameter
         legacy = kernel[:-len(', 0>')] + '>'
         if legacy in table:
@@ -348,7 +364,7 @@ def secondary_leg(wl, local, device, steps, warmup, n_verify):
     from warpstr_amd import _lib
     from warpstr_amd.caller import HipCaller
     n = wl.n
-    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=torch.cuda.current_stream().cuda_stream, workspace_limit=96 << 30)
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=torch.cuda.current_stream().cuda_stream)  # (the library's default limits)
     res = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
     hip.set_pipelined(True)
     for k in range(warmup):
@@ -371,6 +387,130 @@ def secondary_leg(wl, local, device, steps, warmup, n_verify):
     return out
 
 
+MANY_LOCI_PATTERNS = ['(AAAT)', '(AGC)AACAGCCGCCAC(CGC)', '((CAGG){CAGM})(CAGA)(CA)', '(AGC)', '(GGCCCC)', '(CCTG)(TCTG)',
+                      '(AAGGG)(AAAGG)', '(GAA)', '(CAG)CAACAG(CCG)', '(CTG)CTA(CTG)']
+
+
+def make_locus_dirs(root, specs, reads_per_locus, seed):
+    """Locus directories as steps 1-2 of the pipeline leave them (overview.csv with the `saved` rows, the flank file) for
+    specs = [(name, pattern, flank, (Tmin, Tmax), locus seed)], and the reads as raw int16 DAC segments in host memory
+    ({read name: array}; l_start_raw = 0, r_end_raw = len - 1).  Six clean template reads per locus, noise per read."""
+    import pandas as pd
+
+    from warpstr_amd import overview as ov, synth
+    from warpstr_amd.wrapper import LocusPath
+    rng = np.random.default_rng(seed)
+    loci, raws = [], {}
+    for name, pattern, fl, (tmin, tmax), lseed in specs:
+        locus = synth.make_locus(pattern, fl, lseed)
+        tpl = []
+        for _ in range(6):
+            rev = bool(rng.random() < 0.5)
+            t = int(rng.integers(tmin, tmax + 1))
+            hi = max(1, min(30, (t // 4 - 2 * fl - 12) // 14))
+            tpl.append((rev, synth.squiggle(locus, rev, t, rng, lo=1, hi=hi, sigma=0.0)[0]))
+        loc = os.path.join(root, name)
+        ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+        names = [f'{name}_r{i:05d}' for i in range(reads_per_locus)]
+        pick = rng.integers(0, len(tpl), size=reads_per_locus)
+        lens = []
+        for nm, k in zip(names, pick):
+            x = tpl[k][1] + 0.25 * rng.standard_normal(len(tpl[k][1]))
+            raws[nm] = np.clip(np.round(x * 70.0 + 500.0), 0, 2047).astype(np.int16)
+            lens.append(len(x))
+        pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': [tpl[k][0] for k in pick], 'saved': 1, 'l_start_raw': 0,
+                      'r_end_raw': [n - 1 for n in lens]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        loci.append(LocusPath(loc, pattern, fl, name))
+    return loci, raws
+
+
+def _driver_timings(tm, n_loci):
+    per = lambda k: tm.get(k, 0.0) / max(n_loci, 1) * 1e3
+    return {'wall_s': tm['total_s'],
+            'per_locus_ms': {'overview_csv': per('overview_s'), 'automaton_compile': per('automata_s'), 'outputs': per('store_s')},
+            'once_s': {'handle_create_placement': tm['handle_s']},
+            'batches_s': {'host_reads': tm['read_s'], 'submit': tm['submit_s'], 'wait_for_gpu': tm['collect_s']},
+            'workspace_bytes': tm.get('workspace_bytes'), 'workspace_limit_bytes': tm.get('workspace_limit_bytes'),
+            'kernels': tm.get('kernels')}
+
+
+def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
+    """The regime real runs live in: hundreds to thousands of loci with tens of reads each (upstream: one main_wrapper call
+    per locus, WarpSTR.py:33-76).  n_loci loci at the default flank 110, mixed patterns, reads_per_locus reads of 2271-3701
+    samples each, from raw int16 reads in host memory to every locus's output files, through ONE handle
+    (warpstr_amd.wrapper.main_wrapper_loci) -- and, for the first n_loop of them, through one handle per locus
+    (main_wrapper in a loop); the files of those loci must be identical."""
+    import filecmp
+    import shutil
+    import tempfile
+
+    from warpstr_amd.wrapper import main_wrapper, main_wrapper_loci
+    root = tempfile.mkdtemp(prefix='wsx_many_loci_')
+    try:
+        specs = [(f'locus{i:04d}', MANY_LOCI_PATTERNS[i % len(MANY_LOCI_PATTERNS)], 110, (2271, 3701), 5000 + i) for i in range(n_loci)]
+        t0 = time.perf_counter()
+        loci, raws = make_locus_dirs(os.path.join(root, 'batched'), specs, reads_per_locus, 77)
+        loop_loci, _ = make_locus_dirs(os.path.join(root, 'loop'), specs[:n_loop], reads_per_locus, 77)
+        gen_s = time.perf_counter() - t0
+        reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
+        # warm-up on directories of its own (a second pass over a locus finds the first one's columns in its overview.csv):
+        # first use of the kernels' code objects, pinned staging
+        warm_loci, _ = make_locus_dirs(os.path.join(root, 'warm'), specs[:10], reads_per_locus, 77)
+        main_wrapper_loci(warm_loci, 1, raw_reader=reader, device=local, quiet=True)
+        tm = {}
+        main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True, timings=tm)
+        n_reads = n_loci * reads_per_locus
+        out = {'workload': f'{n_loci} loci x {reads_per_locus} reads, flank 110, {len(MANY_LOCI_PATTERNS)} patterns '
+                           f'({", ".join(MANY_LOCI_PATTERNS[:3])}, ...), T in [2271, 3701], raw int16 reads in host memory -> output files',
+               'loci': n_loci, 'reads': n_reads, 'loci_per_s': n_loci / tm['total_s'], 'reads_per_s': n_reads / tm['total_s'],
+               'one_handle': _driver_timings(tm, n_loci), 'generation_s': gen_s}
+        import contextlib
+        import io
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            for locus in loop_loci:
+                main_wrapper(locus, 1, raw_reader=reader, device=local)
+        dt = time.perf_counter() - t0
+        same = True
+        for a, b in zip(loci[:n_loop], loop_loci):
+            for rel in ('overview.csv', 'predictions/sequences/all.fasta', 'summaries/state_similarity.csv'):
+                same = same and filecmp.cmp(os.path.join(a.path, rel), os.path.join(b.path, rel), shallow=False)
+        out['one_handle_per_locus'] = {'loci': n_loop, 'ms_per_locus': dt / max(n_loop, 1) * 1e3, 'loci_per_s': n_loop / dt,
+                                       'reads_per_s': n_loop * reads_per_locus / dt,
+                                       'note': 'main_wrapper per locus: automata, a handle with its streams, first-call allocations and '
+                                               'a drained GPU per locus'}
+        out['ms_per_locus'] = tm['total_s'] / n_loci * 1e3
+        out['speedup_over_per_locus_handles'] = (dt / max(n_loop, 1)) / (tm['total_s'] / n_loci)
+        out['outputs_identical'] = {'loci': n_loop, 'identical': bool(same)}
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def cfg5_driver_leg(reads_per_locus, local):
+    """configs[4]'s share of one GPU (8 loci x 2 strands, ~128-state automata, T in [500, 5000]) through the PRODUCT seam:
+    main_wrapper_loci from raw int16 reads in host memory to the eight loci's output files (the kernel-level figure with the
+    reads resident in HBM is secondary.cfg5)."""
+    import shutil
+    import tempfile
+
+    from warpstr_amd.wrapper import main_wrapper_loci
+    root = tempfile.mkdtemp(prefix='wsx_cfg5_')
+    try:
+        specs = [(f'locus{i}', p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i) for i, p in enumerate(CFG5_PATTERNS)]
+        loci, raws = make_locus_dirs(root, specs, reads_per_locus, 78)
+        reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
+        main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True)  # warm-up (code objects, pinned staging)
+        tm = {}
+        tables = main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True, timings=tm)
+        n = len(loci) * reads_per_locus
+        called = int(sum((np.asarray(df['results']) >= 0).sum() for df, _ in tables))
+        return {'workload': f'8 loci x {reads_per_locus} reads through main_wrapper_loci, raw int16 reads in host memory -> output files',
+                'reads': n, 'called_ok': called, 'reads_per_s': n / tm['total_s'], 'driver': _driver_timings(tm, len(loci))}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -385,6 +525,7 @@ def main():
     ap.add_argument('--no-secondary', action='store_true',
                     help='the default single-GPU headline run also times cfg1, cfg5 and the path from raw int16 segments '
                          '(reported under "secondary"); this switch leaves them out')
+    ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
                          'called sequences requested; reported as from_raw next to the headline')
@@ -456,7 +597,7 @@ def main():
     n = wl.n
     n_pad = (n_total + world - 1) // world if strong else n  # all_gather_into_tensor wants equal shards
     stream = torch.cuda.current_stream().cuda_stream
-    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream, workspace_limit=96 << 30)
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream)  # the library's defaults: no workspace limit, no knob
     # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
     # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
     res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
@@ -508,6 +649,8 @@ def main():
     tm = hip.last_timing()  # HIP events on the launch streams, every fill launch of the timed region
     fb, fe, fr = hip.fill_intervals()
     hip.timing_window(False)
+    workspace = hip.workspace()  # what the timed steps needed (the single-stream step below is one 100k-read chunk: bigger)
+    workspace['limit_bytes'] = hip.workspace_limit()
     # untimed extra step on ONE stream: the fill kernel's duration when nothing runs beside it (VALU roofline)
     hip.set_streams(1)
     step()
@@ -545,6 +688,9 @@ def main():
         kernel = hip.kernel_name(0)
         kernels = sorted({hip.kernel_name(a) for a in range(len(wl.tables))})
         prof = fill_profile(kernel)
+        stale = prof.get('stale') if prof else None
+        if stale:
+            prof = None
         traffic = None
         if prof is not None and prof.get('hbm_bytes_per_sample') is not None:  # HBM bytes per launch from the PMC passes, scaled to this launch size
             traffic = prof['hbm_bytes_per_sample'] * samples * 2 * args.steps / launches_total
@@ -564,7 +710,9 @@ def main():
             'config': {'workload': head + (f'{n_total} reads in total sharded over {world} GPU(s)' if strong else f'{n} reads/GPU') +
                                    f', {wl.desc}, both passes',
                        'name': wl.name, 'reads_per_gpu': n, 'reads_total': n_total, 'mean_samples_per_read': samples / n,
-                       'states': S, 'called_ok': ok_all,
+                       'states': S, 'called_ok': ok_all, 'workspace_limit_bytes': workspace['limit_bytes'],
+                       'chunk_plan': {'chunks_per_call': launches_total / args.steps / 2.0 / max(len(kernels), 1), 'streams': 4,
+                                      'pipelined_calls_in_flight': 2 if n >= 32768 else 4},
                        'results_gather': ((f'{backend} all_gather of 56-B records per step' +
                                           (', overlapped with the next step' if collective else ' (CPU test path, synchronous)')) if world > 1
                                           else ('one-rank nccl group (self test)' if self_gather else 'none (1 GPU)'))},
@@ -581,12 +729,13 @@ def main():
                                  'launches of different chunks overlap on different streams, achieved_over_union divides by the '
                                  'union of their intervals instead. min-plus recurrence: bound by fp64 VALU issue and the LDS '
                                  'pipe, not HBM (see valu_roofline)'},
-            'valu_roofline': valu_roofline(prof, alone_ms, alone_rows, kernel) if prof is not None else {'launch_ms_alone': alone_ms},
+            'valu_roofline': (valu_roofline(prof, alone_ms, alone_rows, kernel) if prof is not None else
+                              {'launch_ms_alone': alone_ms, 'counters': stale or 'none (profiling run)'}),
             'valu': {'dp_cells_per_s': cells_per_s},
             # first enqueue to last finish of the timed region on the device clock (HIP events), per step
             'device_ms_per_step': tm['total_ms'] / args.steps,
             # device memory the handle holds for this workload (all work sets of all streams), and per sample of a call
-            'workspace': hip.workspace(),
+            'workspace': workspace,
         }
         if not args.no_verify:
             nv = min(n, 4096 if not args.no_cpu_baseline else 256)
@@ -628,6 +777,13 @@ def main():
                     rc = 3
                     print(f"bench.py: secondary workload {name}: {leg['verified']['mismatches']} reads differ from the oracle", file=sys.stderr)
             out['secondary']['from_raw'] = out['from_raw']
+            # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
+            out['secondary']['cfg5']['through_driver'] = cfg5_driver_leg(6250, local)
+            if args.many_loci > 0:
+                out['many_loci'] = many_loci_leg(args.many_loci, 30, min(32, args.many_loci), local)
+                if not out['many_loci']['outputs_identical']['identical']:
+                    rc = 3
+                    print('bench.py: many_loci: the batched driver and the per-locus loop wrote different files', file=sys.stderr)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or self_gather:

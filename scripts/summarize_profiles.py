@@ -2,6 +2,9 @@
 Usage: summarize_profiles.py gpurun_out/<TAG> <name>   ->  profiles/<name>_kernel_stats.csv, <name>_pmc.json, <name>_traffic.json"""
 import csv, json, os, sys, collections
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (the counters are valid for these sources only)
+
 src, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, 'profiles')
@@ -79,6 +82,7 @@ for fill in fills:
         'hbm_bytes_per_sample': (fetch_kb + write_kb) * 1024 / samples,
         'launch_ms_under_pmc': f['GRBM_GUI_ACTIVE']['mean_launch_ms_under_pmc'], 'reads': f['SQ_WAVES']['mean_per_launch'],
         'samples_total': samples, 'source': f'profiles/{name}_pmc.json', 'workload': bench['config']['workload'],
+        'kernel_source_hash': kernel_source_hash(),
     }
     traffic[fill] = {
         'workload': {'reads': f['SQ_WAVES']['mean_per_launch'], 'samples_total': samples},

@@ -37,18 +37,34 @@ def test_verify_counts_mismatching_reads():
     assert bench.verify(rec, [o(1, 0, 0, 0, 0)])['mismatches'] == 1   # status differs
 
 
-def test_profiled_counters_must_belong_to_the_kernel(monkeypatch):
+def test_profiled_counters_must_belong_to_the_kernel(monkeypatch, tmp_path):
+    """bench.py quotes PMC counters only for the kernel NAME they were taken from and only while the kernel SOURCES are the
+    ones they were taken on (kernel_source_hash in every entry of profiles/fill_pmc.json)."""
     table = json.load(open(os.path.join(bench.ROOT, 'profiles', 'fill_pmc.json')))
     kernel = sorted(table)[0]
-    prof = bench.fill_profile(kernel)
-    assert prof['source'].startswith('profiles/') and prof['valu_insts_per_wave_row'] > 8
     monkeypatch.delenv('WARPSTR_BENCH_PROFILING', raising=False)
     with pytest.raises(SystemExit):
         bench.fill_profile('dtw_fill_fast<9, 9, 9, 9, false>')
-    monkeypatch.setenv('WARPSTR_BENCH_PROFILING', '1')
-    assert bench.fill_profile('dtw_fill_fast<9, 9, 9, 9, false>') is None
+    # an entry measured on other sources is not quoted
+    real_hash = bench.kernel_source_hash
+    monkeypatch.setattr(bench, 'kernel_source_hash', lambda: 'somethingelse')
+    assert 'stale' in bench.fill_profile(kernel)
+    monkeypatch.setattr(bench, 'kernel_source_hash', lambda: table[kernel].get('kernel_source_hash'))
+    prof = bench.fill_profile(kernel)
+    assert prof['source'].startswith('profiles/') and prof['valu_insts_per_wave_row'] > 8
     r = bench.valu_roofline(prof, 5.0, 2e8, kernel)
     assert r['counters_from'] == prof['source'] and 0 < r['frac'] < r['frac_at_observed_clock'] < 1.2
+    monkeypatch.setattr(bench, 'kernel_source_hash', real_hash)
+    monkeypatch.setenv('WARPSTR_BENCH_PROFILING', '1')
+    assert bench.fill_profile('dtw_fill_fast<9, 9, 9, 9, false>') is None
+
+
+def test_committed_counters_are_those_of_the_committed_kernels():
+    """The headline kernel's entry of profiles/fill_pmc.json was measured on the kernel sources in this tree."""
+    table = json.load(open(os.path.join(bench.ROOT, 'profiles', 'fill_pmc.json')))
+    entry = table['dtw_fill_fast<4, 1, 2, 2, true, 0>']
+    assert entry.get('kernel_source_hash') == bench.kernel_source_hash(), \
+        'kernel sources changed since the PMC passes: re-run scripts/profile_round.sh + scripts/summarize_profiles.py'
 
 
 def test_strong_scaling_partition_covers_the_workload_once():

@@ -79,11 +79,12 @@ __device__ __forceinline__ ReadGeom geom(const PassArgs &a, int slot)
     return g;
 }
 
-// Back-pointer masks of a read: NM 64-bit masks per row, rows consecutive, first row 16-byte aligned (one spare row per
-// read absorbs the rounding).
+// Back-pointer masks of a read: NM 64-bit masks per row, rows consecutive, first row 16-byte aligned.  Where a read's rows
+// start is the host's decision (a.bp_off[lr], in 64-bit words: the reads of a chunk lie back to back whatever kernel variant
+// each of them takes, wsx_api.hip: one region for all launch groups, sized by what the chunk's reads need).
 __device__ __forceinline__ uint64_t *mask_rows(const PassArgs &a, long long off, int lr, int NM)
 {
-    return (uint64_t *)a.bp + ((((size_t)off + (size_t)lr) * (size_t)NM + 1) & ~(size_t)1);
+    return (uint64_t *)a.bp + a.bp_off[lr];
 }
 
 // Packed mask rows (PK; single-slot automata with two candidates whose states with two predecessors all sit in lanes 0..7,
@@ -92,7 +93,7 @@ __device__ __forceinline__ uint64_t *mask_rows(const PassArgs &a, long long off,
 // 144 bytes, so groups stay 16-byte aligned; 9 bytes per row instead of 16.
 __device__ __forceinline__ uint64_t *mask_rows_pk(const PassArgs &a, long long off, int lr)
 {
-    return (uint64_t *)a.bp + ((size_t)(off / 16) + (size_t)lr) * 18;
+    return (uint64_t *)a.bp + a.bp_off[lr];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(64) void dtw_fill_generic(PassArgs a, int K)
         return;
     }
     const double *sig = a.signal + off;
-    uint32_t *bp = a.bp + (size_t)(off / R + lr) * (K * 64);
+    uint32_t *bp = a.bp + 2 * a.bp_off[lr]; // (R rows per 32-bit word and state: (T / R + 1) * K * 64 words per read)
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     const int ring = m + 1;
     const int SP = K * 64;
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(64) void traceback_generic_kernel(PassArgs a, int K
     const DevAutomaton &A = a.aut[a.aut_id[gm.r]];
     const int32_t *pred_ptr = A.pred_ptr, *pred_idx = A.pred_idx;
     const int m = a.m;
-    const uint32_t *bp = a.bp + (size_t)(off / R + lr) * (K * 64);
+    const uint32_t *bp = a.bp + 2 * a.bp_off[lr];
     const uint32_t *maskw = a.maskbits ? (a.maskbits + (off / 32 + lr)) : nullptr;
     uint16_t *run_state = a.run_state + off;
     int32_t *run_start = a.run_start + off;

@@ -44,14 +44,21 @@ struct Variant { // which DP kernel an automaton uses
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
     int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot,
                      // 4 = every slot and two pieces to a lane (stacked)
-    // back-pointer scratch in 32-bit words for a chunk of `samples` samples in `reads` reads:
-    //   register-resident fill: per sample F + (K-1)*FL 64-bit wave masks, one spare row per read (dtw_kernels.hip);
-    //   generic fill: 4 bits per row and state, 8 rows per word, one spare word row per read
+    // back-pointer scratch of ONE read of T samples, in 64-bit words (even: a read's rows start 16-byte aligned):
+    //   register-resident fill: per row F + (K-1)*FL 64-bit wave masks, one spare row (dtw_kernels.hip);
+    //   packed rows: 18 words per 16 rows; generic fill: 4 bits per row and state, 8 rows per 32-bit word
+    size_t bp_read_words(size_t T) const
+    {
+        if (generic) return (T / 8 + 1) * (size_t)(K * 32);
+        if (pk) return (T / 16 + 1) * 18;
+        return (((T + 1) * (size_t)(F + (K - 1) * FL)) + 1) & ~(size_t)1;
+    }
+    // upper bound, in 32-bit words, for a chunk of `samples` samples in `reads` reads that all took this variant
     size_t bp_words(size_t samples, size_t reads) const
     {
         if (generic) return (samples / 8 + reads + 2) * (size_t)(K * 64);
-        if (pk) return (samples / 16 + reads + 4) * 18 * 2; // 18 64-bit words per 16 rows, a read starts a new group
-        return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2;
+        if (pk) return (samples / 16 + reads + 4) * 18 * 2;
+        return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2 + 2 * reads;
     }
     bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm; }
 };
@@ -345,8 +352,8 @@ int get_event_pair(wsx_caller *c, hipEvent_t *a, hipEvent_t *b, int32_t reads)
 // of every distinct kernel variant of the handle (each has a region of its own), and for host buffers the staging areas
 size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 {
-    size_t bp = 0;
-    for (auto &v : c->uvar) bp += v.bp_words(4096, 0) * 4 / 4096 + 1;
+    size_t bp = 0; // (the reads of a chunk lie back to back in ONE region whatever variant each takes: the widest decides)
+    for (auto &v : c->uvar) bp = std::max(bp, v.bp_words(4096, 0) * 4 / 4096 + 1);
     size_t b = 8 /*rescaled*/ + 2 + 4 /*runs*/ + 24 + 1 /*alignment*/ + 16 /*fit pairs*/ + 16 /*scratch*/ +
                1 /*mask bits, rounded up*/ + bp;
     if (host_mem) b += 8 /*signal staging*/ + (want_traces ? (2 + 2 + 8 + 3) : 0);
@@ -356,7 +363,9 @@ size_t per_sample_bytes(const wsx_caller *c, bool host_mem, bool want_traces)
 size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
 {
     size_t b = 168 + sizeof(wsx_result) + 64;
-    for (auto &v : c->uvar) b += v.bp_words(0, 1) * 4; // (distinct variants: a handle may hold thousands of automata)
+    size_t spare = 0;
+    for (auto &v : c->uvar) spare = std::max(spare, v.bp_words(0, 1) * 4);
+    b += spare;
     if (c->prm.reps_as_one) b += 2 * (size_t)c->max_states * sizeof(int32_t);
     if (host_mem) b += 16 + last_row_bytes;
     return b;
@@ -467,35 +476,32 @@ try {
         used += align_up(bytes);
         return d;
     };
-    for (int a = 0; a < n_automata; a++) {
+    // Where the states of every automaton live (wsx_place.h) is host work of a millisecond or two per automaton and
+    // independent between automata: a handle for all loci of a run (thousands of automata, warpstr_amd/loci.py) places them
+    // on several host threads.
+    struct Placed {
+        Variant v;
+        int mf = 0;
+        std::vector<uint16_t> pos, wslot, state_at, paddr;
+        std::vector<uint64_t> p4;
+        bool store_pos = false;
+        uint64_t stack_mask = 0;
+    };
+    std::vector<Placed> placed((size_t)n_automata);
+    auto place_one = [&](int a) {
         const wsx_automaton &A = automata[a];
-        const int S = A.n_states, E = A.pred_ptr[S];
-        DevAutomaton D{};
-        D.n_states = S;
-        D.endstate = A.endstate;
-        D.flank_length = A.flank_length;
+        const int S = A.n_states;
+        Placed &P = placed[a];
         int mf = 0;
         for (int j = 0; j < S; j++) mf = std::max(mf, A.pred_ptr[j + 1] - A.pred_ptr[j]);
-        D.max_fanin = mf;
-        D.seq_idx_last = A.seq_idx[S - 1];
-        D.reverse = A.reverse ? 1 : 0;
-        D.value = (const double *)put(A.value, (size_t)S * 8);
-        D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
-        D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
-        int32_t dummy = 0;
-        D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
-        D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
-        D.last_base = A.last_base ? (const uint8_t *)put(A.last_base, (size_t)S) : nullptr;
-        if (!A.last_base) c->have_bases = false;
-        Variant v;
+        P.mf = mf;
+        Variant &v = P.v;
         v.K = (S + 63) / 64;
         v.F = std::max(mf, 1);
         v.generic = !wsx_fast_pass_supported(c->prm.min_values_per_state, v.K, v.F);
         // Several slots and only a few states with many predecessors (loop entries, IUPAC alternatives): give those
         // states slot 0 (positions 0..63), so that only that slot pays for the extra candidates.  Slots 1.. then
         // consider FL predecessors: 1 when every state with two or more fits in slot 0, else 2.
-        D.pos = nullptr;
-        D.state_at = nullptr;
         const int Fk = v.F <= 2 ? 2 : v.F;
         v.FL = Fk;
         if (!v.generic && wsx_split_supported(c->prm.min_values_per_state, v.K) && !wsx_exp_env("WSX_NO_SPLIT")) {
@@ -509,14 +515,16 @@ try {
             else if (Fk > 2 && n_gt2 <= 64) v.FL = 2;
         }
         // where the states live: position (slot, lane) and LDS export slot of every state (wsx_place.h)
-        std::vector<uint16_t> pos(S), wslot((size_t)v.K * 64);
+        std::vector<uint16_t> &pos = P.pos, &wslot = P.wslot;
+        pos.resize(S);
+        wslot.resize((size_t)v.K * 64);
         std::iota(pos.begin(), pos.end(), (uint16_t)0);
         std::iota(wslot.begin(), wslot.end(), (uint16_t)0);
         if (!v.generic) {
             const bool want_pk = v.K == 1 && Fk == 2 && !wsx_exp_env("WSX_NO_PACK");
             // several slots: the lane-major layout (chains along the slots of a lane, LDS only for slot 0) where it fits
             WsxLanePlacement lp;
-            static const int lm_mode = [] {
+            const int lm_mode = [] {
                 const char *e = wsx_exp_env("WSX_FILL_LM");
                 return e ? atoi(e) : 1; // 0: off; 1: on; 2: on, every slot exports
             }();
@@ -533,7 +541,7 @@ try {
             if (lp.lm != 0) {
                 v.FL = 1;
                 v.lm = lp.lm == 4 ? 4 : lm_mode == 2 ? 2 : (lp.lm == 3 && v.K < 4 ? 2 : lp.lm);
-                D.stack_mask = lp.stack_mask;
+                P.stack_mask = lp.stack_mask;
             }
             const WsxPlacement pl = lp.lm != 0 ? lp.pl
                                     : wsx_exp_env("WSX_PLAIN_PLACEMENT") && v.FL >= Fk
@@ -544,27 +552,24 @@ try {
                 wslot = pl.wslot;
                 v.pk = want_pk && pl.low8;
                 if (!pl.identity) {
-                    D.pos = (const uint16_t *)put(pos.data(), (size_t)S * 2);
-                    D.state_at = (const uint16_t *)put(pl.state_at.data(), pl.state_at.size() * 2);
+                    P.store_pos = true;
+                    P.state_at = pl.state_at;
                 }
             }
-            if (v.K == 1) D.wslot = (const uint16_t *)put(wslot.data(), wslot.size() * 2);
         }
         // pred4: the walk of the mask traceback runs in position space -- per position (slot*64 + lane) the positions of
         // its state's first four predecessors, 16 bits each
-        {
-            std::vector<uint64_t> p4((size_t)v.K * 64, 0);
-            for (int j = 0; j < S; j++)
-                for (int e = A.pred_ptr[j], t = 0; e < A.pred_ptr[j + 1] && t < 4; e++, t++)
-                    p4[pos[j]] |= (uint64_t)pos[A.pred_idx[e]] << (16 * t);
-            D.pred4 = (const uint64_t *)put(p4.data(), p4.size() * 8);
-        }
+        P.p4.assign((size_t)v.K * 64, 0);
+        for (int j = 0; j < S; j++)
+            for (int e = A.pred_ptr[j], t = 0; e < A.pred_ptr[j + 1] && t < 4; e++, t++)
+                P.p4[pos[j]] |= (uint64_t)pos[A.pred_idx[e]] << (16 * t);
         // paddr: which LDS export slot (slot k, predecessor f, lane) reads in the register-resident fill.  A ds_read_b64
         // serves lanes 0-31 and 32-63 in one cycle each when no two lanes of a group hit the same bank pair (slot mod 32)
         // at different addresses; lanes without predecessor f all read the same +inf slot (a broadcast), picked among the
         // 32 spare slots K*64.. so that its bank pair is one the group's real readers leave free.
         if (!v.generic) {
-            std::vector<uint16_t> paddr((size_t)v.K * WSX_MAX_F * 64, (uint16_t)(v.K * 64));
+            std::vector<uint16_t> &paddr = P.paddr;
+            paddr.assign((size_t)v.K * WSX_MAX_F * 64, (uint16_t)(v.K * 64));
             std::vector<int> state_of((size_t)v.K * 64, -1);
             for (int j = 0; j < S; j++) state_of[pos[j]] = j;
             for (int k = 0; k < v.K; k++)
@@ -587,8 +592,59 @@ try {
                                 paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)(v.K * 64 + best);
                         }
                     }
-            D.paddr = (const uint16_t *)put(paddr.data(), paddr.size() * 2);
         }
+    };
+    {
+        const int nt = n_automata >= 16 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+        if (nt <= 1) {
+            for (int a = 0; a < n_automata; a++) place_one(a);
+        } else {
+            std::vector<std::thread> th;
+            std::vector<std::exception_ptr> errs((size_t)nt);
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t] {
+                    try {
+                        for (int a = t; a < n_automata; a += nt) place_one(a);
+                    } catch (...) {
+                        errs[t] = std::current_exception();
+                    }
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (e) std::rethrow_exception(e);
+        }
+    }
+    for (int a = 0; a < n_automata; a++) {
+        const wsx_automaton &A = automata[a];
+        const int S = A.n_states, E = A.pred_ptr[S];
+        Placed &P = placed[a];
+        Variant v = P.v;
+        const int mf = P.mf;
+        DevAutomaton D{};
+        D.n_states = S;
+        D.endstate = A.endstate;
+        D.flank_length = A.flank_length;
+        D.max_fanin = mf;
+        D.seq_idx_last = A.seq_idx[S - 1];
+        D.reverse = A.reverse ? 1 : 0;
+        D.value = (const double *)put(A.value, (size_t)S * 8);
+        D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
+        D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
+        int32_t dummy = 0;
+        D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
+        D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
+        D.last_base = A.last_base ? (const uint8_t *)put(A.last_base, (size_t)S) : nullptr;
+        if (!A.last_base) c->have_bases = false;
+        D.pos = nullptr;
+        D.state_at = nullptr;
+        D.stack_mask = P.stack_mask;
+        if (P.store_pos) {
+            D.pos = (const uint16_t *)put(P.pos.data(), (size_t)S * 2);
+            D.state_at = (const uint16_t *)put(P.state_at.data(), P.state_at.size() * 2);
+        }
+        if (!v.generic && v.K == 1) D.wslot = (const uint16_t *)put(P.wslot.data(), P.wslot.size() * 2);
+        D.pred4 = (const uint64_t *)put(P.p4.data(), P.p4.size() * 8);
+        if (!v.generic) D.paddr = (const uint16_t *)put(P.paddr.data(), P.paddr.size() * 2);
         c->host_aut.push_back(D);
         if (v.generic) {
             if (mf > 15) {
@@ -1013,10 +1069,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
     if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
         HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
-    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4)));
+    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8)));
     if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
         for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
-            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
             if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
             HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
             HIPCHK(c->meta[q].ensure(need));
@@ -1032,9 +1088,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int64_t *d_offsets = mc.take<int64_t>(n + 1);
     int32_t *d_autid = mc.take<int32_t>(n);
     int32_t *d_order = mc.take<int32_t>(n);
+    int64_t *d_bpoff = mc.take<int64_t>(n); // per read (global index): start of its back-pointer rows in its chunk's region
     // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
     // caller's arrays are not referenced after this function returns
-    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4);
+    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
     if (pin_bytes > c->pinned_cap[slot]) {
         if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
         c->pinned[slot] = nullptr;
@@ -1046,6 +1103,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int64_t *h_offsets = pc.take<int64_t>(n + 1);
     int32_t *h_autid = pc.take<int32_t>(n);
     int32_t *h_order = pc.take<int32_t>(n);
+    int64_t *h_bpoff = pc.take<int64_t>(n);
     memcpy(h_offsets, io.offsets, (n + 1) * 8);
     memcpy(h_autid, io.aut_id, n * 4);
     HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1095,21 +1153,22 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         if (full && c->prm.reps_as_one)
             HIPCHK(c->work[w].reps.ensure(R1 * 2 * (size_t)c->max_states * sizeof(int32_t)));
     }
-    // back-pointer scratch: one region per distinct DP kernel variant, so that
-    // launch groups of one chunk never share words (their fills and tracebacks may then be issued in any order)
-    const std::vector<Variant> &uvar = c->uvar;
-    std::vector<size_t> uoff;
-    size_t bp_words = 0;
-    for (auto &v : uvar) {
-        uoff.push_back(bp_words);
-        bp_words += align_up(v.bp_words(S1, R1), 64);
+    // back-pointer scratch: the reads of a chunk lie back to back in one region, each with the rows its own kernel variant
+    // writes (h_bpoff: 64-bit words from the region's start) -- launch groups of a chunk never share words, their fills and
+    // tracebacks may be issued in any order, and a handle with many variants (mixed loci) needs no more than its reads do.
+    // The tracebacks fetch whole blocks of rows and may look past a read's last row: the region ends with slack for that.
+    constexpr size_t kBpSlackWords = 4096;
+    size_t bp_words64 = 0;
+    for (auto &ch : chunks) {
+        size_t at = 0;
+        for (int64_t r = ch.first; r < ch.first + ch.count; r++) {
+            h_bpoff[r] = (int64_t)at;
+            at += c->variant[io.aut_id[r]].bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
+        }
+        bp_words64 = std::max(bp_words64, at + kBpSlackWords);
     }
-    auto bp_offset = [&](const Variant &v) -> size_t {
-        for (size_t u = 0; u < uvar.size(); u++)
-            if (uvar[u].same(v)) return uoff[u];
-        return 0;
-    };
-    for (int k = 0; k < n_sized; k++) HIPCHK(c->work[sized_set(k)].bp.ensure(bp_words * 4));
+    HIPCHK(hipMemcpyAsync(d_bpoff, h_bpoff, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    for (int k = 0; k < n_sized; k++) HIPCHK(c->work[sized_set(k)].bp.ensure(bp_words64 * 8));
     for (int k = 0; k < n_work && host; k++) {
         const int w = wset(k);
         HIPCHK(c->work[w].stage_sig.ensure(S1 * 8));
@@ -1284,6 +1343,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         pa.first_read = (int32_t)f;
         pa.base_off = boff;
         pa.bp = (uint32_t *)W.bp.p;
+        pa.bp_off = d_bpoff + f;
         pa.run_state = d_run_state;
         pa.run_start = d_run_start;
         pa.n_runs = x.d_nruns;
@@ -1335,7 +1395,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         for (size_t g = 0; g < x.groups.size(); g++) {
             PassArgs pa = x.pa;
             pa.signal = sigp;
-            pa.bp += bp_offset(x.gvar[g]);
             pa.order = d_order + x.gpos[g];
             pa.n_launch = (int32_t)x.groups[g].size();
             pa.maskbits = maskbits;
@@ -1355,7 +1414,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     auto do_traceback = [&](Ctx &x, const uint32_t *maskbits, uint16_t *trace, int32_t *status, hipStream_t s) -> int {
         for (size_t g = 0; g < x.groups.size(); g++) {
             PassArgs pa = x.pa;
-            pa.bp += bp_offset(x.gvar[g]);
             pa.order = d_order + x.gpos[g];
             pa.n_launch = (int32_t)x.groups[g].size();
             pa.maskbits = maskbits;

@@ -82,6 +82,7 @@ struct PassArgs {
     int64_t base_off;
     const uint32_t *maskbits;  // packed mask (NULL = unmasked pass)
     uint32_t *bp;              // back-pointer scratch
+    const int64_t *bp_off;     // per read of the chunk (index lr): where its back-pointer rows start, in 64-bit words
     uint16_t *run_state;       // runs, in reverse time order
     int32_t *run_start;
     int32_t *n_runs;           // per read
