@@ -525,6 +525,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true',
                     help='the default single-GPU headline run also times cfg1, cfg5 and the path from raw int16 segments '
                          '(reported under "secondary"); this switch leaves them out')
+    ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
+                    help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
@@ -597,7 +599,8 @@ def main():
     n = wl.n
     n_pad = (n_total + world - 1) // world if strong else n  # all_gather_into_tensor wants equal shards
     stream = torch.cuda.current_stream().cuda_stream
-    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream)  # the library's defaults: no workspace limit, no knob
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream,  # the library's defaults unless asked otherwise
+                    workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None)
     # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
     # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
     res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]

@@ -29,7 +29,7 @@ for name, pat in LOCI:
     aut = np.array([int(base[i][1]) for i in pick], np.int32)
     off = np.arange(n + 1, dtype=np.int64) * T
     res = [torch.zeros((n, 56), dtype=torch.uint8, device=dev) for _ in range(2)]
-    hip = HipCaller([loc.template, loc.reverse], [fl, fl], stream=torch.cuda.current_stream().cuda_stream, workspace_limit=64 << 30)
+    hip = HipCaller([loc.template, loc.reverse], [fl, fl], stream=torch.cuda.current_stream().cuda_stream)
     hip.set_pipelined(True)
     for k in range(2):
         hip.call_device(sig.data_ptr(), off, aut, res[k & 1].data_ptr())

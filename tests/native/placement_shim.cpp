@@ -31,6 +31,13 @@ extern "C" int wsx_test_place_lane_major(int S, const int32_t *pred_ptr, const i
     return p.lm;
 }
 
+// the read-conflict cycles per row the placement code itself counts for its last lane-major result (0 = none left)
+extern "C" int wsx_test_lane_conflicts(int S, const int32_t *pred_ptr, const int32_t *pred_idx, int K, int stacked)
+{
+    const WsxLanePlacement p = stacked ? wsx_place_lane_stacked(S, pred_ptr, pred_idx, K) : wsx_place_lane_major(S, pred_ptr, pred_idx, K);
+    return p.lm == 0 ? -1 : p.pl.conflict_cycles;
+}
+
 extern "C" int wsx_test_place_lane_stacked(int S, const int32_t *pred_ptr, const int32_t *pred_idx, int K, uint16_t *pos,
                                            uint16_t *state_at, int *lanes, uint64_t *stack_mask)
 {

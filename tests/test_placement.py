@@ -264,3 +264,81 @@ def test_stacked_lane_major_on_random_loci(shim):
                 check_lane_stacked(t, K, pos, sa, mask)
     assert fits >= 20
 
+
+
+def model_lane_read_conflicts(t, K, pos, sa, mask, stacked):
+    """Extra ds_read_b64 passes per row of a lane-major placement, by the rule of model_conflicts: position (slot k, lane l)
+    exports to LDS slot k*64 + l, so a read's bank pair is the predecessor's LANE modulo 32.  LDS is read by the slot-0
+    states (one instruction per candidate) and, in the stacked layout, by the first state of an upper piece (slot 2 of the
+    lanes of the stack mask: one more instruction); per instruction and half of the wavefront the largest number of distinct
+    slots on one bank pair, minus one."""
+    F = max(2, int(np.diff(t.pred_ptr).max()))
+    total = 0
+    for k, cands in [(0, range(F))] + ([(2, [0])] if stacked else []):
+        for f in cands:
+            for g in range(2):
+                on = {}
+                for lane in range(g * 32, g * 32 + 32):
+                    j = int(sa[k * 64 + lane])
+                    if j == 0xFFFF or (k == 2 and not (mask >> lane) & 1):
+                        continue
+                    inc = t.incoming(j)
+                    if len(inc) > f:
+                        p = int(pos[inc[f]])
+                        on.setdefault(p & 31, set()).add(p)
+                total += max([len(v) for v in on.values()] or [1]) - 1
+    return total
+
+
+@pytest.mark.parametrize('pattern', ['(AAAT)', '(AGC)AACAGCCGCCAC(CGC)', '((CAGG){CAGM})(CAGA)(CA)', '(AGC)', '(GGCCCC)', '(CCTG)(TCTG)',
+                                     '(AAGGG)(AAAGG)'])
+def test_lane_major_layouts_of_the_flank_110_loci_read_lds_without_bank_conflicts(shim, pattern):
+    """Upstream's own loci at the default flank (HD and DM2 of example/config.yaml among them; their stacked layouts ran 3
+    conflict cycles per row in round 3, profiles/r03_real_loci_pmc.log): whichever lane-major layout the caller takes -- the
+    plain one where it fits, else the stacked one -- its lanes are chosen so that no LDS read has a bank conflict, by this
+    file's own model; and the count the placement code reports is the model's."""
+    locus = synth.make_locus(pattern, 110, 7)
+    p = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data_as(C.c_void_p)
+    for t in (locus.template, locus.reverse):
+        K = (t.n_states + 63) // 64
+        lm, pos, sa, lanes = place_lane_major(shim, t, K)
+        if lm:
+            check_lane_major(t, K, lm, pos, sa)
+            assert model_lane_read_conflicts(t, K, pos, sa, 0, False) == 0, (pattern, t.n_states)
+            assert shim.wsx_test_lane_conflicts(t.n_states, p(t.pred_ptr), p(t.pred_idx), K, 0) == 0
+        else:
+            lm4, pos, sa, lanes, mask = place_lane_stacked(shim, t, K)
+            if lm4 == 0:  # DM2's 254-state strand fits neither way in four slots: it keeps the slot-major kernel
+                assert pattern.startswith('((CAGG)') and K == 4
+                continue
+            check_lane_stacked(t, K, pos, sa, mask)
+            assert model_lane_read_conflicts(t, K, pos, sa, mask, True) == 0, (pattern, t.n_states)
+            assert shim.wsx_test_lane_conflicts(t.n_states, p(t.pred_ptr), p(t.pred_idx), K, 1) == 0
+
+
+def test_lane_conflict_count_is_the_models_on_random_loci(shim):
+    rng = np.random.default_rng(21)
+    units = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA']
+    seen = free = 0
+    p = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data_as(C.c_void_p)
+    for it in range(60):
+        pat = ''.join('(' + units[int(rng.integers(len(units)))] + ')' + ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(0, 6))))
+                      for _ in range(int(rng.integers(1, 4))))
+        locus = synth.make_locus(pat, int(rng.integers(60, 150)), int(rng.integers(1 << 20)))
+        for t in (locus.template, locus.reverse):
+            K = (t.n_states + 63) // 64
+            if K < 3 or K > 5:
+                continue
+            lm, pos, sa, lanes = place_lane_major(shim, t, K)
+            if lm:
+                c = model_lane_read_conflicts(t, K, pos, sa, 0, False)
+                assert c == shim.wsx_test_lane_conflicts(t.n_states, p(t.pred_ptr), p(t.pred_idx), K, 0), pat
+                seen += 1
+                free += c == 0
+            lm4, pos, sa, lanes, mask = place_lane_stacked(shim, t, K) if K >= 4 else (0, 0, 0, 0, 0)
+            if lm4:
+                c = model_lane_read_conflicts(t, K, pos, sa, mask, True)
+                assert c == shim.wsx_test_lane_conflicts(t.n_states, p(t.pred_ptr), p(t.pred_idx), K, 1), pat
+                seen += 1
+                free += c == 0
+    assert seen >= 40 and free >= seen * 3 // 4

@@ -1143,7 +1143,12 @@ hipError_t launch_fill_f(const PassArgs &a, int F, int FL, bool pk, int lm, cons
                 case 43: return launch_fill<M, K, 4, 1, false, 3>(a, tun, s);
                 }
             }
-            if constexpr (K >= 5) { // stacked placement: five slots only (four: measured slower than slot-major, wsx_api.hip)
+#ifdef WSX_EXPERIMENT
+            constexpr int kStackedMinK = 4; // (experiment builds: the four-slot stacked variants too, WSX_STACKED_MIN_K=4)
+#else
+            constexpr int kStackedMinK = 5;
+#endif
+            if constexpr (K >= kStackedMinK) { // stacked placement: five slots only (four: measured slower than slot-major, wsx_api.hip)
                 switch (F * 10 + lm) {
                 case 24: return launch_fill<M, K, 2, 1, false, 4>(a, tun, s);
                 case 34: return launch_fill<M, K, 3, 1, false, 4>(a, tun, s);

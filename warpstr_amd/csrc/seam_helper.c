@@ -98,3 +98,46 @@ int64_t wsx_seam_vbz_decode_i16(const uint8_t *svb, int64_t n_bytes, int64_t n, 
     }
     return 0;
 }
+
+// ---- multi-GPU host path (warpstr_amd/dist.py) ------------------------------------------------------------------------
+// Longest-processing-time partition: items in the given order (descending work), each to the rank with the smallest load so
+// far, the LOWEST rank among equals -- the same rule, and the same floating-point sums in the same order, as the NumPy loop
+// in dist.shard_reads, so every rank derives the same partition whichever of the two it runs.  owner[order[i]] = rank.
+void wsx_seam_lpt(const double *work, const int64_t *order, int64_t n, int32_t world, int64_t *owner)
+{
+    double load[1024];
+    if (world > 1024) world = 1024;
+    for (int r = 0; r < world; r++) load[r] = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        int best = 0;
+        for (int r = 1; r < world; r++)
+            if (load[r] < load[best]) best = r;
+        owner[order[i]] = best;
+        load[best] += work[order[i]];
+    }
+}
+
+// Ragged pieces laid end to end: dst[total ..) = src[start[k] .. start[k] + len[k]) for k = 0..n-1.  Returns the bytes written.
+int64_t wsx_seam_gather_pieces(const uint8_t *src, const int64_t *start, const int64_t *len, int64_t n, uint8_t *dst)
+{
+    int64_t total = 0;
+    for (int64_t k = 0; k < n; k++) {
+        if (len[k] > 0) memcpy(dst + total, src + start[k], (size_t)len[k]);
+        total += len[k] > 0 ? len[k] : 0;
+    }
+    return total;
+}
+
+// ... and back: the k-th piece of src (pieces end to end, lengths len[idx[k]]) goes to dst[start[idx[k]] ..).  Returns the
+// bytes read.
+int64_t wsx_seam_scatter_pieces(const uint8_t *src, const int64_t *idx, int64_t n, const int64_t *start, const int64_t *len,
+                                uint8_t *dst)
+{
+    int64_t at = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t i = idx[k];
+        if (len[i] > 0) memcpy(dst + start[i], src + at, (size_t)len[i]);
+        at += len[i] > 0 ? len[i] : 0;
+    }
+    return at;
+}

@@ -535,7 +535,11 @@ try {
             // 20 000 reads x 3 000 samples, same box (profiles/r03_stacked_ab.log): DM2 17.0 -> 16.5 ms per call; with four
             // slots it LOSES to the slot-major kernel (HD, both strands: 12.1 vs 11.8 ms -- four exports and the extra read
             // load the LDS pipe as much as the slot-major exchange does), so four-slot automata keep that one.
-            if (lp.lm == 0 && lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K) && v.K >= 5 &&
+            const int stacked_min_k = [] {
+                const char *e = wsx_exp_env("WSX_STACKED_MIN_K");
+                return e ? atoi(e) : 5;
+            }();
+            if (lp.lm == 0 && lm_mode != 0 && wsx_lane_major_supported(c->prm.min_values_per_state, v.K) && v.K >= stacked_min_k &&
                 !wsx_exp_env("WSX_NO_STACKED"))
                 lp = wsx_place_lane_stacked(S, A.pred_ptr, A.pred_idx, v.K);
             if (lp.lm != 0) {

@@ -395,6 +395,7 @@ struct WsxLanePlacement {
     uint64_t stack_mask = 0; // lm = 4: lanes whose slot WSX_STACK_SLOT starts a piece of its own (one predecessor, through LDS)
 };
 constexpr int WSX_STACK_SLOT = 2;
+inline int wsx_spread_lanes(int S, const int32_t *pp, const int32_t *pi, int K, WsxLanePlacement &lp); // bank-aware lanes, below
 
 inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int32_t *pi, int K)
 {
@@ -504,8 +505,170 @@ inline WsxLanePlacement wsx_place_lane_major(int S, const int32_t *pp, const int
     }
     pl.identity = false;
     pl.low8 = false;
-    pl.conflict_cycles = 0; // (not modelled: this layout leaves the LDS pipe mostly idle)
+    wsx_spread_lanes(S, pp, pi, K, out); // which lane a column takes: the one that keeps the LDS reads free of bank conflicts
     return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Bank-aware lanes for the lane-major layouts.  Which LANE a column of states takes is free (a state above slot 0 finds its
+// predecessor in its own lane; what a slot-0 state -- or the first state of an upper piece, LM = 4 -- reads comes through
+// LDS by a per-lane address).  Position (slot k, lane l) exports to LDS slot k*64 + l, so the bank pair of a read is the
+// LANE of the predecessor modulo 32, and a ds_read_b64 serves a half of the wavefront in one pass if the predecessors its 32
+// lanes read sit in 32 different lanes modulo 32 (or in the very same slot).  Lanes handed out in order of the chains leave
+// 1-3 extra passes per row on loci with several loops (HD, DM2 at flank 110: 3.0 measured, profiles/r03_real_loci_pmc.log);
+// lane_major_read_conflicts counts them (the model of tests/test_placement.py), wsx_spread_lanes trades lanes -- whole
+// columns, empty ones included -- while a trade lowers the count.
+// ------------------------------------------------------------------------------------------------------------------
+namespace wsx_place_detail {
+
+struct LaneReads { // one entry per LDS read of a lane: which instruction (candidate f of slot 0, or F = the stack slot's), which position
+    std::vector<std::vector<std::pair<int, int>>> of_lane; // [lane] -> (instruction, predecessor position in the UNPERMUTED layout)
+    int n_instr = 0;
+};
+
+inline LaneReads lane_major_reads(int S, const int32_t *pp, const int32_t *pi, int K, const WsxPlacement &pl, uint64_t stack_mask,
+                                  int stack_slot)
+{
+    LaneReads r;
+    r.of_lane.resize(64);
+    int F = 1;
+    for (int j = 0; j < S; j++) F = std::max(F, fanin(pp, j));
+    r.n_instr = F + 1;
+    for (int l = 0; l < 64; l++) {
+        const int j0 = pl.state_at[l] == 0xFFFF ? -1 : pl.state_at[l];
+        if (j0 >= 0)
+            for (int f = 0; f < fanin(pp, j0); f++) r.of_lane[l].push_back({f, pl.pos[pi[pp[j0] + f]]});
+        if ((stack_mask >> l) & 1ull) {
+            const int js = pl.state_at[stack_slot * 64 + l] == 0xFFFF ? -1 : pl.state_at[stack_slot * 64 + l];
+            if (js >= 0 && fanin(pp, js) >= 1) r.of_lane[l].push_back({F, pl.pos[pi[pp[js]]]});
+        }
+    }
+    (void)K;
+    return r;
+}
+
+// extra passes per row with old lane l sitting in lane perm[l]
+inline int lane_major_read_conflicts(const LaneReads &r, const int *perm, int *excess_out = nullptr)
+{
+    int total = 0;
+    // slots[instr][half][bank]: up to a handful of distinct slots
+    static thread_local std::vector<int> seen;
+    seen.assign((size_t)r.n_instr * 2 * 32 * 8, -1);
+    std::vector<int> cnt((size_t)r.n_instr * 2 * 32, 0);
+    for (int l = 0; l < 64; l++) {
+        const int half = perm[l] >> 5;
+        for (auto &rd : r.of_lane[l]) {
+            const int slot = (rd.second & ~63) | perm[rd.second & 63];
+            const size_t cell = ((size_t)rd.first * 2 + half) * 32 + (slot & 31);
+            int *sl = &seen[cell * 8];
+            bool dup = false;
+            for (int q = 0; q < cnt[cell] && q < 8; q++) dup = dup || sl[q] == slot;
+            if (!dup) {
+                if (cnt[cell] < 8) sl[cnt[cell]] = slot;
+                cnt[cell]++;
+            }
+        }
+    }
+    int excess = 0; // slots beyond the first on any bank pair: what the search goes down on a plateau of `total`
+    for (int i = 0; i < r.n_instr; i++)
+        for (int h = 0; h < 2; h++) {
+            int worst = 1;
+            for (int b = 0; b < 32; b++) {
+                const int n = cnt[((size_t)i * 2 + h) * 32 + b];
+                worst = std::max(worst, n);
+                excess += n > 1 ? n - 1 : 0;
+            }
+            total += worst - 1;
+        }
+    if (excess_out) *excess_out = excess;
+    return total;
+}
+
+} // namespace wsx_place_detail
+
+// Trades lanes of a lane-major placement (any lm) until no single trade lowers the modelled read conflicts; rewrites
+// pl.pos / pl.state_at / stack_mask.  Returns the conflict cycles per row that remain (pl.conflict_cycles).
+inline int wsx_spread_lanes(int S, const int32_t *pp, const int32_t *pi, int K, WsxLanePlacement &lp)
+{
+    using namespace wsx_place_detail;
+    if (lp.lm == 0) return 0;
+    WsxPlacement &pl = lp.pl;
+    const LaneReads reads = lane_major_reads(S, pp, pi, K, pl, lp.stack_mask, WSX_STACK_SLOT);
+    int perm[64];
+    std::iota(perm, perm + 64, 0);
+    int excess = 0;
+    int cost = lane_major_read_conflicts(reads, perm, &excess);
+    for (int pass = 0; pass < 12 && cost > 0; pass++) {
+        bool improved = false;
+        for (int a = 0; a < 64 && cost > 0; a++)
+            for (int b = a + 1; b < 64 && cost > 0; b++) {
+                std::swap(perm[a], perm[b]);
+                int ex = 0;
+                const int c = lane_major_read_conflicts(reads, perm, &ex);
+                if (c < cost || (c == cost && ex < excess)) {
+                    cost = c;
+                    excess = ex;
+                    improved = true;
+                } else {
+                    std::swap(perm[a], perm[b]);
+                }
+            }
+        if (!improved) break;
+    }
+    // Stuck above zero: single trades no longer help (two sources in one column read from the same half want their readers
+    // in different halves, which takes a trade that is neutral first).  A seeded walk over neutral trades, descending after
+    // each; the best permutation seen is kept.  Deterministic: every process places an automaton the same way.
+    if (cost > 0) {
+        int best_perm[64], best_cost = cost, best_excess = excess;
+        std::copy(perm, perm + 64, best_perm);
+        uint32_t rng = 0x9E3779B9u ^ (uint32_t)S;
+        auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        for (int step = 0; step < 600 && best_cost > 0; step++) {
+            const int a = (int)(next() % 64), b = (int)(next() % 64);
+            if (a == b) continue;
+            std::swap(perm[a], perm[b]);
+            int ex = 0;
+            int c = lane_major_read_conflicts(reads, perm, &ex);
+            if (c > cost || (c == cost && ex > excess + 1)) { // worse: undo
+                std::swap(perm[a], perm[b]);
+                continue;
+            }
+            cost = c;
+            excess = ex;
+            for (int x = 0; x < 64 && cost > 0; x++) // one descent over the trades of the two lanes that moved
+                for (int y : {a, b}) {
+                    if (x == y) continue;
+                    std::swap(perm[x], perm[y]);
+                    int ex2 = 0;
+                    const int c2 = lane_major_read_conflicts(reads, perm, &ex2);
+                    if (c2 < cost || (c2 == cost && ex2 < excess)) cost = c2, excess = ex2;
+                    else std::swap(perm[x], perm[y]);
+                }
+            if (cost < best_cost || (cost == best_cost && excess < best_excess)) {
+                best_cost = cost;
+                best_excess = excess;
+                std::copy(perm, perm + 64, best_perm);
+            }
+        }
+        std::copy(best_perm, best_perm + 64, perm);
+        cost = best_cost;
+    }
+    bool moved = false;
+    for (int l = 0; l < 64; l++) moved = moved || perm[l] != l;
+    if (moved) {
+        std::vector<uint16_t> at((size_t)K * 64, 0xFFFF);
+        for (int k = 0; k < K; k++)
+            for (int l = 0; l < 64; l++) at[k * 64 + perm[l]] = pl.state_at[k * 64 + l];
+        pl.state_at = at;
+        for (int q = 0; q < K * 64; q++)
+            if (at[q] != 0xFFFF) pl.pos[at[q]] = (uint16_t)q;
+        uint64_t m = 0;
+        for (int l = 0; l < 64; l++)
+            if ((lp.stack_mask >> l) & 1ull) m |= 1ull << perm[l];
+        lp.stack_mask = m;
+    }
+    pl.conflict_cycles = cost;
+    return cost;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -604,6 +767,6 @@ inline WsxLanePlacement wsx_place_lane_stacked(int S, const int32_t *pp, const i
     }
     pl.identity = false;
     pl.low8 = false;
-    pl.conflict_cycles = 0;
+    wsx_spread_lanes(S, pp, pi, K, out); // which lane a column takes: the one that keeps the LDS reads free of bank conflicts
     return out;
 }
