@@ -511,6 +511,46 @@ def cfg5_driver_leg(reads_per_locus, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def generated_fill_leg(wl, local, device, steps, warmup, builtin_records):
+    """The headline workload with the fill GENERATED per automaton and compiled at run time (warpstr_amd/fillgen.py; round 2's
+    "read in four lanes" experiment as a product path: ragged lengths, corner cut, masks, its own traceback).  Same clock rules
+    as the headline; its records must equal the built-in kernels' byte for byte."""
+    import torch
+
+    from warpstr_amd import _lib
+    from warpstr_amd.caller import HipCaller
+    n = wl.n
+    t0 = time.perf_counter()
+    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=torch.cuda.current_stream().cuda_stream, generated_fill=True)
+    setup_s = time.perf_counter() - t0
+    got = {a: v for a, v in hip.generated.items()}
+    if not got or not all(isinstance(v, dict) for v in got.values()):
+        hip.close()
+        return {'skipped': f'no generated fill: {got}'}
+    res = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+    hip.set_pipelined(True)
+    for k in range(warmup):
+        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
+    hip.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
+    hip.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec = res[(steps - 1) % N_BUF].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+    out = {'ms_per_step': dt / steps * 1e3, 'value': n * steps / dt, 'unit': 'reads/s', 'steps': steps,
+           'kernels': sorted({hip.kernel_name(a) for a in range(len(wl.tables))}), 'handle_setup_s': setup_s,
+           'automata': {str(a): v for a, v in got.items()},
+           'identical_to_builtin': bool(rec.tobytes() == np.ascontiguousarray(builtin_records).tobytes()),
+           'note': 'opt-in (HipCaller(generated_fill=True)); per round of 32 768 reads 1.44 ms unmasked / 2.05 ms masked against '
+                   '1.67 / 1.69 ms of dtw_fill_fast (profiles/r04_generated_fill_variants.log): the mask select per state and the '
+                   '16-reads-per-wave granularity cost what the missing predecessor exchange saves'}
+    hip.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -527,6 +567,10 @@ def main():
                          '(reported under "secondary"); this switch leaves them out')
     ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
                     help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
+    ap.add_argument('--generated-fill', action='store_true',
+                    help='automata of at most 64 states get their DP fill generated and compiled at run time (warpstr_amd/fillgen.py: '
+                         'a read in four lanes) instead of the built-in kernel; the default run times that variant as '
+                         'secondary.generated_fill')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
@@ -600,7 +644,8 @@ def main():
     n_pad = (n_total + world - 1) // world if strong else n  # all_gather_into_tensor wants equal shards
     stream = torch.cuda.current_stream().cuda_stream
     hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream,  # the library's defaults unless asked otherwise
-                    workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None)
+                    workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None,
+                    generated_fill=bool(args.generated_fill))
     # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
     # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
     res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
@@ -714,6 +759,9 @@ def main():
                                    f', {wl.desc}, both passes',
                        'name': wl.name, 'reads_per_gpu': n, 'reads_total': n_total, 'mean_samples_per_read': samples / n,
                        'states': S, 'called_ok': ok_all, 'workspace_limit_bytes': workspace['limit_bytes'],
+                       'fill': ({'kind': 'generated per automaton (warpstr_amd/fillgen.py), compiled at run time',
+                                 'automata': {str(k): v for k, v in hip.generated.items()}} if any(isinstance(v, dict) for v in hip.generated.values())
+                                else {'kind': 'built-in'}),
                        'chunk_plan': {'chunks_per_call': launches_total / args.steps / 2.0 / max(len(kernels), 1), 'streams': 4,
                                       'pipelined_calls_in_flight': 2 if n >= 32768 else 4},
                        'results_gather': ((f'{backend} all_gather of 56-B records per step' +
@@ -780,6 +828,7 @@ def main():
                     rc = 3
                     print(f"bench.py: secondary workload {name}: {leg['verified']['mismatches']} reads differ from the oracle", file=sys.stderr)
             out['secondary']['from_raw'] = out['from_raw']
+            out['secondary']['generated_fill'] = generated_fill_leg(wl, local, device, max(5, args.steps // 2), 3, mine)
             # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
             out['secondary']['cfg5']['through_driver'] = cfg5_driver_leg(6250, local)
             if args.many_loci > 0:

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 9
+#define WSX_ABI_VERSION 10
 
 /* function return codes */
 enum {
@@ -279,6 +279,32 @@ int wsx_caller_timing_window(wsx_caller *c, int32_t on);
  */
 int wsx_caller_fill_intervals(wsx_caller *c, double *begin_ms, double *end_ms, int32_t *reads, int32_t capacity,
                               int32_t *n_out);
+
+/*
+ * A DP fill generated for ONE automaton (warpstr_amd/fillgen.py writes the source -- a read in four lanes, straight-line code
+ * over the automaton's states, no predecessor exchange -- and compiles it at run time with hiprtc or `hipcc --genco`): the
+ * code object and the tables of its back-pointer layout.  Same arithmetic per cell as the built-in fills (upstream
+ * _calc_dtw_astates, src/caller/caller.py:198-245); automata of at most 64 states, min_values_per_state 4.
+ */
+typedef struct wsx_generated_fill {
+    int32_t abi;               /* 1 */
+    int32_t words_per_row;     /* 64-bit back-pointer words per row of a wavefront (16 reads); even */
+    int32_t states_per_lane;   /* n: position p = lane_in_quad * n + register, 4 n >= S */
+    int32_t end_position;      /* position of the automaton's end state */
+    const void *code;          /* gfx950 code object with kernels wsx_fill_t_u (unmasked pass) and wsx_fill_t_m (masked pass) */
+    uint64_t code_size;
+    const uint16_t *state_at;  /* [4 n] position -> state id, 0xFFFF = none */
+    const uint8_t *tb_n;       /* [4 n] candidates of the position's state */
+    const uint16_t *tb_word;   /* [4 n * 4] word of the row that holds candidate f's compare mask */
+    const uint16_t *tb_pred;   /* [4 n * 4] position of predecessor f */
+} wsx_generated_fill;
+
+/*
+ * Attach (g != NULL) or remove (g == NULL) the generated fill of automaton `automaton`: its reads then take that kernel and
+ * the traceback over its words instead of the built-in variant (wsx_caller_kernel_name: "wsx_fill_t_u").  Results are the
+ * same either way.  Host pointers; everything is copied.  Not while a call of the handle is in flight.
+ */
+int wsx_caller_set_generated_fill(wsx_caller *c, int32_t automaton, const wsx_generated_fill *g);
 
 /* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<4, 1, 2, 2>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);

@@ -182,9 +182,15 @@ class HipCaller:
     def __init__(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
                  device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None,
-                 reverse_flags: Optional[Sequence[bool]] = None):
+                 reverse_flags: Optional[Sequence[bool]] = None, generated_fill: Optional[bool] = None):
         """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
-        default: odd positions (template, reverse, template, reverse, ...)."""
+        default: odd positions (template, reverse, template, reverse, ...).
+        generated_fill: automata of at most 64 states (min_values_per_state 4) get a DP fill generated and compiled for
+        them (warpstr_amd/fillgen.py: a read in four lanes, no predecessor exchange; a few seconds per automaton the first
+        time, cached on disk afterwards: fillgen.cache_dir()).  True: generate and compile what is not cached; None (default):
+        only automata whose code object is already in the cache get theirs -- no compilation happens behind the caller's
+        back; False: built-in kernels only.  A failure to generate or compile leaves the built-in kernel in place
+        (`generated`: what each automaton got)."""
         self.lib = _lib.load()
         self.device = int(device)
         if self.lib.wsx_device_count() <= 0:
@@ -219,6 +225,45 @@ class HipCaller:
         self.max_states = max(t.n_states for t in self.automata)
         for knob, value in self.default_tuning.items():
             self.set_tuning(knob, value)
+        self.generated = {}
+        if os.environ.get('WARPSTR_GENERATED_FILL') in ('0', '1'):  # (deployment-wide override)
+            generated_fill = os.environ['WARPSTR_GENERATED_FILL'] == '1'
+        if generated_fill is not False and len(self.automata) <= 64:
+            for i in range(len(self.automata)):
+                self.generate_fill(i, compile_missing=generated_fill is True)
+
+    def generate_fill(self, automaton: int, compile_missing: bool = True) -> bool:
+        """Generate, compile and attach the straight-line fill of one automaton (fillgen.py); False (and the built-in kernel
+        stays) if the automaton is not of the kind it is written for, no compiler is there, or -- compile_missing=False --
+        its code object is not in the cache yet."""
+        from . import fillgen
+        t = self.automata[automaton]
+        if not fillgen.supported(t, self.caller_config.min_values_per_state):
+            return False
+        try:
+            gen = fillgen.generate(t, self.flank_lengths[automaton])
+            code, how = fillgen.compile_source(gen, compile_missing)
+        except Exception as e:  # noqa: BLE001 -- the built-in kernel computes the same
+            code, how = None, f'{type(e).__name__}: {e}'
+        if code is None:
+            self.generated[automaton] = how
+            return False
+        buf = C.create_string_buffer(code, len(code))
+        keep = [np.ascontiguousarray(gen.state_at, np.uint16), np.ascontiguousarray(gen.tb_n, np.uint8),
+                np.ascontiguousarray(gen.tb_word, np.uint16), np.ascontiguousarray(gen.tb_pred, np.uint16)]
+        g = _lib.WsxGeneratedFill(1, gen.words_per_row, gen.n_per_lane, gen.end_pos, C.cast(buf, C.c_void_p), len(code),
+                                  *[_lib.ptr(k) for k in keep])
+        rc = self.lib.wsx_caller_set_generated_fill(self.handle, automaton, C.byref(g))
+        if rc != 0:
+            self.generated[automaton] = _lib.last_error()
+            return False
+        self.generated[automaton] = {'compiled': how, 'words_per_row': gen.words_per_row, 'valu_per_wave_row': gen.valu_per_wave_row,
+                                     'key': gen.key}
+        return True
+
+    def drop_generated_fill(self, automaton: int):
+        _lib.check(self.lib.wsx_caller_set_generated_fill(self.handle, automaton, None), 'wsx_caller_set_generated_fill')
+        self.generated.pop(automaton, None)
 
     def set_tuning(self, knob: str, value: int):
         """wsx_caller_set_tuning: how the work is spread over launches, never what is computed (knobs: _lib.TUNING)."""

@@ -1255,6 +1255,13 @@ hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool 
 #endif
 }
 
+hipError_t wsx_launch_expand_trace(const PassArgs &a, hipStream_t s) // per-sample state ids from the run list (every traceback's epilogue)
+{
+    if (a.n_launch <= 0 || !a.trace) return hipSuccess;
+    hipLaunchKernelGGL(expand_trace_kernel, dim3((a.n_launch + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, const WsxTuning &tun, hipStream_t s)
 {
     if (a.n_launch <= 0) return hipSuccess;

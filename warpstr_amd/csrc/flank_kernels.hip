@@ -482,6 +482,11 @@ try {
     const int cpl = max_p <= 64 ? 1 : (max_p <= 128 ? 2 : 4);
     const int max_rows = max_p + (scores->match * max_p) / (-scores->gap_open) + 2;
     const size_t lds = (size_t)(max_rows + 1) * 64 * 2; // directions + tie bits
+    if (lds > 64 * 1024) { // (a launch that asks for more fails with a generic error: say what it is instead)
+        wsx_internal_set_error("wsx_locate_flanks: the traceback window of the longest pattern does not fit 64 KB of LDS with these scores "
+                               "(rows = pattern + match * pattern / |gap| + 2; upstream's 2 / -3 scores need 171 rows per 100 bases)");
+        return WSX_ERR_UNSUPPORTED;
+    }
     const dim3 g1((unsigned)((n + 3) / 4)), g2((unsigned)n);
     switch (cpl) {
     case 1:

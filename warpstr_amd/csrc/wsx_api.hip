@@ -44,11 +44,14 @@ struct Variant { // which DP kernel an automaton uses
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
     int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot,
                      // 4 = every slot and two pieces to a lane (stacked)
+    int gen = 0;     // generated fill (wsx_caller_set_generated_fill): automaton index + 1 -- code of its own, a launch group of its own
+    int nwp = 0;     // ... its 64-bit back-pointer words per wave-row (16 reads)
     // back-pointer scratch of ONE read of T samples, in 64-bit words (even: a read's rows start 16-byte aligned):
     //   register-resident fill: per row F + (K-1)*FL 64-bit wave masks, one spare row (dtw_kernels.hip);
     //   packed rows: 18 words per 16 rows; generic fill: 4 bits per row and state, 8 rows per 32-bit word
     size_t bp_read_words(size_t T) const
     {
+        if (gen) return (T + 1) * (size_t)nwp; // (a WAVE of 16 reads: T = its longest read; run_batch)
         if (generic) return (T / 8 + 1) * (size_t)(K * 32);
         if (pk) return (T / 16 + 1) * 18;
         return (((T + 1) * (size_t)(F + (K - 1) * FL)) + 1) & ~(size_t)1;
@@ -56,11 +59,12 @@ struct Variant { // which DP kernel an automaton uses
     // upper bound, in 32-bit words, for a chunk of `samples` samples in `reads` reads that all took this variant
     size_t bp_words(size_t samples, size_t reads) const
     {
+        if (gen) return (samples / WSX_GEN_RPW + 4 * reads + 4096) * (size_t)nwp * 2;
         if (generic) return (samples / 8 + reads + 2) * (size_t)(K * 64);
         if (pk) return (samples / 16 + reads + 4) * 18 * 2;
         return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2 + 2 * reads;
     }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm && gen == o.gen; }
 };
 
 struct DeviceBuf {
@@ -253,6 +257,13 @@ struct wsx_caller {
     std::vector<int> n_states;
     std::vector<Variant> uvar; // the distinct kernel variants among `variant` (each has a back-pointer region of its own)
     WsxTuning tun;             // launch-policy knobs (wsx_caller_set_tuning)
+    struct GenFill {           // generated fill of one automaton (wsx_caller_set_generated_fill)
+        hipModule_t mod = nullptr;
+        hipFunction_t fn_u = nullptr, fn_m = nullptr; // unmasked pass, masked pass
+        void *tables = nullptr;                       // device copy of the traceback tables
+        Variant before;                               // the variant the automaton had (wsx_caller_set_generated_fill(.., NULL) restores it)
+    };
+    std::vector<GenFill> genfill; // per automaton
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30; // set from the device's free memory at creation (wsx_caller_set_workspace_limit overrides)
     // workspace
@@ -580,9 +591,18 @@ try {
                 for (int f = 0; f < WSX_MAX_F; f++)
                     for (int g = 0; g < 2; g++) {
                         int used[32] = {0};
+                        // (lane-major layouts: a state above slot 0 takes its predecessor from a register; in the stacked
+                        // layout the stack slot's ds_read_b64 is issued by EVERY lane, and the lanes that do not start a piece
+                        // there read the +inf slot -- their in-lane predecessor's export slot would sit on the bank pair of
+                        // their own lane and collide with what the piece heads read: 2 conflict cycles per row on DM2)
+                        auto reads_lds = [&](int l, int j) {
+                            if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f) return false;
+                            if (v.lm != 0 && k > 0) return v.lm == 4 && k == WSX_STACK_SLOT && ((P.stack_mask >> l) & 1ull) != 0;
+                            return true;
+                        };
                         for (int l = g * 32; l < g * 32 + 32; l++) {
                             const int j = state_of[k * 64 + l];
-                            if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f) continue;
+                            if (!reads_lds(l, j)) continue;
                             const int pa = wslot[pos[A.pred_idx[A.pred_ptr[j] + f]]];
                             paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)pa;
                             used[pa & 31]++;
@@ -592,8 +612,7 @@ try {
                             if (used[r] < used[best]) best = r;
                         for (int l = g * 32; l < g * 32 + 32; l++) {
                             const int j = state_of[k * 64 + l];
-                            if (j < 0 || A.pred_ptr[j + 1] - A.pred_ptr[j] <= f)
-                                paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)(v.K * 64 + best);
+                            if (!reads_lds(l, j)) paddr[((size_t)k * WSX_MAX_F + f) * 64 + l] = (uint16_t)(v.K * 64 + best);
                         }
                     }
         }
@@ -682,6 +701,7 @@ try {
         for (auto &u : c->uvar) seen = seen || u.same(v);
         if (!seen) c->uvar.push_back(v);
     }
+    c->genfill.resize(c->variant.size());
     // Workspace limit: what the device can give.  A fixed 16 GiB made a 100 000-read call of 2 kSample reads take eight
     // chunks instead of four (more, smaller chunks lose: the serial per-read stages last as long for 6 000 reads as for
     // 100 000); the handle only ever allocates what a call needs, the limit is an upper bound.
@@ -742,6 +762,10 @@ void wsx_caller_destroy(wsx_caller *c)
     if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
+    for (auto &g : c->genfill) {
+        if (g.mod) (void)hipModuleUnload(g.mod);
+        if (g.tables) (void)hipFree(g.tables);
+    }
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
@@ -799,6 +823,112 @@ int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value)
     return WSX_SUCCESS;
 }
 
+static void rebuild_unique_variants(wsx_caller *c)
+{
+    c->uvar.clear();
+    for (auto &v : c->variant) {
+        bool seen = false;
+        for (auto &u : c->uvar) seen = seen || u.same(v);
+        if (!seen) c->uvar.push_back(v);
+    }
+}
+
+int wsx_caller_set_generated_fill(wsx_caller *c, int32_t automaton, const wsx_generated_fill *g)
+try {
+    if (!c || automaton < 0 || automaton >= (int)c->variant.size()) {
+        g_err = "wsx_caller_set_generated_fill: bad handle or automaton index";
+        return WSX_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // no call of this handle is in flight while its kernels change
+    if (c->join_st) HIPCHK(hipStreamSynchronize(c->join_st));
+    if (c->genfill.size() < c->variant.size()) c->genfill.resize(c->variant.size());
+    wsx_caller::GenFill &G = c->genfill[automaton];
+    DevAutomaton &D = c->host_aut[automaton];
+    if (G.mod) { // replace / remove what was there
+        (void)hipModuleUnload(G.mod);
+        if (G.tables) (void)hipFree(G.tables);
+        c->variant[automaton] = G.before;
+        G = wsx_caller::GenFill{};
+        D.gen_state_at = nullptr;
+        D.gen_tb_n = nullptr;
+        D.gen_tb_word = D.gen_tb_pred = nullptr;
+        D.gen_nwp = D.gen_n = D.gen_end_pos = 0;
+    }
+    if (g) {
+        const int S = c->n_states[automaton];
+        const int P = 4 * g->states_per_lane;
+        if (g->abi != 1 || !g->code || g->code_size == 0 || c->prm.min_values_per_state != 4 || S > 64 || g->states_per_lane <= 0 ||
+            P < S || P > 64 || g->words_per_row < 2 || g->words_per_row > 32 || (g->words_per_row & 1) || g->end_position < 0 ||
+            g->end_position >= P || !g->state_at || !g->tb_n || !g->tb_word || !g->tb_pred) {
+            g_err = "wsx_caller_set_generated_fill: not a generated fill for this automaton (ABI 1, min_values_per_state 4, <= 64 states)";
+            return WSX_ERR_INVALID;
+        }
+        for (int p = 0; p < P; p++) { // the tables must stay inside the automaton and the row
+            if (g->tb_n[p] > WSX_MAX_F || (g->state_at[p] != 0xFFFF && g->state_at[p] >= S)) {
+                g_err = "wsx_caller_set_generated_fill: malformed tables";
+                return WSX_ERR_INVALID;
+            }
+            for (int f = 0; f < g->tb_n[p]; f++)
+                if (g->tb_word[p * WSX_MAX_F + f] >= g->words_per_row || g->tb_pred[p * WSX_MAX_F + f] >= P) {
+                    g_err = "wsx_caller_set_generated_fill: malformed tables";
+                    return WSX_ERR_INVALID;
+                }
+        }
+        if (g->state_at[g->end_position] != c->host_aut[automaton].endstate) {
+            g_err = "wsx_caller_set_generated_fill: the end position does not hold the automaton's end state";
+            return WSX_ERR_INVALID;
+        }
+        hipModule_t mod = nullptr;
+        if (hipModuleLoadData(&mod, g->code) != hipSuccess) {
+            g_err = "wsx_caller_set_generated_fill: the code object does not load on this device";
+            return WSX_ERR_UNSUPPORTED;
+        }
+        hipFunction_t fu = nullptr, fm = nullptr;
+        if (hipModuleGetFunction(&fu, mod, "wsx_fill_t_u") != hipSuccess || hipModuleGetFunction(&fm, mod, "wsx_fill_t_m") != hipSuccess) {
+            (void)hipModuleUnload(mod);
+            g_err = "wsx_caller_set_generated_fill: the code object lacks wsx_fill_t_u / wsx_fill_t_m";
+            return WSX_ERR_INVALID;
+        }
+        // tables: state_at u16[P] | tb_word u16[P*4] | tb_pred u16[P*4] | tb_n u8[P]
+        const size_t o_word = align_up((size_t)P * 2), o_pred = o_word + align_up((size_t)P * WSX_MAX_F * 2),
+                     o_n = o_pred + align_up((size_t)P * WSX_MAX_F * 2), total = o_n + align_up((size_t)P);
+        std::vector<char> h(total, 0);
+        memcpy(h.data(), g->state_at, (size_t)P * 2);
+        memcpy(h.data() + o_word, g->tb_word, (size_t)P * WSX_MAX_F * 2);
+        memcpy(h.data() + o_pred, g->tb_pred, (size_t)P * WSX_MAX_F * 2);
+        memcpy(h.data() + o_n, g->tb_n, (size_t)P);
+        void *dt = nullptr;
+        if (hipMalloc(&dt, total) != hipSuccess || hipMemcpy(dt, h.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+            if (dt) (void)hipFree(dt);
+            (void)hipModuleUnload(mod);
+            g_err = "wsx_caller_set_generated_fill: out of device memory";
+            return WSX_ERR_NOMEM;
+        }
+        G.mod = mod;
+        G.fn_u = fu;
+        G.fn_m = fm;
+        G.tables = dt;
+        G.before = c->variant[automaton];
+        D.gen_state_at = (const uint16_t *)dt;
+        D.gen_tb_word = (const uint16_t *)((char *)dt + o_word);
+        D.gen_tb_pred = (const uint16_t *)((char *)dt + o_pred);
+        D.gen_tb_n = (const uint8_t *)((char *)dt + o_n);
+        D.gen_nwp = g->words_per_row;
+        D.gen_n = g->states_per_lane;
+        D.gen_end_pos = g->end_position;
+        Variant v = G.before;
+        v.gen = automaton + 1;
+        v.nwp = g->words_per_row;
+        c->variant[automaton] = v;
+    }
+    HIPCHK(hipMemcpy((char *)c->aut_table.p + sizeof(DevAutomaton) * automaton, &D, sizeof(DevAutomaton), hipMemcpyHostToDevice));
+    rebuild_unique_variants(c);
+    return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
+}
+
 int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams)
 {
     if (!c || n_streams < 1 || n_streams > WSX_MAX_STREAMS) return WSX_ERR_INVALID;
@@ -851,6 +981,7 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
+    if (v.gen) return "wsx_fill_t_u";
     return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.pk, v.lm, v.generic);
 }
 
@@ -1161,13 +1292,51 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // writes (h_bpoff: 64-bit words from the region's start) -- launch groups of a chunk never share words, their fills and
     // tracebacks may be issued in any order, and a handle with many variants (mixed loci) needs no more than its reads do.
     // The tracebacks fetch whole blocks of rows and may look past a read's last row: the region ends with slack for that.
+    // Launch order of every chunk first (host only): reads grouped by kernel variant, longest first inside a group (load
+    // balance; the generated fills put 16 consecutive reads of their group into one wavefront, which share their rows).
+    struct Launches {
+        std::vector<std::vector<int32_t>> groups;
+        std::vector<Variant> gvar;
+        std::vector<size_t> gpos;
+    };
+    std::vector<Launches> launches(chunks.size());
     constexpr size_t kBpSlackWords = 4096;
     size_t bp_words64 = 0;
-    for (auto &ch : chunks) {
-        size_t at = 0;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const ChunkPlan &ch = chunks[ci];
+        Launches &L = launches[ci];
         for (int64_t r = ch.first; r < ch.first + ch.count; r++) {
-            h_bpoff[r] = (int64_t)at;
-            at += c->variant[io.aut_id[r]].bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
+            const Variant &v = c->variant[io.aut_id[r]];
+            size_t g = 0;
+            for (; g < L.gvar.size(); g++)
+                if (L.gvar[g].same(v)) break;
+            if (g == L.gvar.size()) {
+                L.gvar.push_back(v);
+                L.groups.emplace_back();
+            }
+            L.groups[g].push_back((int32_t)r);
+        }
+        size_t pos = (size_t)ch.first, at = 0;
+        for (size_t g = 0; g < L.groups.size(); g++) {
+            auto &grp = L.groups[g];
+            std::stable_sort(grp.begin(), grp.end(), [&](int32_t p, int32_t q) {
+                return (io.offsets[p + 1] - io.offsets[p]) > (io.offsets[q + 1] - io.offsets[q]);
+            });
+            L.gpos.push_back(pos);
+            std::copy(grp.begin(), grp.end(), h_order + pos);
+            pos += grp.size();
+            const Variant &v = L.gvar[g];
+            if (v.gen) { // a wavefront's 16 reads share the rows of its longest (= first) read
+                for (size_t w0 = 0; w0 < grp.size(); w0 += WSX_GEN_RPW) {
+                    for (size_t e = w0; e < std::min(grp.size(), w0 + WSX_GEN_RPW); e++) h_bpoff[grp[e]] = (int64_t)at;
+                    at += v.bp_read_words((size_t)(io.offsets[grp[w0] + 1] - io.offsets[grp[w0]]));
+                }
+            } else {
+                for (int32_t r : grp) {
+                    h_bpoff[r] = (int64_t)at;
+                    at += v.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
+                }
+            }
         }
         bp_words64 = std::max(bp_words64, at + kBpSlackWords);
     }
@@ -1316,27 +1485,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             }
         }
 
-        // launch order of this chunk: group by kernel variant, longest first (load balance)
-        for (int64_t r = f; r < f + cnt; r++) {
-            const Variant &v = c->variant[io.aut_id[r]];
-            size_t g = 0;
-            for (; g < x.gvar.size(); g++)
-                if (x.gvar[g].same(v)) break;
-            if (g == x.gvar.size()) {
-                x.gvar.push_back(v);
-                x.groups.emplace_back();
-            }
-            x.groups[g].push_back((int32_t)r);
-        }
-        size_t pos = (size_t)f;
-        for (auto &g : x.groups) {
-            std::stable_sort(g.begin(), g.end(), [&](int32_t p, int32_t q) {
-                return (io.offsets[p + 1] - io.offsets[p]) > (io.offsets[q + 1] - io.offsets[q]);
-            });
-            x.gpos.push_back(pos);
-            std::copy(g.begin(), g.end(), order + pos);
-            pos += g.size();
-        }
+        // launch order of this chunk (built above): group by kernel variant, longest first
+        x.groups = std::move(launches[ci].groups);
+        x.gvar = std::move(launches[ci].gvar);
+        x.gpos = std::move(launches[ci].gpos);
         HIPCHK(hipMemcpyAsync(d_order + f, order + f, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
 
         PassArgs &pa = x.pa;
@@ -1410,7 +1562,31 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, c->tun, s));
+            if (x.gvar[g].gen) { // the automaton's own generated code (fillgen.py), 16 reads per wavefront
+                const int aidx = x.gvar[g].gen - 1;
+                GenFillArgs ga{};
+                ga.signal = pa.signal;
+                ga.offsets = pa.offsets;
+                ga.order = pa.order;
+                ga.bp_off = pa.bp_off;
+                ga.bp = (uint64_t *)pa.bp;
+                ga.maskbits = pa.maskbits;
+                ga.end_cost = pa.end_cost;
+                ga.last_row = pa.last_row;
+                ga.status = pa.status;
+                ga.base_off = pa.base_off;
+                ga.n_launch = pa.n_launch;
+                ga.first_read = pa.first_read;
+                ga.last_row_stride = pa.last_row_stride;
+                ga.check_status = pa.check_status;
+                ga.boundary = c->host_aut[aidx].flank_length - 10;
+                void *params[] = {&ga};
+                const unsigned waves = (unsigned)((pa.n_launch + WSX_GEN_RPW - 1) / WSX_GEN_RPW);
+                HIPCHK(hipModuleLaunchKernel(maskbits ? c->genfill[aidx].fn_m : c->genfill[aidx].fn_u, waves, 1, 1, 64, 1, 1, 0, s, params,
+                                             nullptr));
+            } else {
+                HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, c->tun, s));
+            }
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;
@@ -1424,7 +1600,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.trace = trace;
             pa.status = status;
             pa.lane_major = x.gvar[g].lm != 0;
-            HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, c->tun, s));
+            if (x.gvar[g].gen) HIPCHK(wsx_launch_traceback_t(pa, x.gvar[g].nwp, c->host_aut[x.gvar[g].gen - 1].gen_n, s));
+            else HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, c->tun, s));
         }
         return WSX_SUCCESS;
     };

@@ -14,6 +14,11 @@ import numpy as np
 # 1..5 slots, the mean over the layouts a slot count can get).  Beyond five slots the general kernel runs (LDS ring, one
 # wave per read); its cost per slot was measured once (S = 665: ~6x a register-resident slot).
 SLOT_COST = {1: 1.0, 2: 1.54, 3: 2.0, 4: 2.57, 5: 3.35}
+# The ratios hold at other read lengths (profiles/r04_staircase_T.log, 20 000 reads per call: 1 : 1.44 : 1.89 : 2.51 at 1 000
+# samples, 1 : 1.40 : 1.89 : 2.43 : 3.22 at 3 000, 1 : 1.61 : 2.16 : 2.75 : 3.55 at 5 000), but a read also costs something that
+# does not grow with its length (the per-read stages: fit, borders, sort): a one-slot call takes 1.98 / 3.3 / 4.67 / 6.65 ms at
+# 1 000 / 2 000 / 3 000 / 5 000 samples -- a + b T with a / b = 700 samples.  Work of a read = (samples + 700) x slot cost.
+READ_OVERHEAD_SAMPLES = 700
 
 
 def slot_cost(n_states: int) -> float:

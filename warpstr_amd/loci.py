@@ -165,7 +165,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     span = (hi - lo + 1).clip(min=1)
     n_states = np.array([s.n_states for j in jobs for s in (j.temp_sta, j.rev_sta)])
     if collective:
-        shards = wdist.shard_reads(span, world, np.array([wdist.slot_cost(s) for s in n_states])[aut])
+        shards = wdist.shard_reads(span + wdist.READ_OVERHEAD_SAMPLES, world, np.array([wdist.slot_cost(s) for s in n_states])[aut])
     else:
         shards = [np.arange(n_total)]
     mine = shards[rank]
