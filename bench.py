@@ -426,8 +426,12 @@ def make_locus_dirs(root, specs, reads_per_locus, seed):
 
 def _driver_timings(tm, n_loci):
     per = lambda k: tm.get(k, 0.0) / max(n_loci, 1) * 1e3
-    return {'wall_s': tm['total_s'],
-            'per_locus_ms': {'overview_csv': per('overview_s'), 'automaton_compile': per('automata_s'), 'outputs': per('store_s')},
+    pooled = tm.get('host_processes', 1) > 1
+    return {'wall_s': tm['total_s'], 'host_processes': tm.get('host_processes', 1),
+            # CPU time per locus (summed over the worker processes when there are several), and the wall-clock of the two phases
+            'per_locus_ms': {'overview_csv': per('overview_s_cpu' if pooled else 'overview_s'),
+                             'automaton_compile': per('automata_s_cpu' if pooled else 'automata_s'),
+                             'outputs_wall': per('store_s'), 'setup_wall': per('setup_wall_s') if pooled else per('overview_s') + per('automata_s')},
             'once_s': {'handle_create_placement': tm['handle_s']},
             'batches_s': {'host_reads': tm['read_s'], 'submit': tm['submit_s'], 'wait_for_gpu': tm['collect_s']},
             'workspace_bytes': tm.get('workspace_bytes'), 'workspace_limit_bytes': tm.get('workspace_limit_bytes'),
@@ -458,7 +462,8 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
         warm_loci, _ = make_locus_dirs(os.path.join(root, 'warm'), specs[:10], reads_per_locus, 77)
         main_wrapper_loci(warm_loci, 1, raw_reader=reader, device=local, quiet=True)
         tm = {}
-        main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True, timings=tm)
+        workers = min(16, os.cpu_count() or 1)
+        main_wrapper_loci(loci, workers, raw_reader=reader, device=local, quiet=True, timings=tm)
         n_reads = n_loci * reads_per_locus
         out = {'workload': f'{n_loci} loci x {reads_per_locus} reads, flank 110, {len(MANY_LOCI_PATTERNS)} patterns '
                            f'({", ".join(MANY_LOCI_PATTERNS[:3])}, ...), T in [2271, 3701], raw int16 reads in host memory -> output files',

@@ -219,3 +219,23 @@ def test_one_rank_failing_read_raises(tmp_path):
     loci, sig = _make_loci(str(tmp_path / 'a'), poison='L0_read001')
     with pytest.raises(ReadCallError, match='L0_read001'):
         main_wrapper_loci(loci, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+
+
+def test_worker_processes_for_the_per_locus_host_work(tmp_path):
+    """threads > 1 from 64 loci on: overviews / automata / output files on spawned worker processes -- the same files as one
+    process writes."""
+    global LOCI
+    saved = LOCI
+    try:
+        LOCI = [(p, fl, 2 + (i % 3)) for i, (p, fl) in enumerate([('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)] * 17)]
+        a, sig = _make_loci(str(tmp_path / 'a'))
+        b, _ = _make_loci(str(tmp_path / 'b'))
+    finally:
+        LOCI = saved
+    tm = {}
+    main_wrapper_loci(a, 3, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, timings=tm)
+    main_wrapper_loci(b, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+    assert tm['host_processes'] == 3 and tm['n_loci'] == 68
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel

@@ -185,12 +185,11 @@ class HipCaller:
                  reverse_flags: Optional[Sequence[bool]] = None, generated_fill: Optional[bool] = None):
         """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
         default: odd positions (template, reverse, template, reverse, ...).
-        generated_fill: automata of at most 64 states (min_values_per_state 4) get a DP fill generated and compiled for
+        generated_fill: True = automata of at most 64 states (min_values_per_state 4) get a DP fill generated and compiled for
         them (warpstr_amd/fillgen.py: a read in four lanes, no predecessor exchange; a few seconds per automaton the first
-        time, cached on disk afterwards: fillgen.cache_dir()).  True: generate and compile what is not cached; None (default):
-        only automata whose code object is already in the cache get theirs -- no compilation happens behind the caller's
-        back; False: built-in kernels only.  A failure to generate or compile leaves the built-in kernel in place
-        (`generated`: what each automaton got)."""
+        time, cached on disk afterwards: fillgen.cache_dir()).  Opt-in: measured slower than the built-in kernel in the
+        pipelined step; WARPSTR_GENERATED_FILL=1 turns it on for every handle of a process.  A failure
+        to generate or compile leaves the built-in kernel in place (`generated`: what each automaton got)."""
         self.lib = _lib.load()
         self.device = int(device)
         if self.lib.wsx_device_count() <= 0:
@@ -226,11 +225,11 @@ class HipCaller:
         for knob, value in self.default_tuning.items():
             self.set_tuning(knob, value)
         self.generated = {}
-        if os.environ.get('WARPSTR_GENERATED_FILL') in ('0', '1'):  # (deployment-wide override)
-            generated_fill = os.environ['WARPSTR_GENERATED_FILL'] == '1'
-        if generated_fill is not False and len(self.automata) <= 64:
+        if generated_fill is None:
+            generated_fill = os.environ.get('WARPSTR_GENERATED_FILL') == '1'
+        if generated_fill and len(self.automata) <= 64:
             for i in range(len(self.automata)):
-                self.generate_fill(i, compile_missing=generated_fill is True)
+                self.generate_fill(i)
 
     def generate_fill(self, automaton: int, compile_missing: bool = True) -> bool:
         """Generate, compile and attach the straight-line fill of one automaton (fillgen.py); False (and the built-in kernel

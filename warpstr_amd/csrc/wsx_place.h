@@ -43,34 +43,49 @@ inline int fanin(const int32_t *pp, int j) { return pp[j + 1] - pp[j]; }
 inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, const std::vector<uint16_t> &pos,
                            const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot)
 {
+    // (no heap in here: the repair pass of wsx_place_attempt calls this thousands of times per automaton, and a handle for all
+    // loci of a run places thousands of automata)
+    struct Banks {
+        int slot[32][8];
+        int n[32];
+        void clear(int nb) { for (int b = 0; b < nb; b++) n[b] = 0; }
+        void add(int bank, int s)
+        {
+            for (int q = 0; q < n[bank] && q < 8; q++)
+                if (slot[bank][q] == s) return;
+            if (n[bank] < 8) slot[bank][n[bank]] = s;
+            n[bank]++;
+        }
+        int worst(int nb) const
+        {
+            int w = 1;
+            for (int b = 0; b < nb; b++) w = n[b] > w ? n[b] : w;
+            return w;
+        }
+    } on;
     int total = 0;
     for (int k = 0; k < K; k++) {
         for (int q = 0; q < 4; q++) { // writes: 16 lanes at a time, slots distinct modulo 16 (idle lanes write as well)
-            std::vector<std::vector<int>> on(16);
+            on.clear(16);
             for (int l = q * 16; l < q * 16 + 16; l++) {
                 const int slot = wslot[k * 64 + l];
-                auto &v = on[slot & 15];
-                if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+                on.add(slot & 15, slot);
             }
-            size_t worst = 1;
-            for (auto &v : on) worst = std::max(worst, v.size());
-            total += (int)worst - 1;
+            total += on.worst(16) - 1;
         }
         for (int g = 0; g < 2; g++)
             for (int f = 0; f < (k == 0 ? F : FL); f++) { // reads: 32 lanes at a time, slots distinct modulo 32
-                std::vector<std::vector<int>> on(32);
+                on.clear(32);
                 for (int l = g * 32; l < g * 32 + 32; l++) {
                     const int j = state_at[k * 64 + l] == 0xFFFF ? -1 : state_at[k * 64 + l];
                     if (j < 0 || fanin(pp, j) <= f) continue;
                     const int slot = wslot[pos[pi[pp[j] + f]]];
-                    auto &v = on[slot & 31];
-                    if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+                    on.add(slot & 31, slot);
                 }
-                size_t worst = 1;
-                for (auto &v : on) worst = std::max(worst, v.size());
-                total += (int)worst - 1;
+                total += on.worst(32) - 1;
             }
     }
+    (void)S;
     return total;
 }
 

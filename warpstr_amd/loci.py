@@ -102,12 +102,67 @@ def _similarity(job: LocusJob, caller_config: CallerConfig, pore_model, write: b
     cw.check_high_similarity(job.sequence)
 
 
-def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
-                      rescaler_config: Optional[RescalerConfig] = None,
-                      signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
-                      raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False,
-                      batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
-                      timings: Optional[Dict[str, float]] = None, quiet: bool = False, _engine=None):
+# ---- the per-locus host work on several processes (threads > 1) --------------------------------------------------------------
+# Upstream's `threads` are Pool workers over the READS of one locus (src/caller/wrapper.py:104-109).  Here the reads are the
+# GPU's; what is left on the host is per LOCUS -- parsing its overview, compiling two automata, writing its CSV and FASTA
+# files: 4-5 ms of Python and pandas each, thousands of times -- and that is what `threads` spreads: over worker PROCESSES
+# (spawned, so that they never share the parent's HIP state; they import pandas and this package's host modules only).
+def _setup_chunk(args):
+    loci, caller_config, write, quiet = args
+    from .pore_model import default_pore_model
+    pm = default_pore_model()
+    tm = {'overview_s': 0.0, 'automata_s': 0.0}
+    jobs = []
+    for locus in loci:
+        job = LocusJob(locus, pm, tm)
+        with _muted(quiet or not write):
+            _similarity(job, caller_config, pm, write=write)
+        jobs.append(job)
+    return jobs, tm
+
+
+def _store_chunk(args):
+    from .wrapper import _store_outputs
+    out = []
+    for (locus, overview_path, df_overview, names, reverse, rec, s1, s2, write, quiet) in args:
+        l1 = np.where(rec['status'] == 0, rec['len1'], 0).astype(np.int64)
+        l2 = np.where(rec['status'] == 0, rec['len2'], 0).astype(np.int64)
+        o1, o2 = np.cumsum(l1) - l1, np.cumsum(l2) - l2
+        results = CallerResults(names, rec, o1, s1, s2, 'raise', offsets2=o2)
+        with _muted(quiet or not write):
+            out.append(_store_outputs(locus, overview_path, df_overview, results, [bool(v) for v in reverse], write=write))
+    return out
+
+
+def _pool(threads: int, n_loci: int):
+    """A pool of worker processes for the per-locus host work, or None (few loci, one thread, or no way to start one)."""
+    if threads <= 1 or n_loci < 64:
+        return None
+    try:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        return ProcessPoolExecutor(max_workers=min(int(threads), os.cpu_count() or 1), mp_context=mp.get_context('spawn'))
+    except (ImportError, OSError, ValueError):
+        return None
+
+
+def main_wrapper_loci(loci: Sequence, threads: int = 1, **kwargs):
+    """Step 3 for every locus of `loci` through one handle: see _main_wrapper_loci (this wrapper owns the worker processes of
+    the per-locus host work, so that they end with the call however it ends)."""
+    pool = _pool(threads, len(loci))
+    try:
+        return _main_wrapper_loci(loci, threads, pool, **kwargs)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+
+
+def _main_wrapper_loci(loci: Sequence, threads: int, pool, *, caller_config: Optional[CallerConfig] = None,
+                       rescaler_config: Optional[RescalerConfig] = None,
+                       signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
+                       raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False,
+                       batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
+                       timings: Optional[Dict[str, float]] = None, quiet: bool = False, _engine=None):
     """Step 3 (src/caller/wrapper.py:17-41) for every locus of `loci` -- objects with `.path`, `.sequence`, `.flank_length`
     (upstream's Locus, src/schemas/locus.py) -- through one handle.  Returns [(df_overview, df_collapsed), ...] in the order of
     `loci` and writes, per locus, exactly what main_wrapper writes.
@@ -115,7 +170,8 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     signal_loader(fast5path, l_start_raw, r_end_raw) -> normalised float64 segment replaces the GPU loader (default: the int16
     reads go up and are prepared on the device); raw_reader(fast5path) -> int16 read replaces the fast5 reader.
     batch_*: where the read list is cut -- a batch holds at most that many reads, segment samples and raw bytes.
-    shard=True: the run is one torch.distributed job, every rank takes its share of the reads (see the module text).
+    threads: worker processes for the per-locus host work (overview, automata, output files) from 64 loci on; the reads
+    themselves are the GPU's.  shard=True: the run is one torch.distributed job, every rank takes its share of the reads.
     timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure."""
     from . import dist as wdist
     from .pore_model import default_pore_model
@@ -140,11 +196,27 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
 
     # ---- per locus: overview, flanks, automata (every rank: the partition below is derived from them) ---------------
     jobs: List[LocusJob] = []
-    for locus in loci:
-        job = LocusJob(locus, pore_model, tm)
-        with _muted(quiet or rank != 0):  # (upstream prints its similarity warnings once per locus)
-            _similarity(job, caller_config, pore_model, write=rank == 0)
-        jobs.append(job)
+    tm['host_processes'] = pool._max_workers if pool is not None else 1
+    if pool is not None:
+        try:
+            step = max(8, min(64, len(loci) // (4 * pool._max_workers) or 8))
+            parts = [list(loci[k:k + step]) for k in range(0, len(loci), step)]
+            t0 = time.perf_counter()
+            for part_jobs, part_tm in pool.map(_setup_chunk, [(p, caller_config, rank == 0, quiet) for p in parts]):
+                jobs += part_jobs
+                for key, v in part_tm.items():
+                    tm[key + '_cpu'] = tm.get(key + '_cpu', 0.0) + v
+            tm['overview_s'] = tm['automata_s'] = 0.0
+            tm['setup_wall_s'] = time.perf_counter() - t0
+        except Exception:  # noqa: BLE001 -- a locus object that does not pickle, a worker that died: do it here
+            pool, jobs = None, []
+            tm['host_processes'] = 1
+    if pool is None:
+        for locus in loci:
+            job = LocusJob(locus, pore_model, tm)
+            with _muted(quiet or rank != 0):  # (upstream prints its similarity warnings once per locus)
+                _similarity(job, caller_config, pore_model, write=rank == 0)
+            jobs.append(job)
     first = np.zeros(len(jobs) + 1, np.int64)
     np.cumsum([j.n for j in jobs], out=first[1:])
     n_total = int(first[-1])
@@ -256,7 +328,22 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     # ---- per locus: the outputs of main_wrapper -------------------------------------------------------------------------------
     t0 = time.perf_counter()
     out = []
-    for li, job in enumerate(jobs):
+    # the first read a caller failed on ends the run where upstream's loop would have ended: the loci before it are written
+    bad = np.flatnonzero(records['status'] != 0)
+    n_good = int(np.searchsorted(first, bad[0], side='right') - 1) if len(bad) else len(jobs)
+    if pool is not None and n_good >= 64:
+        end1 = np.append(off1, len(seq1)) if len(off1) == n_total else off1
+        end2 = np.append(off2, len(seq2)) if len(off2) == n_total else off2
+        items = []
+        for li, job in enumerate(jobs[:n_good]):
+            a, b = int(first[li]), int(first[li + 1])
+            items.append((job.locus, job.overview_path, job.df_overview, job.names, job.reverse, records[a:b],
+                          seq1[int(end1[a]):int(end1[b])], seq2[int(end2[a]):int(end2[b])], rank == 0, quiet))
+        step = max(8, min(64, len(items) // (4 * pool._max_workers) or 8))
+        for part in pool.map(_store_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
+            out += part
+    for li in range(len(out), len(jobs)):
+        job = jobs[li]
         a, b = int(first[li]), int(first[li + 1])
         results = CallerResults(job.names, records[a:b], off1[a:b], seq1, seq2, 'raise', offsets2=off2[a:b]).check()
         with _muted(quiet or rank != 0):
