@@ -180,6 +180,8 @@ int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams);
  * fewer than 32 768 reads and at most 52 M samples --; the next one blocks the host until the oldest has finished: keep that many
  * sets of output buffers).  Outputs may be consumed only after wsx_caller_join (stream order) or
  * wsx_caller_synchronize / wsx_caller_last_timing (host).  Turning the mode off joins the handle's stream.
+ * Handles created with rescaling.threshold > 1 synchronise the host once per chunk inside every call (the number of reads
+ * that take FITPACK's smoothing branch sizes its workspace), so their calls overlap less.
  */
 int wsx_caller_set_pipelined(wsx_caller *c, int32_t on);
 

@@ -124,6 +124,21 @@ def test_bench_two_ranks_as_the_driver_launches_it(scaling):
     assert d['verified']['mismatches'] == 0
 
 
+def test_bench_four_ranks_on_the_one_card():
+    """The strong-scaling line at four ranks (configs[3]'s partition at a size the card can host four times: the box allows six
+    processes on its GPU, so the driver's --gpus 8 cannot be rehearsed here; the collective is gloo): every read called once,
+    the all-gathered table complete, shards of 2 000-2 001 reads."""
+    env = dict(os.environ, WARPSTR_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '3', '--warmup', '1',
+           '--reads', '8001', '--samples', '900', '--scaling', 'strong', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _one_line(out)
+    assert d['n_gpus'] == 4 and d['scaling'] == 'strong' and d['config']['reads_total'] == 8001 and d['config']['called_ok'] == 8001
+    assert d['config']['reads_per_gpu'] in (2000, 2001) and d['verified']['mismatches'] == 0
+    assert abs(d['value'] - 8001 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+
+
 @pytest.mark.parametrize('scaling', ['weak', 'strong'])
 def test_bench_rccl_collective_path_with_a_one_rank_group(scaling):
     """The code path N > 1 takes on real hardware -- RCCL all_gather_into_tensor of the records on a side stream, ordered

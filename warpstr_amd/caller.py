@@ -125,6 +125,17 @@ class CallerResults(collections.abc.Sequence):
             raise ReadCallError(f'read {self.names[bad[0]]}: caller status {_lib.READ_STATUS.get(st, st)}')
         return self
 
+    def sequences(self):
+        """([seq ...], [resc_seq ...]) of all reads at once ('' for a read that was not called, as __getitem__ gives with
+        on_error='nan'; call check() first to raise instead): one decode of each buffer instead of two objects per read."""
+        ok = self.records['status'] == 0
+        out = []
+        for buf, offs, field in ((self._seq1, self.offsets, 'len1'), (self._seq2, self.offsets2, 'len2')):
+            text = (buf.tobytes() if isinstance(buf, np.ndarray) else bytes(buf)).decode('ascii', 'replace')
+            lens = np.where(ok, self.records[field], 0)
+            out.append([text[o:o + n] for o, n in zip(np.asarray(offs).tolist(), lens.tolist())])
+        return out[0], out[1]
+
     def lengths(self):
         """(len(seq), len(resc_seq)) per read as two integer arrays: all that overview.csv stores of the sequences."""
         return self.records['len1'].copy(), self.records['len2'].copy()
@@ -734,7 +745,14 @@ class CallerWrapper:
         # The reads cross PCIe once, as int16 (2 bytes per sample of the WHOLE read go up, the records and the called
         # sequences come down); the normalised float64 segments are produced and consumed in HBM.  torch is the device
         # allocator here (pinned staging buffer, HBM buffers), nothing else.
-        import torch
+        try:
+            import torch
+            have_torch = torch.cuda.is_available()
+        except ImportError:
+            have_torch = False
+        if not have_torch:  # a process without (a GPU build of) torch: the same through the library's host-buffer entry points
+            signal, offsets, _ = self.hip.prepare_signals(raws, positions, spike_removal)
+            return self._run_packed(list(names), reverses, signal, offsets)
         dev = torch.device('cuda', self.hip.device)
         n = len(names)
         lens = np.fromiter((len(r) for r in raws), dtype=np.int64, count=n)

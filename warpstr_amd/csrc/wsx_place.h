@@ -344,6 +344,30 @@ inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *p
                 }
             if (!improved) break;
         }
+        // Still above zero: a seeded walk over admissible trades that do not raise the count (the plateau is what stops the
+        // descent above), descending again whenever one lowers it; deterministic.  (The count is cheap now -- no heap --, and
+        // this only runs for the few automata the construction leaves with a conflict: DM2's 254-state strand had 1.0 cycles
+        // per row, profiles/r04_real_loci_pmc.log.)
+        if (cur_cost > 0 && K > 1) {
+            uint32_t rng = 0x51ED270Bu ^ (uint32_t)S;
+            auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+            for (int step = 0; step < 4000 && cur_cost > 0; step++) {
+                const int a = (int)(next() % P);
+                const int b = (a & 31) + 32 * (int)(next() % (P / 32)); // same bank pair: the writes stay conflict-free
+                if (a == b || (a / 32) == (b / 32)) continue;
+                const int ja = out.state_at[a] == 0xFFFF ? -1 : out.state_at[a], jb = out.state_at[b] == 0xFFFF ? -1 : out.state_at[b];
+                if ((ja < 0 && jb < 0) || !pinned_ok(ja, b) || !pinned_ok(jb, a)) continue;
+                auto trade = [&]() {
+                    std::swap(out.state_at[a], out.state_at[b]);
+                    if (out.state_at[a] != 0xFFFF) out.pos[out.state_at[a]] = (uint16_t)a;
+                    if (out.state_at[b] != 0xFFFF) out.pos[out.state_at[b]] = (uint16_t)b;
+                };
+                trade();
+                const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
+                if (c <= cur_cost) cur_cost = c;
+                else trade();
+            }
+        }
     }
     out.identity = true;
     for (int j = 0; j < S; j++) out.identity = out.identity && out.pos[j] == j;

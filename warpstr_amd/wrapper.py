@@ -112,8 +112,15 @@ def main_wrapper_loci(loci, threads=1, **kwargs):
 def _store_outputs(locus, overview_path, df_overview, results, reverses, write: bool):
     """The results of all `saved` reads (overview order) -> overview columns, FASTA files, complex-unit table
     (src/caller/wrapper.py:24-41).  write=False: the tables are built and returned, the locus directory is not touched."""
-    seq_results = [(r.seq, r.resc_seq) for r in results]
-    cost_results = [(r.cost, r.resc_cost) for r in results]
+    if hasattr(results, 'sequences'):  # a batch's CallerResults: the columns at once (a locus may have thousands of reads)
+        seqs, resc = results.check().sequences()
+        c1, c2 = results.costs()
+        called = np.asarray(results.records['status']) == 0  # (a read that was not called: '' and NaN, as results[i] gives)
+        c1, c2 = np.where(called, c1, np.nan), np.where(called, c2, np.nan)
+        seq_results, cost_results = list(zip(seqs, resc)), list(zip(c1.tolist(), c2.tolist()))
+    else:
+        seq_results = [(r.seq, r.resc_seq) for r in results]
+        cost_results = [(r.cost, r.resc_cost) for r in results]
     df_overview = ov.store_results(overview_path, df_overview, seq_results, cost_results, locus.path, write=write)
     df_collapsed = None
     units, repeat_units, offsets = break_into_units(locus.sequence.upper())
