@@ -243,6 +243,16 @@ def fill_profile(kernel):
     return table[kernel]
 
 
+def fill_traffic_ratio(kernel, mean_T):
+    try:
+        prof = fill_profile(kernel)
+    except SystemExit:
+        return None
+    if not prof or prof.get('stale') or prof.get('hbm_bytes_per_sample') is None:
+        return None
+    return prof['hbm_bytes_per_sample'] / (6.0 + 16.0 / max(mean_T, 1.0))
+
+
 def valu_roofline(prof, alone_ms, wave_rows, kernel):
     """What actually bounds the fill: wave-level VALU instruction issue (every VALU op, fp64 or 32-bit, occupies a
     SIMD for 4 cycles per wave64) together with the LDS pipe.  alone_ms: one fill launch with nothing beside it."""
@@ -380,9 +390,13 @@ def secondary_leg(wl, local, device, steps, warmup, n_verify):
     got = res[(steps - 1) % N_BUF].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
     nv = min(n, n_verify)
     ores, _ = oracle_sample(wl, wl.signal[: int(wl.offsets[nv])].cpu().numpy(), nv, 2.0)
+    kernels = sorted({hip.kernel_name(a) for a in range(len(wl.tables))})
     out = {'workload': wl.desc, 'reads_per_step': n, 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
-           'value': n * steps / dt, 'unit': 'reads/s', 'kernels': sorted({hip.kernel_name(a) for a in range(len(wl.tables))}),
-           'called_ok': int((got['status'] == 0).sum()), 'verified': verify(got, ores)}
+           'value': n * steps / dt, 'unit': 'reads/s', 'kernels': kernels,
+           'called_ok': int((got['status'] == 0).sum()), 'verified': verify(got, ores),
+           # HBM bytes of a fill launch (FETCH_SIZE + WRITE_SIZE, separate PMC passes) over its algorithmic bytes (6 T + 16 per
+           # read and pass), per kernel, from the committed counters -- null where they were taken on other kernel sources
+           'traffic_over_algorithmic': {k: fill_traffic_ratio(k, float(wl.offsets[-1]) / n) for k in kernels}}
     hip.close()
     return out
 
@@ -507,7 +521,7 @@ def cfg5_driver_leg(reads_per_locus, local):
         reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
         main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True)  # warm-up (code objects, pinned staging)
         tm = {}
-        tables = main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True, timings=tm)
+        tables = main_wrapper_loci(loci, min(8, os.cpu_count() or 1), raw_reader=reader, device=local, quiet=True, timings=tm)
         n = len(loci) * reads_per_locus
         called = int(sum((np.asarray(df['results']) >= 0).sum() for df, _ in tables))
         return {'workload': f'8 loci x {reads_per_locus} reads through main_wrapper_loci, raw int16 reads in host memory -> output files',

@@ -134,9 +134,10 @@ def _store_chunk(args):
     return out
 
 
-def _pool(threads: int, n_loci: int):
-    """A pool of worker processes for the per-locus host work, or None (few loci, one thread, or no way to start one)."""
-    if threads <= 1 or n_loci < 64:
+def _pool(threads: int, n_loci: int, n_reads: int = 0):
+    """A pool of worker processes for the per-locus host work, or None (one thread; too little work -- fewer than 64 loci and,
+    for the output files, fewer than 20 000 reads --; or no way to start one)."""
+    if threads <= 1 or (n_loci < 64 and (n_loci < 2 or n_reads < 20000)):
         return None
     try:
         import multiprocessing as mp
@@ -149,15 +150,16 @@ def _pool(threads: int, n_loci: int):
 def main_wrapper_loci(loci: Sequence, threads: int = 1, **kwargs):
     """Step 3 for every locus of `loci` through one handle: see _main_wrapper_loci (this wrapper owns the worker processes of
     the per-locus host work, so that they end with the call however it ends)."""
-    pool = _pool(threads, len(loci))
+    pools = [_pool(threads, len(loci))]
     try:
-        return _main_wrapper_loci(loci, threads, pool, **kwargs)
+        return _main_wrapper_loci(loci, threads, pools, **kwargs)
     finally:
-        if pool is not None:
-            pool.shutdown(wait=True, cancel_futures=True)
+        for pool in pools:
+            if pool is not None:
+                pool.shutdown(wait=True, cancel_futures=True)
 
 
-def _main_wrapper_loci(loci: Sequence, threads: int, pool, *, caller_config: Optional[CallerConfig] = None,
+def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_config: Optional[CallerConfig] = None,
                        rescaler_config: Optional[RescalerConfig] = None,
                        signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
                        raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False,
@@ -196,6 +198,7 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pool, *, caller_config: Opt
 
     # ---- per locus: overview, flanks, automata (every rank: the partition below is derived from them) ---------------
     jobs: List[LocusJob] = []
+    pool = pools[0]
     tm['host_processes'] = pool._max_workers if pool is not None else 1
     if pool is not None:
         try:
@@ -331,7 +334,12 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pool, *, caller_config: Opt
     # the first read a caller failed on ends the run where upstream's loop would have ended: the loci before it are written
     bad = np.flatnonzero(records['status'] != 0)
     n_good = int(np.searchsorted(first, bad[0], side='right') - 1) if len(bad) else len(jobs)
-    if pool is not None and n_good >= 64:
+    if pool is None:  # few loci with many reads each: the output files are worth a pool of their own
+        pool = _pool(threads, n_good, n_total)
+        pools.append(pool)
+        if pool is not None:
+            tm['host_processes'] = pool._max_workers
+    if pool is not None and n_good >= 2:
         end1 = np.append(off1, len(seq1)) if len(off1) == n_total else off1
         end2 = np.append(off2, len(seq2)) if len(off2) == n_total else off2
         items = []
@@ -339,7 +347,7 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pool, *, caller_config: Opt
             a, b = int(first[li]), int(first[li + 1])
             items.append((job.locus, job.overview_path, job.df_overview, job.names, job.reverse, records[a:b],
                           seq1[int(end1[a]):int(end1[b])], seq2[int(end2[a]):int(end2[b])], rank == 0, quiet))
-        step = max(8, min(64, len(items) // (4 * pool._max_workers) or 8))
+        step = max(1, min(64, len(items) // (4 * pool._max_workers) or 1))
         for part in pool.map(_store_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
             out += part
     for li in range(len(out), len(jobs)):
