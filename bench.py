@@ -440,7 +440,7 @@ def make_locus_dirs(root, specs, reads_per_locus, seed):
 
 def _driver_timings(tm, n_loci):
     per = lambda k: tm.get(k, 0.0) / max(n_loci, 1) * 1e3
-    pooled = tm.get('host_processes', 1) > 1
+    pooled = 'overview_s_cpu' in tm  # the per-locus set-up ran on worker processes: CPU seconds summed over them
     return {'wall_s': tm['total_s'], 'host_processes': tm.get('host_processes', 1),
             # CPU time per locus (summed over the worker processes when there are several), and the wall-clock of the two phases
             'per_locus_ms': {'overview_csv': per('overview_s_cpu' if pooled else 'overview_s'),

@@ -5,8 +5,9 @@
 //                                                                         alignment records)
 //   per-read arrays by                 lr   = r - first_read
 //   packed per-sample bit masks by     loff/32 + lr                       (32 samples per word, one spare word/read)
-//   DP back-pointer scratch by         loff * NM 64-bit wave masks        (NM masks per sample; dtw_kernels.hip)
-// so no extra prefix sums are needed besides the caller's own offsets[].
+//   DP back-pointer scratch by         bp_off[lr]                         (64-bit words from the start of the chunk's region: the reads lie
+//                                                                         back to back, each with the rows its kernel variant writes)
+// so no prefix sums are needed besides the caller's own offsets[] and that one array.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -136,8 +136,9 @@ def _store_chunk(args):
 
 def _pool(threads: int, n_loci: int, n_reads: int = 0):
     """A pool of worker processes for the per-locus host work, or None (one thread; too little work -- fewer than 64 loci and,
-    for the output files, fewer than 20 000 reads --; or no way to start one)."""
-    if threads <= 1 or (n_loci < 64 and (n_loci < 2 or n_reads < 20000)):
+    for the output files, fewer than 250 000 reads: starting the workers takes about a second, which the files of 50 000 reads
+    do not --; or no way to start one)."""
+    if threads <= 1 or (n_loci < 64 and (n_loci < 2 or n_reads < 250000)):
         return None
     try:
         import multiprocessing as mp

@@ -127,7 +127,12 @@ def _store_outputs(locus, overview_path, df_overview, results, reverses, write: 
     if len(units) > 1:
         if write:
             print(f'Running complex genotyping as complex repeat units present: {units}')
-        collapsed = [collapse_repeats(s[1], repeat_units, offsets) for s in seq_results]
+        memo = {}  # the reads of a locus call a handful of distinct sequences: each is scanned once
+        collapsed = []
+        for s in seq_results:
+            if s[1] not in memo:
+                memo[s[1]] = collapse_repeats(s[1], repeat_units, offsets)
+            collapsed.append(memo[s[1]])
         df_collapsed = ov.store_collapsed(collapsed, units, repeat_units, reverses, locus.path, write=write)
     return df_overview, df_collapsed
 
