@@ -570,6 +570,17 @@ def generated_fill_leg(wl, local, device, steps, warmup, builtin_records):
     return out
 
 
+def optional_leg(leg, *a):
+    """A leg above the kernels (the product driver, the opt-in generated fill) must not take the headline line down with it: an
+    exception becomes {'failed': ...} in its place (a result that DIFFERS still fails the run: the callers check that)."""
+    try:
+        return leg(*a)
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        print(f'bench.py: {leg.__name__} failed:\n{traceback.format_exc()}', file=sys.stderr)
+        return {'failed': f'{type(e).__name__}: {e}'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -847,12 +858,15 @@ def main():
                     rc = 3
                     print(f"bench.py: secondary workload {name}: {leg['verified']['mismatches']} reads differ from the oracle", file=sys.stderr)
             out['secondary']['from_raw'] = out['from_raw']
-            out['secondary']['generated_fill'] = generated_fill_leg(wl, local, device, max(5, args.steps // 2), 3, mine)
+            out['secondary']['generated_fill'] = optional_leg(generated_fill_leg, wl, local, device, max(5, args.steps // 2), 3, mine)
+            if out['secondary']['generated_fill'].get('identical_to_builtin') is False:
+                rc = 3
+                print('bench.py: the generated fill and the built-in kernels disagree', file=sys.stderr)
             # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
-            out['secondary']['cfg5']['through_driver'] = cfg5_driver_leg(6250, local)
+            out['secondary']['cfg5']['through_driver'] = optional_leg(cfg5_driver_leg, 6250, local)
             if args.many_loci > 0:
-                out['many_loci'] = many_loci_leg(args.many_loci, 30, min(32, args.many_loci), local)
-                if not out['many_loci']['outputs_identical']['identical']:
+                out['many_loci'] = optional_leg(many_loci_leg, args.many_loci, 30, min(32, args.many_loci), local)
+                if not out['many_loci'].get('outputs_identical', {'identical': True})['identical']:
                     rc = 3
                     print('bench.py: many_loci: the batched driver and the per-locus loop wrote different files', file=sys.stderr)
         sys.stdout.flush()
