@@ -601,6 +601,7 @@ def main():
                     help='automata of at most 64 states get their DP fill generated and compiled at run time (warpstr_amd/fillgen.py: '
                          'a read in four lanes) instead of the built-in kernel; the default run times that variant as '
                          'secondary.generated_fill')
+    ap.add_argument('--generated-passes', type=int, default=3, help='with --generated-fill: 1 = the unmasked pass only, 2 = the masked pass only, 3 = both')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
@@ -676,6 +677,8 @@ def main():
     hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream,  # the library's defaults unless asked otherwise
                     workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None,
                     generated_fill=bool(args.generated_fill))
+    if args.generated_fill:
+        hip.set_tuning('generated_passes', args.generated_passes)
     # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
     # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
     res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]

@@ -160,7 +160,8 @@ enum {
     WSX_TUNE_CHUNKS = 5,               /* > 0: chunks per call instead of the built-in rule (also WSX_CHUNKS at creation); 0 */
     WSX_TUNE_SMALL_PIPE_SAMPLES = 6,   /* pipelined calls up to this many samples stay in one chunk; 52 Mi */
     WSX_TUNE_CALLS_IN_FLIGHT = 7,      /* pipelined calls the host may run ahead of the device, 2..4; 2 */
-    WSX_TUNE_SMALL_CALLS_IN_FLIGHT = 8 /* ... for one-chunk calls, 2..4; 4 */
+    WSX_TUNE_SMALL_CALLS_IN_FLIGHT = 8, /* ... for one-chunk calls, 2..4; 4 */
+    WSX_TUNE_GENERATED_PASSES = 9      /* automata with a generated fill use it in: 1 the unmasked pass, 2 the masked pass, 3 both; 3 */
 };
 int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value);
 

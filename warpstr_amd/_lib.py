@@ -23,7 +23,7 @@ EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_
 
 # wsx_caller_set_tuning knobs (include/warpstr_hip.h: WSX_TUNE_*)
 TUNING = {'stream_traceback_min': 1, 'borders_wave_below': 2, 'segment_two_kernels': 3, 'fill_blocks_per_cu': 4, 'chunks': 5,
-          'small_pipe_samples': 6, 'calls_in_flight': 7, 'small_calls_in_flight': 8}
+          'small_pipe_samples': 6, 'calls_in_flight': 7, 'small_calls_in_flight': 8, 'generated_passes': 9}
 
 
 class WsxGeneratedFill(C.Structure):  # wsx_generated_fill

@@ -264,6 +264,7 @@ struct wsx_caller {
         Variant before;                               // the variant the automaton had (wsx_caller_set_generated_fill(.., NULL) restores it)
     };
     std::vector<GenFill> genfill; // per automaton
+    int gen_passes = 3;           // which passes use a generated fill: bit 0 the unmasked pass, bit 1 the masked one (WSX_TUNE_GENERATED_PASSES)
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30; // set from the device's free memory at creation (wsx_caller_set_workspace_limit overrides)
     // workspace
@@ -818,6 +819,7 @@ int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value)
     case WSX_TUNE_SMALL_PIPE_SAMPLES: c->small_pipe_samples = std::max<int64_t>(0, value); break;
     case WSX_TUNE_CALLS_IN_FLIGHT: c->in_flight = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
     case WSX_TUNE_SMALL_CALLS_IN_FLIGHT: c->in_flight_small = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
+    case WSX_TUNE_GENERATED_PASSES: c->gen_passes = (int)(value & 3); break;
     default: g_err = "wsx_caller_set_tuning: unknown knob"; return WSX_ERR_INVALID;
     }
     return WSX_SUCCESS;
@@ -1204,10 +1206,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
     if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
         HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
-    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8)));
+    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8)));
     if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
         for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
-            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
+            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8);
             if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
             HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
             HIPCHK(c->meta[q].ensure(need));
@@ -1224,9 +1226,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int32_t *d_autid = mc.take<int32_t>(n);
     int32_t *d_order = mc.take<int32_t>(n);
     int64_t *d_bpoff = mc.take<int64_t>(n); // per read (global index): start of its back-pointer rows in its chunk's region
+    int64_t *d_bpoff2 = mc.take<int64_t>(n); // ... in the passes where a read with a generated fill takes its built-in kernel
     // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
     // caller's arrays are not referenced after this function returns
-    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
+    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8);
     if (pin_bytes > c->pinned_cap[slot]) {
         if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
         c->pinned[slot] = nullptr;
@@ -1239,6 +1242,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int32_t *h_autid = pc.take<int32_t>(n);
     int32_t *h_order = pc.take<int32_t>(n);
     int64_t *h_bpoff = pc.take<int64_t>(n);
+    int64_t *h_bpoff2 = pc.take<int64_t>(n);
     memcpy(h_offsets, io.offsets, (n + 1) * 8);
     memcpy(h_autid, io.aut_id, n * 4);
     HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1331,9 +1335,15 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                     for (size_t e = w0; e < std::min(grp.size(), w0 + WSX_GEN_RPW); e++) h_bpoff[grp[e]] = (int64_t)at;
                     at += v.bp_read_words((size_t)(io.offsets[grp[w0] + 1] - io.offsets[grp[w0]]));
                 }
+                // ... and, for the passes these reads run through their built-in kernel (WSX_TUNE_GENERATED_PASSES), its rows
+                const Variant &bv = c->genfill[v.gen - 1].before;
+                for (int32_t r : grp) {
+                    h_bpoff2[r] = (int64_t)at;
+                    if (c->gen_passes != 3) at += bv.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
+                }
             } else {
                 for (int32_t r : grp) {
-                    h_bpoff[r] = (int64_t)at;
+                    h_bpoff[r] = h_bpoff2[r] = (int64_t)at;
                     at += v.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
                 }
             }
@@ -1341,6 +1351,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
         bp_words64 = std::max(bp_words64, at + kBpSlackWords);
     }
     HIPCHK(hipMemcpyAsync(d_bpoff, h_bpoff, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_bpoff2, h_bpoff2, (size_t)n * 8, hipMemcpyHostToDevice, st));
     for (int k = 0; k < n_sized; k++) HIPCHK(c->work[sized_set(k)].bp.ensure(bp_words64 * 8));
     for (int k = 0; k < n_work && host; k++) {
         const int w = wset(k);
@@ -1562,7 +1573,11 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            if (x.gvar[g].gen) { // the automaton's own generated code (fillgen.py), 16 reads per wavefront
+            // a generated fill may be used for the unmasked pass only, for the masked one only, or for both (gen_passes bits 1 / 2)
+            const bool use_gen = x.gvar[g].gen && (c->gen_passes & (maskbits ? 2 : 1));
+            const Variant lv = (x.gvar[g].gen && !use_gen) ? c->genfill[x.gvar[g].gen - 1].before : x.gvar[g];
+            if (x.gvar[g].gen && !use_gen) pa.bp_off = d_bpoff2 + x.ch.first;
+            if (use_gen) { // the automaton's own generated code (fillgen.py), 16 reads per wavefront
                 const int aidx = x.gvar[g].gen - 1;
                 GenFillArgs ga{};
                 ga.signal = pa.signal;
@@ -1585,7 +1600,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
                 HIPCHK(hipModuleLaunchKernel(maskbits ? c->genfill[aidx].fn_m : c->genfill[aidx].fn_u, waves, 1, 1, 64, 1, 1, 0, s, params,
                                              nullptr));
             } else {
-                HIPCHK(wsx_launch_fill(pa, m, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].lm, x.gvar[g].generic, c->tun, s));
+                HIPCHK(wsx_launch_fill(pa, m, lv.K, lv.F, lv.FL, lv.pk, lv.lm, lv.generic, c->tun, s));
             }
             HIPCHK(hipEventRecord(e1, s));
         }
@@ -1599,9 +1614,12 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.maskbits = maskbits;
             pa.trace = trace;
             pa.status = status;
-            pa.lane_major = x.gvar[g].lm != 0;
-            if (x.gvar[g].gen) HIPCHK(wsx_launch_traceback_t(pa, x.gvar[g].nwp, c->host_aut[x.gvar[g].gen - 1].gen_n, s));
-            else HIPCHK(wsx_launch_traceback(pa, x.gvar[g].K, x.gvar[g].F, x.gvar[g].FL, x.gvar[g].pk, x.gvar[g].generic, nA, c->tun, s));
+            const bool use_gen = x.gvar[g].gen && (c->gen_passes & (maskbits ? 2 : 1));
+            const Variant lv = (x.gvar[g].gen && !use_gen) ? c->genfill[x.gvar[g].gen - 1].before : x.gvar[g];
+            if (x.gvar[g].gen && !use_gen) pa.bp_off = d_bpoff2 + x.ch.first;
+            pa.lane_major = lv.lm != 0;
+            if (use_gen) HIPCHK(wsx_launch_traceback_t(pa, x.gvar[g].nwp, c->host_aut[x.gvar[g].gen - 1].gen_n, s));
+            else HIPCHK(wsx_launch_traceback(pa, lv.K, lv.F, lv.FL, lv.pk, lv.generic, nA, c->tun, s));
         }
         return WSX_SUCCESS;
     };

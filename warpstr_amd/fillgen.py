@@ -491,9 +491,18 @@ extern "C" __global__ __launch_bounds__(64) {wpe} void wsx_fill_t_m(GenFillArgs 
 
 # ---- compilation ------------------------------------------------------------------------------------------------------------
 def cache_dir() -> str:
-    d = os.environ.get('WARPSTR_CACHE_DIR') or os.path.join(os.path.expanduser('~'), '.cache', 'warpstr_amd', 'fillgen')
-    os.makedirs(d, exist_ok=True)
-    return d
+    """Where code objects are kept: WARPSTR_CACHE_DIR, else ~/.cache/warpstr_amd/fillgen, else (home not writable) a per-user
+    directory under the system's temporary directory."""
+    choices = [os.environ.get('WARPSTR_CACHE_DIR'), os.path.join(os.path.expanduser('~'), '.cache', 'warpstr_amd', 'fillgen'),
+               os.path.join(tempfile.gettempdir(), f'warpstr_amd_fillgen_{os.getuid()}')]
+    for d in filter(None, choices):
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            continue
+    return tempfile.mkdtemp(prefix='warpstr_amd_fillgen_')
 
 
 _OPTS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-std=c++17']
