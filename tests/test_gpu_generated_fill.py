@@ -123,6 +123,28 @@ def test_attach_and_remove_at_run_time():
     assert hip.kernel_name(0).startswith('dtw_fill_fast')
     again, _ = hip.call(sig, off, aut)
     assert again.tobytes() == base.tobytes()
+    # malformed attachments are refused and leave the handle as it was
+    import ctypes as C
+
+    from warpstr_amd import _lib
+    gen = fillgen.generate(locus.template, 16)
+    code, _ = fillgen.compile_source(gen)
+    buf = C.create_string_buffer(code, len(code))
+    keep = [np.ascontiguousarray(gen.state_at, np.uint16), np.ascontiguousarray(gen.tb_n, np.uint8),
+            np.ascontiguousarray(gen.tb_word, np.uint16), np.ascontiguousarray(gen.tb_pred, np.uint16)]
+    bad_pred = keep[3].copy()
+    bad_pred[np.flatnonzero(keep[1])[0] * 4] = 999  # a predecessor position outside the automaton
+    for fields in ((1, gen.words_per_row + 1, gen.n_per_lane, gen.end_pos, keep),                      # odd row width
+                   (1, gen.words_per_row, gen.n_per_lane, (gen.end_pos + 1) % (4 * gen.n_per_lane), keep),   # wrong end position
+                   (2, gen.words_per_row, gen.n_per_lane, gen.end_pos, keep),                              # unknown ABI
+                   (1, gen.words_per_row, gen.n_per_lane, gen.end_pos, keep[:3] + [bad_pred])):
+        g = _lib.WsxGeneratedFill(fields[0], fields[1], fields[2], fields[3], C.cast(buf, C.c_void_p), len(code), *[_lib.ptr(k) for k in fields[4]])
+        assert hip.lib.wsx_caller_set_generated_fill(hip.handle, 0, C.byref(g)) == -1 and hip.kernel_name(0).startswith('dtw_fill_fast')
+    assert hip.lib.wsx_caller_set_tuning(hip.handle, 99, 1) == -1 and hip.workspace_limit() >= 2 << 30
+    hip.set_tuning('generated_passes', 1)  # the unmasked pass generated, the masked one built in: same results
+    assert hip.generate_fill(0) and hip.generate_fill(1)
+    once, _ = hip.call(sig, off, aut)
+    assert once.tobytes() == base.tobytes()
     big = synth.make_locus('(AAAT)', 110, 1)
     assert not fillgen.supported(big.template, 4)
     hip4 = HipCaller([big.template], [110], generated_fill=True)
