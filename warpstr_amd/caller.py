@@ -539,7 +539,8 @@ class BatchQueue:
             raise ValueError(f'spike_removal must be one of {sorted(SPIKE_REMOVAL)}')
         self.torch, self.hip, self.stream, self.spike = torch, hip, stream, spike_removal
         self.dev = torch.device('cuda', hip.device)
-        self.down = torch.cuda.Stream(device=self.dev)
+        self.down = torch.cuda.Stream(device=self.dev)  # ordered after every call so far (wsx_caller_join): the records come down here
+        self.pack = torch.cuda.Stream(device=self.dev)  # packs a finished batch's sequences: waits for THAT batch only
         self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
         self._turn = 0
         hip.set_pipelined(True)
@@ -625,7 +626,8 @@ class BatchQueue:
         out = [rec]
         starts = torch.from_numpy(ticket['offsets'][:-1].copy())
         packed = []
-        with torch.cuda.stream(self.down):
+        self.pack.wait_event(ticket['done'])  # (not the `down` stream itself: later batches have joined it since)
+        with torch.cuda.stream(self.pack):
             starts_d = starts.to(self.dev, non_blocking=True)
             for field, key in (('len1', 'seq1'), ('len2', 'seq2')):
                 ln = np.where(ok, rec[field], 0).astype(np.int64)
@@ -639,7 +641,7 @@ class BatchQueue:
                     idx = torch.repeat_interleave(starts_d - pos_d, ln_d, output_size=total) + torch.arange(total, device=self.dev)
                     host[:total].copy_(ticket[key][idx], non_blocking=True)
                 packed.append((host, pos, total))
-            self.down.synchronize()
+            self.pack.synchronize()
         for host, pos, total in packed:
             out += [host.numpy()[:total].copy(), pos]
         return tuple(out)
