@@ -4,7 +4,7 @@ rank (or rank 0) can genotype.  Backend 'nccl' is RCCL on
 runs on 'gloo' with CPU tensors for the world_size-2 tests.
 """
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence
 
 import numpy as np
 
