@@ -462,7 +462,7 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
     import shutil
     import tempfile
 
-    from warpstr_amd.wrapper import main_wrapper, main_wrapper_loci
+    from warpstr_amd.wrapper import main_wrapper_loci
     root = tempfile.mkdtemp(prefix='wsx_many_loci_')
     try:
         specs = [(f'locus{i:04d}', MANY_LOCI_PATTERNS[i % len(MANY_LOCI_PATTERNS)], 110, (2271, 3701), 5000 + i) for i in range(n_loci)]
@@ -485,10 +485,30 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
                'one_handle': _driver_timings(tm, n_loci), 'generation_s': gen_s}
         import contextlib
         import io
+        # the per-locus loop, with main_wrapper's own steps timed one by one (src/caller/wrapper.py:17-41)
+        from warpstr_amd import overview as ov
+        from warpstr_amd.caller import CallerWrapper
+        from warpstr_amd.wrapper import _store_outputs, get_raw_workload
+        parts = {'overview_csv': 0.0, 'automata_handle_placement': 0.0, 'read_raw': 0.0, 'first_call_with_allocations': 0.0, 'outputs': 0.0,
+                 'handle_teardown': 0.0}
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
             for locus in loop_loci:
-                main_wrapper(locus, 1, raw_reader=reader, device=local)
+                t = [time.perf_counter()]
+                overview_path, df_overview = ov.load_overview(locus.path)
+                t.append(time.perf_counter())
+                cw = CallerWrapper(locus, 1, device=local)
+                t.append(time.perf_counter())
+                names, reverses, raws_l, positions = get_raw_workload(df_overview, locus.path, reader)
+                t.append(time.perf_counter())
+                results = cw.run_raw(names, reverses, raws_l, positions, 'Brute')
+                t.append(time.perf_counter())
+                _store_outputs(locus, overview_path, df_overview, results, reverses, write=True)
+                t.append(time.perf_counter())
+                cw.hip.close()
+                t.append(time.perf_counter())
+                for k, (x, y) in zip(parts, zip(t[:-1], t[1:])):
+                    parts[k] += y - x
         dt = time.perf_counter() - t0
         same = True
         for a, b in zip(loci[:n_loop], loop_loci):
@@ -496,6 +516,7 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
                 same = same and filecmp.cmp(os.path.join(a.path, rel), os.path.join(b.path, rel), shallow=False)
         out['one_handle_per_locus'] = {'loci': n_loop, 'ms_per_locus': dt / max(n_loop, 1) * 1e3, 'loci_per_s': n_loop / dt,
                                        'reads_per_s': n_loop * reads_per_locus / dt,
+                                       'per_locus_ms': {k: v / max(n_loop, 1) * 1e3 for k, v in parts.items()},
                                        'note': 'main_wrapper per locus: automata, a handle with its streams, first-call allocations and '
                                                'a drained GPU per locus'}
         out['ms_per_locus'] = tm['total_s'] / n_loci * 1e3
