@@ -53,7 +53,8 @@ class FakeEngine:
                 s2.append('')
         return rec, s1, s2
 
-    submit_raw = None
+    def submit_raw(self, raws, lo, hi, aut):
+        return self.submit_signals([np.asarray(r[a:b + 1], np.float64) / 64.0 for r, a, b in zip(raws, lo, hi)], aut)
 
     def collect(self, ticket):
         rec, s1, s2 = ticket
@@ -236,6 +237,25 @@ def test_worker_processes_for_the_per_locus_host_work(tmp_path):
     main_wrapper_loci(a, 3, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, timings=tm)
     main_wrapper_loci(b, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
     assert tm['host_processes'] == 3 and tm['n_loci'] == 68
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_raw_reads_and_the_byte_budget_of_a_batch(tmp_path):
+    """The default path hands whole raw int16 reads to the engine; a batch is closed early when its raw bytes exceed the budget
+    (long reads): the cut does not show in the outputs."""
+    a, sig = _make_loci(str(tmp_path / 'a'))
+    b, _ = _make_loci(str(tmp_path / 'b'))
+    rng = np.random.default_rng(9)
+    raws = {}
+    for nm, s in sig.items():  # the segment sits at [1000, 1000 + len - 1] of a longer read, as the overviews say
+        raws[nm] = np.concatenate([rng.integers(400, 600, 1000), np.round(s * 64).astype(np.int64) + 500, rng.integers(400, 600, 300)]).astype(np.int16)
+    reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
+    tm_a, tm_b = {}, {}
+    main_wrapper_loci(a, 1, raw_reader=reader, _engine=FakeEngine, quiet=True, batch_raw_bytes=40000, timings=tm_a)
+    main_wrapper_loci(b, 1, raw_reader=reader, _engine=FakeEngine, quiet=True, timings=tm_b)
+    assert tm_a['batches'] > tm_b['batches'] == 1
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
