@@ -86,10 +86,10 @@ def test_eight_loci_in_one_handle_equal_eight_main_wrapper_calls(tmp_path):
     _same(one, again)
 
 
-def _cli(args, ranks, extra_env=None):
+def _cli(args, ranks, extra_env=None, module='warpstr_amd.wrapper'):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     env.update(extra_env or {})
-    tail = ['-m', 'warpstr_amd.wrapper'] + args
+    tail = ['-m', module] + args
     if ranks == 1:
         cmd = [sys.executable] + tail
     else:
@@ -117,7 +117,10 @@ def test_config_driven_run_on_one_and_two_ranks(tmp_path):
         cfg = tmp_path / f'{tag}.yaml'
         cfg.write_text(f'output: {tmp_path / tag}\nthreads: 2\ntr_region_calling: True\ngenotyping: False\nloci:\n' + ''.join(
             f'  - name: locus{li}\n    coord: chr1:1-2\n    sequence: {p}\n    flank_length: {fl}\n' for li, (p, fl, _, _) in enumerate(LOCI)))
-        out = _cli(['--config', str(cfg), '--segments-npz', npz], ranks, env)
+        if ranks == 1:  # upstream's command line: `python WarpSTR.py cfg.yaml` -> `python -m warpstr_amd cfg.yaml`
+            out = _cli([str(cfg), '--segments-npz', npz], 1, env, module='warpstr_amd')
+        else:
+            out = _cli(['--config', str(cfg), '--segments-npz', npz], ranks, env)
         for li, (_, _, n, _) in enumerate(LOCI):
             assert f'locus{li}: {n} reads called' in out
         _same(one, [LocusPath(os.path.join(tmp_path, tag, f'locus{li}'), p, fl) for li, (p, fl, _, _) in enumerate(LOCI)])
