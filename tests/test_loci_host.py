@@ -259,3 +259,39 @@ def test_raw_reads_and_the_byte_budget_of_a_batch(tmp_path):
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
+    """From 64 loci on with threads > 1 the batches' fast5 files are opened and decoded on the worker processes (the upstream
+    test file's ten VBZ-compressed reads, 70 loci pointing at them through the caller-only `fast5_path` column): the same files as
+    one process writes."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    pats = [('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)]
+
+    def make(root):
+        loci = []
+        for li in range(70):
+            pattern, fl = pats[li % 4]
+            locus = synth.make_locus(pattern, fl, 900 + li)
+            loc = os.path.join(root, f'locus{li}')
+            ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+            rows = [ids[(li + k) % 10] for k in range(1 + li % 3)]
+            pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool((li + k) & 1) for k in range(len(rows))], 'saved': 1,
+                          'l_start_raw': 5000 + 10 * li, 'r_end_raw': 6500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+            loci.append(LocusPath(loc, pattern, fl))
+        return loci
+    a, b = make(str(tmp_path / 'a')), make(str(tmp_path / 'b'))
+    tm = {}
+    main_wrapper_loci(a, 3, _engine=FakeEngine, quiet=True, timings=tm)
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    assert tm['host_processes'] == 3 and tm['n_reads'] == sum(1 + li % 3 for li in range(70)) >= 64
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel

@@ -121,6 +121,17 @@ def _setup_chunk(args):
     return jobs, tm
 
 
+def _read_chunk(items):
+    """Raw reads of (annotated fast5 path, multi-read fall-back path or None, read name) triples, as LocusJob.raw_read finds them."""
+    out = []
+    for path, fallback, name in items:
+        if not os.path.exists(path) and fallback is not None:
+            out.append(np.ascontiguousarray(read_raw_signal(fallback, name), dtype=np.int16))
+        else:
+            out.append(np.ascontiguousarray(read_raw_signal(path), dtype=np.int16))
+    return out
+
+
 def _store_chunk(args):
     from .wrapper import _store_outputs
     out = []
@@ -279,18 +290,37 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_conf
             b0, b1 = cuts[b], cuts[b + 1]
             t1 = time.perf_counter()
             data, raw_bytes = [], 0
-            for k in range(b0, b1):
-                g = mine[k]
-                job = jobs[locus_of[g]]
-                if signal_loader is None:
-                    data.append(job.raw_read(int(row_of[g]), raw_reader))
-                    raw_bytes += data[-1].nbytes
-                    if raw_bytes > raw_budget and k + 1 < b1:  # long raw reads: close the batch early
-                        cuts.insert(b + 1, k + 1)
-                        b1 = k + 1
-                        break
-                else:
-                    data.append(np.asarray(signal_loader(job.fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
+            if pool is not None and signal_loader is None and raw_reader is read_raw_signal and b1 - b0 >= 64:
+                # the fast5 files of a batch on the worker processes (opening a file, HDF5 and the VBZ decoder take about a
+                # millisecond per read: in one process more than everything else of a many-loci run together)
+                items = []
+                for k in range(b0, b1):
+                    job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
+                    items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
+                step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
+                for part in pool.map(_read_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
+                    data += part
+                keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
+                while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
+                    acc += data[keep].nbytes
+                    keep += 1
+                if keep < len(data):
+                    cuts.insert(b + 1, b0 + keep)
+                    b1 = b0 + keep
+                    del data[keep:]
+            else:
+                for k in range(b0, b1):
+                    g = mine[k]
+                    job = jobs[locus_of[g]]
+                    if signal_loader is None:
+                        data.append(job.raw_read(int(row_of[g]), raw_reader))
+                        raw_bytes += data[-1].nbytes
+                        if raw_bytes > raw_budget and k + 1 < b1:  # long raw reads: close the batch early
+                            cuts.insert(b + 1, k + 1)
+                            b1 = k + 1
+                            break
+                    else:
+                        data.append(np.asarray(signal_loader(job.fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
             tm['read_s'] += time.perf_counter() - t1
             t1 = time.perf_counter()
             sel = mine[b0:b1]
