@@ -1,0 +1,30 @@
+"""A worker process of main_wrapper_loci's per-locus host work (warpstr_amd/loci.py: _WorkerPool): reads pickled
+(function name, argument) pairs from its standard input, runs the named module-level function of warpstr_amd.loci, writes the
+pickled ('ok', result) or ('err', text) to its standard output.  Started with `python -m warpstr_amd._hostworker`, so it never
+imports the parent's main module (multiprocessing's spawn would) and never touches HIP."""
+import os
+import pickle
+import sys
+import traceback
+
+
+def main():
+    out = os.fdopen(os.dup(sys.stdout.fileno()), 'wb')  # results go here; whatever the functions print goes to stderr
+    os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
+    src = sys.stdin.buffer
+    from warpstr_amd import loci
+    while True:
+        try:
+            name, arg = pickle.load(src)
+        except EOFError:
+            return
+        try:
+            res = ('ok', getattr(loci, name)(arg))
+        except Exception:  # noqa: BLE001 -- reported to the parent, which raises
+            res = ('err', traceback.format_exc())
+        pickle.dump(res, out, protocol=pickle.HIGHEST_PROTOCOL)
+        out.flush()
+
+
+if __name__ == '__main__':
+    main()

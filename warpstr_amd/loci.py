@@ -106,7 +106,8 @@ def _similarity(job: LocusJob, caller_config: CallerConfig, pore_model, write: b
 # Upstream's `threads` are Pool workers over the READS of one locus (src/caller/wrapper.py:104-109).  Here the reads are the
 # GPU's; what is left on the host is per LOCUS -- parsing its overview, compiling two automata, writing its CSV and FASTA
 # files: 4-5 ms of Python and pandas each, thousands of times -- and that is what `threads` spreads: over worker PROCESSES
-# (spawned, so that they never share the parent's HIP state; they import pandas and this package's host modules only).
+# (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and import pandas and this package's host
+# modules only).
 def _setup_chunk(args):
     loci, caller_config, write, quiet = args
     from .pore_model import default_pore_model
@@ -145,6 +146,67 @@ def _store_chunk(args):
     return out
 
 
+class _WorkerPool:
+    """`n` worker processes (`python -m warpstr_amd._hostworker`) and an ordered map over them.  Not multiprocessing's pool:
+    its spawned children import the parent's main module again, which a library cannot ask of every script that calls it, and
+    forked children would inherit the parent's HIP state."""
+
+    def __init__(self, n: int):
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       env=env) for _ in range(n)]
+        self._max_workers = n
+
+    def map(self, func, items):
+        """[func(item) for item in items] on the workers (func: a module-level function of this module), in order."""
+        import pickle
+        import threading
+        items = list(items)
+        results, errors = [None] * len(items), []
+        lock, nxt = threading.Lock(), [0]
+
+        def drive(proc):
+            try:
+                while not errors:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(items):
+                        return
+                    pickle.dump((func.__name__, items[i]), proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+                    proc.stdin.flush()
+                    status, payload = pickle.load(proc.stdout)
+                    if status != 'ok':
+                        raise RuntimeError(f'{func.__name__} failed in a worker process:\n{payload}')
+                    results[i] = payload
+            except Exception as e:  # noqa: BLE001 -- raised in the caller's thread below
+                errors.append(e)
+        threads = [threading.Thread(target=drive, args=(p,), daemon=True) for p in self.procs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
+
+    def shutdown(self, **_):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:  # noqa: BLE001
+                p.kill()
+        self.procs = []
+
+
 def _pool(threads: int, n_loci: int, n_reads: int = 0):
     """A pool of worker processes for the per-locus host work, or None (one thread; too little work -- fewer than 64 loci and,
     for the output files, fewer than 250 000 reads: starting the workers takes about a second, which the files of 50 000 reads
@@ -152,9 +214,7 @@ def _pool(threads: int, n_loci: int, n_reads: int = 0):
     if threads <= 1 or (n_loci < 64 and (n_loci < 2 or n_reads < 250000)):
         return None
     try:
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
-        return ProcessPoolExecutor(max_workers=min(int(threads), os.cpu_count() or 1), mp_context=mp.get_context('spawn'))
+        return _WorkerPool(min(int(threads), os.cpu_count() or 1))
     except (ImportError, OSError, ValueError):
         return None
 
@@ -168,7 +228,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, **kwargs):
     finally:
         for pool in pools:
             if pool is not None:
-                pool.shutdown(wait=True, cancel_futures=True)
+                pool.shutdown()
 
 
 def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_config: Optional[CallerConfig] = None,
