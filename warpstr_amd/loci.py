@@ -118,6 +118,7 @@ def _setup_chunk(args):
         job = LocusJob(locus, pm, tm)
         with _muted(quiet or not write):
             _similarity(job, caller_config, pm, write=write)
+        job.df_overview = None  # (not shipped to the parent and back: whoever writes the locus's files reads it again)
         jobs.append(job)
     return jobs, tm
 
@@ -137,6 +138,8 @@ def _store_chunk(args):
     from .wrapper import _store_outputs
     out = []
     for (locus, overview_path, df_overview, names, reverse, rec, s1, s2, write, quiet) in args:
+        if df_overview is None:
+            overview_path, df_overview = ov.load_overview(locus.path)
         l1 = np.where(rec['status'] == 0, rec['len1'], 0).astype(np.int64)
         l2 = np.where(rec['status'] == 0, rec['len2'], 0).astype(np.int64)
         o1, o2 = np.cumsum(l1) - l1, np.cumsum(l2) - l2
@@ -297,7 +300,8 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_conf
     n_total = int(first[-1])
     tm['n_loci'], tm['n_reads'] = len(jobs), n_total
     if n_total == 0:
-        out = [_store_outputs(j.locus, j.overview_path, j.df_overview, [], [], write=rank == 0) for j in jobs]
+        out = [_store_outputs(j.locus, *(ov.load_overview(j.locus.path) if j.df_overview is None else (j.overview_path, j.df_overview)), [], [],
+                              write=rank == 0) for j in jobs]
         if collective:
             tdist.barrier()
         tm['total_s'] = time.perf_counter() - t_start
@@ -443,6 +447,8 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_conf
             out += part
     for li in range(len(out), len(jobs)):
         job = jobs[li]
+        if job.df_overview is None:
+            job.overview_path, job.df_overview = ov.load_overview(job.locus.path)
         a, b = int(first[li]), int(first[li + 1])
         results = CallerResults(job.names, records[a:b], off1[a:b], seq1, seq2, 'raise', offsets2=off2[a:b]).check()
         with _muted(quiet or rank != 0):
