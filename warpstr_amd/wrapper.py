@@ -206,6 +206,11 @@ def main(argv=None):
         cfg = load_config(args.config)
         loci = loci_from_config(cfg)
         genotype = args.genotype or bool(cfg.raw.get('genotyping', False))
+        rank0 = int(os.environ.get('RANK', '0')) == 0
+        for locus in loci:  # (WarpSTR.py:43-45: every locus directory holds the sequence it was run with)
+            if rank0 and os.path.isdir(locus.path):
+                with open(os.path.join(locus.path, 'sequence.txt'), 'w') as f:
+                    f.write(locus.sequence)
         tables = []
         if cfg.tr_region_calling:
             tables = main_wrapper_loci(loci, cfg.threads, caller_config=cfg.caller, rescaler_config=cfg.rescaler, signal_loader=loader,
