@@ -440,12 +440,11 @@ def make_locus_dirs(root, specs, reads_per_locus, seed):
 
 def _driver_timings(tm, n_loci):
     per = lambda k: tm.get(k, 0.0) / max(n_loci, 1) * 1e3
-    pooled = 'overview_s_cpu' in tm  # the per-locus set-up ran on worker processes: CPU seconds summed over them
-    return {'wall_s': tm['total_s'], 'host_processes': tm.get('host_processes', 1),
-            # CPU time per locus (summed over the worker processes when there are several), and the wall-clock of the two phases
-            'per_locus_ms': {'overview_csv': per('overview_s_cpu' if pooled else 'overview_s'),
-                             'automaton_compile': per('automata_s_cpu' if pooled else 'automata_s'),
-                             'outputs_wall': per('store_s'), 'setup_wall': per('setup_wall_s') if pooled else per('overview_s') + per('automata_s')},
+    return {'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads', 1), 'reader_processes': tm.get('reader_processes', 0),
+            'native_overviews': tm.get('native_overviews'),
+            # CPU time per locus (summed over the threads when there are several), and the wall-clock of the two phases
+            'per_locus_ms': {'overview_csv': per('overview_s'), 'automaton_compile': per('automata_s'), 'state_similarity': per('similarity_s'),
+                             'setup_wall': per('setup_wall_s'), 'outputs_wall': per('store_s')},
             'once_s': {'handle_create_placement': tm['handle_s']},
             'batches_s': {'host_reads': tm['read_s'], 'submit': tm['submit_s'], 'wait_for_gpu': tm['collect_s']},
             'workspace_bytes': tm.get('workspace_bytes'), 'workspace_limit_bytes': tm.get('workspace_limit_bytes'),
@@ -474,15 +473,21 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
         # warm-up on directories of its own (a second pass over a locus finds the first one's columns in its overview.csv):
         # first use of the kernels' code objects, pinned staging
         warm_loci, _ = make_locus_dirs(os.path.join(root, 'warm'), specs[:10], reads_per_locus, 77)
-        main_wrapper_loci(warm_loci, 1, raw_reader=reader, device=local, quiet=True)
+        main_wrapper_loci(warm_loci, 1, raw_reads=raws, device=local, quiet=True)
+        # the run with ONE host thread on directories of its own, then the run whose files are compared, with 16
+        single_loci, _ = make_locus_dirs(os.path.join(root, 'single'), specs, reads_per_locus, 77)
+        tm1 = {}
+        main_wrapper_loci(single_loci, 1, raw_reads=raws, device=local, quiet=True, timings=tm1)
         tm = {}
         workers = min(16, os.cpu_count() or 1)
-        main_wrapper_loci(loci, workers, raw_reader=reader, device=local, quiet=True, timings=tm)
+        main_wrapper_loci(loci, workers, raw_reads=raws, device=local, quiet=True, timings=tm)
         n_reads = n_loci * reads_per_locus
         out = {'workload': f'{n_loci} loci x {reads_per_locus} reads, flank 110, {len(MANY_LOCI_PATTERNS)} patterns '
                            f'({", ".join(MANY_LOCI_PATTERNS[:3])}, ...), T in [2271, 3701], raw int16 reads in host memory -> output files',
                'loci': n_loci, 'reads': n_reads, 'loci_per_s': n_loci / tm['total_s'], 'reads_per_s': n_reads / tm['total_s'],
-               'one_handle': _driver_timings(tm, n_loci), 'generation_s': gen_s}
+               'one_handle': _driver_timings(tm, n_loci),
+               'one_handle_one_thread': dict(_driver_timings(tm1, n_loci), loci_per_s=n_loci / tm1['total_s'], reads_per_s=n_reads / tm1['total_s']),
+               'generation_s': gen_s}
         import contextlib
         import io
         # the per-locus loop, with main_wrapper's own steps timed one by one (src/caller/wrapper.py:17-41)
@@ -539,10 +544,9 @@ def cfg5_driver_leg(reads_per_locus, local):
     try:
         specs = [(f'locus{i}', p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i) for i, p in enumerate(CFG5_PATTERNS)]
         loci, raws = make_locus_dirs(root, specs, reads_per_locus, 78)
-        reader = lambda path: raws[os.path.basename(path)[:-len('.fast5')]]
-        main_wrapper_loci(loci, 1, raw_reader=reader, device=local, quiet=True)  # warm-up (code objects, pinned staging)
+        main_wrapper_loci(loci, 1, raw_reads=raws, device=local, quiet=True)  # warm-up (code objects, pinned staging)
         tm = {}
-        tables = main_wrapper_loci(loci, min(8, os.cpu_count() or 1), raw_reader=reader, device=local, quiet=True, timings=tm)
+        tables = main_wrapper_loci(loci, min(8, os.cpu_count() or 1), raw_reads=raws, device=local, quiet=True, timings=tm)
         n = len(loci) * reads_per_locus
         called = int(sum((np.asarray(df['results']) >= 0).sum() for df, _ in tables))
         return {'workload': f'8 loci x {reads_per_locus} reads through main_wrapper_loci, raw int16 reads in host memory -> output files',

@@ -1,0 +1,206 @@
+"""The native host library (warpstr_amd/csrc/host_loci.cpp -> _host_loci.so) against the Python forms it restates: automaton
+tables field for field, repr(float), overview.csv / FASTA / complex-unit files byte for byte with the pandas path -- and that it
+declines what it cannot be sure about."""
+import filecmp
+import os
+import shutil
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from warpstr_amd import _hostlib, automata, overview as ov
+from warpstr_amd.pore_model import default_pore_model
+
+pytestmark = pytest.mark.skipif(_hostlib.lib() is None, reason='warpstr_amd/_host_loci.so is not built')
+
+UNITS = ['AGC', 'AAAT', 'GGCCCC', 'CAG', 'CTG', 'CCTG', 'NGC', 'RY', 'CAGM', 'AAGGG', 'GAA', 'TTTTA', 'GCN', 'CGG', 'AT', 'ATTCT', 'A',
+         'BD', 'HV', 'SWK']
+
+
+def random_pattern(rng):
+    pat = ''
+    for _ in range(int(rng.integers(1, 4))):
+        unit = UNITS[int(rng.integers(len(UNITS)))]
+        r = rng.random()
+        if r < 0.2:
+            unit = '(' + unit + '){' + UNITS[int(rng.integers(len(UNITS)))] + '}'
+        elif r < 0.3:
+            unit = unit + '{' + UNITS[int(rng.integers(len(UNITS)))] + '}'
+        elif r < 0.35:
+            unit = '(' + unit + ')' + UNITS[int(rng.integers(len(UNITS)))]
+        pat += '(' + unit + ')'
+        if rng.random() < 0.4:
+            pat += ''.join('ACGT'[i] for i in rng.integers(0, 4, size=int(rng.integers(1, 14))))
+    return pat
+
+
+def same_table(a, b):
+    assert (a.n_states, a.endstate, a.repstart, a.repend) == (b.n_states, b.endstate, b.repstart, b.repend)
+    for f in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base'):
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and np.array_equal(x, y), f
+    assert a.kmers == b.kmers
+    assert [sorted(s) for s in a.succ] == [sorted(s) for s in b.succ]
+
+
+def test_automata_equal_the_python_compiler_on_random_loci():
+    rng = np.random.default_rng(5)
+    pm = default_pore_model()
+    n = 0
+    for _ in range(600):
+        pat = random_pattern(rng)
+        fl = int(rng.integers(6, 130))
+        left = ''.join('ACGT'[i] for i in rng.integers(0, 4, size=fl))
+        right = ''.join('ACGT'[i] for i in rng.integers(0, 4, size=fl))
+        for full in (left + pat + right, left + automata.reverse_pattern(pat) + right):
+            try:
+                want = automata.compile_automaton(full, pm, native=False)
+            except Exception:  # noqa: BLE001 -- a pattern the compiler refuses: the library must decline it too
+                assert _hostlib.compile_automaton(full, pm) is None
+                continue
+            got = _hostlib.compile_automaton(full, pm)
+            assert got is not None, full
+            same_table(got, want)
+            n += 1
+    assert n > 1000
+
+
+@pytest.mark.parametrize('pattern', ['', 'ACG', 'ACGTAC)AGC(ACGTAC', 'ACGTACGT}AGC{ACGTAC', 'ACGTACxGTACGTAC', 'acgtacgtacgt', 'ACGTAC(AGC'])
+def test_patterns_the_python_compiler_raises_on_are_declined_or_equal(pattern):
+    pm = default_pore_model()
+    try:
+        want = automata.compile_automaton(pattern, pm, native=False)
+    except Exception:  # noqa: BLE001
+        assert _hostlib.compile_automaton(pattern, pm) is None
+        with pytest.raises(Exception):
+            automata.compile_automaton(pattern, pm)  # (the default path ends in the Python compiler's own error)
+        return
+    same_table(_hostlib.compile_automaton(pattern, pm), want)
+
+
+def test_float_text_is_pythons_repr():
+    rng = np.random.default_rng(1)
+    xs = [0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1.5e-7, 1e15, 1e16, 123456789012345680.0, 1e22, 5e-324, 1.7976931348623157e308,
+          2.0 ** -30, 2.0 ** 70, 0.30000000000000004, 100.0, 1234.5, float('inf'), float('-inf')]
+    xs += list(rng.standard_normal(2000)) + list(np.exp(rng.uniform(-40, 40, 2000))) + list(rng.integers(-10 ** 6, 10 ** 6, 500) / 8.0)
+    xs += [float(np.float64(v)) for v in np.round(rng.uniform(0, 5, 500), 3)]
+    for x in xs:
+        assert _hostlib.format_float(x) == repr(float(x)), x
+    col = pd.DataFrame({'x': np.array(xs[:200])}).to_csv(index=False).split('\n')[1:-1]
+    assert col == [_hostlib.format_float(x) for x in xs[:200]]
+
+
+def _random_overview(rng, n, kind):
+    """A table as the earlier pipeline steps leave it (pandas-written), with the column kinds real runs have."""
+    names = [f'{rng.integers(0, 16**8):08x}-{rng.integers(0, 16**4):04x}-read{i}' for i in range(n)]
+    df = pd.DataFrame({'read_name': names, 'run_id': rng.choice(['run_0', 'runB'], n) if kind % 2 else rng.integers(0, 3, n),
+                       'reverse': rng.random(n) < 0.5, 'sam_dist': rng.integers(-50, 50, n),
+                       'saved': (rng.random(n) < 0.8) if kind % 3 else (rng.random(n) < 0.8).astype(int)})
+    lo = rng.integers(0, 50000, n)
+    df['l_start_raw'], df['r_end_raw'] = lo, lo + rng.integers(200, 4000, n)
+    if kind >= 2:   # floats with blanks on unsaved rows, a string column with blanks, scores
+        df['l_start_raw'] = np.where(df['saved'].astype(bool), df['l_start_raw'], np.nan)
+        df['r_end_raw'] = np.where(df['saved'].astype(bool), df['r_end_raw'], np.nan)
+        df['score'] = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)
+        df['note'] = np.where(rng.random(n) < 0.5, 'ok', None)
+        df['flag'] = np.where(rng.random(n) < 0.3, None, rng.random(n) < 0.5)
+    if kind >= 4:   # a re-run: the result columns are there already, and a stale one
+        df['results'], df['orig'], df['dtw_cost1'], df['dtw_cost2'], df['result_old'] = 7, 8, 0.5, 0.25, 'x'
+        df['after'] = rng.integers(0, 9, n)
+    return df
+
+
+@pytest.mark.parametrize('kind', range(6))
+def test_overview_in_and_out_equals_the_pandas_path(tmp_path, kind):
+    rng = np.random.default_rng(100 + kind)
+    for trial in range(8):
+        n = int(rng.integers(1, 60))
+        df = _random_overview(rng, n, kind)
+        if not df['saved'].astype(bool).any():
+            df.loc[0, 'saved'] = True if df['saved'].dtype == bool else 1
+            if kind >= 2:
+                df.loc[0, ['l_start_raw', 'r_end_raw']] = [5.0, 900.0]
+        a, b = str(tmp_path / f'a{trial}'), str(tmp_path / f'b{trial}')
+        for d in (a, b):
+            os.makedirs(d)
+            df.to_csv(os.path.join(d, 'overview.csv'), index=False)
+        nat = _hostlib.NativeOverview.open(os.path.join(a, 'overview.csv'))
+        assert nat is not None, _hostlib.NativeOverview.last_refusal
+        path, ref = ov.load_overview(b)
+        saved = np.flatnonzero(np.asarray(ref['saved']).astype(bool))
+        assert nat.saved.tolist() == saved.tolist()
+        assert nat.names == [str(x) for x in ref.index.to_numpy()[saved]]
+        assert nat.reverse.tolist() == np.asarray(ref['reverse'])[saved].astype(bool).tolist()
+        assert nat.lo.tolist() == np.asarray(ref['l_start_raw'])[saved].astype(np.int64).tolist()
+        assert nat.hi.tolist() == np.asarray(ref['r_end_raw'])[saved].astype(np.int64).tolist()
+        assert nat.run_id == [str(x) for x in np.asarray(ref['run_id'])[saved]]
+        ns = len(saved)
+        seqs = [(''.join(rng.choice(list('ACGT'), int(rng.integers(0, 40)))), ''.join(rng.choice(list('ACGT'), int(rng.integers(0, 40)))))
+                for _ in range(ns)]
+        costs = [(float(rng.random() * 3), float(np.exp(rng.uniform(-12, 3)))) for _ in range(ns)]
+        want = ov.store_results(path, ref, seqs, costs, b, write=True)
+        len1, len2 = [len(s[0]) for s in seqs], [len(s[1]) for s in seqs]
+        seq2 = np.frombuffer(''.join(s[1] for s in seqs).encode(), np.uint8)
+        off2 = np.cumsum([0] + len2)[:-1]
+        text = nat.store(a, len1, len2, [c[0] for c in costs], [c[1] for c in costs], seq2, off2, write=True)
+        for rel in ('overview.csv', 'predictions/sequences/all.fasta', 'predictions/sequences/sequences_template.fasta',
+                    'predictions/sequences/sequences_reverse.fasta'):
+            assert filecmp.cmp(os.path.join(a, rel), os.path.join(b, rel), shallow=False), (kind, trial, rel)
+        assert text == open(os.path.join(b, 'overview.csv')).read()
+        got = ov.table_from_text(text)
+        pd.testing.assert_frame_equal(got, want)
+        nat.close()
+
+
+@pytest.mark.parametrize('edit, why', [
+    (lambda t: t.replace('\n', '\r\n'), 'carriage'),
+    (lambda t: t.replace(',3,', ',03,', 1) if ',3,' in t else t.replace(',1,', ',01,', 1), 're-formatted'),
+    (lambda t: t.replace('run_0', '"run,0"', 1), 'quoted'),
+    (lambda t: t.replace('run_0', 'NA', 1), 're-formatted'),
+    (lambda t: t.replace('True', 'true', 1), 're-formatted'),
+    (lambda t: t.replace('0.5', '+0.5', 1), 're-formatted'),
+    (lambda t: t.replace('0.5', '.5', 1), 're-formatted'),
+    (lambda t: t[:-1], 'newline'),
+    (lambda t: t + '\n', 'blank'),
+    (lambda t: t.replace('read_name', 'read_name,read_name', 1), ''),
+    (lambda t: t.replace('saved', 'kept', 1), 'missing'),
+])
+def test_tables_pandas_would_change_are_declined(tmp_path, edit, why):
+    df = pd.DataFrame({'read_name': ['r1', 'r2', 'r3'], 'run_id': ['run_0', 'run_0', 'run_1'], 'reverse': [True, False, True],
+                       'saved': [1, 1, 0], 'l_start_raw': [3, 13, 1], 'r_end_raw': [900, 950, 1000], 'score': [0.5, 1.25, 3.0]})
+    text = edit(df.to_csv(index=False))
+    p = tmp_path / 'overview.csv'
+    p.write_bytes(text.encode())
+    assert _hostlib.NativeOverview.open(str(p)) is None
+    assert why in _hostlib.NativeOverview.last_refusal
+
+
+def test_missing_overview_raises_upstreams_error(tmp_path):
+    with pytest.raises(FileNotFoundError, match='Not found the overview file'):
+        _hostlib.NativeOverview.open(str(tmp_path / 'overview.csv'))
+
+
+def test_float_columns_come_back_as_pandas_converter_leaves_them(tmp_path):
+    """read_csv's default float converter is not correctly rounded and to_csv writes what it made of a cell: a float column
+    changes on its way through pandas.  The writer does to every float cell what pandas does (pandas_strtod in host_loci.cpp)."""
+    rng = np.random.default_rng(3)
+    cells = ['0.50', '1e5', '5.', '3', '0.0015732835352270625', '123456789.123456789123', '1E-7', '2.5e+300', '1e-320', '4.9e-324',
+             '0.1', '-0.0', '17', '1.7976931348623157e308', '0.30000000000000004', '9007199254740993.0', '1e22', '1e23', '8.5e-5', 'inf',
+             '-inf', '']
+    cells += [repr(float(x)) for x in rng.standard_normal(300) * 10.0 ** rng.integers(-12, 12, 300)]
+    cells += [f'{x:.20f}' for x in rng.random(100)] + [f'{x:.25e}' for x in rng.random(100) * 1e-5]
+    n = len(cells)
+    for d in ('a', 'b'):
+        os.makedirs(tmp_path / d)
+        with open(tmp_path / d / 'overview.csv', 'w') as f:
+            f.write('read_name,run_id,reverse,saved,l_start_raw,r_end_raw,x\n')
+            for i, c in enumerate(cells):
+                f.write(f'r{i},0,False,1,{10 + i}.0,{500 + i},{c}\n')
+    nat = _hostlib.NativeOverview.open(str(tmp_path / 'a' / 'overview.csv'))
+    assert nat is not None, _hostlib.NativeOverview.last_refusal
+    path, ref = ov.load_overview(str(tmp_path / 'b'))
+    assert nat.lo.tolist() == np.asarray(ref['l_start_raw']).astype(np.int64).tolist()
+    ov.store_results(path, ref, [('A', 'AC')] * n, [(0.5, 0.25)] * n, str(tmp_path / 'b'), write=True)
+    nat.store(str(tmp_path / 'a'), [1] * n, [2] * n, [0.5] * n, [0.25] * n, np.frombuffer(b'AC' * n, np.uint8), np.arange(n) * 2, write=True)
+    assert open(tmp_path / 'a' / 'overview.csv').read() == open(tmp_path / 'b' / 'overview.csv').read()

@@ -32,6 +32,7 @@ class FakeEngine:
 
     def __init__(self, tables, flank_lengths, caller_config, rescaler_config, device):
         self.n_aut = len(tables)
+        self.key = [int(t.n_states) + int(t.endstate) for t in tables]   # (a property of the automaton, not its place in the handle)
         self.batches = 0
 
     def submit_signals(self, signals, aut):
@@ -41,7 +42,7 @@ class FakeEngine:
         s1, s2 = [], []
         for i, (x, a) in enumerate(zip(signals, aut)):
             assert 0 <= a < self.n_aut
-            h = int(abs(float(np.sum(x))) * 1000) + int(a)
+            h = int(abs(float(np.sum(x))) * 1000) + self.key[a]
             rec['status'][i] = 3 if x[0] > 90.0 else 0
             rec['len1'][i], rec['len2'][i] = 4 + h % 9, 3 + h % 11
             rec['cost1'][i], rec['cost2'][i] = float(np.mean(x)), float(np.max(x))
@@ -222,9 +223,9 @@ def test_one_rank_failing_read_raises(tmp_path):
         main_wrapper_loci(loci, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
 
 
-def test_worker_processes_for_the_per_locus_host_work(tmp_path):
-    """threads > 1 from 64 loci on: overviews / automata / output files on spawned worker processes -- the same files as one
-    process writes."""
+def test_threads_for_the_per_locus_host_work(tmp_path):
+    """threads > 1: overviews / automata / output files on threads of this process (native code without the GIL) -- the same
+    files as one thread writes."""
     global LOCI
     saved = LOCI
     try:
@@ -236,7 +237,7 @@ def test_worker_processes_for_the_per_locus_host_work(tmp_path):
     tm = {}
     main_wrapper_loci(a, 3, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, timings=tm)
     main_wrapper_loci(b, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
-    assert tm['host_processes'] == 3 and tm['n_loci'] == 68
+    assert tm['host_threads'] == 3 and tm['n_loci'] == 68 and tm['reader_processes'] == 0
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
@@ -291,7 +292,134 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
     tm = {}
     main_wrapper_loci(a, 3, _engine=FakeEngine, quiet=True, timings=tm)
     main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
-    assert tm['host_processes'] == 3 and tm['n_reads'] == sum(1 + li % 3 for li in range(70)) >= 64
+    assert tm['reader_processes'] == 3 and tm['n_reads'] == sum(1 + li % 3 for li in range(70)) >= 64
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_native_and_pandas_host_paths_write_the_same_files(tmp_path):
+    """The native per-locus host work (csrc/host_loci.cpp) against the pandas / Python forms it replaces: every output file
+    byte for byte, the returned tables equal; and a table the native parser declines (a quoted field) takes the pandas path
+    inside a native run."""
+    a, sig = _make_loci(str(tmp_path / 'a'))
+    b, _ = _make_loci(str(tmp_path / 'b'))
+    for loci in (a, b):   # one table the native parser will not touch
+        p = os.path.join(loci[2].path, 'overview.csv')
+        df = pd.read_csv(p)
+        df['note'] = ['with, comma'] + ['x'] * (len(df) - 1)
+        df.to_csv(p, index=False)
+    tm_a, tm_b = {}, {}
+    ta = main_wrapper_loci(a, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, timings=tm_a)
+    tb = main_wrapper_loci(b, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, native=False, timings=tm_b)
+    from warpstr_amd import _hostlib
+    if _hostlib.lib() is not None:
+        assert tm_a['native_overviews'] == len(a) - 1
+    assert tm_b['native_overviews'] == 0
+    for la, lb, (dfa, ca), (dfb, cb) in zip(a, b, ta, tb):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+        pd.testing.assert_frame_equal(dfa, dfb)
+        assert (ca is None) == (cb is None)
+        if ca is not None:
+            pd.testing.assert_frame_equal(ca, cb)
+            rel = 'predictions/complexSTR_analysis/complex_repeat_units.csv'
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False)
+    assert any(c is not None for _, c in ta)
+
+
+def test_reads_in_host_memory_by_name(tmp_path):
+    """raw_reads={name: int16 read}: the same outputs as a raw_reader call-back per read."""
+    a, sig = _make_loci(str(tmp_path / 'a'))
+    b, _ = _make_loci(str(tmp_path / 'b'))
+    rng = np.random.default_rng(9)
+    raws = {nm: np.concatenate([rng.integers(400, 600, 1000), np.round(s * 64).astype(np.int64) + 500]).astype(np.int16) for nm, s in sig.items()}
+    main_wrapper_loci(a, 2, raw_reads=raws, _engine=FakeEngine, quiet=True, batch_reads=7)
+    main_wrapper_loci(b, 1, raw_reader=lambda path: raws[os.path.basename(path)[:-len('.fast5')]], _engine=FakeEngine, quiet=True)
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_store_time_does_not_grow_with_the_run(tmp_path):
+    """The outputs of a locus are made from ITS slice of the run's sequence buffers (each locus once decoded the whole run's
+    buffers: quadratic).  400 loci through the pandas path: the store phase stays a small multiple of 100 loci's."""
+    global LOCI
+    saved = LOCI
+    try:
+        LOCI = [('(AGC)', 16, 3)] * 400
+        a, sig = _make_loci(str(tmp_path / 'a'))
+    finally:
+        LOCI = saved
+    tm_small, tm_big = {}, {}
+    main_wrapper_loci(a[:100], 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, native=False, timings=tm_small)
+    main_wrapper_loci(a, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, native=False, timings=tm_big)
+    assert tm_big['store_s'] < 8 * tm_small['store_s'] + 0.5, (tm_big['store_s'], tm_small['store_s'])
+
+
+def _rank_many(rank, world, port, root, out_dir, mode):
+    import json
+
+    import torch.distributed as dist
+    global LOCI
+    LOCI = [(p, fl, 1 + (i * 7) % 5) for i, (p, fl) in enumerate([('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)] * 18)]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    loci, sig = _make_loci(root) if rank == 0 else (None, None)
+    dist.barrier()
+    if rank != 0:
+        import tempfile
+        with tempfile.TemporaryDirectory() as scratch:
+            _, sig = _make_loci(scratch)
+        loci = [LocusPath(os.path.join(root, f'locus{li}'), p, fl) for li, (p, fl, _) in enumerate(LOCI)]
+    if mode == 'poison':
+        sig['L40_read000'] = sig['L40_read000'].copy()
+        sig['L40_read000'][0] = 99.0
+    tm, msg, lens = {}, 'ok', None
+    try:
+        tables = main_wrapper_loci(loci, 2, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True, shard=True, timings=tm)
+        lens = [int((np.asarray(tables[i][0]['results']) >= 0).sum()) for i in (0, 35, 71)]   # other ranks' loci come from their files
+    except Exception as e:  # noqa: BLE001
+        msg = f'{type(e).__name__}: {e}'
+    with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as f:
+        json.dump({'msg': msg, 'set_up': tm.get('loci_set_up'), 'partition': tm.get('partition'), 'lens': lens}, f)
+    dist.destroy_process_group()
+
+
+def test_many_loci_are_partitioned_by_locus_over_the_ranks(tmp_path):
+    """72 loci on 8 ranks (>= 8 per rank): every rank sets up, calls and writes ONLY its own loci -- together every locus exactly
+    once --, no result travels, and the files equal one rank's."""
+    import json
+    global LOCI
+    saved = LOCI
+    try:
+        LOCI = [(p, fl, 1 + (i * 7) % 5) for i, (p, fl) in enumerate([('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)] * 18)]
+        one, sig = _make_loci(str(tmp_path / 'one'))
+        n_reads = [n for _, _, n in LOCI]
+    finally:
+        LOCI = saved
+    main_wrapper_loci(one, 1, signal_loader=_loader(sig), _engine=FakeEngine, quiet=True)
+    world, root = 8, str(tmp_path / 'many')
+    mp.spawn(_rank_many, args=(world, _free_port(), root, str(tmp_path), 'plain'), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(world)]
+    assert all(g['msg'] == 'ok' and g['partition'] == 'loci' for g in got), got
+    owned = sorted(i for g in got for i in g['set_up'])
+    assert owned == list(range(72))                       # every locus on exactly one rank
+    assert all(4 <= len(g['set_up']) <= 14 for g in got)   # ... and the ranks share them
+    assert all(g['lens'] == [n_reads[0], n_reads[35], n_reads[71]] for g in got)
+    for li, l1 in enumerate(one):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(l1.path, rel), os.path.join(root, f'locus{li}', rel), shallow=False), (li, rel)
+
+
+def test_locus_partition_a_failing_read_stops_every_rank_where_upstream_would_stop(tmp_path):
+    """Partition by locus, a read of locus 40 fails on the rank that owns it: that rank raises upstream's error, the others an
+    error naming it; the loci before 40 are complete on every rank, locus 40 and later ones are not written."""
+    import json
+    world, root = 4, str(tmp_path / 'many')
+    mp.spawn(_rank_many, args=(world, _free_port(), root, str(tmp_path), 'poison'), nprocs=world, join=True)
+    msgs = [json.load(open(tmp_path / f'rank{r}.json'))['msg'] for r in range(world)]
+    assert sum(m.startswith('ReadCallError') and 'L40_read000' in m for m in msgs) == 1, msgs
+    assert sum(m.startswith('RuntimeError') and 'L40_read000' in m for m in msgs) == world - 1, msgs
+    fasta = lambda li: os.path.exists(os.path.join(root, f'locus{li}', 'predictions', 'sequences', 'all.fasta'))
+    assert all(fasta(li) for li in range(40)) and not any(fasta(li) for li in range(40, 72))

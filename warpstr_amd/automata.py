@@ -9,7 +9,6 @@ Pattern grammar (src/caller/automata.py:57-150):
   plain bases, IUPAC codes (parallel alternatives), ``( .. )`` one-or-more loop,
   ``{ .. }`` optional block (the base before ``{`` also links to the first plain base after ``}``).
 """
-from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -90,21 +89,44 @@ def _nucleotide_graph(pattern: str) -> Tuple[List[str], List[List[int]], int, in
     return base, succ, rep_first, rep_last
 
 
-@dataclass
 class AutomatonTable:
     """Flat automaton: what the C ABI takes (include/warpstr_hip.h: wsx_automaton)."""
-    n_states: int
-    endstate: int
-    value: np.ndarray        # f64[S]  expected level per state
-    seq_idx: np.ndarray      # i32[S]  position of the state's last base in the expanded pattern
-    pred_ptr: np.ndarray     # i32[S+1] CSR offsets into pred_idx
-    pred_idx: np.ndarray     # i32[E]  predecessors in the reference's `incoming` order
-    repeat_mask: np.ndarray  # u8[S]
-    last_base: np.ndarray    # u8[S]  ASCII of the k-mer's last base
-    kmers: List[str] = field(default_factory=list)
-    succ: List[List[int]] = field(default_factory=list)
-    repstart: int = -1
-    repend: int = -1
+
+    def __init__(self, n_states: int, endstate: int, value: np.ndarray, seq_idx: np.ndarray, pred_ptr: np.ndarray,
+                 pred_idx: np.ndarray, repeat_mask: np.ndarray, last_base: np.ndarray, kmers: Optional[List[str]] = None,
+                 succ: Optional[List[List[int]]] = None, repstart: int = -1, repend: int = -1,
+                 kmer_codes: Optional[np.ndarray] = None, kmersize: int = 6):
+        self.n_states = n_states
+        self.endstate = endstate
+        self.value = value              # f64[S]  expected level per state
+        self.seq_idx = seq_idx          # i32[S]  position of the state's last base in the expanded pattern
+        self.pred_ptr = pred_ptr        # i32[S+1] CSR offsets into pred_idx
+        self.pred_idx = pred_idx        # i32[E]  predecessors in the reference's `incoming` order
+        self.repeat_mask = repeat_mask  # u8[S]
+        self.last_base = last_base      # u8[S]  ASCII of the k-mer's last base
+        self.repstart, self.repend = repstart, repend
+        self._kmers, self._succ = kmers, succ
+        self.kmer_codes, self.kmersize = kmer_codes, kmersize   # (the native compiler returns codes; the strings are made on demand)
+
+    @property
+    def kmers(self) -> List[str]:
+        if self._kmers is None:
+            if self.kmer_codes is None:
+                return []
+            k = self.kmersize
+            self._kmers = [''.join('ACGT'[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k)) for c in self.kmer_codes]
+        return self._kmers
+
+    @property
+    def succ(self) -> List[List[int]]:
+        """Successor states per state, ordered by target index (sources of `incoming`, transposed)."""
+        if self._succ is None:
+            out: List[List[int]] = [[] for _ in range(self.n_states)]
+            for j in range(self.n_states):
+                for p in self.pred_idx[self.pred_ptr[j]:self.pred_ptr[j + 1]]:
+                    out[int(p)].append(j)
+            self._succ = out
+        return self._succ
 
     @property
     def max_fanin(self) -> int:
@@ -114,9 +136,15 @@ class AutomatonTable:
         return [int(p) for p in self.pred_idx[self.pred_ptr[j]:self.pred_ptr[j + 1]]]
 
 
-def compile_automaton(pattern: str, pore_model: Optional[PoreModel] = None) -> AutomatonTable:
-    """Build the k-mer automaton of ``left flank + locus pattern + right flank``."""
+def compile_automaton(pattern: str, pore_model: Optional[PoreModel] = None, native: bool = True) -> AutomatonTable:
+    """Build the k-mer automaton of ``left flank + locus pattern + right flank``.  native=True: by the host library
+    (csrc/host_loci.cpp, the same tables 50 times faster; tests/test_host_native.py) when it is there and takes the pattern."""
     pm = pore_model or default_pore_model()
+    if native:
+        from . import _hostlib
+        table = _hostlib.compile_automaton(pattern, pm)
+        if table is not None:
+            return table
     k = pm.kmersize
     base, succ, rep_first, rep_last = _nucleotide_graph(pattern)
     n_nodes = len(base)

@@ -16,6 +16,8 @@ HEADERS = ['wsx_device.h', 'wsx_place.h', os.path.join('..', '..', 'include', 'w
 LIB = os.path.join(HERE, 'libwarpstr_hip.so')
 SEAM_SRC = os.path.join(CSRC, 'seam_helper.c')  # CPython-API loops of the Python seam (no compute); optional at run time
 SEAM_LIB = os.path.join(HERE, '_seam_helper.so')
+HOST_SRC = os.path.join(CSRC, 'host_loci.cpp')   # the per-locus host work (overview.csv, automata, output files): plain C++, no HIP
+HOST_LIB = os.path.join(HERE, '_host_loci.so')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fgpu-rdc' if False else '-fno-gpu-rdc']
 
@@ -52,6 +54,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if force or _stale(SEAM_LIB, [SEAM_SRC]):
         import sysconfig
         cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I', sysconfig.get_paths()['include'], SEAM_SRC, '-o', SEAM_LIB]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or _stale(HOST_LIB, [HOST_SRC]):
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-fvisibility=hidden', '-Wall',
+               HOST_SRC, '-o', HOST_LIB]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

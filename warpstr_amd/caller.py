@@ -659,6 +659,23 @@ def sequence_from_trace(table: AutomatonTable, flank_length: int, trace: np.ndar
     return seq.translate(_COMPLEMENT)[::-1] if reverse else seq
 
 
+def similarity_report(sequence: str, pore_model, min_state_similarity: float):
+    """(text of summaries/state_similarity.csv, upstream's warning lines, (template_problems, reverse_problems)) of a locus
+    pattern: CallerWrapper.check_high_similarity (src/caller/wrapper.py:122-160) without the side effects."""
+    from .automata import reverse_pattern
+    diffs_t = pore_model.get_diffs_for_all(sequence)
+    diffs_r = pore_model.get_diffs_for_all(reverse_pattern(sequence))
+    lines = ['pattern,strand,mean_diff,median_diff\n']
+    lines += [f'{k},template,{mean:.3f},{med:.3f}\n' for k, (mean, med) in diffs_t.items()]
+    lines += [f'{k},reverse,{mean:.3f},{med:.3f}\n' for k, (mean, med) in diffs_r.items()]
+    lim = min_state_similarity
+    problems = [[dict(pattern=k, mean_diff=mean, median_diff=med) for k, (mean, med) in d.items() if lim > mean or lim > med]
+                for d in (diffs_t, diffs_r)]
+    warnings = ['Warning: Template has repeat unit {} with high state similarity'.format(p['pattern']) for p in problems[0]]
+    warnings += ['Warning: high similarity of state values in reverse pattern {}'.format(p['pattern']) for p in problems[1]]
+    return ''.join(lines), warnings, (problems[0], problems[1])
+
+
 class CallerWrapper:
     """Step-3 driver for one locus (src/caller/wrapper.py:57-120).
 
@@ -705,27 +722,16 @@ class CallerWrapper:
         <locus.path>/summaries/state_similarity.csv (same columns and %.3f formatting), prints upstream's warnings for
         units whose mean or median level difference is below caller_config.min_state_similarity, and returns
         (template_problems, reverse_problems)."""
-        from .automata import reverse_pattern
-        diffs_t = self.pore_model.get_diffs_for_all(sequence)
-        diffs_r = self.pore_model.get_diffs_for_all(reverse_pattern(sequence))
+        text, warnings, problems = similarity_report(sequence, self.pore_model, self.caller_config.min_state_similarity)
         if out_dir is None and self.locus is not None and self._write_summaries:
             out_dir = os.path.join(self.locus.path, 'summaries')
         if out_dir is not None:
             os.makedirs(out_dir, exist_ok=True)
             with open(os.path.join(out_dir, 'state_similarity.csv'), 'w') as f:
-                f.write('pattern,strand,mean_diff,median_diff\n')
-                for k, (mean, med) in diffs_t.items():
-                    f.write(f'{k},template,{mean:.3f},{med:.3f}\n')
-                for k, (mean, med) in diffs_r.items():
-                    f.write(f'{k},reverse,{mean:.3f},{med:.3f}\n')
-        lim = self.caller_config.min_state_similarity
-        problems = [[dict(pattern=k, mean_diff=mean, median_diff=med) for k, (mean, med) in d.items() if lim > mean or lim > med]
-                    for d in (diffs_t, diffs_r)]
-        for p in problems[0]:
-            print('Warning: Template has repeat unit {} with high state similarity'.format(p['pattern']))
-        for p in problems[1]:
-            print('Warning: high similarity of state values in reverse pattern {}'.format(p['pattern']))
-        return problems[0], problems[1]
+                f.write(text)
+        for line in warnings:
+            print(line)
+        return problems
 
     def run(self, workload: List[ReadSignal]) -> 'CallerResults':
         """Run the caller for each piece of signal in the workload; results align with the workload."""

@@ -1,0 +1,820 @@
+// host_loci.cpp -- the per-LOCUS host work of step 3 as plain native code (no HIP, no Python API): built by
+// warpstr_amd/build.py into warpstr_amd/_host_loci.so and loaded with ctypes.CDLL, so every call runs WITHOUT the GIL and the
+// `threads` of main_wrapper_loci are threads of one process.
+//
+// Upstream does this work per locus in Python: the overview table through pandas (src/caller/overview.py:37-45, 57-115), two
+// StateAutomata (src/caller/automata.py:36-226), the FASTA files (overview.py:76-100), the complex-unit table
+// (src/caller/wrapper.py:220-248, overview.py:11-34).  A run of thousands of loci with tens of reads each spends 4-5 ms per
+// locus there, a hundred times what the GPU needs for the locus's reads.  The Python forms (warpstr_amd/automata.py,
+// overview.py, units.py) stay the definition -- they are what the fixtures recorded from upstream pin --; this file restates
+// them and tests/test_host_native.py holds the two against each other byte for byte.  Whatever this file is not sure to
+// reproduce (an overview.csv that pandas would re-format on its way through, a pattern the Python compiler raises on) it
+// REFUSES with a positive status and the caller takes the Python path for that locus.
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// repr(float): the shortest digits that round-trip (std::to_chars), laid out by CPython's rule for format code 'r'
+// (Python/pystrtod.c: format_float_short -- exponent form iff decpt <= -4 or decpt > 16, at least two exponent digits, ".0"
+// appended to a plain integer).  pandas writes a float64 column that way (DataFrame.to_csv without float_format).
+int format_repr(double x, char *out)
+{
+    if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) { if (x < 0) { memcpy(out, "-inf", 4); return 4; } memcpy(out, "inf", 3); return 3; }
+    char tmp[48];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, x, std::chars_format::scientific);
+    *r.ptr = 0;   // (to_chars does not terminate; atoi below reads the exponent)
+    const char *p = tmp, *end = r.ptr;
+    char *o = out;
+    if (*p == '-') { *o++ = '-'; p++; }
+    char digits[24] = {'0'};
+    int nd = 0;
+    const char *e = p;
+    while (e < end && *e != 'e') { if (*e != '.') digits[nd++] = *e; e++; }
+    const int ex = atoi(e + 1);       // value = d.ddd x 10^ex
+    const int decpt = ex + 1;         // value = 0.ddd x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        int ax = ex;
+        if (ax < 0) { *o++ = '-'; ax = -ax; } else *o++ = '+';
+        char eb[8];
+        int ne = 0;
+        do { eb[ne++] = char('0' + ax % 10); ax /= 10; } while (ax);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) *o++ = eb[--ne];
+    } else if (decpt <= 0) {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -decpt; i++) *o++ = '0';
+        memcpy(o, digits, nd); o += nd;
+    } else if (decpt >= nd) {
+        memcpy(o, digits, nd); o += nd;
+        for (int i = nd; i < decpt; i++) *o++ = '0';
+        *o++ = '.'; *o++ = '0';
+    } else {
+        memcpy(o, digits, decpt); o += decpt;
+        *o++ = '.';
+        memcpy(o, digits + decpt, nd - decpt); o += nd - decpt;
+    }
+    return int(o - out);
+}
+
+int format_int(int64_t v, char *out)
+{
+    auto r = std::to_chars(out, out + 24, v);
+    return int(r.ptr - out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pattern -> k-mer state automaton (warpstr_amd/automata.py, which follows src/caller/automata.py:57-226 node for node).
+const char *iupac(char c)
+{
+    switch (c) {  // src/templates.py:32-44
+    case 'R': return "AG"; case 'Y': return "CT"; case 'S': return "GC"; case 'W': return "AT"; case 'K': return "GT";
+    case 'M': return "AC"; case 'B': return "CGT"; case 'D': return "AGT"; case 'H': return "ACT"; case 'V': return "ACG";
+    case 'N': return "ACGT"; default: return nullptr;
+    }
+}
+
+int base_code(char c)
+{
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+struct LoopHead { bool many; int id; std::vector<int> ids; };
+
+struct Automaton {
+    int n_states = 0, endstate = -1, repstart = -1, repend = -1;
+    std::vector<double> value;
+    std::vector<int32_t> seq_idx, pred_ptr, pred_idx;
+    std::vector<uint8_t> repeat_mask, last_base;
+    std::vector<uint32_t> kmer;
+};
+
+struct KState { uint32_t code; int node, from; std::vector<std::pair<int, int>> next; };
+
+// 0 = built; 1 = the Python compiler would raise on this pattern (the caller lets it)
+int compile_automaton(const char *pat, int64_t n, const double *levels, int k, Automaton &A)
+{
+    if (n < 1 || k < 2 || k > 12) return 1;
+    std::vector<char> base{pat[0]};
+    std::vector<std::vector<int>> succ(1);
+    std::vector<int> tails{0}, opt_tails, pending;
+    std::vector<LoopHead> heads;
+    int rep_first = -1, rep_last = -1, nxt = 1;
+    for (int64_t i = 1; i < n; i++) {
+        const char ch = pat[i];
+        if (ch == '(') {
+            heads.push_back({false, nxt, {}});
+            if (rep_first == -1) rep_first = nxt;
+        } else if (ch == ')') {
+            rep_last = nxt;
+            if (heads.empty()) return 1;
+            LoopHead h = std::move(heads.back());
+            heads.pop_back();
+            for (int t : tails) {
+                if (h.many) succ[t].insert(succ[t].end(), h.ids.begin(), h.ids.end());
+                else succ[t].push_back(h.id);
+            }
+        } else if (ch == '{') {
+            opt_tails.push_back(nxt - 1);
+        } else if (ch == '}') {
+            if (opt_tails.empty()) return 1;
+            pending.push_back(opt_tails.back());
+            opt_tails.pop_back();
+        } else if (const char *alts = iupac(ch)) {
+            bool opens = !heads.empty() && !heads.back().many && heads.back().id == nxt;
+            opens = opens || (!opt_tails.empty() && opt_tails.back() == nxt);
+            std::vector<int> created;
+            for (const char *a = alts; *a; a++) {
+                base.push_back(*a);
+                succ.emplace_back();
+                created.push_back(nxt);
+                for (int t : tails) succ[t].push_back(nxt);
+                nxt++;
+            }
+            if (opens) {
+                if (heads.empty()) return 1;
+                heads.back().many = true;
+                heads.back().ids = created;
+            }
+            tails = created;
+        } else {
+            base.push_back(ch);
+            succ.emplace_back();
+            for (int t : tails) succ[t].push_back(nxt);
+            tails.assign(1, nxt);
+            for (int t : pending) succ[t].push_back(nxt);
+            pending.clear();
+            nxt++;
+        }
+    }
+    const int n_nodes = int(base.size());
+    if (n_nodes < k) return 1;
+    std::vector<int8_t> code(n_nodes);
+    for (int i = 0; i < n_nodes; i++) code[i] = int8_t(base_code(base[i]));
+
+    // k-mer states, bucketed by the node of their last base; depth first with an explicit LIFO stack
+    std::vector<KState> st;
+    std::vector<std::vector<int>> bucket(n_nodes);
+    const uint32_t tail_mod = 1u << (2 * (k - 1));
+    uint32_t first = 0;
+    for (int i = 0; i < k; i++) {
+        if (code[i] < 0) return 1;
+        first = first * 4 + uint32_t(code[i]);
+    }
+    st.push_back({first, k - 1, -1, {}});
+    bucket[k - 1].push_back(0);
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int cur = stack.back();
+        stack.pop_back();
+        const uint32_t tail = (st[cur].code % tail_mod) * 4;
+        const int cnode = st[cur].node;
+        for (int node : succ[cnode]) {
+            if (code[node] < 0) return 1;
+            const uint32_t km = tail + uint32_t(code[node]);
+            bool linked = false;
+            const std::vector<int> &b = bucket[node];
+            for (int slot = 0; slot < int(b.size()); slot++) {
+                if (st[b[slot]].code == km && st[b[slot]].from == cnode) {
+                    st[cur].next.emplace_back(node, slot);
+                    linked = true;
+                }
+            }
+            if (!linked) {
+                st[cur].next.emplace_back(node, int(bucket[node].size()));
+                bucket[node].push_back(int(st.size()));
+                stack.push_back(int(st.size()));
+                st.push_back({km, node, cnode, {}});
+            }
+        }
+    }
+
+    // flatten in node order
+    std::vector<int> base_of(n_nodes + 1, 0);
+    for (int i = 0; i < n_nodes; i++) base_of[i + 1] = base_of[i] + int(bucket[i].size());
+    const int S = base_of[n_nodes];
+    A.n_states = S;
+    A.repstart = rep_first;
+    A.repend = rep_last;
+    A.value.resize(S); A.seq_idx.resize(S); A.repeat_mask.resize(S); A.last_base.resize(S); A.kmer.resize(S);
+    std::vector<int> flat(st.size());
+    for (int nd = 0; nd < n_nodes; nd++)
+        for (int s = 0; s < int(bucket[nd].size()); s++) flat[bucket[nd][s]] = base_of[nd] + s;
+    std::vector<int32_t> fan(S + 1, 0);
+    for (int nd = 0; nd < n_nodes; nd++) {
+        for (int id : bucket[nd]) {
+            const int j = flat[id];
+            A.kmer[j] = st[id].code;
+            A.seq_idx[j] = nd;
+            A.value[j] = levels[st[id].code];
+            A.repeat_mask[j] = (rep_first - 1 <= nd && nd <= rep_last + 10) ? 1 : 0;
+            A.last_base[j] = uint8_t(base[nd]);
+            for (auto &e : st[id].next) fan[base_of[e.first] + e.second + 1]++;
+        }
+    }
+    A.endstate = bucket[n_nodes - 1].empty() ? -1 : S - 1;
+    A.pred_ptr.assign(S + 1, 0);
+    for (int j = 0; j < S; j++) A.pred_ptr[j + 1] = A.pred_ptr[j] + fan[j + 1];
+    A.pred_idx.resize(A.pred_ptr[S]);
+    std::vector<int32_t> fill(A.pred_ptr.begin(), A.pred_ptr.end() - 1);
+    for (int nd = 0; nd < n_nodes; nd++)       // sources in state order: `incoming` comes out ordered by source index
+        for (int id : bucket[nd])
+            for (auto &e : st[id].next) A.pred_idx[fill[base_of[e.first] + e.second]++] = flat[id];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// overview.csv without pandas.  The file goes through pandas twice upstream (read_csv, then to_csv with four columns
+// replaced); here the rows keep their TEXT and only the new columns are formatted -- which equals the pandas round trip exactly
+// when every cell is already written the way pandas would write it back.  classify() decides that per column, conservatively.
+enum Cell : uint8_t { C_EMPTY = 0, C_INT, C_FLOAT, C_BOOL, C_STR, C_BAD };
+enum Col : uint8_t { K_EMPTY = 0, K_INT, K_FLOAT, K_BOOL, K_BOOL_OBJ, K_STR, K_BAD };
+
+bool is_na_token(std::string_view s)
+{   // pandas' default NA strings (pandas/_libs/parsers.pyx: STR_NA_VALUES)
+    static const std::unordered_set<std::string_view> na = {"#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND",
+                                                            "1.#QNAN", "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+    return na.count(s) != 0;
+}
+
+bool ieq(std::string_view s, const char *lit)
+{
+    size_t n = strlen(lit);
+    if (s.size() != n) return false;
+    for (size_t i = 0; i < n; i++)
+        if (tolower((unsigned char)s[i]) != lit[i]) return false;
+    return true;
+}
+
+// pandas' default float converter (pandas/_libs/src/parser/tokenizer.c: precise_xstrtod, `float_precision=None` since pandas
+// 1.2): at most 17 digits -- leading zeros included -- accumulated in a double, then ONE multiplication or division by a cached
+// power of ten.  It is not correctly rounded, so a float column does not survive read_csv -> to_csv unchanged
+// ("0.0015732835352270625" comes back as "0.001573283535227"); the writer below sends every cell of a float column through
+// this function and repr(), which is what the pandas round trip does to it.
+double pandas_strtod(std::string_view s)
+{
+    static double e[309];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i <= 308; i++) {
+            char b[16];
+            snprintf(b, sizeof b, "1e%d", i);
+            e[i] = strtod(b, nullptr);
+        }
+        init = true;
+    }
+    const char *p = s.data(), *end = s.data() + s.size();
+    auto dig = [&](const char *q) { return q < end && *q >= '0' && *q <= '9'; };
+    bool negative = false;
+    if (p < end && *p == '-') { negative = true; p++; }
+    double number = 0.0;
+    int exponent = 0, num_digits = 0, num_decimals = 0;
+    const int max_digits = 17;
+    while (dig(p)) {
+        if (num_digits < max_digits) { number = number * 10. + (*p - '0'); num_digits++; }
+        else ++exponent;
+        p++;
+    }
+    if (p < end && *p == '.') {
+        p++;
+        while (num_digits < max_digits && dig(p)) { number = number * 10. + (*p - '0'); p++; num_digits++; num_decimals++; }
+        if (num_digits >= max_digits)
+            while (dig(p)) ++p;
+        exponent -= num_decimals;
+    }
+    if (negative) number = -number;
+    if (p < end && (*p == 'e' || *p == 'E')) {
+        bool neg = false;
+        ++p;
+        if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
+        int n = 0, nd = 0;
+        while (nd < max_digits && dig(p)) { n = n * 10 + (*p - '0'); nd++; p++; }
+        if (neg) exponent -= n; else exponent += n;
+    }
+    if (exponent > 308) return negative ? -HUGE_VAL : HUGE_VAL;
+    if (exponent > 0) number *= e[exponent];
+    else if (exponent < -308) {
+        if (exponent < -616) number = 0.;
+        else { number /= e[-308 - exponent]; number /= e[308]; }
+    } else number /= e[-exponent];
+    return number;
+}
+
+// -?digits+ ( . digits* )? ( [eE] [+-]? digits{1,3} )? with a '.' or an exponent present; or inf / -inf
+bool float_grammar(std::string_view s)
+{
+    if (s == "inf" || s == "-inf") return true;
+    size_t i = 0, n = s.size();
+    auto dig = [&](size_t q) { return q < n && s[q] >= '0' && s[q] <= '9'; };
+    if (i < n && s[i] == '-') i++;
+    if (!dig(i)) return false;
+    size_t nd = 0;
+    while (dig(i)) { i++; nd++; }
+    bool marked = false;
+    if (i < n && s[i] == '.') { marked = true; i++; while (dig(i)) { i++; nd++; } }
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        marked = true;
+        i++;
+        if (i < n && (s[i] == '+' || s[i] == '-')) i++;
+        size_t ne = 0;
+        while (dig(i)) { i++; ne++; }
+        if (ne < 1 || ne > 3) return false;
+    }
+    return marked && i == n && nd <= 40;
+}
+
+Cell classify_cell(std::string_view s, double *val)
+{
+    if (s.empty()) return C_EMPTY;
+    if (s == "True" || s == "False") { *val = s[0] == 'T'; return C_BOOL; }
+    if (is_na_token(s) || ieq(s, "true") || ieq(s, "false")) return C_BAD;   // pandas turns these into something else
+    // canonical int64: -?(0|[1-9][0-9]*), no "-0"
+    {
+        size_t i = 0;
+        const bool neg = s[0] == '-';
+        if (neg) i = 1;
+        if (i < s.size() && s.size() - i <= 18 && s[i] >= '0' && s[i] <= '9' && !(s[i] == '0' && (s.size() - i > 1 || neg))) {
+            int64_t v = 0;
+            size_t j = i;
+            for (; j < s.size() && s[j] >= '0' && s[j] <= '9'; j++) v = v * 10 + (s[j] - '0');
+            if (j == s.size()) { *val = double(neg ? -v : v); return C_INT; }
+        }
+    }
+    if (float_grammar(s)) {
+        if (s == "inf" || s == "-inf") *val = s[0] == '-' ? -HUGE_VAL : HUGE_VAL;
+        else *val = pandas_strtod(s);
+        return C_FLOAT;
+    }
+    // anything else strtod takes whole (after blanks) is a number to pandas too, or close enough to one not to be trusted as text
+    char buf[64];
+    if (s.size() < sizeof buf) {
+        memcpy(buf, s.data(), s.size());
+        buf[s.size()] = 0;
+        char *endp = nullptr;
+        (void)strtod(buf, &endp);
+        while (*endp == ' ' || *endp == '\t') endp++;
+        if (endp != buf && *endp == 0) return C_BAD;
+    } else {
+        bool digits_only = true;   // a very long token of digits and number punctuation: let pandas decide
+        for (char c : s) digits_only = digits_only && (isdigit((unsigned char)c) || c == '.' || c == '-' || c == '+' || c == 'e' || c == 'E');
+        if (digits_only) return C_BAD;
+    }
+    for (char c : s)
+        if (c == '"' || c == '\r' || c == '\n') return C_BAD;
+    if (s.front() == ' ' || s.back() == ' ' || s.front() == '\t' || s.back() == '\t') return C_BAD;
+    return C_STR;
+}
+
+struct Locus {
+    std::string text;                    // overview.csv as read
+    int n_rows = 0, n_cols = 0;
+    std::vector<int32_t> hb, he;         // header cells
+    std::vector<int32_t> cb, ce;         // data cells, row-major
+    std::vector<uint8_t> kind;           // per column (Col)
+    std::vector<double> num;             // numeric value of a cell (int / float / bool), row-major
+    std::vector<uint8_t> cls;            // per cell (Cell)
+    int c_name = -1, c_saved = -1, c_reverse = -1, c_lo = -1, c_hi = -1, c_run = -1, c_f5 = -1;
+    std::vector<int32_t> saved_rows;
+    std::vector<uint8_t> reverse;        // per saved row
+    std::vector<int64_t> lo, hi;         // per saved row
+    std::string names, runs, f5s;        // per saved row, back to back
+    std::vector<int64_t> names_off, runs_off, f5s_off;
+    std::string err;
+};
+
+std::string_view cell(const Locus &L, int r, int c) { return std::string_view(L.text).substr(L.cb[size_t(r) * L.n_cols + c], L.ce[size_t(r) * L.n_cols + c] - L.cb[size_t(r) * L.n_cols + c]); }
+std::string_view head(const Locus &L, int c) { return std::string_view(L.text).substr(L.hb[c], L.he[c] - L.hb[c]); }
+
+bool read_file(const char *path, std::string &out)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return false; }
+    out.resize(size_t(sb.st_size));
+    size_t got = 0;
+    while (got < out.size()) {
+        const ssize_t n = read(fd, &out[got], out.size() - got);
+        if (n <= 0) break;
+        got += size_t(n);
+    }
+    close(fd);
+    out.resize(got);
+    return true;
+}
+
+bool write_file(const std::string &path, const std::string &data)
+{
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return false;
+    size_t put = 0;
+    while (put < data.size()) {
+        const ssize_t n = write(fd, data.data() + put, data.size() - put);
+        if (n <= 0) { close(fd); return false; }
+        put += size_t(n);
+    }
+    return close(fd) == 0;
+}
+
+bool make_dirs(const std::string &path)
+{   // os.makedirs(path, exist_ok=True)
+    struct stat sb;
+    if (stat(path.c_str(), &sb) == 0) return S_ISDIR(sb.st_mode);
+    const size_t cut = path.find_last_of('/');
+    if (cut != std::string::npos && cut > 0 && !make_dirs(path.substr(0, cut))) return false;
+    return mkdir(path.c_str(), 0777) == 0 || errno == EEXIST;
+}
+
+// 0 ok; > 0: not sure to equal the pandas round trip (reason in L.err) -> the caller takes the pandas path
+int parse_overview(Locus &L)
+{
+    const std::string &t = L.text;
+    const size_t n = t.size();
+    if (n == 0 || t.back() != '\n') { L.err = "no final newline"; return 2; }
+    if (n >= (size_t(1) << 31)) { L.err = "file too large"; return 2; }
+    if (memchr(t.data(), '"', n) || memchr(t.data(), '\r', n)) { L.err = "quoted fields or carriage returns"; return 2; }
+    // header
+    size_t pos = 0;
+    {
+        size_t b = 0;
+        for (;; pos++) {
+            if (t[pos] == ',' || t[pos] == '\n') {
+                L.hb.push_back(int32_t(b));
+                L.he.push_back(int32_t(pos));
+                b = pos + 1;
+                if (t[pos] == '\n') break;
+            }
+        }
+        pos++;
+    }
+    L.n_cols = int(L.hb.size());
+    for (int c = 0; c < L.n_cols; c++) {
+        std::string_view h = head(L, c);
+        if (h.empty() || h.front() == ' ' || h.back() == ' ') { L.err = "empty or padded column name"; return 2; }
+        for (int d = 0; d < c; d++)
+            if (head(L, d) == h) { L.err = "duplicate column name"; return 2; }
+        if (h == "read_name") L.c_name = c;
+        else if (h == "saved") L.c_saved = c;
+        else if (h == "reverse") L.c_reverse = c;
+        else if (h == "l_start_raw") L.c_lo = c;
+        else if (h == "r_end_raw") L.c_hi = c;
+        else if (h == "run_id") L.c_run = c;
+        else if (h == "fast5_path") L.c_f5 = c;
+    }
+    if (L.c_name < 0 || L.c_saved < 0 || L.c_reverse < 0 || L.c_lo < 0 || L.c_hi < 0) { L.err = "a column the caller needs is missing"; return 3; }
+    // rows
+    while (pos < n) {
+        int c = 0;
+        size_t b = pos;
+        for (;; pos++) {
+            if (t[pos] == ',' || t[pos] == '\n') {
+                if (c >= L.n_cols) { L.err = "a row with too many fields"; return 2; }
+                L.cb.push_back(int32_t(b));
+                L.ce.push_back(int32_t(pos));
+                c++;
+                b = pos + 1;
+                if (t[pos] == '\n') break;
+            }
+        }
+        pos++;
+        if (c != L.n_cols) { L.err = c == 1 && L.ce.back() == L.cb.back() ? "blank line" : "a row with too few fields"; return 2; }
+        L.n_rows++;
+    }
+    // classify
+    L.cls.resize(L.cb.size());
+    L.num.assign(L.cb.size(), 0.0);
+    L.kind.resize(L.n_cols);
+    for (int c = 0; c < L.n_cols; c++) {
+        int cnt[6] = {0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < L.n_rows; r++) {
+            const size_t i = size_t(r) * L.n_cols + c;
+            L.cls[i] = classify_cell(cell(L, r, c), &L.num[i]);
+            cnt[L.cls[i]]++;
+        }
+        Col k;
+        if (cnt[C_BAD]) k = K_BAD;
+        else if (cnt[C_EMPTY] == L.n_rows) k = K_EMPTY;
+        else if (cnt[C_INT] == L.n_rows) k = K_INT;
+        else if (cnt[C_FLOAT] + cnt[C_INT] + cnt[C_EMPTY] == L.n_rows) k = K_FLOAT;   // ints beside floats or blanks: a float column
+        else if (cnt[C_BOOL] == L.n_rows) k = K_BOOL;
+        else if (cnt[C_BOOL] && cnt[C_BOOL] + cnt[C_EMPTY] == L.n_rows) k = K_BOOL_OBJ;
+        else if (cnt[C_STR] && cnt[C_STR] + cnt[C_EMPTY] == L.n_rows) k = K_STR;
+        else k = K_BAD;   // numbers beside text, booleans beside numbers
+        L.kind[c] = k;
+        if (k == K_FLOAT)
+            for (int r = 0; r < L.n_rows; r++) {
+                const size_t i = size_t(r) * L.n_cols + c;
+                if (L.cls[i] == C_INT) L.num[i] = pandas_strtod(cell(L, r, c));
+            }
+        if (k == K_BAD) { L.err = "column '" + std::string(head(L, c)) + "' would be re-formatted by pandas"; return 2; }
+    }
+    if (L.n_rows == 0) { L.err = "no rows"; return 2; }   // (pandas makes every column of an empty table `object`)
+    if (L.kind[L.c_name] == K_EMPTY || L.kind[L.c_name] == K_BOOL_OBJ || L.kind[L.c_name] == K_FLOAT) { L.err = "read names are not plain"; return 2; }
+    for (int c : {L.c_name, L.c_run, L.c_f5})   // str(nan) is what the Python path would make of a blank: leave those tables to it
+        for (int r = 0; c >= 0 && r < L.n_rows; r++)
+            if (L.cls[size_t(r) * L.n_cols + c] == C_EMPTY) { L.err = "blank read name / run_id / fast5_path"; return 3; }
+    // the columns the caller reads: np.asarray(df[col]).astype(bool / int64) of an int, float or bool column
+    auto truthy = [&](int c) { return L.kind[c] == K_INT || L.kind[c] == K_BOOL; };
+    if (!truthy(L.c_saved) || !truthy(L.c_reverse)) { L.err = "`saved` / `reverse` are not integer or boolean columns"; return 3; }
+    for (int c : {L.c_lo, L.c_hi})
+        if (L.kind[c] != K_INT && L.kind[c] != K_FLOAT) { L.err = "`l_start_raw` / `r_end_raw` are not numeric columns"; return 3; }
+    for (int r = 0; r < L.n_rows; r++) {
+        if (L.num[size_t(r) * L.n_cols + L.c_saved] == 0.0) continue;
+        const size_t i = size_t(r) * L.n_cols;
+        for (int c : {L.c_lo, L.c_hi}) {
+            const double v = L.num[i + c];
+            if (L.cls[i + c] == C_EMPTY || !(std::fabs(v) < 9.0e15)) { L.err = "a saved read without l_start_raw / r_end_raw"; return 3; }
+        }
+        L.saved_rows.push_back(r);
+        L.reverse.push_back(L.num[i + L.c_reverse] != 0.0);
+        L.lo.push_back(int64_t(L.num[i + L.c_lo]));   // (astype(int64) truncates towards zero, as the cast does)
+        L.hi.push_back(int64_t(L.num[i + L.c_hi]));
+    }
+    auto gather = [&](int c, std::string &blob, std::vector<int64_t> &off) {
+        off.push_back(0);
+        if (c < 0) return;
+        for (int r : L.saved_rows) {
+            blob.append(cell(L, r, c));
+            off.push_back(int64_t(blob.size()));
+        }
+    };
+    gather(L.c_name, L.names, L.names_off);
+    gather(L.c_run, L.runs, L.runs_off);
+    gather(L.c_f5, L.f5s, L.f5s_off);
+    return 0;
+}
+
+bool starts_with(std::string_view s, const char *p) { return s.size() >= strlen(p) && memcmp(s.data(), p, strlen(p)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+#define WSH_EXPORT __attribute__((visibility("default")))
+
+struct wsh_automaton {   // what AutomatonTable (warpstr_amd/automata.py) holds; arrays owned by the object behind `owner`
+    int32_t n_states, endstate, repstart, repend, n_edges, reserved;
+    const double *value;
+    const int32_t *seq_idx, *pred_ptr, *pred_idx;
+    const uint8_t *repeat_mask, *last_base;
+    const uint32_t *kmer;
+    void *owner;
+};
+
+struct wsh_overview_info {
+    int32_t n_rows, n_cols, n_saved, has_run_id, has_fast5_path, reserved;
+    const int32_t *saved_rows;
+    const uint8_t *reverse;
+    const int64_t *lo, *hi;
+    const char *names; const int64_t *names_off;
+    const char *runs; const int64_t *runs_off;
+    const char *f5s; const int64_t *f5s_off;
+};
+
+WSH_EXPORT int wsh_abi_version(void) { return 1; }
+
+WSH_EXPORT int wsh_format_float(double x, char *out) { return format_repr(x, out); }
+
+// status 0: *out filled (free with wsh_automaton_free); 1: the Python compiler would raise on this pattern -- run it
+WSH_EXPORT int wsh_automaton_compile(const char *pattern, int64_t len, const double *levels, int32_t k, wsh_automaton *out)
+{
+    Automaton *A = new Automaton;
+    const int rc = compile_automaton(pattern, len, levels, k, *A);
+    if (rc != 0) { delete A; return rc; }
+    out->n_states = A->n_states; out->endstate = A->endstate; out->repstart = A->repstart; out->repend = A->repend;
+    out->n_edges = int32_t(A->pred_idx.size()); out->reserved = 0;
+    out->value = A->value.data(); out->seq_idx = A->seq_idx.data(); out->pred_ptr = A->pred_ptr.data(); out->pred_idx = A->pred_idx.data();
+    out->repeat_mask = A->repeat_mask.data(); out->last_base = A->last_base.data(); out->kmer = A->kmer.data();
+    out->owner = A;
+    return 0;
+}
+
+WSH_EXPORT void wsh_automaton_free(wsh_automaton *a)
+{
+    delete static_cast<Automaton *>(a->owner);
+    a->owner = nullptr;
+}
+
+// <locus_path>/overview.csv read and parsed.  0: *out is a handle (wsh_locus_free); -1: no such file; > 0: the table is one
+// pandas might re-format or read differently (reason: wsh_locus_error) -- the handle is still returned for the message and the
+// caller takes the pandas path.
+WSH_EXPORT int wsh_locus_open(const char *overview_path, void **out)
+{
+    Locus *L = new Locus;
+    *out = L;
+    if (!read_file(overview_path, L->text)) { L->err = "cannot read the file"; return -1; }
+    return parse_overview(*L);
+}
+
+WSH_EXPORT const char *wsh_locus_error(void *h) { return static_cast<Locus *>(h)->err.c_str(); }
+
+WSH_EXPORT void wsh_locus_free(void *h) { delete static_cast<Locus *>(h); }
+
+WSH_EXPORT void wsh_locus_info(void *h, wsh_overview_info *o)
+{
+    const Locus &L = *static_cast<Locus *>(h);
+    o->n_rows = L.n_rows; o->n_cols = L.n_cols; o->n_saved = int32_t(L.saved_rows.size());
+    o->has_run_id = L.c_run >= 0; o->has_fast5_path = L.c_f5 >= 0; o->reserved = 0;
+    o->saved_rows = L.saved_rows.data(); o->reverse = L.reverse.data(); o->lo = L.lo.data(); o->hi = L.hi.data();
+    o->names = L.names.data(); o->names_off = L.names_off.data();
+    o->runs = L.runs.data(); o->runs_off = L.runs_off.data();
+    o->f5s = L.f5s.data(); o->f5s_off = L.f5s_off.data();
+}
+
+// The text of overview.csv (the bytes that were read), for the DataFrame a caller may ask for later.
+WSH_EXPORT const char *wsh_locus_text(void *h, int64_t *len)
+{
+    const Locus &L = *static_cast<Locus *>(h);
+    *len = int64_t(L.text.size());
+    return L.text.data();
+}
+
+// store_results (warpstr_amd/overview.py; src/caller/overview.py:48-115) for the locus behind `h`: the four result columns
+// (len2 -> results, len1 -> orig, cost1 -> dtw_cost1, cost2 -> dtw_cost2; -1 on rows that are not saved; a NaN cost is an empty
+// field) replace / join the table's columns the way DataFrame assignment does after the `result*` columns were dropped, and the
+// three FASTA files get the called sequences (seq2[off2[r] .. off2[r] + len2[r]) of saved read r).  flags: 1 = write overview.csv,
+// 2 = write the FASTA files.  If `table_out` is not NULL the new overview text is returned there (malloc'ed: wsh_free).
+// 0 = done; -2 = a file could not be written (wsh_locus_error).
+WSH_EXPORT int wsh_locus_store(void *h, const char *locus_path, const int32_t *len1, const int32_t *len2, const double *cost1,
+                               const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags, char **table_out,
+                               int64_t *table_len)
+{
+    Locus &L = *static_cast<Locus *>(h);
+    const int ns = int(L.saved_rows.size());
+    // output columns: the index first, then the surviving columns in their order, the four new ones in place or at the end
+    static const char *const NEW[4] = {"results", "orig", "dtw_cost1", "dtw_cost2"};
+    std::vector<int> src;   // >= 0: source column; -1 - k: new column k
+    for (int c = 0; c < L.n_cols; c++) {
+        if (c == L.c_name) continue;
+        std::string_view hd = head(L, c);
+        if (starts_with(hd, "result")) continue;
+        int k = -1;
+        for (int q = 1; q < 4; q++)
+            if (hd == NEW[q]) k = q;
+        src.push_back(k >= 0 ? -1 - k : c);
+    }
+    for (int k = 0; k < 4; k++)
+        if (std::find(src.begin(), src.end(), -1 - k) == src.end()) src.push_back(-1 - k);
+    std::string out;
+    out.reserve(L.text.size() + size_t(L.n_rows) * 64 + 64);
+    out.append("read_name");
+    for (int s : src) {
+        out.push_back(',');
+        if (s >= 0) out.append(head(L, s)); else out.append(NEW[-1 - s]);
+    }
+    out.push_back('\n');
+    char buf[48];
+    int next_saved = 0;
+    for (int r = 0; r < L.n_rows; r++) {
+        const bool sv = next_saved < ns && L.saved_rows[next_saved] == r;
+        out.append(cell(L, r, L.c_name));
+        for (int s : src) {
+            out.push_back(',');
+            if (s >= 0) {
+                const size_t i = size_t(r) * L.n_cols + s;
+                if (L.kind[s] == K_FLOAT && L.cls[i] != C_EMPTY) out.append(buf, size_t(format_repr(L.num[i], buf)));   // what pandas' parser made of it
+                else out.append(cell(L, r, s));
+                continue;
+            }
+            const int k = -1 - s;
+            int n;
+            if (k < 2) n = format_int(sv ? (k == 0 ? len2[next_saved] : len1[next_saved]) : -1, buf);
+            else {
+                const double v = sv ? (k == 2 ? cost1[next_saved] : cost2[next_saved]) : -1.0;
+                n = std::isnan(v) ? 0 : format_repr(v, buf);
+            }
+            out.append(buf, size_t(n));
+        }
+        out.push_back('\n');
+        next_saved += sv;
+    }
+    const std::string root(locus_path);
+    if (flags & 2) {
+        const std::string dir = root + "/predictions/sequences";
+        if (!make_dirs(dir)) { L.err = "cannot create " + dir; return -2; }
+        std::string all, tmpl, rev;
+        for (int i = 0; i < ns; i++) {
+            std::string rec(">");
+            rec.append(L.names.data() + L.names_off[i], size_t(L.names_off[i + 1] - L.names_off[i]));
+            rec.push_back('\n');
+            rec.append(reinterpret_cast<const char *>(seq2) + off2[i], size_t(len2[i] > 0 ? len2[i] : 0));
+            rec.append("\n\n");
+            all.append(rec);
+            (L.reverse[i] ? rev : tmpl).append(rec);
+        }
+        if (!write_file(dir + "/all.fasta", all) || !write_file(dir + "/sequences_template.fasta", tmpl) ||
+            !write_file(dir + "/sequences_reverse.fasta", rev)) { L.err = "cannot write the FASTA files under " + dir; return -2; }
+    }
+    if ((flags & 1) && !write_file(root + "/overview.csv", out)) { L.err = "cannot write " + root + "/overview.csv"; return -2; }
+    if (table_out) {
+        *table_out = static_cast<char *>(malloc(out.size() + 1));
+        memcpy(*table_out, out.data(), out.size());
+        (*table_out)[out.size()] = 0;
+        *table_len = int64_t(out.size());
+    }
+    return 0;
+}
+
+WSH_EXPORT void wsh_free(void *p) { free(p); }
+
+// collapse_repeats (warpstr_amd/units.py; src/caller/wrapper.py:220-248) for n called sequences at once and the table of
+// store_collapsed (overview.py:11-34) as CSV text with pandas' default index column.  units: n_units repeat units, unit u has
+// n_alt[u] alternative strings (alts, back to back; alt_off) and is preceded by offsets[u] plain bases.  counts (n x total alts,
+// row-major) receives every count.  header: the column names, comma separated, without the index column and the final newline.
+// flags 1: write <locus_path>/predictions/complexSTR_analysis/complex_repeat_units.csv.  Returns 0, or -2 (cannot write), or
+// 1 (an empty alternative: the Python form raises after its iteration limit -- let it).
+WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8_t *seq, const int64_t *off, const int32_t *len,
+                                  const uint8_t *reverse, int32_t n_units, const int32_t *n_alt, const char *alts,
+                                  const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t flags,
+                                  int64_t *counts, char **table_out, int64_t *table_len)
+{
+    int total = 0;
+    for (int u = 0; u < n_units; u++) total += n_alt[u];
+    for (int a = 0; a < total; a++)
+        if (alt_off[a + 1] == alt_off[a]) return 1;
+    std::string out;
+    out.reserve(size_t(n) * (8 + 4 * size_t(total)) + strlen(header) + 8);
+    out.push_back(',');
+    out.append(header);
+    out.push_back('\n');
+    char buf[32];
+    for (int i = 0; i < n; i++) {
+        const char *s = reinterpret_cast<const char *>(seq) + off[i];
+        int64_t rem = len[i] > 0 ? len[i] : 0;
+        int64_t *cnt = counts + size_t(i) * total;
+        std::fill(cnt, cnt + total, 0);
+        int a0 = 0;
+        for (int u = 0; u < n_units; u++) {
+            const int64_t skip = std::min<int64_t>(offsets[u], rem);   // slide = slide[off:]
+            s += skip;
+            rem -= skip;
+            while (rem > 0) {
+                int64_t adv = -1;
+                for (int k = 0; k < n_alt[u]; k++) {
+                    const int64_t al = alt_off[a0 + k + 1] - alt_off[a0 + k];
+                    if (al <= rem && memcmp(alts + alt_off[a0 + k], s, size_t(al)) == 0) {
+                        cnt[a0 + k]++;
+                        adv = al;   // the LAST matching alternative advances
+                    }
+                }
+                if (adv < 0) break;
+                s += adv;
+                rem -= adv;
+            }
+            a0 += n_alt[u];
+        }
+        out.append(buf, size_t(format_int(i, buf)));
+        a0 = 0;
+        for (int u = 0; u < n_units; u++) {
+            if (n_alt[u] > 1) {
+                int64_t sum = 0;
+                for (int k = 0; k < n_alt[u]; k++) sum += cnt[a0 + k];
+                out.push_back(',');
+                out.append(buf, size_t(format_int(sum, buf)));
+                for (int k = 1; k < n_alt[u]; k++) {
+                    out.push_back(',');
+                    out.append(buf, size_t(format_int(cnt[a0 + k], buf)));
+                }
+            } else {
+                out.push_back(',');
+                out.append(buf, size_t(format_int(cnt[a0], buf)));
+            }
+            a0 += n_alt[u];
+        }
+        out.append(reverse[i] ? ",True\n" : ",False\n");
+    }
+    if (flags & 1) {
+        const std::string dir = std::string(locus_path) + "/predictions/complexSTR_analysis";
+        if (!make_dirs(dir) || !write_file(dir + "/complex_repeat_units.csv", out)) return -2;
+    }
+    if (table_out) {
+        *table_out = static_cast<char *>(malloc(out.size() + 1));
+        memcpy(*table_out, out.data(), out.size());
+        (*table_out)[out.size()] = 0;
+        *table_len = int64_t(out.size());
+    }
+    return 0;
+}
+
+}  // extern "C"

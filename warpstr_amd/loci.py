@@ -9,48 +9,84 @@ reads of all loci form one list that is cut into mixed-locus batches (every read
 batches follow each other on the GPU while the host reads the next one's files, and each locus then gets exactly the
 outputs `main_wrapper` writes for it (overview.csv columns, FASTA files, complex-unit table, state_similarity.csv).
 
-Under `python -m torch.distributed.run --nproc-per-node N` (shard=True) the read list is dealt over the N GPUs by cost
-(samples x what a sample costs on the read's automaton, dist.slot_cost); every rank reads and calls only its share, two
-all-gathers return every record and called sequence to every rank, rank 0 writes.
+The per-locus host work -- overview.csv in and out, two automata, the FASTA files, the complex-unit table -- is native code
+without the GIL (csrc/host_loci.cpp through _hostlib; the Python / pandas forms of automata.py, overview.py and units.py are
+the definition and the fall-back for whatever the native code declines), so `threads` are THREADS of this process.
+
+Under `python -m torch.distributed.run --nproc-per-node N` (shard=True) the work is dealt over the N GPUs:
+  * many loci (>= 8 per rank): by LOCUS -- a rank parses, compiles, reads, calls and WRITES only its own loci (cost of a locus =
+    size of its overview.csv x what a sample costs on an automaton of its size); no result travels, one barrier at the end;
+  * few loci with many reads (configs[3]): by READ -- every rank sets up every locus, calls its share of the reads (samples x
+    dist.slot_cost), two all-gathers return every record and called sequence to every rank, rank 0 writes.
 """
+import collections.abc
 import os
+import sys
 import time
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Mapping, Optional, Sequence
 
 import numpy as np
 
-from . import overview as ov
-from .caller import BatchQueue, CallerConfig, CallerResults, HipCaller, RescalerConfig
+from . import _hostlib, overview as ov
+from .caller import BatchQueue, CallerConfig, CallerResults, HipCaller, ReadCallError, RescalerConfig, similarity_report
 from .fast5 import read_raw_signal
+
+LOCI_PER_RANK_FOR_LOCUS_PARTITION = 8
 
 
 class LocusJob:
-    """One locus of a multi-locus run: its overview, the rows that are called, its two automata."""
+    """One locus of a multi-locus run: the `saved` rows of its overview, its two automata, and later its outputs."""
 
-    def __init__(self, locus, pore_model, tm: Dict[str, float]):
+    def __init__(self, locus, pore_model, tm: Dict[str, float], caller_config: Optional[CallerConfig] = None, write: bool = False,
+                 native: bool = True):
         from .automata import locus_automata
         t0 = time.perf_counter()
         self.locus = locus
         self.sequence = locus.sequence.upper()
         self.flank_length = int(locus.flank_length)
-        self.overview_path, self.df_overview = ov.load_overview(locus.path)
-        df = self.df_overview
-        self.saved = np.flatnonzero(np.asarray(df['saved']).astype(bool))
-        take = lambda col, dt: np.asarray(df[col])[self.saved].astype(dt)
-        self.names = [str(x) for x in df.index.to_numpy()[self.saved]]
-        self.reverse = take('reverse', bool)
-        self.lo, self.hi = take('l_start_raw', np.int64), take('r_end_raw', np.int64)
-        self.run_id = np.asarray(df['run_id'])[self.saved] if 'run_id' in df.columns else None
-        self.fast5_path = np.asarray(df['fast5_path'])[self.saved] if 'fast5_path' in df.columns else None
+        self.overview_path = os.path.join(locus.path, ov.OVERVIEW_NAME)
+        self._df = None
+        self.native = _hostlib.NativeOverview.open(self.overview_path) if native else None
+        if self.native is not None:
+            nat = self.native
+            self.saved, self.names, self.reverse, self.lo, self.hi = nat.saved, nat.names, nat.reverse, nat.lo, nat.hi
+            self.run_id, self.fast5_path = nat.run_id, nat.fast5_path
+        else:  # the table goes through pandas, as upstream's does (src/caller/overview.py:37-45)
+            self.overview_path, df = ov.load_overview(locus.path)
+            self._df = df
+            self.saved = np.flatnonzero(np.asarray(df['saved']).astype(bool))
+            take = lambda col, dt: np.asarray(df[col])[self.saved].astype(dt)
+            self.names = [str(x) for x in df.index.to_numpy()[self.saved]]
+            self.reverse = take('reverse', bool)
+            self.lo, self.hi = take('l_start_raw', np.int64), take('r_end_raw', np.int64)
+            self.run_id = np.asarray(df['run_id'])[self.saved] if 'run_id' in df.columns else None
+            self.fast5_path = np.asarray(df['fast5_path'])[self.saved] if 'fast5_path' in df.columns else None
         t1 = time.perf_counter()
         lt, rt, lr, rr = ov.load_flanks(locus.path)
         self.temp_sta, self.rev_sta = locus_automata(lt, rt, lr, rr, self.sequence, pore_model)
-        tm['overview_s'] += t1 - t0
-        tm['automata_s'] += time.perf_counter() - t1
+        t2 = time.perf_counter()
+        # summaries/state_similarity.csv; upstream's warnings are printed by the caller, in the order of the loci
+        self.warnings: List[str] = []
+        if caller_config is not None:
+            text, self.warnings, _ = similarity_report(self.sequence, pore_model, caller_config.min_state_similarity)
+            if write:
+                out_dir = os.path.join(locus.path, 'summaries')
+                os.makedirs(out_dir, exist_ok=True)
+                with open(os.path.join(out_dir, 'state_similarity.csv'), 'w') as f:
+                    f.write(text)
+        tm['overview_s'] = tm.get('overview_s', 0.0) + t1 - t0
+        tm['automata_s'] = tm.get('automata_s', 0.0) + t2 - t1
+        tm['similarity_s'] = tm.get('similarity_s', 0.0) + time.perf_counter() - t2
 
     @property
     def n(self) -> int:
         return len(self.saved)
+
+    @property
+    def df_overview(self):
+        if self._df is None:
+            self._df = ov.table_from_text(self.native.text())
+        return self._df
 
     def fast5_of(self, k: int) -> str:
         from .wrapper import annot_fast5_path
@@ -94,35 +130,81 @@ def _muted(on: bool):
     return contextlib.redirect_stdout(io.StringIO()) if on else contextlib.nullcontext()
 
 
-def _similarity(job: LocusJob, caller_config: CallerConfig, pore_model, write: bool):
-    """summaries/state_similarity.csv and upstream's warnings (CallerWrapper.check_high_similarity)."""
-    from .caller import CallerWrapper
-    cw = CallerWrapper.__new__(CallerWrapper)  # only the similarity report of the class is used: no handle is created
-    cw.locus, cw.pore_model, cw.caller_config, cw._write_summaries = job.locus, pore_model, caller_config, write
-    cw.check_high_similarity(job.sequence)
+class LociTables(collections.abc.Sequence):
+    """What main_wrapper_loci returns: per locus the pair main_wrapper returns, (df_overview, df_collapsed) -- built when it is
+    looked at (a run of thousands of loci writes thousands of files and usually looks at none of the tables; a DataFrame costs
+    more than the files of its locus).  An entry is ('frames', df_overview, df_collapsed), ('text', overview CSV text, complex-unit
+    CSV text or None) or ('disk', locus path: another rank wrote it)."""
+
+    def __init__(self, entries: list):
+        self._e = entries
+
+    def __len__(self):
+        return len(self._e)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        e = self._e[i]
+        if e[0] == 'text':
+            import io
+
+            import pandas as pd
+            e = self._e[i] = ('frames', ov.table_from_text(e[1]), None if e[2] is None else pd.read_csv(io.StringIO(e[2]), index_col=0))
+        elif e[0] == 'disk':
+            import pandas as pd
+            cpath = os.path.join(e[1], ov.PREDICTIONS_SUBDIR, ov.COMPLEX_SUBDIR, 'complex_repeat_units.csv')
+            e = self._e[i] = ('frames', ov.load_overview(e[1])[1], pd.read_csv(cpath, index_col=0) if e[2] and os.path.exists(cpath) else None)
+        return e[1], e[2]
 
 
-# ---- the per-locus host work on several processes (threads > 1) --------------------------------------------------------------
-# Upstream's `threads` are Pool workers over the READS of one locus (src/caller/wrapper.py:104-109).  Here the reads are the
-# GPU's; what is left on the host is per LOCUS -- parsing its overview, compiling two automata, writing its CSV and FASTA
-# files: 4-5 ms of Python and pandas each, thousands of times -- and that is what `threads` spreads: over worker PROCESSES
-# (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and import pandas and this package's host
-# modules only).
-def _setup_chunk(args):
-    loci, caller_config, write, quiet = args
-    from .pore_model import default_pore_model
-    pm = default_pore_model()
-    tm = {'overview_s': 0.0, 'automata_s': 0.0}
-    jobs = []
-    for locus in loci:
-        job = LocusJob(locus, pm, tm)
-        with _muted(quiet or not write):
-            _similarity(job, caller_config, pm, write=write)
-        job.df_overview = None  # (not shipped to the parent and back: whoever writes the locus's files reads it again)
-        jobs.append(job)
-    return jobs, tm
+def _complex_header(units, repeat_units):
+    """Column names of store_collapsed's table (overview.py; src/caller/overview.py:11-34) without the trailing `reverse`, or
+    None when two columns would share a name (a dict keeps one of them: the pandas form decides which)."""
+    cols = []
+    for unit, alts in zip(units, repeat_units):
+        if len(alts) > 1:
+            cols.append('main_' + alts[0])
+            cols += ['inter_' + a[len(alts[0]):] for a in alts[1:]]
+        else:
+            cols.append(unit.strip('(').strip(')'))
+    if len(set(cols)) != len(cols) or 'reverse' in cols or any(',' in c or '"' in c or not c for c in cols):
+        return None
+    return ','.join(cols + ['reverse'])
 
 
+def _store_job(job: LocusJob, rec, seq1, off1, seq2, off2, write: bool):
+    """The outputs of one locus from its reads' records and called sequences (offsets into seq1 / seq2 per read): the files
+    main_wrapper writes (write=True) and the entry of LociTables.  Returns (entry, messages to print)."""
+    from .units import break_into_units
+    from .wrapper import _store_outputs
+    ok = rec['status'] == 0
+    if job.native is not None and bool(ok.all()):
+        l1, l2 = rec['len1'], rec['len2']
+        text = job.native.store(job.locus.path, l1, l2, rec['cost1'], rec['cost2'], seq2, off2, write)
+        units, repeat_units, offsets = break_into_units(job.sequence)
+        if len(units) <= 1:
+            return ('text', text, None), []
+        header = _complex_header(units, repeat_units) if job.n > 0 else None
+        got = _hostlib.collapse_store(job.locus.path, seq2, off2, l2, job.reverse, repeat_units, offsets, header, write) if header else None
+        if got is not None:
+            return ('text', text, got[1]), [f'Running complex genotyping as complex repeat units present: {units}']
+        # (the complex-unit table through pandas; overview.csv and the FASTA files are written)
+        from .units import collapse_repeats
+        s2 = bytes(seq2).decode('ascii', 'replace')
+        called = [s2[o:o + n] for o, n in zip(np.asarray(off2).tolist(), np.asarray(l2).tolist())]
+        df_collapsed = ov.store_collapsed([collapse_repeats(s, repeat_units, offsets) for s in called], units, repeat_units,
+                                          [bool(v) for v in job.reverse], job.locus.path, write=write)
+        return ('frames', ov.table_from_text(text), df_collapsed), [f'Running complex genotyping as complex repeat units present: {units}']
+    results = CallerResults(job.names, rec, off1, seq1, seq2, 'raise', offsets2=off2).check()
+    with _muted(not write):
+        dfo, dfc = _store_outputs(job.locus, job.overview_path, job.df_overview, results, [bool(v) for v in job.reverse], write=write)
+    return ('frames', dfo, dfc), []
+
+
+# ---- fast5 files on worker processes -----------------------------------------------------------------------------------------
+# Opening a file, HDF5 and zstd take about a millisecond per read, and libhdf5 is not thread-safe: the one part of the host work
+# that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state).
 def _read_chunk(items):
     """Raw reads of (annotated fast5 path, multi-read fall-back path or None, read name) triples, as LocusJob.raw_read finds them."""
     out = []
@@ -134,21 +216,6 @@ def _read_chunk(items):
     return out
 
 
-def _store_chunk(args):
-    from .wrapper import _store_outputs
-    out = []
-    for (locus, overview_path, df_overview, names, reverse, rec, s1, s2, write, quiet) in args:
-        if df_overview is None:
-            overview_path, df_overview = ov.load_overview(locus.path)
-        l1 = np.where(rec['status'] == 0, rec['len1'], 0).astype(np.int64)
-        l2 = np.where(rec['status'] == 0, rec['len2'], 0).astype(np.int64)
-        o1, o2 = np.cumsum(l1) - l1, np.cumsum(l2) - l2
-        results = CallerResults(names, rec, o1, s1, s2, 'raise', offsets2=o2)
-        with _muted(quiet or not write):
-            out.append(_store_outputs(locus, overview_path, df_overview, results, [bool(v) for v in reverse], write=write))
-    return out
-
-
 class _WorkerPool:
     """`n` worker processes (`python -m warpstr_amd._hostworker`) and an ordered map over them.  Not multiprocessing's pool:
     its spawned children import the parent's main module again, which a library cannot ask of every script that calls it, and
@@ -156,7 +223,6 @@ class _WorkerPool:
 
     def __init__(self, n: int):
         import subprocess
-        import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
         self.procs = [subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
@@ -164,7 +230,8 @@ class _WorkerPool:
         self._max_workers = n
 
     def map(self, func, items):
-        """[func(item) for item in items] on the workers (func: a module-level function of this module), in order."""
+        """[func(item) for item in items] on the workers (func: a module-level function of this module), in order.  An error
+        raised inside `func` on a worker is raised here (RuntimeError with the worker's traceback)."""
         import pickle
         import threading
         items = list(items)
@@ -210,53 +277,91 @@ class _WorkerPool:
         self.procs = []
 
 
-def _pool(threads: int, n_loci: int, n_reads: int = 0):
-    """A pool of worker processes for the per-locus host work, or None (one thread; too little work -- fewer than 64 loci and,
-    for the output files, fewer than 250 000 reads: starting the workers takes about a second, which the files of 50 000 reads
-    do not --; or no way to start one)."""
-    if threads <= 1 or (n_loci < 64 and (n_loci < 2 or n_reads < 250000)):
+def _reader_pool(threads: int, n_loci: int):
+    """Worker processes for the fast5 files of a run, or None: one thread, or fewer than 64 loci (starting the workers takes
+    about a second).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported
+    once and the files are read in this process; what a worker raises while reading is raised by _WorkerPool.map."""
+    if threads <= 1 or n_loci < 64:
         return None
     try:
         return _WorkerPool(min(int(threads), os.cpu_count() or 1))
-    except (ImportError, OSError, ValueError):
+    except OSError as e:
+        print(f'warpstr_amd: could not start {threads} reader processes ({e}); reading the fast5 files in this process', file=sys.stderr)
         return None
 
 
-def main_wrapper_loci(loci: Sequence, threads: int = 1, **kwargs):
-    """Step 3 for every locus of `loci` through one handle: see _main_wrapper_loci (this wrapper owns the worker processes of
-    the per-locus host work, so that they end with the call however it ends)."""
-    pools = [_pool(threads, len(loci))]
+def _thread_map(executor, func, items):
+    """[func(x) for x in items], on the executor's threads if there is one; the first exception is raised here."""
+    if executor is None:
+        return [func(x) for x in items]
+    return list(executor.map(func, items))
+
+
+def partition_loci(loci: Sequence, world: int) -> List[np.ndarray]:
+    """Which rank owns which locus (sorted index arrays per rank), derived alike on every rank without opening a table: cost of
+    a locus = bytes of its overview.csv (proportional to its reads) x the cost of a sample on an automaton of about its size
+    (dist.slot_cost of 2 x flank + pattern length), dealt greedily, most expensive first (dist.shard_reads)."""
+    from . import dist as wdist
+    cost = np.ones(len(loci), np.int64)
+    per_sample = np.ones(len(loci), np.float64)
+    for i, locus in enumerate(loci):
+        try:
+            cost[i] = max(os.path.getsize(os.path.join(locus.path, ov.OVERVIEW_NAME)), 1)
+        except OSError:
+            pass  # (the rank that owns it raises upstream's error for the missing table)
+        per_sample[i] = wdist.slot_cost(2 * int(locus.flank_length) + len(locus.sequence))
+    return wdist.shard_reads(cost, world, per_sample)
+
+
+def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
+                      rescaler_config: Optional[RescalerConfig] = None,
+                      signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
+                      raw_reader: Callable[[str], np.ndarray] = read_raw_signal,
+                      raw_reads: Optional[Mapping[str, np.ndarray]] = None, pore_model=None, device: int = 0, shard: bool = False,
+                      partition: str = 'auto', batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
+                      timings: Optional[Dict[str, float]] = None, quiet: bool = False, native: bool = True, _engine=None):
+    """Step 3 (src/caller/wrapper.py:17-41) for every locus of `loci` -- objects with `.path`, `.sequence`, `.flank_length`
+    (upstream's Locus, src/schemas/locus.py) -- through one handle.  Returns a LociTables: [(df_overview, df_collapsed), ...] in
+    the order of `loci` (built when looked at), and writes, per locus, exactly what main_wrapper writes.
+
+    signal_loader(fast5path, l_start_raw, r_end_raw) -> normalised float64 segment replaces the GPU loader (default: the int16
+    reads go up and are prepared on the device); raw_reader(fast5path) -> int16 read replaces the fast5 reader; raw_reads: a
+    mapping read name -> int16 read for reads that are in host memory already (no per-read call-back).
+    pore_model: a pore_model.PoreModel (default: the built-in r9.4 table; `pore_model_path` of a configuration).
+    batch_*: where the read list is cut -- a batch holds at most that many reads, segment samples and raw bytes.
+    threads: threads of the per-locus host work (native code without the GIL: overview, automata, output files); with more than
+    one thread and 64 loci or more the fast5 files are read on as many worker processes.
+    shard=True: the run is one torch.distributed job.  partition: 'loci' = every rank takes whole loci, 'reads' = every rank
+    takes its share of every locus's reads, 'auto' = 'loci' from LOCI_PER_RANK_FOR_LOCUS_PARTITION loci per rank on.
+    timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure."""
+    pools: list = []
+    executor = None
+    if threads and int(threads) > 1 and len(loci) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        executor = ThreadPoolExecutor(max_workers=min(int(threads), 64))
     try:
-        return _main_wrapper_loci(loci, threads, pools, **kwargs)
-    finally:
+        return _main_wrapper_loci(loci, int(threads or 1), pools, executor, caller_config=caller_config, rescaler_config=rescaler_config,
+                                  signal_loader=signal_loader, raw_reader=raw_reader, raw_reads=raw_reads, pore_model=pore_model,
+                                  device=device, shard=shard, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
+                                  batch_raw_bytes=batch_raw_bytes, timings=timings, quiet=quiet, native=native, _engine=_engine)
+    finally:  # the threads and the reader processes end with the call, however it ends
+        if executor is not None:
+            executor.shutdown(wait=True)
         for pool in pools:
             if pool is not None:
                 pool.shutdown()
 
 
-def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_config: Optional[CallerConfig] = None,
-                       rescaler_config: Optional[RescalerConfig] = None,
-                       signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
-                       raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False,
-                       batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
-                       timings: Optional[Dict[str, float]] = None, quiet: bool = False, _engine=None):
-    """Step 3 (src/caller/wrapper.py:17-41) for every locus of `loci` -- objects with `.path`, `.sequence`, `.flank_length`
-    (upstream's Locus, src/schemas/locus.py) -- through one handle.  Returns [(df_overview, df_collapsed), ...] in the order of
-    `loci` and writes, per locus, exactly what main_wrapper writes.
-
-    signal_loader(fast5path, l_start_raw, r_end_raw) -> normalised float64 segment replaces the GPU loader (default: the int16
-    reads go up and are prepared on the device); raw_reader(fast5path) -> int16 read replaces the fast5 reader.
-    batch_*: where the read list is cut -- a batch holds at most that many reads, segment samples and raw bytes.
-    threads: worker processes for the per-locus host work (overview, automata, output files) from 64 loci on; the reads
-    themselves are the GPU's.  shard=True: the run is one torch.distributed job, every rank takes its share of the reads.
-    timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure."""
+def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescaler_config, signal_loader, raw_reader, raw_reads, pore_model,
+                       device, shard, partition, batch_reads, batch_samples, batch_raw_bytes, timings, quiet, native, _engine):
     from . import dist as wdist
     from .pore_model import default_pore_model
-    from .wrapper import _store_outputs
     t_start = time.perf_counter()
     tm = timings if timings is not None else {}
-    for key in ('overview_s', 'automata_s', 'handle_s', 'read_s', 'submit_s', 'collect_s', 'gather_s', 'store_s'):
+    for key in ('overview_s', 'automata_s', 'similarity_s', 'handle_s', 'read_s', 'submit_s', 'collect_s', 'gather_s', 'store_s'):
         tm[key] = 0.0
+    if partition not in ('auto', 'loci', 'reads'):
+        raise ValueError("partition must be 'auto', 'loci' or 'reads'")
     caller_config = caller_config or CallerConfig()
     rank, world = wdist.process_group() if shard else (0, 1)
     collective = shard and (world > 1 or wdist.force_collectives())
@@ -269,196 +374,231 @@ def _main_wrapper_loci(loci: Sequence, threads: int, pools: list, *, caller_conf
         if tdist.get_backend() == 'nccl':
             torch.cuda.set_device(local_gpu)
             coll_device = torch.device('cuda', local_gpu)
-    pore_model = default_pore_model()
+    pore_model = pore_model or default_pore_model()
+    by_locus = collective and (partition == 'loci' or (partition == 'auto' and len(loci) >= LOCI_PER_RANK_FOR_LOCUS_PARTITION * world))
+    tm['partition'] = 'loci' if by_locus else ('reads' if collective else 'none')
+    tm['host_threads'] = threads if executor is not None else 1
 
-    # ---- per locus: overview, flanks, automata (every rank: the partition below is derived from them) ---------------
+    # ---- whose loci: all of them, or (partition by locus) this rank's ------------------------------------------------------
+    if by_locus:
+        own = partition_loci(loci, world)[rank]
+    else:
+        own = np.arange(len(loci))
+    tm['loci_set_up'] = [int(i) for i in own]
+    writes = rank == 0 or by_locus   # (by locus: a rank writes its own loci; by read: rank 0 writes everything)
+    fast5_on_workers = signal_loader is None and raw_reader is read_raw_signal and raw_reads is None
+    pool = _reader_pool(threads, len(own)) if fast5_on_workers else None   # (started first: they import while the set-up runs)
+    pools.append(pool)
+    tm['reader_processes'] = pool._max_workers if pool is not None else 0
+
+    # ---- per locus: overview, flanks, automata, state_similarity.csv --------------------------------------------------------
+    error = None
     jobs: List[LocusJob] = []
-    pool = pools[0]
-    tm['host_processes'] = pool._max_workers if pool is not None else 1
-    if pool is not None:
-        try:
-            step = max(8, min(64, len(loci) // (4 * pool._max_workers) or 8))
-            parts = [list(loci[k:k + step]) for k in range(0, len(loci), step)]
-            t0 = time.perf_counter()
-            for part_jobs, part_tm in pool.map(_setup_chunk, [(p, caller_config, rank == 0, quiet) for p in parts]):
-                jobs += part_jobs
-                for key, v in part_tm.items():
-                    tm[key + '_cpu'] = tm.get(key + '_cpu', 0.0) + v
-            tm['overview_s'] = tm['automata_s'] = 0.0
-            tm['setup_wall_s'] = time.perf_counter() - t0
-        except Exception:  # noqa: BLE001 -- a locus object that does not pickle, a worker that died: do it here
-            pool, jobs = None, []
-            tm['host_processes'] = 1
-    if pool is None:
-        for locus in loci:
-            job = LocusJob(locus, pore_model, tm)
-            with _muted(quiet or rank != 0):  # (upstream prints its similarity warnings once per locus)
-                _similarity(job, caller_config, pore_model, write=rank == 0)
-            jobs.append(job)
+    t0 = time.perf_counter()
+    try:
+        step = max(1, min(64, len(own) // (4 * max(tm['host_threads'], 1)) or 1))
+        parts = [own[k:k + step] for k in range(0, len(own), step)]
+
+        def setup(part):
+            ptm: Dict[str, float] = {}
+            return [LocusJob(loci[i], pore_model, ptm, caller_config, write=writes, native=native) for i in part], ptm
+        for part_jobs, ptm in _thread_map(executor, setup, parts):
+            jobs += part_jobs
+            for key, v in ptm.items():
+                tm[key] += v   # (CPU seconds, summed over the threads)
+    except Exception as e:  # noqa: BLE001 -- agreed on below
+        if not collective:
+            raise
+        error = e
+    tm['setup_wall_s'] = time.perf_counter() - t0
+    if collective:
+        wdist.agree_or_raise(error, world, coll_device, 'setting up the loci')
+    if not quiet and writes:
+        for job in jobs:
+            for line in job.warnings:
+                print(line)
     first = np.zeros(len(jobs) + 1, np.int64)
     np.cumsum([j.n for j in jobs], out=first[1:])
     n_total = int(first[-1])
     tm['n_loci'], tm['n_reads'] = len(jobs), n_total
-    if n_total == 0:
-        out = [_store_outputs(j.locus, *(ov.load_overview(j.locus.path) if j.df_overview is None else (j.overview_path, j.df_overview)), [], [],
-                              write=rank == 0) for j in jobs]
-        if collective:
-            tdist.barrier()
-        tm['total_s'] = time.perf_counter() - t_start
-        return out
+    tm['native_overviews'] = sum(j.native is not None for j in jobs)
 
-    # ---- the global read list: (locus, row) -> automaton, cost ----------------------------------------------------------
-    locus_of = np.repeat(np.arange(len(jobs)), [j.n for j in jobs])
-    row_of = np.concatenate([np.arange(j.n) for j in jobs])
-    reverse = np.concatenate([j.reverse for j in jobs])
-    lo, hi = np.concatenate([j.lo for j in jobs]), np.concatenate([j.hi for j in jobs])
-    aut = (2 * locus_of + reverse).astype(np.int32)
-    span = (hi - lo + 1).clip(min=1)
-    n_states = np.array([s.n_states for j in jobs for s in (j.temp_sta, j.rev_sta)])
-    if collective:
-        shards = wdist.shard_reads(span + wdist.READ_OVERHEAD_SAMPLES, world, np.array([wdist.slot_cost(s) for s in n_states])[aut])
-    else:
-        shards = [np.arange(n_total)]
-    mine = shards[rank]
+    records = np.zeros(0, dtype=_result_dtype())
+    seq1 = seq2 = np.zeros(0, np.uint8)
+    off1 = off2 = np.zeros(1, np.int64)
+    if n_total == 0 and collective:
+        wdist.agree_or_raise(None, world, coll_device, 'reading / calling the reads')   # (the other ranks are in this collective)
+    if n_total > 0:
+        # ---- the read list: (locus, row) -> automaton, cost ---------------------------------------------------------------
+        counts = [j.n for j in jobs]
+        locus_of = np.repeat(np.arange(len(jobs)), counts)
+        row_of = np.concatenate([np.arange(c) for c in counts]) if jobs else np.zeros(0, np.int64)
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+        reverse = cat([j.reverse for j in jobs], bool)
+        lo, hi = cat([j.lo for j in jobs], np.int64), cat([j.hi for j in jobs], np.int64)
+        aut = (2 * locus_of + reverse).astype(np.int32)
+        span = (hi - lo + 1).clip(min=1)
+        if collective and not by_locus:
+            n_states = np.array([s.n_states for j in jobs for s in (j.temp_sta, j.rev_sta)])
+            shards = wdist.shard_reads(span + wdist.READ_OVERHEAD_SAMPLES, world, np.array([wdist.slot_cost(s) for s in n_states])[aut])
+        else:
+            shards = [np.arange(n_total)] * max(rank + 1, 1)
+        mine = shards[rank]
+        whole = len(mine) == n_total
+        all_names = None
+        if raw_reads is not None:
+            all_names = [nm for j in jobs for nm in j.names]
 
-    # ---- rank-local: one handle, mixed-locus batches one behind the other ----------------------------------------------
-    error = None
-    records = np.zeros(len(mine), dtype=_result_dtype())
-    seqs = [[], []]
-    try:
-        t0 = time.perf_counter()
-        queue = (_engine or HipEngine)([s for j in jobs for s in (j.temp_sta, j.rev_sta)], [j.flank_length for j in jobs for _ in range(2)],
-                                       caller_config, rescaler_config, local_gpu)
-        tm['handle_s'] += time.perf_counter() - t0
-        # cut the rank's reads (in global order) into batches
-        raw_budget = batch_raw_bytes // 2
-        cuts, a, smp = [0], 0, 0
-        for k, g in enumerate(mine):
-            if k > a and (k - a >= batch_reads or smp + span[g] > batch_samples):
-                cuts.append(k)
-                a, smp = k, 0
-            smp += int(span[g])
-        cuts.append(len(mine))
-        pending = []  # (ticket, first, count)
+        # ---- rank-local: one handle, mixed-locus batches one behind the other ------------------------------------------
+        error = None
+        records = np.zeros(len(mine), dtype=_result_dtype())
+        seqs = [[], []]
+        try:
+            t0 = time.perf_counter()
+            queue = None
+            if len(mine):
+                queue = (_engine or HipEngine)([s for j in jobs for s in (j.temp_sta, j.rev_sta)],
+                                               [j.flank_length for j in jobs for _ in range(2)], caller_config, rescaler_config, local_gpu)
+            tm['handle_s'] += time.perf_counter() - t0
+            # cut the rank's reads (in global order) into batches: at most batch_reads reads and batch_samples segment samples
+            raw_budget = batch_raw_bytes // 2
+            csum = np.cumsum(span[mine])
+            cuts, a = [0], 0
+            while a < len(mine):
+                base = int(csum[a - 1]) if a else 0
+                b = int(np.searchsorted(csum, base + batch_samples, side='right'))
+                a = max(a + 1, min(a + batch_reads, b))
+                cuts.append(a)
+            pending = []  # (ticket, first, count)
 
-        def finish(ticket, b0, b1):
-            t1 = time.perf_counter()
-            rec, s1, p1, s2, p2 = queue.collect(ticket)
-            tm['collect_s'] += time.perf_counter() - t1
-            records[b0:b1] = rec
-            seqs[0].append(s1)
-            seqs[1].append(s2)
+            def finish(ticket, b0, b1):
+                t1 = time.perf_counter()
+                rec, s1, p1, s2, p2 = queue.collect(ticket)
+                tm['collect_s'] += time.perf_counter() - t1
+                records[b0:b1] = rec
+                seqs[0].append(s1)
+                seqs[1].append(s2)
 
-        b = 0
-        while b < len(cuts) - 1:
-            b0, b1 = cuts[b], cuts[b + 1]
-            t1 = time.perf_counter()
-            data, raw_bytes = [], 0
-            if pool is not None and signal_loader is None and raw_reader is read_raw_signal and b1 - b0 >= 64:
-                # the fast5 files of a batch on the worker processes (opening a file, HDF5 and the VBZ decoder take about a
-                # millisecond per read: in one process more than everything else of a many-loci run together)
-                items = []
-                for k in range(b0, b1):
-                    job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
-                    items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
-                step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
-                for part in pool.map(_read_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
-                    data += part
-                keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
-                while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
-                    acc += data[keep].nbytes
-                    keep += 1
-                if keep < len(data):
-                    cuts.insert(b + 1, b0 + keep)
-                    b1 = b0 + keep
-                    del data[keep:]
-            else:
-                for k in range(b0, b1):
-                    g = mine[k]
-                    job = jobs[locus_of[g]]
-                    if signal_loader is None:
-                        data.append(job.raw_read(int(row_of[g]), raw_reader))
-                        raw_bytes += data[-1].nbytes
-                        if raw_bytes > raw_budget and k + 1 < b1:  # long raw reads: close the batch early
-                            cuts.insert(b + 1, k + 1)
-                            b1 = k + 1
-                            break
-                    else:
-                        data.append(np.asarray(signal_loader(job.fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
-            tm['read_s'] += time.perf_counter() - t1
-            t1 = time.perf_counter()
-            sel = mine[b0:b1]
-            if signal_loader is None:
-                ticket = queue.submit_raw(data, lo[sel], hi[sel], aut[sel])
-            else:
-                ticket = queue.submit_signals(data, aut[sel])
-            tm['submit_s'] += time.perf_counter() - t1
-            pending.append((ticket, b0, b1))
-            if len(pending) > 2:  # at most three batches' buffers in HBM / in flight
+            b = 0
+            while b < len(cuts) - 1:
+                b0, b1 = cuts[b], cuts[b + 1]
+                t1 = time.perf_counter()
+                data, raw_bytes = [], 0
+                if raw_reads is not None:
+                    sel_names = all_names[b0:b1] if whole else [all_names[g] for g in mine[b0:b1]]
+                    data = [raw_reads[nm] for nm in sel_names]
+                elif pool is not None and b1 - b0 >= 64:
+                    # the fast5 files of a batch on the worker processes
+                    items = []
+                    for k in range(b0, b1):
+                        job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
+                        items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
+                    step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
+                    for part in pool.map(_read_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
+                        data += part
+                elif signal_loader is None:
+                    for k in range(b0, b1):
+                        g = mine[k]
+                        data.append(jobs[locus_of[g]].raw_read(int(row_of[g]), raw_reader))
+                else:
+                    for k in range(b0, b1):
+                        g = mine[k]
+                        data.append(np.asarray(signal_loader(jobs[locus_of[g]].fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
+                if signal_loader is None:
+                    keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
+                    while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
+                        acc += data[keep].nbytes
+                        keep += 1
+                    if keep < len(data):
+                        cuts.insert(b + 1, b0 + keep)
+                        b1 = b0 + keep
+                        del data[keep:]
+                tm['read_s'] += time.perf_counter() - t1
+                t1 = time.perf_counter()
+                sel = mine[b0:b1]
+                if signal_loader is None:
+                    ticket = queue.submit_raw(data, lo[sel], hi[sel], aut[sel])
+                else:
+                    ticket = queue.submit_signals(data, aut[sel])
+                tm['submit_s'] += time.perf_counter() - t1
+                pending.append((ticket, b0, b1))
+                if len(pending) > 2:  # at most three batches' buffers in HBM / in flight
+                    finish(*pending.pop(0))
+                b += 1
+            while pending:
                 finish(*pending.pop(0))
-            b += 1
-        while pending:
-            finish(*pending.pop(0))
-        tm.update(queue.info())
-        queue.close()
-    except Exception as e:  # noqa: BLE001 -- agreed on below: no rank may wait in a collective for one that failed
-        error = e
-    if collective or error is not None:
-        wdist.agree_or_raise(error, world if collective else 1, coll_device, 'reading / calling the reads')
+            if queue is not None:
+                tm.update(queue.info())
+                queue.close()
+        except Exception as e:  # noqa: BLE001 -- agreed on below: no rank may wait in a collective for one that failed
+            error = e
+        if collective or error is not None:
+            wdist.agree_or_raise(error, world if collective else 1, coll_device, 'reading / calling the reads')
 
-    # ---- the complete table, on every rank ---------------------------------------------------------------------------------
-    t0 = time.perf_counter()
-    ok = records['status'] == 0
-    l1 = np.where(ok, records['len1'], 0).astype(np.int64)
-    l2 = np.where(ok, records['len2'], 0).astype(np.int64)
-    off1, off2 = np.zeros(len(mine) + 1, np.int64), np.zeros(len(mine) + 1, np.int64)
-    np.cumsum(l1, out=off1[1:])
-    np.cumsum(l2, out=off2[1:])
-    seq1 = np.concatenate(seqs[0]) if seqs[0] else np.zeros(0, np.uint8)
-    seq2 = np.concatenate(seqs[1]) if seqs[1] else np.zeros(0, np.uint8)
-    if collective:
-        local = CallerResults([], records, off1[:-1], seq1, seq2, 'nan', offsets2=off2[:-1])
-        records, seq1, off1, seq2, off2 = wdist.gather_called(local, mine, shards, n_total, world, coll_device)
-    else:
-        off1, off2 = off1[:-1], off2[:-1]
-    tm['gather_s'] += time.perf_counter() - t0
+        # ---- the complete table of this rank's loci ---------------------------------------------------------------------------
+        t0 = time.perf_counter()
+        ok = records['status'] == 0
+        l1 = np.where(ok, records['len1'], 0).astype(np.int64)
+        l2 = np.where(ok, records['len2'], 0).astype(np.int64)
+        off1, off2 = np.zeros(len(mine) + 1, np.int64), np.zeros(len(mine) + 1, np.int64)
+        np.cumsum(l1, out=off1[1:])
+        np.cumsum(l2, out=off2[1:])
+        seq1 = np.concatenate(seqs[0]) if seqs[0] else np.zeros(0, np.uint8)
+        seq2 = np.concatenate(seqs[1]) if seqs[1] else np.zeros(0, np.uint8)
+        if collective and not by_locus:
+            local = CallerResults([], records, off1[:-1], seq1, seq2, 'nan', offsets2=off2[:-1])
+            records, seq1, o1, seq2, o2 = wdist.gather_called(local, mine, shards, n_total, world, coll_device)
+            off1, off2 = np.append(o1, len(seq1)), np.append(o2, len(seq2))
+        tm['gather_s'] += time.perf_counter() - t0
 
     # ---- per locus: the outputs of main_wrapper -------------------------------------------------------------------------------
     t0 = time.perf_counter()
-    out = []
     # the first read a caller failed on ends the run where upstream's loop would have ended: the loci before it are written
     bad = np.flatnonzero(records['status'] != 0)
     n_good = int(np.searchsorted(first, bad[0], side='right') - 1) if len(bad) else len(jobs)
-    if pool is None:  # few loci with many reads each: the output files are worth a pool of their own
-        pool = _pool(threads, n_good, n_total)
-        pools.append(pool)
-        if pool is not None:
-            tm['host_processes'] = pool._max_workers
-    if pool is not None and n_good >= 2:
-        end1 = np.append(off1, len(seq1)) if len(off1) == n_total else off1
-        end2 = np.append(off2, len(seq2)) if len(off2) == n_total else off2
-        items = []
-        for li, job in enumerate(jobs[:n_good]):
-            a, b = int(first[li]), int(first[li + 1])
-            items.append((job.locus, job.overview_path, job.df_overview, job.names, job.reverse, records[a:b],
-                          seq1[int(end1[a]):int(end1[b])], seq2[int(end2[a]):int(end2[b])], rank == 0, quiet))
-        step = max(1, min(64, len(items) // (4 * pool._max_workers) or 1))
-        for part in pool.map(_store_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
-            out += part
-    for li in range(len(out), len(jobs)):
+    first_bad = int(own[n_good]) if n_good < len(jobs) else len(loci)   # (index in `loci`)
+    if by_locus:
+        first_bad = int(wdist.gather_counts(first_bad, world, coll_device).min())
+        n_good = int(np.searchsorted(own, first_bad))
+
+    def store(li):
         job = jobs[li]
-        if job.df_overview is None:
-            job.overview_path, job.df_overview = ov.load_overview(job.locus.path)
         a, b = int(first[li]), int(first[li + 1])
-        results = CallerResults(job.names, records[a:b], off1[a:b], seq1, seq2, 'raise', offsets2=off2[a:b]).check()
-        with _muted(quiet or rank != 0):
-            out.append(_store_outputs(job.locus, job.overview_path, job.df_overview, results, [bool(v) for v in job.reverse],
-                                      write=rank == 0))
+        s1, s2 = seq1[int(off1[a]):int(off1[b])], seq2[int(off2[a]):int(off2[b])]
+        return _store_job(job, records[a:b], s1, off1[a:b] - off1[a], s2, off2[a:b] - off2[a], writes)
+
+    entries: list = [None] * len(loci)
+    error = None
+    try:
+        native_ids = [li for li in range(n_good) if jobs[li].native is not None]
+        done = dict(zip(native_ids, _thread_map(executor, store, native_ids)))
+        for li in range(n_good):  # (tables that went through pandas: here, one after the other)
+            entry, messages = done[li] if li in done else store(li)
+            entries[int(own[li])] = entry
+            if not quiet and writes:
+                for line in messages:
+                    print(line)
+        if n_good < len(jobs) and int(own[n_good]) == first_bad:
+            store(n_good)   # raises upstream's error for the locus's first failed read
+    except Exception as e:  # noqa: BLE001
+        if not collective:
+            raise
+        error = e
     tm['store_s'] += time.perf_counter() - t0
     if collective:
+        wdist.agree_or_raise(error, world, coll_device, 'writing the outputs')
+        if first_bad < len(loci):  # (another rank's locus: it has raised ReadCallError, agree_or_raise named it here)
+            raise ReadCallError(f'a read of locus {getattr(loci[first_bad], "path", first_bad)} could not be called')
         tdist.barrier()  # the files are complete when any rank returns
+    for i in range(len(loci)):
+        if entries[i] is None:   # another rank's locus: its files say everything
+            units_gt1 = sum(ch == '(' for ch in loci[i].sequence) > 0
+            entries[i] = ('disk', loci[i].path, units_gt1)
+    for job in jobs:
+        if job.native is not None:
+            job.native.close()
     tm['total_s'] = time.perf_counter() - t_start
-    return out
+    return LociTables(entries)
 
 
 def _result_dtype():

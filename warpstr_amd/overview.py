@@ -24,6 +24,15 @@ def load_overview(locus_path: str):
     return overview_path, df
 
 
+def table_from_text(text: str):
+    """The DataFrame load_overview would give for a file with this content."""
+    import io
+    df = pd.read_csv(io.StringIO(text))
+    df.set_index('read_name', inplace=True)
+    df.columns = df.columns.map(str)
+    return df
+
+
 def load_flanks(locus_path: str) -> Tuple[str, str, str, str]:
     """(left_template, right_template, left_reverse, right_reverse) from expected_signals/sequences.csv."""
     path = os.path.join(locus_path, LOCUS_INFO_SUBDIR, LOCUS_FLANKS)

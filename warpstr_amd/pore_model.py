@@ -79,31 +79,67 @@ class PoreModel:
     def _get_consecutive_diff(self, pattern: str):
         """Mean and median |difference| between the expected levels of consecutive k-mers of a repeated unit
         (src/squiggler/pore_model.py:34-43).  Like upstream, a one-base unit runs past the repeated pattern
-        (IndexError there; here too)."""
-        rep = pattern * self.kmersize
-        kmers = [rep[i:self.kmersize + i] for i in range(len(pattern) + 1)]
-        if any(len(k) != self.kmersize for k in kmers):
-            raise IndexError(f'repeat unit {pattern!r} is too short for {self.kmersize}-mers')
-        pore_values = np.abs(np.diff([self.get_value(k) for k in kmers]))
-        return np.mean(pore_values), np.median(pore_values)
+        (IndexError there; here too).  np.mean / np.median of the handful of values are restated on Python floats (NumPy's
+        pairwise sum: one accumulator below eight values, eight above; the median as the mean of the middle pair) -- the same
+        doubles, a tenth of the time: this runs for every unit of every locus of a run (tests/test_host_logic.py holds the two
+        forms against each other)."""
+        k = self.kmersize
+        rep = pattern * k
+        if len(pattern) + k > len(rep):
+            raise IndexError(f'repeat unit {pattern!r} is too short for {k}-mers')
+        level = self.level_norm
+        vals = [float(level[kmer_code(rep[i:k + i])]) for i in range(len(pattern) + 1)]
+        diffs = [abs(b - a) for a, b in zip(vals, vals[1:])]
+        n = len(diffs)
+        if n == 0 or n > 128:
+            arr = np.abs(np.diff(vals))
+            return np.mean(arr), np.median(arr)
+        ordered = sorted(diffs)
+        med = ordered[n // 2] if n & 1 else (ordered[n // 2 - 1] + ordered[n // 2]) / 2.0
+        return np.float64(_pairwise_sum(diffs) / n), np.float64(med)
 
     def get_diffs_for_all(self, sequence: str):
         """{unit: (mean_diff, median_diff)} for every bracketed unit of a locus pattern, IUPAC codes expanded
         (src/squiggler/pore_model.py:49-71; same insertion order, later duplicates overwrite earlier ones)."""
-        import re
-        iupac = {'R': 'AG', 'Y': 'CT', 'S': 'GC', 'W': 'AT', 'K': 'GT', 'M': 'AC', 'B': 'CGT', 'D': 'AGT', 'H': 'ACT', 'V': 'ACG',
-                 'N': 'ACGT'}  # src/templates.py:32-44
         diffs = {}
-        for r in re.findall(r'[\(\{].*?[\)\}]', sequence):
+        for r in _UNIT_RE.findall(sequence):
             patterns = ['']
             for char in (c for c in r if c not in '(){}'):
-                if char not in iupac:
+                if char not in _IUPAC:
                     patterns = [p + char for p in patterns]
                 else:
-                    patterns = [p + alt for alt in iupac[char] for p in patterns]
+                    patterns = [p + alt for alt in _IUPAC[char] for p in patterns]
             for p in patterns:
                 diffs[p] = self._get_consecutive_diff(p)
         return diffs
+
+
+import re  # noqa: E402
+
+_UNIT_RE = re.compile(r'[\(\{].*?[\)\}]')
+_IUPAC = {'R': 'AG', 'Y': 'CT', 'S': 'GC', 'W': 'AT', 'K': 'GT', 'M': 'AC', 'B': 'CGT', 'D': 'AGT', 'H': 'ACT', 'V': 'ACG',
+          'N': 'ACGT'}  # src/templates.py:32-44
+
+
+def _pairwise_sum(a):
+    """np.add.reduce of up to 128 doubles (numpy/core/src/umath/loops_utils.h.src: pairwise_sum)."""
+    n = len(a)
+    if n < 8:
+        res = 0.0
+        for x in a:
+            res += x
+        return res
+    r = list(a[:8])
+    i = 8
+    while i < n - (n % 8):
+        for j in range(8):
+            r[j] += a[i + j]
+        i += 8
+    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+    while i < n:
+        res += a[i]
+        i += 1
+    return res
 
 
 _default: Optional[PoreModel] = None
