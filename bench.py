@@ -438,6 +438,12 @@ def make_locus_dirs(root, specs, reads_per_locus, seed):
     return loci, raws
 
 
+def scratch_dir():
+    """Where the driver legs put their locus directories: memory-backed when the box has it (the legs time this package's host
+    work, not the container's overlay file system: five small files per locus)."""
+    return '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+
+
 def _driver_timings(tm, n_loci):
     per = lambda k: tm.get(k, 0.0) / max(n_loci, 1) * 1e3
     return {'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads', 1), 'reader_processes': tm.get('reader_processes', 0),
@@ -445,7 +451,7 @@ def _driver_timings(tm, n_loci):
             # CPU time per locus (summed over the threads when there are several), and the wall-clock of the two phases
             'per_locus_ms': {'overview_csv': per('overview_s'), 'automaton_compile': per('automata_s'), 'state_similarity': per('similarity_s'),
                              'setup_wall': per('setup_wall_s'), 'outputs_wall': per('store_s')},
-            'once_s': {'handle_create_placement': tm['handle_s']},
+            'once_s': {'handle_create_placement': tm['handle_s'], 'inside_wsx_caller_create': tm.get('handle_create_s')},
             'batches_s': {'host_reads': tm['read_s'], 'submit': tm['submit_s'], 'wait_for_gpu': tm['collect_s']},
             'workspace_bytes': tm.get('workspace_bytes'), 'workspace_limit_bytes': tm.get('workspace_limit_bytes'),
             'kernels': tm.get('kernels')}
@@ -462,7 +468,7 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
     import tempfile
 
     from warpstr_amd.wrapper import main_wrapper_loci
-    root = tempfile.mkdtemp(prefix='wsx_many_loci_')
+    root = tempfile.mkdtemp(prefix='wsx_many_loci_', dir=scratch_dir())
     try:
         specs = [(f'locus{i:04d}', MANY_LOCI_PATTERNS[i % len(MANY_LOCI_PATTERNS)], 110, (2271, 3701), 5000 + i) for i in range(n_loci)]
         t0 = time.perf_counter()
@@ -483,7 +489,7 @@ def many_loci_leg(n_loci, reads_per_locus, n_loop, local):
         main_wrapper_loci(loci, workers, raw_reads=raws, device=local, quiet=True, timings=tm)
         n_reads = n_loci * reads_per_locus
         out = {'workload': f'{n_loci} loci x {reads_per_locus} reads, flank 110, {len(MANY_LOCI_PATTERNS)} patterns '
-                           f'({", ".join(MANY_LOCI_PATTERNS[:3])}, ...), T in [2271, 3701], raw int16 reads in host memory -> output files',
+                           f'({", ".join(MANY_LOCI_PATTERNS[:3])}, ...), T in [2271, 3701], raw int16 reads in host memory -> output files (under ' + (scratch_dir() or 'the default temporary directory') + ')',
                'loci': n_loci, 'reads': n_reads, 'loci_per_s': n_loci / tm['total_s'], 'reads_per_s': n_reads / tm['total_s'],
                'one_handle': _driver_timings(tm, n_loci),
                'one_handle_one_thread': dict(_driver_timings(tm1, n_loci), loci_per_s=n_loci / tm1['total_s'], reads_per_s=n_reads / tm1['total_s']),
@@ -540,7 +546,7 @@ def cfg5_driver_leg(reads_per_locus, local):
     import tempfile
 
     from warpstr_amd.wrapper import main_wrapper_loci
-    root = tempfile.mkdtemp(prefix='wsx_cfg5_')
+    root = tempfile.mkdtemp(prefix='wsx_cfg5_', dir=scratch_dir())
     try:
         specs = [(f'locus{i}', p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i) for i, p in enumerate(CFG5_PATTERNS)]
         loci, raws = make_locus_dirs(root, specs, reads_per_locus, 78)
@@ -555,48 +561,8 @@ def cfg5_driver_leg(reads_per_locus, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def generated_fill_leg(wl, local, device, steps, warmup, builtin_records):
-    """The headline workload with the fill GENERATED per automaton and compiled at run time (warpstr_amd/fillgen.py; round 2's
-    "read in four lanes" experiment as a product path: ragged lengths, corner cut, masks, its own traceback).  Same clock rules
-    as the headline; its records must equal the built-in kernels' byte for byte."""
-    import torch
-
-    from warpstr_amd import _lib
-    from warpstr_amd.caller import HipCaller
-    n = wl.n
-    t0 = time.perf_counter()
-    hip = HipCaller(wl.tables, wl.flanks, device=local, stream=torch.cuda.current_stream().cuda_stream, generated_fill=True)
-    setup_s = time.perf_counter() - t0
-    got = {a: v for a, v in hip.generated.items()}
-    if not got or not all(isinstance(v, dict) for v in got.values()):
-        hip.close()
-        return {'skipped': f'no generated fill: {got}'}
-    res = [torch.zeros((n, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
-    hip.set_pipelined(True)
-    for k in range(warmup):
-        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
-    hip.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        hip.call_device(wl.signal.data_ptr(), wl.offsets, wl.aut, res[k % N_BUF].data_ptr())
-    hip.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    rec = res[(steps - 1) % N_BUF].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
-    out = {'ms_per_step': dt / steps * 1e3, 'value': n * steps / dt, 'unit': 'reads/s', 'steps': steps,
-           'kernels': sorted({hip.kernel_name(a) for a in range(len(wl.tables))}), 'handle_setup_s': setup_s,
-           'automata': {str(a): v for a, v in got.items()},
-           'identical_to_builtin': bool(rec.tobytes() == np.ascontiguousarray(builtin_records).tobytes()),
-           'note': 'opt-in (HipCaller(generated_fill=True)); per round of 32 768 reads 1.44 ms unmasked / 2.05 ms masked against '
-                   '1.67 / 1.69 ms of dtw_fill_fast (profiles/r04_generated_fill_variants.log): the mask select per state and the '
-                   '16-reads-per-wave granularity cost what the missing predecessor exchange saves'}
-    hip.close()
-    return out
-
-
 def optional_leg(leg, *a):
-    """A leg above the kernels (the product driver, the opt-in generated fill) must not take the headline line down with it: an
+    """A leg above the kernels (the product driver) must not take the headline line down with it: an
     exception becomes {'failed': ...} in its place (a result that DIFFERS still fails the run: the callers check that)."""
     try:
         return leg(*a)
@@ -622,11 +588,6 @@ def main():
                          '(reported under "secondary"); this switch leaves them out')
     ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
                     help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
-    ap.add_argument('--generated-fill', action='store_true',
-                    help='automata of at most 64 states get their DP fill generated and compiled at run time (warpstr_amd/fillgen.py: '
-                         'a read in four lanes) instead of the built-in kernel; the default run times that variant as '
-                         'secondary.generated_fill')
-    ap.add_argument('--generated-passes', type=int, default=3, help='with --generated-fill: 1 = the unmasked pass only, 2 = the masked pass only, 3 = both')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
@@ -700,10 +661,7 @@ def main():
     n_pad = (n_total + world - 1) // world if strong else n  # all_gather_into_tensor wants equal shards
     stream = torch.cuda.current_stream().cuda_stream
     hip = HipCaller(wl.tables, wl.flanks, device=local, stream=stream,  # the library's defaults unless asked otherwise
-                    workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None,
-                    generated_fill=bool(args.generated_fill))
-    if args.generated_fill:
-        hip.set_tuning('generated_passes', args.generated_passes)
+                    workspace_limit=int(args.workspace_limit_gib * (1 << 30)) or None)
     # Result buffers: the all-gather of step k runs on a side stream while the kernels of step k+1 already fill the
     # next buffer (the collective moves 56 B per read and rank over xGMI: latency-bound, nothing for the CUs to do).
     res_bufs = [torch.zeros((n_pad, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device) for _ in range(N_BUF)]
@@ -817,9 +775,6 @@ def main():
                                    f', {wl.desc}, both passes',
                        'name': wl.name, 'reads_per_gpu': n, 'reads_total': n_total, 'mean_samples_per_read': samples / n,
                        'states': S, 'called_ok': ok_all, 'workspace_limit_bytes': workspace['limit_bytes'],
-                       'fill': ({'kind': 'generated per automaton (warpstr_amd/fillgen.py), compiled at run time',
-                                 'automata': {str(k): v for k, v in hip.generated.items()}} if any(isinstance(v, dict) for v in hip.generated.values())
-                                else {'kind': 'built-in'}),
                        'chunk_plan': {'chunks_per_call': launches_total / args.steps / 2.0 / max(len(kernels), 1), 'streams': 4,
                                       'pipelined_calls_in_flight': 2 if n >= 32768 else 4},
                        'results_gather': ((f'{backend} all_gather of 56-B records per step' +
@@ -886,10 +841,6 @@ def main():
                     rc = 3
                     print(f"bench.py: secondary workload {name}: {leg['verified']['mismatches']} reads differ from the oracle", file=sys.stderr)
             out['secondary']['from_raw'] = out['from_raw']
-            out['secondary']['generated_fill'] = optional_leg(generated_fill_leg, wl, local, device, max(5, args.steps // 2), 3, mine)
-            if out['secondary']['generated_fill'].get('identical_to_builtin') is False:
-                rc = 3
-                print('bench.py: the generated fill and the built-in kernels disagree', file=sys.stderr)
             # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
             out['secondary']['cfg5']['through_driver'] = optional_leg(cfg5_driver_leg, 6250, local)
             if args.many_loci > 0:

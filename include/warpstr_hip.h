@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 10
+#define WSX_ABI_VERSION 11
 
 /* function return codes */
 enum {
@@ -160,8 +160,7 @@ enum {
     WSX_TUNE_CHUNKS = 5,               /* > 0: chunks per call instead of the built-in rule (also WSX_CHUNKS at creation); 0 */
     WSX_TUNE_SMALL_PIPE_SAMPLES = 6,   /* pipelined calls up to this many samples stay in one chunk; 52 Mi */
     WSX_TUNE_CALLS_IN_FLIGHT = 7,      /* pipelined calls the host may run ahead of the device, 2..4; 2 */
-    WSX_TUNE_SMALL_CALLS_IN_FLIGHT = 8, /* ... for one-chunk calls, 2..4; 4 */
-    WSX_TUNE_GENERATED_PASSES = 9      /* automata with a generated fill use it in: 1 the unmasked pass, 2 the masked pass, 3 both; 3 */
+    WSX_TUNE_SMALL_CALLS_IN_FLIGHT = 8 /* ... for one-chunk calls, 2..4; 4 */
 };
 int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value);
 
@@ -284,30 +283,11 @@ int wsx_caller_fill_intervals(wsx_caller *c, double *begin_ms, double *end_ms, i
                               int32_t *n_out);
 
 /*
- * A DP fill generated for ONE automaton (warpstr_amd/fillgen.py writes the source -- a read in four lanes, straight-line code
- * over the automaton's states, no predecessor exchange -- and compiles it at run time with hiprtc or `hipcc --genco`): the
- * code object and the tables of its back-pointer layout.  Same arithmetic per cell as the built-in fills (upstream
- * _calc_dtw_astates, src/caller/caller.py:198-245); automata of at most 64 states, min_values_per_state 4.
+ * Where wsx_caller_create spent its time, in seconds (a handle for all loci of a run holds thousands of automata: placing
+ * their states is host work).  seconds[0] validation and sizing, [1] state placement (wsx_place.h, on host threads),
+ * [2] packing the tables, [3] upload, [4] streams and events; at most `capacity` entries are written.  No upstream counterpart.
  */
-typedef struct wsx_generated_fill {
-    int32_t abi;               /* 1 */
-    int32_t words_per_row;     /* 64-bit back-pointer words per row of a wavefront (16 reads); even */
-    int32_t states_per_lane;   /* n: position p = lane_in_quad * n + register, 4 n >= S */
-    int32_t end_position;      /* position of the automaton's end state */
-    const void *code;          /* gfx950 code object with kernels wsx_fill_t_u (unmasked pass) and wsx_fill_t_m (masked pass) */
-    uint64_t code_size;
-    const uint16_t *state_at;  /* [4 n] position -> state id, 0xFFFF = none */
-    const uint8_t *tb_n;       /* [4 n] candidates of the position's state */
-    const uint16_t *tb_word;   /* [4 n * 4] word of the row that holds candidate f's compare mask */
-    const uint16_t *tb_pred;   /* [4 n * 4] position of predecessor f */
-} wsx_generated_fill;
-
-/*
- * Attach (g != NULL) or remove (g == NULL) the generated fill of automaton `automaton`: its reads then take that kernel and
- * the traceback over its words instead of the built-in variant (wsx_caller_kernel_name: "wsx_fill_t_u").  Results are the
- * same either way.  Host pointers; everything is copied.  Not while a call of the handle is in flight.
- */
-int wsx_caller_set_generated_fill(wsx_caller *c, int32_t automaton, const wsx_generated_fill *g);
+int wsx_caller_create_times(const wsx_caller *c, double *seconds, int32_t capacity);
 
 /* Name of the DP fill kernel variant used for automaton `a` (for profiles), e.g. "dtw_fill_fast<4, 1, 2, 2>". */
 const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a);

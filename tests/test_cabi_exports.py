@@ -31,7 +31,7 @@ def test_exports_match_header(lib):
     assert declared and sorted(_lib.EXPORTS) == declared
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.wsx_abi_version() == 10
+    assert lib.wsx_abi_version() == 11
 
 
 def test_struct_layouts():
@@ -42,8 +42,7 @@ def test_struct_layouts():
     assert [_lib.RESULT_DTYPE.fields[k][1] for k in ('status', 'len1', 'len2', 'cost1', 'dtw_end_cost2')] == \
         [0, 4, 8, 24, 48]
     assert C.sizeof(_lib.WsxAlignScores) == 16
-    assert C.sizeof(_lib.WsxGeneratedFill) == 64 and _lib.WsxGeneratedFill.code.offset == 16 and _lib.WsxGeneratedFill.tb_pred.offset == 56
-    assert sorted(_lib.TUNING.values()) == list(range(1, 10))
+    assert sorted(_lib.TUNING.values()) == list(range(1, 9))
     assert _lib.FLANK_HIT_DTYPE.itemsize == 64 and _lib.FLANK_HIT_DTYPE.fields['n_ops'][1] == 52 and _lib.FLANK_HIT_DTYPE.fields['tie_steps'][1] == 60
 
 

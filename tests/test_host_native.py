@@ -204,3 +204,43 @@ def test_float_columns_come_back_as_pandas_converter_leaves_them(tmp_path):
     ov.store_results(path, ref, [('A', 'AC')] * n, [(0.5, 0.25)] * n, str(tmp_path / 'b'), write=True)
     nat.store(str(tmp_path / 'a'), [1] * n, [2] * n, [0.5] * n, [0.25] * n, np.frombuffer(b'AC' * n, np.uint8), np.arange(n) * 2, write=True)
     assert open(tmp_path / 'a' / 'overview.csv').read() == open(tmp_path / 'b' / 'overview.csv').read()
+
+
+def test_one_call_setup_equals_the_python_forms(tmp_path):
+    """wsh_locus_setup (overview + flank file + both automata + state_similarity.csv in one call) against load_flanks,
+    locus_automata and similarity_report, over random loci incl. ones the Python forms raise on (then the library declines)."""
+    from warpstr_amd import synth
+    from warpstr_amd.caller import similarity_report
+    rng = np.random.default_rng(11)
+    pm = default_pore_model()
+    n_ok = 0
+    for trial in range(150):
+        pat = random_pattern(rng) if trial % 10 else '(A)' + random_pattern(rng)   # a one-base unit: IndexError in the similarity report
+        fl = int(rng.integers(8, 120))
+        flanks = [''.join('ACGT'[i] for i in rng.integers(0, 4, size=fl)) for _ in range(4)]
+        loc = str(tmp_path / f'l{trial}')
+        ov.store_flanks(loc, flanks)
+        pd.DataFrame({'read_name': ['a', 'b'], 'run_id': 0, 'reverse': [True, False], 'saved': 1, 'l_start_raw': 0,
+                      'r_end_raw': [99, 120]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        lim = float(rng.choice([0.75, 0.2, 1.5]))
+        st = _hostlib.NativeSetup.run(loc, pat, pm, lim, True)
+        assert st is not None and st.overview is not None and st.overview.names == ['a', 'b']
+        try:
+            want = automata.locus_automata(*ov.load_flanks(loc), pat, pm)
+        except Exception:  # noqa: BLE001
+            assert st.tables is None
+            want = None
+        if want is not None:
+            assert st.tables is not None
+            for got, w in zip(st.tables, want):
+                assert 'value' not in got.__dict__   # (nothing copied until somebody looks)
+                same_table(got, w)
+        try:
+            text, warnings, _ = similarity_report(pat, pm, lim)
+        except IndexError:
+            assert st.similarity is None
+            continue
+        assert st.similarity == (text, warnings)
+        assert open(os.path.join(loc, 'summaries', 'state_similarity.csv')).read() == text
+        n_ok += 1
+    assert n_ok > 100

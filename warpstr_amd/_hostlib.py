@@ -26,8 +26,15 @@ class WshOverviewInfo(C.Structure):
                 ('runs', C.c_void_p), ('runs_off', C.c_void_p), ('f5s', C.c_void_p), ('f5s_off', C.c_void_p)]
 
 
+class WshSetup(C.Structure):
+    _fields_ = [('owner', C.c_void_p), ('locus', C.c_void_p), ('overview_status', C.c_int32), ('automata_status', C.c_int32),
+                ('similarity_status', C.c_int32), ('reserved', C.c_int32), ('aut', WshAutomaton * 2), ('similarity_csv', C.c_char_p),
+                ('warnings', C.c_char_p)]
+
+
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
-           'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store']
+           'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
+           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup']
 
 
 def lib():
@@ -52,14 +59,22 @@ def lib():
                     h.wsh_locus_info.restype = None
                     h.wsh_locus_text.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
                     h.wsh_locus_text.restype = C.c_void_p
-                    h.wsh_locus_store.argtypes = [C.c_void_p, C.c_char_p] + [C.c_void_p] * 6 + [C.c_int32, C.POINTER(C.c_void_p),
-                                                                                                C.POINTER(C.c_int64)]
+                    h.wsh_locus_store.argtypes = [C.c_void_p, C.c_char_p] + [C.c_void_p] * 6 + [C.c_int32]
+                    h.wsh_locus_table.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+                    h.wsh_locus_table.restype = C.c_void_p
+                    h.wsh_loci_store.argtypes = [C.c_int32] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]
+                    h.wsh_loci_setup.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p]
+                    h.wsh_loci_setup.restype = None
                     h.wsh_free.argtypes = [C.c_void_p]
                     h.wsh_free.restype = None
                     h.wsh_collapse_store.argtypes = [C.c_char_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_char_p,
-                                                                                                   C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32,
-                                                                                                   C.c_void_p, C.POINTER(C.c_void_p),
+                                                                                                   C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p,
+                                                                                                   C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                                                                                    C.POINTER(C.c_int64)]
+                    h.wsh_locus_setup.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.POINTER(WshSetup)]
+                    h.wsh_locus_setup.restype = None
+                    h.wsh_setup_free.argtypes = [C.POINTER(WshSetup)]
+                    h.wsh_setup_free.restype = None
                     _LIB = h
             except OSError:
                 pass
@@ -112,8 +127,8 @@ class NativeOverview:
     step-3 files.  open() returns None when the table has to go through pandas (reason in `NativeOverview.last_refusal`)."""
     last_refusal = ''
 
-    def __init__(self, handle, path):
-        self._h, self.path = handle, path
+    def __init__(self, handle, path, owner=None):
+        self._h, self.path, self._owner = handle, path, owner   # owner: a NativeSetup that holds (and frees) the handle
         info = WshOverviewInfo()
         lib().wsh_locus_info(handle, C.byref(info))
         n = self.n_saved = info.n_saved
@@ -166,24 +181,26 @@ class NativeOverview:
                 np.ascontiguousarray(cost2, np.float64), np.ascontiguousarray(seq2, np.uint8), np.ascontiguousarray(off2, np.int64)]
         if any(len(a) != self.n_saved for a in arrs[:4] + arrs[5:]):
             raise ValueError(f'{self.n_saved} saved reads in the overview but {len(arrs[0])} results')
-        out, n = C.c_void_p(), C.c_int64()
-        rc = h.wsh_locus_store(self._h, os.fsencode(locus_path), *[a.ctypes.data for a in arrs], 3 if write else 0, C.byref(out), C.byref(n))
+        rc = h.wsh_locus_store(self._h, os.fsencode(locus_path), *[a.ctypes.data for a in arrs], 3 if write else 0)
         if rc != 0:
             raise OSError((h.wsh_locus_error(self._h) or b'').decode('utf-8', 'replace'))
-        try:
-            return C.string_at(out, n.value).decode('utf-8')
-        finally:
-            h.wsh_free(out)
+        return self.table_text()
+
+    def table_text(self) -> str:
+        """The table the last store made (the text of the new overview.csv)."""
+        n = C.c_int64()
+        p = lib().wsh_locus_table(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode('utf-8')
 
     def close(self):
-        if self._h is not None and lib() is not None:
+        if self._h is not None and self._owner is None and lib() is not None:
             lib().wsh_locus_free(self._h)
-        self._h = None
+        self._h = self._owner = None
 
     __del__ = close
 
 
-def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, offsets, header: str, write: bool):
+def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, offsets, header: str, sel, write: bool):
     """collapse_repeats for every called sequence + the complex-unit table: (counts [n x alternatives], CSV text), or None when
     the Python form has to run (library absent, an empty alternative)."""
     h = lib()
@@ -199,9 +216,11 @@ def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, off
     arrs = [np.ascontiguousarray(seq2, np.uint8), np.ascontiguousarray(off2, np.int64), np.ascontiguousarray(len2, np.int32),
             np.ascontiguousarray(reverse, np.uint8)]
     offs = np.ascontiguousarray(offsets, np.int32)
+    sel = np.ascontiguousarray(sel, np.int32)
     out, ln = C.c_void_p(), C.c_int64()
     rc = h.wsh_collapse_store(os.fsencode(locus_path), n, *[a.ctypes.data for a in arrs], len(repeat_units), n_alt.ctypes.data, blob,
-                              alt_off.ctypes.data, offs.ctypes.data, header.encode('utf-8'), 1 if write else 0, counts.ctypes.data,
+                              alt_off.ctypes.data, offs.ctypes.data, header.encode('utf-8'), len(sel), sel.ctypes.data, 1 if write else 0,
+                              counts.ctypes.data,
                               C.byref(out), C.byref(ln))
     if rc > 0:
         return None
@@ -211,3 +230,119 @@ def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, off
         return counts, C.string_at(out, ln.value).decode('utf-8')
     finally:
         h.wsh_free(out)
+
+
+def _native_table(a: WshAutomaton, kmersize: int, owner):
+    from .automata import AutomatonTable
+
+    class _Lazy(AutomatonTable):
+        """An AutomatonTable whose arrays stay in the library's memory until somebody looks at them: the handle of a run takes
+        the pointers as they are (caller.HipCaller), a run of thousands of loci never builds the 14 000 NumPy arrays."""
+
+        def __init__(self):  # noqa: D107 -- no arrays yet
+            self.n_states, self.endstate, self.repstart, self.repend = a.n_states, a.endstate, a.repstart, a.repend
+            self.kmersize, self._kmers, self._succ = kmersize, None, None
+            self._n_edges = a.n_edges
+            self._owner = owner
+            self.native_ptrs = (a.value, a.seq_idx, a.pred_ptr, a.pred_idx, a.repeat_mask, a.last_base)
+            self._kmer_ptr = a.kmer
+
+        def __getattr__(self, name):  # only reached for attributes that are not set yet: the arrays
+            if name in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer_codes'):
+                S, E = self.n_states, self._n_edges
+                p = self.native_ptrs
+                self.value, self.seq_idx = _copy(p[0], np.float64, S), _copy(p[1], np.int32, S)
+                self.pred_ptr, self.pred_idx = _copy(p[2], np.int32, S + 1), _copy(p[3], np.int32, E)
+                self.repeat_mask, self.last_base = _copy(p[4], np.uint8, S), _copy(p[5], np.uint8, S)
+                self.kmer_codes = _copy(self._kmer_ptr, np.uint32, S)
+                return self.__dict__[name]
+            raise AttributeError(name)
+
+        def __deepcopy__(self, memo):
+            return AutomatonTable(self.n_states, self.endstate, self.value.copy(), self.seq_idx.copy(), self.pred_ptr.copy(),
+                                  self.pred_idx.copy(), self.repeat_mask.copy(), self.last_base.copy(), repstart=self.repstart,
+                                  repend=self.repend, kmer_codes=self.kmer_codes.copy(), kmersize=self.kmersize)
+    return _Lazy()
+
+
+def store_many(overviews, locus_paths, start, len1, len2, cost1, cost2, seq2, off2, write: bool):
+    """NativeOverview.store for a chunk of loci in ONE library call (no GIL for the whole chunk): locus i's reads are
+    [start[i], start[i + 1]) of the run's contiguous per-read arrays (int32 lengths, float64 costs, int64 offsets into seq2)."""
+    h = lib()
+    n = len(overviews)
+    handles = (C.c_void_p * n)(*[o._h for o in overviews])
+    paths = (C.c_char_p * n)(*[os.fsencode(p) for p in locus_paths])
+    start = np.ascontiguousarray(start, np.int64)
+    status = np.zeros(n, np.int32)
+    for a, dt in ((len1, np.int32), (len2, np.int32), (cost1, np.float64), (cost2, np.float64), (seq2, np.uint8), (off2, np.int64)):
+        assert a.dtype == dt and a.flags.c_contiguous
+    bad = h.wsh_loci_store(n, handles, paths, start.ctypes.data, len1.ctypes.data, len2.ctypes.data, cost1.ctypes.data, cost2.ctypes.data,
+                           seq2.ctypes.data, off2.ctypes.data, 3 if write else 0, status.ctypes.data)
+    if bad:
+        i = int(np.flatnonzero(status)[0])
+        raise OSError((h.wsh_locus_error(overviews[i]._h) or b'').decode('utf-8', 'replace'))
+
+
+class NativeSetup:
+    """Everything of a locus that precedes the calling, from one library call without the GIL: `overview` (NativeOverview or
+    None: the pandas path), `tables` ((template, reverse) AutomatonTables or None: the Python compiler, which raises what
+    upstream raises), `similarity` ((CSV text, [warning lines]) or None: the Python form).  None altogether without the library."""
+
+    def __init__(self, raw: WshSetup, locus_path: str, kmersize: int):
+        self._raw = raw
+        self.overview = self.tables = self.similarity = None
+        self.overview_status = raw.overview_status
+        if raw.overview_status == 0:
+            self.overview = NativeOverview(raw.locus, os.path.join(locus_path, 'overview.csv'), owner=self)
+        else:
+            NativeOverview.last_refusal = (lib().wsh_locus_error(raw.locus) or b'').decode('utf-8', 'replace')
+        if raw.automata_status == 0:
+            self.tables = (_native_table(raw.aut[0], kmersize, self), _native_table(raw.aut[1], kmersize, self))
+        if raw.similarity_status == 0:
+            self.similarity = ((raw.similarity_csv or b'').decode('ascii'), (raw.warnings or b'').decode('ascii').splitlines())
+
+    @classmethod
+    def run(cls, locus_path: str, sequence: str, pore_model, min_state_similarity: float, write_similarity: bool):
+        h = lib()
+        if h is None:
+            return None
+        try:
+            seq = sequence.encode('ascii')
+        except UnicodeEncodeError:
+            return None
+        levels = pore_model.level_norm
+        if levels.dtype != np.float64 or not levels.flags.c_contiguous:
+            levels = np.ascontiguousarray(levels, np.float64)
+        raw = WshSetup()
+        h.wsh_locus_setup(os.fsencode(locus_path), seq, levels.ctypes.data, int(pore_model.kmersize), float(min_state_similarity),
+                          1 if write_similarity else 0, C.byref(raw))
+        return cls(raw, locus_path, int(pore_model.kmersize))
+
+    @classmethod
+    def run_many(cls, locus_paths, sequences, pore_model, min_state_similarity: float, write_similarity: bool):
+        """run() for a chunk of loci in ONE library call (no GIL for the whole chunk); None without the library."""
+        h = lib()
+        if h is None:
+            return None
+        try:
+            seqs = [s.encode('ascii') for s in sequences]
+        except UnicodeEncodeError:
+            return None
+        n = len(seqs)
+        levels = pore_model.level_norm
+        if levels.dtype != np.float64 or not levels.flags.c_contiguous:
+            levels = np.ascontiguousarray(levels, np.float64)
+        raws = (WshSetup * n)()
+        h.wsh_loci_setup(n, (C.c_char_p * n)(*[os.fsencode(p) for p in locus_paths]), (C.c_char_p * n)(*seqs), levels.ctypes.data,
+                         int(pore_model.kmersize), float(min_state_similarity), 1 if write_similarity else 0, raws)
+        out = []
+        for i, p in enumerate(locus_paths):   # (each entry owns a copy of its struct: the array may go)
+            raw = WshSetup()
+            C.memmove(C.byref(raw), C.byref(raws[i]), C.sizeof(WshSetup))
+            out.append(cls(raw, p, int(pore_model.kmersize)))
+        return out
+
+    def __del__(self):
+        h = lib()
+        if h is not None and getattr(self, '_raw', None) is not None and self._raw.owner:
+            h.wsh_setup_free(C.byref(self._raw))

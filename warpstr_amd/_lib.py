@@ -16,20 +16,14 @@ WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
                7: 'segment_range'}
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
-           'wsx_caller_set_workspace_limit', 'wsx_caller_get_workspace_limit', 'wsx_caller_set_tuning', 'wsx_caller_set_generated_fill', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
+           'wsx_caller_set_workspace_limit', 'wsx_caller_get_workspace_limit', 'wsx_caller_set_tuning', 'wsx_caller_create_times', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
            'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
 
 
 # wsx_caller_set_tuning knobs (include/warpstr_hip.h: WSX_TUNE_*)
 TUNING = {'stream_traceback_min': 1, 'borders_wave_below': 2, 'segment_two_kernels': 3, 'fill_blocks_per_cu': 4, 'chunks': 5,
-          'small_pipe_samples': 6, 'calls_in_flight': 7, 'small_calls_in_flight': 8, 'generated_passes': 9}
-
-
-class WsxGeneratedFill(C.Structure):  # wsx_generated_fill
-    _fields_ = [('abi', C.c_int32), ('words_per_row', C.c_int32), ('states_per_lane', C.c_int32), ('end_position', C.c_int32),
-                ('code', C.c_void_p), ('code_size', C.c_uint64), ('state_at', C.c_void_p), ('tb_n', C.c_void_p),
-                ('tb_word', C.c_void_p), ('tb_pred', C.c_void_p)]
+          'small_pipe_samples': 6, 'calls_in_flight': 7, 'small_calls_in_flight': 8}
 
 
 class WsxAutomaton(C.Structure):
@@ -133,7 +127,7 @@ def load():
     lib.wsx_caller_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]
     lib.wsx_caller_get_workspace_limit.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.wsx_caller_set_tuning.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
-    lib.wsx_caller_set_generated_fill.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.wsx_caller_create_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.wsx_caller_set_streams.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_caller_synchronize.argtypes = [C.c_void_p]
     lib.wsx_caller_set_pipelined.argtypes = [C.c_void_p, C.c_int32]

@@ -193,14 +193,9 @@ class HipCaller:
     def __init__(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
                  device: int = 0, stream: int = 0, workspace_limit: Optional[int] = None,
-                 reverse_flags: Optional[Sequence[bool]] = None, generated_fill: Optional[bool] = None):
+                 reverse_flags: Optional[Sequence[bool]] = None):
         """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
-        default: odd positions (template, reverse, template, reverse, ...).
-        generated_fill: True = automata of at most 64 states (min_values_per_state 4) get a DP fill generated and compiled for
-        them (warpstr_amd/fillgen.py: a read in four lanes, no predecessor exchange; a few seconds per automaton the first
-        time, cached on disk afterwards: fillgen.cache_dir()).  Opt-in: measured slower than the built-in kernel in the
-        pipelined step; WARPSTR_GENERATED_FILL=1 turns it on for every handle of a process.  A failure
-        to generate or compile leaves the built-in kernel in place (`generated`: what each automaton got)."""
+        default: odd positions (template, reverse, template, reverse, ...)."""
         self.lib = _lib.load()
         self.device = int(device)
         if self.lib.wsx_device_count() <= 0:
@@ -215,6 +210,12 @@ class HipCaller:
             reverse_flags = [bool(i & 1) for i in range(len(self.automata))]
         self.reverse_flags = [bool(x) for x in reverse_flags]
         for i, (t, fl) in enumerate(zip(self.automata, self.flank_lengths)):
+            ptrs = t.__dict__.get('native_ptrs') if 'value' not in t.__dict__ else None
+            if ptrs is not None:  # tables still in the host library's memory (_hostlib.NativeSetup): the pointers as they are
+                self._keep.append(t)
+                arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if self.reverse_flags[i] else 0,
+                                           *ptrs)
+                continue
             bufs = [np.ascontiguousarray(t.value, np.float64), np.ascontiguousarray(t.seq_idx, np.int32),
                     np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32),
                     np.ascontiguousarray(t.repeat_mask, np.uint8), np.ascontiguousarray(t.last_base, np.uint8)]
@@ -235,45 +236,12 @@ class HipCaller:
         self.max_states = max(t.n_states for t in self.automata)
         for knob, value in self.default_tuning.items():
             self.set_tuning(knob, value)
-        self.generated = {}
-        if generated_fill is None:
-            generated_fill = os.environ.get('WARPSTR_GENERATED_FILL') == '1'
-        if generated_fill and len(self.automata) <= 64:
-            for i in range(len(self.automata)):
-                self.generate_fill(i)
 
-    def generate_fill(self, automaton: int, compile_missing: bool = True) -> bool:
-        """Generate, compile and attach the straight-line fill of one automaton (fillgen.py); False (and the built-in kernel
-        stays) if the automaton is not of the kind it is written for, no compiler is there, or -- compile_missing=False --
-        its code object is not in the cache yet."""
-        from . import fillgen
-        t = self.automata[automaton]
-        if not fillgen.supported(t, self.caller_config.min_values_per_state):
-            return False
-        try:
-            gen = fillgen.generate(t, self.flank_lengths[automaton])
-            code, how = fillgen.compile_source(gen, compile_missing)
-        except Exception as e:  # noqa: BLE001 -- the built-in kernel computes the same
-            code, how = None, f'{type(e).__name__}: {e}'
-        if code is None:
-            self.generated[automaton] = how
-            return False
-        buf = C.create_string_buffer(code, len(code))
-        keep = [np.ascontiguousarray(gen.state_at, np.uint16), np.ascontiguousarray(gen.tb_n, np.uint8),
-                np.ascontiguousarray(gen.tb_word, np.uint16), np.ascontiguousarray(gen.tb_pred, np.uint16)]
-        g = _lib.WsxGeneratedFill(1, gen.words_per_row, gen.n_per_lane, gen.end_pos, C.cast(buf, C.c_void_p), len(code),
-                                  *[_lib.ptr(k) for k in keep])
-        rc = self.lib.wsx_caller_set_generated_fill(self.handle, automaton, C.byref(g))
-        if rc != 0:
-            self.generated[automaton] = _lib.last_error()
-            return False
-        self.generated[automaton] = {'compiled': how, 'words_per_row': gen.words_per_row, 'valu_per_wave_row': gen.valu_per_wave_row,
-                                     'key': gen.key}
-        return True
-
-    def drop_generated_fill(self, automaton: int):
-        _lib.check(self.lib.wsx_caller_set_generated_fill(self.handle, automaton, None), 'wsx_caller_set_generated_fill')
-        self.generated.pop(automaton, None)
+    def create_times(self) -> dict:
+        """Where wsx_caller_create spent its time (seconds): a handle for all loci of a run places thousands of automata."""
+        v = (C.c_double * 5)()
+        _lib.check(self.lib.wsx_caller_create_times(self.handle, v, 5), 'wsx_caller_create_times')
+        return dict(zip(('validate', 'placement', 'pack', 'upload', 'streams'), [float(x) for x in v]))
 
     def set_tuning(self, knob: str, value: int):
         """wsx_caller_set_tuning: how the work is spread over launches, never what is computed (knobs: _lib.TUNING)."""

@@ -110,15 +110,17 @@ struct Automaton {
     std::vector<uint32_t> kmer;
 };
 
-struct KState { uint32_t code; int node, from; std::vector<std::pair<int, int>> next; };
-
 // 0 = built; 1 = the Python compiler would raise on this pattern (the caller lets it)
 int compile_automaton(const char *pat, int64_t n, const double *levels, int k, Automaton &A)
 {
     if (n < 1 || k < 2 || k > 12) return 1;
-    std::vector<char> base{pat[0]};
-    std::vector<std::vector<int>> succ(1);
-    std::vector<int> tails{0}, opt_tails, pending;
+    // one node per (expanded) base; the edges in the order they are made (a node's successor list is its edges in that order)
+    std::vector<char> base;
+    base.reserve(size_t(n) + 8);
+    base.push_back(pat[0]);
+    std::vector<std::pair<int, int>> edges;
+    edges.reserve(size_t(n) + 16);
+    std::vector<int> tails{0}, opt_tails, pending, created;
     std::vector<LoopHead> heads;
     int rep_first = -1, rep_last = -1, nxt = 1;
     for (int64_t i = 1; i < n; i++) {
@@ -132,8 +134,8 @@ int compile_automaton(const char *pat, int64_t n, const double *levels, int k, A
             LoopHead h = std::move(heads.back());
             heads.pop_back();
             for (int t : tails) {
-                if (h.many) succ[t].insert(succ[t].end(), h.ids.begin(), h.ids.end());
-                else succ[t].push_back(h.id);
+                if (h.many) for (int id : h.ids) edges.emplace_back(t, id);
+                else edges.emplace_back(t, h.id);
             }
         } else if (ch == '{') {
             opt_tails.push_back(nxt - 1);
@@ -144,12 +146,11 @@ int compile_automaton(const char *pat, int64_t n, const double *levels, int k, A
         } else if (const char *alts = iupac(ch)) {
             bool opens = !heads.empty() && !heads.back().many && heads.back().id == nxt;
             opens = opens || (!opt_tails.empty() && opt_tails.back() == nxt);
-            std::vector<int> created;
+            created.clear();
             for (const char *a = alts; *a; a++) {
                 base.push_back(*a);
-                succ.emplace_back();
                 created.push_back(nxt);
-                for (int t : tails) succ[t].push_back(nxt);
+                for (int t : tails) edges.emplace_back(t, nxt);
                 nxt++;
             }
             if (opens) {
@@ -160,10 +161,9 @@ int compile_automaton(const char *pat, int64_t n, const double *levels, int k, A
             tails = created;
         } else {
             base.push_back(ch);
-            succ.emplace_back();
-            for (int t : tails) succ[t].push_back(nxt);
+            for (int t : tails) edges.emplace_back(t, nxt);
             tails.assign(1, nxt);
-            for (int t : pending) succ[t].push_back(nxt);
+            for (int t : pending) edges.emplace_back(t, nxt);
             pending.clear();
             nxt++;
         }
@@ -172,75 +172,91 @@ int compile_automaton(const char *pat, int64_t n, const double *levels, int k, A
     if (n_nodes < k) return 1;
     std::vector<int8_t> code(n_nodes);
     for (int i = 0; i < n_nodes; i++) code[i] = int8_t(base_code(base[i]));
+    std::vector<int> sp(n_nodes + 1, 0), sx(edges.size());     // successor lists, CSR (a stable counting sort keeps their order)
+    for (auto &e : edges) sp[e.first + 1]++;
+    for (int i = 0; i < n_nodes; i++) sp[i + 1] += sp[i];
+    {
+        std::vector<int> at(sp.begin(), sp.end() - 1);
+        for (auto &e : edges) sx[at[e.first]++] = e.second;
+    }
 
-    // k-mer states, bucketed by the node of their last base; depth first with an explicit LIFO stack
-    std::vector<KState> st;
-    std::vector<std::vector<int>> bucket(n_nodes);
+    // k-mer states, bucketed by the node of their last base (a linked list per node; a state's slot = its rank in its bucket);
+    // depth first with an explicit LIFO stack; the transitions out of a state are one block of `next`
+    std::vector<uint32_t> s_code;
+    std::vector<int> s_node, s_from, s_slot, s_link, s_nb, s_ne;
+    std::vector<std::pair<int, int>> next;   // (node, slot)
+    std::vector<int> b_head(n_nodes, -1), b_size(n_nodes, 0);
+    const size_t guess = size_t(n_nodes) + 64;
+    s_code.reserve(guess); s_node.reserve(guess); s_from.reserve(guess); s_slot.reserve(guess); s_link.reserve(guess);
+    s_nb.reserve(guess); s_ne.reserve(guess); next.reserve(guess + 64);
+    auto add_state = [&](uint32_t c, int node, int from) {
+        const int id = int(s_code.size());
+        s_code.push_back(c); s_node.push_back(node); s_from.push_back(from); s_slot.push_back(b_size[node]++);
+        s_link.push_back(b_head[node]); s_nb.push_back(0); s_ne.push_back(0);
+        b_head[node] = id;
+        return id;
+    };
     const uint32_t tail_mod = 1u << (2 * (k - 1));
     uint32_t first = 0;
     for (int i = 0; i < k; i++) {
         if (code[i] < 0) return 1;
         first = first * 4 + uint32_t(code[i]);
     }
-    st.push_back({first, k - 1, -1, {}});
-    bucket[k - 1].push_back(0);
-    std::vector<int> stack{0};
+    std::vector<int> stack{add_state(first, k - 1, -1)};
     while (!stack.empty()) {
         const int cur = stack.back();
         stack.pop_back();
-        const uint32_t tail = (st[cur].code % tail_mod) * 4;
-        const int cnode = st[cur].node;
-        for (int node : succ[cnode]) {
+        const uint32_t tail = (s_code[cur] % tail_mod) * 4;
+        const int cnode = s_node[cur];
+        s_nb[cur] = int(next.size());
+        for (int q = sp[cnode]; q < sp[cnode + 1]; q++) {
+            const int node = sx[q];
             if (code[node] < 0) return 1;
             const uint32_t km = tail + uint32_t(code[node]);
             bool linked = false;
-            const std::vector<int> &b = bucket[node];
-            for (int slot = 0; slot < int(b.size()); slot++) {
-                if (st[b[slot]].code == km && st[b[slot]].from == cnode) {
-                    st[cur].next.emplace_back(node, slot);
+            for (int o = b_head[node]; o >= 0; o = s_link[o]) {
+                if (s_code[o] == km && s_from[o] == cnode) {
+                    next.emplace_back(node, s_slot[o]);
                     linked = true;
                 }
             }
             if (!linked) {
-                st[cur].next.emplace_back(node, int(bucket[node].size()));
-                bucket[node].push_back(int(st.size()));
-                stack.push_back(int(st.size()));
-                st.push_back({km, node, cnode, {}});
+                const int id = add_state(km, node, cnode);
+                next.emplace_back(node, s_slot[id]);
+                stack.push_back(id);
             }
         }
+        s_ne[cur] = int(next.size());
     }
 
     // flatten in node order
     std::vector<int> base_of(n_nodes + 1, 0);
-    for (int i = 0; i < n_nodes; i++) base_of[i + 1] = base_of[i] + int(bucket[i].size());
+    for (int i = 0; i < n_nodes; i++) base_of[i + 1] = base_of[i] + b_size[i];
     const int S = base_of[n_nodes];
     A.n_states = S;
     A.repstart = rep_first;
     A.repend = rep_last;
     A.value.resize(S); A.seq_idx.resize(S); A.repeat_mask.resize(S); A.last_base.resize(S); A.kmer.resize(S);
-    std::vector<int> flat(st.size());
-    for (int nd = 0; nd < n_nodes; nd++)
-        for (int s = 0; s < int(bucket[nd].size()); s++) flat[bucket[nd][s]] = base_of[nd] + s;
-    std::vector<int32_t> fan(S + 1, 0);
-    for (int nd = 0; nd < n_nodes; nd++) {
-        for (int id : bucket[nd]) {
-            const int j = flat[id];
-            A.kmer[j] = st[id].code;
-            A.seq_idx[j] = nd;
-            A.value[j] = levels[st[id].code];
-            A.repeat_mask[j] = (rep_first - 1 <= nd && nd <= rep_last + 10) ? 1 : 0;
-            A.last_base[j] = uint8_t(base[nd]);
-            for (auto &e : st[id].next) fan[base_of[e.first] + e.second + 1]++;
-        }
-    }
-    A.endstate = bucket[n_nodes - 1].empty() ? -1 : S - 1;
+    std::vector<int> by_flat(S);   // state id at every flat index
+    for (int id = 0; id < S; id++) by_flat[base_of[s_node[id]] + s_slot[id]] = id;
     A.pred_ptr.assign(S + 1, 0);
-    for (int j = 0; j < S; j++) A.pred_ptr[j + 1] = A.pred_ptr[j] + fan[j + 1];
+    for (int j = 0; j < S; j++) {
+        const int id = by_flat[j], nd = s_node[id];
+        A.kmer[j] = s_code[id];
+        A.seq_idx[j] = nd;
+        A.value[j] = levels[s_code[id]];
+        A.repeat_mask[j] = (rep_first - 1 <= nd && nd <= rep_last + 10) ? 1 : 0;
+        A.last_base[j] = uint8_t(base[nd]);
+        for (int q = s_nb[id]; q < s_ne[id]; q++) A.pred_ptr[base_of[next[q].first] + next[q].second + 1]++;
+    }
+    A.endstate = b_size[n_nodes - 1] == 0 ? -1 : S - 1;
+    for (int j = 0; j < S; j++) A.pred_ptr[j + 1] += A.pred_ptr[j];
     A.pred_idx.resize(A.pred_ptr[S]);
     std::vector<int32_t> fill(A.pred_ptr.begin(), A.pred_ptr.end() - 1);
-    for (int nd = 0; nd < n_nodes; nd++)       // sources in state order: `incoming` comes out ordered by source index
-        for (int id : bucket[nd])
-            for (auto &e : st[id].next) A.pred_idx[fill[base_of[e.first] + e.second]++] = flat[id];
+    for (int j = 0; j < S; j++) {      // sources in state order: `incoming` comes out ordered by source index
+        const int id = by_flat[j];
+        for (int q = s_nb[id]; q < s_ne[id]; q++) A.pred_idx[fill[base_of[next[q].first] + next[q].second]++] = j;
+    }
     return 0;
 }
 
@@ -400,6 +416,7 @@ struct Locus {
     std::vector<int64_t> lo, hi;         // per saved row
     std::string names, runs, f5s;        // per saved row, back to back
     std::vector<int64_t> names_off, runs_off, f5s_off;
+    std::string out_text;                // the table after store_results (wsh_locus_store)
     std::string err;
 };
 
@@ -565,6 +582,176 @@ int parse_overview(Locus &L)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The rest of a locus's set-up: the flank file (overview.py: load_flanks; src/extractor/tr_extractor.py:108-140), the reverse
+// strand's pattern (automata.py: reverse_pattern; src/caller/wrapper.py:78-84) and summaries/state_similarity.csv with
+// upstream's warnings (caller.py: similarity_report; src/caller/wrapper.py:122-160, src/squiggler/pore_model.py:34-71).
+char strand_swap(char c)
+{
+    switch (c) {  // src/templates.py:45-65
+    case '(': return ')'; case ')': return '('; case '{': return '}'; case '}': return '{';
+    case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; case 'M': return 'K'; case 'K': return 'M';
+    case 'N': return 'N'; case 'W': return 'W'; case 'S': return 'S'; case 'R': return 'Y'; case 'Y': return 'R'; case 'B': return 'V';
+    case 'D': return 'H'; case 'H': return 'D'; case 'V': return 'B'; default: return 0;
+    }
+}
+
+bool reverse_pattern(const std::string &seq, std::string &out)
+{
+    out.clear();
+    for (size_t i = seq.size(); i-- > 0;) {
+        const char c = strand_swap(seq[i]);
+        if (!c) return false;
+        out.push_back(c);
+    }
+    return true;
+}
+
+std::string rstrip(std::string_view s)
+{
+    size_t n = s.size();
+    while (n && (s[n - 1] == ' ' || s[n - 1] == '\t' || s[n - 1] == '\r' || s[n - 1] == '\n' || s[n - 1] == '\f' || s[n - 1] == '\v')) n--;
+    return std::string(s.substr(0, n));
+}
+
+// the four flank sequences; false = let the Python reader run (it raises what upstream raises, or handles what this does not)
+bool load_flanks(const std::string &path, std::string out[4])
+{
+    std::string t;
+    if (!read_file(path.c_str(), t)) return false;
+    for (unsigned char c : t)
+        if (c >= 0x80 || c == '\r') return false;   // (text-mode decoding / universal newlines: Python's business)
+    std::vector<std::string_view> lines;
+    size_t b = 0;
+    while (b < t.size() && lines.size() < 5) {
+        size_t e = t.find('\n', b);
+        if (e == std::string::npos) e = t.size();
+        lines.push_back(std::string_view(t).substr(b, e - b));
+        b = e + 1;
+    }
+    if (lines.size() < 5) return false;
+    auto split = [](std::string_view l) {
+        std::vector<std::string_view> f;
+        size_t b = 0;
+        for (;;) {
+            size_t e = l.find(',', b);
+            if (e == std::string_view::npos) { f.push_back(l.substr(b)); break; }
+            f.push_back(l.substr(b, e - b));
+            b = e + 1;
+        }
+        return f;
+    };
+    size_t seqid = 0;
+    {
+        auto cols = split(lines[0]);
+        for (size_t i = 0; i < cols.size(); i++)
+            if (rstrip(cols[i]) == "sequence") { seqid = i; break; }
+    }
+    for (int r = 0; r < 4; r++) {
+        auto f = split(lines[r + 1]);
+        if (seqid >= f.size()) return false;
+        out[r] = rstrip(f[seqid]);
+    }
+    return true;
+}
+
+double np_pairwise_sum(const double *a, int n)
+{   // np.add.reduce of up to 128 doubles (numpy: pairwise_sum)
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// {unit: (mean, median)} in insertion order for one strand's pattern; false = the Python form must run (it raises, or the
+// unit is longer than this restates)
+bool unit_diffs(const std::string &seq, const double *levels, int k, std::vector<std::string> &keys, std::vector<std::pair<double, double>> &vals)
+{
+    size_t pos = 0;
+    while (pos < seq.size()) {
+        size_t i = seq.find_first_of("({", pos);
+        if (i == std::string::npos) break;
+        size_t j = seq.find_first_of(")}", i + 1);
+        if (j == std::string::npos) break;
+        std::vector<std::string> pats{""};
+        for (size_t q = i; q <= j; q++) {
+            const char c = seq[q];
+            if (c == '(' || c == ')' || c == '{' || c == '}') continue;
+            if (const char *alts = iupac(c)) {
+                std::vector<std::string> nx;
+                for (const char *a = alts; *a; a++)
+                    for (auto &p : pats) nx.push_back(p + *a);
+                pats.swap(nx);
+            } else {
+                for (auto &p : pats) p.push_back(c);
+            }
+            if (pats.size() > 4096) return false;
+        }
+        for (auto &p : pats) {
+            const int L = int(p.size());
+            if (L + k > L * k || L > 128) return false;   // (a one-base unit: IndexError upstream and in the Python form)
+            double v[130], d[130];
+            for (int a = 0; a <= L; a++) {
+                uint32_t code = 0;
+                for (int b = 0; b < k; b++) {
+                    const int bc = base_code(p[size_t(a + b) % size_t(L)]);
+                    if (bc < 0) return false;
+                    code = code * 4 + uint32_t(bc);
+                }
+                v[a] = levels[code];
+            }
+            for (int a = 0; a < L; a++) d[a] = std::fabs(v[a + 1] - v[a]);
+            const double mean = np_pairwise_sum(d, L) / L;
+            std::sort(d, d + L);
+            const double med = (L & 1) ? d[L / 2] : (d[L / 2 - 1] + d[L / 2]) / 2.0;
+            size_t at = 0;
+            while (at < keys.size() && keys[at] != p) at++;
+            if (at == keys.size()) { keys.push_back(p); vals.emplace_back(mean, med); }
+            else vals[at] = {mean, med};
+        }
+        pos = j + 1;
+    }
+    return true;
+}
+
+bool similarity(const std::string &seq, const std::string &rev, const double *levels, int k, double lim, std::string &csv, std::string &warn)
+{
+    std::vector<std::string> kt, kr;
+    std::vector<std::pair<double, double>> vt, vr;
+    if (!unit_diffs(seq, levels, k, kt, vt) || !unit_diffs(rev, levels, k, kr, vr)) return false;
+    csv = "pattern,strand,mean_diff,median_diff\n";
+    char buf[96];
+    for (size_t i = 0; i < kt.size(); i++) {
+        snprintf(buf, sizeof buf, ",template,%.3f,%.3f\n", vt[i].first, vt[i].second);
+        csv += kt[i]; csv += buf;
+    }
+    for (size_t i = 0; i < kr.size(); i++) {
+        snprintf(buf, sizeof buf, ",reverse,%.3f,%.3f\n", vr[i].first, vr[i].second);
+        csv += kr[i]; csv += buf;
+    }
+    warn.clear();
+    for (size_t i = 0; i < kt.size(); i++)
+        if (lim > vt[i].first || lim > vt[i].second) warn += "Warning: Template has repeat unit " + kt[i] + " with high state similarity\n";
+    for (size_t i = 0; i < kr.size(); i++)
+        if (lim > vr[i].first || lim > vr[i].second) warn += "Warning: high similarity of state values in reverse pattern " + kr[i] + "\n";
+    return true;
+}
+
+struct Setup {
+    Locus *locus = nullptr;
+    Automaton aut[2];
+    std::string sim_csv, warnings;
+};
+
 bool starts_with(std::string_view s, const char *p) { return s.size() >= strlen(p) && memcmp(s.data(), p, strlen(p)) == 0; }
 
 }  // namespace
@@ -657,8 +844,7 @@ WSH_EXPORT const char *wsh_locus_text(void *h, int64_t *len)
 // 2 = write the FASTA files.  If `table_out` is not NULL the new overview text is returned there (malloc'ed: wsh_free).
 // 0 = done; -2 = a file could not be written (wsh_locus_error).
 WSH_EXPORT int wsh_locus_store(void *h, const char *locus_path, const int32_t *len1, const int32_t *len2, const double *cost1,
-                               const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags, char **table_out,
-                               int64_t *table_len)
+                               const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags)
 {
     Locus &L = *static_cast<Locus *>(h);
     const int ns = int(L.saved_rows.size());
@@ -676,7 +862,8 @@ WSH_EXPORT int wsh_locus_store(void *h, const char *locus_path, const int32_t *l
     }
     for (int k = 0; k < 4; k++)
         if (std::find(src.begin(), src.end(), -1 - k) == src.end()) src.push_back(-1 - k);
-    std::string out;
+    std::string &out = L.out_text;
+    out.clear();
     out.reserve(L.text.size() + size_t(L.n_rows) * 64 + 64);
     out.append("read_name");
     for (int s : src) {
@@ -727,13 +914,101 @@ WSH_EXPORT int wsh_locus_store(void *h, const char *locus_path, const int32_t *l
             !write_file(dir + "/sequences_reverse.fasta", rev)) { L.err = "cannot write the FASTA files under " + dir; return -2; }
     }
     if ((flags & 1) && !write_file(root + "/overview.csv", out)) { L.err = "cannot write " + root + "/overview.csv"; return -2; }
-    if (table_out) {
-        *table_out = static_cast<char *>(malloc(out.size() + 1));
-        memcpy(*table_out, out.data(), out.size());
-        (*table_out)[out.size()] = 0;
-        *table_len = int64_t(out.size());
-    }
     return 0;
+}
+
+// The table wsh_locus_store made (the text of the new overview.csv), for the DataFrame a caller may ask for later.
+WSH_EXPORT const char *wsh_locus_table(void *h, int64_t *len)
+{
+    const Locus &L = *static_cast<Locus *>(h);
+    *len = int64_t(L.out_text.size());
+    return L.out_text.data();
+}
+
+// wsh_locus_store for n loci in one call (one call without the GIL per chunk of loci): locus i's reads are
+// [start[i], start[i + 1]) of the run's per-read arrays, off2 absolute into seq2.  status[i] receives each locus's return value;
+// returns the number of loci that failed.
+WSH_EXPORT int wsh_loci_store(int32_t n, void *const *handles, const char *const *locus_paths, const int64_t *start, const int32_t *len1,
+                              const int32_t *len2, const double *cost1, const double *cost2, const uint8_t *seq2, const int64_t *off2,
+                              int32_t flags, int32_t *status)
+{
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t a = start[i];
+        status[i] = wsh_locus_store(handles[i], locus_paths[i], len1 + a, len2 + a, cost1 + a, cost2 + a, seq2, off2 + a, flags);
+        bad += status[i] != 0;
+    }
+    return bad;
+}
+
+struct wsh_setup {
+    void *owner;                 // wsh_setup_free
+    void *locus;                 // overview handle for wsh_locus_* (owned by `owner`), valid when overview_status == 0
+    int32_t overview_status;     // 0 parsed; > 0 declined (wsh_locus_error(locus)): the pandas path; -1 no such file
+    int32_t automata_status;     // 0 built; 1: the Python loader / compiler must run (and raises what upstream raises)
+    int32_t similarity_status;   // 0 done (and written if asked); 1: the Python form must run
+    int32_t reserved;
+    wsh_automaton aut[2];        // template, reverse (arrays owned by `owner`)
+    const char *similarity_csv;  // text of summaries/state_similarity.csv
+    const char *warnings;        // upstream's high-similarity warnings, one per line
+};
+
+// Everything main_wrapper does for a locus before its reads are called, in one call without the GIL: overview.csv parsed,
+// the flank file read, both automata compiled, summaries/state_similarity.csv made (flags & 1: and written).
+WSH_EXPORT void wsh_locus_setup(const char *locus_path, const char *sequence, const double *levels, int32_t k, double min_state_similarity,
+                                int32_t flags, wsh_setup *out)
+{
+    Setup *S = new Setup;
+    S->locus = new Locus;
+    memset(out, 0, sizeof *out);
+    out->owner = S;
+    out->locus = S->locus;
+    const std::string root(locus_path), seq(sequence);
+    if (!read_file((root + "/overview.csv").c_str(), S->locus->text)) { S->locus->err = "cannot read the file"; out->overview_status = -1; }
+    else out->overview_status = parse_overview(*S->locus);
+    std::string fl[4], rev;
+    out->automata_status = 1;
+    const bool have_rev = reverse_pattern(seq, rev);
+    if (have_rev && load_flanks(root + "/expected_signals/sequences.csv", fl)) {
+        const std::string t = fl[0] + seq + fl[1], r = fl[2] + rev + fl[3];
+        if (compile_automaton(t.data(), int64_t(t.size()), levels, k, S->aut[0]) == 0 &&
+            compile_automaton(r.data(), int64_t(r.size()), levels, k, S->aut[1]) == 0) {
+            out->automata_status = 0;
+            for (int a = 0; a < 2; a++) {
+                Automaton &A = S->aut[a];
+                wsh_automaton &o = out->aut[a];
+                o.n_states = A.n_states; o.endstate = A.endstate; o.repstart = A.repstart; o.repend = A.repend;
+                o.n_edges = int32_t(A.pred_idx.size()); o.reserved = 0;
+                o.value = A.value.data(); o.seq_idx = A.seq_idx.data(); o.pred_ptr = A.pred_ptr.data(); o.pred_idx = A.pred_idx.data();
+                o.repeat_mask = A.repeat_mask.data(); o.last_base = A.last_base.data(); o.kmer = A.kmer.data();
+                o.owner = nullptr;
+            }
+        }
+    }
+    out->similarity_status = 1;
+    if (have_rev && similarity(seq, rev, levels, k, min_state_similarity, S->sim_csv, S->warnings)) {
+        out->similarity_status = 0;
+        if (flags & 1) {
+            const std::string dir = root + "/summaries";
+            if (!make_dirs(dir) || !write_file(dir + "/state_similarity.csv", S->sim_csv)) out->similarity_status = 1;   // (Python reports the OSError)
+        }
+    }
+    out->similarity_csv = S->sim_csv.c_str();
+    out->warnings = S->warnings.c_str();
+}
+
+// wsh_locus_setup for n loci in one call.
+WSH_EXPORT void wsh_loci_setup(int32_t n, const char *const *locus_paths, const char *const *sequences, const double *levels, int32_t k,
+                               double min_state_similarity, int32_t flags, wsh_setup *out)
+{
+    for (int i = 0; i < n; i++) wsh_locus_setup(locus_paths[i], sequences[i], levels, k, min_state_similarity, flags, out + i);
+}
+
+WSH_EXPORT void wsh_setup_free(wsh_setup *s)
+{
+    Setup *S = static_cast<Setup *>(s->owner);
+    if (S) { delete S->locus; delete S; }
+    s->owner = s->locus = nullptr;
 }
 
 WSH_EXPORT void wsh_free(void *p) { free(p); }
@@ -741,13 +1016,15 @@ WSH_EXPORT void wsh_free(void *p) { free(p); }
 // collapse_repeats (warpstr_amd/units.py; src/caller/wrapper.py:220-248) for n called sequences at once and the table of
 // store_collapsed (overview.py:11-34) as CSV text with pandas' default index column.  units: n_units repeat units, unit u has
 // n_alt[u] alternative strings (alts, back to back; alt_off) and is preceded by offsets[u] plain bases.  counts (n x total alts,
-// row-major) receives every count.  header: the column names, comma separated, without the index column and the final newline.
+// row-major) receives every count.  header: the column names, comma separated, without the index column and the final newline;
+// sel[c]: which of the generated columns (per unit: the sum and one per further alternative, or the single count) output column
+// c shows -- units of the same name share a column, as the keys of upstream's dict do.
 // flags 1: write <locus_path>/predictions/complexSTR_analysis/complex_repeat_units.csv.  Returns 0, or -2 (cannot write), or
 // 1 (an empty alternative: the Python form raises after its iteration limit -- let it).
 WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8_t *seq, const int64_t *off, const int32_t *len,
                                   const uint8_t *reverse, int32_t n_units, const int32_t *n_alt, const char *alts,
-                                  const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t flags,
-                                  int64_t *counts, char **table_out, int64_t *table_len)
+                                  const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t n_out, const int32_t *sel,
+                                  int32_t flags, int64_t *counts, char **table_out, int64_t *table_len)
 {
     int total = 0;
     for (int u = 0; u < n_units; u++) total += n_alt[u];
@@ -759,6 +1036,7 @@ WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8
     out.append(header);
     out.push_back('\n');
     char buf[32];
+    std::vector<int64_t> gen;
     for (int i = 0; i < n; i++) {
         const char *s = reinterpret_cast<const char *>(seq) + off[i];
         int64_t rem = len[i] > 0 ? len[i] : 0;
@@ -785,22 +1063,23 @@ WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8
             a0 += n_alt[u];
         }
         out.append(buf, size_t(format_int(i, buf)));
+        // the columns store_collapsed makes, in its order: per unit `main` (all its counts) + one per further alternative, or the count
+        gen.clear();
         a0 = 0;
         for (int u = 0; u < n_units; u++) {
             if (n_alt[u] > 1) {
                 int64_t sum = 0;
                 for (int k = 0; k < n_alt[u]; k++) sum += cnt[a0 + k];
-                out.push_back(',');
-                out.append(buf, size_t(format_int(sum, buf)));
-                for (int k = 1; k < n_alt[u]; k++) {
-                    out.push_back(',');
-                    out.append(buf, size_t(format_int(cnt[a0 + k], buf)));
-                }
+                gen.push_back(sum);
+                for (int k = 1; k < n_alt[u]; k++) gen.push_back(cnt[a0 + k]);
             } else {
-                out.push_back(',');
-                out.append(buf, size_t(format_int(cnt[a0], buf)));
+                gen.push_back(cnt[a0]);
             }
             a0 += n_alt[u];
+        }
+        for (int c = 0; c < n_out; c++) {   // (two units of the same name share a column: the later one's values, `sel` says which)
+            out.push_back(',');
+            out.append(buf, size_t(format_int(gen[size_t(sel[c])], buf)));
         }
         out.append(reverse[i] ? ",True\n" : ",False\n");
     }

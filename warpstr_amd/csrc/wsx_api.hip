@@ -8,9 +8,12 @@
 //   -> fit (Givens LSQ cubic) -> eval (rescaled signal) -> dtw_fill (masked, rescaled signal) -> traceback
 //   -> mid(pass 2: run statistics, borders, cost2, allele length)
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -44,14 +47,11 @@ struct Variant { // which DP kernel an automaton uses
     bool pk = false; // packed mask rows (K = 1, F = 2, the states with two predecessors in lanes 0..7): 9 bytes per row
     int lm = 0;      // lane-major placement (wsx_place.h): 1 = slots 0 and K-1 export through LDS, 3 = 0, 1 and K-1, 2 = every slot,
                      // 4 = every slot and two pieces to a lane (stacked)
-    int gen = 0;     // generated fill (wsx_caller_set_generated_fill): automaton index + 1 -- code of its own, a launch group of its own
-    int nwp = 0;     // ... its 64-bit back-pointer words per wave-row (16 reads)
     // back-pointer scratch of ONE read of T samples, in 64-bit words (even: a read's rows start 16-byte aligned):
     //   register-resident fill: per row F + (K-1)*FL 64-bit wave masks, one spare row (dtw_kernels.hip);
     //   packed rows: 18 words per 16 rows; generic fill: 4 bits per row and state, 8 rows per 32-bit word
     size_t bp_read_words(size_t T) const
     {
-        if (gen) return (T + 1) * (size_t)nwp; // (a WAVE of 16 reads: T = its longest read; run_batch)
         if (generic) return (T / 8 + 1) * (size_t)(K * 32);
         if (pk) return (T / 16 + 1) * 18;
         return (((T + 1) * (size_t)(F + (K - 1) * FL)) + 1) & ~(size_t)1;
@@ -59,12 +59,11 @@ struct Variant { // which DP kernel an automaton uses
     // upper bound, in 32-bit words, for a chunk of `samples` samples in `reads` reads that all took this variant
     size_t bp_words(size_t samples, size_t reads) const
     {
-        if (gen) return (samples / WSX_GEN_RPW + 4 * reads + 4096) * (size_t)nwp * 2;
         if (generic) return (samples / 8 + reads + 2) * (size_t)(K * 64);
         if (pk) return (samples / 16 + reads + 4) * 18 * 2;
         return (samples + reads + 64) * (size_t)(F + (K - 1) * FL) * 2 + 2 * reads;
     }
-    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm && gen == o.gen; }
+    bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm; }
 };
 
 struct DeviceBuf {
@@ -257,14 +256,7 @@ struct wsx_caller {
     std::vector<int> n_states;
     std::vector<Variant> uvar; // the distinct kernel variants among `variant` (each has a back-pointer region of its own)
     WsxTuning tun;             // launch-policy knobs (wsx_caller_set_tuning)
-    struct GenFill {           // generated fill of one automaton (wsx_caller_set_generated_fill)
-        hipModule_t mod = nullptr;
-        hipFunction_t fn_u = nullptr, fn_m = nullptr; // unmasked pass, masked pass
-        void *tables = nullptr;                       // device copy of the traceback tables
-        Variant before;                               // the variant the automaton had (wsx_caller_set_generated_fill(.., NULL) restores it)
-    };
-    std::vector<GenFill> genfill; // per automaton
-    int gen_passes = 3;           // which passes use a generated fill: bit 0 the unmasked pass, bit 1 the masked one (WSX_TUNE_GENERATED_PASSES)
+    double create_s[5] = {0, 0, 0, 0, 0}; // wsx_caller_create_times
     DeviceBuf aut_blob, aut_table;
     uint64_t ws_limit = 16ull << 30; // set from the device's free memory at creation (wsx_caller_set_workspace_limit overrides)
     // workspace
@@ -448,6 +440,9 @@ try {
     c->stream = (hipStream_t)stream;
     c->prm = *params;
     HIPCHK(hipSetDevice(device));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    auto t_phase = now();
 
     // validate + size the automaton blob
     size_t blob = 0;
@@ -480,11 +475,14 @@ try {
     }
     HIPCHK(c->aut_blob.ensure(blob));
     HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
-    std::vector<char> hblob(blob);
+    std::unique_ptr<char[]> hblob_mem(new char[blob]); // (not value-initialised: every byte the device reads is written below)
+    char *const hblob = hblob_mem.get();
+    c->create_s[0] = since(t_phase);
+    t_phase = now();
     size_t used = 0;
     auto put = [&](const void *src, size_t bytes) -> void * {
         void *d = (char *)c->aut_blob.p + used;
-        memcpy(hblob.data() + used, src, bytes);
+        memcpy(hblob + used, src, bytes);
         used += align_up(bytes);
         return d;
     };
@@ -623,12 +621,15 @@ try {
         if (nt <= 1) {
             for (int a = 0; a < n_automata; a++) place_one(a);
         } else {
+            // (taken one at a time from a shared counter: a five-slot automaton with nested loops takes a hundred times as long
+            // as a four-slot chain, and the loci of a run repeat with a period that a fixed stride maps onto a few threads)
             std::vector<std::thread> th;
             std::vector<std::exception_ptr> errs((size_t)nt);
+            std::atomic<int> next_a{0};
             for (int t = 0; t < nt; t++)
                 th.emplace_back([&, t] {
                     try {
-                        for (int a = t; a < n_automata; a += nt) place_one(a);
+                        for (int a = next_a.fetch_add(1); a < n_automata; a = next_a.fetch_add(1)) place_one(a);
                     } catch (...) {
                         errs[t] = std::current_exception();
                     }
@@ -638,6 +639,8 @@ try {
                 if (e) std::rethrow_exception(e);
         }
     }
+    c->create_s[1] = since(t_phase);
+    t_phase = now();
     for (int a = 0; a < n_automata; a++) {
         const wsx_automaton &A = automata[a];
         const int S = A.n_states, E = A.pred_ptr[S];
@@ -702,7 +705,6 @@ try {
         for (auto &u : c->uvar) seen = seen || u.same(v);
         if (!seen) c->uvar.push_back(v);
     }
-    c->genfill.resize(c->variant.size());
     // Workspace limit: what the device can give.  A fixed 16 GiB made a 100 000-read call of 2 kSample reads take eight
     // chunks instead of four (more, smaller chunks lose: the serial per-read stages last as long for 6 000 reads as for
     // 100 000); the handle only ever allocates what a call needs, the limit is an upper bound.
@@ -712,8 +714,12 @@ try {
             c->ws_limit = std::max<uint64_t>(2ull << 30, (uint64_t)((double)free_b * 0.6));
     }
     if (c->prm.threshold > 1.0) HIPCHK(hipHostMalloc((void **)&c->smooth_host, 2 * WSX_MAX_STREAMS * sizeof(int32_t), hipHostMallocDefault));
-    HIPCHK(hipMemcpy(c->aut_blob.p, hblob.data(), blob, hipMemcpyHostToDevice));
+    c->create_s[2] = since(t_phase);
+    t_phase = now();
+    HIPCHK(hipMemcpy(c->aut_blob.p, hblob, used, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
+    c->create_s[3] = since(t_phase);
+    t_phase = now();
     HIPCHK(hipEventCreate(&c->ev_begin));
     HIPCHK(hipEventCreate(&c->ev_end));
     for (auto &e : c->ev_meta) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -738,11 +744,19 @@ try {
         HIPCHK(hipStreamCreateWithFlags(&c->aux[w], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_joins[w], hipEventDisableTiming));
     }
+    c->create_s[4] = since(t_phase);
     guard.c = nullptr;
     *out = c;
     return WSX_SUCCESS;
 } catch (...) {
     return wsx_internal_on_exception();
+}
+
+int wsx_caller_create_times(const wsx_caller *c, double *seconds, int32_t capacity)
+{
+    if (!c || !seconds || capacity < 0) return WSX_ERR_INVALID;
+    for (int i = 0; i < std::min<int32_t>(capacity, 5); i++) seconds[i] = c->create_s[i];
+    return WSX_SUCCESS;
 }
 
 void wsx_caller_destroy(wsx_caller *c)
@@ -763,10 +777,6 @@ void wsx_caller_destroy(wsx_caller *c)
     if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
-    for (auto &g : c->genfill) {
-        if (g.mod) (void)hipModuleUnload(g.mod);
-        if (g.tables) (void)hipFree(g.tables);
-    }
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
@@ -819,117 +829,11 @@ int wsx_caller_set_tuning(wsx_caller *c, int32_t knob, int64_t value)
     case WSX_TUNE_SMALL_PIPE_SAMPLES: c->small_pipe_samples = std::max<int64_t>(0, value); break;
     case WSX_TUNE_CALLS_IN_FLIGHT: c->in_flight = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
     case WSX_TUNE_SMALL_CALLS_IN_FLIGHT: c->in_flight_small = (int)std::max<int64_t>(2, std::min<int64_t>(value, wsx_caller::kMetaSlots)); break;
-    case WSX_TUNE_GENERATED_PASSES: c->gen_passes = (int)(value & 3); break;
     default: g_err = "wsx_caller_set_tuning: unknown knob"; return WSX_ERR_INVALID;
     }
     return WSX_SUCCESS;
 }
 
-static void rebuild_unique_variants(wsx_caller *c)
-{
-    c->uvar.clear();
-    for (auto &v : c->variant) {
-        bool seen = false;
-        for (auto &u : c->uvar) seen = seen || u.same(v);
-        if (!seen) c->uvar.push_back(v);
-    }
-}
-
-int wsx_caller_set_generated_fill(wsx_caller *c, int32_t automaton, const wsx_generated_fill *g)
-try {
-    if (!c || automaton < 0 || automaton >= (int)c->variant.size()) {
-        g_err = "wsx_caller_set_generated_fill: bad handle or automaton index";
-        return WSX_ERR_INVALID;
-    }
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream)); // no call of this handle is in flight while its kernels change
-    if (c->join_st) HIPCHK(hipStreamSynchronize(c->join_st));
-    if (c->genfill.size() < c->variant.size()) c->genfill.resize(c->variant.size());
-    wsx_caller::GenFill &G = c->genfill[automaton];
-    DevAutomaton &D = c->host_aut[automaton];
-    if (G.mod) { // replace / remove what was there
-        (void)hipModuleUnload(G.mod);
-        if (G.tables) (void)hipFree(G.tables);
-        c->variant[automaton] = G.before;
-        G = wsx_caller::GenFill{};
-        D.gen_state_at = nullptr;
-        D.gen_tb_n = nullptr;
-        D.gen_tb_word = D.gen_tb_pred = nullptr;
-        D.gen_nwp = D.gen_n = D.gen_end_pos = 0;
-    }
-    if (g) {
-        const int S = c->n_states[automaton];
-        const int P = 4 * g->states_per_lane;
-        if (g->abi != 1 || !g->code || g->code_size == 0 || c->prm.min_values_per_state != 4 || S > 64 || g->states_per_lane <= 0 ||
-            P < S || P > 64 || g->words_per_row < 2 || g->words_per_row > 32 || (g->words_per_row & 1) || g->end_position < 0 ||
-            g->end_position >= P || !g->state_at || !g->tb_n || !g->tb_word || !g->tb_pred) {
-            g_err = "wsx_caller_set_generated_fill: not a generated fill for this automaton (ABI 1, min_values_per_state 4, <= 64 states)";
-            return WSX_ERR_INVALID;
-        }
-        for (int p = 0; p < P; p++) { // the tables must stay inside the automaton and the row
-            if (g->tb_n[p] > WSX_MAX_F || (g->state_at[p] != 0xFFFF && g->state_at[p] >= S)) {
-                g_err = "wsx_caller_set_generated_fill: malformed tables";
-                return WSX_ERR_INVALID;
-            }
-            for (int f = 0; f < g->tb_n[p]; f++)
-                if (g->tb_word[p * WSX_MAX_F + f] >= g->words_per_row || g->tb_pred[p * WSX_MAX_F + f] >= P) {
-                    g_err = "wsx_caller_set_generated_fill: malformed tables";
-                    return WSX_ERR_INVALID;
-                }
-        }
-        if (g->state_at[g->end_position] != c->host_aut[automaton].endstate) {
-            g_err = "wsx_caller_set_generated_fill: the end position does not hold the automaton's end state";
-            return WSX_ERR_INVALID;
-        }
-        hipModule_t mod = nullptr;
-        if (hipModuleLoadData(&mod, g->code) != hipSuccess) {
-            g_err = "wsx_caller_set_generated_fill: the code object does not load on this device";
-            return WSX_ERR_UNSUPPORTED;
-        }
-        hipFunction_t fu = nullptr, fm = nullptr;
-        if (hipModuleGetFunction(&fu, mod, "wsx_fill_t_u") != hipSuccess || hipModuleGetFunction(&fm, mod, "wsx_fill_t_m") != hipSuccess) {
-            (void)hipModuleUnload(mod);
-            g_err = "wsx_caller_set_generated_fill: the code object lacks wsx_fill_t_u / wsx_fill_t_m";
-            return WSX_ERR_INVALID;
-        }
-        // tables: state_at u16[P] | tb_word u16[P*4] | tb_pred u16[P*4] | tb_n u8[P]
-        const size_t o_word = align_up((size_t)P * 2), o_pred = o_word + align_up((size_t)P * WSX_MAX_F * 2),
-                     o_n = o_pred + align_up((size_t)P * WSX_MAX_F * 2), total = o_n + align_up((size_t)P);
-        std::vector<char> h(total, 0);
-        memcpy(h.data(), g->state_at, (size_t)P * 2);
-        memcpy(h.data() + o_word, g->tb_word, (size_t)P * WSX_MAX_F * 2);
-        memcpy(h.data() + o_pred, g->tb_pred, (size_t)P * WSX_MAX_F * 2);
-        memcpy(h.data() + o_n, g->tb_n, (size_t)P);
-        void *dt = nullptr;
-        if (hipMalloc(&dt, total) != hipSuccess || hipMemcpy(dt, h.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
-            if (dt) (void)hipFree(dt);
-            (void)hipModuleUnload(mod);
-            g_err = "wsx_caller_set_generated_fill: out of device memory";
-            return WSX_ERR_NOMEM;
-        }
-        G.mod = mod;
-        G.fn_u = fu;
-        G.fn_m = fm;
-        G.tables = dt;
-        G.before = c->variant[automaton];
-        D.gen_state_at = (const uint16_t *)dt;
-        D.gen_tb_word = (const uint16_t *)((char *)dt + o_word);
-        D.gen_tb_pred = (const uint16_t *)((char *)dt + o_pred);
-        D.gen_tb_n = (const uint8_t *)((char *)dt + o_n);
-        D.gen_nwp = g->words_per_row;
-        D.gen_n = g->states_per_lane;
-        D.gen_end_pos = g->end_position;
-        Variant v = G.before;
-        v.gen = automaton + 1;
-        v.nwp = g->words_per_row;
-        c->variant[automaton] = v;
-    }
-    HIPCHK(hipMemcpy((char *)c->aut_table.p + sizeof(DevAutomaton) * automaton, &D, sizeof(DevAutomaton), hipMemcpyHostToDevice));
-    rebuild_unique_variants(c);
-    return WSX_SUCCESS;
-} catch (...) {
-    return wsx_internal_on_exception();
-}
 
 int wsx_caller_set_streams(wsx_caller *c, int32_t n_streams)
 {
@@ -983,7 +887,6 @@ const char *wsx_caller_kernel_name(wsx_caller *c, int32_t a)
 {
     if (!c || a < 0 || a >= (int)c->variant.size()) return "";
     const Variant &v = c->variant[a];
-    if (v.gen) return "wsx_fill_t_u";
     return wsx_pass_kernel_name(c->prm.min_values_per_state, v.K, v.F, v.FL, v.pk, v.lm, v.generic);
 }
 
@@ -1206,10 +1109,10 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     HIPCHK(hipEventSynchronize(c->ev_meta[slot]));
     if (pipe && depth < wsx_caller::kMetaSlots && seq >= (uint64_t)depth)
         HIPCHK(hipEventSynchronize(c->ev_meta[(seq - depth) % (uint64_t)wsx_caller::kMetaSlots]));
-    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8)));
+    HIPCHK(c->meta[slot].ensure(align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8)));
     if (pipe) // (the other slots too, once: an allocation in the middle of a pipelined sequence stalls the streams)
         for (int q = 0; q < wsx_caller::kMetaSlots; q++) {
-            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8);
+            const size_t need = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
             if (q == slot || (c->meta[q].cap >= need && c->pinned_cap[q] >= need)) continue;
             HIPCHK(hipEventSynchronize(c->ev_meta[q])); // (only ever waits when the batch size grows mid-sequence)
             HIPCHK(c->meta[q].ensure(need));
@@ -1226,10 +1129,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int32_t *d_autid = mc.take<int32_t>(n);
     int32_t *d_order = mc.take<int32_t>(n);
     int64_t *d_bpoff = mc.take<int64_t>(n); // per read (global index): start of its back-pointer rows in its chunk's region
-    int64_t *d_bpoff2 = mc.take<int64_t>(n); // ... in the passes where a read with a generated fill takes its built-in kernel
     // metadata goes through a pinned buffer owned by the handle: the uploads are then truly asynchronous and the
     // caller's arrays are not referenced after this function returns
-    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4) + 2 * align_up(n * 8);
+    const size_t pin_bytes = align_up((n + 1) * 8) + 2 * align_up(n * 4) + align_up(n * 8);
     if (pin_bytes > c->pinned_cap[slot]) {
         if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
         c->pinned[slot] = nullptr;
@@ -1242,7 +1144,6 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     int32_t *h_autid = pc.take<int32_t>(n);
     int32_t *h_order = pc.take<int32_t>(n);
     int64_t *h_bpoff = pc.take<int64_t>(n);
-    int64_t *h_bpoff2 = pc.take<int64_t>(n);
     memcpy(h_offsets, io.offsets, (n + 1) * 8);
     memcpy(h_autid, io.aut_id, n * 4);
     HIPCHK(hipMemcpyAsync(d_offsets, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1297,7 +1198,7 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
     // tracebacks may be issued in any order, and a handle with many variants (mixed loci) needs no more than its reads do.
     // The tracebacks fetch whole blocks of rows and may look past a read's last row: the region ends with slack for that.
     // Launch order of every chunk first (host only): reads grouped by kernel variant, longest first inside a group (load
-    // balance; the generated fills put 16 consecutive reads of their group into one wavefront, which share their rows).
+    // balance).
     struct Launches {
         std::vector<std::vector<int32_t>> groups;
         std::vector<Variant> gvar;
@@ -1330,28 +1231,14 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             std::copy(grp.begin(), grp.end(), h_order + pos);
             pos += grp.size();
             const Variant &v = L.gvar[g];
-            if (v.gen) { // a wavefront's 16 reads share the rows of its longest (= first) read
-                for (size_t w0 = 0; w0 < grp.size(); w0 += WSX_GEN_RPW) {
-                    for (size_t e = w0; e < std::min(grp.size(), w0 + WSX_GEN_RPW); e++) h_bpoff[grp[e]] = (int64_t)at;
-                    at += v.bp_read_words((size_t)(io.offsets[grp[w0] + 1] - io.offsets[grp[w0]]));
-                }
-                // ... and, for the passes these reads run through their built-in kernel (WSX_TUNE_GENERATED_PASSES), its rows
-                const Variant &bv = c->genfill[v.gen - 1].before;
-                for (int32_t r : grp) {
-                    h_bpoff2[r] = (int64_t)at;
-                    if (c->gen_passes != 3) at += bv.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
-                }
-            } else {
-                for (int32_t r : grp) {
-                    h_bpoff[r] = h_bpoff2[r] = (int64_t)at;
-                    at += v.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
-                }
+            for (int32_t r : grp) {
+                h_bpoff[r] = (int64_t)at;
+                at += v.bp_read_words((size_t)(io.offsets[r + 1] - io.offsets[r]));
             }
         }
         bp_words64 = std::max(bp_words64, at + kBpSlackWords);
     }
     HIPCHK(hipMemcpyAsync(d_bpoff, h_bpoff, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_bpoff2, h_bpoff2, (size_t)n * 8, hipMemcpyHostToDevice, st));
     for (int k = 0; k < n_sized; k++) HIPCHK(c->work[sized_set(k)].bp.ensure(bp_words64 * 8));
     for (int k = 0; k < n_work && host; k++) {
         const int w = wset(k);
@@ -1573,35 +1460,8 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             int rc2 = get_event_pair(c, &e0, &e1, pa.n_launch);
             if (rc2) return rc2;
             HIPCHK(hipEventRecord(e0, s));
-            // a generated fill may be used for the unmasked pass only, for the masked one only, or for both (gen_passes bits 1 / 2)
-            const bool use_gen = x.gvar[g].gen && (c->gen_passes & (maskbits ? 2 : 1));
-            const Variant lv = (x.gvar[g].gen && !use_gen) ? c->genfill[x.gvar[g].gen - 1].before : x.gvar[g];
-            if (x.gvar[g].gen && !use_gen) pa.bp_off = d_bpoff2 + x.ch.first;
-            if (use_gen) { // the automaton's own generated code (fillgen.py), 16 reads per wavefront
-                const int aidx = x.gvar[g].gen - 1;
-                GenFillArgs ga{};
-                ga.signal = pa.signal;
-                ga.offsets = pa.offsets;
-                ga.order = pa.order;
-                ga.bp_off = pa.bp_off;
-                ga.bp = (uint64_t *)pa.bp;
-                ga.maskbits = pa.maskbits;
-                ga.end_cost = pa.end_cost;
-                ga.last_row = pa.last_row;
-                ga.status = pa.status;
-                ga.base_off = pa.base_off;
-                ga.n_launch = pa.n_launch;
-                ga.first_read = pa.first_read;
-                ga.last_row_stride = pa.last_row_stride;
-                ga.check_status = pa.check_status;
-                ga.boundary = c->host_aut[aidx].flank_length - 10;
-                void *params[] = {&ga};
-                const unsigned waves = (unsigned)((pa.n_launch + WSX_GEN_RPW - 1) / WSX_GEN_RPW);
-                HIPCHK(hipModuleLaunchKernel(maskbits ? c->genfill[aidx].fn_m : c->genfill[aidx].fn_u, waves, 1, 1, 64, 1, 1, 0, s, params,
-                                             nullptr));
-            } else {
-                HIPCHK(wsx_launch_fill(pa, m, lv.K, lv.F, lv.FL, lv.pk, lv.lm, lv.generic, c->tun, s));
-            }
+            const Variant &lv = x.gvar[g];
+            HIPCHK(wsx_launch_fill(pa, m, lv.K, lv.F, lv.FL, lv.pk, lv.lm, lv.generic, c->tun, s));
             HIPCHK(hipEventRecord(e1, s));
         }
         return WSX_SUCCESS;
@@ -1614,12 +1474,9 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
             pa.maskbits = maskbits;
             pa.trace = trace;
             pa.status = status;
-            const bool use_gen = x.gvar[g].gen && (c->gen_passes & (maskbits ? 2 : 1));
-            const Variant lv = (x.gvar[g].gen && !use_gen) ? c->genfill[x.gvar[g].gen - 1].before : x.gvar[g];
-            if (x.gvar[g].gen && !use_gen) pa.bp_off = d_bpoff2 + x.ch.first;
+            const Variant &lv = x.gvar[g];
             pa.lane_major = lv.lm != 0;
-            if (use_gen) HIPCHK(wsx_launch_traceback_t(pa, x.gvar[g].nwp, c->host_aut[x.gvar[g].gen - 1].gen_n, s));
-            else HIPCHK(wsx_launch_traceback(pa, lv.K, lv.F, lv.FL, lv.pk, lv.generic, nA, c->tun, s));
+            HIPCHK(wsx_launch_traceback(pa, lv.K, lv.F, lv.FL, lv.pk, lv.generic, nA, c->tun, s));
         }
         return WSX_SUCCESS;
     };

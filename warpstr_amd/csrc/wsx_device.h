@@ -60,35 +60,7 @@ struct DevAutomaton {
     const uint64_t *pred4;  // per POSITION (slot*64 + lane; K*64 entries): the positions of its state's first four
                             // predecessors, 16 bits each (mask traceback)
     uint64_t stack_mask;    // stacked lane-major placement (wsx_place.h, LM = 4): lanes whose slot WSX_STACK_SLOT reads LDS
-    // generated fill (warpstr_amd/fillgen.py; wsx_caller_set_generated_fill): a read in four lanes, gen_n states per lane;
-    // position p = lane_in_quad * gen_n + register.  Null / 0 for automata without one.
-    const uint16_t *gen_state_at; // position -> state (0xFFFF = none)
-    const uint8_t *gen_tb_n;      // position -> number of candidates
-    const uint16_t *gen_tb_word;  // [position * 4 + f]: which 64-bit word of a wave-row holds candidate f's bits
-    const uint16_t *gen_tb_pred;  // [position * 4 + f]: position of predecessor f
-    int32_t gen_nwp;              // 64-bit words per wave-row
-    int32_t gen_n;
-    int32_t gen_end_pos;          // position of the end state
-    int32_t gen_pad;
 };
-
-// Arguments of a generated fill kernel (fillgen.py writes the same struct into the source it generates: ABI 1).
-struct GenFillArgs {
-    const double *signal;
-    const int64_t *offsets;
-    const int32_t *order;
-    const int64_t *bp_off;
-    uint64_t *bp;
-    const uint32_t *maskbits;
-    double *end_cost;
-    double *last_row;
-    int32_t *status;
-    int64_t base_off;
-    int32_t n_launch, first_read, last_row_stride, check_status;
-    int32_t boundary;
-    int32_t pad;
-};
-constexpr int WSX_GEN_RPW = 16; // reads per wavefront of a generated fill (four lanes each)
 
 struct DevParams {
     int32_t m;                  // min_values_per_state
@@ -211,7 +183,6 @@ struct EvalArgs {
 // lm: lane-major placement (0 = no; 1 = slots 0 and K-1 export to LDS; 3 = slots 0, 1 and K-1; 2 = every slot), dtw_kernels.hip: dp_row
 hipError_t wsx_launch_fill(const PassArgs &a, int m, int K, int F, int FL, bool pk, int lm, bool generic, const WsxTuning &tun, hipStream_t s);
 hipError_t wsx_launch_traceback(const PassArgs &a, int K, int F, int FL, bool pk, bool generic, int n_aut, const WsxTuning &tun, hipStream_t s);
-hipError_t wsx_launch_traceback_t(const PassArgs &a, int nwp, int n_per_lane, hipStream_t s); // over the words of a generated fill (gen_kernels.hip)
 hipError_t wsx_launch_expand_trace(const PassArgs &a, hipStream_t s);
 hipError_t wsx_launch_mid(const MidArgs &a, int max_T, const WsxTuning &tun, hipStream_t s);
 hipError_t wsx_launch_fit(const FitArgs &a, hipStream_t s);

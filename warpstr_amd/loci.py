@@ -38,7 +38,8 @@ class LocusJob:
     """One locus of a multi-locus run: the `saved` rows of its overview, its two automata, and later its outputs."""
 
     def __init__(self, locus, pore_model, tm: Dict[str, float], caller_config: Optional[CallerConfig] = None, write: bool = False,
-                 native: bool = True):
+                 native: bool = True, setup=None):
+        """setup: the locus's _hostlib.NativeSetup if the caller made it already (a chunk of loci in one library call)."""
         from .automata import locus_automata
         t0 = time.perf_counter()
         self.locus = locus
@@ -46,7 +47,15 @@ class LocusJob:
         self.flank_length = int(locus.flank_length)
         self.overview_path = os.path.join(locus.path, ov.OVERVIEW_NAME)
         self._df = None
-        self.native = _hostlib.NativeOverview.open(self.overview_path) if native else None
+        lim = caller_config.min_state_similarity if caller_config is not None else 0.0
+        # overview.csv, the flank file, both automata and state_similarity.csv in one library call without the GIL; whatever
+        # the library leaves out (`None`) is done below by the Python form, which also raises what upstream raises
+        if setup is None and native:
+            setup = _hostlib.NativeSetup.run(locus.path, self.sequence, pore_model, lim, write and caller_config is not None)
+        self._setup = setup
+        if self._setup is not None and self._setup.overview_status < 0:
+            raise FileNotFoundError(f'Not found the overview file {self.overview_path} - Please check the "output" in config')
+        self.native = self._setup.overview if self._setup is not None else None
         if self.native is not None:
             nat = self.native
             self.saved, self.names, self.reverse, self.lo, self.hi = nat.saved, nat.names, nat.reverse, nat.lo, nat.hi
@@ -62,19 +71,25 @@ class LocusJob:
             self.run_id = np.asarray(df['run_id'])[self.saved] if 'run_id' in df.columns else None
             self.fast5_path = np.asarray(df['fast5_path'])[self.saved] if 'fast5_path' in df.columns else None
         t1 = time.perf_counter()
-        lt, rt, lr, rr = ov.load_flanks(locus.path)
-        self.temp_sta, self.rev_sta = locus_automata(lt, rt, lr, rr, self.sequence, pore_model)
+        if self._setup is not None and self._setup.tables is not None:
+            self.temp_sta, self.rev_sta = self._setup.tables
+        else:
+            lt, rt, lr, rr = ov.load_flanks(locus.path)
+            self.temp_sta, self.rev_sta = locus_automata(lt, rt, lr, rr, self.sequence, pore_model)
         t2 = time.perf_counter()
         # summaries/state_similarity.csv; upstream's warnings are printed by the caller, in the order of the loci
         self.warnings: List[str] = []
         if caller_config is not None:
-            text, self.warnings, _ = similarity_report(self.sequence, pore_model, caller_config.min_state_similarity)
-            if write:
-                out_dir = os.path.join(locus.path, 'summaries')
-                os.makedirs(out_dir, exist_ok=True)
-                with open(os.path.join(out_dir, 'state_similarity.csv'), 'w') as f:
-                    f.write(text)
-        tm['overview_s'] = tm.get('overview_s', 0.0) + t1 - t0
+            if self._setup is not None and self._setup.similarity is not None:
+                self.warnings = self._setup.similarity[1]
+            else:
+                text, self.warnings, _ = similarity_report(self.sequence, pore_model, caller_config.min_state_similarity)
+                if write:
+                    out_dir = os.path.join(locus.path, 'summaries')
+                    os.makedirs(out_dir, exist_ok=True)
+                    with open(os.path.join(out_dir, 'state_similarity.csv'), 'w') as f:
+                        f.write(text)
+        tm['overview_s'] = tm.get('overview_s', 0.0) + t1 - t0   # (native: the whole set-up call is booked here)
         tm['automata_s'] = tm.get('automata_s', 0.0) + t2 - t1
         tm['similarity_s'] = tm.get('similarity_s', 0.0) + time.perf_counter() - t2
 
@@ -116,6 +131,7 @@ class HipEngine:
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
+                'handle_create_s': self.hip.create_times(),
                 'kernels': sorted({self.hip.kernel_name(a) for a in range(min(len(self.hip.automata), 256))})}
 
     def close(self):
@@ -134,7 +150,8 @@ class LociTables(collections.abc.Sequence):
     """What main_wrapper_loci returns: per locus the pair main_wrapper returns, (df_overview, df_collapsed) -- built when it is
     looked at (a run of thousands of loci writes thousands of files and usually looks at none of the tables; a DataFrame costs
     more than the files of its locus).  An entry is ('frames', df_overview, df_collapsed), ('text', overview CSV text, complex-unit
-    CSV text or None) or ('disk', locus path: another rank wrote it)."""
+    CSV text or None), ('native', the locus's _hostlib.NativeOverview after its store, complex-unit CSV text or None) or ('disk',
+    locus path, whether it may have a complex-unit table: another rank wrote it)."""
 
     def __init__(self, entries: list):
         self._e = entries
@@ -146,6 +163,8 @@ class LociTables(collections.abc.Sequence):
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
         e = self._e[i]
+        if e[0] == 'native':
+            e = self._e[i] = ('text', e[1].table_text(), e[2])
         if e[0] == 'text':
             import io
 
@@ -159,8 +178,9 @@ class LociTables(collections.abc.Sequence):
 
 
 def _complex_header(units, repeat_units):
-    """Column names of store_collapsed's table (overview.py; src/caller/overview.py:11-34) without the trailing `reverse`, or
-    None when two columns would share a name (a dict keeps one of them: the pandas form decides which)."""
+    """(column names of store_collapsed's table incl. the trailing `reverse`, which generated column each shows) -- the table
+    is a dict upstream (overview.py; src/caller/overview.py:11-34): units of the same name share ONE column, at the place of the
+    first, with the values of the last --, or None for names a CSV line cannot hold as they are."""
     cols = []
     for unit, alts in zip(units, repeat_units):
         if len(alts) > 1:
@@ -168,38 +188,56 @@ def _complex_header(units, repeat_units):
             cols += ['inter_' + a[len(alts[0]):] for a in alts[1:]]
         else:
             cols.append(unit.strip('(').strip(')'))
-    if len(set(cols)) != len(cols) or 'reverse' in cols or any(',' in c or '"' in c or not c for c in cols):
+    last = {}
+    for idx, name in enumerate(cols):
+        last[name] = idx   # (a dict keeps a key's first position and its last value)
+    if 'reverse' in last or any(',' in c or '"' in c or '\n' in c or not c for c in last):
         return None
-    return ','.join(cols + ['reverse'])
+    return ','.join(list(last) + ['reverse']), list(last.values())
 
 
-def _store_job(job: LocusJob, rec, seq1, off1, seq2, off2, write: bool):
+def _store_job(job: LocusJob, rec, seq1, off1, seq2, off2, write: bool, quiet: bool = False, overview_done: bool = False):
     """The outputs of one locus from its reads' records and called sequences (offsets into seq1 / seq2 per read): the files
-    main_wrapper writes (write=True) and the entry of LociTables.  Returns (entry, messages to print)."""
-    from .units import break_into_units
+    main_wrapper writes (write=True) and the entry of LociTables.  overview_done: overview.csv and the FASTA files of this
+    (native) locus were written with its chunk (_hostlib.store_many).  Returns (entry, messages to print)."""
     from .wrapper import _store_outputs
-    ok = rec['status'] == 0
-    if job.native is not None and bool(ok.all()):
-        l1, l2 = rec['len1'], rec['len2']
-        text = job.native.store(job.locus.path, l1, l2, rec['cost1'], rec['cost2'], seq2, off2, write)
-        units, repeat_units, offsets = break_into_units(job.sequence)
+    if job.native is not None and (overview_done or bool((rec['status'] == 0).all())):
+        l2 = rec['len2']
+        if not overview_done:
+            job.native.store(job.locus.path, rec['len1'], l2, rec['cost1'], rec['cost2'], seq2, off2, write)
+        units, repeat_units, offsets = _units_of(job.sequence)
         if len(units) <= 1:
-            return ('text', text, None), []
+            return ('native', job.native, None), []
         header = _complex_header(units, repeat_units) if job.n > 0 else None
-        got = _hostlib.collapse_store(job.locus.path, seq2, off2, l2, job.reverse, repeat_units, offsets, header, write) if header else None
+        got = _hostlib.collapse_store(job.locus.path, seq2, off2, l2, job.reverse, repeat_units, offsets, header[0], header[1], write) if header else None
         if got is not None:
-            return ('text', text, got[1]), [f'Running complex genotyping as complex repeat units present: {units}']
+            return ('native', job.native, got[1]), [f'Running complex genotyping as complex repeat units present: {units}']
         # (the complex-unit table through pandas; overview.csv and the FASTA files are written)
         from .units import collapse_repeats
         s2 = bytes(seq2).decode('ascii', 'replace')
         called = [s2[o:o + n] for o, n in zip(np.asarray(off2).tolist(), np.asarray(l2).tolist())]
         df_collapsed = ov.store_collapsed([collapse_repeats(s, repeat_units, offsets) for s in called], units, repeat_units,
                                           [bool(v) for v in job.reverse], job.locus.path, write=write)
-        return ('frames', ov.table_from_text(text), df_collapsed), [f'Running complex genotyping as complex repeat units present: {units}']
+        return (('frames', ov.table_from_text(job.native.table_text()), df_collapsed),
+                [f'Running complex genotyping as complex repeat units present: {units}'])
     results = CallerResults(job.names, rec, off1, seq1, seq2, 'raise', offsets2=off2).check()
-    with _muted(not write):
+    with _muted(quiet or not write):
         dfo, dfc = _store_outputs(job.locus, job.overview_path, job.df_overview, results, [bool(v) for v in job.reverse], write=write)
     return ('frames', dfo, dfc), []
+
+
+_UNITS: Dict[str, tuple] = {}
+
+
+def _units_of(sequence: str):
+    """units.break_into_units, remembered per pattern (a run's loci repeat a few hundred patterns at most)."""
+    got = _UNITS.get(sequence)
+    if got is None:
+        from .units import break_into_units
+        if len(_UNITS) > 4096:
+            _UNITS.clear()
+        got = _UNITS[sequence] = break_into_units(sequence)
+    return got
 
 
 # ---- fast5 files on worker processes -----------------------------------------------------------------------------------------
@@ -358,7 +396,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     from .pore_model import default_pore_model
     t_start = time.perf_counter()
     tm = timings if timings is not None else {}
-    for key in ('overview_s', 'automata_s', 'similarity_s', 'handle_s', 'read_s', 'submit_s', 'collect_s', 'gather_s', 'store_s'):
+    for key in ('native_setup_s', 'overview_s', 'automata_s', 'similarity_s', 'handle_s', 'read_s', 'submit_s', 'collect_s', 'gather_s', 'store_s'):
         tm[key] = 0.0
     if partition not in ('auto', 'loci', 'reads'):
         raise ValueError("partition must be 'auto', 'loci' or 'reads'")
@@ -401,7 +439,13 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
 
         def setup(part):
             ptm: Dict[str, float] = {}
-            return [LocusJob(loci[i], pore_model, ptm, caller_config, write=writes, native=native) for i in part], ptm
+            t1 = time.perf_counter()
+            chunk = [loci[i] for i in part]
+            sts = _hostlib.NativeSetup.run_many([l.path for l in chunk], [l.sequence.upper() for l in chunk], pore_model,
+                                                caller_config.min_state_similarity, writes) if native else None
+            ptm['native_setup_s'] = time.perf_counter() - t1
+            return [LocusJob(l, pore_model, ptm, caller_config, write=writes, native=native, setup=sts[q] if sts else None)
+                    for q, l in enumerate(chunk)], ptm
         for part_jobs, ptm in _thread_map(executor, setup, parts):
             jobs += part_jobs
             for key, v in ptm.items():
@@ -561,17 +605,32 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         first_bad = int(wdist.gather_counts(first_bad, world, coll_device).min())
         n_good = int(np.searchsorted(own, first_bad))
 
-    def store(li):
+    def store(li, overview_done=False):
         job = jobs[li]
         a, b = int(first[li]), int(first[li + 1])
         s1, s2 = seq1[int(off1[a]):int(off1[b])], seq2[int(off2[a]):int(off2[b])]
-        return _store_job(job, records[a:b], s1, off1[a:b] - off1[a], s2, off2[a:b] - off2[a], writes)
+        return _store_job(job, records[a:b], s1, off1[a:b] - off1[a], s2, off2[a:b] - off2[a], writes, quiet, overview_done)
+
+    # the run's per-read columns, contiguous: a chunk of native loci writes its overview.csv / FASTA files in ONE library call
+    cols = None
+    if n_good and _hostlib.lib() is not None:
+        cols = (np.ascontiguousarray(records['len1'], np.int32), np.ascontiguousarray(records['len2'], np.int32),
+                np.ascontiguousarray(records['cost1'], np.float64), np.ascontiguousarray(records['cost2'], np.float64),
+                np.ascontiguousarray(seq2, np.uint8), np.ascontiguousarray(off2[:-1] if len(off2) > len(records) else off2, np.int64))
+
+    def store_chunk(ids):
+        _hostlib.store_many([jobs[li].native for li in ids], [jobs[li].locus.path for li in ids], [first[li] for li in ids], *cols, writes)
+        return [store(li, True) for li in ids]
 
     entries: list = [None] * len(loci)
     error = None
     try:
-        native_ids = [li for li in range(n_good) if jobs[li].native is not None]
-        done = dict(zip(native_ids, _thread_map(executor, store, native_ids)))
+        native_ids = [li for li in range(n_good) if jobs[li].native is not None] if cols is not None else []
+        step = max(1, min(64, len(native_ids) // (4 * max(tm['host_threads'], 1)) or 1))
+        done = {}
+        for ids, part in zip([native_ids[k:k + step] for k in range(0, len(native_ids), step)],
+                             _thread_map(executor, store_chunk, [native_ids[k:k + step] for k in range(0, len(native_ids), step)])):
+            done.update(zip(ids, part))
         for li in range(n_good):  # (tables that went through pandas: here, one after the other)
             entry, messages = done[li] if li in done else store(li)
             entries[int(own[li])] = entry
@@ -594,9 +653,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         if entries[i] is None:   # another rank's locus: its files say everything
             units_gt1 = sum(ch == '(' for ch in loci[i].sequence) > 0
             entries[i] = ('disk', loci[i].path, units_gt1)
-    for job in jobs:
-        if job.native is not None:
-            job.native.close()
     tm['total_s'] = time.perf_counter() - t_start
     return LociTables(entries)
 
