@@ -37,7 +37,7 @@ class _Seq:  # minimal Bio.Seq.Seq stand-in (only reverse_complement is used)
 
 
 def import_reference(min_values_per_state=4, states_in_segment=6, threshold=0.5,
-                     max_std=0.5, method='mean', reps_as_one=False, flank_length=110):
+                     max_std=0.5, method='mean', reps_as_one=False, flank_length=110, pore_model_path=None, genotyping_config=None):
     """Returns a namespace with the reference's caller symbols.  One config per process."""
     if not reference_available():
         raise RuntimeError('reference not present')
@@ -68,6 +68,8 @@ tr_region_extraction: False
 tr_region_calling: True
 genotyping: False
 flank_length: {flank_length}
+{('pore_model_path: ' + pore_model_path) if pore_model_path else ''}
+{('genotyping_config: ' + repr(dict(genotyping_config))) if genotyping_config else ''}
 tr_calling_config:
   min_values_per_state: {min_values_per_state}
   states_in_segment: {states_in_segment}

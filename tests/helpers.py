@@ -27,3 +27,19 @@ def assert_close_rel(a, b, rel=1e-5):
         assert a == b
         return
     assert abs(a - b) <= rel * max(abs(a), abs(b), 1e-300), (a, b)
+
+
+def write_perturbed_pore_model(path: str) -> str:
+    """A pore-model table in upstream's format (example/deps/template_median68pA.model: tab-separated, columns kmer and
+    level_mean among others) whose levels differ from the built-in r9.4 table -- a deterministic function of it -- for the tests
+    of the `pore_model_path` configuration key (tests/golden/cfg_keys.*: recorded from upstream with this very file)."""
+    from warpstr_amd import pore_model
+    level = np.load(pore_model._DATA)
+    i = np.arange(len(level))
+    new = level * 1.04 + ((i * 2654435761) % 1009) / 400.0 - 1.2   # (products, sums and one exact division: no libm)
+    with open(path, 'w') as f:
+        f.write('kmer\tlevel_mean\tlevel_stdv\n')
+        for k, v in enumerate(new):
+            kmer = ''.join('ACGT'[(k >> (2 * (5 - b))) & 3] for b in range(6))
+            f.write(f'{kmer}\t{float(v)!r}\t1.5\n')
+    return path

@@ -124,3 +124,125 @@ def test_config_driven_run_on_one_and_two_ranks(tmp_path):
         for li, (_, _, n, _) in enumerate(LOCI):
             assert f'locus{li}: {n} reads called' in out
         _same(one, [LocusPath(os.path.join(tmp_path, tag, f'locus{li}'), p, fl) for li, (p, fl, _, _) in enumerate(LOCI)])
+
+
+def test_configuration_keys_reach_the_kernels_and_the_genotyper(tmp_path, capsys):
+    """`python -m warpstr_amd cfg.yaml` with a perturbed `pore_model_path`, non-default `genotyping_config` and `force_overwrite`
+    (tests/golden/cfg_keys.*: upstream run with the same table and settings): every read's called lengths and costs as upstream's
+    caller gave them under THAT table, alleles.csv as upstream's genotyper wrote it under THOSE settings, last run's files gone."""
+    import json
+
+    import yaml
+
+    from tests.helpers import GOLDEN, load_case, write_perturbed_pore_model
+    from warpstr_amd.wrapper import main
+    fix = json.load(open(os.path.join(GOLDEN, 'cfg_keys.json')))
+    z = load_case('cfg_keys')
+    n = int(z['n_reads'])
+    loc = tmp_path / 'out' / 'L'
+    ov.store_flanks(str(loc), [str(x) for x in z['flanks']])
+    names = [f'read{i:03d}' for i in range(n)]
+    pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': z['reverse'].astype(bool), 'saved': 1, 'l_start_raw': 0,
+                  'r_end_raw': [len(z[f'r{i}_signal']) - 1 for i in range(n)]}).to_csv(loc / 'overview.csv', index=False)
+    os.makedirs(loc / 'predictions' / 'sequences')
+    (loc / 'predictions' / 'sequences' / 'stale.fasta').write_text('>old\n')
+    npz = str(tmp_path / 'segments.npz')
+    np.savez(npz, **{nm: z[f'r{i}_signal'] for i, nm in enumerate(names)})
+    cfg = {'output': str(tmp_path / 'out'), 'threads': 2, 'tr_region_calling': True, 'genotyping': True, 'force_overwrite': True,
+           'flank_length': fix['flank_length'], 'pore_model_path': write_perturbed_pore_model(str(tmp_path / 'perturbed.model')),
+           'tr_calling_config': {'visualize_alignment': False, 'visualize_phase': False, 'visualize_strand': False, 'visualize_cost': False},
+           'genotyping_config': fix['genotyping_config'], 'loci': [{'name': 'L', 'coord': 'chr1:1-2', 'sequence': fix['pattern']}]}
+    path = str(tmp_path / 'cfg.yaml')
+    with open(path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    case = fix['cases'][0]
+    np.random.seed(case['seed'])
+    main(['--config', path, '--segments-npz', npz])
+    df = pd.read_csv(loc / 'overview.csv')
+    for i in range(n):
+        assert (int(df['orig'][i]), int(df['results'][i])) == (len(str(z[f'r{i}_seq'][0])), len(str(z[f'r{i}_seq'][1]))), i
+        assert abs(df['dtw_cost1'][i] - z[f'r{i}_cost'][0]) <= 1e-9 * abs(z[f'r{i}_cost'][0])
+        assert abs(df['dtw_cost2'][i] - z[f'r{i}_cost'][1]) <= 1e-9 * abs(z[f'r{i}_cost'][1])
+    assert [int(v) for v in df['results']] == case['results']
+    assert open(loc / 'predictions' / 'alleles.csv').read() == case['alleles_csv']
+    assert case['stdout'].strip() in capsys.readouterr().out
+    assert not (loc / 'predictions' / 'sequences' / 'stale.fasta').exists()
+    # the same reads under the default table are called differently: the key is not decoration
+    cfg2 = dict(cfg, pore_model_path='example/deps/template_median68pA.model', genotyping=False)
+    with open(path, 'w') as f:
+        yaml.safe_dump(cfg2, f)
+    main(['--config', path, '--segments-npz', npz])
+    df2 = pd.read_csv(loc / 'overview.csv')
+    assert not np.allclose(df2['dtw_cost2'], df['dtw_cost2'])
+
+
+MANY = [('(AGC)', 16, (900, 1400)), ('(AAAT)', 40, (1200, 1800)), ('(AGC)AACAGCCGCCAC(CGC)', 20, (1300, 1900)), ('(GGCCCC)', 30, (1000, 1500)),
+        ('(CTG)CTA(CTG)', 24, (1200, 1700))]
+
+
+def _make_many(root, tag, n_loci):
+    """n_loci small loci (1-6 reads, one without saved reads) + the normalised segments by read name."""
+    loci, segs = [], {}
+    for li in range(n_loci):
+        pattern, fl, T = MANY[li % len(MANY)]
+        n = 0 if li == 7 else 1 + (li * 5) % 6
+        locus = synth.make_locus(pattern, fl, 700 + li)
+        sigs, revs, _ = synth.batch(locus, n, T, 800 + li, lo=3, hi=10)
+        loc = os.path.join(root, tag, f'locus{li:02d}')
+        ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+        names = [f'M{li:02d}r{i}' for i in range(n + 1)]
+        pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': list(revs) + [False], 'saved': [1] * n + [0], 'l_start_raw': 0,
+                      'r_end_raw': [len(s) - 1 for s in sigs] + [50]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        segs.update(dict(zip(names, sigs)))
+        loci.append(LocusPath(loc, pattern, fl, f'locus{li:02d}'))
+    return loci, segs
+
+
+def _many_cfg(tmp_path, tag, n_loci):
+    cfg = tmp_path / f'{tag}.yaml'
+    cfg.write_text(f'output: {tmp_path / tag}\nthreads: 2\ntr_region_calling: True\ngenotyping: False\nloci:\n' + ''.join(
+        f'  - name: locus{li:02d}\n    coord: chr1:1-2\n    sequence: {MANY[li % len(MANY)][0]}\n    flank_length: {MANY[li % len(MANY)][1]}\n'
+        for li in range(n_loci)))
+    return str(cfg)
+
+
+def test_forty_loci_partitioned_over_four_ranks_on_the_one_card(tmp_path):
+    """The locus partition of a many-loci run (>= 8 loci per rank) on real kernels: four fresh ranks on the one card (gloo for the
+    collectives), every rank setting up, calling and writing only its own loci -- the files of one rank's run, byte for byte."""
+    n_loci = 40
+    one, segs = _make_many(str(tmp_path), 'one', n_loci)
+    _make_many(str(tmp_path), 'four', n_loci)
+    npz = str(tmp_path / 'segments.npz')
+    np.savez(npz, **segs)
+    out1 = _cli(['--config', _many_cfg(tmp_path, 'one', n_loci), '--segments-npz', npz], 1)
+    out4 = _cli(['--config', _many_cfg(tmp_path, 'four', n_loci), '--segments-npz', npz], 4, {'WARPSTR_DIST_BACKEND': 'gloo'})
+    for li in range(n_loci):
+        n = 0 if li == 7 else 1 + (li * 5) % 6
+        assert f'locus{li:02d}: {n} reads called' in out1 and f'locus{li:02d}: {n} reads called' in out4
+    _same(one, [LocusPath(os.path.join(tmp_path, 'four', f'locus{li:02d}'), *MANY[li % len(MANY)][:2]) for li in range(n_loci)])
+
+
+@pytest.mark.parametrize('partition', ['loci', 'reads'])
+def test_many_loci_through_a_one_rank_rccl_group(tmp_path, partition):
+    """The collectives of a sharded many-loci run over the nccl backend (RCCL), as far as one GPU can show them: a one-rank group
+    (WARPSTR_DIST_SELF_GATHER=1), partition by locus (counts + barrier) and by read (records and sequences all-gathered) -- the
+    files of a plain run."""
+    n_loci = 24
+    one, segs = _make_many(str(tmp_path), 'one', n_loci)
+    _make_many(str(tmp_path), 'rccl', n_loci)
+    npz = str(tmp_path / 'segments.npz')
+    np.savez(npz, **segs)
+    _cli(['--config', _many_cfg(tmp_path, 'one', n_loci), '--segments-npz', npz], 1)
+    script = (f"import os, sys, json; sys.path.insert(0, {ROOT!r})\n"
+              "import numpy as np\n"
+              "from warpstr_amd.wrapper import LocusPath, main_wrapper_loci, _npz_loader\n"
+              f"loci = [LocusPath(os.path.join({str(tmp_path / 'rccl')!r}, 'locus%02d' % li), *{MANY!r}[li % {len(MANY)}][:2]) for li in range({n_loci})]\n"
+              f"tm = {{}}\nmain_wrapper_loci(loci, 2, signal_loader=_npz_loader({npz!r}), shard=True, partition={partition!r}, quiet=True, timings=tm)\n"
+              "import torch.distributed as d\nprint(json.dumps({'backend': d.get_backend(), 'partition': tm['partition'], 'gather_s': tm['gather_s']}))\nd.destroy_process_group()\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', WARPSTR_DIST_SELF_GATHER='1', WARPSTR_DIST_BACKEND='nccl', MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info['backend'] == 'nccl' and info['partition'] == partition
+    _same(one, [LocusPath(os.path.join(tmp_path, 'rccl', f'locus{li:02d}'), *MANY[li % len(MANY)][:2]) for li in range(n_loci)])

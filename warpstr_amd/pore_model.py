@@ -50,19 +50,24 @@ class PoreModel:
 
     @staticmethod
     def _read_tsv(path: str):
+        """`level_mean` by k-mer from a tab-separated model table (src/squiggler/pore_model.py:15-33).  The numbers are parsed
+        by pandas' reader, as upstream's are: its default float converter is not correctly rounded, a table written with 17
+        significant digits comes out a last bit different from float() -- and the state levels with it."""
         if not os.path.exists(path):
             raise FileNotFoundError('Not found pore model table at path', path)
-        with open(path, 'r') as f:
-            header = f.readline().rstrip('\n').split('\t')
-            if 'kmer' not in header or 'level_mean' not in header:
-                raise ValueError('Pore model table do not contains "kmer" and "level_mean" columns')
-            ik, il = header.index('kmer'), header.index('level_mean')
-            rows = [line.rstrip('\n').split('\t') for line in f if line.strip()]
-        k = len(rows[0][ik])
+        from pandas import read_csv
+        table = read_csv(path, sep='\t', header=0)
+        if 'kmer' not in table or 'level_mean' not in table:
+            raise ValueError('Pore model table do not contains "kmer" and "level_mean" columns')
+        kmers = [str(k) for k in table['kmer']]
+        k = len(kmers[0])
         out = np.full(4 ** k, np.nan)
-        for r in rows:
-            out[kmer_code(r[ik])] = float(r[il])
-        if np.isnan(out).any():
+        seen = np.zeros(4 ** k, bool)
+        for kmer, level in zip(kmers, np.asarray(table['level_mean'], dtype=np.float64)):
+            code = kmer_code(kmer)
+            if not seen[code]:   # (upstream's look-up takes the first row of a k-mer)
+                out[code], seen[code] = level, True
+        if not seen.all():
             raise ValueError('pore model table is missing k-mers')
         return out, k
 

@@ -6,6 +6,7 @@ with the HIP caller, and writes the same outputs as the reference: overview.csv 
 repeat unit, predictions/complexSTR_analysis/complex_repeat_units.csv.  Plots are not produced.
 """
 import os
+import sys
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -69,7 +70,8 @@ class LocusPath:
 def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
                  caller_config: Optional[CallerConfig] = None, rescaler_config: Optional[RescalerConfig] = None,
                  signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
-                 raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False, **kwargs):
+                 raw_reader: Callable[[str], np.ndarray] = read_raw_signal, device: int = 0, shard: bool = False, pore_model=None,
+                 **kwargs):
     """Load data for calling and handle results (src/caller/wrapper.py:17-41).
 
     main_wrapper(locus, threads) -- the reference's call: `locus` is any object with `.path`, `.sequence`, `.flank_length`.
@@ -89,9 +91,9 @@ def main_wrapper(locus, threads=1, flank_length: Optional[int] = None, *args,
     caller_config = caller_config or CallerConfig()
     if shard:
         return main_wrapper_loci([locus], threads, caller_config=caller_config, rescaler_config=rescaler_config,
-                                 signal_loader=signal_loader, raw_reader=raw_reader, device=device, shard=True)[0]
+                                 signal_loader=signal_loader, raw_reader=raw_reader, device=device, shard=True, pore_model=pore_model)[0]
     overview_path, df_overview = ov.load_overview(locus.path)
-    cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device)
+    cw = CallerWrapper(locus, threads, caller_config=caller_config, rescaler_config=rescaler_config, device=device, pore_model=pore_model)
     if signal_loader is None:
         # default: int16 reads straight from the .fast5 files, prepared on the GPU
         names, reverses, raws, positions = get_raw_workload(df_overview, locus.path, raw_reader)
@@ -180,57 +182,109 @@ def under_torchrun() -> bool:
     return int(os.environ.get('WORLD_SIZE', '1')) > 1 or wdist.force_collectives()
 
 
+def prepare_subdirs(locus_path: str, tr_region_calling: bool, force_overwrite: bool):
+    """The directories of a locus that steps 3 and 4 write into, as upstream prepares them before a run
+    (src/helpers.py:32-69: `summaries`; with tr_region_calling `predictions` and its DTW_alignments / basecalls / sequences, each
+    emptied first when `force_overwrite` is set -- the previous results of the step go, nothing of the other steps is touched)."""
+    import shutil
+
+    def handle(path):
+        if not os.path.exists(path):
+            os.mkdir(path)
+        elif force_overwrite:
+            shutil.rmtree(path)
+            os.mkdir(path)
+    if not os.path.exists(locus_path):
+        os.mkdir(locus_path)
+    if not os.path.exists(os.path.join(locus_path, 'summaries')):
+        os.mkdir(os.path.join(locus_path, 'summaries'))
+    if tr_region_calling:
+        pred = os.path.join(locus_path, ov.PREDICTIONS_SUBDIR)
+        handle(pred)
+        for sub in ('DTW_alignments', 'basecalls', 'sequences'):
+            handle(os.path.join(pred, sub))
+
+
 def main(argv=None):
     """Step 3 (and optionally step 4) from the command line.
 
       python -m warpstr_amd.wrapper --config cfg.yaml             every locus of a WarpSTR configuration (WarpSTR.py:33-76)
       python -m warpstr_amd.wrapper LOCUS_PATH SEQUENCE FLANK     one locus directory
 
-    Under `python -m torch.distributed.run --nproc-per-node N -m warpstr_amd.wrapper ...` the reads are sharded over the N
-    GPUs of the node."""
+    Under `python -m torch.distributed.run --nproc-per-node N -m warpstr_amd.wrapper ...` the work is sharded over the N
+    GPUs of the node (whole loci from 8 loci per GPU on, else every locus's reads: warpstr_amd/loci.py)."""
     import argparse
+    import time
     ap = argparse.ArgumentParser(prog='python -m warpstr_amd.wrapper', description=main.__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('locus_path', nargs='?')
     ap.add_argument('sequence', nargs='?')
     ap.add_argument('flank_length', type=int, nargs='?')
-    ap.add_argument('--config', help="a WarpSTR YAML configuration (upstream's keys: output, loci, flank_length, threads, "
-                                     'tr_calling_config, rescaling, tr_region_calling, genotyping)')
+    ap.add_argument('--config', help="a WarpSTR YAML configuration (upstream's keys: output, loci, flank_length, threads, verbose, "
+                                     'force_overwrite, pore_model_path, tr_calling_config, rescaling, genotyping_config, '
+                                     'tr_region_calling, genotyping)')
     ap.add_argument('--segments-npz', dest='signals', help='.npz archive of normalised segments by read name (instead of the fast5 files)')
-    ap.add_argument('--genotype', action='store_true', help='also run step 4 on the results (rank 0)')
+    ap.add_argument('--genotype', action='store_true', help='also run step 4 on the results')
     args = ap.parse_args(argv)
     shard = under_torchrun()
+    from . import dist as wdist
+    rank, world = (wdist.process_group() if shard else (0, 1))
     loader = _npz_loader(args.signals) if args.signals else None
+    t_start = time.perf_counter()
+    verbose, settings, own = 0, {}, None
+
+    def duration(process, since):
+        if verbose > 0 and rank == 0:  # (src/helpers.py:16-29, src/templates.py:3)
+            t = time.perf_counter() - since
+            print(f'  Duration for {process}: {int(t // 3600):02}h {int(t % 3600 // 60):02}m {int(t % 60):02}s')
+
     if args.config:
         from .config import load_config
         cfg = load_config(args.config)
+        verbose, settings = cfg.verbose, cfg.genotyping_config.settings()
         loci = loci_from_config(cfg)
-        genotype = args.genotype or bool(cfg.raw.get('genotyping', False))
-        rank0 = int(os.environ.get('RANK', '0')) == 0
-        for locus in loci:  # (WarpSTR.py:43-45: every locus directory holds the sequence it was run with)
-            if rank0 and os.path.isdir(locus.path):
-                with open(os.path.join(locus.path, 'sequence.txt'), 'w') as f:
-                    f.write(locus.sequence)
-        tables = []
+        genotype = args.genotype or cfg.genotyping
+        if rank == 0:
+            for line in cfg.notices():
+                print('warpstr_amd: ' + line, file=sys.stderr)
+            for locus in loci:  # (WarpSTR.py:42-45: the step's directories, and the sequence the locus was run with)
+                if os.path.isdir(locus.path):
+                    prepare_subdirs(locus.path, cfg.tr_region_calling, cfg.force_overwrite)
+                    with open(os.path.join(locus.path, 'sequence.txt'), 'w') as f:
+                        f.write(locus.sequence)
+        if shard:
+            import torch.distributed as tdist
+            tdist.barrier()  # (the directories are as rank 0 left them before any rank writes into them)
+        tables = [(None, None)] * len(loci)   # calling switched off: step 4 reads the overview.csv the earlier run left (WarpSTR.py:71-79)
         if cfg.tr_region_calling:
+            tm = {}
             tables = main_wrapper_loci(loci, cfg.threads, caller_config=cfg.caller, rescaler_config=cfg.rescaler, signal_loader=loader,
-                                       shard=shard)
+                                       shard=shard, pore_model=cfg.pore_model(), timings=tm)
+            if tm.get('partition') == 'loci':
+                own = set(tm['loci_set_up'])   # every rank genotypes the loci it called
+            duration('tr calling', t_start)
     else:
         if args.locus_path is None or args.sequence is None or args.flank_length is None:
             ap.error('either --config or LOCUS_PATH SEQUENCE FLANK_LENGTH')
         loci = [LocusPath(args.locus_path, args.sequence, args.flank_length)]
         genotype = args.genotype
         tables = [main_wrapper(loci[0], 1, signal_loader=loader, shard=shard)]
-    from . import dist as wdist
-    rank, _ = wdist.process_group() if shard else (0, 1)
-    if rank == 0:
-        for locus, (df_overview, df_collapsed) in zip(loci, tables):
+    t_gt = time.perf_counter()
+    for i, (locus, pair) in enumerate(zip(loci, tables)):
+        if (own is None and rank != 0) or (own is not None and i not in own):
+            continue
+        df_overview, df_collapsed = pair
+        if df_overview is not None:
             called = int((np.asarray(df_overview['results']) >= 0).sum())
             print(f'{locus.name}: {called} reads called')
-            if genotype:
-                from .genotyper import run_genotyping_complex, run_genotyping_overview
-                run_genotyping_overview(df_overview, locus.path, None)
-                run_genotyping_complex(locus.path, df_collapsed)
+        if genotype:
+            from .genotyper import run_genotyping_complex, run_genotyping_overview
+            run_genotyping_overview(df_overview, locus.path, None, **settings)
+            run_genotyping_complex(locus.path, df_collapsed, **settings)
+    if genotype:
+        duration('genotyping', t_gt)
+    if verbose > 0 and rank == 0:
+        duration('whole', t_start)
     if shard:
         import torch.distributed as tdist
         if tdist.is_available() and tdist.is_initialized():
