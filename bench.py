@@ -561,6 +561,119 @@ def cfg5_driver_leg(reads_per_locus, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def from_fast5_leg(n_copies, local):
+    """The path real input takes: .fast5 files on disk -> output files (upstream: get_workload opens one fast5 per read through
+    Fast5.get_data_processed, src/caller/wrapper.py:44-54, src/schemas/fast5.py:45-57).  n_copies copies of the upstream test
+    file (tests/golden/real/batch_0.fast5: 10 real VBZ-compressed R9.4 reads of 59-170 k samples) laid out as the caller-only
+    input (prepare_caller_only.py: an overview per locus whose `fast5_path` column points at the read's multi-read file), one
+    locus -- the upstream test locus, (AAAT) at flank 110 -- per copy, through main_wrapper_loci to every locus's output files:
+    once with the files read in this process, once on 16 reader processes (libhdf5 is not thread-safe) that decode straight
+    into the staging buffers the upload starts from.  The genotype of the outputs must be the README's (44, 40)."""
+    import contextlib
+    import io
+    import json as js
+    import shutil
+    import tempfile
+
+    import pandas as pd
+
+    from warpstr_amd import fast5, overview as ov
+    from warpstr_amd.genotyper import run_genotyping_overview
+    from warpstr_amd.wrapper import LocusPath, main_wrapper_loci
+    real = os.path.join(ROOT, 'tests', 'golden', 'real')
+    fj = js.load(open(os.path.join(real, 'flanks.json')))
+    ex = pd.read_csv(os.path.join(real, 'example.csv'), dtype={'read_name': str})
+    size = os.path.getsize(os.path.join(real, 'batch_0.fast5'))
+    base = scratch_dir()
+    if base is not None:   # room for the copies AND the staging buffers?
+        st = os.statvfs(base)
+        if st.f_bavail * st.f_frsize < n_copies * size * 3 + (4 << 30):
+            base = None
+    root = tempfile.mkdtemp(prefix='wsx_from_fast5_', dir=base)
+    try:
+        def make(tag):
+            loci = []
+            for i in range(n_copies):
+                loc = os.path.join(root, tag, f'copy{i:04d}')
+                f5 = os.path.join(root, 'fast5', f'batch_{i:04d}.fast5')
+                if not os.path.exists(f5):
+                    os.makedirs(os.path.dirname(f5), exist_ok=True)
+                    shutil.copyfile(os.path.join(real, 'batch_0.fast5'), f5)
+                ov.store_flanks(loc, [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']])
+                pd.DataFrame({'read_name': ex['read_name'], 'fast5_path': f5, 'reverse': ex['reverse'].astype(bool), 'l_start_raw': ex['l_start_raw'],
+                              'r_end_raw': ex['r_end_raw'], 'run_id': 'run_0', 'saved': 1}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+                loci.append(LocusPath(loc, fj['sequence'], int(fj['flank_length']), f'copy{i:04d}'))
+            return loci
+        n_reads = n_copies * len(ex)
+        warm = make('warm')[:8]
+        main_wrapper_loci(warm, 1, device=local, quiet=True)
+        out = {'workload': f'{n_copies} copies of the upstream test fast5 (10 real VBZ reads each, {size} bytes), one (AAAT) flank-110 locus per copy, '
+                           f'caller-only layout, files under {base or "the default temporary directory"} (page cache) -> output files',
+               'reads': n_reads}
+        for tag, threads in (('one_process', 1), ('sixteen_reader_processes', min(16, os.cpu_count() or 1))):
+            loci = make(tag)
+            tm = {}
+            tables = main_wrapper_loci(loci, threads, device=local, quiet=True, timings=tm)
+            with contextlib.redirect_stdout(io.StringIO()):
+                calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
+            lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results']) for l in loci]
+            out[tag] = {'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
+                        'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
+                        'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
+                                     'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
+                                     'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
+                        'shared_staging_refused': tm.get('shared_staging_refused'),
+                        'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
+        # where a read's time goes, in one process (ms per read; the ten reads of the file, repeated)
+        f = fast5.Fast5File(os.path.join(real, 'batch_0.fast5'))
+        ids = f.read_ids()
+        h, zs = fast5._libs()
+        import ctypes as C
+        reps, n = 5, 5 * len(ids)
+        t = {}
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fast5.Fast5File(os.path.join(real, 'batch_0.fast5')).close()
+        t['file_open_close'] = (time.perf_counter() - t0) / n * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for i in ids:
+                f.signal_length(i)
+        t['dataset_lookup_and_metadata'] = (time.perf_counter() - t0) / n * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for i in ids:
+                f.raw_signal(i)
+        t['whole_read_decoded'] = (time.perf_counter() - t0) / n * 1e3
+        d, ns, vbz, cl = f._open_signal(ids[0])
+        off, sz, mask = (C.c_uint64 * 1)(0), C.c_uint64(), C.c_uint32()
+        h.H5Dget_chunk_storage_size(d, off, C.byref(sz))
+        buf = C.create_string_buffer(sz.value)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            h.H5Dread_chunk(d, 0, off, C.byref(mask), buf)
+        t['chunk_read_first_read'] = (time.perf_counter() - t0) / 50 * 1e3
+        body = buf.raw[4:]
+        zsz = zs.ZSTD_getFrameContentSize(body, len(body))
+        zout = C.create_string_buffer(zsz)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            zs.ZSTD_decompress(zout, zsz, body, len(body))
+        t['zstd_first_read'] = (time.perf_counter() - t0) / 50 * 1e3
+        dst = np.empty(ns, np.int16)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            f.raw_signal_into(ids[0], dst)
+        t['first_read_whole'] = (time.perf_counter() - t0) / 50 * 1e3
+        t['first_read_samples'], t['first_read_chunk_bytes'] = int(ns), int(sz.value)
+        h.H5Dclose(d)
+        f.close()
+        out['per_read_ms_one_process'] = t
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def optional_leg(leg, *a):
     """A leg above the kernels (the product driver) must not take the headline line down with it: an
     exception becomes {'failed': ...} in its place (a result that DIFFERS still fails the run: the callers check that)."""
@@ -588,6 +701,7 @@ def main():
                          '(reported under "secondary"); this switch leaves them out')
     ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
                     help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
+    ap.add_argument('--from-fast5', type=int, default=600, help='copies of the upstream test fast5 in the from_fast5 leg of the default run (0: leave it out)')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
@@ -843,6 +957,8 @@ def main():
             out['secondary']['from_raw'] = out['from_raw']
             # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
             out['secondary']['cfg5']['through_driver'] = optional_leg(cfg5_driver_leg, 6250, local)
+            if args.from_fast5 > 0:
+                out['from_fast5'] = optional_leg(from_fast5_leg, args.from_fast5, local)
             if args.many_loci > 0:
                 out['many_loci'] = optional_leg(many_loci_leg, args.many_loci, 30, min(32, args.many_loci), local)
                 if not out['many_loci'].get('outputs_identical', {'identical': True})['identical']:

@@ -246,3 +246,37 @@ def test_many_loci_through_a_one_rank_rccl_group(tmp_path, partition):
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info['backend'] == 'nccl' and info['partition'] == partition
     _same(one, [LocusPath(os.path.join(tmp_path, 'rccl', f'locus{li:02d}'), *MANY[li % len(MANY)][:2]) for li in range(n_loci)])
+
+
+def test_fast5_reads_decoded_by_reader_processes_into_the_upload_buffers(tmp_path):
+    """The path real input takes, on the GPU: 70 loci whose reads are the upstream test file's ten VBZ reads (caller-only layout),
+    read in this process against three reader processes that decode straight into the page-locked staging buffers both sides map
+    (caller.SharedStaging) -- the same files, and the reads were uploaded from the shared buffers."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+
+    def make(root):
+        loci = []
+        for li in range(70):
+            pattern, fl, _ = MANY[li % len(MANY)]
+            locus = synth.make_locus(pattern, fl, 900 + li)
+            loc = os.path.join(root, f'locus{li}')
+            ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+            rows = [ids[(li + k) % 10] for k in range(1 + li % 3)]
+            pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool((li + k) & 1) for k in range(len(rows))], 'saved': 1,
+                          'l_start_raw': 5000 + 10 * li, 'r_end_raw': 6500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+            loci.append(LocusPath(loc, pattern, fl))
+        return loci
+    a, b = make(str(tmp_path / 'a')), make(str(tmp_path / 'b'))
+    tm_a, tm_b = {}, {}
+    main_wrapper_loci(a, 3, quiet=True, timings=tm_a)
+    main_wrapper_loci(b, 1, quiet=True, timings=tm_b)
+    assert tm_a['reader_processes'] == 3 and tm_a.get('raw_bytes', 0) > 0 and not tm_a.get('shared_staging_refused')
+    assert tm_b['reader_processes'] == 0
+    _same(a, b)

@@ -70,6 +70,30 @@ class FakeEngine:
         pass
 
 
+class SharedFakeEngine(FakeEngine):
+    """... with the staging buffers the reader processes decode into (caller.SharedStaging; nothing to page-lock on a CPU)."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        from warpstr_amd.caller import SharedStaging
+        self.staging = SharedStaging(3)
+        self.shared_batches = 0
+
+    def stage_shared(self, count):
+        return self.staging.take(count)
+
+    def submit_raw_shared(self, slot, roff, lo, hi, aut):
+        self.shared_batches += 1
+        raws = [slot['view'][roff[r]:roff[r + 1]].copy() for r in range(len(roff) - 1)]
+        return self.submit_raw(raws, lo, hi, aut)
+
+    def info(self):
+        return {'batches': self.batches, 'shared_batches': self.shared_batches}
+
+    def close(self):
+        self.staging.close()
+
+
 def _make_loci(root, poison=None):
     """Five synthetic locus directories (one without saved reads, one with a single read) + the normalised segments by read
     name; returns (loci, {read name: signal})."""
@@ -288,14 +312,20 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
                           'l_start_raw': 5000 + 10 * li, 'r_end_raw': 6500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
             loci.append(LocusPath(loc, pattern, fl))
         return loci
-    a, b = make(str(tmp_path / 'a')), make(str(tmp_path / 'b'))
-    tm = {}
+    a, b, c = make(str(tmp_path / 'a')), make(str(tmp_path / 'b')), make(str(tmp_path / 'c'))
+    tm, tm_c = {}, {}
     main_wrapper_loci(a, 3, _engine=FakeEngine, quiet=True, timings=tm)
     main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
     assert tm['reader_processes'] == 3 and tm['n_reads'] == sum(1 + li % 3 for li in range(70)) >= 64
-    for la, lb in zip(a, b):
+    # ... and decoded by the workers straight into the staging buffers both sides map (lengths first, then every read to its
+    # place), the batches cut by the raw-byte budget
+    main_wrapper_loci(c, 3, _engine=SharedFakeEngine, quiet=True, timings=tm_c, batch_raw_bytes=12 << 20)
+    assert 3 <= tm_c['shared_batches'] <= tm_c['batches'] and tm_c['reader_processes'] == 3   # (the tail of fewer than 64 reads is read here)
+    for la, lb, lc in zip(a, b, c):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+            assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_stage_')]
 
 
 def test_native_and_pandas_host_paths_write_the_same_files(tmp_path):

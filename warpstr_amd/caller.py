@@ -491,6 +491,72 @@ def slice_lengths(lo: np.ndarray, hi: np.ndarray, lens: np.ndarray) -> np.ndarra
     return np.clip(np.minimum(hi + 1, lens) - np.minimum(lo, lens), 0, None)
 
 
+class SharedStaging:
+    """A ring of int16 staging buffers that OTHER PROCESSES can fill: files under /dev/shm mapped here and -- by path -- in the
+    reader processes of a many-loci run (loci.py), which decode fast5 reads straight into them; `register(address, bytes)` (the
+    GPU side: hipHostRegister through torch) makes a mapping page-locked so that the upload starts from it without another copy.
+    A slot is {'path', 'view' (np.int16), 'event' (None or something with .synchronize(): its last upload)}."""
+
+    def __init__(self, n_slots: int = 3, register=None, unregister=None, directory: str = '/dev/shm'):
+        if not (os.path.isdir(directory) and os.access(directory, os.W_OK)):
+            raise OSError(f'{directory} is not a writable directory')
+        self._dir, self._register, self._unregister = directory, register, unregister
+        self._slots = [dict(path=None, view=None, event=None, mm=None, registered=False) for _ in range(n_slots)]
+        self._turn = 0
+
+    def take(self, count: int) -> dict:
+        """The next slot of the ring with room for `count` samples, its previous upload finished."""
+        import mmap
+        import tempfile
+        slot = self._slots[self._turn % len(self._slots)]
+        self._turn += 1
+        if slot['event'] is not None:
+            slot['event'].synchronize()
+            slot['event'] = None
+        if slot['view'] is None or slot['view'].size < count:
+            self._release(slot)
+            cap = max(count + count // 4, 1 << 22)
+            st = os.statvfs(self._dir)   # (a memory-backed file system takes the truncate and faults on the first write past its limit)
+            if st.f_bavail * st.f_frsize < cap * 2 + (64 << 20):
+                raise OSError(f'{self._dir} has no room for a staging buffer of {cap * 2} bytes')
+            fd, path = tempfile.mkstemp(prefix='warpstr_stage_', dir=self._dir)
+            try:
+                os.ftruncate(fd, cap * 2)
+                mm = mmap.mmap(fd, cap * 2)
+            finally:
+                os.close(fd)
+            view = np.frombuffer(mm, dtype=np.int16)
+            slot.update(path=path, view=view, mm=mm, registered=False)
+            if self._register is not None:
+                slot['registered'] = bool(self._register(view.ctypes.data, cap * 2))
+        return slot
+
+    def _release(self, slot):
+        if slot['view'] is not None:
+            if slot['registered'] and self._unregister is not None:
+                self._unregister(slot['view'].ctypes.data)
+            slot['view'] = None
+            slot['mm'] = None   # (the mapping goes with its last reference)
+            try:
+                os.unlink(slot['path'])
+            except OSError:
+                pass
+            slot['path'] = None
+
+    def close(self):
+        for slot in self._slots:
+            if slot['event'] is not None:
+                slot['event'].synchronize()
+                slot['event'] = None
+            self._release(slot)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class BatchQueue:
     """Back-to-back batches on one handle without draining the GPU in between: submit() enqueues the upload, the signal
     loader and the caller of a batch and returns at once; collect() waits for that batch only and returns its records and
@@ -511,6 +577,7 @@ class BatchQueue:
         self.pack = torch.cuda.Stream(device=self.dev)  # packs a finished batch's sequences: waits for THAT batch only
         self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
         self._turn = 0
+        self._shared = None  # SharedStaging: buffers the reader processes fill (stage_shared)
         hip.set_pipelined(True)
 
     def _stage(self, dtype, count: int):
@@ -565,6 +632,53 @@ class BatchQueue:
         if n:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
         return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+
+    def stage_shared(self, count: int) -> dict:
+        """A staging slot of `count` int16 samples that reader processes can fill by path (SharedStaging), page-locked for the
+        upload where the runtime allows it; submit_raw_shared() takes it."""
+        if self._shared is None:
+            torch = self.torch
+            rt = torch.cuda.cudart()
+
+            def register(address, nbytes):
+                try:
+                    return int(rt.cudaHostRegister(address, nbytes, 0)) == 0
+                except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
+                    return False
+
+            def unregister(address):
+                try:
+                    rt.cudaHostUnregister(address)
+                except Exception:  # noqa: BLE001
+                    pass
+            self._shared = SharedStaging(3, register, unregister)
+        return self._shared.take(count)
+
+    def submit_raw_shared(self, slot: dict, roff: np.ndarray, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
+        """submit_raw() for reads that lie back to back in a staging slot already (read r = slot['view'][roff[r] : roff[r + 1]])."""
+        torch = self.torch
+        n = len(roff) - 1
+        roff = np.ascontiguousarray(roff, np.int64)
+        lens = np.diff(roff)
+        total_raw = int(roff[-1])
+        lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
+        host = torch.from_numpy(slot['view'])
+        with torch.cuda.stream(self.stream):
+            raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
+            raw_dev[:total_raw].copy_(host[:total_raw], non_blocking=True)
+            slot['event'] = torch.cuda.Event()
+            slot['event'].record()
+            signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
+        if n:
+            self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
+        return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+
+    def close(self):
+        if self._shared is not None:
+            self._shared.close()
+            self._shared = None
 
     def submit_signals(self, signals: Sequence[np.ndarray], aut: np.ndarray):
         """Already normalised float64 segments (a `signal_loader`, or ReadSignal workloads)."""

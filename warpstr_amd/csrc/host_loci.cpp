@@ -1096,4 +1096,72 @@ WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One VBZ-filtered HDF5 chunk of 16-bit samples -> the samples, in one call without the GIL (warpstr_amd/fast5.py reads the chunk's
+// bytes with H5Dread_chunk; the reader processes of a run decode straight into the staging buffer the GPU upload starts from).
+// Layout (the published VBZ version 0): u32 uncompressed byte count, then -- zstd_level != 0 -- a zstd frame holding a StreamVByte
+// block: ceil(n/4) key bytes (2 bits per value = byte length - 1, first value in the low bits), then the little-endian value
+// bytes; the values are deltas, zig-zag mapped if `zigzag`.  zstd comes as two function pointers (ZSTD_getFrameContentSize,
+// ZSTD_decompress of whatever libzstd the process loaded): this library links against nothing.
+// Returns the number of samples written, or -1 chunk too short, -2 not a sized zstd frame, -3 zstd failed, -4 StreamVByte block
+// shorter than its key area, -5 shorter than its keys say, -6 more samples than `cap`.
+typedef unsigned long long (*zstd_size_fn)(const void *, size_t);
+typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
+
+WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int32_t zigzag, int32_t zstd_level, void *size_fn, void *decompress_fn,
+                                      int16_t *out, int64_t cap)
+{
+    if (n_chunk < 4) return -1;
+    uint32_t n_bytes;
+    memcpy(&n_bytes, chunk, 4);
+    const int64_t n = n_bytes / 2;
+    if (n > cap) return -6;
+    const uint8_t *svb = chunk + 4;
+    int64_t svb_bytes = n_chunk - 4;
+    static thread_local std::vector<uint8_t> scratch;
+    if (zstd_level != 0) {
+        const unsigned long long size = reinterpret_cast<zstd_size_fn>(size_fn)(svb, size_t(svb_bytes));
+        if (size >= (1ull << 62)) return -2;
+        if (scratch.size() < size + 8) scratch.resize(size + 8);
+        const size_t got = reinterpret_cast<zstd_decompress_fn>(decompress_fn)(scratch.data(), size, svb, size_t(svb_bytes));
+        if (got != size) return -3;
+        svb = scratch.data();
+        svb_bytes = int64_t(size);
+    }
+    const int64_t n_keys = (n + 3) / 4;
+    if (svb_bytes < n_keys) return -4;
+    const uint8_t *data = svb + n_keys, *end = svb + svb_bytes;
+    uint32_t acc = 0;   // (the running sum wraps to 16 bits in the end: 32 are enough)
+    auto put = [&](int64_t i, uint32_t v) {
+        acc += zigzag ? (v >> 1) ^ (0u - (v & 1u)) : v;
+        out[i] = int16_t(uint16_t(acc));
+    };
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const uint8_t key = svb[i >> 2];
+        if (key == 0 && data + 4 <= end) {   // four one-byte values: almost every group of a nanopore signal
+            put(i, data[0]); put(i + 1, data[1]); put(i + 2, data[2]); put(i + 3, data[3]);
+            data += 4;
+            continue;
+        }
+        for (int q = 0; q < 4; q++) {
+            const int len = ((key >> (2 * q)) & 3) + 1;
+            if (data + len > end) return -5;
+            uint32_t v = 0;
+            for (int k = 0; k < len; k++) v |= uint32_t(data[k]) << (8 * k);
+            data += len;
+            put(i + q, v);
+        }
+    }
+    for (; i < n; i++) {
+        const int len = ((svb[i >> 2] >> ((i & 3) * 2)) & 3) + 1;
+        if (data + len > end) return -5;
+        uint32_t v = 0;
+        for (int k = 0; k < len; k++) v |= uint32_t(data[k]) << (8 * k);
+        data += len;
+        put(i, v);
+    }
+    return n;
+}
+
 }  // extern "C"

@@ -228,8 +228,8 @@ class Fast5File:
                 return f'read_{ids[0]}/Raw/Signal'
         raise Fast5Error(f'{self.path}: no raw signal' + (f' for read {read_id}' if read_id else ''))
 
-    def raw_signal(self, read_id: Optional[str] = None) -> np.ndarray:
-        """The DAC samples of a read (int16), whatever the dataset's storage filter."""
+    def _open_signal(self, read_id: Optional[str]):
+        """(dataset id, samples, VBZ parameters [version, integer size, zig-zag, zstd level] or None, samples per chunk or 0)."""
         h = self.h
         d = h.H5Dopen2(self.fid, self.signal_path(read_id).encode(), 0)
         if d < 0:
@@ -248,33 +248,103 @@ class Fast5File:
             chunk_len = (C.c_uint64 * 1)(0)
             chunked = h.H5Pget_layout(pl) == 2 and h.H5Pget_chunk(pl, 1, chunk_len) == 1
             h.H5Pclose(pl)
-            if vbz is None:  # contiguous / gzip / ...: the library's own pipeline handles it
+            if vbz is not None and not chunked:
+                raise Fast5Error(f'{self.path}: VBZ filter on a dataset that is not chunked')
+            return d, int(n), vbz, int(chunk_len[0]) if chunked else 0
+        except Exception:
+            h.H5Dclose(d)
+            raise
+
+    def signal_length(self, read_id: Optional[str] = None) -> int:
+        """Samples of a read's raw signal (metadata only: nothing is decoded)."""
+        d, n, _, _ = self._open_signal(read_id)
+        self.h.H5Dclose(d)
+        return n
+
+    def raw_signal(self, read_id: Optional[str] = None) -> np.ndarray:
+        """The DAC samples of a read (int16), whatever the dataset's storage filter."""
+        return self.raw_signal_into(read_id, None)
+
+    def raw_signal_into(self, read_id: Optional[str], out: Optional[np.ndarray]) -> np.ndarray:
+        """raw_signal() decoded straight into `out` (a C-contiguous int16 array of exactly the read's length: a slice of a
+        staging buffer, main_wrapper_loci's reader processes); out=None allocates."""
+        h = self.h
+        d, n, vbz, chunk_len = self._open_signal(read_id)
+        try:
+            if out is None:
                 out = np.empty(n, dtype=np.int16)
+            elif out.dtype != np.int16 or out.ndim != 1 or out.size != n or not out.flags.c_contiguous or not out.flags.writeable:
+                raise Fast5Error(f'{self.path}: the destination must be a writable contiguous int16 array of {n} samples')
+            if vbz is None:  # contiguous / gzip / ...: the library's own pipeline handles it
                 native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
                 if h.H5Dread(d, native_i16, 0, 0, 0, out.ctypes.data_as(C.c_void_p)) < 0:
                     raise Fast5Error(f'{self.path}: H5Dread failed')
                 return out
-            if not chunked:
-                raise Fast5Error(f'{self.path}: VBZ filter on a dataset that is not chunked')
             version, int_size, zigzag, level = vbz[0], vbz[1], vbz[2], vbz[3]
-            parts = []
-            for start in range(0, n, int(chunk_len[0])):
+            native = _vbz_native() if (version == 0 and int_size == 2) else None
+            done = 0
+            for start in range(0, n, chunk_len):
                 off, size, mask = (C.c_uint64 * 1)(start), C.c_uint64(), C.c_uint32()
                 if h.H5Dget_chunk_storage_size(d, off, C.byref(size)) < 0 or size.value == 0:
                     raise Fast5Error(f'{self.path}: missing chunk at sample {start}')
-                buf = C.create_string_buffer(size.value)
+                buf = _scratch(size.value)
                 if h.H5Dread_chunk(d, 0, off, C.byref(mask), buf) < 0:
                     raise Fast5Error(f'{self.path}: H5Dread_chunk failed at sample {start}')
+                want = min(chunk_len, n - start)
                 if mask.value & 1:  # the filter was skipped when this chunk was written: plain samples
-                    parts.append(np.frombuffer(buf.raw, dtype=np.int16))
+                    part = np.frombuffer(buf, dtype=np.int16, count=size.value // 2)[:want]
+                    out[start:start + len(part)] = part
+                    got = len(part)
+                elif native is not None and want == min(chunk_len, struct.unpack_from('<I', buf, 0)[0] // 2):
+                    fn, f_size, f_dec = native
+                    got = fn(buf, size.value, int(bool(zigzag)), int(level), f_size, f_dec, out.ctypes.data + 2 * start, want)
+                    if got < 0:
+                        raise Fast5Error(f'{self.path}: ' + _VBZ_ERRORS.get(int(got), f'VBZ decoder error {got}'))
                 else:
-                    parts.append(vbz_decode_chunk(buf.raw, int_size, bool(zigzag), version, level))
-            out = np.concatenate(parts)[:n] if parts else np.empty(0, np.int16)
-            if out.size != n or out.dtype != np.int16:
-                raise Fast5Error(f'{self.path}: decoded {out.size} samples of {out.dtype}, the dataset holds {n} int16')
+                    part = vbz_decode_chunk(bytes(buf[:size.value]), int_size, bool(zigzag), version, level)[:want]
+                    if part.dtype != np.int16:
+                        raise Fast5Error(f'{self.path}: decoded samples of {part.dtype}, the dataset holds int16')
+                    out[start:start + len(part)] = part
+                    got = len(part)
+                done += int(got)
+            if done != n:
+                raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')
             return out
         finally:
             h.H5Dclose(d)
+
+
+_SCRATCH = None
+_VBZ_NATIVE = False
+_VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
+               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
+               -6: 'a VBZ chunk holds more samples than the dataset says'}
+
+
+def _scratch(nbytes: int):
+    """A buffer of at least nbytes that lives with the process (a chunk's compressed bytes: no allocation per read)."""
+    global _SCRATCH
+    if _SCRATCH is None or len(_SCRATCH) < nbytes:
+        _SCRATCH = (C.c_char * max(nbytes + nbytes // 2, 1 << 20))()
+    return _SCRATCH
+
+
+def _vbz_native():
+    """(wsh_vbz_decode_i16 of warpstr_amd/_host_loci.so, ZSTD_getFrameContentSize, ZSTD_decompress as addresses): one call without
+    the GIL per chunk -- zstd frame -> StreamVByte -> zig-zag -> running sum -> the destination; or None (library not built: the
+    decoders above do the same arithmetic)."""
+    global _VBZ_NATIVE
+    if _VBZ_NATIVE is False:
+        _VBZ_NATIVE = None
+        from . import _hostlib
+        lib = _hostlib.lib()
+        if lib is not None and hasattr(lib, 'wsh_vbz_decode_i16'):
+            _, zs = _libs()
+            fn = lib.wsh_vbz_decode_i16
+            fn.restype = C.c_int64
+            fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+            _VBZ_NATIVE = (fn, C.cast(zs.ZSTD_getFrameContentSize, C.c_void_p).value, C.cast(zs.ZSTD_decompress, C.c_void_p).value)
+    return _VBZ_NATIVE
 
 
 def read_raw_signal(path: str, read_id: Optional[str] = None) -> np.ndarray:

@@ -128,6 +128,7 @@ class HipEngine:
         self.hip = HipCaller(tables, flank_lengths, caller_config, rescaler_config, device=device, stream=self.stream.cuda_stream)
         self.queue = BatchQueue(self.hip, self.stream, (caller_config or CallerConfig()).spike_removal)
         self.submit_raw, self.submit_signals, self.collect = self.queue.submit_raw, self.queue.submit_signals, self.queue.collect
+        self.stage_shared, self.submit_raw_shared = self.queue.stage_shared, self.queue.submit_raw_shared
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
@@ -136,6 +137,7 @@ class HipEngine:
 
     def close(self):
         self.hip.synchronize()
+        self.queue.close()
         self.hip.close()
 
 
@@ -252,6 +254,57 @@ def _read_chunk(items):
         else:
             out.append(np.ascontiguousarray(read_raw_signal(path), dtype=np.int16))
     return out
+
+
+# The same in two steps, without the decoded samples going through a pipe: the workers first say how long their reads are
+# (metadata), the parent lays the batch out in a staging buffer both sides map (caller.SharedStaging), the workers then decode
+# each read straight to its place -- and the GPU upload starts from that buffer.
+_OPEN: Dict[str, object] = {}    # per worker process: fast5 path -> open Fast5File (a batch reads many reads of few files)
+_MAPS: Dict[str, tuple] = {}     # per worker process: staging path -> (mmap, int16 view)
+
+
+def _fast5(path: str):
+    from .fast5 import Fast5File
+    f = _OPEN.get(path)
+    if f is None:
+        if len(_OPEN) >= 64:
+            _OPEN.pop(next(iter(_OPEN))).close()
+        f = _OPEN[path] = Fast5File(path)
+    return f
+
+
+def _resolve(item):
+    path, fallback, name = item
+    if not os.path.exists(path) and fallback is not None:
+        return fallback, name     # caller-only input: the read is still in its multi-read file
+    return path, None
+
+
+def _probe_chunk(items):
+    """Samples of each read of (annotated fast5 path, fall-back path, read name) triples; nothing is decoded."""
+    out = []
+    for item in items:
+        path, read_id = _resolve(item)
+        out.append(_fast5(path).signal_length(read_id))
+    return out
+
+
+def _decode_chunk(args):
+    """Decode each read into staging[offset : offset + length] of the staging file both processes map."""
+    import mmap
+    staging, items, offsets, lengths = args
+    got = _MAPS.get(staging)
+    if got is None or len(got[1]) < max((o + n for o, n in zip(offsets, lengths)), default=0):
+        for key in [k for k in _MAPS if not os.path.exists(k)]:
+            _MAPS.pop(key)
+        with open(staging, 'r+b') as fh:
+            mm = mmap.mmap(fh.fileno(), 0)
+        got = _MAPS[staging] = (mm, np.frombuffer(mm, dtype=np.int16))
+    view = got[1]
+    for item, off, n in zip(items, offsets, lengths):
+        path, read_id = _resolve(item)
+        _fast5(path).raw_signal_into(read_id, view[off:off + n])
+    return len(items)
 
 
 class _WorkerPool:
@@ -527,7 +580,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             while b < len(cuts) - 1:
                 b0, b1 = cuts[b], cuts[b + 1]
                 t1 = time.perf_counter()
-                data, raw_bytes = [], 0
+                data, raw_bytes, shared_slot = [], 0, None
                 if raw_reads is not None:
                     sel_names = all_names[b0:b1] if whole else [all_names[g] for g in mine[b0:b1]]
                     data = [raw_reads[nm] for nm in sel_names]
@@ -538,8 +591,36 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
                         items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
                     step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
-                    for part in pool.map(_read_chunk, [items[k:k + step] for k in range(0, len(items), step)]):
-                        data += part
+                    parts = [items[k:k + step] for k in range(0, len(items), step)]
+                    use_shared = hasattr(queue, 'stage_shared') and not tm.get('shared_staging_refused')
+                    if use_shared:
+                        # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
+                        t2 = time.perf_counter()
+                        lens_b = np.array([n for part in pool.map(_probe_chunk, parts) for n in part], np.int64)
+                        tm['probe_s'] = tm.get('probe_s', 0.0) + time.perf_counter() - t2
+                        keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, raw_budget, side='right')))   # long raw reads: the byte budget
+                        if keep < len(items):
+                            cuts.insert(b + 1, b0 + keep)
+                            b1 = b0 + keep
+                            items, lens_b = items[:keep], lens_b[:keep]
+                            parts = [items[k:k + step] for k in range(0, len(items), step)]
+                        shared_roff = np.zeros(len(items) + 1, np.int64)
+                        np.cumsum(lens_b, out=shared_roff[1:])
+                        try:
+                            shared_slot = queue.stage_shared(int(shared_roff[-1]))
+                        except OSError as e:   # no room under /dev/shm: the decoded reads come back through the pipes instead
+                            print(f'warpstr_amd: no shared staging buffer ({e}); the reader processes return the reads through their pipes', file=sys.stderr)
+                            tm['shared_staging_refused'] = str(e)
+                            use_shared = False
+                    if use_shared:
+                        t2 = time.perf_counter()
+                        pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist())
+                                                 for k, part in zip(range(0, len(items), step), parts)])
+                        tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t2
+                        tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
+                    else:
+                        for part in pool.map(_read_chunk, parts):
+                            data += part
                 elif signal_loader is None:
                     for k in range(b0, b1):
                         g = mine[k]
@@ -548,7 +629,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     for k in range(b0, b1):
                         g = mine[k]
                         data.append(np.asarray(signal_loader(jobs[locus_of[g]].fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
-                if signal_loader is None:
+                if signal_loader is None and shared_slot is None:
                     keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
                     while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
                         acc += data[keep].nbytes
@@ -560,7 +641,9 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 tm['read_s'] += time.perf_counter() - t1
                 t1 = time.perf_counter()
                 sel = mine[b0:b1]
-                if signal_loader is None:
+                if shared_slot is not None:
+                    ticket = queue.submit_raw_shared(shared_slot, shared_roff, lo[sel], hi[sel], aut[sel])
+                elif signal_loader is None:
                     ticket = queue.submit_raw(data, lo[sel], hi[sel], aut[sel])
                 else:
                     ticket = queue.submit_signals(data, aut[sel])
