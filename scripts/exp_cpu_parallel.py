@@ -31,6 +31,9 @@ def work(reps):
             h.wsh_automaton_free(C.byref(a))
 
 
+if '--worker' in sys.argv:
+    work(200)
+    sys.exit(0)
 print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))
 for nt in (1, 2, 4, 8, 16):
     ths = [threading.Thread(target=work, args=(40,)) for _ in range(nt)]
@@ -40,5 +43,10 @@ for nt in (1, 2, 4, 8, 16):
     dt = time.perf_counter() - t
     print(f'{nt:2d} threads: {nt * 40 * n / dt:9.0f} compiles/s', flush=True)
 # the same as PROCESSES (no shared interpreter at all)
-import subprocess
-code = ("import sys; sys.path.insert(0, %r); import scripts.exp_cpu_parallel_worker" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if '--worker' not in sys.argv:
+    import subprocess
+    for nt in (1, 4, 16):
+        t = time.perf_counter()
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--worker'], stdout=subprocess.DEVNULL) for _ in range(nt)]
+        [q.wait() for q in ps]
+        print(f'{nt:2d} processes (start-up included): {time.perf_counter() - t:.2f} s for {nt} x 5 threads-worth of work', flush=True)
