@@ -13,6 +13,8 @@ def main():
     os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
     src = sys.stdin.buffer
     from warpstr_amd import loci
+    if len(sys.argv) > 1 and sys.argv[1].isdigit():
+        loci.spread_over_cpus(int(sys.argv[1]))   # (the k-th worker starts on the k-th CPU of the mask; nothing stays pinned)
     while True:
         try:
             name, arg = pickle.load(src)

@@ -19,6 +19,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "../../include/warpstr_hip.h"
 #include "wsx_device.h"
 #include "wsx_place.h"
@@ -375,6 +378,28 @@ size_t per_read_bytes(const wsx_caller *c, bool host_mem, size_t last_row_bytes)
     return b;
 }
 
+// A new thread starts on its parent's CPU and waits for the kernel's load balancer to move it, which on virtualised hosts takes
+// longer than the placement of a handle lasts (16 threads then share one CPU).  Move thread t to the t-th CPU of the process's
+// affinity mask and restore the mask at once: nothing stays pinned.
+void spread_thread(int t)
+{
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    if (sched_getaffinity(0, sizeof all, &all) != 0) return;
+    const int n = CPU_COUNT(&all);
+    if (n < 2) return;
+    int local_rank = 0;
+    if (const char *e = getenv("LOCAL_RANK")) local_rank = atoi(e);
+    int want = (t + 1 + 16 * local_rank) % n, cpu = -1;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &all) && want-- == 0) { cpu = c; break; }
+    if (cpu < 0) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    if (pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0) (void)pthread_setaffinity_np(pthread_self(), sizeof all, &all);
+}
+
 __global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, int first_read, int64_t base_off, int n,
                                  uint32_t *bits)
 {
@@ -629,6 +654,7 @@ try {
             for (int t = 0; t < nt; t++)
                 th.emplace_back([&, t] {
                     try {
+                        spread_thread(t);
                         for (int a = next_a.fetch_add(1); a < n_automata; a = next_a.fetch_add(1)) place_one(a);
                     } catch (...) {
                         errs[t] = std::current_exception();

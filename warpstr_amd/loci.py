@@ -316,8 +316,8 @@ class _WorkerPool:
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-        self.procs = [subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                       env=env) for _ in range(n)]
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       env=env) for k in range(n)]
         self._max_workers = n
 
     def map(self, func, items):
@@ -381,6 +381,31 @@ def _reader_pool(threads: int, n_loci: int):
         return None
 
 
+_SPREAD = [0]
+
+
+def spread_over_cpus(k: Optional[int] = None):
+    """Move the calling thread to the k-th CPU of the process's affinity mask and release it again (the mask is restored at
+    once: nothing stays pinned).  A new thread starts on its parent's CPU and is moved by the kernel's load balancer, which on
+    virtualised hosts takes longer than a phase of this driver lasts: sixteen threads created for 100 ms of work then share one
+    CPU (8 threads: 77 k automata/s spread, 9 k/s not: scripts/exp_cpu_parallel.py).  k=None: the next index of a process-wide
+    counter, offset by LOCAL_RANK so that the ranks of a node do not start on the same CPUs."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) < 2:
+            return
+        if k is None:
+            k = _SPREAD[0]
+            _SPREAD[0] += 1
+        k += int(os.environ.get('LOCAL_RANK', '0') or 0) * 16
+        os.sched_setaffinity(0, {allowed[k % len(allowed)]})
+        os.sched_setaffinity(0, allowed)
+    except OSError:
+        pass
+
+
 def _thread_map(executor, func, items):
     """[func(x) for x in items], on the executor's threads if there is one; the first exception is raised here."""
     if executor is None:
@@ -429,7 +454,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     executor = None
     if threads and int(threads) > 1 and len(loci) > 1:
         from concurrent.futures import ThreadPoolExecutor
-        executor = ThreadPoolExecutor(max_workers=min(int(threads), 64))
+        executor = ThreadPoolExecutor(max_workers=min(int(threads), 64), initializer=spread_over_cpus)
     try:
         return _main_wrapper_loci(loci, int(threads or 1), pools, executor, caller_config=caller_config, rescaler_config=rescaler_config,
                                   signal_loader=signal_loader, raw_reader=raw_reader, raw_reads=raw_reads, pore_model=pore_model,
