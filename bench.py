@@ -701,7 +701,7 @@ def main():
                          '(reported under "secondary"); this switch leaves them out')
     ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
                     help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
-    ap.add_argument('--from-fast5', type=int, default=600, help='copies of the upstream test fast5 in the from_fast5 leg of the default run (0: leave it out)')
+    ap.add_argument('--from-fast5', type=int, default=1500, help='copies of the upstream test fast5 in the from_fast5 leg of the default run (0: leave it out)')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '

@@ -1,7 +1,7 @@
-"""A worker process of main_wrapper_loci's per-locus host work (warpstr_amd/loci.py: _WorkerPool): reads pickled
-(function name, argument) pairs from its standard input, runs the named module-level function of warpstr_amd.loci, writes the
-pickled ('ok', result) or ('err', text) to its standard output.  Started with `python -m warpstr_amd._hostworker`, so it never
-imports the parent's main module (multiprocessing's spawn would) and never touches HIP."""
+"""A reader process of main_wrapper_loci (warpstr_amd/loci.py: _WorkerPool): reads pickled (function name, argument) pairs from
+its standard input, runs the named function of warpstr_amd._readers (the fast5 files of a batch), writes the pickled
+('ok', result) or ('err', text) to its standard output.  Started with `python -m warpstr_amd._hostworker K`, so it never imports
+the parent's main module (multiprocessing's spawn would), never touches HIP, and imports NumPy and the fast5 reader only."""
 import os
 import pickle
 import sys
@@ -12,16 +12,18 @@ def main():
     out = os.fdopen(os.dup(sys.stdout.fileno()), 'wb')  # results go here; whatever the functions print goes to stderr
     os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
     src = sys.stdin.buffer
-    from warpstr_amd import loci
+    from warpstr_amd import _readers
     if len(sys.argv) > 1 and sys.argv[1].isdigit():
-        loci.spread_over_cpus(int(sys.argv[1]))   # (the k-th worker starts on the k-th CPU of the mask; nothing stays pinned)
+        _readers.spread_over_cpus(int(sys.argv[1]))   # (the k-th worker starts on the k-th CPU of the mask; nothing stays pinned)
+    names = {'_read_chunk': _readers.read_chunk, '_probe_chunk': _readers.probe_chunk, '_decode_chunk': _readers.decode_chunk,
+             'read_chunk': _readers.read_chunk, 'probe_chunk': _readers.probe_chunk, 'decode_chunk': _readers.decode_chunk}
     while True:
         try:
             name, arg = pickle.load(src)
         except EOFError:
             return
         try:
-            res = ('ok', getattr(loci, name)(arg))
+            res = ('ok', names[name](arg))
         except Exception:  # noqa: BLE001 -- reported to the parent, which raises
             res = ('err', traceback.format_exc())
         pickle.dump(res, out, protocol=pickle.HIGHEST_PROTOCOL)

@@ -41,7 +41,7 @@ inline int fanin(const int32_t *pp, int j) { return pp[j + 1] - pp[j]; }
 // extra LDS cycles per row of a placement: for every slot k, candidate f and half g the largest number of distinct slots
 // on one bank pair, minus one; the same for the export writes
 inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, const std::vector<uint16_t> &pos,
-                           const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot)
+                           const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot, int *surplus_out = nullptr)
 {
     // (no heap in here: the repair pass of wsx_place_attempt calls this thousands of times per automaton, and a handle for all
     // loci of a run places thousands of automata)
@@ -62,8 +62,14 @@ inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, i
             for (int b = 0; b < nb; b++) w = n[b] > w ? n[b] : w;
             return w;
         }
+        int surplus(int nb) const // slots beyond the first on their bank pair, over all bank pairs
+        {
+            int x = 0;
+            for (int b = 0; b < nb; b++) x += n[b] > 1 ? n[b] - 1 : 0;
+            return x;
+        }
     } on;
-    int total = 0;
+    int total = 0, extra = 0;
     for (int k = 0; k < K; k++) {
         for (int q = 0; q < 4; q++) { // writes: 16 lanes at a time, slots distinct modulo 16 (idle lanes write as well)
             on.clear(16);
@@ -72,6 +78,7 @@ inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, i
                 on.add(slot & 15, slot);
             }
             total += on.worst(16) - 1;
+            extra += on.surplus(16);
         }
         for (int g = 0; g < 2; g++)
             for (int f = 0; f < (k == 0 ? F : FL); f++) { // reads: 32 lanes at a time, slots distinct modulo 32
@@ -83,9 +90,11 @@ inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, i
                     on.add(slot & 31, slot);
                 }
                 total += on.worst(32) - 1;
+                extra += on.surplus(32);
             }
     }
     (void)S;
+    if (surplus_out) *surplus_out = extra;
     return total;
 }
 
@@ -349,12 +358,18 @@ inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *p
         // this only runs for the few automata the construction leaves with a conflict: DM2's 254-state strand had 1.0 cycles
         // per row, profiles/r04_real_loci_pmc.log.)
         if (cur_cost > 0 && K > 1) {
+            // (round 5: ANY two positions may trade -- with several slots the export slot of a position is the position, the
+            // writes never collide --, and among equal counts the walk prefers fewer surplus slots per bank pair: the count is the
+            // worst bank pair of each read, so three colliding pairs in one read stay "1" until the last of them is resolved
+            // and a walk that sees no difference between two and three of them does not get there.  configs[4]'s 127-state
+            // four-candidate automaton: 1 cycle per row left by the walk before, 0 now after ~1 500 steps.)
             uint32_t rng = 0x51ED270Bu ^ (uint32_t)S;
             auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
-            for (int step = 0; step < 4000 && cur_cost > 0; step++) {
-                const int a = (int)(next() % P);
-                const int b = (a & 31) + 32 * (int)(next() % (P / 32)); // same bank pair: the writes stay conflict-free
-                if (a == b || (a / 32) == (b / 32)) continue;
+            int cur_extra = 0;
+            (void)conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &cur_extra);
+            for (int step = 0; step < 12000 && cur_cost > 0; step++) {
+                const int a = (int)(next() % P), b = (int)(next() % P);
+                if (a == b) continue;
                 const int ja = out.state_at[a] == 0xFFFF ? -1 : out.state_at[a], jb = out.state_at[b] == 0xFFFF ? -1 : out.state_at[b];
                 if ((ja < 0 && jb < 0) || !pinned_ok(ja, b) || !pinned_ok(jb, a)) continue;
                 auto trade = [&]() {
@@ -363,9 +378,14 @@ inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *p
                     if (out.state_at[b] != 0xFFFF) out.pos[out.state_at[b]] = (uint16_t)b;
                 };
                 trade();
-                const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot);
-                if (c <= cur_cost) cur_cost = c;
-                else trade();
+                int extra = 0;
+                const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &extra);
+                if (c < cur_cost || (c == cur_cost && extra <= cur_extra)) {
+                    cur_cost = c;
+                    cur_extra = extra;
+                } else {
+                    trade();
+                }
             }
         }
     }

@@ -32,6 +32,8 @@ from .caller import BatchQueue, CallerConfig, CallerResults, HipCaller, ReadCall
 from .fast5 import read_raw_signal
 
 LOCI_PER_RANK_FOR_LOCUS_PARTITION = 8
+SHARED_BATCH_BYTES = 160 << 20   # raw bytes of a batch that reader processes decode into a shared staging buffer
+SHARED_BATCH_READS = 1024        # ... and its reads
 
 
 class LocusJob:
@@ -112,9 +114,10 @@ class LocusJob:
         path = self.fast5_of(k)
         if raw_reader is not read_raw_signal:
             return np.ascontiguousarray(raw_reader(path), dtype=np.int16)
-        if not os.path.exists(path) and self.fast5_path is not None:
-            return np.ascontiguousarray(read_raw_signal(str(self.fast5_path[k]), self.names[k]), dtype=np.int16)  # caller-only input
-        return np.ascontiguousarray(read_raw_signal(path), dtype=np.int16)
+        # (files stay open while the run reads them: a multi-read file holds many of a batch's reads; closed by main_wrapper_loci)
+        from ._readers import fast5_file, resolve
+        path, read_id = resolve((path, str(self.fast5_path[k]) if self.fast5_path is not None else None, self.names[k]))
+        return np.ascontiguousarray(fast5_file(path).raw_signal(read_id), dtype=np.int16)
 
 
 class HipEngine:
@@ -243,68 +246,10 @@ def _units_of(sequence: str):
 
 
 # ---- fast5 files on worker processes -----------------------------------------------------------------------------------------
-# Opening a file, HDF5 and zstd take about a millisecond per read, and libhdf5 is not thread-safe: the one part of the host work
-# that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state).
-def _read_chunk(items):
-    """Raw reads of (annotated fast5 path, multi-read fall-back path or None, read name) triples, as LocusJob.raw_read finds them."""
-    out = []
-    for path, fallback, name in items:
-        if not os.path.exists(path) and fallback is not None:
-            out.append(np.ascontiguousarray(read_raw_signal(fallback, name), dtype=np.int16))
-        else:
-            out.append(np.ascontiguousarray(read_raw_signal(path), dtype=np.int16))
-    return out
-
-
-# The same in two steps, without the decoded samples going through a pipe: the workers first say how long their reads are
-# (metadata), the parent lays the batch out in a staging buffer both sides map (caller.SharedStaging), the workers then decode
-# each read straight to its place -- and the GPU upload starts from that buffer.
-_OPEN: Dict[str, object] = {}    # per worker process: fast5 path -> open Fast5File (a batch reads many reads of few files)
-_MAPS: Dict[str, tuple] = {}     # per worker process: staging path -> (mmap, int16 view)
-
-
-def _fast5(path: str):
-    from .fast5 import Fast5File
-    f = _OPEN.get(path)
-    if f is None:
-        if len(_OPEN) >= 64:
-            _OPEN.pop(next(iter(_OPEN))).close()
-        f = _OPEN[path] = Fast5File(path)
-    return f
-
-
-def _resolve(item):
-    path, fallback, name = item
-    if not os.path.exists(path) and fallback is not None:
-        return fallback, name     # caller-only input: the read is still in its multi-read file
-    return path, None
-
-
-def _probe_chunk(items):
-    """Samples of each read of (annotated fast5 path, fall-back path, read name) triples; nothing is decoded."""
-    out = []
-    for item in items:
-        path, read_id = _resolve(item)
-        out.append(_fast5(path).signal_length(read_id))
-    return out
-
-
-def _decode_chunk(args):
-    """Decode each read into staging[offset : offset + length] of the staging file both processes map."""
-    import mmap
-    staging, items, offsets, lengths = args
-    got = _MAPS.get(staging)
-    if got is None or len(got[1]) < max((o + n for o, n in zip(offsets, lengths)), default=0):
-        for key in [k for k in _MAPS if not os.path.exists(k)]:
-            _MAPS.pop(key)
-        with open(staging, 'r+b') as fh:
-            mm = mmap.mmap(fh.fileno(), 0)
-        got = _MAPS[staging] = (mm, np.frombuffer(mm, dtype=np.int16))
-    view = got[1]
-    for item, off, n in zip(items, offsets, lengths):
-        path, read_id = _resolve(item)
-        _fast5(path).raw_signal_into(read_id, view[off:off + n])
-    return len(items)
+# Opening a file, HDF5 and zstd take a few tenths of a millisecond per read, and libhdf5 is not thread-safe: the one part of the
+# host work that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and
+# import NumPy and the fast5 reader only -- warpstr_amd/_readers.py).
+from ._readers import decode_chunk as _decode_chunk, probe_chunk as _probe_chunk, read_chunk as _read_chunk  # noqa: E402
 
 
 class _WorkerPool:
@@ -461,6 +406,9 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
                                   device=device, shard=shard, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
                                   batch_raw_bytes=batch_raw_bytes, timings=timings, quiet=quiet, native=native, _engine=_engine)
     finally:  # the threads and the reader processes end with the call, however it ends
+        from . import _readers
+        while _readers._OPEN:
+            _readers._OPEN.popitem()[1].close()
         if executor is not None:
             executor.shutdown(wait=True)
         for pool in pools:
@@ -592,6 +540,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 a = max(a + 1, min(a + batch_reads, b))
                 cuts.append(a)
             pending = []  # (ticket, first, count)
+            raw_len = np.full(len(mine), -1, np.int64)   # samples of a read's whole raw signal, once a reader process has said
 
             def finish(ticket, b0, b1):
                 t1 = time.perf_counter()
@@ -611,19 +560,30 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     data = [raw_reads[nm] for nm in sel_names]
                 elif pool is not None and b1 - b0 >= 64:
                     # the fast5 files of a batch on the worker processes
+                    use_shared = hasattr(queue, 'stage_shared') and not tm.get('shared_staging_refused')
+                    if use_shared and b1 - b0 > SHARED_BATCH_READS:   # (a shared batch is small: see SHARED_BATCH_BYTES)
+                        cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
+                        b1 = b0 + SHARED_BATCH_READS
                     items = []
                     for k in range(b0, b1):
                         job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
                         items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
                     step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
                     parts = [items[k:k + step] for k in range(0, len(items), step)]
-                    use_shared = hasattr(queue, 'stage_shared') and not tm.get('shared_staging_refused')
                     if use_shared:
                         # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
                         t2 = time.perf_counter()
-                        lens_b = np.array([n for part in pool.map(_probe_chunk, parts) for n in part], np.int64)
+                        todo = [k for k in range(len(items)) if raw_len[b0 + k] < 0]   # (a read is asked for its length once)
+                        if todo:
+                            tstep = max(8, min(256, len(todo) // (4 * pool._max_workers) or 8))
+                            got = [n for part in pool.map(_probe_chunk, [[items[k] for k in todo[q:q + tstep]] for q in range(0, len(todo), tstep)])
+                                   for n in part]
+                            raw_len[b0 + np.asarray(todo)] = got
+                        lens_b = raw_len[b0:b1].copy()
                         tm['probe_s'] = tm.get('probe_s', 0.0) + time.perf_counter() - t2
-                        keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, raw_budget, side='right')))   # long raw reads: the byte budget
+                        # (a shared batch is a fraction of the byte budget: the three staging buffers are then reused -- their pages
+                        # are touched and page-locked once -- and the decoding of one batch runs beside the upload of the last)
+                        keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
                         if keep < len(items):
                             cuts.insert(b + 1, b0 + keep)
                             b1 = b0 + keep

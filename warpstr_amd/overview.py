@@ -111,7 +111,7 @@ def store_collapsed(results, units: List[str], rep_units: List[List[str]], rever
     alternative, a plain unit gives one column named after its bases; last column `reverse`."""
     table = {}
     for u, (unit, alts) in enumerate(zip(units, rep_units)):
-        counts = np.array([r[u] for r in results], dtype=np.int64).reshape(len(results), -1)
+        counts = np.array([r[u] for r in results], dtype=np.int64).reshape(len(results), len(alts))   # (no reads: an empty table; upstream's IndexError)
         if counts.shape[1] > 1:
             table['main_' + alts[0]] = counts.sum(axis=1)
             for a_idx in range(1, len(alts)):
