@@ -624,51 +624,70 @@ def from_fast5_leg(n_copies, local):
                                      'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
                         'shared_staging_refused': tm.get('shared_staging_refused'),
                         'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
-        # where a read's time goes, in one process (ms per read; the ten reads of the file, repeated)
-        f = fast5.Fast5File(os.path.join(real, 'batch_0.fast5'))
-        ids = f.read_ids()
-        h, zs = fast5._libs()
+        # where a read's time goes in one process, COLD -- every read of a run is read exactly once, from a file whose metadata
+        # libhdf5 has not parsed yet: 40 fresh copies x 10 reads, each library call timed (ms per read)
         import ctypes as C
-        reps, n = 5, 5 * len(ids)
-        t = {}
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fast5.Fast5File(os.path.join(real, 'batch_0.fast5')).close()
-        t['file_open_close'] = (time.perf_counter() - t0) / n * 1e3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            for i in ids:
-                f.signal_length(i)
-        t['dataset_lookup_and_metadata'] = (time.perf_counter() - t0) / n * 1e3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            for i in ids:
-                f.raw_signal(i)
-        t['whole_read_decoded'] = (time.perf_counter() - t0) / n * 1e3
-        d, ns, vbz, cl = f._open_signal(ids[0])
-        off, sz, mask = (C.c_uint64 * 1)(0), C.c_uint64(), C.c_uint32()
-        h.H5Dget_chunk_storage_size(d, off, C.byref(sz))
-        buf = C.create_string_buffer(sz.value)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            h.H5Dread_chunk(d, 0, off, C.byref(mask), buf)
-        t['chunk_read_first_read'] = (time.perf_counter() - t0) / 50 * 1e3
-        body = buf.raw[4:]
-        zsz = zs.ZSTD_getFrameContentSize(body, len(body))
-        zout = C.create_string_buffer(zsz)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            zs.ZSTD_decompress(zout, zsz, body, len(body))
-        t['zstd_first_read'] = (time.perf_counter() - t0) / 50 * 1e3
-        dst = np.empty(ns, np.int16)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            f.raw_signal_into(ids[0], dst)
-        t['first_read_whole'] = (time.perf_counter() - t0) / 50 * 1e3
-        t['first_read_samples'], t['first_read_chunk_bytes'] = int(ns), int(sz.value)
-        h.H5Dclose(d)
-        f.close()
-        out['per_read_ms_one_process'] = t
+        h, zs = fast5._libs()
+        native = fast5._vbz_native()
+        cold = os.path.join(root, 'cold')
+        os.makedirs(cold)
+        t = {k: 0.0 for k in ('H5Fopen', 'H5Dopen2_by_name', 'dataspace_and_filter_queries', 'H5Dget_chunk_storage_size', 'H5Dread_chunk',
+                              'zstd_decompress', 'streamvbyte_zigzag_prefix_sum', 'H5Dclose', 'H5Fclose')}
+        ids = fast5.Fast5File(os.path.join(real, 'batch_0.fast5')).read_ids()
+        n_cold, samples, chunk_bytes = 0, 0, 0
+        clock = time.perf_counter
+        for i in range(40):
+            path = os.path.join(cold, f'c{i}.fast5')
+            shutil.copyfile(os.path.join(real, 'batch_0.fast5'), path)
+            t0 = clock()
+            fid = h.H5Fopen(path.encode(), 0, 0)
+            t['H5Fopen'] += clock() - t0
+            for rid in ids:
+                t0 = clock()
+                d = h.H5Dopen2(fid, f'read_{rid}/Raw/Signal'.encode(), 0)
+                t1 = clock()
+                sp = h.H5Dget_space(d)
+                ns = h.H5Sget_simple_extent_npoints(sp)
+                h.H5Sclose(sp)
+                pl = h.H5Dget_create_plist(d)
+                cd, ne, flags, fc, name = (C.c_uint * 8)(), C.c_size_t(8), C.c_uint(), C.c_uint(), C.create_string_buffer(64)
+                h.H5Pget_filter2(pl, 0, C.byref(flags), C.byref(ne), cd, 64, name, C.byref(fc))
+                cl = (C.c_uint64 * 1)(0)
+                h.H5Pget_chunk(pl, 1, cl)
+                h.H5Pclose(pl)
+                t2 = clock()
+                off, sz, mask = (C.c_uint64 * 1)(0), C.c_uint64(), C.c_uint32()
+                h.H5Dget_chunk_storage_size(d, off, C.byref(sz))
+                t3 = clock()
+                buf = C.create_string_buffer(sz.value)
+                h.H5Dread_chunk(d, 0, off, C.byref(mask), buf)
+                t4 = clock()
+                zsz = zs.ZSTD_getFrameContentSize(C.cast(C.addressof(buf) + 4, C.c_char_p), sz.value - 4)
+                zout = C.create_string_buffer(zsz)
+                zs.ZSTD_decompress(zout, zsz, C.cast(C.addressof(buf) + 4, C.c_char_p), sz.value - 4)
+                t5 = clock()
+                dst = np.empty(ns, np.int16)
+                if native is not None:   # the whole chunk decoder, minus the zstd share measured above
+                    native[0](buf, sz.value, int(cd[2]), int(cd[3]), native[1], native[2], dst.ctypes.data, ns)
+                t6 = clock()
+                h.H5Dclose(d)
+                t7 = clock()
+                for key, dt in zip(('H5Dopen2_by_name', 'dataspace_and_filter_queries', 'H5Dget_chunk_storage_size', 'H5Dread_chunk', 'zstd_decompress',
+                                    'H5Dclose'), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t7 - t6)):
+                    t[key] += dt
+                t['streamvbyte_zigzag_prefix_sum'] += max((t6 - t5) - (t5 - t4), 0.0)
+                n_cold += 1
+                samples += int(ns)
+                chunk_bytes += int(sz.value)
+            t0 = clock()
+            h.H5Fclose(fid)
+            t['H5Fclose'] += clock() - t0
+        t = {k: v / n_cold * 1e3 for k, v in t.items()}
+        t['total'] = sum(t.values())
+        t['mean_samples'], t['mean_chunk_bytes'], t['reads'] = samples / n_cold, chunk_bytes / n_cold, n_cold
+        t['note'] = ('cold files: each read is opened once; H5Fopen / H5Fclose are per FILE of ten reads, shown per read; the decoder '
+                     'call includes a second zstd pass, subtracted')
+        out['per_read_ms_one_process_cold'] = t
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)

@@ -453,3 +453,46 @@ def test_locus_partition_a_failing_read_stops_every_rank_where_upstream_would_st
     assert sum(m.startswith('RuntimeError') and 'L40_read000' in m for m in msgs) == world - 1, msgs
     fasta = lambda li: os.path.exists(os.path.join(root, f'locus{li}', 'predictions', 'sequences', 'all.fasta'))
     assert all(fasta(li) for li in range(40)) and not any(fasta(li) for li in range(40, 72))
+
+
+def _fast5_loci(root, src, ids, n_loci=70, missing=None):
+    loci = []
+    pats = [('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)]
+    for li in range(n_loci):
+        pattern, fl = pats[li % 4]
+        locus = synth.make_locus(pattern, fl, 900 + li)
+        loc = os.path.join(root, f'locus{li}')
+        ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+        rows = [ids[(li + k) % 10] for k in range(1 + li % 3)]
+        pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool((li + k) & 1) for k in range(len(rows))], 'saved': 1,
+                      'l_start_raw': 5000 + 10 * li, 'r_end_raw': 6500 + 10 * li,
+                      'fast5_path': src if li != missing else src + '.gone'}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        loci.append(LocusPath(loc, pattern, fl))
+    return loci
+
+
+def test_reader_processes_that_cannot_start_are_reported_and_what_a_worker_raises_is_raised(tmp_path, monkeypatch, capsys):
+    """Only the START of the reader processes falls back to reading in this process (said once on stderr, same files); an error
+    raised INSIDE a worker -- a fast5 file that is not there -- is raised here, not turned into a slower run."""
+    import sys
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    a, b = _fast5_loci(str(tmp_path / 'a'), src, ids), _fast5_loci(str(tmp_path / 'b'), src, ids)
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    with monkeypatch.context() as mp_:
+        mp_.setattr(sys, 'executable', str(tmp_path / 'no-such-python'))
+        tm = {}
+        main_wrapper_loci(a, 3, _engine=FakeEngine, quiet=True, timings=tm)
+    assert tm['reader_processes'] == 0 and 'could not start 3 reader processes' in capsys.readouterr().err
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    c = _fast5_loci(str(tmp_path / 'c'), src, ids, missing=40)
+    with pytest.raises(RuntimeError, match='failed in a worker process'):
+        main_wrapper_loci(c, 3, _engine=SharedFakeEngine, quiet=True)

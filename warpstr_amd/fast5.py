@@ -231,7 +231,11 @@ class Fast5File:
     def _open_signal(self, read_id: Optional[str]):
         """(dataset id, samples, VBZ parameters [version, integer size, zig-zag, zstd level] or None, samples per chunk or 0)."""
         h = self.h
-        d = h.H5Dopen2(self.fid, self.signal_path(read_id).encode(), 0)
+        # (a multi-read file's dataset is opened by its name straight away: probing the three levels of its path first costs as
+        # much again on a file whose metadata is cold -- and every read of a run is read exactly once)
+        d = h.H5Dopen2(self.fid, f'read_{read_id}/Raw/Signal'.encode(), 0) if read_id is not None else -1
+        if d < 0:
+            d = h.H5Dopen2(self.fid, self.signal_path(read_id).encode(), 0)
         if d < 0:
             raise Fast5Error(f'{self.path}: cannot open the signal dataset')
         try:

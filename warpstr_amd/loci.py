@@ -259,11 +259,31 @@ class _WorkerPool:
 
     def __init__(self, n: int):
         import subprocess
+        import threading
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-        self.procs = [subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                       env=env) for k in range(n)]
         self._max_workers = n
+        self._procs, self._error = [], None
+
+        def start():   # (on a thread of its own: forking a process with the GPU runtime mapped sixteen times takes a good part of a
+            try:       # second, in which the caller parses its overviews)
+                for k in range(n):
+                    self._procs.append(subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE,
+                                                        stdout=subprocess.PIPE, env=env))
+            except OSError as e:
+                self._error = e
+        self._starter = threading.Thread(target=start, daemon=True)
+        self._starter.start()
+
+    @property
+    def procs(self):
+        """The worker processes, all started (raises what starting one of them raised)."""
+        if self._starter is not None:
+            self._starter.join()
+            self._starter = None
+        if self._error is not None:
+            raise self._error
+        return self._procs
 
     def map(self, func, items):
         """[func(item) for item in items] on the workers (func: a module-level function of this module), in order.  An error
@@ -300,17 +320,20 @@ class _WorkerPool:
         return results
 
     def shutdown(self, **_):
-        for p in self.procs:
+        if self._starter is not None:
+            self._starter.join()
+            self._starter = None
+        for p in self._procs:
             try:
                 p.stdin.close()
             except OSError:
                 pass
-        for p in self.procs:
+        for p in self._procs:
             try:
                 p.wait(timeout=10)
             except Exception:  # noqa: BLE001
                 p.kill()
-        self.procs = []
+        self._procs = []
 
 
 def _reader_pool(threads: int, n_loci: int):
@@ -319,10 +342,19 @@ def _reader_pool(threads: int, n_loci: int):
     once and the files are read in this process; what a worker raises while reading is raised by _WorkerPool.map."""
     if threads <= 1 or n_loci < 64:
         return None
+    return _WorkerPool(min(int(threads), os.cpu_count() or 1))
+
+
+def _started(pool, tm):
+    """The pool once its processes are up, or None (reported once) if they could not be started."""
+    if pool is None:
+        return None
     try:
-        return _WorkerPool(min(int(threads), os.cpu_count() or 1))
+        pool.procs
+        return pool
     except OSError as e:
-        print(f'warpstr_amd: could not start {threads} reader processes ({e}); reading the fast5 files in this process', file=sys.stderr)
+        print(f'warpstr_amd: could not start {pool._max_workers} reader processes ({e}); reading the fast5 files in this process', file=sys.stderr)
+        tm['reader_processes'] = 0
         return None
 
 
@@ -540,6 +572,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 a = max(a + 1, min(a + batch_reads, b))
                 cuts.append(a)
             pending = []  # (ticket, first, count)
+            pool = _started(pool, tm)
             raw_len = np.full(len(mine), -1, np.int64)   # samples of a read's whole raw signal, once a reader process has said
 
             def finish(ticket, b0, b1):
