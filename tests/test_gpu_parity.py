@@ -506,6 +506,43 @@ def test_automaton_of_more_than_ten_slots():
     assert n_ok >= 2
 
 
+def test_a_call_that_no_longer_fits_is_planned_again_under_a_smaller_limit():
+    """The default limit is 60 % of the memory that was free when the handle was created; when something else has taken that
+    memory since (another handle, the caller's buffers), a call whose work sets do not fit is drained, released and planned again
+    under a smaller limit -- same results -- instead of failing with hipErrorOutOfMemory."""
+    import torch
+    locus = synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)
+    sigs, revs, _ = synth.batch(locus, 6000, 1500, 5)
+    sig, off = pack_signals(sigs)
+    aut = np.array([1 if x else 0 for x in revs], dtype=np.int32)
+    dev = torch.device('cuda:0')
+    dsig = torch.from_numpy(sig).to(dev)
+    res = torch.zeros((len(aut), 56), dtype=torch.uint8, device=dev)
+    ref_res = torch.zeros((len(aut), 56), dtype=torch.uint8, device=dev)
+    roomy = HipCaller([locus.template, locus.reverse], [19, 19])
+    roomy.call_device(dsig.data_ptr(), off, aut, ref_res.data_ptr())     # ~0.9 GB of workspace in four chunks
+    roomy.synchronize()
+    roomy.close()
+    late = HipCaller([locus.template, locus.reverse], [19, 19])
+    late.call_device(dsig.data_ptr(), off[:9], aut[:8], res.data_ptr())   # (first launches: the runtime's own scratch allocation)
+    late.synchronize()
+    before = late.workspace_limit()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    hog = torch.empty(free - (700 << 20), dtype=torch.uint8, device=dev)  # what is left does not hold the call's work sets
+    try:
+        late.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
+        late.synchronize()
+        assert late.workspace_limit() < before and late.workspace_limit() <= (700 << 20)
+        assert late.last_timing()['dp_launches'] > 8
+        assert torch.equal(res, ref_res)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        late.close()
+
+
 def test_workspace_limit_is_honoured():
     """wsx_caller_set_workspace_limit bounds everything a call allocates (all work sets together, include/warpstr_hip.h);
     a batch that needs several times the limit is cut into more chunks and gives the same results."""

@@ -69,6 +69,8 @@ struct Variant { // which DP kernel an automaton uses
     bool same(const Variant &o) const { return K == o.K && F == o.F && generic == o.generic && FL == o.FL && pk == o.pk && lm == o.lm; }
 };
 
+thread_local bool g_alloc_oom = false; // a DeviceBuf of this thread's call ran out of device memory
+
 struct DeviceBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -85,6 +87,10 @@ struct DeviceBuf {
             e = hipMalloc(&p, want);
         }
         if (e == hipSuccess) cap = want;
+        else if (e == hipErrorOutOfMemory) {
+            g_alloc_oom = true; // (run_batch_retry: a smaller workspace limit and another plan instead of a failed call)
+            (void)hipGetLastError();
+        }
         return e;
     }
     void release()
@@ -1668,6 +1674,27 @@ int run_batch(wsx_caller *c, const BatchIO &io, bool full)
 
 extern "C" {
 
+// A call whose work sets do not fit the device any more -- the limit was sized from the memory that was free when the handle was
+// created, and another handle, the loader's pool or the caller's own buffers have taken some since -- is planned again under a
+// smaller limit instead of failing: everything of this handle is drained and released first (allocations precede the launches
+// of a call: nothing of the failed attempt is in flight), then the limit becomes half of what it was or 60 % of what is free
+// now, whichever is less.  Same results: the chunk plan never shows in them.
+static int run_batch_retry(wsx_caller *c, const BatchIO &io, bool full)
+{
+    for (int attempt = 0;; attempt++) {
+        g_alloc_oom = false;
+        const int rc = run_batch(c, io, full);
+        if (rc == WSX_SUCCESS || !g_alloc_oom || attempt >= 6 || c->ws_limit <= (256ull << 20)) return rc;
+        (void)hipDeviceSynchronize();
+        for (auto &w : c->work)
+            for (DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps, &w.smooth}) b->release();
+        size_t free_b = 0, total_b = 0;
+        uint64_t next = c->ws_limit / 2;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) next = std::min<uint64_t>(next, (uint64_t)((double)free_b * 0.6));
+        c->ws_limit = std::max<uint64_t>(next, 256ull << 20);
+    }
+}
+
 int wsx_call_batch(wsx_caller *c, int mem, const double *signal, const int64_t *offsets, const int32_t *automaton_id,
                    int64_t n_reads, wsx_result *results, const wsx_traces *traces)
 try {
@@ -1679,7 +1706,7 @@ try {
     io.n = n_reads;
     io.results = results;
     if (traces) io.traces = *traces;
-    return run_batch(c, io, true);
+    return run_batch_retry(c, io, true);
 } catch (...) {
     return wsx_internal_on_exception();
 }
@@ -1708,7 +1735,7 @@ try {
     io.n = n_reads;
     io.results = results;
     if (traces) io.traces = *traces;
-    return run_batch(c, io, true);
+    return run_batch_retry(c, io, true);
 } catch (...) {
     return wsx_internal_on_exception();
 }
@@ -1733,7 +1760,7 @@ try {
         g_err = "last_row_stride smaller than the largest automaton";
         return WSX_ERR_INVALID;
     }
-    return run_batch(c, io, false);
+    return run_batch_retry(c, io, false);
 } catch (...) {
     return wsx_internal_on_exception();
 }
