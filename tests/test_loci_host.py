@@ -82,13 +82,17 @@ class SharedFakeEngine(FakeEngine):
     def stage_shared(self, count):
         return self.staging.take(count)
 
+    def stage_local(self, count):
+        self.local_batches = getattr(self, 'local_batches', 0) + 1
+        return dict(path=None, view=np.zeros(max(count, 1), np.int16), event=None)
+
     def submit_raw_shared(self, slot, roff, lo, hi, aut):
         self.shared_batches += 1
         raws = [slot['view'][roff[r]:roff[r + 1]].copy() for r in range(len(roff) - 1)]
         return self.submit_raw(raws, lo, hi, aut)
 
     def info(self):
-        return {'batches': self.batches, 'shared_batches': self.shared_batches}
+        return {'batches': self.batches, 'shared_batches': self.shared_batches, 'local_batches': getattr(self, 'local_batches', 0)}
 
     def close(self):
         self.staging.close()

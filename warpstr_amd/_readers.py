@@ -52,8 +52,17 @@ def probe_chunk(items):
     return out
 
 
+def decode_into(view: np.ndarray, items, offsets, lengths) -> int:
+    """Decode each read into view[offset : offset + length] (an int16 staging buffer)."""
+    for item, off, n in zip(items, offsets, lengths):
+        path, read_id = resolve(item)
+        fast5_file(path).raw_signal_into(read_id, view[off:off + n])
+    return len(items)
+
+
 def decode_chunk(args):
-    """Decode each read into staging[offset : offset + length] of the staging file both processes map."""
+    """decode_into() for the staging FILE both processes map (caller.SharedStaging), by its path.  The mapping is made with its
+    pages present (MAP_POPULATE): a worker otherwise takes a page fault for every 4 KiB it writes for the first time."""
     import mmap
     staging, items, offsets, lengths = args
     got = _MAPS.get(staging)
@@ -61,13 +70,10 @@ def decode_chunk(args):
         for key in [k for k in _MAPS if not os.path.exists(k)]:
             _MAPS.pop(key)
         with open(staging, 'r+b') as fh:
-            mm = mmap.mmap(fh.fileno(), 0)
+            size = os.fstat(fh.fileno()).st_size
+            mm = mmap.mmap(fh.fileno(), size, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0))
         got = _MAPS[staging] = (mm, np.frombuffer(mm, dtype=np.int16))
-    view = got[1]
-    for item, off, n in zip(items, offsets, lengths):
-        path, read_id = resolve(item)
-        fast5_file(path).raw_signal_into(read_id, view[off:off + n])
-    return len(items)
+    return decode_into(got[1], items, offsets, lengths)
 
 
 def spread_over_cpus(k: int):

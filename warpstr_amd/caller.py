@@ -522,7 +522,7 @@ class SharedStaging:
             fd, path = tempfile.mkstemp(prefix='warpstr_stage_', dir=self._dir)
             try:
                 os.ftruncate(fd, cap * 2)
-                mm = mmap.mmap(fd, cap * 2)
+                mm = mmap.mmap(fd, cap * 2, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0))   # (pages present from the start)
             finally:
                 os.close(fd)
             view = np.frombuffer(mm, dtype=np.int16)
@@ -654,6 +654,12 @@ class BatchQueue:
             self._shared = SharedStaging(3, register, unregister)
         return self._shared.take(count)
 
+    def stage_local(self, count: int) -> dict:
+        """A staging slot of `count` int16 samples in this process's page-locked ring (the one submit_raw concatenates into), for
+        a reader that decodes its reads straight to their places; submit_raw_shared() takes it."""
+        pinned = self._stage(self.torch.int16, count)
+        return dict(path=None, view=pinned[0].numpy(), tensor=pinned[0], pinned=pinned, event=None)
+
     def submit_raw_shared(self, slot: dict, roff: np.ndarray, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
         """submit_raw() for reads that lie back to back in a staging slot already (read r = slot['view'][roff[r] : roff[r + 1]])."""
         torch = self.torch
@@ -664,12 +670,14 @@ class BatchQueue:
         lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
         offsets = np.zeros(n + 1, np.int64)
         np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
-        host = torch.from_numpy(slot['view'])
+        host = slot['tensor'] if slot.get('tensor') is not None else torch.from_numpy(slot['view'])
         with torch.cuda.stream(self.stream):
             raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
             raw_dev[:total_raw].copy_(host[:total_raw], non_blocking=True)
             slot['event'] = torch.cuda.Event()
             slot['event'].record()
+            if slot.get('pinned') is not None:
+                slot['pinned'][1] = slot['event']   # (the ring waits for this upload before it hands the buffer out again)
             signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
         if n:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)

@@ -131,7 +131,7 @@ class HipEngine:
         self.hip = HipCaller(tables, flank_lengths, caller_config, rescaler_config, device=device, stream=self.stream.cuda_stream)
         self.queue = BatchQueue(self.hip, self.stream, (caller_config or CallerConfig()).spike_removal)
         self.submit_raw, self.submit_signals, self.collect = self.queue.submit_raw, self.queue.submit_signals, self.queue.collect
-        self.stage_shared, self.submit_raw_shared = self.queue.stage_shared, self.queue.submit_raw_shared
+        self.stage_shared, self.submit_raw_shared, self.stage_local = self.queue.stage_shared, self.queue.submit_raw_shared, self.queue.stage_local
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
@@ -249,7 +249,7 @@ def _units_of(sequence: str):
 # Opening a file, HDF5 and zstd take a few tenths of a millisecond per read, and libhdf5 is not thread-safe: the one part of the
 # host work that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and
 # import NumPy and the fast5 reader only -- warpstr_amd/_readers.py).
-from ._readers import decode_chunk as _decode_chunk, probe_chunk as _probe_chunk, read_chunk as _read_chunk  # noqa: E402
+from ._readers import decode_chunk as _decode_chunk, decode_into as _decode_into, probe_chunk as _probe_chunk, read_chunk as _read_chunk  # noqa: E402
 
 
 class _WorkerPool:
@@ -639,6 +639,27 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     else:
                         for part in pool.map(_read_chunk, parts):
                             data += part
+                elif fast5_on_workers and hasattr(queue, 'stage_local'):
+                    # the fast5 files of a batch in this process, decoded straight to their places in the page-locked staging ring
+                    # (a fresh array per read costs a page fault per 4 KiB -- more than HDF5, zstd and StreamVByte together)
+                    if b1 - b0 > SHARED_BATCH_READS:
+                        cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
+                        b1 = b0 + SHARED_BATCH_READS
+                    items = []
+                    for k in range(b0, b1):
+                        job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
+                        items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
+                    lens_b = np.array(_probe_chunk(items), np.int64)
+                    keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
+                    if keep < len(items):
+                        cuts.insert(b + 1, b0 + keep)
+                        b1 = b0 + keep
+                        items, lens_b = items[:keep], lens_b[:keep]
+                    shared_roff = np.zeros(len(items) + 1, np.int64)
+                    np.cumsum(lens_b, out=shared_roff[1:])
+                    shared_slot = queue.stage_local(int(shared_roff[-1]))
+                    _decode_into(shared_slot['view'], items, shared_roff[:-1].tolist(), lens_b.tolist())
+                    tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
                 elif signal_loader is None:
                     for k in range(b0, b1):
                         g = mine[k]
