@@ -41,7 +41,8 @@ inline int fanin(const int32_t *pp, int j) { return pp[j + 1] - pp[j]; }
 // extra LDS cycles per row of a placement: for every slot k, candidate f and half g the largest number of distinct slots
 // on one bank pair, minus one; the same for the export writes
 inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, int F, int FL, const std::vector<uint16_t> &pos,
-                           const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot, int *surplus_out = nullptr)
+                           const std::vector<uint16_t> &state_at, const std::vector<uint16_t> &wslot, int *surplus_out = nullptr,
+                           int *culprit_out = nullptr)
 {
     // (no heap in here: the repair pass of wsx_place_attempt calls this thousands of times per automaton, and a handle for all
     // loci of a run places thousands of automata)
@@ -69,7 +70,7 @@ inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, i
             return x;
         }
     } on;
-    int total = 0, extra = 0;
+    int total = 0, extra = 0, culprit = -1, seen = 0;
     for (int k = 0; k < K; k++) {
         for (int q = 0; q < 4; q++) { // writes: 16 lanes at a time, slots distinct modulo 16 (idle lanes write as well)
             on.clear(16);
@@ -91,10 +92,20 @@ inline int conflict_cycles(int S, const int32_t *pp, const int32_t *pi, int K, i
                 }
                 total += on.worst(32) - 1;
                 extra += on.surplus(32);
+                if (culprit_out && on.surplus(32) > 0) // a position whose export shares its bank pair with another one read here
+                    for (int l = g * 32; l < g * 32 + 32; l++) {
+                        const int j = state_at[k * 64 + l] == 0xFFFF ? -1 : state_at[k * 64 + l];
+                        if (j < 0 || fanin(pp, j) <= f) continue;
+                        const int q = pos[pi[pp[j] + f]];
+                        if (on.n[wslot[q] & 31] <= 1) continue;
+                        seen++; // (one of them, each with the same chance, by a fixed hash of its rank: deterministic)
+                        if ((((unsigned)seen * 2654435761u) >> 7) % (unsigned)seen == 0) culprit = (seen & 1) ? q : k * 64 + l;
+                    }
             }
     }
     (void)S;
     if (surplus_out) *surplus_out = extra;
+    if (culprit_out) *culprit_out = culprit;
     return total;
 }
 
@@ -365,10 +376,13 @@ inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *p
             // four-candidate automaton: 1 cycle per row left by the walk before, 0 now after ~1 500 steps.)
             uint32_t rng = 0x51ED270Bu ^ (uint32_t)S;
             auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
-            int cur_extra = 0;
-            (void)conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &cur_extra);
-            for (int step = 0; step < 12000 && cur_cost > 0; step++) {
-                const int a = (int)(next() % P), b = (int)(next() % P);
+            int cur_extra = 0, culprit = -1;
+            (void)conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &cur_extra, &culprit);
+            for (int step = 0; step < 6000 && cur_cost > 0; step++) {
+                // (three steps in four move a position that is part of a collision -- a reader or the predecessor it reads, picked
+                // by the count itself --, the fourth is blind: ~6 x fewer steps to zero than a blind walk, and the walk is what a
+                // handle for thousands of loci spends its creation time in)
+                const int a = (culprit >= 0 && (step & 3) != 3) ? culprit : (int)(next() % P), b = (int)(next() % P);
                 if (a == b) continue;
                 const int ja = out.state_at[a] == 0xFFFF ? -1 : out.state_at[a], jb = out.state_at[b] == 0xFFFF ? -1 : out.state_at[b];
                 if ((ja < 0 && jb < 0) || !pinned_ok(ja, b) || !pinned_ok(jb, a)) continue;
@@ -378,11 +392,12 @@ inline WsxPlacement wsx_place_attempt(int S, const int32_t *pp, const int32_t *p
                     if (out.state_at[b] != 0xFFFF) out.pos[out.state_at[b]] = (uint16_t)b;
                 };
                 trade();
-                int extra = 0;
-                const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &extra);
+                int extra = 0, next_culprit = -1;
+                const int c = conflict_cycles(S, pp, pi, K, F, FL, out.pos, out.state_at, out.wslot, &extra, &next_culprit);
                 if (c < cur_cost || (c == cur_cost && extra <= cur_extra)) {
                     cur_cost = c;
                     cur_extra = extra;
+                    culprit = next_culprit;
                 } else {
                     trade();
                 }
