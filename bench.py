@@ -621,6 +621,7 @@ def from_fast5_leg(n_copies, local):
                         'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
                         'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
                                      'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
+                                     'decode_summed_over_reader_processes': tm.get('decode_worker_s'),
                                      'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
                         'shared_staging_refused': tm.get('shared_staging_refused'),
                         'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}

@@ -1,0 +1,10 @@
+"""The from_fast5 leg of bench.py by itself (N copies of the upstream test fast5 through main_wrapper_loci, files -> output files).
+Usage: exp_from_fast5.py [n_copies]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+print(json.dumps(bench.from_fast5_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 1500, 0), indent=1))

@@ -52,17 +52,18 @@ def probe_chunk(items):
     return out
 
 
-def decode_into(view: np.ndarray, items, offsets, lengths) -> int:
-    """Decode each read into view[offset : offset + length] (an int16 staging buffer)."""
+def decode_into(view: np.ndarray, items, offsets, lengths) -> float:
+    """Decode each read into view[offset : offset + length] (an int16 staging buffer); returns the seconds it took."""
+    import time
+    t0 = time.perf_counter()
     for item, off, n in zip(items, offsets, lengths):
         path, read_id = resolve(item)
         fast5_file(path).raw_signal_into(read_id, view[off:off + n])
-    return len(items)
+    return time.perf_counter() - t0
 
 
 def decode_chunk(args):
-    """decode_into() for the staging FILE both processes map (caller.SharedStaging), by its path.  The mapping is made with its
-    pages present (MAP_POPULATE): a worker otherwise takes a page fault for every 4 KiB it writes for the first time."""
+    """decode_into() for the staging FILE both processes map (caller.SharedStaging), by its path."""
     import mmap
     staging, items, offsets, lengths = args
     got = _MAPS.get(staging)
@@ -71,7 +72,7 @@ def decode_chunk(args):
             _MAPS.pop(key)
         with open(staging, 'r+b') as fh:
             size = os.fstat(fh.fileno()).st_size
-            mm = mmap.mmap(fh.fileno(), size, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0))
+            mm = mmap.mmap(fh.fileno(), size)   # (not pre-faulted: a worker writes a sixteenth of it)
         got = _MAPS[staging] = (mm, np.frombuffer(mm, dtype=np.int16))
     return decode_into(got[1], items, offsets, lengths)
 

@@ -632,9 +632,10 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             use_shared = False
                     if use_shared:
                         t2 = time.perf_counter()
-                        pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist())
-                                                 for k, part in zip(range(0, len(items), step), parts)])
+                        busy = pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist())
+                                                        for k, part in zip(range(0, len(items), step), parts)])
                         tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t2
+                        tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(sum(busy))   # (summed over the reader processes)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
                     else:
                         for part in pool.map(_read_chunk, parts):
