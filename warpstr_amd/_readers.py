@@ -63,9 +63,11 @@ def decode_into(view: np.ndarray, items, offsets, lengths) -> float:
 
 
 def decode_chunk(args):
-    """decode_into() for the staging FILE both processes map (caller.SharedStaging), by its path."""
+    """decode_into() for the staging FILE both processes map (caller.SharedStaging), by its path.  A fifth element: items of the
+    NEXT batch whose lengths the parent does not know yet -- answered in the same round trip (the parent then lays that batch out
+    without a round of its own).  Returns (seconds spent decoding, [their lengths])."""
     import mmap
-    staging, items, offsets, lengths = args
+    staging, items, offsets, lengths = args[:4]
     got = _MAPS.get(staging)
     if got is None or len(got[1]) < max((o + n for o, n in zip(offsets, lengths)), default=0):
         for key in [k for k in _MAPS if not os.path.exists(k)]:
@@ -74,7 +76,8 @@ def decode_chunk(args):
             size = os.fstat(fh.fileno()).st_size
             mm = mmap.mmap(fh.fileno(), size)   # (not pre-faulted: a worker writes a sixteenth of it)
         got = _MAPS[staging] = (mm, np.frombuffer(mm, dtype=np.int16))
-    return decode_into(got[1], items, offsets, lengths)
+    busy = decode_into(got[1], items, offsets, lengths)
+    return busy, (probe_chunk(args[4]) if len(args) > 4 and args[4] else [])
 
 
 def spread_over_cpus(k: int):

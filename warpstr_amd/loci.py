@@ -575,6 +575,10 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             pool = _started(pool, tm)
             raw_len = np.full(len(mine), -1, np.int64)   # samples of a read's whole raw signal, once a reader process has said
 
+            def item_of(k):   # what a reader needs to find read k of this rank: (annotated fast5, multi-read fall-back, read name)
+                job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
+                return (job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row])
+
             def finish(ticket, b0, b1):
                 t1 = time.perf_counter()
                 rec, s1, p1, s2, p2 = queue.collect(ticket)
@@ -597,18 +601,15 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     if use_shared and b1 - b0 > SHARED_BATCH_READS:   # (a shared batch is small: see SHARED_BATCH_BYTES)
                         cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
                         b1 = b0 + SHARED_BATCH_READS
-                    items = []
-                    for k in range(b0, b1):
-                        job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
-                        items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
-                    step = max(8, min(256, len(items) // (4 * pool._max_workers) or 8))
+                    items = [item_of(k) for k in range(b0, b1)]
+                    step = max(8, -(-len(items) // (2 * pool._max_workers)))   # (two chunks per worker: a round trip costs ~0.1 ms)
                     parts = [items[k:k + step] for k in range(0, len(items), step)]
                     if use_shared:
                         # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
                         t2 = time.perf_counter()
                         todo = [k for k in range(len(items)) if raw_len[b0 + k] < 0]   # (a read is asked for its length once)
                         if todo:
-                            tstep = max(8, min(256, len(todo) // (4 * pool._max_workers) or 8))
+                            tstep = max(8, -(-len(todo) // (2 * pool._max_workers)))
                             got = [n for part in pool.map(_probe_chunk, [[items[k] for k in todo[q:q + tstep]] for q in range(0, len(todo), tstep)])
                                    for n in part]
                             raw_len[b0 + np.asarray(todo)] = got
@@ -632,10 +633,19 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             use_shared = False
                     if use_shared:
                         t2 = time.perf_counter()
-                        busy = pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist())
-                                                        for k, part in zip(range(0, len(items), step), parts)])
+                        # (the reads after this batch whose lengths are not known yet ride along: the next batch is then laid out
+                        # without a round trip of its own)
+                        ahead = [k for k in range(b1, min(len(mine), b1 + SHARED_BATCH_READS)) if raw_len[k] < 0]
+                        n_parts = len(parts)
+                        asked = [ahead[q::n_parts] for q in range(n_parts)]
+                        answers = pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist(),
+                                                            [item_of(x) for x in asked[q]])
+                                                           for q, (k, part) in enumerate(zip(range(0, len(items), step), parts))])
+                        for q, (busy, lens_ahead) in enumerate(answers):
+                            tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)   # (summed over the reader processes)
+                            if asked[q]:
+                                raw_len[np.asarray(asked[q])] = lens_ahead
                         tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t2
-                        tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(sum(busy))   # (summed over the reader processes)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
                     else:
                         for part in pool.map(_read_chunk, parts):
@@ -646,10 +656,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     if b1 - b0 > SHARED_BATCH_READS:
                         cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
                         b1 = b0 + SHARED_BATCH_READS
-                    items = []
-                    for k in range(b0, b1):
-                        job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
-                        items.append((job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row]))
+                    items = [item_of(k) for k in range(b0, b1)]
                     lens_b = np.array(_probe_chunk(items), np.int64)
                     keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
                     if keep < len(items):
