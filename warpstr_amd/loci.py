@@ -263,7 +263,7 @@ class _WorkerPool:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
         self._max_workers = n
-        self._procs, self._error = [], None
+        self._procs, self._error, self._drivers = [], None, None
 
         def start():   # (on a thread of its own: forking a process with the GPU runtime mapped sixteen times takes a good part of a
             try:       # second, in which the caller parses its overviews)
@@ -310,11 +310,11 @@ class _WorkerPool:
                     results[i] = payload
             except Exception as e:  # noqa: BLE001 -- raised in the caller's thread below
                 errors.append(e)
-        threads = [threading.Thread(target=drive, args=(p,), daemon=True) for p in self.procs]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        if self._drivers is None:   # (one thread per worker process, kept: a map is a few milliseconds of work)
+            from concurrent.futures import ThreadPoolExecutor
+            self._drivers = ThreadPoolExecutor(max_workers=len(self.procs))
+        for f in [self._drivers.submit(drive, p) for p in self.procs[:max(1, min(len(self.procs), len(items)))]]:
+            f.result()
         if errors:
             raise errors[0]
         return results
@@ -323,6 +323,9 @@ class _WorkerPool:
         if self._starter is not None:
             self._starter.join()
             self._starter = None
+        if self._drivers is not None:
+            self._drivers.shutdown(wait=True)
+            self._drivers = None
         for p in self._procs:
             try:
                 p.stdin.close()
