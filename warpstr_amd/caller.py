@@ -642,7 +642,8 @@ class BatchQueue:
 
             def register(address, nbytes):
                 try:
-                    return int(rt.cudaHostRegister(address, nbytes, 0)) == 0
+                    with torch.cuda.device(self.dev):   # (may be called from the driver's reader thread)
+                        return int(rt.cudaHostRegister(address, nbytes, 0)) == 0
                 except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
                     return False
 

@@ -590,105 +590,113 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 seqs[0].append(s1)
                 seqs[1].append(s2)
 
-            b = 0
-            while b < len(cuts) - 1:
-                b0, b1 = cuts[b], cuts[b + 1]
-                t1 = time.perf_counter()
-                data, raw_bytes, shared_slot = [], 0, None
-                if raw_reads is not None:
-                    sel_names = all_names[b0:b1] if whole else [all_names[g] for g in mine[b0:b1]]
-                    data = [raw_reads[nm] for nm in sel_names]
-                elif pool is not None and b1 - b0 >= 64:
-                    # the fast5 files of a batch on the worker processes
-                    use_shared = hasattr(queue, 'stage_shared') and not tm.get('shared_staging_refused')
-                    if use_shared and b1 - b0 > SHARED_BATCH_READS:   # (a shared batch is small: see SHARED_BATCH_BYTES)
-                        cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
-                        b1 = b0 + SHARED_BATCH_READS
-                    items = [item_of(k) for k in range(b0, b1)]
-                    step = max(8, -(-len(items) // (2 * pool._max_workers)))   # (two chunks per worker: a round trip costs ~0.1 ms)
-                    parts = [items[k:k + step] for k in range(0, len(items), step)]
-                    if use_shared:
-                        # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
-                        t2 = time.perf_counter()
-                        todo = [k for k in range(len(items)) if raw_len[b0 + k] < 0]   # (a read is asked for its length once)
-                        if todo:
-                            tstep = max(8, -(-len(todo) // (2 * pool._max_workers)))
-                            got = [n for part in pool.map(_probe_chunk, [[items[k] for k in todo[q:q + tstep]] for q in range(0, len(todo), tstep)])
-                                   for n in part]
-                            raw_len[b0 + np.asarray(todo)] = got
-                        lens_b = raw_len[b0:b1].copy()
-                        tm['probe_s'] = tm.get('probe_s', 0.0) + time.perf_counter() - t2
-                        # (a shared batch is a fraction of the byte budget: the three staging buffers are then reused -- their pages
-                        # are touched and page-locked once -- and the decoding of one batch runs beside the upload of the last)
+            def batches():
+                """The rank's batches one after the other, read: (first, end, reads or [], staging slot or None, its read offsets).
+                Run by the caller's thread, or -- with reader processes -- by a thread of its own, so that a batch is decoded while
+                the previous one is submitted and an earlier one collected."""
+                b = 0
+                while b < len(cuts) - 1:
+                    b0, b1 = cuts[b], cuts[b + 1]
+                    t1 = time.perf_counter()
+                    data, raw_bytes, shared_slot = [], 0, None
+                    if raw_reads is not None:
+                        sel_names = all_names[b0:b1] if whole else [all_names[g] for g in mine[b0:b1]]
+                        data = [raw_reads[nm] for nm in sel_names]
+                    elif pool is not None and b1 - b0 >= 64:
+                        # the fast5 files of a batch on the worker processes
+                        use_shared = hasattr(queue, 'stage_shared') and not tm.get('shared_staging_refused')
+                        if use_shared and b1 - b0 > SHARED_BATCH_READS:   # (a shared batch is small: see SHARED_BATCH_BYTES)
+                            cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
+                            b1 = b0 + SHARED_BATCH_READS
+                        items = [item_of(k) for k in range(b0, b1)]
+                        step = max(8, -(-len(items) // (2 * pool._max_workers)))   # (two chunks per worker: a round trip costs ~0.1 ms)
+                        parts = [items[k:k + step] for k in range(0, len(items), step)]
+                        if use_shared:
+                            # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
+                            t2 = time.perf_counter()
+                            todo = [k for k in range(len(items)) if raw_len[b0 + k] < 0]   # (a read is asked for its length once)
+                            if todo:
+                                tstep = max(8, -(-len(todo) // (2 * pool._max_workers)))
+                                got = [n for part in pool.map(_probe_chunk, [[items[k] for k in todo[q:q + tstep]] for q in range(0, len(todo), tstep)])
+                                       for n in part]
+                                raw_len[b0 + np.asarray(todo)] = got
+                            lens_b = raw_len[b0:b1].copy()
+                            tm['probe_s'] = tm.get('probe_s', 0.0) + time.perf_counter() - t2
+                            # (a shared batch is a fraction of the byte budget: the three staging buffers are then reused -- their pages
+                            # are touched and page-locked once -- and the decoding of one batch runs beside the upload of the last)
+                            keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
+                            if keep < len(items):
+                                cuts.insert(b + 1, b0 + keep)
+                                b1 = b0 + keep
+                                items, lens_b = items[:keep], lens_b[:keep]
+                                parts = [items[k:k + step] for k in range(0, len(items), step)]
+                            shared_roff = np.zeros(len(items) + 1, np.int64)
+                            np.cumsum(lens_b, out=shared_roff[1:])
+                            try:
+                                shared_slot = queue.stage_shared(int(shared_roff[-1]))
+                            except OSError as e:   # no room under /dev/shm: the decoded reads come back through the pipes instead
+                                print(f'warpstr_amd: no shared staging buffer ({e}); the reader processes return the reads through their pipes', file=sys.stderr)
+                                tm['shared_staging_refused'] = str(e)
+                                use_shared = False
+                        if use_shared:
+                            t2 = time.perf_counter()
+                            # (the reads after this batch whose lengths are not known yet ride along: the next batch is then laid out
+                            # without a round trip of its own)
+                            ahead = [k for k in range(b1, min(len(mine), b1 + SHARED_BATCH_READS)) if raw_len[k] < 0]
+                            n_parts = len(parts)
+                            asked = [ahead[q::n_parts] for q in range(n_parts)]
+                            answers = pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist(),
+                                                                [item_of(x) for x in asked[q]])
+                                                               for q, (k, part) in enumerate(zip(range(0, len(items), step), parts))])
+                            for q, (busy, lens_ahead) in enumerate(answers):
+                                tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)   # (summed over the reader processes)
+                                if asked[q]:
+                                    raw_len[np.asarray(asked[q])] = lens_ahead
+                            tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t2
+                            tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
+                        else:
+                            for part in pool.map(_read_chunk, parts):
+                                data += part
+                    elif fast5_on_workers and hasattr(queue, 'stage_local'):
+                        # the fast5 files of a batch in this process, decoded straight to their places in the page-locked staging ring
+                        # (a fresh array per read costs a page fault per 4 KiB -- more than HDF5, zstd and StreamVByte together)
+                        if b1 - b0 > SHARED_BATCH_READS:
+                            cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
+                            b1 = b0 + SHARED_BATCH_READS
+                        items = [item_of(k) for k in range(b0, b1)]
+                        lens_b = np.array(_probe_chunk(items), np.int64)
                         keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
                         if keep < len(items):
                             cuts.insert(b + 1, b0 + keep)
                             b1 = b0 + keep
                             items, lens_b = items[:keep], lens_b[:keep]
-                            parts = [items[k:k + step] for k in range(0, len(items), step)]
                         shared_roff = np.zeros(len(items) + 1, np.int64)
                         np.cumsum(lens_b, out=shared_roff[1:])
-                        try:
-                            shared_slot = queue.stage_shared(int(shared_roff[-1]))
-                        except OSError as e:   # no room under /dev/shm: the decoded reads come back through the pipes instead
-                            print(f'warpstr_amd: no shared staging buffer ({e}); the reader processes return the reads through their pipes', file=sys.stderr)
-                            tm['shared_staging_refused'] = str(e)
-                            use_shared = False
-                    if use_shared:
-                        t2 = time.perf_counter()
-                        # (the reads after this batch whose lengths are not known yet ride along: the next batch is then laid out
-                        # without a round trip of its own)
-                        ahead = [k for k in range(b1, min(len(mine), b1 + SHARED_BATCH_READS)) if raw_len[k] < 0]
-                        n_parts = len(parts)
-                        asked = [ahead[q::n_parts] for q in range(n_parts)]
-                        answers = pool.map(_decode_chunk, [(shared_slot['path'], part, shared_roff[k:k + len(part)].tolist(), lens_b[k:k + len(part)].tolist(),
-                                                            [item_of(x) for x in asked[q]])
-                                                           for q, (k, part) in enumerate(zip(range(0, len(items), step), parts))])
-                        for q, (busy, lens_ahead) in enumerate(answers):
-                            tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)   # (summed over the reader processes)
-                            if asked[q]:
-                                raw_len[np.asarray(asked[q])] = lens_ahead
-                        tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t2
+                        shared_slot = queue.stage_local(int(shared_roff[-1]))
+                        _decode_into(shared_slot['view'], items, shared_roff[:-1].tolist(), lens_b.tolist())
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
+                    elif signal_loader is None:
+                        for k in range(b0, b1):
+                            g = mine[k]
+                            data.append(jobs[locus_of[g]].raw_read(int(row_of[g]), raw_reader))
                     else:
-                        for part in pool.map(_read_chunk, parts):
-                            data += part
-                elif fast5_on_workers and hasattr(queue, 'stage_local'):
-                    # the fast5 files of a batch in this process, decoded straight to their places in the page-locked staging ring
-                    # (a fresh array per read costs a page fault per 4 KiB -- more than HDF5, zstd and StreamVByte together)
-                    if b1 - b0 > SHARED_BATCH_READS:
-                        cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
-                        b1 = b0 + SHARED_BATCH_READS
-                    items = [item_of(k) for k in range(b0, b1)]
-                    lens_b = np.array(_probe_chunk(items), np.int64)
-                    keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
-                    if keep < len(items):
-                        cuts.insert(b + 1, b0 + keep)
-                        b1 = b0 + keep
-                        items, lens_b = items[:keep], lens_b[:keep]
-                    shared_roff = np.zeros(len(items) + 1, np.int64)
-                    np.cumsum(lens_b, out=shared_roff[1:])
-                    shared_slot = queue.stage_local(int(shared_roff[-1]))
-                    _decode_into(shared_slot['view'], items, shared_roff[:-1].tolist(), lens_b.tolist())
-                    tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
-                elif signal_loader is None:
-                    for k in range(b0, b1):
-                        g = mine[k]
-                        data.append(jobs[locus_of[g]].raw_read(int(row_of[g]), raw_reader))
-                else:
-                    for k in range(b0, b1):
-                        g = mine[k]
-                        data.append(np.asarray(signal_loader(jobs[locus_of[g]].fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
-                if signal_loader is None and shared_slot is None:
-                    keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
-                    while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
-                        acc += data[keep].nbytes
-                        keep += 1
-                    if keep < len(data):
-                        cuts.insert(b + 1, b0 + keep)
-                        b1 = b0 + keep
-                        del data[keep:]
-                tm['read_s'] += time.perf_counter() - t1
+                        for k in range(b0, b1):
+                            g = mine[k]
+                            data.append(np.asarray(signal_loader(jobs[locus_of[g]].fast5_of(int(row_of[g])), int(lo[g]), int(hi[g])), dtype=np.float64))
+                    if signal_loader is None and shared_slot is None:
+                        keep, acc = 0, 0  # long raw reads: as many as fit the byte budget, the rest open the next batch
+                        while keep < len(data) and (keep == 0 or acc + data[keep].nbytes <= raw_budget):
+                            acc += data[keep].nbytes
+                            keep += 1
+                        if keep < len(data):
+                            cuts.insert(b + 1, b0 + keep)
+                            b1 = b0 + keep
+                            del data[keep:]
+                    tm['read_s'] += time.perf_counter() - t1
+                    yield b0, b1, data, shared_slot, (shared_roff if shared_slot is not None else None)
+                    b += 1
+
+            def submit(b0, b1, data, shared_slot, shared_roff):
                 t1 = time.perf_counter()
                 sel = mine[b0:b1]
                 if shared_slot is not None:
@@ -701,7 +709,52 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 pending.append((ticket, b0, b1))
                 if len(pending) > 2:  # at most three batches' buffers in HBM / in flight
                     finish(*pending.pop(0))
-                b += 1
+
+            if pool is not None and hasattr(queue, 'stage_shared'):
+                # A reader thread runs one batch ahead: the staging ring has three slots, and a slot is taken again only after the
+                # batch that used it was submitted (the hand-over queue holds one batch: taking the slot of batch n + 3 follows
+                # putting batch n + 2, which follows the consumer's get of batch n + 1, i.e. its submit of batch n).
+                import queue as _queue
+                import threading
+                handover: '_queue.Queue' = _queue.Queue(maxsize=1)
+                stop = threading.Event()
+
+                def produce():
+                    try:
+                        for item in batches():
+                            while not stop.is_set():
+                                try:
+                                    handover.put(item, timeout=0.2)
+                                    break
+                                except _queue.Full:
+                                    pass
+                            if stop.is_set():
+                                return
+                        item = None
+                    except BaseException as e:  # noqa: BLE001 -- raised by the consumer below
+                        item = e
+                    while not stop.is_set():
+                        try:
+                            handover.put(item, timeout=0.2)
+                            return
+                        except _queue.Full:
+                            pass
+                reader = threading.Thread(target=produce, name='warpstr-reader', daemon=True)
+                reader.start()
+                try:
+                    while True:
+                        item = handover.get()
+                        if item is None:
+                            break
+                        if isinstance(item, BaseException):
+                            raise item
+                        submit(*item)
+                finally:
+                    stop.set()
+                    reader.join()
+            else:
+                for item in batches():
+                    submit(*item)
             while pending:
                 finish(*pending.pop(0))
             if queue is not None:
