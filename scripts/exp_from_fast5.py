@@ -1,10 +1,15 @@
 """The from_fast5 leg of bench.py by itself (N copies of the upstream test fast5 through main_wrapper_loci, files -> output files).
-Usage: exp_from_fast5.py [n_copies]"""
+Usage: [WSX_SHARED_MB=.. WSX_SHARED_READS=..] exp_from_fast5.py [n_copies]"""
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from warpstr_amd import loci
+
+if os.environ.get('WSX_SHARED_MB'):   # experiment: raw bytes / reads of a batch the reader processes decode into a staging buffer
+    loci.SHARED_BATCH_BYTES = int(os.environ['WSX_SHARED_MB']) << 20
+    loci.SHARED_BATCH_READS = int(os.environ.get('WSX_SHARED_READS', loci.SHARED_BATCH_READS))
 
 print(json.dumps(bench.from_fast5_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 1500, 0), indent=1))
