@@ -17,6 +17,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <pthread.h>
@@ -648,9 +649,37 @@ try {
         }
     };
     {
-        const int nt = n_automata >= 16 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+        // Where a state lives depends on the GRAPH of its automaton alone (the predecessor lists), not on the levels: the loci of a
+        // panel repeat a few dozen patterns, and the flanks of a locus change its levels far more often than its graph.  Automata
+        // with the same graph are placed once (found by a hash of the lists, confirmed by comparing them).
+        std::vector<int> rep((size_t)n_automata), todo;
+        {
+            std::unordered_map<uint64_t, std::vector<int>> seen;
+            for (int a = 0; a < n_automata; a++) {
+                const wsx_automaton &A = automata[a];
+                const int S = A.n_states, E = A.pred_ptr[S];
+                uint64_t h = 1469598103934665603ull ^ (uint64_t)S;
+                for (int j = 0; j <= S; j++) h = (h ^ (uint64_t)(uint32_t)A.pred_ptr[j]) * 1099511628211ull;
+                for (int e = 0; e < E; e++) h = (h ^ (uint64_t)(uint32_t)A.pred_idx[e]) * 1099511628211ull;
+                rep[a] = a;
+                for (int b : seen[h]) {
+                    const wsx_automaton &B = automata[b];
+                    if (B.n_states == S && memcmp(B.pred_ptr, A.pred_ptr, (size_t)(S + 1) * 4) == 0 &&
+                        memcmp(B.pred_idx, A.pred_idx, (size_t)E * 4) == 0) {
+                        rep[a] = b;
+                        break;
+                    }
+                }
+                if (rep[a] == a) {
+                    seen[h].push_back(a);
+                    todo.push_back(a);
+                }
+            }
+        }
+        const int n_todo = (int)todo.size();
+        const int nt = n_todo >= 16 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
         if (nt <= 1) {
-            for (int a = 0; a < n_automata; a++) place_one(a);
+            for (int a : todo) place_one(a);
         } else {
             // (taken one at a time from a shared counter: a five-slot automaton with nested loops takes a hundred times as long
             // as a four-slot chain, and the loci of a run repeat with a period that a fixed stride maps onto a few threads)
@@ -661,7 +690,7 @@ try {
                 th.emplace_back([&, t] {
                     try {
                         spread_thread(t);
-                        for (int a = next_a.fetch_add(1); a < n_automata; a = next_a.fetch_add(1)) place_one(a);
+                        for (int q = next_a.fetch_add(1); q < n_todo; q = next_a.fetch_add(1)) place_one(todo[q]);
                     } catch (...) {
                         errs[t] = std::current_exception();
                     }
@@ -670,6 +699,8 @@ try {
             for (auto &e : errs)
                 if (e) std::rethrow_exception(e);
         }
+        for (int a = 0; a < n_automata; a++)
+            if (rep[a] != a) placed[a] = placed[rep[a]];
     }
     c->create_s[1] = since(t_phase);
     t_phase = now();
