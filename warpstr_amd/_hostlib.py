@@ -34,7 +34,7 @@ class WshSetup(C.Structure):
 
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
            'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
-           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16']
+           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_gather']
 
 
 def lib():
@@ -71,6 +71,8 @@ def lib():
                                                                                                    C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p,
                                                                                                    C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                                                                                    C.POINTER(C.c_int64)]
+                    h.wsh_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+                    h.wsh_gather.restype = None
                     h.wsh_locus_setup.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.POINTER(WshSetup)]
                     h.wsh_locus_setup.restype = None
                     h.wsh_setup_free.argtypes = [C.POINTER(WshSetup)]

@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
     if force or _stale(HOST_LIB, [HOST_SRC]):
-        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-fvisibility=hidden', '-Wall',
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-fvisibility=hidden', '-Wall', '-pthread',
                HOST_SRC, '-o', HOST_LIB]
         if verbose:
             print(' '.join(cmd), flush=True)

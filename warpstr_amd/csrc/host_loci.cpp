@@ -21,6 +21,7 @@
 #include <cstring>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -1162,6 +1163,32 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
         put(i, v);
     }
     return n;
+}
+
+// n pieces of host memory laid end to end into dst (the raw reads of a batch into the page-locked staging buffer the upload
+// starts from), split by bytes over up to `threads` threads: 275 MB in 50 000 pieces is 30 ms of one core's memcpy.
+WSH_EXPORT void wsh_gather(const void *const *src, const int64_t *bytes, int64_t n, void *dst, int32_t threads)
+{
+    std::vector<int64_t> at((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) at[i + 1] = at[i] + (bytes[i] > 0 ? bytes[i] : 0);
+    const int64_t total = at[n];
+    auto run = [&](int64_t lo, int64_t hi) {   // pieces [lo, hi)
+        for (int64_t i = lo; i < hi; i++)
+            if (bytes[i] > 0) memcpy(static_cast<char *>(dst) + at[i], src[i], size_t(bytes[i]));
+    };
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, 16), total >> 22)));   // >= 4 MB per thread
+    if (nt <= 1) { run(0, n); return; }
+    std::vector<std::thread> th;
+    int64_t lo = 0;
+    for (int t = 0; t < nt; t++) {
+        const int64_t want = total * (t + 1) / nt;
+        int64_t hi = t == nt - 1 ? n : int64_t(std::upper_bound(at.begin(), at.end(), want) - at.begin()) - 1;
+        hi = std::max(hi, lo);
+        if (t == nt - 1) run(lo, hi);
+        else th.emplace_back(run, lo, hi);
+        lo = hi;
+    }
+    for (auto &x : th) x.join();
 }
 
 }  // extern "C"

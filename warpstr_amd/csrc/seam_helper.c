@@ -74,6 +74,35 @@ int64_t wsx_seam_pack_sequences(const uint8_t *src, const int64_t *offsets, cons
     return total;
 }
 
+// For every item of `arrays` (a sequence of C-contiguous 1-d int16 buffers: the raw reads of a batch): ptrs[i] / lens[i] = address
+// and number of samples.  Returns n, -(i+1) if item i is something else (the caller then lets NumPy convert), INT64_MIN on a
+// Python error.  The buffers are only read while the caller keeps `arrays` alive.
+int64_t wsx_seam_buffers_i16(PyObject *arrays, uintptr_t *ptrs, int64_t *lens)
+{
+    PyObject *fast = PySequence_Fast(arrays, "the reads must be a sequence");
+    if (!fast) return INT64_MIN;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+    int64_t rc = n;
+    for (Py_ssize_t i = 0; i < n && rc == n; i++) {
+        Py_buffer view;
+        if (PyObject_GetBuffer(PySequence_Fast_GET_ITEM(fast, i), &view, PyBUF_FORMAT | PyBUF_ND | PyBUF_C_CONTIGUOUS) != 0) {
+            PyErr_Clear();
+            rc = -(int64_t)(i + 1);
+            break;
+        }
+        const char *f = view.format ? view.format : "B";
+        if (*f == '@' || *f == '=' || *f == '<') f++;
+        if (view.ndim != 1 || view.itemsize != 2 || strcmp(f, "h") != 0) rc = -(int64_t)(i + 1);
+        else {
+            ptrs[i] = (uintptr_t)view.buf;
+            lens[i] = (int64_t)view.shape[0];
+        }
+        PyBuffer_Release(&view);
+    }
+    Py_DECREF(fast);
+    return rc;
+}
+
 // ---- VBZ payloads (warpstr_amd/fast5.py) ----------------------------------------------------------------------------
 // One StreamVByte block (2-bit length keys, ceil(n/4) key bytes first, then the little-endian value bytes back to back) of
 // delta-coded, optionally zig-zag-mapped 16-bit samples -> the samples (running sum, wrapped to int16 as NumPy's cast
