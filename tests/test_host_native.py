@@ -161,6 +161,7 @@ def test_overview_in_and_out_equals_the_pandas_path(tmp_path, kind):
     (lambda t: t.replace('True', 'true', 1), 're-formatted'),
     (lambda t: t.replace('0.5', '+0.5', 1), 're-formatted'),
     (lambda t: t.replace('0.5', '.5', 1), 're-formatted'),
+    (lambda t: t.replace('0.5', '1e400', 1), 're-formatted'),
     (lambda t: t[:-1], 'newline'),
     (lambda t: t + '\n', 'blank'),
     (lambda t: t.replace('read_name', 'read_name,read_name', 1), ''),

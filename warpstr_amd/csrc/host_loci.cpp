@@ -379,9 +379,13 @@ Cell classify_cell(std::string_view s, double *val)
         }
     }
     if (float_grammar(s)) {
-        if (s == "inf" || s == "-inf") *val = s[0] == '-' ? -HUGE_VAL : HUGE_VAL;
-        else *val = pandas_strtod(s);
-        return C_FLOAT;
+        if (s == "inf" || s == "-inf") {
+            *val = s[0] == '-' ? -HUGE_VAL : HUGE_VAL;
+            return C_FLOAT;
+        }
+        *val = pandas_strtod(s);
+        // (out of range: pandas' converter reports an error there and the column is read as text -- its business)
+        return std::isinf(*val) ? C_BAD : C_FLOAT;
     }
     // anything else strtod takes whole (after blanks) is a number to pandas too, or close enough to one not to be trusted as text
     char buf[64];
