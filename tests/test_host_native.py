@@ -245,3 +245,14 @@ def test_one_call_setup_equals_the_python_forms(tmp_path):
         assert open(os.path.join(loc, 'summaries', 'state_similarity.csv')).read() == text
         n_ok += 1
     assert n_ok > 100
+
+
+def test_hostile_tables_are_declined_or_equal_to_the_pandas_path():
+    """scripts/fuzz_overview.py: 800 tables of tokens pandas treats specially; whatever the native parser accepts equals pandas."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_overview.py'), '7', '800'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1].split()
+    assert int(last[1]) > 30 and int(last[3]) > 300 and int(last[5]) == 0, last

@@ -553,6 +553,8 @@ int parse_overview(Locus &L)
     }
     if (L.n_rows == 0) { L.err = "no rows"; return 2; }   // (pandas makes every column of an empty table `object`)
     if (L.kind[L.c_name] == K_EMPTY || L.kind[L.c_name] == K_BOOL_OBJ || L.kind[L.c_name] == K_FLOAT) { L.err = "read names are not plain"; return 2; }
+    for (int c : {L.c_run, L.c_f5})   // (a float column: str() of what pandas' converter made of the text -- leave it to pandas)
+        if (c >= 0 && L.kind[c] == K_FLOAT) { L.err = "run_id / fast5_path is a column of floats"; return 3; }
     for (int c : {L.c_name, L.c_run, L.c_f5})   // str(nan) is what the Python path would make of a blank: leave those tables to it
         for (int r = 0; c >= 0 && r < L.n_rows; r++)
             if (L.cls[size_t(r) * L.n_cols + c] == C_EMPTY) { L.err = "blank read name / run_id / fast5_path"; return 3; }
