@@ -256,3 +256,52 @@ def test_hostile_tables_are_declined_or_equal_to_the_pandas_path():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1].split()
     assert int(last[1]) > 30 and int(last[3]) > 300 and int(last[5]) == 0, last
+
+
+def test_complex_unit_tables_equal_the_python_forms(tmp_path):
+    """collapse_repeats + store_collapsed in the library against units.collapse_repeats / overview.store_collapsed: random
+    patterns (nested units, optional blocks, IUPAC codes, units of the same name), sequences built from their units with errors."""
+    from warpstr_amd.loci import _complex_header
+    from warpstr_amd.units import break_into_units, collapse_repeats
+    rng = np.random.default_rng(21)
+    done = 0
+    for trial in range(300):
+        pat = random_pattern(rng)
+        try:
+            units, repeat_units, offsets = break_into_units(pat)
+        except Exception:  # noqa: BLE001
+            continue
+        if len(units) < 2:
+            continue
+        seqs = []
+        for _ in range(int(rng.integers(1, 12))):
+            s = ''
+            for alts, off in zip(repeat_units, offsets):
+                s += ''.join('ACGT'[i] for i in rng.integers(0, 4, size=off))
+                for _ in range(int(rng.integers(0, 7))):
+                    s += alts[int(rng.integers(len(alts)))] if alts and rng.random() < 0.9 else 'ACGT'[int(rng.integers(4))]
+            seqs.append(s)
+        reverse = [bool(rng.integers(0, 2)) for _ in seqs]
+        try:
+            want_counts = [collapse_repeats(s, repeat_units, offsets, max_iter=10000) for s in seqs]
+        except RuntimeError:  # an empty alternative: the library must leave it to the Python form too
+            header = _complex_header(units, repeat_units)
+            if header is not None:
+                buf = np.frombuffer(''.join(seqs).encode(), np.uint8)
+                lens = np.array([len(s) for s in seqs], np.int32)
+                assert _hostlib.collapse_store(str(tmp_path), buf, np.cumsum(lens) - lens, lens, reverse, repeat_units, offsets, header[0], header[1], False) is None
+            continue
+        header = _complex_header(units, repeat_units)
+        assert header is not None
+        a, b = tmp_path / f'a{trial}', tmp_path / f'b{trial}'
+        want = ov.store_collapsed(want_counts, units, repeat_units, reverse, str(b), write=True)
+        buf = np.frombuffer(''.join(seqs).encode(), np.uint8)
+        lens = np.array([len(s) for s in seqs], np.int32)
+        counts, text = _hostlib.collapse_store(str(a), buf, np.cumsum(lens) - lens, lens, reverse, repeat_units, offsets, header[0], header[1], True)
+        assert counts.tolist() == [[c for unit in row for c in unit] for row in want_counts]
+        rel = os.path.join('predictions', 'complexSTR_analysis', 'complex_repeat_units.csv')
+        assert open(a / rel).read() == open(b / rel).read() == text
+        import io
+        pd.testing.assert_frame_equal(pd.read_csv(io.StringIO(text), index_col=0), want)
+        done += 1
+    assert done > 60
