@@ -94,6 +94,28 @@ class SharedFakeEngine(FakeEngine):
     def info(self):
         return {'batches': self.batches, 'shared_batches': self.shared_batches, 'local_batches': getattr(self, 'local_batches', 0)}
 
+
+class ArenaFakeEngine(SharedFakeEngine):
+    """... and with the reader arenas (every reader process decodes into files of its own, one upload per chunk)."""
+    ARENA_REGIONS = 3
+
+    def region_wait(self, region):
+        pass
+
+    def submit_raw_parts(self, region, parts, lo, hi, aut):
+        self.arena_batches = getattr(self, 'arena_batches', 0) + 1
+        raws = []
+        for path, cap, base, lens in parts:
+            view = np.memmap(path, dtype=np.int16, mode='r')
+            at = base
+            for n in lens:
+                raws.append(np.array(view[at:at + n]))
+                at += n
+        return self.submit_raw(raws, lo, hi, aut)
+
+    def info(self):
+        return dict(super().info(), arena_batches=getattr(self, 'arena_batches', 0))
+
     def close(self):
         self.staging.close()
 
@@ -325,10 +347,22 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
     # place), the batches cut by the raw-byte budget
     main_wrapper_loci(c, 3, _engine=SharedFakeEngine, quiet=True, timings=tm_c, batch_raw_bytes=12 << 20)
     assert 3 <= tm_c['shared_batches'] <= tm_c['batches'] and tm_c['reader_processes'] == 3   # (the tail of fewer than 64 reads is read here)
-    for la, lb, lc in zip(a, b, c):
+    # ... and into arenas of their own, handed out a batch ahead (batches of 40 reads here: several generations per region)
+    import warpstr_amd.loci as wl
+    d, tm_d = make(str(tmp_path / 'd')), {}
+    old_reads = wl.SHARED_BATCH_READS
+    wl.SHARED_BATCH_READS = 40
+    try:
+        main_wrapper_loci(d, 3, _engine=ArenaFakeEngine, quiet=True, timings=tm_d)
+    finally:
+        wl.SHARED_BATCH_READS = old_reads
+    assert tm_d['reader_mode'] == 'arenas' and tm_d['arena_batches'] == tm_d['batches'] >= 4 and tm_d['shared_batches'] == 0
+    for la, lb, lc, ld in zip(a, b, c, d):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+            assert filecmp.cmp(os.path.join(ld.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_arena_')]
     assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_stage_')]
 
 

@@ -16,7 +16,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1].isdigit():
         _readers.spread_over_cpus(int(sys.argv[1]))   # (the k-th worker starts on the k-th CPU of the mask; nothing stays pinned)
     names = {'_read_chunk': _readers.read_chunk, '_probe_chunk': _readers.probe_chunk, '_decode_chunk': _readers.decode_chunk,
-             'read_chunk': _readers.read_chunk, 'probe_chunk': _readers.probe_chunk, 'decode_chunk': _readers.decode_chunk}
+             'read_chunk': _readers.read_chunk, 'probe_chunk': _readers.probe_chunk, 'decode_chunk': _readers.decode_chunk,
+             'decode_arena': _readers.decode_arena}
     while True:
         try:
             name, arg = pickle.load(src)

@@ -80,6 +80,83 @@ def decode_chunk(args):
     return busy, (probe_chunk(args[4]) if len(args) > 4 and args[4] else [])
 
 
+# ---- arenas: one phase, no barrier -------------------------------------------------------------------------------------------
+# A reader decodes a chunk of reads back to back into a memory-backed file of ITS OWN (one per region: the parent hands out the
+# regions in turn and lets a region be written again only after what it held has been uploaded) and answers with the lengths.
+# Nothing has to be known about a read before it is decoded, so the parent can hand out the next batch's chunks while this one's
+# slowest chunk is still running: the readers never wait for each other.  The parent maps the same files and page-locks them.
+_ARENAS: Dict[int, list] = {}     # region -> [path, mmap, int16 view]
+ARENA_DIR = '/dev/shm'
+
+
+def _arena(region: int, samples: int):
+    """The region's file mapped with room for `samples` more... (grown by doubling; at least 8 M samples)."""
+    import atexit
+    import mmap
+    import tempfile
+    cur = _ARENAS.get(region)
+    if cur is not None and len(cur[2]) >= samples:
+        return cur
+    cap = max(samples + samples // 2, 8 << 20)
+    if cur is None:
+        fd, path = tempfile.mkstemp(prefix=f'warpstr_arena_{os.getpid()}_{region}_', dir=ARENA_DIR)
+        if not _ARENAS:
+            atexit.register(_drop_arenas)
+    else:
+        path = cur[0]
+        cur[2] = cur[1] = None   # (unmap before the file grows)
+        fd = os.open(path, os.O_RDWR)
+    try:
+        st = os.statvfs(ARENA_DIR)
+        if st.f_bavail * st.f_frsize < cap * 2 + (64 << 20):
+            raise OSError(f'{ARENA_DIR} has no room for a reader arena of {cap * 2} bytes')
+        os.ftruncate(fd, cap * 2)
+        mm = mmap.mmap(fd, cap * 2)
+    finally:
+        os.close(fd)
+    _ARENAS[region] = [path, mm, np.frombuffer(mm, dtype=np.int16)]
+    return _ARENAS[region]
+
+
+def _drop_arenas():
+    for path, _, _ in list(_ARENAS.values()):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    _ARENAS.clear()
+
+
+_CURSOR: Dict[int, list] = {}    # region -> [generation, samples written in it]
+
+
+def decode_arena(args):
+    """(region, generation, items) -> (arena path, its size in samples, where this chunk starts, [length of every read], seconds):
+    the reads decoded back to back behind whatever this process has already written into the region in this generation (a batch may
+    give a reader several chunks); a new generation starts at the region's beginning."""
+    import time
+    region, generation, items = args
+    t0 = time.perf_counter()
+    cur = _CURSOR.setdefault(region, [generation, 0])
+    if cur[0] != generation:
+        cur[0], cur[1] = generation, 0
+    base = at = cur[1]
+    lens = []
+
+    def place(n):   # the destination of the next read, once the reader knows its length
+        nonlocal at
+        out = _arena(region, at + n)[2][at:at + n]   # (growing keeps what is there: the file is the memory)
+        lens.append(int(n))
+        at += n
+        return out
+    for item in items:
+        path, read_id = resolve(item)
+        fast5_file(path).raw_signal_into(read_id, place)
+    cur[1] = at
+    arena = _arena(region, max(at, 1))
+    return arena[0], len(arena[2]), base, lens, time.perf_counter() - t0
+
+
 def spread_over_cpus(k: int):
     """Move this process to the k-th CPU of its affinity mask and release it again (loci.spread_over_cpus, without the package)."""
     if not hasattr(os, 'sched_setaffinity'):

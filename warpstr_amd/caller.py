@@ -580,6 +580,8 @@ class BatchQueue:
         self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
         self._turn = 0
         self._shared = None  # SharedStaging: buffers the reader processes fill (stage_shared)
+        self._arenas = {}    # reader arena path -> (mmap, page-locked int16 tensor, registered, address)
+        self._region_events = {}   # arena region -> event of the upload that last read it
         hip.set_pipelined(True)
 
     def _stage(self, dtype, count: int):
@@ -699,10 +701,81 @@ class BatchQueue:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
         return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
 
+    # ---- reader arenas (_readers.decode_arena): every reader process decodes its chunks into memory-backed files of its own ----
+    ARENA_REGIONS = 3   # a region is written again only after the batch that used it was uploaded
+
+    def region_wait(self, region: int):
+        """Block until the batch that last used `region` of the readers' arenas has been uploaded."""
+        ev = self._region_events.get(region)
+        if ev is not None:
+            ev.synchronize()
+
+    def _arena_tensor(self, path: str, samples: int):
+        """A reader's arena file as a page-locked tensor (mapped, and registered with the runtime, once per size)."""
+        import mmap
+        torch = self.torch
+        got = self._arenas.get(path)
+        if got is None or got[1].numel() < samples:
+            if got is not None:
+                self._unregister(got)
+            with open(path, 'r+b') as fh:
+                size = os.fstat(fh.fileno()).st_size
+                mm = mmap.mmap(fh.fileno(), size, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0))
+            view = np.frombuffer(mm, dtype=np.int16)
+            registered = False
+            try:
+                with torch.cuda.device(self.dev):
+                    registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
+            except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
+                pass
+            got = self._arenas[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
+        return got[1]
+
+    def _unregister(self, got):
+        if got[2]:
+            try:
+                self.torch.cuda.cudart().cudaHostUnregister(got[3])
+            except Exception:  # noqa: BLE001
+                pass
+
+    def submit_raw_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
+        """submit_raw() for a batch whose reads lie in the readers' arenas: parts = [(arena path, its size in samples, start of the
+        chunk, [length of every read]), ...] in batch order; one upload per chunk, straight from the page-locked arena."""
+        torch = self.torch
+        lens = np.array([n for _, _, _, ls in parts for n in ls], np.int64)
+        n = len(lens)
+        roff = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=roff[1:])
+        total_raw = int(roff[-1])
+        lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
+        with torch.cuda.stream(self.stream):
+            raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
+            at = 0
+            for path, cap, base, ls in parts:
+                m = int(sum(ls))
+                if m:
+                    raw_dev[at:at + m].copy_(self._arena_tensor(path, cap)[base:base + m], non_blocking=True)
+                at += m
+            ev = torch.cuda.Event()
+            ev.record()
+            self._region_events[region] = ev
+            signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
+        if n:
+            self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
+        return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+
     def close(self):
         if self._shared is not None:
             self._shared.close()
             self._shared = None
+        for ev in self._region_events.values():
+            ev.synchronize()
+        self._region_events.clear()
+        for got in self._arenas.values():
+            self._unregister(got)
+        self._arenas.clear()
 
     def submit_signals(self, signals: Sequence[np.ndarray], aut: np.ndarray):
         """Already normalised float64 segments (a `signal_loader`, or ReadSignal workloads)."""

@@ -271,13 +271,16 @@ class Fast5File:
 
     def raw_signal_into(self, read_id: Optional[str], out: Optional[np.ndarray]) -> np.ndarray:
         """raw_signal() decoded straight into `out` (a C-contiguous int16 array of exactly the read's length: a slice of a
-        staging buffer, main_wrapper_loci's reader processes); out=None allocates."""
+        staging buffer, main_wrapper_loci's reader processes); out=None allocates; a callable is asked for the destination once the
+        length is known (out(n) -> array of n samples)."""
         h = self.h
         d, n, vbz, chunk_len = self._open_signal(read_id)
         try:
             if out is None:
                 out = np.empty(n, dtype=np.int16)
-            elif out.dtype != np.int16 or out.ndim != 1 or out.size != n or not out.flags.c_contiguous or not out.flags.writeable:
+            elif callable(out):
+                out = out(n)
+            if out.dtype != np.int16 or out.ndim != 1 or out.size != n or not out.flags.c_contiguous or not out.flags.writeable:
                 raise Fast5Error(f'{self.path}: the destination must be a writable contiguous int16 array of {n} samples')
             if vbz is None:  # contiguous / gzip / ...: the library's own pipeline handles it
                 native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value

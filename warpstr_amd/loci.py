@@ -133,6 +133,7 @@ class HipEngine:
         self.queue = BatchQueue(self.hip, self.stream, (caller_config or CallerConfig()).spike_removal)
         self.submit_raw, self.submit_signals, self.collect = self.queue.submit_raw, self.queue.submit_signals, self.queue.collect
         self.stage_shared, self.submit_raw_shared, self.stage_local = self.queue.stage_shared, self.queue.submit_raw_shared, self.queue.stage_local
+        self.submit_raw_parts, self.region_wait, self.ARENA_REGIONS = self.queue.submit_raw_parts, self.queue.region_wait, self.queue.ARENA_REGIONS
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
@@ -250,7 +251,8 @@ def _units_of(sequence: str):
 # Opening a file, HDF5 and zstd take a few tenths of a millisecond per read, and libhdf5 is not thread-safe: the one part of the
 # host work that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and
 # import NumPy and the fast5 reader only -- warpstr_amd/_readers.py).
-from ._readers import decode_chunk as _decode_chunk, decode_into as _decode_into, probe_chunk as _probe_chunk, read_chunk as _read_chunk  # noqa: E402
+from ._readers import (decode_arena as _decode_arena, decode_chunk as _decode_chunk, decode_into as _decode_into,  # noqa: E402
+                       probe_chunk as _probe_chunk, read_chunk as _read_chunk)
 
 
 class _WorkerPool:
@@ -286,46 +288,58 @@ class _WorkerPool:
             raise self._error
         return self._procs
 
-    def map(self, func, items):
-        """[func(item) for item in items] on the workers (func: a module-level function of this module), in order.  An error
-        raised inside `func` on a worker is raised here (RuntimeError with the worker's traceback)."""
+    def _drive(self, proc):
+        """One thread per worker process: takes the next task of the pool's queue, sends it down the worker's pipe, waits for the
+        answer, resolves the task's future.  (The queue is shared: a worker that finishes early takes the next task, whichever
+        batch it belongs to.)"""
         import pickle
-        import threading
-        items = list(items)
-        results, errors = [None] * len(items), []
-        lock, nxt = threading.Lock(), [0]
-
-        def drive(proc):
+        while True:
+            task = self._tasks.get()
+            if task is None:
+                return
+            name, item, future = task
+            if not future.set_running_or_notify_cancel():
+                continue
             try:
-                while not errors:
-                    with lock:
-                        i = nxt[0]
-                        nxt[0] += 1
-                    if i >= len(items):
-                        return
-                    pickle.dump((func.__name__, items[i]), proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
-                    proc.stdin.flush()
-                    status, payload = pickle.load(proc.stdout)
-                    if status != 'ok':
-                        raise RuntimeError(f'{func.__name__} failed in a worker process:\n{payload}')
-                    results[i] = payload
-            except Exception as e:  # noqa: BLE001 -- raised in the caller's thread below
-                errors.append(e)
-        if self._drivers is None:   # (one thread per worker process, kept: a map is a few milliseconds of work)
-            from concurrent.futures import ThreadPoolExecutor
-            self._drivers = ThreadPoolExecutor(max_workers=len(self.procs))
-        for f in [self._drivers.submit(drive, p) for p in self.procs[:max(1, min(len(self.procs), len(items)))]]:
-            f.result()
-        if errors:
-            raise errors[0]
-        return results
+                pickle.dump((name, item), proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+                proc.stdin.flush()
+                status, payload = pickle.load(proc.stdout)
+                if status != 'ok':
+                    raise RuntimeError(f'{name} failed in a worker process:\n{payload}')
+                future.set_result(payload)
+            except BaseException as e:  # noqa: BLE001 -- raised where the future is waited for
+                future.set_exception(e)
+                if not isinstance(e, RuntimeError):   # the pipe is gone: this worker takes no more tasks
+                    return
+
+    def submit(self, func, item):
+        """func(item) on a worker (func: a function of warpstr_amd._readers); a concurrent.futures.Future.  An error raised inside
+        `func` on the worker is raised by .result() (RuntimeError with the worker's traceback)."""
+        import queue as _queue
+        import threading
+        from concurrent.futures import Future
+        if self._drivers is None:
+            self._tasks = _queue.Queue()
+            self._drivers = [threading.Thread(target=self._drive, args=(p,), name='warpstr-pipe', daemon=True) for p in self.procs]
+            for t in self._drivers:
+                t.start()
+        future = Future()
+        self._tasks.put((func.__name__, item, future))
+        return future
+
+    def map(self, func, items):
+        """[func(item) for item in items] on the workers, in order; the first error is raised."""
+        return [f.result() for f in [self.submit(func, item) for item in items]]
 
     def shutdown(self, **_):
         if self._starter is not None:
             self._starter.join()
             self._starter = None
         if self._drivers is not None:
-            self._drivers.shutdown(wait=True)
+            for _t in self._drivers:
+                self._tasks.put(None)
+            for t in self._drivers:
+                t.join(timeout=10)
             self._drivers = None
         for p in self._procs:
             try:
@@ -700,10 +714,47 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     yield b0, b1, data, shared_slot, (shared_roff if shared_slot is not None else None)
                     b += 1
 
+            def arena_batches():
+                """The same with reader processes that decode into arenas of their own (_readers.decode_arena): nothing is asked of
+                a read before it is decoded, so the chunks of the next batch are handed out while this batch's slowest chunk is
+                still running -- the readers never wait for each other, only a region for the upload of the batch that used it
+                three batches ago."""
+                import collections
+                regions = queue.ARENA_REGIONS
+                inflight = collections.deque()
+                b, k, ci = 0, 0, 1
+                while b < len(mine) or inflight:
+                    while b < len(mine) and len(inflight) < regions - 1:
+                        while cuts[ci] <= b:
+                            ci += 1
+                        b1 = min(cuts[ci], b + SHARED_BATCH_READS)
+                        t1 = time.perf_counter()
+                        region = k % regions
+                        queue.region_wait(region)
+                        items = [item_of(x) for x in range(b, b1)]
+                        step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                        futures = [pool.submit(_decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
+                        inflight.append((b, b1, region, futures))
+                        tm['read_s'] += time.perf_counter() - t1
+                        b, k = b1, k + 1
+                    b0, b1, region, futures = inflight.popleft()
+                    t1 = time.perf_counter()
+                    parts = []
+                    for f in futures:
+                        path, cap, base, lens_p, busy = f.result()
+                        parts.append((path, cap, base, lens_p))
+                        tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
+                        tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
+                    tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
+                    tm['read_s'] += time.perf_counter() - t1
+                    yield b0, b1, parts, ('arena', region), None
+
             def submit(b0, b1, data, shared_slot, shared_roff):
                 t1 = time.perf_counter()
                 sel = mine[b0:b1]
-                if shared_slot is not None:
+                if isinstance(shared_slot, tuple) and shared_slot[0] == 'arena':
+                    ticket = queue.submit_raw_parts(shared_slot[1], data, lo[sel], hi[sel], aut[sel])
+                elif shared_slot is not None:
                     ticket = queue.submit_raw_shared(shared_slot, shared_roff, lo[sel], hi[sel], aut[sel])
                 elif signal_loader is None:
                     ticket = queue.submit_raw(data, lo[sel], hi[sel], aut[sel])
@@ -723,9 +774,12 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 handover: '_queue.Queue' = _queue.Queue(maxsize=1)
                 stop = threading.Event()
 
+                arenas = hasattr(queue, 'submit_raw_parts') and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')
+                tm['reader_mode'] = 'arenas' if arenas else 'shared staging'
+
                 def produce():
                     try:
-                        for item in batches():
+                        for item in (arena_batches() if arenas else batches()):
                             while not stop.is_set():
                                 try:
                                     handover.put(item, timeout=0.2)
