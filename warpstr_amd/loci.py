@@ -501,7 +501,12 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     tm['loci_set_up'] = [int(i) for i in own]
     writes = rank == 0 or by_locus   # (by locus: a rank writes its own loci; by read: rank 0 writes everything)
     fast5_on_workers = signal_loader is None and raw_reader is read_raw_signal and raw_reads is None
-    pool = None
+    # (the reader processes start first: they come up -- half a second of imports -- while the loci are set up.  On the bench's
+    # sandboxed box sixteen interpreters starting slow whatever runs beside them: the set-up 0.3 -> 0.9 s for 3 000 loci; started
+    # beside the handle's creation instead they cost that 0.2 -> 1.5 s.)
+    pool = _reader_pool(threads, len(own)) if fast5_on_workers else None
+    pools.append(pool)
+    tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
     # ---- per locus: overview, flanks, automata, state_similarity.csv --------------------------------------------------------
     error = None
@@ -535,11 +540,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         for job in jobs:
             for line in job.warnings:
                 print(line)
-    # (the reader processes start now, not beside the set-up: sixteen interpreters coming up slowed the set-up threads by more
-    # than they gained -- 0.9 instead of 0.3 s for 3 000 loci --; they import while the handle is created and placed)
-    pool = _reader_pool(threads, len(own)) if fast5_on_workers else None
-    pools.append(pool)
-    tm['reader_processes'] = pool._max_workers if pool is not None else 0
     first = np.zeros(len(jobs) + 1, np.int64)
     np.cumsum([j.n for j in jobs], out=first[1:])
     n_total = int(first[-1])
