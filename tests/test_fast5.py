@@ -123,3 +123,109 @@ def test_upstream_known_answer_from_golden_lengths():
     assert sorted(set(lens)) == [40, 44]
     gt = call_alleles(lens, random_state=0)
     assert gt.heterozygous and sorted(gt.alleles, reverse=True) == [44, 40]
+
+
+@needs_hdf5
+def test_a_reader_process_decodes_into_its_arena_without_numpy(tmp_path):
+    """The arena path of a reader process (loci._WorkerPool -> _hostworker -> _readers.decode_arena -> _h5core.decode_to): the
+    samples in the arena equal Fast5File.raw_signal's, and the worker has not imported NumPy to get there (what makes sixteen of
+    them start in a tenth of the time); with the native decoder switched off the same call falls back to fast5.py's decoders."""
+    import mmap
+    from warpstr_amd import _readers, loci
+    path = os.path.join(REAL, 'batch_0.fast5')
+    with fast5.Fast5File(path) as f:
+        ids = f.read_ids()
+        want = [f.raw_signal(i) for i in ids]
+    items = [(str(tmp_path / 'absent.fast5'), path, i) for i in ids]
+
+    def loaded_modules(prefix):   # (only its name travels to the worker)
+        raise AssertionError
+    for no_native in ('', '1'):
+        old = os.environ.pop('WARPSTR_NO_HOST_NATIVE', None)
+        if no_native:
+            os.environ['WARPSTR_NO_HOST_NATIVE'] = '1'
+        try:
+            pool = loci._WorkerPool(1)
+            pool.procs
+        finally:
+            os.environ.pop('WARPSTR_NO_HOST_NATIVE', None)
+            if old is not None:
+                os.environ['WARPSTR_NO_HOST_NATIVE'] = old
+        try:
+            arena, cap, base, lens, _ = pool.submit(_readers.decode_arena, (0, 1, items[:6])).result()
+            arena2, cap2, base2, lens2, _ = pool.submit(_readers.decode_arena, (0, 1, items[6:])).result()
+            assert base == 0 and base2 == sum(lens) and arena2 == arena and lens + lens2 == [len(w) for w in want]
+            with open(arena, 'rb') as fh:
+                mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            got = np.frombuffer(mm, dtype=np.int16, count=sum(lens + lens2)).copy()
+            mm.close()
+            assert np.array_equal(got, np.concatenate(want))
+            numpy_loaded = pool.submit(loaded_modules, 'numpy').result()
+            assert bool(numpy_loaded) == bool(no_native) or fast5._vbz_native() is None, numpy_loaded
+        finally:
+            pool.shutdown()
+        assert not os.path.exists(arena)   # the worker removes its arenas when it goes
+
+
+def write_plain_single_read_fast5(path, sig, deflate=0, chunk=0):
+    """A single-read file as steps 1-2 of the reference leave them (Raw/Reads/Read_7/Signal), written through libhdf5 itself:
+    contiguous, or chunked with gzip."""
+    import ctypes as C
+    h, _ = fast5._libs()
+    hid = C.c_int64
+    for fn, res, args in [('H5Fcreate', hid, [C.c_char_p, C.c_uint, hid, hid]), ('H5Gcreate2', hid, [hid, C.c_char_p, hid, hid, hid]),
+                          ('H5Screate_simple', hid, [C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
+                          ('H5Dcreate2', hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), ('H5Pcreate', hid, [hid]),
+                          ('H5Pset_chunk', C.c_int, [hid, C.c_int, C.POINTER(C.c_uint64)]), ('H5Pset_deflate', C.c_int, [hid, C.c_uint]),
+                          ('H5Dwrite', C.c_int, [hid, hid, hid, hid, hid, C.c_void_p])]:
+        f = getattr(h, fn)
+        f.restype, f.argtypes = res, args
+    fid = h.H5Fcreate(path.encode(), 2, 0, 0)
+    assert fid >= 0
+    for g in ('Raw', 'Raw/Reads', 'Raw/Reads/Read_7'):
+        h.H5Gclose(h.H5Gcreate2(fid, g.encode(), 0, 0, 0))
+    sp = h.H5Screate_simple(1, (C.c_uint64 * 1)(len(sig)), None)
+    pl = h.H5Pcreate(hid.in_dll(h, 'H5P_CLS_DATASET_CREATE_ID_g').value)
+    if chunk:
+        assert h.H5Pset_chunk(pl, 1, (C.c_uint64 * 1)(chunk)) >= 0
+        if deflate:
+            assert h.H5Pset_deflate(pl, deflate) >= 0
+    i16 = hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
+    d = h.H5Dcreate2(fid, b'Raw/Reads/Read_7/Signal', i16, sp, 0, pl, 0)
+    assert d >= 0
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    assert h.H5Dwrite(d, i16, 0, 0, 0, sig.ctypes.data_as(C.c_void_p)) >= 0
+    h.H5Dclose(d)
+    h.H5Pclose(pl)
+    h.H5Sclose(sp)
+    h.H5Fclose(fid)
+
+
+@needs_hdf5
+def test_core_reader_equals_the_array_reader_on_every_storage(tmp_path):
+    """_h5core.Fast5Core.decode_to (an address) against Fast5File.raw_signal: the upstream VBZ multi-read file, and contiguous,
+    chunked and gzip single-read files (libhdf5's own pipeline)."""
+    from warpstr_amd import _h5core
+    rng = np.random.default_rng(5)
+    sig = rng.integers(-2000, 2000, size=5000).astype(np.int16)
+    cases = [(os.path.join(REAL, 'batch_0.fast5'), None)]
+    for k, kw in enumerate(({}, {'chunk': 777}, {'chunk': 1024, 'deflate': 4})):
+        p = str(tmp_path / f's{k}.fast5')
+        write_plain_single_read_fast5(p, sig, **kw)
+        cases.append((p, sig))
+    for path, expect in cases:
+        with fast5.Fast5File(path) as f, _h5core.Fast5Core(path) as c:
+            for rid in (f.read_ids() or [None]):
+                want = f.raw_signal(rid)
+                buf = np.full(len(want) + 8, 12345, dtype=np.int16)
+                seen = []
+                try:
+                    n = c.decode_to(rid, lambda n: (seen.append(n), buf.ctypes.data + 8)[1])
+                except _h5core.NeedsNumpy:
+                    assert fast5._vbz_native() is None
+                    continue
+                assert n == len(want) == seen[0] and np.array_equal(buf[4:4 + n], want)
+                assert (buf[:4] == 12345).all() and (buf[4 + n:] == 12345).all()
+                assert c.signal_length(rid) == n
+                if expect is not None:
+                    assert np.array_equal(want, expect)

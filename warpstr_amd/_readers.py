@@ -1,5 +1,6 @@
 """What a reader process of main_wrapper_loci runs (warpstr_amd/_hostworker.py; loci.py: _WorkerPool): the fast5 files of a batch.
-This module imports NumPy and the fast5 reader only -- a worker is up in the time the parent needs to parse its overviews.
+This module imports the NumPy-free core of the fast5 reader (_h5core) and nothing else until a function that hands arrays around is
+called: the arena path (decode_arena) never is one, so sixteen readers are up in ~80 ms instead of ~0.7 s.
 
 Items are (annotated single-read fast5 path, multi-read fall-back path or None, read name) triples, resolved the way
 LocusJob.raw_read / wrapper.get_raw_workload resolve them (src/caller/wrapper.py:44-54; prepare_caller_only.py keeps the reads
@@ -7,20 +8,25 @@ of a caller-only input in their multi-read files)."""
 import os
 from typing import Dict
 
-import numpy as np
-
 _OPEN: Dict[str, object] = {}    # per process: fast5 path -> open Fast5File (a batch reads many reads of few files)
 _MAPS: Dict[str, tuple] = {}     # per process: staging path -> (mmap, int16 view)
 MAX_OPEN = 64
 
 
-def fast5_file(path: str):
-    from .fast5 import Fast5File
+def fast5_file(path: str, arrays: bool = True):
+    """The open file of a path; arrays=False: its NumPy-free core is enough (lengths, decode_to an address)."""
     f = _OPEN.get(path)
+    if f is not None and arrays and not hasattr(f, 'raw_signal'):
+        _OPEN.pop(path).close()
+        f = None
     if f is None:
         if len(_OPEN) >= MAX_OPEN:
             _OPEN.pop(next(iter(_OPEN))).close()
-        f = _OPEN[path] = Fast5File(path)
+        if arrays:
+            from .fast5 import Fast5File as cls
+        else:
+            from ._h5core import Fast5Core as cls
+        f = _OPEN[path] = cls(path)
     return f
 
 
@@ -33,6 +39,7 @@ def resolve(item):
 
 def read_chunk(items):
     """The raw reads (int16) of the items, returned through the pipe."""
+    import numpy as np
     out = []
     for item in items:
         path, read_id = resolve(item)
@@ -48,11 +55,11 @@ def probe_chunk(items):
     out = []
     for item in items:
         path, read_id = resolve(item)
-        out.append(fast5_file(path).signal_length(read_id))
+        out.append(fast5_file(path, arrays=False).signal_length(read_id))
     return out
 
 
-def decode_into(view: np.ndarray, items, offsets, lengths) -> float:
+def decode_into(view, items, offsets, lengths) -> float:
     """Decode each read into view[offset : offset + length] (an int16 staging buffer); returns the seconds it took."""
     import time
     t0 = time.perf_counter()
@@ -67,6 +74,8 @@ def decode_chunk(args):
     NEXT batch whose lengths the parent does not know yet -- answered in the same round trip (the parent then lays that batch out
     without a round of its own).  Returns (seconds spent decoding, [their lengths])."""
     import mmap
+
+    import numpy as np
     staging, items, offsets, lengths = args[:4]
     got = _MAPS.get(staging)
     if got is None or len(got[1]) < max((o + n for o, n in zip(offsets, lengths)), default=0):
@@ -85,17 +94,18 @@ def decode_chunk(args):
 # regions in turn and lets a region be written again only after what it held has been uploaded) and answers with the lengths.
 # Nothing has to be known about a read before it is decoded, so the parent can hand out the next batch's chunks while this one's
 # slowest chunk is still running: the readers never wait for each other.  The parent maps the same files and page-locks them.
-_ARENAS: Dict[int, list] = {}     # region -> [path, mmap, int16 view]
+_ARENAS: Dict[int, list] = {}     # region -> [path, mmap, its first byte as a ctypes object (keeps the address valid), samples]
 ARENA_DIR = '/dev/shm'
 
 
 def _arena(region: int, samples: int):
-    """The region's file mapped with room for `samples` more... (grown by doubling; at least 8 M samples)."""
+    """The region's file mapped with room for `samples` samples (grown by half as much again; at least 8 M samples)."""
     import atexit
+    import ctypes
     import mmap
     import tempfile
     cur = _ARENAS.get(region)
-    if cur is not None and len(cur[2]) >= samples:
+    if cur is not None and cur[3] >= samples:
         return cur
     cap = max(samples + samples // 2, 8 << 20)
     if cur is None:
@@ -104,7 +114,9 @@ def _arena(region: int, samples: int):
             atexit.register(_drop_arenas)
     else:
         path = cur[0]
-        cur[2] = cur[1] = None   # (unmap before the file grows)
+        cur[2] = None            # (unmap before the file grows: the export first, then the mapping)
+        cur[1].close()
+        cur[1], cur[3] = None, 0
         fd = os.open(path, os.O_RDWR)
     try:
         st = os.statvfs(ARENA_DIR)
@@ -114,14 +126,19 @@ def _arena(region: int, samples: int):
         mm = mmap.mmap(fd, cap * 2)
     finally:
         os.close(fd)
-    _ARENAS[region] = [path, mm, np.frombuffer(mm, dtype=np.int16)]
+    _ARENAS[region] = [path, mm, ctypes.c_char.from_buffer(mm), cap]
     return _ARENAS[region]
 
 
+def _arena_address(region: int, samples: int) -> int:
+    import ctypes
+    return ctypes.addressof(_arena(region, samples)[2])
+
+
 def _drop_arenas():
-    for path, _, _ in list(_ARENAS.values()):
+    for rec in list(_ARENAS.values()):
         try:
-            os.unlink(path)
+            os.unlink(rec[0])
         except OSError:
             pass
     _ARENAS.clear()
@@ -133,8 +150,11 @@ _CURSOR: Dict[int, list] = {}    # region -> [generation, samples written in it]
 def decode_arena(args):
     """(region, generation, items) -> (arena path, its size in samples, where this chunk starts, [length of every read], seconds):
     the reads decoded back to back behind whatever this process has already written into the region in this generation (a batch may
-    give a reader several chunks); a new generation starts at the region's beginning."""
+    give a reader several chunks); a new generation starts at the region's beginning.  No NumPy on this path (_h5core.decode_to
+    writes at an address) unless a file holds chunks only fast5.py's decoders read."""
     import time
+
+    from ._h5core import NeedsNumpy
     region, generation, items = args
     t0 = time.perf_counter()
     cur = _CURSOR.setdefault(region, [generation, 0])
@@ -144,17 +164,23 @@ def decode_arena(args):
     lens = []
 
     def place(n):   # the destination of the next read, once the reader knows its length
-        nonlocal at
-        out = _arena(region, at + n)[2][at:at + n]   # (growing keeps what is there: the file is the memory)
+        addr = _arena_address(region, at + n) + 2 * at   # (growing keeps what is there: the file is the memory)
         lens.append(int(n))
-        at += n
-        return out
+        return addr
     for item in items:
         path, read_id = resolve(item)
-        fast5_file(path).raw_signal_into(read_id, place)
+        done = len(lens)
+        try:
+            fast5_file(path, arrays=False).decode_to(read_id, place)
+        except NeedsNumpy:
+            import ctypes
+            del lens[done:]
+            raw = fast5_file(path).raw_signal(read_id)
+            ctypes.memmove(place(len(raw)), raw.ctypes.data, 2 * len(raw))
+        at += lens[-1]
     cur[1] = at
     arena = _arena(region, max(at, 1))
-    return arena[0], len(arena[2]), base, lens, time.perf_counter() - t0
+    return arena[0], arena[3], base, lens, time.perf_counter() - t0
 
 
 def spread_over_cpus(k: int):

@@ -9,78 +9,14 @@ Layouts understood: single-read files written by the reference's steps 1-2 / `pr
 (`Raw/Reads/<first>/Signal`) and multi-read files (`read_<id>/Raw/Signal`).
 """
 import ctypes as C
-import ctypes.util
-import glob
 import os
 import struct
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 
-VBZ_FILTER = 32020
-_hid = C.c_int64
-_h5 = None
-_zstd = None
-
-
-class Fast5Error(RuntimeError):
-    pass
-
-
-def _find(name: str, extra: List[str]) -> Optional[str]:
-    cand = ctypes.util.find_library(name)
-    if cand:
-        return cand
-    for pat in extra:
-        hits = sorted(glob.glob(pat))
-        if hits:
-            return hits[0]
-    return None
-
-
-def _libs():
-    global _h5, _zstd
-    if _h5 is not None:
-        return _h5, _zstd
-    p = os.environ.get('WARPSTR_LIBHDF5') or _find('hdf5', ['/opt/conda/lib/libhdf5.so*', '/usr/lib/*/libhdf5*.so*'])
-    if not p:
-        raise Fast5Error('libhdf5 not found (set WARPSTR_LIBHDF5 to its path)')
-    h = C.CDLL(p)
-    z = _find('zstd', ['/opt/conda/lib/libzstd.so*', '/usr/lib/*/libzstd.so*'])
-    if not z:
-        raise Fast5Error('libzstd not found')
-    zs = C.CDLL(z)
-    h.H5open()
-    for fn, res, args in [
-            ('H5Fopen', _hid, [C.c_char_p, C.c_uint, _hid]), ('H5Fclose', C.c_int, [_hid]),
-            ('H5Gopen2', _hid, [_hid, C.c_char_p, _hid]), ('H5Gclose', C.c_int, [_hid]),
-            ('H5Gget_num_objs', C.c_int, [_hid, C.POINTER(C.c_uint64)]),
-            ('H5Gget_objname_by_idx', C.c_ssize_t, [_hid, C.c_uint64, C.c_char_p, C.c_size_t]),
-            ('H5Lexists', C.c_int, [_hid, C.c_char_p, _hid]),
-            ('H5Dopen2', _hid, [_hid, C.c_char_p, _hid]), ('H5Dclose', C.c_int, [_hid]),
-            ('H5Dget_space', _hid, [_hid]), ('H5Sclose', C.c_int, [_hid]),
-            ('H5Sget_simple_extent_npoints', C.c_int64, [_hid]),
-            ('H5Dget_create_plist', _hid, [_hid]), ('H5Pclose', C.c_int, [_hid]),
-            ('H5Pget_nfilters', C.c_int, [_hid]),
-            ('H5Pget_filter2', C.c_int, [_hid, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_size_t),
-                                         C.POINTER(C.c_uint), C.c_size_t, C.c_char_p, C.POINTER(C.c_uint)]),
-            ('H5Pget_layout', C.c_int, [_hid]),
-            ('H5Pget_chunk', C.c_int, [_hid, C.c_int, C.POINTER(C.c_uint64)]),
-            ('H5Dget_chunk_storage_size', C.c_int, [_hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-            ('H5Dread_chunk', C.c_int, [_hid, _hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]),
-            ('H5Dread', C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
-            ('H5Eset_auto2', C.c_int, [_hid, C.c_void_p, C.c_void_p])]:
-        f = getattr(h, fn)
-        f.restype, f.argtypes = res, args
-    h.H5Eset_auto2(0, None, None)  # errors are reported through return codes below, not printed by the library
-    zs.ZSTD_getFrameContentSize.restype = C.c_uint64
-    zs.ZSTD_getFrameContentSize.argtypes = [C.c_char_p, C.c_size_t]
-    zs.ZSTD_decompress.restype = C.c_size_t
-    zs.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
-    zs.ZSTD_isError.restype = C.c_uint
-    zs.ZSTD_isError.argtypes = [C.c_size_t]
-    _h5, _zstd = h, zs
-    return h, zs
+from ._h5core import VBZ_FILTER, Fast5Core, Fast5Error, NeedsNumpy  # noqa: F401
+from ._h5core import libs as _libs, vbz_native as _vbz_native  # noqa: F401 -- the names this module always had
 
 
 def streamvbyte_decode(buf: np.ndarray, n: int) -> np.ndarray:
@@ -162,196 +98,51 @@ def vbz_decode_chunk(chunk: bytes, int_size: int, zigzag: bool, version: int, zs
     return np.cumsum(delta, dtype=np.int64).astype({1: np.int8, 2: np.int16, 4: np.int32}[int_size])
 
 
-class Fast5File:
-    """Read-only view of the raw signals of a .fast5 file."""
-
-    def __init__(self, path: str):
-        self.h, _ = _libs()
-        self.path = path
-        self.fid = self.h.H5Fopen(path.encode(), 0, 0)
-        if self.fid < 0:
-            raise Fast5Error(f'cannot open {path} as HDF5')
-
-    def close(self):
-        if self.fid >= 0:
-            self.h.H5Fclose(self.fid)
-            self.fid = -1
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001 - interpreter shutdown
-            pass
-
-    def _children(self, group: str) -> List[str]:
-        g = self.h.H5Gopen2(self.fid, group.encode(), 0)
-        if g < 0:
-            raise Fast5Error(f'{self.path}: no group {group}')
-        n = C.c_uint64()
-        self.h.H5Gget_num_objs(g, C.byref(n))
-        buf = C.create_string_buffer(512)
-        out = []
-        for i in range(n.value):
-            self.h.H5Gget_objname_by_idx(g, i, buf, 512)
-            out.append(buf.value.decode())
-        self.h.H5Gclose(g)
-        return out
-
-    def _exists(self, path: str) -> bool:
-        cur = ''
-        for part in path.strip('/').split('/'):
-            cur = f'{cur}/{part}' if cur else part
-            if self.h.H5Lexists(self.fid, cur.encode(), 0) <= 0:
-                return False
-        return True
-
-    def read_ids(self) -> List[str]:
-        """Read ids of a multi-read file ([] for a single-read file)."""
-        return [k[5:] for k in self._children('/') if k.startswith('read_')]
-
-    def signal_path(self, read_id: Optional[str] = None) -> str:
-        if read_id is not None and self._exists(f'read_{read_id}/Raw/Signal'):
-            return f'read_{read_id}/Raw/Signal'
-        if self._exists('Raw/Reads'):  # single-read layout: first read, as fast5.py:50-52
-            names = self._children('Raw/Reads')
-            if names:
-                return f'Raw/Reads/{names[0]}/Signal'
-        if read_id is None:
-            ids = self.read_ids()
-            if len(ids) == 1:
-                return f'read_{ids[0]}/Raw/Signal'
-        raise Fast5Error(f'{self.path}: no raw signal' + (f' for read {read_id}' if read_id else ''))
-
-    def _open_signal(self, read_id: Optional[str]):
-        """(dataset id, samples, VBZ parameters [version, integer size, zig-zag, zstd level] or None, samples per chunk or 0)."""
-        h = self.h
-        # (a multi-read file's dataset is opened by its name straight away: probing the three levels of its path first costs as
-        # much again on a file whose metadata is cold -- and every read of a run is read exactly once)
-        d = h.H5Dopen2(self.fid, f'read_{read_id}/Raw/Signal'.encode(), 0) if read_id is not None else -1
-        if d < 0:
-            d = h.H5Dopen2(self.fid, self.signal_path(read_id).encode(), 0)
-        if d < 0:
-            raise Fast5Error(f'{self.path}: cannot open the signal dataset')
-        try:
-            sp = h.H5Dget_space(d)
-            n = h.H5Sget_simple_extent_npoints(sp)
-            h.H5Sclose(sp)
-            pl = h.H5Dget_create_plist(d)
-            vbz = None
-            for i in range(max(h.H5Pget_nfilters(pl), 0)):
-                flags, ne, cd, fc = C.c_uint(), C.c_size_t(8), (C.c_uint * 8)(), C.c_uint()
-                name = C.create_string_buffer(64)
-                if h.H5Pget_filter2(pl, i, C.byref(flags), C.byref(ne), cd, 64, name, C.byref(fc)) == VBZ_FILTER:
-                    vbz = list(cd)[:ne.value] + [0] * 4
-            chunk_len = (C.c_uint64 * 1)(0)
-            chunked = h.H5Pget_layout(pl) == 2 and h.H5Pget_chunk(pl, 1, chunk_len) == 1
-            h.H5Pclose(pl)
-            if vbz is not None and not chunked:
-                raise Fast5Error(f'{self.path}: VBZ filter on a dataset that is not chunked')
-            return d, int(n), vbz, int(chunk_len[0]) if chunked else 0
-        except Exception:
-            h.H5Dclose(d)
-            raise
-
-    def signal_length(self, read_id: Optional[str] = None) -> int:
-        """Samples of a read's raw signal (metadata only: nothing is decoded)."""
-        d, n, _, _ = self._open_signal(read_id)
-        self.h.H5Dclose(d)
-        return n
+class Fast5File(Fast5Core):
+    """Read-only view of the raw signals of a .fast5 file (the container and the VBZ fast path: _h5core.Fast5Core)."""
 
     def raw_signal(self, read_id: Optional[str] = None) -> np.ndarray:
         """The DAC samples of a read (int16), whatever the dataset's storage filter."""
         return self.raw_signal_into(read_id, None)
 
-    def raw_signal_into(self, read_id: Optional[str], out: Optional[np.ndarray]) -> np.ndarray:
+    def raw_signal_into(self, read_id: Optional[str], out) -> np.ndarray:
         """raw_signal() decoded straight into `out` (a C-contiguous int16 array of exactly the read's length: a slice of a
         staging buffer, main_wrapper_loci's reader processes); out=None allocates; a callable is asked for the destination once the
         length is known (out(n) -> array of n samples)."""
-        h = self.h
+        dest = []
+
+        def place(n):
+            o = np.empty(n, dtype=np.int16) if out is None else (out(n) if callable(out) else out)
+            if o.dtype != np.int16 or o.ndim != 1 or o.size != n or not o.flags.c_contiguous or not o.flags.writeable:
+                raise Fast5Error(f'{self.path}: the destination must be a writable contiguous int16 array of {n} samples')
+            dest.append(o)
+            return o.ctypes.data
+        try:
+            self.decode_to(read_id, place)
+            return dest[0]
+        except NeedsNumpy:   # another integer size, a chunk longer than its share of the dataset, _host_loci.so not built
+            pass
         d, n, vbz, chunk_len = self._open_signal(read_id)
         try:
-            if out is None:
-                out = np.empty(n, dtype=np.int16)
-            elif callable(out):
-                out = out(n)
-            if out.dtype != np.int16 or out.ndim != 1 or out.size != n or not out.flags.c_contiguous or not out.flags.writeable:
-                raise Fast5Error(f'{self.path}: the destination must be a writable contiguous int16 array of {n} samples')
-            if vbz is None:  # contiguous / gzip / ...: the library's own pipeline handles it
-                native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
-                if h.H5Dread(d, native_i16, 0, 0, 0, out.ctypes.data_as(C.c_void_p)) < 0:
-                    raise Fast5Error(f'{self.path}: H5Dread failed')
-                return out
+            if not dest:
+                place(n)
+            o = dest[0]
             version, int_size, zigzag, level = vbz[0], vbz[1], vbz[2], vbz[3]
-            native = _vbz_native() if (version == 0 and int_size == 2) else None
             done = 0
-            for start in range(0, n, chunk_len):
-                off, size, mask = (C.c_uint64 * 1)(start), C.c_uint64(), C.c_uint32()
-                if h.H5Dget_chunk_storage_size(d, off, C.byref(size)) < 0 or size.value == 0:
-                    raise Fast5Error(f'{self.path}: missing chunk at sample {start}')
-                buf = _scratch(size.value)
-                if h.H5Dread_chunk(d, 0, off, C.byref(mask), buf) < 0:
-                    raise Fast5Error(f'{self.path}: H5Dread_chunk failed at sample {start}')
-                want = min(chunk_len, n - start)
-                if mask.value & 1:  # the filter was skipped when this chunk was written: plain samples
-                    part = np.frombuffer(buf, dtype=np.int16, count=size.value // 2)[:want]
-                    out[start:start + len(part)] = part
-                    got = len(part)
-                elif native is not None and want == min(chunk_len, struct.unpack_from('<I', buf, 0)[0] // 2):
-                    fn, f_size, f_dec = native
-                    got = fn(buf, size.value, int(bool(zigzag)), int(level), f_size, f_dec, out.ctypes.data + 2 * start, want)
-                    if got < 0:
-                        raise Fast5Error(f'{self.path}: ' + _VBZ_ERRORS.get(int(got), f'VBZ decoder error {got}'))
+            for start, want, buf, size, plain in self._chunks(d, n, chunk_len):
+                if plain:  # the filter was skipped when this chunk was written: plain samples
+                    part = np.frombuffer(buf, dtype=np.int16, count=size // 2)[:want]
                 else:
-                    part = vbz_decode_chunk(bytes(buf[:size.value]), int_size, bool(zigzag), version, level)[:want]
+                    part = vbz_decode_chunk(bytes(buf[:size]), int_size, bool(zigzag), version, level)[:want]
                     if part.dtype != np.int16:
                         raise Fast5Error(f'{self.path}: decoded samples of {part.dtype}, the dataset holds int16')
-                    out[start:start + len(part)] = part
-                    got = len(part)
-                done += int(got)
+                o[start:start + len(part)] = part
+                done += len(part)
             if done != n:
                 raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')
-            return out
+            return o
         finally:
-            h.H5Dclose(d)
-
-
-_SCRATCH = None
-_VBZ_NATIVE = False
-_VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
-               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
-               -6: 'a VBZ chunk holds more samples than the dataset says'}
-
-
-def _scratch(nbytes: int):
-    """A buffer of at least nbytes that lives with the process (a chunk's compressed bytes: no allocation per read)."""
-    global _SCRATCH
-    if _SCRATCH is None or len(_SCRATCH) < nbytes:
-        _SCRATCH = (C.c_char * max(nbytes + nbytes // 2, 1 << 20))()
-    return _SCRATCH
-
-
-def _vbz_native():
-    """(wsh_vbz_decode_i16 of warpstr_amd/_host_loci.so, ZSTD_getFrameContentSize, ZSTD_decompress as addresses): one call without
-    the GIL per chunk -- zstd frame -> StreamVByte -> zig-zag -> running sum -> the destination; or None (library not built: the
-    decoders above do the same arithmetic)."""
-    global _VBZ_NATIVE
-    if _VBZ_NATIVE is False:
-        _VBZ_NATIVE = None
-        from . import _hostlib
-        lib = _hostlib.lib()
-        if lib is not None and hasattr(lib, 'wsh_vbz_decode_i16'):
-            _, zs = _libs()
-            fn = lib.wsh_vbz_decode_i16
-            fn.restype = C.c_int64
-            fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
-            _VBZ_NATIVE = (fn, C.cast(zs.ZSTD_getFrameContentSize, C.c_void_p).value, C.cast(zs.ZSTD_decompress, C.c_void_p).value)
-    return _VBZ_NATIVE
+            self.h.H5Dclose(d)
 
 
 def read_raw_signal(path: str, read_id: Optional[str] = None) -> np.ndarray:

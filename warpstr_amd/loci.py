@@ -250,7 +250,7 @@ def _units_of(sequence: str):
 # ---- fast5 files on worker processes -----------------------------------------------------------------------------------------
 # Opening a file, HDF5 and zstd take a few tenths of a millisecond per read, and libhdf5 is not thread-safe: the one part of the
 # host work that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and
-# import NumPy and the fast5 reader only -- warpstr_amd/_readers.py).
+# import the NumPy-free core of the fast5 reader only -- warpstr_amd/_readers.py, _h5core.py).
 from ._readers import (decode_arena as _decode_arena, decode_chunk as _decode_chunk, decode_into as _decode_into,  # noqa: E402
                        probe_chunk as _probe_chunk, read_chunk as _read_chunk)
 
@@ -270,6 +270,11 @@ class _WorkerPool:
 
         def start():   # (on a thread of its own: forking a process with the GPU runtime mapped sixteen times takes a good part of a
             try:       # second, in which the caller parses its overviews)
+                try:   # (the libraries looked up once, here, instead of by every worker)
+                    from ._h5core import lib_paths
+                    env['WARPSTR_LIBHDF5'], env['WARPSTR_LIBZSTD'] = lib_paths()
+                except RuntimeError:
+                    pass   # (a worker says which library is missing when it is asked for its first read)
                 for k in range(n):
                     self._procs.append(subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE,
                                                         stdout=subprocess.PIPE, env=env))
