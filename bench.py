@@ -619,6 +619,8 @@ def from_fast5_leg(n_copies, local):
             lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results']) for l in loci]
             out[tag] = {'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
                         'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
+                        'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
+                        'inside_submit_upload': tm.get('submit_parts_s'),
                         'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
                                      'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
                                      'decode_summed_over_reader_processes': tm.get('decode_worker_s'),

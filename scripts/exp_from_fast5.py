@@ -12,4 +12,18 @@ if os.environ.get('WSX_SHARED_MB'):   # experiment: raw bytes / reads of a batch
     loci.SHARED_BATCH_BYTES = int(os.environ['WSX_SHARED_MB']) << 20
     loci.SHARED_BATCH_READS = int(os.environ.get('WSX_SHARED_READS', loci.SHARED_BATCH_READS))
 
+if os.environ.get('WSX_NO_GC'):   # experiment: are the phases that sometimes take 0.4 s longer full garbage collections?
+    import gc
+    gc.disable()
+if os.environ.get('WSX_GC_DEBUG'):
+    import gc
+    import time
+    _t = [0.0]
+
+    def _cb(phase, info):
+        if phase == 'start':
+            _t[0] = time.perf_counter()
+        elif info['generation'] == 2:
+            print(f'gen-2 collection: {(time.perf_counter() - _t[0]) * 1e3:.0f} ms', file=sys.stderr, flush=True)
+    gc.callbacks.append(_cb)
 print(json.dumps(bench.from_fast5_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 1500, 0), indent=1))

@@ -534,3 +534,42 @@ def test_reader_processes_that_cannot_start_are_reported_and_what_a_worker_raise
     c = _fast5_loci(str(tmp_path / 'c'), src, ids, missing=40)
     with pytest.raises(RuntimeError, match='failed in a worker process'):
         main_wrapper_loci(c, 3, _engine=SharedFakeEngine, quiet=True)
+
+
+def test_garbage_collector_paused_during_a_long_run_and_back_afterwards(tmp_path, monkeypatch):
+    """main_wrapper_loci pauses the cyclic collector for a run of GC_PAUSE_FROM_LOCI loci or more -- and only then, only if it was
+    on, and it is on again after the call, also when the call raises."""
+    import gc
+    seen = []
+
+    class Probe(FakeEngine):
+        def __init__(self, *a, **k):
+            seen.append(gc.isenabled())
+            super().__init__(*a, **k)
+
+    class Failing(FakeEngine):
+        def __init__(self, *a, **k):
+            seen.append(gc.isenabled())
+            raise RuntimeError('no handle')
+    from warpstr_amd import loci as loci_mod
+    monkeypatch.setattr(loci_mod, 'GC_PAUSE_FROM_LOCI', 3)
+    loci, sig = _make_loci(str(tmp_path / 'a'))
+    kw = dict(signal_loader=_loader(sig), quiet=True)
+    assert gc.isenabled()
+    loci_mod.main_wrapper_loci(loci, 1, **kw, _engine=Probe)
+    assert seen == [False] and gc.isenabled()
+    with pytest.raises(RuntimeError, match='no handle'):
+        loci_mod.main_wrapper_loci(loci, 1, **kw, _engine=Failing)
+    assert seen == [False, False] and gc.isenabled()
+    loci_mod.main_wrapper_loci(loci[:2], 1, **kw, _engine=Probe)   # a short run: left alone
+    assert seen[-1] is True
+    monkeypatch.setenv('WARPSTR_KEEP_GC', '1')
+    loci_mod.main_wrapper_loci(loci, 1, **kw, _engine=Probe)
+    assert seen[-1] is True
+    monkeypatch.delenv('WARPSTR_KEEP_GC')
+    gc.disable()
+    try:
+        loci_mod.main_wrapper_loci(loci, 1, **kw, _engine=Probe)
+        assert not gc.isenabled()   # it was off before the call: it stays off
+    finally:
+        gc.enable()

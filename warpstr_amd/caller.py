@@ -12,6 +12,7 @@ turns state paths into base strings (WarpSTR._get_sequence, src/caller/caller.py
 import collections.abc
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -198,6 +199,8 @@ class HipCaller:
                  reverse_flags: Optional[Sequence[bool]] = None):
         """reverse_flags[i]: automaton i belongs to the reverse strand (its called sequences are reverse-complemented);
         default: odd positions (template, reverse, template, reverse, ...)."""
+        import time
+        t_init = time.perf_counter()
         self.lib = _lib.load()
         self.device = int(device)
         if self.lib.wsx_device_count() <= 0:
@@ -230,8 +233,10 @@ class HipCaller:
                              1 if self.rescaler_config.reps_as_one else 0)
         self.handle = C.c_void_p()
         self._seq_landing = None
+        t_call = time.perf_counter()
         _lib.check(self.lib.wsx_caller_create(C.byref(self.handle), device, C.byref(arr), len(self.automata),
                                               C.byref(prm), C.c_void_p(stream)), 'wsx_caller_create')
+        self.init_s = {'host_tables': t_call - t_init, 'wsx_caller_create': time.perf_counter() - t_call}
         if workspace_limit:
             _lib.check(self.lib.wsx_caller_set_workspace_limit(self.handle, workspace_limit),
                        'wsx_caller_set_workspace_limit')
@@ -243,7 +248,7 @@ class HipCaller:
         """Where wsx_caller_create spent its time (seconds): a handle for all loci of a run places thousands of automata."""
         v = (C.c_double * 5)()
         _lib.check(self.lib.wsx_caller_create_times(self.handle, v, 5), 'wsx_caller_create_times')
-        return dict(zip(('validate', 'placement', 'pack', 'upload', 'streams'), [float(x) for x in v]))
+        return dict(zip(('validate', 'placement', 'pack', 'upload', 'streams'), [float(x) for x in v]), **{f'host_{k}': v for k, v in self.init_s.items()})
 
     def set_tuning(self, knob: str, value: int):
         """wsx_caller_set_tuning: how the work is spread over launches, never what is computed (knobs: _lib.TUNING)."""
@@ -581,6 +586,8 @@ class BatchQueue:
         self._turn = 0
         self._shared = None  # SharedStaging: buffers the reader processes fill (stage_shared)
         self._arenas = {}    # reader arena path -> (mmap, page-locked int16 tensor, registered, address)
+        self._arena_lock = threading.Lock()
+        self.parts_s = {}    # where submit_raw_parts spent its time (seconds, summed over the batches)
         self._region_events = {}   # arena region -> event of the upload that last read it
         hip.set_pipelined(True)
 
@@ -711,25 +718,35 @@ class BatchQueue:
             ev.synchronize()
 
     def _arena_tensor(self, path: str, samples: int):
-        """A reader's arena file as a page-locked tensor (mapped, and registered with the runtime, once per size)."""
+        """A reader's arena file as a page-locked tensor (mapped, and registered with the runtime, once per size).  Called by the
+        thread that waits for the readers as soon as a chunk's answer names the arena (arena_ready), so that page-locking --
+        48 arenas of 16 MB: ~0.1 s, scripts/exp_arena_register.py -- is not on the submitting thread's path; hence the lock."""
         import mmap
         torch = self.torch
         got = self._arenas.get(path)
-        if got is None or got[1].numel() < samples:
-            if got is not None:
-                self._unregister(got)
-            with open(path, 'r+b') as fh:
-                size = os.fstat(fh.fileno()).st_size
-                mm = mmap.mmap(fh.fileno(), size, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0))
-            view = np.frombuffer(mm, dtype=np.int16)
-            registered = False
-            try:
-                with torch.cuda.device(self.dev):
-                    registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
-            except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
-                pass
-            got = self._arenas[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
-        return got[1]
+        if got is not None and got[1].numel() >= samples:
+            return got[1]   # (without the lock: the other thread may hold it for the milliseconds page-locking ANOTHER arena takes)
+        with self._arena_lock:
+            got = self._arenas.get(path)
+            if got is None or got[1].numel() < samples:
+                if got is not None:
+                    self._unregister(got)
+                with open(path, 'r+b') as fh:
+                    size = os.fstat(fh.fileno()).st_size
+                    mm = mmap.mmap(fh.fileno(), size)   # (not pre-faulted: page-locking maps the pages, and faster)
+                view = np.frombuffer(mm, dtype=np.int16)
+                registered = False
+                try:
+                    with torch.cuda.device(self.dev):
+                        registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
+                except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
+                    pass
+                got = self._arenas[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
+            return got[1]
+
+    def arena_ready(self, path: str, samples: int):
+        """Map and page-lock a reader's arena ahead of the submit_raw_parts() that uploads from it (any thread)."""
+        self._arena_tensor(path, samples)
 
     def _unregister(self, got):
         if got[2]:
@@ -741,7 +758,10 @@ class BatchQueue:
     def submit_raw_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
         """submit_raw() for a batch whose reads lie in the readers' arenas: parts = [(arena path, its size in samples, start of the
         chunk, [length of every read]), ...] in batch order; one upload per chunk, straight from the page-locked arena."""
+        import time
         torch = self.torch
+        clock, acc = time.perf_counter, self.parts_s
+        t0 = clock()
         lens = np.array([n for _, _, _, ls in parts for n in ls], np.int64)
         n = len(lens)
         roff = np.zeros(n + 1, np.int64)
@@ -750,8 +770,10 @@ class BatchQueue:
         lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
         offsets = np.zeros(n + 1, np.int64)
         np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
+        t1 = clock()
         with torch.cuda.stream(self.stream):
             raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
+            t2 = clock()
             at = 0
             for path, cap, base, ls in parts:
                 m = int(sum(ls))
@@ -761,10 +783,16 @@ class BatchQueue:
             ev = torch.cuda.Event()
             ev.record()
             self._region_events[region] = ev
+            t3 = clock()
             signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
+        t4 = clock()
         if n:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
-        return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+        t5 = clock()
+        ticket = self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+        for key, dt in (('lengths', t1 - t0), ('allocate', t2 - t1 + t4 - t3), ('copies', t3 - t2), ('prepare', t5 - t4), ('launch', clock() - t5)):
+            acc[key] = acc.get(key, 0.0) + dt
+        return ticket
 
     def close(self):
         if self._shared is not None:

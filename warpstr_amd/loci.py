@@ -134,10 +134,11 @@ class HipEngine:
         self.submit_raw, self.submit_signals, self.collect = self.queue.submit_raw, self.queue.submit_signals, self.queue.collect
         self.stage_shared, self.submit_raw_shared, self.stage_local = self.queue.stage_shared, self.queue.submit_raw_shared, self.queue.stage_local
         self.submit_raw_parts, self.region_wait, self.ARENA_REGIONS = self.queue.submit_raw_parts, self.queue.region_wait, self.queue.ARENA_REGIONS
+        self.arena_ready = self.queue.arena_ready
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
-                'handle_create_s': self.hip.create_times(),
+                'handle_create_s': self.hip.create_times(), 'submit_parts_s': dict(self.queue.parts_s),
                 'kernels': sorted({self.hip.kernel_name(a) for a in range(min(len(self.hip.automata), 256))})}
 
     def close(self):
@@ -429,6 +430,9 @@ def partition_loci(loci: Sequence, world: int) -> List[np.ndarray]:
     return wdist.shard_reads(cost, world, per_sample)
 
 
+GC_PAUSE_FROM_LOCI = 64
+
+
 def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
                       rescaler_config: Optional[RescalerConfig] = None,
                       signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
@@ -449,9 +453,18 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     one thread and 64 loci or more the fast5 files are read on as many worker processes.
     shard=True: the run is one torch.distributed job.  partition: 'loci' = every rank takes whole loci, 'reads' = every rank
     takes its share of every locus's reads, 'auto' = 'loci' from LOCI_PER_RANK_FOR_LOCUS_PARTITION loci per rank on.
-    timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure."""
+    timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure.
+
+    Python's cyclic garbage collector is paused for the duration of a run of GC_PAUSE_FROM_LOCI loci or more (and switched on again
+    when the call returns or raises; WARPSTR_KEEP_GC=1 leaves it alone): the run builds a few objects per read and none of them
+    in a cycle, but every ~70 000 of them trigger a full collection that walks the whole heap of the process -- torch, pandas and
+    NumPy's modules included -- for 0.1-0.6 s each: 0.9 s of a 2.2 s run of 6 000 loci (scripts/exp_from_fast5.py, WSX_GC_DEBUG)."""
+    import gc
     pools: list = []
     executor = None
+    paused = len(loci) >= GC_PAUSE_FROM_LOCI and gc.isenabled() and not os.environ.get('WARPSTR_KEEP_GC')
+    if paused:
+        gc.disable()
     if threads and int(threads) > 1 and len(loci) > 1:
         from concurrent.futures import ThreadPoolExecutor
         executor = ThreadPoolExecutor(max_workers=min(int(threads), 64), initializer=spread_over_cpus)
@@ -461,6 +474,8 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
                                   device=device, shard=shard, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
                                   batch_raw_bytes=batch_raw_bytes, timings=timings, quiet=quiet, native=native, _engine=_engine)
     finally:  # the threads and the reader processes end with the call, however it ends
+        if paused:
+            gc.enable()
         from . import _readers
         while _readers._OPEN:
             _readers._OPEN.popitem()[1].close()
@@ -745,8 +760,11 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     b0, b1, region, futures = inflight.popleft()
                     t1 = time.perf_counter()
                     parts = []
+                    ready = getattr(queue, 'arena_ready', None)
                     for f in futures:
                         path, cap, base, lens_p, busy = f.result()
+                        if ready is not None:
+                            ready(path, cap)   # (page-locked here, on the reader thread, while the other chunks are still decoding)
                         parts.append((path, cap, base, lens_p))
                         tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
