@@ -591,9 +591,9 @@ def from_fast5_leg(n_copies, local):
             base = None
     root = tempfile.mkdtemp(prefix='wsx_from_fast5_', dir=base)
     try:
-        def make(tag):
+        def make(tag, n=n_copies):
             loci = []
-            for i in range(n_copies):
+            for i in range(n):
                 loc = os.path.join(root, tag, f'copy{i:04d}')
                 f5 = os.path.join(root, 'fast5', f'batch_{i:04d}.fast5')
                 if not os.path.exists(f5):
@@ -604,20 +604,25 @@ def from_fast5_leg(n_copies, local):
                               'r_end_raw': ex['r_end_raw'], 'run_id': 'run_0', 'saved': 1}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
                 loci.append(LocusPath(loc, fj['sequence'], int(fj['flank_length']), f'copy{i:04d}'))
             return loci
-        n_reads = n_copies * len(ex)
-        warm = make('warm')[:8]
+        warm = make('warm', 8)
         main_wrapper_loci(warm, 1, device=local, quiet=True)
         out = {'workload': f'{n_copies} copies of the upstream test fast5 (10 real VBZ reads each, {size} bytes), one (AAAT) flank-110 locus per copy, '
                            f'caller-only layout, files under {base or "the default temporary directory"} (page cache) -> output files',
-               'reads': n_reads}
-        for tag, threads in (('one_process', 1), ('sixteen_reader_processes', min(16, os.cpu_count() or 1))):
-            loci = make(tag)
+               'reads': n_copies * len(ex)}
+        many = min(16, os.cpu_count() or 1)
+        legs = [('one_process', 1, n_copies), ('sixteen_reader_processes', many, n_copies)]
+        st = os.statvfs(root)
+        if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
+            legs.append(('sixteen_reader_processes_4x_the_copies', many, 4 * n_copies))   # batch's tail -- weigh less on a longer run)
+        for tag, threads, n in legs:
+            loci = make(tag, n)
+            n_reads = n * len(ex)
             tm = {}
             tables = main_wrapper_loci(loci, threads, device=local, quiet=True, timings=tm)
             with contextlib.redirect_stdout(io.StringIO()):
                 calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
-            lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results']) for l in loci]
-            out[tag] = {'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
+            lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results']) for l in loci[::max(1, n // n_copies)]]
+            out[tag] = {'reads': n_reads, 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
                         'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
                         'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
                         'inside_submit_upload': tm.get('submit_parts_s'),
