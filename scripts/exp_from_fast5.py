@@ -12,6 +12,26 @@ if os.environ.get('WSX_SHARED_MB'):   # experiment: raw bytes / reads of a batch
     loci.SHARED_BATCH_BYTES = int(os.environ['WSX_SHARED_MB']) << 20
     loci.SHARED_BATCH_READS = int(os.environ.get('WSX_SHARED_READS', loci.SHARED_BATCH_READS))
 
+if os.environ.get('WSX_PROFILE'):   # experiment: where the calling thread of the 16-reader legs spends its time (cProfile, to stderr)
+    import cProfile
+    import io
+    import pstats
+    from warpstr_amd import wrapper
+    _orig = wrapper.main_wrapper_loci
+
+    def _profiled(loci_, threads, **kw):
+        if threads <= 1 or len(loci_) < 64:
+            return _orig(loci_, threads, **kw)
+        pr = cProfile.Profile()
+        pr.enable()
+        try:
+            return _orig(loci_, threads, **kw)
+        finally:
+            pr.disable()
+            out = io.StringIO()
+            pstats.Stats(pr, stream=out).sort_stats('tottime').print_stats(28)
+            print(out.getvalue(), file=sys.stderr, flush=True)
+    wrapper.main_wrapper_loci = _profiled
 if os.environ.get('WSX_NO_GC'):   # experiment: are the phases that sometimes take 0.4 s longer full garbage collections?
     import gc
     gc.disable()

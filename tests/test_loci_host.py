@@ -573,3 +573,49 @@ def test_garbage_collector_paused_during_a_long_run_and_back_afterwards(tmp_path
         assert not gc.isenabled()   # it was off before the call: it stays off
     finally:
         gc.enable()
+
+
+def test_readers_decode_while_the_handle_is_created_and_stop_if_it_cannot_be(tmp_path):
+    """With arenas the reader thread is started BEFORE the engine: its constructor already finds the thread running (and, given
+    time, the first chunks decoded); an engine that cannot be created ends the run with its own error, the thread and the reader
+    processes gone; a worker's error is still raised (a fast5 file that is not there)."""
+    import threading
+    import time
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    if not os.path.isdir('/dev/shm'):
+        pytest.skip('no /dev/shm')
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    seen = {}
+
+    class Slow(ArenaFakeEngine):
+        def __init__(self, *a):
+            seen['reader_running'] = any(t.name == 'warpstr-reader' for t in threading.enumerate())
+            time.sleep(0.5)
+            seen['arena_files'] = len([f for f in os.listdir('/dev/shm') if f.startswith('warpstr_arena_')])
+            super().__init__(*a)
+
+    class Broken(ArenaFakeEngine):
+        def __init__(self, *a):
+            raise RuntimeError('no device')
+    a, b = _fast5_loci(str(tmp_path / 'a'), src, ids), _fast5_loci(str(tmp_path / 'b'), src, ids)
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    tm = {}
+    main_wrapper_loci(a, 3, _engine=Slow, quiet=True, timings=tm)
+    assert seen['reader_running'] and seen['arena_files'] >= 1 and tm['reader_mode'] == 'arenas' and tm['arena_batches'] >= 1
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    c = _fast5_loci(str(tmp_path / 'c'), src, ids)
+    with pytest.raises(RuntimeError, match='no device'):
+        main_wrapper_loci(c, 3, _engine=Broken, quiet=True)
+    assert not any(t.name == 'warpstr-reader' for t in threading.enumerate())
+    d = _fast5_loci(str(tmp_path / 'd'), src, ids, missing=40)
+    with pytest.raises(RuntimeError, match='failed in a worker process'):
+        main_wrapper_loci(d, 3, _engine=ArenaFakeEngine, quiet=True)
+    assert not any(t.name == 'warpstr-reader' for t in threading.enumerate())

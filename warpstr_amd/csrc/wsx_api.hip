@@ -648,11 +648,13 @@ try {
                     }
         }
     };
+    // Where a state lives depends on the GRAPH of its automaton alone (the predecessor lists), not on the levels: the loci of a
+    // panel repeat a few dozen patterns, and the flanks of a locus change its levels far more often than its graph.  Automata
+    // with the same graph are placed once (found by a hash of the lists, confirmed by comparing them) -- and what follows from
+    // the graph alone (the lists themselves, positions, predecessor words, LDS addresses) is in the device blob once.
+    std::vector<int> rep((size_t)n_automata);
     {
-        // Where a state lives depends on the GRAPH of its automaton alone (the predecessor lists), not on the levels: the loci of a
-        // panel repeat a few dozen patterns, and the flanks of a locus change its levels far more often than its graph.  Automata
-        // with the same graph are placed once (found by a hash of the lists, confirmed by comparing them).
-        std::vector<int> rep((size_t)n_automata), todo;
+        std::vector<int> todo;
         {
             std::unordered_map<uint64_t, std::vector<int>> seen;
             for (int a = 0; a < n_automata; a++) {
@@ -699,15 +701,15 @@ try {
             for (auto &e : errs)
                 if (e) std::rethrow_exception(e);
         }
-        for (int a = 0; a < n_automata; a++)
-            if (rep[a] != a) placed[a] = placed[rep[a]];
     }
     c->create_s[1] = since(t_phase);
     t_phase = now();
+    c->host_aut.reserve((size_t)n_automata);
     for (int a = 0; a < n_automata; a++) {
         const wsx_automaton &A = automata[a];
         const int S = A.n_states, E = A.pred_ptr[S];
-        Placed &P = placed[a];
+        const bool first = rep[a] == a;   // (a representative comes before the automata it stands for)
+        const Placed &P = placed[rep[a]];
         Variant v = P.v;
         const int mf = P.mf;
         DevAutomaton D{};
@@ -719,22 +721,30 @@ try {
         D.reverse = A.reverse ? 1 : 0;
         D.value = (const double *)put(A.value, (size_t)S * 8);
         D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
-        D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
-        int32_t dummy = 0;
-        D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
+        if (!first) {
+            const DevAutomaton &R = c->host_aut[(size_t)rep[a]];
+            D.pred_ptr = R.pred_ptr, D.pred_idx = R.pred_idx;
+            D.pos = R.pos, D.state_at = R.state_at, D.wslot = R.wslot, D.pred4 = R.pred4, D.paddr = R.paddr;
+        } else {
+            D.pred_ptr = (const int32_t *)put(A.pred_ptr, (size_t)(S + 1) * 4);
+            int32_t dummy = 0;
+            D.pred_idx = (const int32_t *)put(E ? (const void *)A.pred_idx : (const void *)&dummy, (size_t)std::max(E, 1) * 4);
+        }
         D.repeat_mask = (const uint8_t *)put(A.repeat_mask, (size_t)S);
         D.last_base = A.last_base ? (const uint8_t *)put(A.last_base, (size_t)S) : nullptr;
         if (!A.last_base) c->have_bases = false;
-        D.pos = nullptr;
-        D.state_at = nullptr;
         D.stack_mask = P.stack_mask;
-        if (P.store_pos) {
-            D.pos = (const uint16_t *)put(P.pos.data(), (size_t)S * 2);
-            D.state_at = (const uint16_t *)put(P.state_at.data(), P.state_at.size() * 2);
+        if (first) {
+            D.pos = nullptr;
+            D.state_at = nullptr;
+            if (P.store_pos) {
+                D.pos = (const uint16_t *)put(P.pos.data(), (size_t)S * 2);
+                D.state_at = (const uint16_t *)put(P.state_at.data(), P.state_at.size() * 2);
+            }
+            if (!v.generic && v.K == 1) D.wslot = (const uint16_t *)put(P.wslot.data(), P.wslot.size() * 2);
+            D.pred4 = (const uint64_t *)put(P.p4.data(), P.p4.size() * 8);
+            if (!v.generic) D.paddr = (const uint16_t *)put(P.paddr.data(), P.paddr.size() * 2);
         }
-        if (!v.generic && v.K == 1) D.wslot = (const uint16_t *)put(P.wslot.data(), P.wslot.size() * 2);
-        D.pred4 = (const uint64_t *)put(P.p4.data(), P.p4.size() * 8);
-        if (!v.generic) D.paddr = (const uint16_t *)put(P.paddr.data(), P.paddr.size() * 2);
         c->host_aut.push_back(D);
         if (v.generic) {
             if (mf > 15) {

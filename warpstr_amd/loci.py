@@ -133,8 +133,18 @@ class HipEngine:
         self.queue = BatchQueue(self.hip, self.stream, (caller_config or CallerConfig()).spike_removal)
         self.submit_raw, self.submit_signals, self.collect = self.queue.submit_raw, self.queue.submit_signals, self.queue.collect
         self.stage_shared, self.submit_raw_shared, self.stage_local = self.queue.stage_shared, self.queue.submit_raw_shared, self.queue.stage_local
-        self.submit_raw_parts, self.region_wait, self.ARENA_REGIONS = self.queue.submit_raw_parts, self.queue.region_wait, self.queue.ARENA_REGIONS
-        self.arena_ready = self.queue.arena_ready
+
+    # (methods, not attributes: main_wrapper_loci asks the CLASS what an engine can do before it creates one)
+    ARENA_REGIONS = BatchQueue.ARENA_REGIONS
+
+    def submit_raw_parts(self, *a):
+        return self.queue.submit_raw_parts(*a)
+
+    def region_wait(self, region):
+        return self.queue.region_wait(region)
+
+    def arena_ready(self, path, samples):
+        return self.queue.arena_ready(path, samples)
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
@@ -597,12 +607,21 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         records = np.zeros(len(mine), dtype=_result_dtype())
         seqs = [[], []]
         try:
-            t0 = time.perf_counter()
+            import queue as _queue
+            import threading
             queue = None
-            if len(mine):
-                queue = (_engine or HipEngine)([s for j in jobs for s in (j.temp_sta, j.rev_sta)],
-                                               [j.flank_length for j in jobs for _ in range(2)], caller_config, rescaler_config, local_gpu)
-            tm['handle_s'] += time.perf_counter() - t0
+            engine_cls = _engine or HipEngine
+            engine_ready, stop = threading.Event(), threading.Event()
+            handover: '_queue.Queue' = _queue.Queue(maxsize=1)
+
+            def make_engine():
+                nonlocal queue
+                t0 = time.perf_counter()
+                if len(mine):
+                    queue = engine_cls([s for j in jobs for s in (j.temp_sta, j.rev_sta)],
+                                       [j.flank_length for j in jobs for _ in range(2)], caller_config, rescaler_config, local_gpu)
+                tm['handle_s'] += time.perf_counter() - t0
+                engine_ready.set()
             # cut the rank's reads (in global order) into batches: at most batch_reads reads and batch_samples segment samples
             raw_budget = batch_raw_bytes // 2
             csum = np.cumsum(span[mine])
@@ -740,7 +759,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 still running -- the readers never wait for each other, only a region for the upload of the batch that used it
                 three batches ago."""
                 import collections
-                regions = queue.ARENA_REGIONS
+                regions = engine_cls.ARENA_REGIONS
                 inflight = collections.deque()
                 b, k, ci = 0, 0, 1
                 while b < len(mine) or inflight:
@@ -750,7 +769,11 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         b1 = min(cuts[ci], b + SHARED_BATCH_READS)
                         t1 = time.perf_counter()
                         region = k % regions
-                        queue.region_wait(region)
+                        if k >= regions:   # (a region's first use waits for nothing -- and the handle may still be in the making)
+                            engine_ready.wait()
+                            if stop.is_set():
+                                return
+                            queue.region_wait(region)
                         items = [item_of(x) for x in range(b, b1)]
                         step = max(8, -(-len(items) // (2 * pool._max_workers)))
                         futures = [pool.submit(_decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
@@ -760,7 +783,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     b0, b1, region, futures = inflight.popleft()
                     t1 = time.perf_counter()
                     parts = []
-                    ready = getattr(queue, 'arena_ready', None)
+                    ready = getattr(queue, 'arena_ready', None) if engine_ready.is_set() else None
                     for f in futures:
                         path, cap, base, lens_p, busy = f.result()
                         if ready is not None:
@@ -788,41 +811,47 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 if len(pending) > 2:  # at most three batches' buffers in HBM / in flight
                     finish(*pending.pop(0))
 
-            if pool is not None and hasattr(queue, 'stage_shared'):
-                # A reader thread runs one batch ahead: the staging ring has three slots, and a slot is taken again only after the
-                # batch that used it was submitted (the hand-over queue holds one batch: taking the slot of batch n + 3 follows
-                # putting batch n + 2, which follows the consumer's get of batch n + 1, i.e. its submit of batch n).
-                import queue as _queue
-                import threading
-                handover: '_queue.Queue' = _queue.Queue(maxsize=1)
-                stop = threading.Event()
-
-                arenas = hasattr(queue, 'submit_raw_parts') and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')
-                tm['reader_mode'] = 'arenas' if arenas else 'shared staging'
-
-                def produce():
-                    try:
-                        for item in (arena_batches() if arenas else batches()):
-                            while not stop.is_set():
-                                try:
-                                    handover.put(item, timeout=0.2)
-                                    break
-                                except _queue.Full:
-                                    pass
-                            if stop.is_set():
-                                return
-                        item = None
-                    except BaseException as e:  # noqa: BLE001 -- raised by the consumer below
-                        item = e
-                    while not stop.is_set():
-                        try:
-                            handover.put(item, timeout=0.2)
-                            return
-                        except _queue.Full:
-                            pass
-                reader = threading.Thread(target=produce, name='warpstr-reader', daemon=True)
-                reader.start()
+            def produce(source):
                 try:
+                    for item in source():
+                        while not stop.is_set():
+                            try:
+                                handover.put(item, timeout=0.2)
+                                break
+                            except _queue.Full:
+                                pass
+                        if stop.is_set():
+                            return
+                    item = None
+                except BaseException as e:  # noqa: BLE001 -- raised by the consumer below
+                    item = e
+                while not stop.is_set():
+                    try:
+                        handover.put(item, timeout=0.2)
+                        return
+                    except _queue.Full:
+                        pass
+
+            # With reader processes a reader thread runs one batch ahead of the calling thread: shared staging has three slots, and a
+            # slot is taken again only after the batch that used it was submitted (the hand-over queue holds one batch: taking the
+            # slot of batch n + 3 follows putting batch n + 2, which follows the consumer's get of batch n + 1, i.e. its submit of
+            # batch n).  With arenas nothing of the handle is needed to decode the first batches: the reader thread starts BEFORE the
+            # handle is created, and the readers decode while 12 000 automata are placed and packed.
+            probe = engine_cls if isinstance(engine_cls, type) else None   # (what the engine can do, asked of its class)
+            arenas = (pool is not None and probe is not None and hasattr(probe, 'submit_raw_parts') and hasattr(probe, 'ARENA_REGIONS')
+                      and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS') and len(mine) > 0)
+            reader = None
+            try:
+                if arenas:
+                    tm['reader_mode'] = 'arenas'
+                    reader = threading.Thread(target=produce, args=(arena_batches,), name='warpstr-reader', daemon=True)
+                    reader.start()
+                make_engine()
+                if reader is None and pool is not None and hasattr(queue, 'stage_shared'):
+                    tm['reader_mode'] = 'shared staging'
+                    reader = threading.Thread(target=produce, args=(batches,), name='warpstr-reader', daemon=True)
+                    reader.start()
+                if reader is not None:
                     while True:
                         item = handover.get()
                         if item is None:
@@ -830,12 +859,14 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         if isinstance(item, BaseException):
                             raise item
                         submit(*item)
-                finally:
-                    stop.set()
+                else:
+                    for item in batches():
+                        submit(*item)
+            finally:
+                stop.set()
+                engine_ready.set()
+                if reader is not None:
                     reader.join()
-            else:
-                for item in batches():
-                    submit(*item)
             while pending:
                 finish(*pending.pop(0))
             if queue is not None:
