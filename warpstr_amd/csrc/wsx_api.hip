@@ -767,12 +767,22 @@ try {
     // variants, 12 % of the reads, took 1.8 of a pass's 4.3 ms).  Variants that differ only in the number of candidates of slot
     // 0 share the larger kernel where the difference is one candidate (three vector instructions per row for those reads).
     // (Their launches on side streams instead: slower, 17.1-22 vs 16.4 ms per step -- more streams than the runtime's queues.)
-    if (!wsx_exp_env("WSX_NO_VARIANT_MERGE"))
-        for (auto &v : c->variant) {
-            if (v.generic || v.pk || v.K < 2) continue;
-            for (const auto &u : c->variant)
-                if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == v.F + 1 && v.F >= 3) v.F = u.F;
+    // (the variants of a handle are few and its automata many: the partners are looked for among the distinct variants, as they
+    // were before any merge -- with every automaton compared against every other, a handle of 48 000 automata took 2.2 s here)
+    if (!wsx_exp_env("WSX_NO_VARIANT_MERGE")) {
+        std::vector<Variant> distinct;
+        for (const auto &v : c->variant) {
+            bool seen = false;
+            for (const auto &u : distinct) seen = seen || u.same(v);
+            if (!seen) distinct.push_back(v);
         }
+        for (auto &v : c->variant) {
+            if (v.generic || v.pk || v.K < 2 || v.F < 3) continue;
+            const int f0 = v.F;   // (one step: a variant joins the kernel with ONE candidate more, whatever the order of the automata)
+            for (const auto &u : distinct)
+                if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == f0 + 1) v.F = u.F;
+        }
+    }
     for (auto &v : c->variant) {
         bool seen = false;
         for (auto &u : c->uvar) seen = seen || u.same(v);
