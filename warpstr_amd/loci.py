@@ -783,17 +783,26 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     b0, b1, region, futures = inflight.popleft()
                     t1 = time.perf_counter()
                     parts = []
-                    ready = getattr(queue, 'arena_ready', None) if engine_ready.is_set() else None
                     for f in futures:
                         path, cap, base, lens_p, busy = f.result()
-                        if ready is not None:
-                            ready(path, cap)   # (page-locked here, on the reader thread, while the other chunks are still decoding)
+                        page_lock([(path, cap)])   # (here, on the reader thread, while the other chunks are still decoding)
                         parts.append((path, cap, base, lens_p))
                         tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
                     tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
                     tm['read_s'] += time.perf_counter() - t1
                     yield b0, b1, parts, ('arena', region), None
+
+            def page_lock(parts):
+                """Map and page-lock the arenas the parts lie in, if the engine is there to do it (else the submitting thread does it
+                when it uploads from them); True once done."""
+                if not engine_ready.is_set():
+                    return False
+                ready = getattr(queue, 'arena_ready', None)
+                if ready is not None:
+                    for part in parts:
+                        ready(part[0], part[1])
+                return True
 
             def submit(b0, b1, data, shared_slot, shared_roff):
                 t1 = time.perf_counter()
@@ -814,9 +823,12 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             def produce(source):
                 try:
                     for item in source():
+                        locked = not (isinstance(item[3], tuple) and item[3][0] == 'arena')
                         while not stop.is_set():
+                            # (a batch decoded before the handle existed: its arenas are page-locked while it waits its turn)
+                            locked = locked or page_lock(item[2])
                             try:
-                                handover.put(item, timeout=0.2)
+                                handover.put(item, timeout=0.2 if locked else 0.01)
                                 break
                             except _queue.Full:
                                 pass
