@@ -14,6 +14,10 @@
  *                             _backtracking 247-301)
  *   wsx_prepare_signals  <->  Fast5.get_data_processed for every `saved` read (get_workload),
  *                             src/schemas/fast5.py:45-57, src/caller/wrapper.py:44-54
+ *   wsx_vbz_decode       <->  what h5py hands `Fast5.get_data_processed` when it reads `Raw/Signal` (src/schemas/fast5.py:50-52):
+ *                             the samples of a VBZ-filtered dataset.  Upstream leaves the decoding to the HDF5 filter plugin
+ *                             (filter id 32020, ont-vbz-hdf-plugin: absent from the upstream tree); this entry point does
+ *                             the part of it behind the zstd frame -- StreamVByte, zig-zag, running sum -- on the device
  *   wsx_locate_flanks    <->  find_sequence(text, pattern) for a batch of (basecalled window, flank) pairs,
  *                             src/extractor/tr_extractor.py:196-250 (align_seq 253-274 calls it twice per read);
  *                             the alignment itself is Bio.pairwise2.align.localms (biopython ==1.75, absent here:
@@ -48,7 +52,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 11
+#define WSX_ABI_VERSION 12
 
 /* function return codes */
 enum {
@@ -247,6 +251,34 @@ int wsx_warp_batch(wsx_caller *c, int mem, const double *signal, const int64_t *
 int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_t *raw_offsets, const int64_t *seg_start,
                         const int64_t *seg_end, int64_t n_reads, int32_t spike_removal, double *signal_out,
                         const int64_t *out_offsets, double *shift_scale);
+
+/*
+ * The samples of VBZ-compressed signal datasets, decoded on the device (the step between the file and wsx_prepare_signals).
+ * A VBZ chunk (HDF5 filter 32020, version 0, 2-byte integers) is a u32 byte count and a zstd frame; inside the frame is a
+ * StreamVByte block: ceil(n/4) key bytes -- two bits per value, byte length - 1, first value in the low bits -- followed by
+ * the values' little-endian bytes back to back; the values are the (optionally zig-zag mapped) differences of consecutive
+ * samples, the first against 0.  The host undoes zstd (a byte-serial entropy decoder); what is left is two prefix sums --
+ * where a value's bytes start, and the running sum of the differences -- which this entry point computes a workgroup per block.
+ *   src            device: the blocks' bytes (StreamVByte blocks as they leave zstd, or plain little-endian int16 samples)
+ *   blocks         host wsx_vbz_block[n_blocks]: where a block lies in src, what it is, where its samples go in dst.
+ *                  Checked before anything is enqueued (WSX_ERR_INVALID: a block outside src / dst, fewer bytes than its
+ *                  key area plus one byte per value); copied before the call returns
+ *   dst            device int16: sample dst_offset + i of block b is its i-th sample (the running sum wraps as int16 does)
+ *   status         device int32[n_blocks] or NULL: 0, or 1 for a block whose keys ask for more bytes than it has (its
+ *                  samples from there on are those of zero bytes; nothing outside the block is read).  Valid in stream order
+ * Enqueued on the handle's stream; returns without waiting.  A wsx_prepare_signals on the same handle that follows reads dst in
+ * stream order.
+ */
+typedef struct wsx_vbz_block {
+    int64_t src_offset; /* first byte of the block in src */
+    int64_t src_bytes;  /* its size */
+    int64_t dst_offset; /* its first sample in dst (in samples) */
+    int32_t n_samples;
+    int32_t kind;       /* WSX_VBZ_PLAIN: int16 samples; WSX_VBZ_SVB_ZIGZAG / WSX_VBZ_SVB: StreamVByte of (zig-zag) differences */
+} wsx_vbz_block;
+enum { WSX_VBZ_PLAIN = 0, WSX_VBZ_SVB_ZIGZAG = 1, WSX_VBZ_SVB = 2 };
+int wsx_vbz_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const wsx_vbz_block *blocks, int64_t n_blocks,
+                   int16_t *dst, int64_t dst_samples, int32_t *status);
 
 int wsx_caller_synchronize(wsx_caller *c);
 

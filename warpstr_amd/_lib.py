@@ -18,7 +18,7 @@ READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_ord
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
            'wsx_caller_set_workspace_limit', 'wsx_caller_get_workspace_limit', 'wsx_caller_set_tuning', 'wsx_caller_create_times', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
-           'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw']
+           'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw', 'wsx_vbz_decode']
 
 
 # wsx_caller_set_tuning knobs (include/warpstr_hip.h: WSX_TUNE_*)
@@ -47,6 +47,13 @@ RESULT_DTYPE = np.dtype([('status', np.int32), ('len1', np.int32), ('len2', np.i
                          ('n_trans2', np.int32), ('reserved', np.int32), ('cost1', np.float64), ('cost2', np.float64),
                          ('dtw_end_cost1', np.float64), ('dtw_end_cost2', np.float64)], align=True)
 assert RESULT_DTYPE.itemsize == 56
+
+
+# numpy view of wsx_vbz_block (wsx_vbz_decode); kinds: WSX_VBZ_*
+VBZ_BLOCK_DTYPE = np.dtype([('src_offset', np.int64), ('src_bytes', np.int64), ('dst_offset', np.int64), ('n_samples', np.int32),
+                            ('kind', np.int32)])
+assert VBZ_BLOCK_DTYPE.itemsize == 32
+VBZ_PLAIN, VBZ_SVB_ZIGZAG, VBZ_SVB = 0, 1, 2
 
 
 class WsxAlignScores(C.Structure):
@@ -148,6 +155,7 @@ def load():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.wsx_moves_to_raw.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.wsx_vbz_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     _lib = lib
     return lib
 

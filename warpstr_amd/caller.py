@@ -426,6 +426,14 @@ class HipCaller:
                                                 SPIKE_REMOVAL[spike_removal], C.c_void_p(out_ptr), _lib.ptr(out_offsets),
                                                 C.c_void_p(shift_scale_ptr or None)), 'wsx_prepare_signals')
 
+    def vbz_decode_device(self, src_ptr: int, src_bytes: int, blocks: np.ndarray, dst_ptr: int, dst_samples: int, status_ptr: int = 0):
+        """wsx_vbz_decode: StreamVByte blocks (what is inside a VBZ chunk's zstd frame) or plain int16 samples in HBM -> the
+        int16 samples in HBM, where `blocks` (_lib.VBZ_BLOCK_DTYPE) says.  Asynchronous, on the handle's stream: a prepare_device
+        that follows reads the samples in stream order."""
+        blocks = np.ascontiguousarray(blocks, _lib.VBZ_BLOCK_DTYPE)
+        _lib.check(self.lib.wsx_vbz_decode(self.handle, C.c_void_p(src_ptr), int(src_bytes), _lib.ptr(blocks), len(blocks),
+                                           C.c_void_p(dst_ptr), int(dst_samples), C.c_void_p(status_ptr or None)), 'wsx_vbz_decode')
+
     def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
                     trace1_ptr: int = 0, trace2_ptr: int = 0, seq1_ptr: int = 0, seq2_ptr: int = 0):
         """wsx_call_batch on device buffers; asynchronous (see set_pipelined / join / synchronize)."""

@@ -317,6 +317,13 @@ struct wsx_caller {
     void *prep_pinned = nullptr; // ... and its metadata staging (pinned), with the event recorded after the last use
     size_t prep_pinned_cap = 0;
     hipEvent_t ev_prep = nullptr;
+    struct VbzSlot {             // wsx_vbz_decode: block tables on their way to the device (three calls may be in flight)
+        void *host = nullptr;
+        size_t host_cap = 0;
+        DeviceBuf dev;
+        hipEvent_t ev = nullptr;
+    } vbz_ring[3];
+    unsigned vbz_turn = 0;
     void *pinned_res = nullptr; // host-buffer calls: the batch's result records land here first
     size_t pinned_res_cap = 0;
 };
@@ -859,6 +866,11 @@ void wsx_caller_destroy(wsx_caller *c)
     if (c->smooth_host) (void)hipHostFree(c->smooth_host);
     if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    for (auto &v : c->vbz_ring) {
+        if (v.host) (void)hipHostFree(v.host);
+        if (v.ev) (void)hipEventDestroy(v.ev);
+        v.dev.release();
+    }
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
@@ -1010,6 +1022,26 @@ hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEv
     }
     *p = c->prep_pinned;
     *last_use = c->ev_prep;
+    return hipSuccess;
+}
+// the next slot of the ring wsx_vbz_decode stages its block tables in (csrc/wsx_vbz.hip)
+hipError_t wsx_internal_vbz_slot(wsx_caller *c, size_t bytes, void **host, void **dev, hipEvent_t *last_use)
+{
+    auto &v = c->vbz_ring[c->vbz_turn++ % 3];
+    hipError_t e = hipSuccess;
+    if (!v.ev && (e = hipEventCreateWithFlags(&v.ev, hipEventDisableTiming)) != hipSuccess) return e;
+    if (bytes > v.host_cap) {
+        if ((e = hipEventSynchronize(v.ev)) != hipSuccess) return e;
+        if (v.host) (void)hipHostFree(v.host);
+        v.host = nullptr;
+        v.host_cap = 0;
+        if ((e = hipHostMalloc(&v.host, bytes + bytes / 2, hipHostMallocDefault)) != hipSuccess) return e;
+        v.host_cap = bytes + bytes / 2;
+    }
+    if ((e = v.dev.ensure(bytes + bytes / 2)) != hipSuccess) return e;
+    *host = v.host;
+    *dev = v.dev.p;
+    *last_use = v.ev;
     return hipSuccess;
 }
 // buffer `slot` of the signal loader's pool, at least `bytes` large (grown when needed, freed with the handle)
