@@ -120,6 +120,32 @@ class ArenaFakeEngine(SharedFakeEngine):
         self.staging.close()
 
 
+class VbzFakeEngine(ArenaFakeEngine):
+    """... and one that takes the reads as the blocks inside their VBZ chunks (wsx_vbz_decode's part played by oracle/vbz.py)."""
+
+    def submit_vbz_parts(self, region, parts, lo, hi, aut):
+        from oracle import vbz
+        self.vbz_batches = getattr(self, 'vbz_batches', 0) + 1
+        raws = []
+        for path, cap, base, used, lens, table in parts:
+            view = np.memmap(path, dtype=np.uint8, mode='r')
+            assert cap <= len(view) and base + used <= cap
+            t = np.frombuffer(table, np.int64).reshape(-1, 5)
+            per_read = [[] for _ in lens]
+            for r, kind, off, nbytes, ns in t:
+                assert off % 16 == 0 and base <= off and off + nbytes <= base + used
+                blk = np.array(view[off:off + nbytes])
+                per_read[r].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(ns), kind == 1))
+            for n, pieces in zip(lens, per_read):
+                raw = np.concatenate(pieces)
+                assert len(raw) == n
+                raws.append(raw)
+        return self.submit_raw(raws, lo, hi, aut)
+
+    def info(self):
+        return dict(super().info(), vbz_batches=getattr(self, 'vbz_batches', 0))
+
+
 def _make_loci(root, poison=None):
     """Five synthetic locus directories (one without saved reads, one with a single read) + the normalised segments by read
     name; returns (loci, {read name: signal})."""
@@ -357,11 +383,39 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
     finally:
         wl.SHARED_BATCH_READS = old_reads
     assert tm_d['reader_mode'] == 'arenas' and tm_d['arena_batches'] == tm_d['batches'] >= 4 and tm_d['shared_batches'] == 0
-    for la, lb, lc, ld in zip(a, b, c, d):
+    # ... and, for an engine that decodes VBZ itself, as the StreamVByte blocks inside the chunks' zstd frames
+    e, tm_e = make(str(tmp_path / 'e')), {}
+    wl.SHARED_BATCH_READS = 40
+    try:
+        main_wrapper_loci(e, 3, _engine=VbzFakeEngine, quiet=True, timings=tm_e)
+    finally:
+        wl.SHARED_BATCH_READS = old_reads
+    assert tm_e['reader_mode'] == 'arenas, VBZ decoded on the GPU' and tm_e['vbz_batches'] == tm_e['batches'] >= 4 and tm_e['arena_batches'] == 0
+    assert tm_e['uploaded_bytes'] < 0.75 * tm_e['raw_bytes'] and tm_d['uploaded_bytes'] == tm_d['raw_bytes']
+    # ... and a region is not handed out again before the calling thread has SUBMITTED the batch that used it (an engine that
+    # dawdles before it looks at the arenas: the readers would have overwritten them when taking a batch from the queue was enough)
+    import time
+
+    class Dawdling(ArenaFakeEngine):
+        def submit_raw_parts(self, *args):
+            time.sleep(0.05)
+            return super().submit_raw_parts(*args)
+    f, tm_f = make(str(tmp_path / 'f')), {}
+    wl.SHARED_BATCH_READS = 16
+    try:
+        main_wrapper_loci(f, 3, _engine=Dawdling, quiet=True, timings=tm_f)
+    finally:
+        wl.SHARED_BATCH_READS = old_reads
+    assert tm_f['arena_batches'] >= 8
+    for lf, lb in zip(f, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(lf.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    for la, lb, lc, ld, le in zip(a, b, c, d, e):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(ld.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+            assert filecmp.cmp(os.path.join(le.path, rel), os.path.join(lb.path, rel), shallow=False), rel
     assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_arena_')]
     assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_stage_')]
 

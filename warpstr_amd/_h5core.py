@@ -95,9 +95,11 @@ def libs():
 
 _SCRATCH = None
 _VBZ_NATIVE = False
+PLAIN, SVB_ZIGZAG, SVB = 0, 1, 2   # what a block written by Fast5Core.blocks_to holds (= WSX_VBZ_* of include/warpstr_hip.h)
 VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
               -6: 'a VBZ chunk holds more samples than the dataset says'}
+
 
 
 def scratch(nbytes: int):
@@ -118,13 +120,16 @@ def vbz_native():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_host_loci.so')
         if os.path.exists(path) and not os.environ.get('WARPSTR_NO_HOST_NATIVE'):
             try:
-                fn = C.CDLL(path).wsh_vbz_decode_i16
+                lib = C.CDLL(path)
+                fn, unpack = lib.wsh_vbz_decode_i16, lib.wsh_vbz_unpack
             except (OSError, AttributeError):
                 return None
             _, zs = libs()
             fn.restype = C.c_int64
             fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
-            _VBZ_NATIVE = (fn, C.cast(zs.ZSTD_getFrameContentSize, C.c_void_p).value, C.cast(zs.ZSTD_decompress, C.c_void_p).value)
+            unpack.restype = C.c_int64
+            unpack.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+            _VBZ_NATIVE = (fn, C.cast(zs.ZSTD_getFrameContentSize, C.c_void_p).value, C.cast(zs.ZSTD_decompress, C.c_void_p).value, unpack)
     return _VBZ_NATIVE
 
 
@@ -261,7 +266,7 @@ class Fast5Core:
                 if h.H5Dread(d, native_i16, 0, 0, 0, C.c_void_p(addr)) < 0:
                     raise Fast5Error(f'{self.path}: H5Dread failed')
                 return n
-            fn, f_size, f_dec = native
+            fn, f_size, f_dec = native[:3]
             zigzag, level = int(bool(vbz[2])), int(vbz[3])
             done = 0
             for start, want, buf, size, plain in self._chunks(d, n, chunk_len):
@@ -280,5 +285,53 @@ class Fast5Core:
             if done != n:
                 raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')
             return n
+        finally:
+            h.H5Dclose(d)
+
+    def blocks_to(self, read_id: Optional[str], place):
+        """A read as the device decoder takes it (wsx_vbz_decode): every chunk of a VBZ dataset as the StreamVByte block inside
+        its zstd frame -- zstd is the part a GPU does not do --, anything else as plain int16 samples.  place(nbytes) -> the address
+        the next block goes to (asked once per block, in order).  Returns (samples of the read, [(kind, bytes, samples), ...]).
+        NeedsNumpy as for decode_to (before place() is asked for the first time, or after: the caller starts the read again)."""
+        h = self.h
+        d, n, vbz, chunk_len = self._open_signal(read_id)
+        try:
+            if vbz is None:  # contiguous / gzip / ...: the library's own pipeline, plain samples
+                native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
+                if h.H5Dread(d, native_i16, 0, 0, 0, C.c_void_p(int(place(2 * n)))) < 0:
+                    raise Fast5Error(f'{self.path}: H5Dread failed')
+                return n, [(PLAIN, 2 * n, n)]
+            native = vbz_native() if (vbz[0] == 0 and vbz[1] == 2) else None
+            if native is None:
+                raise NeedsNumpy()
+            _, f_size, f_dec, unpack = native
+            _, zs = libs()
+            kind, level = (SVB_ZIGZAG if vbz[2] else SVB), int(vbz[3])
+            blocks, done, n_out = [], 0, C.c_int64()
+            for start, want, buf, size, plain in self._chunks(d, n, chunk_len):
+                if plain:  # the filter was skipped when this chunk was written: plain samples
+                    got = min(size // 2, want)
+                    C.memmove(int(place(2 * got)), buf, 2 * got)
+                    blocks.append((PLAIN, 2 * got, got))
+                else:
+                    if size < 4:
+                        raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-1])
+                    if want != min(chunk_len, struct.unpack_from('<I', buf, 0)[0] // 2):
+                        raise NeedsNumpy()
+                    if level != 0:
+                        cap = zs.ZSTD_getFrameContentSize(C.cast(C.addressof(buf) + 4, C.c_char_p), size - 4)
+                        if cap >= (1 << 62):
+                            raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-2])
+                    else:
+                        cap = size - 4
+                    nb = unpack(buf, size, level, f_size, f_dec, int(place(int(cap))), int(cap), C.byref(n_out))
+                    if nb < 0:
+                        raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS.get(int(nb), f'VBZ decoder error {nb}'))
+                    got = want
+                    blocks.append((kind, int(nb), got))
+                done += got
+            if done != n:
+                raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')
+            return n, blocks
         finally:
             h.H5Dclose(d)

@@ -18,7 +18,7 @@ def main():
         _readers.spread_over_cpus(int(sys.argv[1]))   # (the k-th worker starts on the k-th CPU of the mask; nothing stays pinned)
     names = {'_read_chunk': _readers.read_chunk, '_probe_chunk': _readers.probe_chunk, '_decode_chunk': _readers.decode_chunk,
              'read_chunk': _readers.read_chunk, 'probe_chunk': _readers.probe_chunk, 'decode_chunk': _readers.decode_chunk,
-             'decode_arena': _readers.decode_arena,
+             'decode_arena': _readers.decode_arena, 'pack_arena': _readers.pack_arena,
              'loaded_modules': lambda prefix: sorted(m for m in sys.modules if m.startswith(prefix))}   # (what a test asks)
     while True:
         try:

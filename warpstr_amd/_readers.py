@@ -183,6 +183,53 @@ def decode_arena(args):
     return arena[0], arena[3], base, lens, time.perf_counter() - t0
 
 
+_BYTE_CURSOR: Dict[int, list] = {}    # region -> [generation, bytes written in it] (pack_arena)
+
+
+def pack_arena(args):
+    """decode_arena() for a parent that decodes on the GPU (wsx_vbz_decode): every read's blocks -- StreamVByte blocks as they
+    leave zstd, or plain samples -- back to back (16-byte aligned) in the region's arena.  (region, generation, items) ->
+    (arena path, its size in bytes, first byte of this chunk, bytes used from there, [samples of every read],
+    int64 quintuples (read of the chunk, kind, first byte in the arena, bytes, samples) of all blocks as bytes, seconds)."""
+    import array
+    import time
+
+    from ._h5core import PLAIN, NeedsNumpy
+    region, generation, items = args
+    t0 = time.perf_counter()
+    cur = _BYTE_CURSOR.setdefault(region, [generation, 0])
+    if cur[0] != generation:
+        cur[0], cur[1] = generation, 0
+    base = at = cur[1]
+    lens, table, offs = [], array.array('q'), []
+
+    def place(nbytes):   # where the next block goes
+        nonlocal at
+        at = (at + 15) & ~15
+        addr = _arena_address(region, (at + nbytes + 1) // 2 + 8) + at
+        offs.append(at)
+        at += nbytes
+        return addr
+    for r, item in enumerate(items):
+        path, read_id = resolve(item)
+        mark, n_offs = at, len(offs)
+        try:
+            n, blocks = fast5_file(path, arrays=False).blocks_to(read_id, place)
+        except NeedsNumpy:
+            import ctypes
+            at = mark
+            del offs[n_offs:]
+            raw = fast5_file(path).raw_signal(read_id)
+            ctypes.memmove(place(2 * len(raw)), raw.ctypes.data, 2 * len(raw))
+            n, blocks = len(raw), [(PLAIN, 2 * len(raw), len(raw))]
+        lens.append(int(n))
+        for (kind, nbytes, ns), off in zip(blocks, offs[n_offs:]):
+            table.extend((r, kind, off, nbytes, ns))
+    cur[1] = at
+    arena = _arena(region, max((at + 1) // 2, 1))
+    return arena[0], 2 * arena[3], base, at - base, lens, table.tobytes(), time.perf_counter() - t0
+
+
 def spread_over_cpus(k: int):
     """Move this process to the k-th CPU of its affinity mask and release it again (loci.spread_over_cpus, without the package)."""
     if not hasattr(os, 'sched_setaffinity'):

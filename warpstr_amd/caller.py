@@ -802,6 +802,70 @@ class BatchQueue:
             acc[key] = acc.get(key, 0.0) + dt
         return ticket
 
+    def submit_vbz_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
+        """submit_raw_parts() for readers that leave the decoding to the device (_readers.pack_arena): parts = [(arena path, its
+        size in bytes, first byte of the chunk, bytes used, [samples of every read], the blocks' quintuples as bytes), ...] in
+        batch order.  One upload per chunk of what the readers wrote -- StreamVByte blocks, 0.6 of the samples' bytes --, then
+        wsx_vbz_decode into the batch's int16 buffer, then the signal loader and the caller as ever."""
+        import time
+        torch = self.torch
+        clock, acc = time.perf_counter, self.parts_s
+        t0 = clock()
+        lens = np.array([n for p in parts for n in p[4]], np.int64)
+        n = len(lens)
+        roff = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=roff[1:])
+        total_raw = int(roff[-1])
+        lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
+        # the block table: where a block lies in the batch's byte buffer, where its samples go
+        tables, at_src, first_read, spans = [], 0, 0, []
+        for path, cap, base, used, ls, tb in parts:
+            t = np.frombuffer(tb, np.int64).reshape(-1, 5)
+            blk = np.zeros(len(t), _lib.VBZ_BLOCK_DTYPE)
+            if len(t):
+                blk['src_offset'] = at_src + (t[:, 2] - base)
+                blk['src_bytes'], blk['n_samples'], blk['kind'] = t[:, 3], t[:, 4], t[:, 1]
+                # samples of the read's earlier blocks (a read is several blocks when its dataset has several chunks)
+                before = np.cumsum(t[:, 4]) - t[:, 4]
+                starts = np.flatnonzero(np.r_[True, t[1:, 0] != t[:-1, 0]])
+                before -= np.repeat(before[starts], np.diff(np.r_[starts, len(t)]))
+                blk['dst_offset'] = roff[first_read + t[:, 0]] + before
+            tables.append(blk)
+            spans.append((path, cap, base, used, at_src))
+            at_src += (int(used) + 15) & ~15
+            first_read += len(ls)
+        blocks = np.concatenate(tables) if tables else np.zeros(0, _lib.VBZ_BLOCK_DTYPE)
+        t1 = clock()
+        with torch.cuda.stream(self.stream):
+            src_dev = torch.empty(max(at_src, 16), dtype=torch.uint8, device=self.dev)
+            raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
+            status = torch.empty(max(len(blocks), 1), dtype=torch.int32, device=self.dev)
+            t2 = clock()
+            for path, cap, base, used, at in spans:
+                if used:
+                    src_dev[at:at + used].copy_(self._arena_tensor(path, cap // 2).view(torch.uint8)[base:base + used], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._region_events[region] = ev
+            t3 = clock()
+            signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
+        t4 = clock()
+        if len(blocks):
+            self.hip.vbz_decode_device(src_dev.data_ptr(), at_src, blocks, raw_dev.data_ptr(), max(total_raw, 1), status.data_ptr())
+        if n:
+            self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
+        t5 = clock()
+        with torch.cuda.stream(self.stream):   # (src_dev and status were allocated on this stream: their memory is reused in its order)
+            bad = status[:len(blocks)].ne(0).any() if len(blocks) else None   # (read with the records: collect())
+        ticket = self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+        ticket['vbz_bad'] = bad
+        self.vbz_bytes = getattr(self, 'vbz_bytes', 0) + at_src
+        for key, dt in (('lengths', t1 - t0), ('allocate', t2 - t1 + t4 - t3), ('copies', t3 - t2), ('prepare', t5 - t4), ('launch', clock() - t5)):
+            acc[key] = acc.get(key, 0.0) + dt
+        return ticket
+
     def close(self):
         if self._shared is not None:
             self._shared.close()
@@ -836,6 +900,9 @@ class BatchQueue:
         torch = self.torch
         n = ticket['n']
         ticket['done'].synchronize()
+        if ticket.get('vbz_bad') is not None and bool(ticket['vbz_bad'].item()):
+            # (the readers check every block before it is uploaded: this is a block that changed on its way, not a bad file)
+            raise RuntimeError('wsx_vbz_decode flagged a StreamVByte block whose keys ask for more bytes than it has')
         rec = ticket['rec_host'].numpy().view(_lib.RESULT_DTYPE).reshape(-1)[:n].copy()
         ok = rec['status'] == 0
         out = [rec]

@@ -1171,6 +1171,55 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
     return n;
 }
 
+// The same chunk taken only as far as a GPU cannot take it (wsx_vbz_decode does the rest): the zstd frame's content -- the
+// StreamVByte block -- written to `out` (a reader's page-locked arena), checked: the keys of its n values must ask for exactly
+// the bytes that follow them (so that the device kernel never meets a block it has to flag).  Returns the block's size in bytes,
+// or -1 .. -5 as above, -6 the block does not fit `cap` bytes; *n_out = the samples the chunk says it holds.  (Bytes behind the
+// last value are not part of the block, as for the decoder above.)  (zstd_level == 0: the chunk's bytes are the block; copied.)
+WSH_EXPORT int64_t wsh_vbz_unpack(const uint8_t *chunk, int64_t n_chunk, int32_t zstd_level, void *size_fn, void *decompress_fn, uint8_t *out,
+                                  int64_t cap, int64_t *n_out)
+{
+    if (n_chunk < 4) return -1;
+    uint32_t n_bytes;
+    memcpy(&n_bytes, chunk, 4);
+    const int64_t n = n_bytes / 2;
+    *n_out = n;
+    const uint8_t *body = chunk + 4;
+    const int64_t body_bytes = n_chunk - 4;
+    int64_t size = body_bytes;
+    if (zstd_level != 0) {
+        const unsigned long long zs = reinterpret_cast<zstd_size_fn>(size_fn)(body, size_t(body_bytes));
+        if (zs >= (1ull << 62)) return -2;
+        if (int64_t(zs) > cap) return -6;
+        if (reinterpret_cast<zstd_decompress_fn>(decompress_fn)(out, size_t(zs), body, size_t(body_bytes)) != zs) return -3;
+        size = int64_t(zs);
+    } else {
+        if (size > cap) return -6;
+        memcpy(out, body, size_t(size));
+    }
+    const int64_t n_keys = (n + 3) / 4;
+    if (size < n_keys) return -4;
+    // bytes the keys ask for: n + the sum of their two-bit fields (eight key bytes at a time: fields -> nibble sums -> byte sums)
+    uint64_t extra = 0;
+    const int64_t full = n / 4;   // key bytes whose four values all exist
+    int64_t k = 0;
+    for (; k + 8 <= full; k += 8) {
+        uint64_t x;
+        memcpy(&x, out + k, 8);
+        uint64_t t = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+        t = (t + (t >> 4)) & 0x0f0f0f0f0f0f0f0full;
+        extra += (t * 0x0101010101010101ull) >> 56;
+    }
+    for (; k < full; k++) {
+        const uint8_t key = out[k];
+        extra += (key & 3) + ((key >> 2) & 3) + ((key >> 4) & 3) + (key >> 6);
+    }
+    for (int64_t i = full * 4; i < n; i++) extra += (out[i >> 2] >> ((i & 3) * 2)) & 3;
+    const int64_t need = n_keys + n + int64_t(extra);
+    if (need > size) return -5;
+    return need;
+}
+
 // n pieces of host memory laid end to end into dst (the raw reads of a batch into the page-locked staging buffer the upload
 // starts from), split by bytes over up to `threads` threads: 275 MB in 50 000 pieces is 30 ms of one core's memcpy.
 WSH_EXPORT void wsh_gather(const void *const *src, const int64_t *bytes, int64_t n, void *dst, int32_t threads)

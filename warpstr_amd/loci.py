@@ -140,6 +140,9 @@ class HipEngine:
     def submit_raw_parts(self, *a):
         return self.queue.submit_raw_parts(*a)
 
+    def submit_vbz_parts(self, *a):
+        return self.queue.submit_vbz_parts(*a)
+
     def region_wait(self, region):
         return self.queue.region_wait(region)
 
@@ -263,7 +266,7 @@ def _units_of(sequence: str):
 # host work that runs on worker PROCESSES (`python -m warpstr_amd._hostworker`: they never share the parent's HIP state and
 # import the NumPy-free core of the fast5 reader only -- warpstr_amd/_readers.py, _h5core.py).
 from ._readers import (decode_arena as _decode_arena, decode_chunk as _decode_chunk, decode_into as _decode_into,  # noqa: E402
-                       probe_chunk as _probe_chunk, read_chunk as _read_chunk)
+                       pack_arena as _pack_arena, probe_chunk as _probe_chunk, read_chunk as _read_chunk)
 
 
 class _WorkerPool:
@@ -612,6 +615,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             queue = None
             engine_cls = _engine or HipEngine
             engine_ready, stop = threading.Event(), threading.Event()
+            submitted: Dict[int, threading.Event] = {}   # arena batches: number -> "the calling thread has submitted it"
             handover: '_queue.Queue' = _queue.Queue(maxsize=1)
 
             def make_engine():
@@ -770,28 +774,42 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         t1 = time.perf_counter()
                         region = k % regions
                         if k >= regions:   # (a region's first use waits for nothing -- and the handle may still be in the making)
-                            engine_ready.wait()
+                            # the batch that used the region before must have been SUBMITTED by the calling thread (its copies
+                            # enqueued, the region's event recorded: taking it from the hand-over queue is not enough) ...
+                            while not submitted[k - regions].wait(0.2):
+                                if stop.is_set():
+                                    return
                             if stop.is_set():
                                 return
-                            queue.region_wait(region)
+                            queue.region_wait(region)   # ... and uploaded
+                            del submitted[k - regions]
+                        submitted[k] = threading.Event()
                         items = [item_of(x) for x in range(b, b1)]
                         step = max(8, -(-len(items) // (2 * pool._max_workers)))
-                        futures = [pool.submit(_decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
-                        inflight.append((b, b1, region, futures))
+                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step]))
+                                   for q in range(0, len(items), step)]
+                        inflight.append((b, b1, region, futures, k))
                         tm['read_s'] += time.perf_counter() - t1
                         b, k = b1, k + 1
-                    b0, b1, region, futures = inflight.popleft()
+                    b0, b1, region, futures, kb = inflight.popleft()
                     t1 = time.perf_counter()
                     parts = []
                     for f in futures:
-                        path, cap, base, lens_p, busy = f.result()
+                        if gpu_vbz:
+                            path, cap, base, used, lens_p, table, busy = f.result()
+                            cap //= 2   # (the arena's size in samples, as the engine counts it)
+                            parts.append((path, 2 * cap, base, used, lens_p, table))
+                            tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + int(used)
+                        else:
+                            path, cap, base, lens_p, busy = f.result()
+                            parts.append((path, cap, base, lens_p))
+                            tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + 2 * int(sum(lens_p))
                         page_lock([(path, cap)])   # (here, on the reader thread, while the other chunks are still decoding)
-                        parts.append((path, cap, base, lens_p))
                         tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
                     tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
                     tm['read_s'] += time.perf_counter() - t1
-                    yield b0, b1, parts, ('arena', region), None
+                    yield b0, b1, parts, ('vbz' if gpu_vbz else 'arena', region, kb), None
 
             def page_lock(parts):
                 """Map and page-lock the arenas the parts lie in, if the engine is there to do it (else the submitting thread does it
@@ -801,13 +819,15 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 ready = getattr(queue, 'arena_ready', None)
                 if ready is not None:
                     for part in parts:
-                        ready(part[0], part[1])
+                        ready(part[0], part[1] // 2 if len(part) == 6 else part[1])   # (a part of packed blocks counts bytes)
                 return True
 
             def submit(b0, b1, data, shared_slot, shared_roff):
                 t1 = time.perf_counter()
                 sel = mine[b0:b1]
-                if isinstance(shared_slot, tuple) and shared_slot[0] == 'arena':
+                if isinstance(shared_slot, tuple) and shared_slot[0] == 'vbz':
+                    ticket = queue.submit_vbz_parts(shared_slot[1], data, lo[sel], hi[sel], aut[sel])
+                elif isinstance(shared_slot, tuple) and shared_slot[0] == 'arena':
                     ticket = queue.submit_raw_parts(shared_slot[1], data, lo[sel], hi[sel], aut[sel])
                 elif shared_slot is not None:
                     ticket = queue.submit_raw_shared(shared_slot, shared_roff, lo[sel], hi[sel], aut[sel])
@@ -816,6 +836,8 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 else:
                     ticket = queue.submit_signals(data, aut[sel])
                 tm['submit_s'] += time.perf_counter() - t1
+                if isinstance(shared_slot, tuple) and len(shared_slot) == 3:
+                    submitted[shared_slot[2]].set()   # (the reader thread may hand the batch's arena region out again)
                 pending.append((ticket, b0, b1))
                 if len(pending) > 2:  # at most three batches' buffers in HBM / in flight
                     finish(*pending.pop(0))
@@ -823,7 +845,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             def produce(source):
                 try:
                     for item in source():
-                        locked = not (isinstance(item[3], tuple) and item[3][0] == 'arena')
+                        locked = not (isinstance(item[3], tuple) and item[3][0] in ('arena', 'vbz'))
                         while not stop.is_set():
                             # (a batch decoded before the handle existed: its arenas are page-locked while it waits its turn)
                             locked = locked or page_lock(item[2])
@@ -852,10 +874,13 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             probe = engine_cls if isinstance(engine_cls, type) else None   # (what the engine can do, asked of its class)
             arenas = (pool is not None and probe is not None and hasattr(probe, 'submit_raw_parts') and hasattr(probe, 'ARENA_REGIONS')
                       and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS') and len(mine) > 0)
+            # (and if the engine decodes VBZ itself -- wsx_vbz_decode -- the readers stop at the zstd frame's content: StreamVByte,
+            # zig-zag and the running sum are a quarter of a reader's time per read and 0.6 of the bytes to upload)
+            gpu_vbz = arenas and hasattr(probe, 'submit_vbz_parts') and not os.environ.get('WARPSTR_NO_GPU_VBZ')
             reader = None
             try:
                 if arenas:
-                    tm['reader_mode'] = 'arenas'
+                    tm['reader_mode'] = 'arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas'
                     reader = threading.Thread(target=produce, args=(arena_batches,), name='warpstr-reader', daemon=True)
                     reader.start()
                 make_engine()
