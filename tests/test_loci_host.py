@@ -410,6 +410,19 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
     for lf, lb in zip(f, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(lf.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    # ... and without reader processes the same arenas are filled by the reader thread of this process
+    for tag, engine in (('g', ArenaFakeEngine), ('h', VbzFakeEngine)):
+        g, tm_g = make(str(tmp_path / tag)), {}
+        wl.SHARED_BATCH_READS = 64   # (an inline batch is a quarter of it)
+        try:
+            main_wrapper_loci(g, 1, _engine=engine, quiet=True, timings=tm_g)
+        finally:
+            wl.SHARED_BATCH_READS = old_reads
+        assert tm_g['reader_mode'].endswith('filled in this process') and tm_g['reader_processes'] == 0 and tm_g['batches'] >= 8
+        assert tm_g['vbz_batches' if engine is VbzFakeEngine else 'arena_batches'] == tm_g['batches']
+        for lg, lb in zip(g, b):
+            for rel in OUTPUTS:
+                assert filecmp.cmp(os.path.join(lg.path, rel), os.path.join(lb.path, rel), shallow=False), rel
     for la, lb, lc, ld, le in zip(a, b, c, d, e):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel

@@ -94,6 +94,8 @@ def decode_chunk(args):
 # regions in turn and lets a region be written again only after what it held has been uploaded) and answers with the lengths.
 # Nothing has to be known about a read before it is decoded, so the parent can hand out the next batch's chunks while this one's
 # slowest chunk is still running: the readers never wait for each other.  The parent maps the same files and page-locks them.
+_CURSOR: Dict[int, list] = {}         # region -> [generation, samples written in it] (decode_arena)
+_BYTE_CURSOR: Dict[int, list] = {}    # region -> [generation, bytes written in it] (pack_arena)
 _ARENAS: Dict[int, list] = {}     # region -> [path, mmap, its first byte as a ctypes object (keeps the address valid), samples]
 ARENA_DIR = '/dev/shm'
 
@@ -142,9 +144,8 @@ def _drop_arenas():
         except OSError:
             pass
     _ARENAS.clear()
-
-
-_CURSOR: Dict[int, list] = {}    # region -> [generation, samples written in it]
+    _CURSOR.clear()
+    _BYTE_CURSOR.clear()
 
 
 def decode_arena(args):
@@ -181,9 +182,6 @@ def decode_arena(args):
     cur[1] = at
     arena = _arena(region, max(at, 1))
     return arena[0], arena[3], base, lens, time.perf_counter() - t0
-
-
-_BYTE_CURSOR: Dict[int, list] = {}    # region -> [generation, bytes written in it] (pack_arena)
 
 
 def pack_arena(args):

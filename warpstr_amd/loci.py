@@ -373,6 +373,26 @@ class _WorkerPool:
         self._procs = []
 
 
+class _InlinePool:
+    """The reader "pool" of a run without reader processes: a chunk is decoded by the thread that hands it out -- the reader
+    thread of main_wrapper_loci, beside the calling thread (the library calls inside release the GIL; libhdf5 is used by that one
+    thread only).  The same arenas, the same hand-over, one chunk at a time."""
+    _max_workers = 1
+    inline = True
+
+    def submit(self, func, item):
+        from concurrent.futures import Future
+        future = Future()
+        try:
+            future.set_result(func(item))
+        except BaseException as e:  # noqa: BLE001 -- raised where the future is waited for
+            future.set_exception(e)
+        return future
+
+    def shutdown(self, **_):
+        pass
+
+
 def _reader_pool(threads: int, n_loci: int):
     """Worker processes for the fast5 files of a run, or None: one thread, or fewer than 64 loci (starting the workers takes
     about a second).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported
@@ -492,6 +512,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
         from . import _readers
         while _readers._OPEN:
             _readers._OPEN.popitem()[1].close()
+        _readers._drop_arenas()   # (arenas this process filled itself: _InlinePool)
         if executor is not None:
             executor.shutdown(wait=True)
         for pool in pools:
@@ -770,7 +791,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     while b < len(mine) and len(inflight) < regions - 1:
                         while cuts[ci] <= b:
                             ci += 1
-                        b1 = min(cuts[ci], b + SHARED_BATCH_READS)
+                        b1 = min(cuts[ci], b + (SHARED_BATCH_READS // 4 if getattr(pool, 'inline', False) else SHARED_BATCH_READS))
                         t1 = time.perf_counter()
                         region = k % regions
                         if k >= regions:   # (a region's first use waits for nothing -- and the handle may still be in the making)
@@ -872,15 +893,21 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             # batch n).  With arenas nothing of the handle is needed to decode the first batches: the reader thread starts BEFORE the
             # handle is created, and the readers decode while 12 000 automata are placed and packed.
             probe = engine_cls if isinstance(engine_cls, type) else None   # (what the engine can do, asked of its class)
-            arenas = (pool is not None and probe is not None and hasattr(probe, 'submit_raw_parts') and hasattr(probe, 'ARENA_REGIONS')
+            arenas = (probe is not None and hasattr(probe, 'submit_raw_parts') and hasattr(probe, 'ARENA_REGIONS')
                       and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS') and len(mine) > 0)
+            if pool is None and arenas and fast5_on_workers:
+                # no reader processes (one thread, few loci, or they could not be started): the same arenas, filled by the reader
+                # thread itself -- a read is opened once (no pass for the lengths first) and decoded beside the calling thread
+                pool = _InlinePool()
+                pools.append(pool)
+            arenas = arenas and pool is not None
             # (and if the engine decodes VBZ itself -- wsx_vbz_decode -- the readers stop at the zstd frame's content: StreamVByte,
             # zig-zag and the running sum are a quarter of a reader's time per read and 0.6 of the bytes to upload)
             gpu_vbz = arenas and hasattr(probe, 'submit_vbz_parts') and not os.environ.get('WARPSTR_NO_GPU_VBZ')
             reader = None
             try:
                 if arenas:
-                    tm['reader_mode'] = 'arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas'
+                    tm['reader_mode'] = ('arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas') + (', filled in this process' if getattr(pool, 'inline', False) else '')
                     reader = threading.Thread(target=produce, args=(arena_batches,), name='warpstr-reader', daemon=True)
                     reader.start()
                 make_engine()
