@@ -107,9 +107,8 @@ def test_keys_that_ask_for_more_bytes_than_the_block_has(hip):
     fits = int(np.searchsorted(np.cumsum(lens), len(bad) - (n + 3) // 4, side='right'))   # values whose bytes are there
     ref = vbz.svb_decode(np.concatenate([bad, np.zeros(4 * n, np.uint8)]), n).astype(np.uint32)
     ref[fits:] = 0
-    # (a lane decodes its four values or none: the first lane that runs over gives zeros for all four)
-    first_bad_key = fits // 4
-    ref[4 * first_bad_key:] = 0
+    # (a lane decodes the four values of its key byte or none: the first lane that runs over gives zeros for all four)
+    ref[4 * (fits // 4):] = 0
     assert np.array_equal(outs[1], vbz.samples_from_values(ref, True))
 
 

@@ -11,7 +11,7 @@
 //   the sample                        = sum of the differences up to it, mod 2^16 (scan over the values)
 // vbz_decode_kernel: a workgroup of 256 lanes per block (a read's chunk: 60-170 k samples), 1024 values per round -- a lane takes
 // a key byte, i.e. four values: their lengths, a workgroup scan, <= 16 data bytes, four differences, a second workgroup scan,
-// four samples.  Integer work, bit-exact against the host decoders (warpstr_amd/fast5.py, csrc/host_loci.cpp).
+// four samples; the next round's keys are fetched a round ahead.  Integer work, bit-exact against the host decoders (warpstr_amd/fast5.py, csrc/host_loci.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -22,6 +22,8 @@
 namespace {
 
 constexpr int VBZ_LANES = 256;
+constexpr int VBZ_KEYS = 1; // key bytes per lane and round (two -- eight values, half the barriers -- is slower: 1.00 vs 0.84 ms per
+                            // 2 048 blocks, the lane's chain of dependent byte loads is twice as long)
 
 __device__ __forceinline__ int wave_inclusive_sum(int v)
 {
@@ -54,13 +56,28 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
     long long doff = 0; // bytes of the values before this round (the same in every lane)
     int acc = 0;        // sum of the differences before this round; only its low 16 bits matter
     bool bad = false;
-    for (int k0 = 0; k0 < nkeys; k0 += VBZ_LANES) {
-        const int ki = k0 + tid;
-        const int valid = ki < nkeys ? min(4, n - 4 * ki) : 0; // values of this lane's key byte that exist
-        const int key = valid > 0 ? p[ki] : 0;
-        const int l0 = valid > 0 ? (key & 3) + 1 : 0, l1 = valid > 1 ? ((key >> 2) & 3) + 1 : 0;
-        const int l2 = valid > 2 ? ((key >> 4) & 3) + 1 : 0, l3 = valid > 3 ? (key >> 6) + 1 : 0;
-        const int tl = l0 + l1 + l2 + l3;
+    constexpr int V = 4 * VBZ_KEYS;
+    // the keys of the next round are fetched a round ahead: they depend on nothing (the values' bytes do: on the scan)
+    int key_next[VBZ_KEYS];
+#pragma unroll
+    for (int q = 0; q < VBZ_KEYS; q++) {
+        const int ki = VBZ_KEYS * tid + q;
+        key_next[q] = ki < nkeys ? p[ki] : 0;
+    }
+    for (int k0 = 0; k0 < nkeys; k0 += VBZ_KEYS * VBZ_LANES) {
+        const int kfirst = k0 + VBZ_KEYS * tid; // this lane's first key byte; its values: 4 * kfirst ..
+        int len[V];
+#pragma unroll
+        for (int q = 0; q < VBZ_KEYS; q++) {
+            const int key = key_next[q];
+            const int kn = kfirst + VBZ_KEYS * VBZ_LANES + q;
+            key_next[q] = kn < nkeys ? p[kn] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) len[4 * q + j] = 4 * (kfirst + q) + j < n ? ((key >> (2 * j)) & 3) + 1 : 0;
+        }
+        int tl = 0;
+#pragma unroll
+        for (int j = 0; j < V; j++) tl += len[j];
         const int incl = wave_inclusive_sum(tl);
         if (lane == 63) wsum[0][wave] = incl;
         __syncthreads();
@@ -72,28 +89,27 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
             round_bytes += s;
         }
         const long long my = doff + before + incl - tl;
-        uint32_t v[4] = {0, 0, 0, 0};
+        int sum[V]; // running sum of this lane's differences
+        int run = 0;
         if (my + tl <= data_bytes) {
             const uint8_t *q = data + my;
-            const int len[4] = {l0, l1, l2, l3};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < V; j++) {
                 uint32_t x = 0;
                 if (len[j] > 0) x = q[0];
                 if (len[j] > 1) x |= (uint32_t)q[1] << 8;
                 if (len[j] > 2) x |= (uint32_t)q[2] << 16;
                 if (len[j] > 3) x |= (uint32_t)q[3] << 24;
-                v[j] = x;
                 q += len[j];
+                run += zigzag ? (int)((x >> 1) ^ (0u - (x & 1u))) : (int)x;
+                sum[j] = run;
             }
-        } else if (tl > 0) {
-            bad = true; // the keys ask for bytes the block does not have: zeros from here on
-        }
-        int d[4];
+        } else {
+            if (tl > 0) bad = true; // the keys ask for bytes the block does not have: zeros from here on
 #pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = zigzag ? (int)((v[j] >> 1) ^ (0u - (v[j] & 1u))) : (int)v[j];
-        const int s0 = d[0], s1 = s0 + d[1], s2 = s1 + d[2], s3 = s2 + d[3];
-        const int vincl = wave_inclusive_sum(s3);
+            for (int j = 0; j < V; j++) sum[j] = 0;
+        }
+        const int vincl = wave_inclusive_sum(run);
         if (lane == 63) wsum[1][wave] = vincl;
         __syncthreads();
         int vbefore = 0, round_sum = 0;
@@ -103,12 +119,11 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
             vbefore += w < wave ? s : 0;
             round_sum += s;
         }
-        const int base = acc + vbefore + vincl - s3;
-        int16_t *o = out + 4 * (size_t)ki;
-        if (valid > 0) o[0] = (int16_t)(base + s0);
-        if (valid > 1) o[1] = (int16_t)(base + s1);
-        if (valid > 2) o[2] = (int16_t)(base + s2);
-        if (valid > 3) o[3] = (int16_t)(base + s3);
+        const int base = acc + vbefore + vincl - run;
+        int16_t *o = out + 4 * (size_t)kfirst;
+#pragma unroll
+        for (int j = 0; j < V; j++)
+            if (len[j] > 0) o[j] = (int16_t)(base + sum[j]);
         acc += round_sum;
         doff += round_bytes;
         // (wsum[0] is written again after the second barrier of this round, wsum[1] after the first of the next: two suffice)
