@@ -561,14 +561,79 @@ def cfg5_driver_leg(reads_per_locus, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def vbz_kernel_leg(path, local, n_blocks=2048, launches=20):
+    """wsx_vbz_decode alone at the size of a from_fast5 batch: n_blocks blocks cycling through the upstream test file's ten reads
+    (their real StreamVByte blocks, zstd undone), HIP-event time per launch on the handle's stream against the bytes a launch has
+    to move (block bytes in + 2 B per sample out); the first ten blocks checked against oracle/vbz.py."""
+    import ctypes as C
+    import struct
+
+    import torch
+
+    from oracle import vbz as ovbz
+    from warpstr_amd import _lib, fast5, synth
+    from warpstr_amd.caller import HipCaller
+    h, zs = fast5._libs()
+    real = []
+    with fast5.Fast5File(path) as f:
+        for rid in f.read_ids():
+            d, n, prm, chunk_len = f._open_signal(rid)
+            try:
+                for _, _, buf, size, plain in f._chunks(d, n, chunk_len):
+                    assert not plain and prm[:2] == [0, 2] and struct.unpack_from('<I', buf, 0)[0] == 2 * n
+                    body = bytes(buf[4:size])
+                    m = zs.ZSTD_getFrameContentSize(body, len(body))
+                    blk = C.create_string_buffer(m)
+                    assert zs.ZSTD_decompress(blk, m, body, len(body)) == m
+                    real.append((np.frombuffer(blk.raw[:m], np.uint8), n, bool(prm[2])))
+            finally:
+                h.H5Dclose(d)
+    locus = synth.make_locus('(AGC)', 16, 1)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.Stream(device=dev)
+    hip = HipCaller([locus.template, locus.reverse], [16, 16], device=local, stream=stream.cuda_stream)
+    blobs = [real[i % len(real)] for i in range(n_blocks)]
+    src = np.concatenate([np.concatenate([b[0], np.zeros(-len(b[0]) % 16, np.uint8)]) for b in blobs])
+    blocks = np.zeros(n_blocks, _lib.VBZ_BLOCK_DTYPE)
+    at = out = 0
+    for i, (blk, n, zz) in enumerate(blobs):
+        blocks[i] = (at, len(blk), out, n, _lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB)
+        at += len(blk) + (-len(blk) % 16)
+        out += n
+    with torch.cuda.stream(stream):
+        src_d = torch.from_numpy(src).to(dev)
+        dst_d = torch.empty(out, dtype=torch.int16, device=dev)
+        st_d = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+        args = (src_d.data_ptr(), len(src), blocks, dst_d.data_ptr(), out, st_d.data_ptr())
+        for _ in range(3):
+            hip.vbz_decode_device(*args)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+        ev[0].record()
+        for k in range(launches):
+            hip.vbz_decode_device(*args)
+            ev[k + 1].record()
+        stream.synchronize()
+    ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(launches)]))
+    got = dst_d.cpu().numpy()
+    ok = int(st_d.sum()) == 0 and all(np.array_equal(got[blocks[i]['dst_offset']:blocks[i]['dst_offset'] + blocks[i]['n_samples']],
+                                                     ovbz.decode_block(*blobs[i])) for i in range(min(10, n_blocks)))
+    hip.close()
+    algo = int(blocks['src_bytes'].sum()) + 2 * out
+    return {'kernel': 'vbz_decode_kernel', 'blocks_per_launch': n_blocks, 'samples_per_launch': out, 'algorithmic_bytes_per_launch': algo,
+            'launch_ms': ms, 'roofline': {'bound': 'hbm', 'achieved': algo / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algo / ms / 1e6 / 8000.0},
+            'samples_per_s': out / ms * 1e3, 'equal_to_oracle': bool(ok),
+            'note': 'a workgroup per block, two workgroup scans per 1 024 values; the from_fast5 leg needs 8 x 10^9 samples/s of it'}
+
+
 def from_fast5_leg(n_copies, local):
     """The path real input takes: .fast5 files on disk -> output files (upstream: get_workload opens one fast5 per read through
     Fast5.get_data_processed, src/caller/wrapper.py:44-54, src/schemas/fast5.py:45-57).  n_copies copies of the upstream test
     file (tests/golden/real/batch_0.fast5: 10 real VBZ-compressed R9.4 reads of 59-170 k samples) laid out as the caller-only
     input (prepare_caller_only.py: an overview per locus whose `fast5_path` column points at the read's multi-read file), one
     locus -- the upstream test locus, (AAAT) at flank 110 -- per copy, through main_wrapper_loci to every locus's output files:
-    once with the files read in this process, once on 16 reader processes (libhdf5 is not thread-safe) that decode straight
-    into the staging buffers the upload starts from.  The genotype of the outputs must be the README's (44, 40)."""
+    once with the files read in this process, once on 16 reader processes (libhdf5 is not thread-safe); either way the readers
+    undo zstd into page-locked arenas the upload starts from, and StreamVByte, zig-zag and the running sum are undone on the
+    device (wsx_vbz_decode).  The genotype of the outputs must be the README's (44, 40)."""
     import contextlib
     import io
     import json as js
@@ -696,6 +761,7 @@ def from_fast5_leg(n_copies, local):
         t['note'] = ('cold files: each read is opened once; H5Fopen / H5Fclose are per FILE of ten reads, shown per read; the decoder '
                      'call includes a second zstd pass, subtracted')
         out['per_read_ms_one_process_cold'] = t
+        out['vbz_decode_kernel'] = vbz_kernel_leg(os.path.join(real, 'batch_0.fast5'), local)
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
