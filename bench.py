@@ -679,7 +679,8 @@ def from_fast5_leg(n_copies, local):
         st = os.statvfs(root)
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
             legs.append(('sixteen_reader_processes_4x_the_copies', many, 4 * n_copies))   # batch's tail -- weigh less on a longer run)
-        for tag, threads, n in legs:
+        only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
+        for tag, threads, n in [leg for leg in legs if not only or leg[0] == only]:
             loci = make(tag, n)
             n_reads = n * len(ex)
             tm = {}

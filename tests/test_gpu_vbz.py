@@ -83,7 +83,12 @@ def test_random_streams_of_every_shape(hip):
     blobs.append(vbz.svb_encode(vals))
     specs.append((_lib.VBZ_SVB_ZIGZAG, len(vals)))
     want.append(vbz.samples_from_values(vals.astype(np.uint32), True))
-    for pad in (0, 1, 7):
+    # rounds whose 1 024 values take all four bytes each: the whole 4 KB window of a round and, at odd addresses, its 16-byte tail
+    big = rng.integers(2 ** 24, 2 ** 32, size=5000, dtype=np.uint64)
+    blobs.append(vbz.svb_encode(big))
+    specs.append((_lib.VBZ_SVB, len(big)))
+    want.append(vbz.samples_from_values(big.astype(np.uint32), False))
+    for pad in (0, 1, 7, 15):
         outs, st = decode(hip, blobs, specs, pad=pad, status=pad != 7)
         if pad != 7:
             assert (st == 0).all()

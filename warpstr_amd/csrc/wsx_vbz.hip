@@ -11,7 +11,7 @@
 //   the sample                        = sum of the differences up to it, mod 2^16 (scan over the values)
 // vbz_decode_kernel: a workgroup of 256 lanes per block (a read's chunk: 60-170 k samples), 1024 values per round -- a lane takes
 // a key byte, i.e. four values: their lengths, a workgroup scan, <= 16 data bytes, four differences, a second workgroup scan,
-// four samples; the next round's keys are fetched a round ahead.  Integer work, bit-exact against the host decoders (warpstr_amd/fast5.py, csrc/host_loci.cpp).
+// four samples; the next round's keys and the 4 KB window its value bytes lie in are fetched a round ahead (the window into LDS).  Integer work, bit-exact against the host decoders (warpstr_amd/fast5.py, csrc/host_loci.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -22,8 +22,7 @@
 namespace {
 
 constexpr int VBZ_LANES = 256;
-constexpr int VBZ_KEYS = 1; // key bytes per lane and round (two -- eight values, half the barriers -- is slower: 1.00 vs 0.84 ms per
-                            // 2 048 blocks, the lane's chain of dependent byte loads is twice as long)
+constexpr int VBZ_WINDOW = VBZ_LANES * 16; // bytes of values a round can ask for (1 024 values of four bytes)
 
 __device__ __forceinline__ int wave_inclusive_sum(int v)
 {
@@ -36,10 +35,31 @@ __device__ __forceinline__ int wave_inclusive_sum(int v)
     return v;
 }
 
-__global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__restrict__ src, const wsx_vbz_block *__restrict__ blocks,
-                                                               int16_t *__restrict__ dst, int32_t *__restrict__ status)
+typedef uint32_t vbz_u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte chunk `chunk` of the window that starts at the 16-byte boundary at or below `from`: one wide load where that lies
+// inside [lo, hi) (the whole of src), byte by byte at the two ends of the buffer
+__device__ __forceinline__ vbz_u32x4 window_load(const uint8_t *from, const uint8_t *lo, const uint8_t *hi, int chunk)
 {
-    __shared__ int wsum[2][VBZ_LANES / 64]; // per wavefront: bytes, differences
+    const uint8_t *a = (const uint8_t *)((uintptr_t)from & ~(uintptr_t)15) + 16 * chunk;
+    vbz_u32x4 w = {0, 0, 0, 0};
+    if (a >= lo && a + 16 <= hi) {
+        w = *(const vbz_u32x4 *)a;
+    } else if (a + 16 > lo && a < hi) {
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++)
+            if (a + i >= lo && a + i < hi) t[i >> 2] |= (uint32_t)a[i] << (8 * (i & 3));
+        w = vbz_u32x4{t[0], t[1], t[2], t[3]};
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__restrict__ src, long long src_total,
+                                                               const wsx_vbz_block *__restrict__ blocks, int16_t *__restrict__ dst,
+                                                               int32_t *__restrict__ status)
+{
+    __shared__ int wsum[2][VBZ_LANES / 64];                      // per wavefront: bytes, differences
+    __shared__ __attribute__((aligned(16))) uint8_t win[2][VBZ_WINDOW + 16]; // the value bytes of this round and of the next
     const wsx_vbz_block B = blocks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = B.n_samples;
@@ -56,31 +76,27 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
     long long doff = 0; // bytes of the values before this round (the same in every lane)
     int acc = 0;        // sum of the differences before this round; only its low 16 bits matter
     bool bad = false;
-    constexpr int V = 4 * VBZ_KEYS;
-    // the keys of the next round are fetched a round ahead: they depend on nothing (the values' bytes do: on the scan)
-    int key_next[VBZ_KEYS];
-#pragma unroll
-    for (int q = 0; q < VBZ_KEYS; q++) {
-        const int ki = VBZ_KEYS * tid + q;
-        key_next[q] = ki < nkeys ? p[ki] : 0;
-    }
-    for (int k0 = 0; k0 < nkeys; k0 += VBZ_KEYS * VBZ_LANES) {
-        const int kfirst = k0 + VBZ_KEYS * tid; // this lane's first key byte; its values: 4 * kfirst ..
-        int len[V];
-#pragma unroll
-        for (int q = 0; q < VBZ_KEYS; q++) {
-            const int key = key_next[q];
-            const int kn = kfirst + VBZ_KEYS * VBZ_LANES + q;
-            key_next[q] = kn < nkeys ? p[kn] : 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) len[4 * q + j] = 4 * (kfirst + q) + j < n ? ((key >> (2 * j)) & 3) + 1 : 0;
-        }
-        int tl = 0;
-#pragma unroll
-        for (int j = 0; j < V; j++) tl += len[j];
+    // A round's chain would be: key byte (global) -> scan -> value bytes (global, at an address the scan gives) -> scan -> store.
+    // Both loads are taken out of it: the keys of round r+1 depend on nothing and are fetched in round r; the value bytes of round
+    // r+1 start where round r's end -- known after round r's FIRST scan -- so the 4 KB window that holds them, whatever the keys of
+    // round r+1 will say, is fetched then (one 16-byte load per lane), lands in LDS at the end of round r and is read from there.
+    int key_next = tid < nkeys ? p[tid] : 0;
+    // (the window is 4 096 + 16 bytes: it starts at a 16-byte boundary up to 15 bytes before the round's first value byte; the last
+    // chunk is lane 0's second load)
+    *(vbz_u32x4 *)&win[0][16 * tid] = window_load(data, src, src + src_total, tid);
+    if (tid == 0) *(vbz_u32x4 *)&win[0][VBZ_WINDOW] = window_load(data, src, src + src_total, VBZ_LANES);
+    int par = 0;
+    for (int k0 = 0; k0 < nkeys; k0 += VBZ_LANES, par ^= 1) {
+        const int ki = k0 + tid;
+        const int valid = ki < nkeys ? min(4, n - 4 * ki) : 0; // values of this lane's key byte that exist
+        const int key = key_next;
+        key_next = ki + VBZ_LANES < nkeys ? p[ki + VBZ_LANES] : 0;
+        const int l0 = valid > 0 ? (key & 3) + 1 : 0, l1 = valid > 1 ? ((key >> 2) & 3) + 1 : 0;
+        const int l2 = valid > 2 ? ((key >> 4) & 3) + 1 : 0, l3 = valid > 3 ? (key >> 6) + 1 : 0;
+        const int tl = l0 + l1 + l2 + l3;
         const int incl = wave_inclusive_sum(tl);
         if (lane == 63) wsum[0][wave] = incl;
-        __syncthreads();
+        __syncthreads(); // (also: the window of this round, written at the end of the last, is in LDS)
         int before = 0, round_bytes = 0;
 #pragma unroll
         for (int w = 0; w < VBZ_LANES / 64; w++) {
@@ -88,29 +104,36 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
             before += w < wave ? s : 0;
             round_bytes += s;
         }
+        const vbz_u32x4 next = window_load(data + doff + round_bytes, src, src + src_total, tid); // (in flight during this round)
+        vbz_u32x4 next_tail = {0, 0, 0, 0};
+        if (tid == 0) next_tail = window_load(data + doff + round_bytes, src, src + src_total, VBZ_LANES);
         const long long my = doff + before + incl - tl;
-        int sum[V]; // running sum of this lane's differences
-        int run = 0;
+        const int at = (int)(((uintptr_t)(data + doff) & 15) + (my - doff)); // this lane's first byte in the window
+        uint32_t v[4] = {0, 0, 0, 0};
         if (my + tl <= data_bytes) {
-            const uint8_t *q = data + my;
+            const uint8_t *q = &win[par][at];
+            const int len[4] = {l0, l1, l2, l3};
 #pragma unroll
-            for (int j = 0; j < V; j++) {
+            for (int j = 0; j < 4; j++) {
                 uint32_t x = 0;
                 if (len[j] > 0) x = q[0];
                 if (len[j] > 1) x |= (uint32_t)q[1] << 8;
                 if (len[j] > 2) x |= (uint32_t)q[2] << 16;
                 if (len[j] > 3) x |= (uint32_t)q[3] << 24;
+                v[j] = x;
                 q += len[j];
-                run += zigzag ? (int)((x >> 1) ^ (0u - (x & 1u))) : (int)x;
-                sum[j] = run;
             }
-        } else {
-            if (tl > 0) bad = true; // the keys ask for bytes the block does not have: zeros from here on
-#pragma unroll
-            for (int j = 0; j < V; j++) sum[j] = 0;
+        } else if (tl > 0) {
+            bad = true; // the keys ask for bytes the block does not have: zeros from here on
         }
-        const int vincl = wave_inclusive_sum(run);
+        int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] = zigzag ? (int)((v[j] >> 1) ^ (0u - (v[j] & 1u))) : (int)v[j];
+        const int s0 = d[0], s1 = s0 + d[1], s2 = s1 + d[2], s3 = s2 + d[3];
+        const int vincl = wave_inclusive_sum(s3);
         if (lane == 63) wsum[1][wave] = vincl;
+        *(vbz_u32x4 *)&win[par ^ 1][16 * tid] = next; // (last read in the round before this one, two barriers ago)
+        if (tid == 0) *(vbz_u32x4 *)&win[par ^ 1][VBZ_WINDOW] = next_tail;
         __syncthreads();
         int vbefore = 0, round_sum = 0;
 #pragma unroll
@@ -119,11 +142,12 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
             vbefore += w < wave ? s : 0;
             round_sum += s;
         }
-        const int base = acc + vbefore + vincl - run;
-        int16_t *o = out + 4 * (size_t)kfirst;
-#pragma unroll
-        for (int j = 0; j < V; j++)
-            if (len[j] > 0) o[j] = (int16_t)(base + sum[j]);
+        const int base = acc + vbefore + vincl - s3;
+        int16_t *o = out + 4 * (size_t)ki;
+        if (valid > 0) o[0] = (int16_t)(base + s0);
+        if (valid > 1) o[1] = (int16_t)(base + s1);
+        if (valid > 2) o[2] = (int16_t)(base + s2);
+        if (valid > 3) o[3] = (int16_t)(base + s3);
         acc += round_sum;
         doff += round_bytes;
         // (wsum[0] is written again after the second barrier of this round, wsum[1] after the first of the next: two suffice)
@@ -190,7 +214,7 @@ try {
     VCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
     VCHK(hipEventRecord(ev, st));
     if (status) VCHK(hipMemsetAsync(status, 0, (size_t)n_blocks * sizeof(int32_t), st));
-    hipLaunchKernelGGL(vbz_decode_kernel, dim3((unsigned)n_blocks), dim3(VBZ_LANES), 0, st, src, (const wsx_vbz_block *)d, dst, status);
+    hipLaunchKernelGGL(vbz_decode_kernel, dim3((unsigned)n_blocks), dim3(VBZ_LANES), 0, st, src, (long long)src_bytes, (const wsx_vbz_block *)d, dst, status);
     VCHK(hipGetLastError());
     return WSX_SUCCESS;
 } catch (...) {
