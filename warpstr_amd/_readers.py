@@ -137,15 +137,17 @@ def _arena_address(region: int, samples: int) -> int:
     return ctypes.addressof(_arena(region, samples)[2])
 
 
-def _drop_arenas():
-    for rec in list(_ARENAS.values()):
+def _drop_arenas(owner=None):
+    """Unlink and forget the arenas (of the regions whose key starts with `owner`: a run that filled arenas in its own process
+    drops its own -- loci._InlinePool -- and leaves those of a run on another thread alone)."""
+    for key in [k for k in _ARENAS if owner is None or str(k).startswith(owner)]:
+        rec = _ARENAS.pop(key)
         try:
             os.unlink(rec[0])
         except OSError:
             pass
-    _ARENAS.clear()
-    _CURSOR.clear()
-    _BYTE_CURSOR.clear()
+        _CURSOR.pop(key, None)
+        _BYTE_CURSOR.pop(key, None)
 
 
 def decode_arena(args):

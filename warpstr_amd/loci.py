@@ -380,17 +380,23 @@ class _InlinePool:
     _max_workers = 1
     inline = True
 
+    def __init__(self):
+        self.owner = f'run{id(self):x}.'   # (its regions' keys in _readers: another run on another thread has its own)
+
     def submit(self, func, item):
         from concurrent.futures import Future
         future = Future()
         try:
+            if func in (_decode_arena, _pack_arena):
+                item = (f'{self.owner}{item[0]}',) + tuple(item[1:])
             future.set_result(func(item))
         except BaseException as e:  # noqa: BLE001 -- raised where the future is waited for
             future.set_exception(e)
         return future
 
     def shutdown(self, **_):
-        pass
+        from . import _readers
+        _readers._drop_arenas(self.owner)
 
 
 def _reader_pool(threads: int, n_loci: int):
@@ -512,7 +518,6 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
         from . import _readers
         while _readers._OPEN:
             _readers._OPEN.popitem()[1].close()
-        _readers._drop_arenas()   # (arenas this process filled itself: _InlinePool)
         if executor is not None:
             executor.shutdown(wait=True)
         for pool in pools:
