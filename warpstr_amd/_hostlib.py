@@ -234,37 +234,42 @@ def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, off
         h.wsh_free(out)
 
 
+_LAZY_CLASS = None
+
+
 def _native_table(a: WshAutomaton, kmersize: int, owner):
-    from .automata import AutomatonTable
+    """An AutomatonTable whose arrays stay in the library's memory until somebody looks at them: the handle of a run takes
+    the pointers as they are (caller.HipCaller), a run of thousands of loci never builds the 14 000 NumPy arrays."""
+    global _LAZY_CLASS
+    if _LAZY_CLASS is None:   # (made once, and not at import: automata.py imports this module)
+        from .automata import AutomatonTable
 
-    class _Lazy(AutomatonTable):
-        """An AutomatonTable whose arrays stay in the library's memory until somebody looks at them: the handle of a run takes
-        the pointers as they are (caller.HipCaller), a run of thousands of loci never builds the 14 000 NumPy arrays."""
+        class _Lazy(AutomatonTable):
+            def __init__(self, a, kmersize, owner):  # noqa: D107 -- no arrays yet
+                self.n_states, self.endstate, self.repstart, self.repend = a.n_states, a.endstate, a.repstart, a.repend
+                self.kmersize, self._kmers, self._succ = kmersize, None, None
+                self._n_edges = a.n_edges
+                self._owner = owner
+                self.native_ptrs = (a.value, a.seq_idx, a.pred_ptr, a.pred_idx, a.repeat_mask, a.last_base)
+                self._kmer_ptr = a.kmer
 
-        def __init__(self):  # noqa: D107 -- no arrays yet
-            self.n_states, self.endstate, self.repstart, self.repend = a.n_states, a.endstate, a.repstart, a.repend
-            self.kmersize, self._kmers, self._succ = kmersize, None, None
-            self._n_edges = a.n_edges
-            self._owner = owner
-            self.native_ptrs = (a.value, a.seq_idx, a.pred_ptr, a.pred_idx, a.repeat_mask, a.last_base)
-            self._kmer_ptr = a.kmer
+            def __getattr__(self, name):  # only reached for attributes that are not set yet: the arrays
+                if name in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer_codes'):
+                    S, E = self.n_states, self._n_edges
+                    p = self.native_ptrs
+                    self.value, self.seq_idx = _copy(p[0], np.float64, S), _copy(p[1], np.int32, S)
+                    self.pred_ptr, self.pred_idx = _copy(p[2], np.int32, S + 1), _copy(p[3], np.int32, E)
+                    self.repeat_mask, self.last_base = _copy(p[4], np.uint8, S), _copy(p[5], np.uint8, S)
+                    self.kmer_codes = _copy(self._kmer_ptr, np.uint32, S)
+                    return self.__dict__[name]
+                raise AttributeError(name)
 
-        def __getattr__(self, name):  # only reached for attributes that are not set yet: the arrays
-            if name in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer_codes'):
-                S, E = self.n_states, self._n_edges
-                p = self.native_ptrs
-                self.value, self.seq_idx = _copy(p[0], np.float64, S), _copy(p[1], np.int32, S)
-                self.pred_ptr, self.pred_idx = _copy(p[2], np.int32, S + 1), _copy(p[3], np.int32, E)
-                self.repeat_mask, self.last_base = _copy(p[4], np.uint8, S), _copy(p[5], np.uint8, S)
-                self.kmer_codes = _copy(self._kmer_ptr, np.uint32, S)
-                return self.__dict__[name]
-            raise AttributeError(name)
-
-        def __deepcopy__(self, memo):
-            return AutomatonTable(self.n_states, self.endstate, self.value.copy(), self.seq_idx.copy(), self.pred_ptr.copy(),
-                                  self.pred_idx.copy(), self.repeat_mask.copy(), self.last_base.copy(), repstart=self.repstart,
-                                  repend=self.repend, kmer_codes=self.kmer_codes.copy(), kmersize=self.kmersize)
-    return _Lazy()
+            def __deepcopy__(self, memo):
+                return AutomatonTable(self.n_states, self.endstate, self.value.copy(), self.seq_idx.copy(), self.pred_ptr.copy(),
+                                      self.pred_idx.copy(), self.repeat_mask.copy(), self.last_base.copy(), repstart=self.repstart,
+                                      repend=self.repend, kmer_codes=self.kmer_codes.copy(), kmersize=self.kmersize)
+        _LAZY_CLASS = _Lazy
+    return _LAZY_CLASS(a, kmersize, owner)
 
 
 def store_many(overviews, locus_paths, start, len1, len2, cost1, cost2, seq2, off2, write: bool):
