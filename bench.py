@@ -597,7 +597,7 @@ def vbz_kernel_leg(path, local, n_blocks=2048, launches=20):
     blocks = np.zeros(n_blocks, _lib.VBZ_BLOCK_DTYPE)
     at = out = 0
     for i, (blk, n, zz) in enumerate(blobs):
-        blocks[i] = (at, len(blk), out, n, _lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB)
+        blocks[i] = (at, len(blk), out, n, _lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB, n, 0)
         at += len(blk) + (-len(blk) % 16)
         out += n
     with torch.cuda.stream(stream):

@@ -261,8 +261,8 @@ int wsx_prepare_signals(wsx_caller *c, int mem, const int16_t *raw, const int64_
  * where a value's bytes start, and the running sum of the differences -- which this entry point computes a workgroup per block.
  *   src            device: the blocks' bytes (StreamVByte blocks as they leave zstd, or plain little-endian int16 samples)
  *   blocks         host wsx_vbz_block[n_blocks]: where a block lies in src, what it is, where its samples go in dst.
- *                  Checked before anything is enqueued (WSX_ERR_INVALID: a block outside src / dst, fewer bytes than its
- *                  key area plus one byte per value); copied before the call returns
+ *                  Checked before anything is enqueued (WSX_ERR_INVALID: a block outside src / dst, n_values < n_samples, fewer
+ *                  bytes than its key area plus one byte per value); copied before the call returns
  *   dst            device int16: sample dst_offset + i of block b is its i-th sample (the running sum wraps as int16 does)
  *   status         device int32[n_blocks] or NULL: 0, or 1 for a block whose keys ask for more bytes than it has (its
  *                  samples from there on are those of zero bytes; nothing outside the block is read).  Valid in stream order
@@ -273,8 +273,11 @@ typedef struct wsx_vbz_block {
     int64_t src_offset; /* first byte of the block in src */
     int64_t src_bytes;  /* its size */
     int64_t dst_offset; /* its first sample in dst (in samples) */
-    int32_t n_samples;
+    int32_t n_samples;  /* samples wanted of it: its first n_samples */
     int32_t kind;       /* WSX_VBZ_PLAIN: int16 samples; WSX_VBZ_SVB_ZIGZAG / WSX_VBZ_SVB: StreamVByte of (zig-zag) differences */
+    int32_t n_values;   /* values the block codes (>= n_samples; its key area is ceil(n_values / 4) bytes): HDF5 hands a filter the
+                           whole chunk, so the last chunk of a dataset codes chunk-length values of which the dataset holds fewer */
+    int32_t reserved;   /* 0 */
 } wsx_vbz_block;
 enum { WSX_VBZ_PLAIN = 0, WSX_VBZ_SVB_ZIGZAG = 1, WSX_VBZ_SVB = 2 };
 int wsx_vbz_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const wsx_vbz_block *blocks, int64_t n_blocks,

@@ -24,7 +24,7 @@ src = np.concatenate([np.concatenate([b[1], np.zeros(-len(b[1]) % 16, np.uint8)]
 blocks = np.zeros(n_blocks, _lib.VBZ_BLOCK_DTYPE)
 at = out = 0
 for i, (_, blk, n, zz) in enumerate(blobs):
-    blocks[i] = (at, len(blk), out, n, _lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB)
+    blocks[i] = (at, len(blk), out, n, _lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB, n, 0)
     at += len(blk) + (-len(blk) % 16)
     out += n
 with torch.cuda.stream(stream):

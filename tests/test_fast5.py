@@ -229,3 +229,73 @@ def test_core_reader_equals_the_array_reader_on_every_storage(tmp_path):
                 assert c.signal_length(rid) == n
                 if expect is not None:
                     assert np.array_equal(want, expect)
+
+
+@needs_hdf5
+@pytest.mark.parametrize('zigzag,level', [(True, 1), (False, 3), (True, 0)])
+def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
+    """Reads whose dataset is several VBZ chunks (tests/helpers.write_vbz_fast5: coded by oracle/vbz.py's encoder, written without
+    the plugin): the last chunk codes a whole chunk of which the dataset holds a part, one chunk is stored with the filter skipped.
+    Every way of reading them gives the samples: the array reader, its NumPy decoders alone, the core reader to an address, and the
+    blocks the device decoder takes (checked here by the oracle)."""
+    import ctypes
+    from oracle import vbz
+    from tests.helpers import write_vbz_fast5
+    from warpstr_amd import _h5core, _readers
+    rng = np.random.default_rng(int(zigzag) + 2 * level)
+    reads = {'r0': np.cumsum(rng.integers(-200, 201, size=10000)).astype(np.int16),       # 2.44 chunks
+             'r1': rng.integers(-32768, 32768, size=4096).astype(np.int16),               # exactly one chunk, every code length
+             'r2': np.cumsum(rng.integers(-5, 6, size=1)).astype(np.int16),               # a single sample
+             'r3': np.cumsum(rng.integers(-90, 91, size=12289)).astype(np.int16)}         # three chunks and one sample
+    path = write_vbz_fast5(str(tmp_path / 'multi.fast5'), reads, 4096, zigzag, level, skip_filter_on=(1,))
+    with fast5.Fast5File(path) as f:
+        assert sorted(f.read_ids()) == sorted(reads)
+        for rid, sig in reads.items():
+            assert np.array_equal(f.raw_signal(rid), sig), rid
+            assert f.signal_length(rid) == len(sig)
+    with _h5core.Fast5Core(path) as c:
+        for rid, sig in reads.items():
+            buf = np.full(len(sig) + 4, 777, np.int16)
+            assert c.decode_to(rid, lambda n: buf.ctypes.data + 4) == len(sig)
+            assert np.array_equal(buf[2:-2], sig) and (buf[:2] == 777).all() and (buf[-2:] == 777).all()
+            room = np.zeros(4 * len(sig) + 65536, np.uint8)
+            at, offs = [0], []
+
+            def place(nbytes):
+                at[0] = (at[0] + 15) & ~15
+                offs.append(at[0])
+                at[0] += nbytes
+                assert at[0] <= len(room)
+                return room.ctypes.data + offs[-1]
+            n, blocks = c.blocks_to(rid, place)
+            assert n == len(sig) and len(blocks) == -(-len(sig) // 4096) and sum(b[2] for b in blocks) == n
+            pieces = []
+            for (kind, nbytes, ns, nv), off in zip(blocks, offs):
+                blk = room[off:off + nbytes]
+                assert nv >= ns and (kind == _h5core.PLAIN) == (len(pieces) == 1 and len(blocks) > 1)
+                pieces.append(blk.view(np.int16)[:ns] if kind == _h5core.PLAIN else vbz.decode_block(blk, nv, kind == _h5core.SVB_ZIGZAG)[:ns])
+            assert np.array_equal(np.concatenate(pieces), sig)
+    # the NumPy decoders alone (a build without _host_loci.so takes them)
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from warpstr_amd import fast5; f = fast5.Fast5File(%r); "
+            "assert fast5._vbz_native() is None; np.save(%r, np.concatenate([f.raw_signal(r) for r in %r]))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, str(tmp_path / 'np.npy'), sorted(reads)))
+    subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, WARPSTR_NO_HOST_NATIVE='1'))
+    assert np.array_equal(np.load(str(tmp_path / 'np.npy')), np.concatenate([reads[r] for r in sorted(reads)]))
+    # ... and what a reader process hands the parent of a GPU run (several blocks per read)
+    items = [(str(tmp_path / 'absent'), path, rid) for rid in reads]
+    arena, cap, base, used, lens, table, _ = _readers.pack_arena(('test_vbz_chunks', 1, items))
+    try:
+        t = np.frombuffer(table, np.int64).reshape(-1, 6)
+        assert lens == [len(reads[r]) for r in reads] and len(t) == sum(-(-len(s) // 4096) for s in reads.values())
+        view = np.memmap(arena, dtype=np.uint8, mode='r')
+        got = {r: [] for r in range(len(reads))}
+        for r, kind, off, nbytes, ns, nv in t:
+            blk = np.array(view[off:off + nbytes])
+            got[int(r)].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(nv), kind == 1)[:ns])
+        for r, rid in enumerate(reads):
+            assert np.array_equal(np.concatenate(got[r]), reads[rid])
+    finally:
+        _readers._drop_arenas('test_vbz_chunks')
+    assert ctypes.sizeof(ctypes.c_int16) == 2

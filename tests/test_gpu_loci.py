@@ -291,3 +291,45 @@ def test_fast5_reads_decoded_by_reader_processes_into_the_upload_buffers(tmp_pat
         assert 0 < tm_a['uploaded_bytes'] < 0.75 * tm_a['raw_bytes']
     assert tm_b['reader_processes'] == 0
     _same(a, b)
+
+
+def test_reads_whose_datasets_are_several_vbz_chunks(tmp_path, monkeypatch):
+    """Reads stored as several VBZ chunks each (tests/helpers.write_vbz_fast5: the last chunk codes a whole chunk of which the
+    dataset holds a part, one chunk has the filter skipped): several blocks per read through wsx_vbz_decode -- the samples of a
+    read's later blocks land behind its earlier ones -- against the same run with the readers decoding themselves."""
+    from tests.helpers import write_vbz_fast5
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    rng = np.random.default_rng(77)
+    # ten reads of 9-23 k samples around the levels of a squiggle, in chunks of 4 096
+    reads = {f'read{k:02d}': (rng.normal(520, 70, size=int(rng.integers(9000, 23000)))).astype(np.int16) for k in range(10)}
+    src = write_vbz_fast5(str(tmp_path / 'chunks.fast5'), reads, 4096, skip_filter_on=(2,))
+    ids = list(reads)
+
+    def make(root):
+        loci = []
+        for li in range(70):
+            pattern, fl, _ = MANY[li % len(MANY)]
+            locus = synth.make_locus(pattern, fl, 900 + li)
+            loc = os.path.join(root, f'locus{li}')
+            ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+            rows = [ids[(li + k) % 10] for k in range(1 + li % 3)]
+            pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool((li + k) & 1) for k in range(len(rows))], 'saved': 1,
+                          'l_start_raw': 3000 + 10 * li, 'r_end_raw': 4500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+            loci.append(LocusPath(loc, pattern, fl))
+        return loci
+    monkeypatch.setattr('warpstr_amd.loci.SHARED_BATCH_READS', 24)
+    a, b, c = make(str(tmp_path / 'a')), make(str(tmp_path / 'b')), make(str(tmp_path / 'c'))
+    tm_a, tm_b, tm_c = {}, {}, {}
+    main_wrapper_loci(a, 3, quiet=True, timings=tm_a)
+    main_wrapper_loci(c, 1, quiet=True, timings=tm_c)
+    monkeypatch.setenv('WARPSTR_NO_GPU_VBZ', '1')
+    main_wrapper_loci(b, 3, quiet=True, timings=tm_b)
+    assert tm_a['reader_mode'] == 'arenas, VBZ decoded on the GPU' and tm_b['reader_mode'] == 'arenas'
+    assert tm_c['reader_mode'] == 'arenas, VBZ decoded on the GPU, filled in this process'
+    assert tm_a['uploaded_bytes'] < tm_a['raw_bytes'] == tm_b['raw_bytes'] == tm_c['raw_bytes']
+    _same(a, b)
+    _same(c, b)

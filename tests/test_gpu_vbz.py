@@ -22,14 +22,15 @@ def hip():
 
 
 def decode(hip, blobs, specs, pad=0, status=True):
-    """blobs: list of uint8 arrays; specs: (kind, n) per blob.  Lays the blobs out back to back behind `pad` bytes (so that they
-    start at odd addresses), runs the library, returns (samples per block, status per block)."""
+    """blobs: list of uint8 arrays; specs: (kind, n) or (kind, n wanted, n coded) per blob.  Lays the blobs out back to back behind
+    `pad` bytes (so that they start at odd addresses), runs the library, returns (samples per block, status per block)."""
     import torch
     src = np.concatenate([np.zeros(pad, np.uint8)] + [np.asarray(b, np.uint8) for b in blobs]) if blobs else np.zeros(pad, np.uint8)
     blocks = np.zeros(len(blobs), _lib.VBZ_BLOCK_DTYPE)
     at, out_at = pad, 3
-    for i, (b, (kind, n)) in enumerate(zip(blobs, specs)):
-        blocks[i] = (at, len(b), out_at, n, kind)
+    for i, (b, spec) in enumerate(zip(blobs, specs)):
+        kind, n, coded = spec if len(spec) == 3 else (spec[0], spec[1], spec[1])
+        blocks[i] = (at, len(b), out_at, n, kind, coded, 0)
         at += len(b)
         out_at += n + (i % 3)          # (gaps between the outputs: nothing may be written into them)
     dev = torch.device('cuda', hip.device)
@@ -96,6 +97,24 @@ def test_random_streams_of_every_shape(hip):
             assert np.array_equal(got, w), (pad, i, specs[i])
 
 
+def test_blocks_that_code_more_values_than_are_wanted(hip):
+    """A dataset's last chunk: HDF5 hands the filter a whole chunk, the block codes chunk-length values, the dataset holds fewer --
+    the first n_samples leave, whatever the lengths of the values behind them."""
+    rng = np.random.default_rng(21)
+    blobs, specs, want = [], [], []
+    for coded, n in ((4096, 1), (4096, 1000), (4096, 4095), (1025, 1024), (5000, 0), (3000, 2999), (20000, 7777)):
+        sig = np.cumsum(rng.integers(-3000, 3001, size=coded)).astype(np.int16)
+        for zz in (True, False):
+            blobs.append(vbz.svb_encode(vbz.values_from_samples(sig, zz)))
+            specs.append((_lib.VBZ_SVB_ZIGZAG if zz else _lib.VBZ_SVB, n, coded))
+            want.append(sig[:n])
+    for pad in (0, 5):
+        outs, st = decode(hip, blobs, specs, pad=pad)
+        assert (st == 0).all()
+        for i, (got, w) in enumerate(zip(outs, want)):
+            assert np.array_equal(got, w), (pad, i, specs[i])
+
+
 def test_keys_that_ask_for_more_bytes_than_the_block_has(hip):
     """Flagged per block, nothing outside the block is read, the blocks beside it are decoded as ever."""
     rng = np.random.default_rng(8)
@@ -123,16 +142,17 @@ def test_descriptors_the_library_refuses(hip):
     src = torch.zeros(1000, dtype=torch.uint8, device=dev)
     dst = torch.zeros(1000, dtype=torch.int16, device=dev)
 
-    def call(*block, src_bytes=1000, dst_samples=1000):
+    def call(*block, src_bytes=1000, dst_samples=1000, coded=None, reserved=0):
         blocks = np.zeros(1, _lib.VBZ_BLOCK_DTYPE)
-        blocks[0] = block
+        blocks[0] = block + (block[3] if coded is None else coded, reserved)
         hip.vbz_decode_device(src.data_ptr(), src_bytes, blocks, dst.data_ptr(), dst_samples)
     call(0, 1000, 0, 500, _lib.VBZ_PLAIN)             # fine
     call(0, 125 + 500, 500, 500, _lib.VBZ_SVB_ZIGZAG)  # fine: key area + a byte per value
     hip.synchronize()
     for block, kw in [((0, 1001, 0, 10, 0), {}), ((990, 20, 0, 5, 0), {}), ((-1, 10, 0, 5, 0), {}), ((0, 10, 996, 5, 0), {}),
                       ((0, 10, -1, 5, 0), {}), ((0, 10, 0, -1, 0), {}), ((0, 10, 0, 5, 3), {}), ((0, 9, 0, 5, 0), {}),
-                      ((0, 124 + 500, 0, 500, 1), {}), ((0, 100, 0, 10, 0), {'src_bytes': 50}), ((0, 100, 0, 10, 0), {'dst_samples': 9})]:
+                      ((0, 124 + 500, 0, 500, 1), {}), ((0, 100, 0, 10, 0), {'src_bytes': 50}), ((0, 100, 0, 10, 0), {'dst_samples': 9}),
+                      ((0, 1000, 0, 500, 1), {'coded': 499}), ((0, 1000, 0, 10, 1), {'coded': 801}), ((0, 1000, 0, 10, 1), {'reserved': 1})]:
         with pytest.raises(RuntimeError, match='wsx_vbz_decode'):
             call(*block, **kw)
     hip.vbz_decode_device(0, 0, np.zeros(0, _lib.VBZ_BLOCK_DTYPE), 0, 0)   # no blocks: nothing to do

@@ -130,12 +130,12 @@ class VbzFakeEngine(ArenaFakeEngine):
         for path, cap, base, used, lens, table in parts:
             view = np.memmap(path, dtype=np.uint8, mode='r')
             assert cap <= len(view) and base + used <= cap
-            t = np.frombuffer(table, np.int64).reshape(-1, 5)
+            t = np.frombuffer(table, np.int64).reshape(-1, 6)
             per_read = [[] for _ in lens]
-            for r, kind, off, nbytes, ns in t:
-                assert off % 16 == 0 and base <= off and off + nbytes <= base + used
+            for r, kind, off, nbytes, ns, nv in t:
+                assert off % 16 == 0 and base <= off and off + nbytes <= base + used and nv >= ns
                 blk = np.array(view[off:off + nbytes])
-                per_read[r].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(ns), kind == 1))
+                per_read[r].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(nv), kind == 1)[:ns])
             for n, pieces in zip(lens, per_read):
                 raw = np.concatenate(pieces)
                 assert len(raw) == n

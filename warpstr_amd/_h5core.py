@@ -8,7 +8,6 @@ Reference: what `Fast5.get_data_processed` reads (src/schemas/fast5.py:45-57); l
 import ctypes as C
 import glob
 import os
-import struct
 from typing import List, Optional
 
 VBZ_FILTER = 32020
@@ -98,7 +97,7 @@ _VBZ_NATIVE = False
 PLAIN, SVB_ZIGZAG, SVB = 0, 1, 2   # what a block written by Fast5Core.blocks_to holds (= WSX_VBZ_* of include/warpstr_hip.h)
 VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
-              -6: 'a VBZ chunk holds more samples than the dataset says'}
+              -6: 'a VBZ block does not fit the room made for it'}
 
 
 
@@ -276,8 +275,7 @@ class Fast5Core:
                 else:
                     if size < 4:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-1])
-                    if want != min(chunk_len, struct.unpack_from('<I', buf, 0)[0] // 2):
-                        raise NeedsNumpy()   # (a chunk that says it holds another number of samples: decoded whole, then cut)
+                    # (a dataset's last chunk codes chunk-length samples -- HDF5 hands a filter whole chunks --: the first `want`)
                     got = fn(buf, size, zigzag, level, f_size, f_dec, addr + 2 * start, want)
                     if got < 0:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS.get(int(got), f'VBZ decoder error {got}'))
@@ -291,7 +289,7 @@ class Fast5Core:
     def blocks_to(self, read_id: Optional[str], place):
         """A read as the device decoder takes it (wsx_vbz_decode): every chunk of a VBZ dataset as the StreamVByte block inside
         its zstd frame -- zstd is the part a GPU does not do --, anything else as plain int16 samples.  place(nbytes) -> the address
-        the next block goes to (asked once per block, in order).  Returns (samples of the read, [(kind, bytes, samples), ...]).
+        the next block goes to (asked once per block, in order).  Returns (samples of the read, [(kind, bytes, samples wanted, values coded), ...]).
         NeedsNumpy as for decode_to (before place() is asked for the first time, or after: the caller starts the read again)."""
         h = self.h
         d, n, vbz, chunk_len = self._open_signal(read_id)
@@ -300,7 +298,7 @@ class Fast5Core:
                 native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
                 if h.H5Dread(d, native_i16, 0, 0, 0, C.c_void_p(int(place(2 * n)))) < 0:
                     raise Fast5Error(f'{self.path}: H5Dread failed')
-                return n, [(PLAIN, 2 * n, n)]
+                return n, [(PLAIN, 2 * n, n, n)]
             native = vbz_native() if (vbz[0] == 0 and vbz[1] == 2) else None
             if native is None:
                 raise NeedsNumpy()
@@ -312,12 +310,10 @@ class Fast5Core:
                 if plain:  # the filter was skipped when this chunk was written: plain samples
                     got = min(size // 2, want)
                     C.memmove(int(place(2 * got)), buf, 2 * got)
-                    blocks.append((PLAIN, 2 * got, got))
+                    blocks.append((PLAIN, 2 * got, got, got))
                 else:
                     if size < 4:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-1])
-                    if want != min(chunk_len, struct.unpack_from('<I', buf, 0)[0] // 2):
-                        raise NeedsNumpy()
                     if level != 0:
                         cap = zs.ZSTD_getFrameContentSize(C.cast(C.addressof(buf) + 4, C.c_char_p), size - 4)
                         if cap >= (1 << 62):
@@ -327,8 +323,8 @@ class Fast5Core:
                     nb = unpack(buf, size, level, f_size, f_dec, int(place(int(cap))), int(cap), C.byref(n_out))
                     if nb < 0:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS.get(int(nb), f'VBZ decoder error {nb}'))
-                    got = want
-                    blocks.append((kind, int(nb), got))
+                    got = min(want, int(n_out.value))
+                    blocks.append((kind, int(nb), got, int(n_out.value)))
                 done += got
             if done != n:
                 raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')

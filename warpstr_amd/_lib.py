@@ -51,8 +51,8 @@ assert RESULT_DTYPE.itemsize == 56
 
 # numpy view of wsx_vbz_block (wsx_vbz_decode); kinds: WSX_VBZ_*
 VBZ_BLOCK_DTYPE = np.dtype([('src_offset', np.int64), ('src_bytes', np.int64), ('dst_offset', np.int64), ('n_samples', np.int32),
-                            ('kind', np.int32)])
-assert VBZ_BLOCK_DTYPE.itemsize == 32
+                            ('kind', np.int32), ('n_values', np.int32), ('reserved', np.int32)])
+assert VBZ_BLOCK_DTYPE.itemsize == 40
 VBZ_PLAIN, VBZ_SVB_ZIGZAG, VBZ_SVB = 0, 1, 2
 
 

@@ -190,7 +190,8 @@ def pack_arena(args):
     """decode_arena() for a parent that decodes on the GPU (wsx_vbz_decode): every read's blocks -- StreamVByte blocks as they
     leave zstd, or plain samples -- back to back (16-byte aligned) in the region's arena.  (region, generation, items) ->
     (arena path, its size in bytes, first byte of this chunk, bytes used from there, [samples of every read],
-    int64 quintuples (read of the chunk, kind, first byte in the arena, bytes, samples) of all blocks as bytes, seconds)."""
+    int64 sextuples (read of the chunk, kind, first byte in the arena, bytes, samples wanted, values coded) of all blocks as bytes,
+    seconds)."""
     import array
     import time
 
@@ -221,10 +222,10 @@ def pack_arena(args):
             del offs[n_offs:]
             raw = fast5_file(path).raw_signal(read_id)
             ctypes.memmove(place(2 * len(raw)), raw.ctypes.data, 2 * len(raw))
-            n, blocks = len(raw), [(PLAIN, 2 * len(raw), len(raw))]
+            n, blocks = len(raw), [(PLAIN, 2 * len(raw), len(raw), len(raw))]
         lens.append(int(n))
-        for (kind, nbytes, ns), off in zip(blocks, offs[n_offs:]):
-            table.extend((r, kind, off, nbytes, ns))
+        for (kind, nbytes, ns, nv), off in zip(blocks, offs[n_offs:]):
+            table.extend((r, kind, off, nbytes, ns, nv))
     cur[1] = at
     arena = _arena(region, max((at + 1) // 2, 1))
     return arena[0], 2 * arena[3], base, at - base, lens, table.tobytes(), time.perf_counter() - t0

@@ -804,7 +804,7 @@ class BatchQueue:
 
     def submit_vbz_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
         """submit_raw_parts() for readers that leave the decoding to the device (_readers.pack_arena): parts = [(arena path, its
-        size in bytes, first byte of the chunk, bytes used, [samples of every read], the blocks' quintuples as bytes), ...] in
+        size in bytes, first byte of the chunk, bytes used, [samples of every read], the blocks' sextuples as bytes), ...] in
         batch order.  One upload per chunk of what the readers wrote -- StreamVByte blocks, 0.6 of the samples' bytes --, then
         wsx_vbz_decode into the batch's int16 buffer, then the signal loader and the caller as ever."""
         import time
@@ -822,11 +822,11 @@ class BatchQueue:
         # the block table: where a block lies in the batch's byte buffer, where its samples go
         tables, at_src, first_read, spans = [], 0, 0, []
         for path, cap, base, used, ls, tb in parts:
-            t = np.frombuffer(tb, np.int64).reshape(-1, 5)
+            t = np.frombuffer(tb, np.int64).reshape(-1, 6)
             blk = np.zeros(len(t), _lib.VBZ_BLOCK_DTYPE)
             if len(t):
                 blk['src_offset'] = at_src + (t[:, 2] - base)
-                blk['src_bytes'], blk['n_samples'], blk['kind'] = t[:, 3], t[:, 4], t[:, 1]
+                blk['src_bytes'], blk['n_samples'], blk['kind'], blk['n_values'] = t[:, 3], t[:, 4], t[:, 1], t[:, 5]
                 # samples of the read's earlier blocks (a read is several blocks when its dataset has several chunks)
                 before = np.cumsum(t[:, 4]) - t[:, 4]
                 starts = np.flatnonzero(np.r_[True, t[1:, 0] != t[:-1, 0]])

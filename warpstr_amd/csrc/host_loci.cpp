@@ -1110,8 +1110,8 @@ WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8
 // block: ceil(n/4) key bytes (2 bits per value = byte length - 1, first value in the low bits), then the little-endian value
 // bytes; the values are deltas, zig-zag mapped if `zigzag`.  zstd comes as two function pointers (ZSTD_getFrameContentSize,
 // ZSTD_decompress of whatever libzstd the process loaded): this library links against nothing.
-// Returns the number of samples written, or -1 chunk too short, -2 not a sized zstd frame, -3 zstd failed, -4 StreamVByte block
-// shorter than its key area, -5 shorter than its keys say, -6 more samples than `cap`.
+// Returns the number of samples written (the chunk's, or its first `cap`), or -1 chunk too short, -2 not a sized zstd frame,
+// -3 zstd failed, -4 StreamVByte block shorter than its key area, -5 shorter than its keys say.
 typedef unsigned long long (*zstd_size_fn)(const void *, size_t);
 typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
 
@@ -1121,8 +1121,10 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
     if (n_chunk < 4) return -1;
     uint32_t n_bytes;
     memcpy(&n_bytes, chunk, 4);
-    const int64_t n = n_bytes / 2;
-    if (n > cap) return -6;
+    const int64_t coded = n_bytes / 2;   // values in the block: its key area is ceil(coded / 4) bytes
+    // (HDF5 hands a filter the whole chunk: the last chunk of a dataset codes chunk-length samples of which the dataset holds
+    // fewer -- `cap` of them are wanted, the first)
+    const int64_t n = coded < cap ? coded : cap;
     const uint8_t *svb = chunk + 4;
     int64_t svb_bytes = n_chunk - 4;
     static thread_local std::vector<uint8_t> scratch;
@@ -1135,7 +1137,7 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
         svb = scratch.data();
         svb_bytes = int64_t(size);
     }
-    const int64_t n_keys = (n + 3) / 4;
+    const int64_t n_keys = (coded + 3) / 4;
     if (svb_bytes < n_keys) return -4;
     const uint8_t *data = svb + n_keys, *end = svb + svb_bytes;
     uint32_t acc = 0;   // (the running sum wraps to 16 bits in the end: 32 are enough)

@@ -75,9 +75,10 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
         return;
     }
     const bool zigzag = B.kind == WSX_VBZ_SVB_ZIGZAG;
-    const int nkeys = (n + 3) >> 2;
-    const uint8_t *data = p + nkeys;
-    const long long data_bytes = B.src_bytes - nkeys; // (>= n: checked on the host)
+    const int nkeys = (n + 3) >> 2;                       // key bytes that matter: those of the samples wanted
+    const int key_area = (B.n_values + 3) >> 2;           // ... of all the values the block codes
+    const uint8_t *data = p + key_area;
+    const long long data_bytes = B.src_bytes - key_area; // (>= n_values: checked on the host)
     long long doff = 0; // bytes of the values before this round (the same in every lane)
     int acc = 0;        // sum of the differences before this round; only its low 16 bits matter
     bool bad = false;
@@ -201,7 +202,12 @@ try {
             wsx_internal_set_error("wsx_vbz_decode: a block lies outside src or dst");
             return WSX_ERR_INVALID;
         }
-        const int64_t least = B.kind == WSX_VBZ_PLAIN ? 2 * n : (n + 3) / 4 + n; // key area + a byte per value
+        if (B.n_values < B.n_samples || B.reserved != 0) {
+            wsx_internal_set_error("wsx_vbz_decode: a block must code at least the samples wanted of it (n_values >= n_samples, reserved = 0)");
+            return WSX_ERR_INVALID;
+        }
+        const int64_t nv = B.n_values;
+        const int64_t least = B.kind == WSX_VBZ_PLAIN ? 2 * n : (nv + 3) / 4 + nv; // key area + a byte per value
         if (B.src_bytes < least) {
             wsx_internal_set_error(B.kind == WSX_VBZ_PLAIN ? "wsx_vbz_decode: a block of plain samples shorter than 2 bytes per sample"
                                                            : "wsx_vbz_decode: StreamVByte block shorter than its key area and a byte per value");
