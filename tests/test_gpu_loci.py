@@ -303,10 +303,11 @@ def test_reads_whose_datasets_are_several_vbz_chunks(tmp_path, monkeypatch):
         fast5._libs()
     except fast5.Fast5Error as e:
         pytest.skip(str(e))
-    rng = np.random.default_rng(77)
-    # ten reads of 9-23 k samples around the levels of a squiggle, in chunks of 4 096
-    reads = {f'read{k:02d}': (rng.normal(520, 70, size=int(rng.integers(9000, 23000)))).astype(np.int16) for k in range(10)}
-    src = write_vbz_fast5(str(tmp_path / 'chunks.fast5'), reads, 4096, skip_filter_on=(2,))
+    # the upstream test file's ten reads (59-170 k samples), stored again in chunks of 20 480 samples: 3-9 blocks per read
+    from tests.helpers import GOLDEN
+    with fast5.Fast5File(os.path.join(GOLDEN, 'real', 'batch_0.fast5')) as f:
+        reads = {rid: f.raw_signal(rid) for rid in f.read_ids()[:10]}
+    src = write_vbz_fast5(str(tmp_path / 'chunks.fast5'), reads, 20480, skip_filter_on=(2,))
     ids = list(reads)
 
     def make(root):
@@ -318,7 +319,7 @@ def test_reads_whose_datasets_are_several_vbz_chunks(tmp_path, monkeypatch):
             ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
             rows = [ids[(li + k) % 10] for k in range(1 + li % 3)]
             pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool((li + k) & 1) for k in range(len(rows))], 'saved': 1,
-                          'l_start_raw': 3000 + 10 * li, 'r_end_raw': 4500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+                          'l_start_raw': 5000 + 10 * li, 'r_end_raw': 6500 + 10 * li, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
             loci.append(LocusPath(loc, pattern, fl))
         return loci
     monkeypatch.setattr('warpstr_amd.loci.SHARED_BATCH_READS', 24)
