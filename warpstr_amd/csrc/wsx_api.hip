@@ -84,6 +84,7 @@ struct DeviceBuf {
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError(); // (the runtime remembers a failed call until it is asked: the next launch's check would report it)
             want = bytes;
             e = hipMalloc(&p, want);
         }
@@ -1766,6 +1767,8 @@ static int run_batch_retry(wsx_caller *c, const BatchIO &io, bool full)
 {
     for (int attempt = 0;; attempt++) {
         g_alloc_oom = false;
+        (void)hipGetLastError(); // (an error some earlier call of this thread left behind -- the host program's own failed allocation,
+                                 // say -- is not this call's: the checks behind the launches ask for the last error)
         const int rc = run_batch(c, io, full);
         if (rc == WSX_SUCCESS || !g_alloc_oom || attempt >= 6 || c->ws_limit <= (256ull << 20)) return rc;
         (void)hipDeviceSynchronize();
