@@ -126,3 +126,23 @@ def write_vbz_fast5(path: str, reads: dict, chunk_len: int, zigzag: bool = True,
         h.H5Sclose(sp)
     h.H5Fclose(fid)
     return path
+
+
+def free_port() -> int:
+    """A TCP port for a rendezvous on 127.0.0.1, taken BELOW the kernel's range of ephemeral ports (32768-60999 by default): a port
+    of that range found free by binding port 0 can be the source port of somebody's outgoing connection a moment later -- gloo
+    opens many -- and the rendezvous then fails with EADDRINUSE (seen once in a round's last GPU run)."""
+    import random
+    import socket
+    rng = random.Random(os.getpid() * 7919 + int.from_bytes(os.urandom(4), 'little'))
+    for _ in range(200):
+        port = rng.randrange(20000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', port))
+            return port
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError('no free port between 20000 and 29999')

@@ -11,11 +11,8 @@ from warpstr_amd.dist import gather_results, gather_results_ragged, shard_reads
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from tests.helpers import free_port
+    return free_port()
 
 
 def _fake_records(idx):

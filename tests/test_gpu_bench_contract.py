@@ -93,11 +93,8 @@ def test_default_run_carries_the_secondary_workloads():
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from tests.helpers import free_port
+    return free_port()
 
 
 @pytest.mark.parametrize('scaling', ['weak', 'strong'])

@@ -27,11 +27,8 @@ LOCI = [('(AGC)', 16, 33, (900, 1600)), ('(AGC)AACAGCCGCCAC(CGC)', 20, 40, (1400
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from tests.helpers import free_port
+    return free_port()
 
 
 def _make(root, tag):

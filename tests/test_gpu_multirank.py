@@ -23,11 +23,8 @@ OUTPUTS = ['overview.csv', 'predictions/sequences/all.fasta', 'predictions/seque
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from tests.helpers import free_port
+    return free_port()
 
 
 def _run(locus_args, ranks, extra_env=None, genotype=False):

@@ -20,11 +20,8 @@ LOCI = [('(AGC)', 16, 7), ('(AGC)AACAGCCGCCAC(CGC)', 20, 12), ('(AAAT)', 30, 1),
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from tests.helpers import free_port
+    return free_port()
 
 
 class FakeEngine:
