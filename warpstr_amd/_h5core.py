@@ -94,6 +94,8 @@ def libs():
 
 _SCRATCH = None
 _VBZ_NATIVE = False
+_VBZ_CONTEXT: list = []   # [(wsh_vbz_context, ZSTD_createDCtx, address of ZSTD_decompressDCtx)] once vbz_native() has bound them
+_THREAD = None            # threading.local(): has this thread its decompression context?
 PLAIN, SVB_ZIGZAG, SVB = 0, 1, 2   # what a block written by Fast5Core.blocks_to holds (= WSX_VBZ_* of include/warpstr_hip.h)
 VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
@@ -129,7 +131,29 @@ def vbz_native():
             unpack.restype = C.c_int64
             unpack.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
             _VBZ_NATIVE = (fn, C.cast(zs.ZSTD_getFrameContentSize, C.c_void_p).value, C.cast(zs.ZSTD_decompress, C.c_void_p).value, unpack)
+            try:
+                zs.ZSTD_createDCtx.restype = C.c_void_p
+                lib.wsh_vbz_context.restype, lib.wsh_vbz_context.argtypes = None, [C.c_void_p, C.c_void_p]
+                _VBZ_CONTEXT.append((lib.wsh_vbz_context, zs.ZSTD_createDCtx, C.cast(zs.ZSTD_decompressDCtx, C.c_void_p).value))
+            except AttributeError:
+                pass
     return _VBZ_NATIVE
+
+
+def thread_context():
+    """A zstd decompression context of its own for the calling thread, kept for the life of the process (the native decoders
+    then skip the context ZSTD_decompress makes and drops per call: 9 % of a frame's time)."""
+    global _THREAD
+    if _THREAD is None:
+        import threading
+        _THREAD = threading.local()
+    if getattr(_THREAD, 'done', False) or not _VBZ_CONTEXT:
+        return
+    _THREAD.done = True
+    set_context, create, decompress = _VBZ_CONTEXT[0]
+    dctx = create()
+    if dctx:
+        set_context(dctx, decompress)
 
 
 class Fast5Core:
@@ -266,6 +290,7 @@ class Fast5Core:
                     raise Fast5Error(f'{self.path}: H5Dread failed')
                 return n
             fn, f_size, f_dec = native[:3]
+            thread_context()
             zigzag, level = int(bool(vbz[2])), int(vbz[3])
             done = 0
             for start, want, buf, size, plain in self._chunks(d, n, chunk_len):
@@ -303,6 +328,7 @@ class Fast5Core:
             if native is None:
                 raise NeedsNumpy()
             _, f_size, f_dec, unpack = native
+            thread_context()
             _, zs = libs()
             kind, level = (SVB_ZIGZAG if vbz[2] else SVB), int(vbz[3])
             blocks, done, n_out = [], 0, C.c_int64()

@@ -34,7 +34,7 @@ class WshSetup(C.Structure):
 
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
            'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
-           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_gather']
+           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_vbz_context', 'wsh_gather']
 
 
 def lib():

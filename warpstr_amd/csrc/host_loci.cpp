@@ -1114,6 +1114,29 @@ WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8
 // -3 zstd failed, -4 StreamVByte block shorter than its key area, -5 shorter than its keys say.
 typedef unsigned long long (*zstd_size_fn)(const void *, size_t);
 typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
+typedef size_t (*zstd_decompress_dctx_fn)(void *, void *, size_t, const void *, size_t);
+
+// (a decompression context the process keeps -- wsh_vbz_context -- saves ZSTD_decompress the context it otherwise makes and
+// drops per call: 9 % of a 115 KB frame's time)
+struct VbzContext {
+    void *dctx = nullptr;
+    zstd_decompress_dctx_fn fn = nullptr;
+};
+static thread_local VbzContext g_vbz_ctx;
+
+static inline size_t zstd_run(void *decompress_fn, void *dst, size_t cap, const void *src, size_t n)
+{
+    if (g_vbz_ctx.dctx && g_vbz_ctx.fn) return g_vbz_ctx.fn(g_vbz_ctx.dctx, dst, cap, src, n);
+    return reinterpret_cast<zstd_decompress_fn>(decompress_fn)(dst, cap, src, n);
+}
+
+// dctx: a ZSTD_DCtx the caller made (ZSTD_createDCtx) and keeps alive, decompress_dctx_fn: ZSTD_decompressDCtx -- used by this
+// THREAD's wsh_vbz_decode_i16 / wsh_vbz_unpack from now on instead of the plain ZSTD_decompress they are handed (null: back to that)
+WSH_EXPORT void wsh_vbz_context(void *dctx, void *decompress_dctx_fn)
+{
+    g_vbz_ctx.dctx = dctx;
+    g_vbz_ctx.fn = reinterpret_cast<zstd_decompress_dctx_fn>(decompress_dctx_fn);
+}
 
 WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int32_t zigzag, int32_t zstd_level, void *size_fn, void *decompress_fn,
                                       int16_t *out, int64_t cap)
@@ -1132,7 +1155,7 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
         const unsigned long long size = reinterpret_cast<zstd_size_fn>(size_fn)(svb, size_t(svb_bytes));
         if (size >= (1ull << 62)) return -2;
         if (scratch.size() < size + 8) scratch.resize(size + 8);
-        const size_t got = reinterpret_cast<zstd_decompress_fn>(decompress_fn)(scratch.data(), size, svb, size_t(svb_bytes));
+        const size_t got = zstd_run(decompress_fn, scratch.data(), size, svb, size_t(svb_bytes));
         if (got != size) return -3;
         svb = scratch.data();
         svb_bytes = int64_t(size);
@@ -1193,7 +1216,7 @@ WSH_EXPORT int64_t wsh_vbz_unpack(const uint8_t *chunk, int64_t n_chunk, int32_t
         const unsigned long long zs = reinterpret_cast<zstd_size_fn>(size_fn)(body, size_t(body_bytes));
         if (zs >= (1ull << 62)) return -2;
         if (int64_t(zs) > cap) return -6;
-        if (reinterpret_cast<zstd_decompress_fn>(decompress_fn)(out, size_t(zs), body, size_t(body_bytes)) != zs) return -3;
+        if (zstd_run(decompress_fn, out, size_t(zs), body, size_t(body_bytes)) != zs) return -3;
         size = int64_t(zs);
     } else {
         if (size > cap) return -6;
