@@ -683,3 +683,52 @@ def test_readers_decode_while_the_handle_is_created_and_stop_if_it_cannot_be(tmp
     with pytest.raises(RuntimeError, match='failed in a worker process'):
         main_wrapper_loci(d, 3, _engine=ArenaFakeEngine, quiet=True)
     assert not any(t.name == 'warpstr-reader' for t in threading.enumerate())
+
+
+def test_a_reader_process_that_dies_ends_the_run_with_an_error(tmp_path):
+    """A reader process killed in the middle of a run: the chunk it held fails (its pipe ends), the run raises -- it neither hangs
+    nor writes files from half a batch -- and the other reader processes are gone afterwards."""
+    import threading
+    import psutil
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    me = psutil.Process()
+    before = {p.pid for p in me.children(recursive=True)}
+    killed = []
+
+    class Killer(ArenaFakeEngine):
+        def submit_raw_parts(self, *args):
+            if not killed:
+                workers = [p for p in me.children(recursive=True) if p.pid not in before and '_hostworker' in ' '.join(p.cmdline())]
+                assert len(workers) == 3
+                workers[0].kill()
+                killed.append(workers[0].pid)
+            return super().submit_raw_parts(*args)
+    loci = _fast5_loci(str(tmp_path / 'a'), src, ids, n_loci=200)
+    old = wl.SHARED_BATCH_READS
+    wl.SHARED_BATCH_READS = 16
+    done = []
+
+    def run():
+        try:
+            main_wrapper_loci(loci, 3, _engine=Killer, quiet=True)
+            done.append(None)
+        except BaseException as e:  # noqa: BLE001
+            done.append(e)
+    try:
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(60)
+        assert not t.is_alive(), 'the run hangs after a reader process died'
+    finally:
+        wl.SHARED_BATCH_READS = old
+    assert killed and isinstance(done[0], (EOFError, OSError, RuntimeError)), done
+    assert not [p for p in me.children(recursive=True) if p.pid not in before and p.is_running() and p.status() != psutil.STATUS_ZOMBIE]
+    assert not os.path.exists(os.path.join(loci[-1].path, 'predictions', 'sequences', 'all.fasta'))
