@@ -732,3 +732,29 @@ def test_a_reader_process_that_dies_ends_the_run_with_an_error(tmp_path):
     assert killed and isinstance(done[0], (EOFError, OSError, RuntimeError)), done
     assert not [p for p in me.children(recursive=True) if p.pid not in before and p.is_running() and p.status() != psutil.STATUS_ZOMBIE]
     assert not os.path.exists(os.path.join(loci[-1].path, 'predictions', 'sequences', 'all.fasta'))
+
+
+def test_arenas_are_not_used_when_dev_shm_has_no_room_for_them(tmp_path, monkeypatch):
+    """A container's default /dev/shm (64 MB) cannot hold the reader arenas: the run says so in its timings and reads through the
+    staging ring (reader processes) or the page-locked ring (one process) instead -- same files."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    a, b, c = (_fast5_loci(str(tmp_path / t), src, ids) for t in 'abc')
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    monkeypatch.setattr(wl, 'ARENA_ROOM_PER_READ', 1 << 40)   # (as if every read took a terabyte)
+    tm_a, tm_c = {}, {}
+    main_wrapper_loci(a, 3, _engine=ArenaFakeEngine, quiet=True, timings=tm_a)
+    main_wrapper_loci(c, 1, _engine=ArenaFakeEngine, quiet=True, timings=tm_c)
+    assert 'MB free' in tm_a['arenas_refused'] and tm_a['reader_mode'] == 'shared staging' and tm_a['arena_batches'] == 0 and tm_a['shared_batches'] > 0
+    assert 'MB free' in tm_c['arenas_refused'] and tm_c['arena_batches'] == 0 and tm_c['local_batches'] > 0
+    for la, lb, lc in zip(a, b, c):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+            assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel

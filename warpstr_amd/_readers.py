@@ -123,7 +123,7 @@ def _arena(region: int, samples: int):
     try:
         st = os.statvfs(ARENA_DIR)
         if st.f_bavail * st.f_frsize < cap * 2 + (64 << 20):
-            raise OSError(f'{ARENA_DIR} has no room for a reader arena of {cap * 2} bytes')
+            raise OSError(f'{ARENA_DIR} has no room for a reader arena of {cap * 2} bytes (WARPSTR_NO_READER_ARENAS=1 reads without arenas)')
         os.ftruncate(fd, cap * 2)
         mm = mmap.mmap(fd, cap * 2)
     finally:

@@ -470,6 +470,7 @@ def partition_loci(loci: Sequence, world: int) -> List[np.ndarray]:
 
 
 GC_PAUSE_FROM_LOCI = 64
+ARENA_ROOM_PER_READ = 400 << 10   # bytes of /dev/shm a read may take in a reader arena (a 200 k-sample read as int16 samples)
 
 
 def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
@@ -900,6 +901,17 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             probe = engine_cls if isinstance(engine_cls, type) else None   # (what the engine can do, asked of its class)
             arenas = (probe is not None and hasattr(probe, 'submit_raw_parts') and hasattr(probe, 'ARENA_REGIONS')
                       and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS') and len(mine) > 0)
+            if arenas and (pool is not None or fast5_on_workers):
+                # room for the arenas?  Three regions of a batch each -- ARENA_ROOM_PER_READ bytes a read, 16 MB a reader process at
+                # least -- and half as much again; a container's default /dev/shm of 64 MB has not, and the run then takes the
+                # staging ring (which falls back to the pipes by itself) or, in one process, the page-locked ring
+                workers = pool._max_workers if pool is not None else 1
+                reads = min(len(mine), SHARED_BATCH_READS if pool is not None else SHARED_BATCH_READS // 4)
+                need = int(1.5 * probe.ARENA_REGIONS * max(workers * (16 << 20), reads * ARENA_ROOM_PER_READ))
+                st = os.statvfs('/dev/shm')
+                if st.f_bavail * st.f_frsize < need + (64 << 20):
+                    tm['arenas_refused'] = f'/dev/shm has {st.f_bavail * st.f_frsize >> 20} MB free, the reader arenas may take {need >> 20} MB'
+                    arenas = False
             if pool is None and arenas and fast5_on_workers:
                 # no reader processes (one thread, few loci, or they could not be started): the same arenas, filled by the reader
                 # thread itself -- a read is opened once (no pass for the lengths first) and decoded beside the calling thread
