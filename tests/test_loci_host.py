@@ -732,6 +732,7 @@ def test_a_reader_process_that_dies_ends_the_run_with_an_error(tmp_path):
     assert killed and isinstance(done[0], (EOFError, OSError, RuntimeError)), done
     assert not [p for p in me.children(recursive=True) if p.pid not in before and p.is_running() and p.status() != psutil.STATUS_ZOMBIE]
     assert not os.path.exists(os.path.join(loci[-1].path, 'predictions', 'sequences', 'all.fasta'))
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'warpstr_arena_{killed[0]}_')]   # (the dead reader's arenas too)
 
 
 def test_arenas_are_not_used_when_dev_shm_has_no_room_for_them(tmp_path, monkeypatch):

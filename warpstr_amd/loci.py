@@ -370,6 +370,15 @@ class _WorkerPool:
                 p.wait(timeout=10)
             except Exception:  # noqa: BLE001
                 p.kill()
+        # (a reader removes its arenas when it ends; one that was killed cannot: what carries its process number goes here)
+        import glob
+        from ._readers import ARENA_DIR
+        for p in self._procs:
+            for path in glob.glob(os.path.join(ARENA_DIR, f'warpstr_arena_{p.pid}_*')):
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
         self._procs = []
 
 
