@@ -759,45 +759,3 @@ def test_arenas_are_not_used_when_dev_shm_has_no_room_for_them(tmp_path, monkeyp
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
-
-
-def test_a_pipelined_run_writes_what_one_group_writes(tmp_path, monkeypatch):
-    """A long run goes in groups of loci, two in flight, a handle each (loci._pipelined): the same files as the run in one piece --
-    from host reads, from fast5 files through reader processes (arenas: the groups take turns on two sets of regions) and in one
-    process (two reader threads share libhdf5 under a lock); a read that cannot be called in the second group leaves the first
-    group's files and none of the later groups'; the error is that read's."""
-    import warpstr_amd.loci as wl
-    from tests.helpers import GOLDEN
-    from warpstr_amd import fast5
-    monkeypatch.setattr(wl, 'PIPELINE_GROUP_LOCI', 12)
-    monkeypatch.setattr(wl, 'PIPELINE_FROM_GROUPS', 2)
-    try:
-        fast5._libs()
-    except fast5.Fast5Error as e:
-        pytest.skip(str(e))
-    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
-    ids = fast5.Fast5File(src).read_ids()[:10]
-    one = _fast5_loci(str(tmp_path / 'one'), src, ids)
-    monkeypatch.setenv('WARPSTR_NO_PIPELINE', '1')
-    tm_one = {}
-    main_wrapper_loci(one, 1, _engine=FakeEngine, quiet=True, timings=tm_one)
-    assert 'pipelined_groups' not in tm_one
-    monkeypatch.delenv('WARPSTR_NO_PIPELINE')
-    for tag, threads, engine in (('p1', 1, FakeEngine), ('p2', 3, ArenaFakeEngine), ('p3', 1, VbzFakeEngine), ('p4', 3, VbzFakeEngine)):
-        loci, tm = _fast5_loci(str(tmp_path / tag), src, ids), {}
-        monkeypatch.setattr(wl, 'SHARED_BATCH_READS', 8)
-        tables = main_wrapper_loci(loci, threads, _engine=engine, quiet=True, timings=tm)
-        assert tm['pipelined_groups'] == 6 and tm['n_loci'] == 70 and tm['n_reads'] == tm_one['n_reads'] and len(tables) == 70
-        assert sorted(tm['loci_set_up']) == list(range(70))
-        for la, lb in zip(loci, one):
-            for rel in OUTPUTS:
-                assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), (tag, rel)
-        assert tables[69][0]['results'].tolist() == pd.read_csv(os.path.join(loci[69].path, 'overview.csv'))['results'].tolist()
-    assert not [f for f in os.listdir('/dev/shm') if f.startswith('warpstr_arena_')]
-    # a fast5 file that is not there, in the third group: the first two groups' files are written, no later group's
-    bad = _fast5_loci(str(tmp_path / 'bad'), src, ids, missing=30)
-    with pytest.raises((RuntimeError, fast5.Fast5Error, OSError)) as info:
-        main_wrapper_loci(bad, 3, _engine=ArenaFakeEngine, quiet=True)
-    assert not isinstance(info.value, wl._EarlierGroupFailed)
-    fasta = lambda l: os.path.join(l.path, 'predictions', 'sequences', 'all.fasta')
-    assert all(os.path.exists(fasta(l)) for l in bad[:24]) and not any(os.path.exists(fasta(l)) for l in bad[24:])

@@ -382,9 +382,6 @@ class _WorkerPool:
         self._procs = []
 
 
-_INLINE_LOCK = __import__('threading').Lock()
-
-
 class _InlinePool:
     """The reader "pool" of a run without reader processes: a chunk is decoded by the thread that hands it out -- the reader
     thread of main_wrapper_loci, beside the calling thread (the library calls inside release the GIL; libhdf5 is used by that one
@@ -401,8 +398,7 @@ class _InlinePool:
         try:
             if func in (_decode_arena, _pack_arena):
                 item = (f'{self.owner}{item[0]}',) + tuple(item[1:])
-            with _INLINE_LOCK:   # (libhdf5 is not thread-safe, and two groups of a pipelined run have a reader thread each)
-                future.set_result(func(item))
+            future.set_result(func(item))
         except BaseException as e:  # noqa: BLE001 -- raised where the future is waited for
             future.set_exception(e)
         return future
@@ -483,8 +479,6 @@ def partition_loci(loci: Sequence, world: int) -> List[np.ndarray]:
 
 
 GC_PAUSE_FROM_LOCI = 64
-PIPELINE_GROUP_LOCI = 500    # loci of a group of a pipelined run (a handle, a set of batches, a set of output calls each)
-PIPELINE_FROM_GROUPS = 3     # ... and from how many groups on a run is pipelined
 ARENA_ROOM_PER_READ = 400 << 10   # bytes of /dev/shm a read may take in a reader arena (a 200 k-sample read as int16 samples)
 
 
@@ -523,13 +517,11 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     if threads and int(threads) > 1 and len(loci) > 1:
         from concurrent.futures import ThreadPoolExecutor
         executor = ThreadPoolExecutor(max_workers=min(int(threads), 64), initializer=spread_over_cpus)
-    kwargs = dict(caller_config=caller_config, rescaler_config=rescaler_config, signal_loader=signal_loader, raw_reader=raw_reader,
-                  raw_reads=raw_reads, pore_model=pore_model, device=device, shard=shard, partition=partition, batch_reads=batch_reads,
-                  batch_samples=batch_samples, batch_raw_bytes=batch_raw_bytes, quiet=quiet, native=native, _engine=_engine)
     try:
-        if not shard and len(loci) >= PIPELINE_FROM_GROUPS * PIPELINE_GROUP_LOCI and not os.environ.get('WARPSTR_NO_PIPELINE'):
-            return _pipelined(loci, int(threads or 1), pools, executor, kwargs, timings)
-        return _main_wrapper_loci(loci, int(threads or 1), pools, executor, timings=timings, **kwargs)
+        return _main_wrapper_loci(loci, int(threads or 1), pools, executor, caller_config=caller_config, rescaler_config=rescaler_config,
+                                  signal_loader=signal_loader, raw_reader=raw_reader, raw_reads=raw_reads, pore_model=pore_model,
+                                  device=device, shard=shard, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
+                                  batch_raw_bytes=batch_raw_bytes, timings=timings, quiet=quiet, native=native, _engine=_engine)
     finally:  # the threads and the reader processes end with the call, however it ends
         if paused:
             gc.enable()
@@ -543,105 +535,8 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
                 pool.shutdown()
 
 
-class _EarlierGroupFailed(Exception):
-    """A group of a pipelined run that may not write its files: an earlier group failed."""
-
-
-def _pipelined(loci, threads, pools, executor, kwargs, timings):
-    """A long run in groups of PIPELINE_GROUP_LOCI loci, two of them in flight: while one group's reads are on the GPU, the next
-    group's loci are set up and its handle is made, the previous group's files are written -- a handle per group instead of one
-    for the run (what a handle shares between loci, the placements of equal graphs, it still shares within a group).  The reader
-    processes are the run's: the chunks of a group queue up behind those of the group before, so the readers never wait for a
-    set-up.  What stays in the order of the loci: the output files (a group writes its files when every earlier group has
-    written its own, and not at all after one that failed -- upstream's loop would have ended there: WarpSTR.py:66-76) and the
-    error that is raised (the first group's that failed)."""
-    import threading
-    t_start = time.perf_counter()
-    n = len(loci)
-    bounds = list(range(0, n, PIPELINE_GROUP_LOCI)) + [n]
-    if bounds[-1] - bounds[-2] < PIPELINE_GROUP_LOCI // 2 and len(bounds) > 2:
-        del bounds[-2]   # (a short tail joins the last group)
-    groups = [(bounds[k], bounds[k + 1]) for k in range(len(bounds) - 1)]
-    fast5_on_workers = kwargs['signal_loader'] is None and kwargs['raw_reader'] is read_raw_signal and kwargs['raw_reads'] is None
-    shared = _reader_pool(threads, n) if fast5_on_workers else None
-    pools.append(shared)
-    done = [threading.Event() for _ in groups]
-    errors: list = [None] * len(groups)
-    results: list = [None] * len(groups)
-    tms: list = [dict() for _ in groups]
-    failed = threading.Event()
-
-    def gate(k):
-        if k:
-            done[k - 1].wait()
-            if errors[k - 1] is not None:
-                raise _EarlierGroupFailed()
-
-    def run(first):
-        for k in range(first, len(groups), 2):   # (this thread's groups: its previous one has ended, so its set of regions is free)
-            try:
-                if failed.is_set():
-                    raise _EarlierGroupFailed()
-                a, b = groups[k]
-                results[k] = _main_wrapper_loci(loci[a:b], threads, pools, executor, timings=tms[k], _pool=shared, _slot=k % 2, _group=k,
-                                                _gate=lambda k=k: gate(k), **kwargs)
-            except BaseException as e:  # noqa: BLE001 -- raised by the calling thread below, the first group's first
-                errors[k] = e
-                failed.set()
-            finally:
-                done[k].set()
-    workers = [threading.Thread(target=run, args=(t,), name=f'warpstr-group-{t}', daemon=True) for t in range(min(2, len(groups)))]
-    for t in workers:
-        t.start()
-    for t in workers:
-        t.join()
-    for e in errors:
-        if e is not None and not isinstance(e, _EarlierGroupFailed):
-            raise e
-    entries: list = []
-    for r in results:
-        entries += r._e
-    if timings is not None:
-        _merge_timings(timings, tms, [a for a, _ in groups])
-        timings['total_s'] = time.perf_counter() - t_start
-        timings['pipelined_groups'] = len(groups)
-    return LociTables(entries)
-
-
-def _merge_timings(into, tms, first_locus):
-    """The timings of a pipelined run's groups as one: seconds and counts summed (the groups overlap: the sums are work, not
-    wall-clock -- `total_s` is), lists joined (locus numbers shifted to the run's), anything else from the first group."""
-    for tm, base in zip(tms, first_locus):
-        for key, v in tm.items():
-            if isinstance(v, bool) or v is None:
-                into.setdefault(key, v)
-            elif isinstance(v, (int, float)):
-                if key in ('host_threads', 'reader_processes'):
-                    into[key] = v
-                elif key in ('workspace_bytes', 'workspace_limit_bytes'):
-                    into[key] = max(into.get(key, 0), v)
-                else:
-                    into[key] = into.get(key, 0) + v
-            elif isinstance(v, list):
-                into.setdefault(key, [])
-                into[key] += [x + base for x in v] if key == 'loci_set_up' else v
-                if key == 'kernels':
-                    into[key] = sorted(set(into[key]))
-            elif isinstance(v, dict):
-                cur = into.setdefault(key, {})
-                for kk, vv in v.items():
-                    cur[kk] = cur.get(kk, 0) + vv if isinstance(vv, (int, float)) and not isinstance(vv, bool) else vv
-            else:
-                into.setdefault(key, v)
-
-
 def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescaler_config, signal_loader, raw_reader, raw_reads, pore_model,
-                       device, shard, partition, batch_reads, batch_samples, batch_raw_bytes, timings, quiet, native, _engine,
-                       _pool=None, _slot=0, _group=0, _gate=None):
-    """main_wrapper_loci for one group of loci.  _pool: the reader processes of a pipelined run (shared by its groups); _slot: which
-    of the two sets of arena regions the group's readers write (two groups are in flight); _group: its number (arena generations
-    are counted from _group * 10^6: a reader tells a region's new use from its last by the generation); _gate(): called before
-    the first output file is written -- returns when every earlier group has written its files, raises if one of them failed."""
+                       device, shard, partition, batch_reads, batch_samples, batch_raw_bytes, timings, quiet, native, _engine):
     from . import dist as wdist
     from .pore_model import default_pore_model
     t_start = time.perf_counter()
@@ -678,11 +573,8 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     # (the reader processes start first: they come up -- half a second of imports -- while the loci are set up.  On the bench's
     # sandboxed box sixteen interpreters starting slow whatever runs beside them: the set-up 0.3 -> 0.9 s for 3 000 loci; started
     # beside the handle's creation instead they cost that 0.2 -> 1.5 s.)
-    if _pool is not None:
-        pool = _pool if fast5_on_workers else None
-    else:
-        pool = _reader_pool(threads, len(own)) if fast5_on_workers else None
-        pools.append(pool)
+    pool = _reader_pool(threads, len(own)) if fast5_on_workers else None
+    pools.append(pool)
     tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
     # ---- per locus: overview, flanks, automata, state_similarity.csv --------------------------------------------------------
@@ -869,8 +761,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
                             b1 = b0 + SHARED_BATCH_READS
                         items = [item_of(k) for k in range(b0, b1)]
-                        with _INLINE_LOCK:   # (libhdf5 is not thread-safe: another group of a pipelined run may be reading too)
-                            lens_b = np.array(_probe_chunk(items), np.int64)
+                        lens_b = np.array(_probe_chunk(items), np.int64)
                         keep = max(1, int(np.searchsorted(np.cumsum(lens_b) * 2, min(raw_budget, SHARED_BATCH_BYTES), side='right')))
                         if keep < len(items):
                             cuts.insert(b + 1, b0 + keep)
@@ -879,14 +770,12 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         shared_roff = np.zeros(len(items) + 1, np.int64)
                         np.cumsum(lens_b, out=shared_roff[1:])
                         shared_slot = queue.stage_local(int(shared_roff[-1]))
-                        with _INLINE_LOCK:
-                            _decode_into(shared_slot['view'], items, shared_roff[:-1].tolist(), lens_b.tolist())
+                        _decode_into(shared_slot['view'], items, shared_roff[:-1].tolist(), lens_b.tolist())
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(shared_roff[-1]) * 2
                     elif signal_loader is None:
-                        with _INLINE_LOCK:   # (the default raw_reader is the fast5 reader)
-                            for k in range(b0, b1):
-                                g = mine[k]
-                                data.append(jobs[locus_of[g]].raw_read(int(row_of[g]), raw_reader))
+                        for k in range(b0, b1):
+                            g = mine[k]
+                            data.append(jobs[locus_of[g]].raw_read(int(row_of[g]), raw_reader))
                     else:
                         for k in range(b0, b1):
                             g = mine[k]
@@ -933,7 +822,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         submitted[k] = threading.Event()
                         items = [item_of(x) for x in range(b, b1)]
                         step = max(8, -(-len(items) // (2 * pool._max_workers)))
-                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (f's{_slot}.{region}', _group * 1000000 + k, items[q:q + step]))
+                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step]))
                                    for q in range(0, len(items), step)]
                         inflight.append((b, b1, region, futures, k))
                         tm['read_s'] += time.perf_counter() - t1
@@ -1073,8 +962,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             if queue is not None:
                 tm.update(queue.info())
                 queue.close()
-            if getattr(pool, 'inline', False):
-                pool.shutdown()   # (its arenas: uploaded by now)
         except Exception as e:  # noqa: BLE001 -- agreed on below: no rank may wait in a collective for one that failed
             error = e
         if collective or error is not None:
@@ -1097,8 +984,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         tm['gather_s'] += time.perf_counter() - t0
 
     # ---- per locus: the outputs of main_wrapper -------------------------------------------------------------------------------
-    if _gate is not None:
-        _gate()   # (a pipelined run: the groups write their files in the order of the loci, and none after one that failed)
     t0 = time.perf_counter()
     # the first read a caller failed on ends the run where upstream's loop would have ended: the loci before it are written
     bad = np.flatnonzero(records['status'] != 0)
