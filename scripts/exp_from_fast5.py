@@ -32,8 +32,6 @@ if os.environ.get('WSX_PROFILE'):   # experiment: where the calling thread of th
             pstats.Stats(pr, stream=out).sort_stats('tottime').print_stats(28)
             print(out.getvalue(), file=sys.stderr, flush=True)
     wrapper.main_wrapper_loci = _profiled
-if os.environ.get('WSX_SWITCH'):   # experiment: the interpreter's thread switch interval (default 5 ms) under a pipelined run
-    sys.setswitchinterval(float(os.environ['WSX_SWITCH']))
 if os.environ.get('WSX_NO_GC'):   # experiment: are the phases that sometimes take 0.4 s longer full garbage collections?
     import gc
     gc.disable()
