@@ -156,3 +156,32 @@ def test_descriptors_the_library_refuses(hip):
         with pytest.raises(RuntimeError, match='wsx_vbz_decode'):
             call(*block, **kw)
     hip.vbz_decode_device(0, 0, np.zeros(0, _lib.VBZ_BLOCK_DTYPE), 0, 0)   # no blocks: nothing to do
+
+
+def test_a_launch_of_many_random_blocks(hip):
+    """600 blocks of random kinds, sizes (0 .. 40 000 values), code lengths, wanted prefixes and addresses in ONE launch -- the shape
+    of a batch of reads -- every sample against the oracle."""
+    rng = np.random.default_rng(2024)
+    blobs, specs, want = [], [], []
+    for i in range(600):
+        coded = int(rng.choice([0, 1, 2, 3, 4, 5, 1023, 1024, 1025, int(rng.integers(6, 40000))]))
+        n = coded if rng.random() < 0.7 else int(rng.integers(0, coded + 1))
+        style = rng.integers(0, 3)
+        if style == 0:      # a squiggle: small differences
+            sig = np.cumsum(rng.integers(-60, 61, size=coded)).astype(np.int16)
+        elif style == 1:    # anything: differences of every size, wrap-around
+            sig = rng.integers(-32768, 32768, size=coded).astype(np.int16)
+        else:               # long flat stretches with jumps
+            sig = np.repeat(rng.integers(-3000, 3000, size=coded // 50 + 1), 50)[:coded].astype(np.int16)
+        kind = int(rng.choice([_lib.VBZ_SVB_ZIGZAG, _lib.VBZ_SVB_ZIGZAG, _lib.VBZ_SVB, _lib.VBZ_PLAIN]))
+        if kind == _lib.VBZ_PLAIN:
+            blobs.append(sig.view(np.uint8).copy())
+            specs.append((kind, n, n))
+        else:
+            blobs.append(vbz.svb_encode(vbz.values_from_samples(sig, kind == _lib.VBZ_SVB_ZIGZAG)))
+            specs.append((kind, n, coded))
+        want.append(sig[:n])
+    outs, st = decode(hip, blobs, specs, pad=9)
+    assert (st == 0).all()
+    for i, (got, w) in enumerate(zip(outs, want)):
+        assert np.array_equal(got, w), (i, specs[i])
