@@ -305,3 +305,50 @@ def test_complex_unit_tables_equal_the_python_forms(tmp_path):
         pd.testing.assert_frame_equal(pd.read_csv(io.StringIO(text), index_col=0), want)
         done += 1
     assert done > 60
+
+
+def test_a_chunk_of_loci_hands_its_columns_over_together(tmp_path):
+    """NativeSetup.run_many takes the overview columns of a chunk in two library calls (wsh_loci_counts / wsh_loci_columns); locus
+    by locus they must be what NativeOverview.open gives: loci with and without run_id / fast5_path columns, without saved rows,
+    with names that are not ASCII, with a table the library declines in the middle of the chunk, in random order."""
+    rng = np.random.default_rng(5)
+    pm = default_pore_model()
+    paths, seqs = [], []
+    for i in range(60):
+        loc = str(tmp_path / f'l{i}')
+        fl = int(rng.integers(8, 40))
+        ov.store_flanks(loc, [''.join('ACGT'[k] for k in rng.integers(0, 4, size=fl)) for _ in range(4)])
+        n = int(rng.integers(0, 7))
+        kind = i % 6
+        names = [f'read{i}_{r}' for r in range(n)]
+        if kind == 4:
+            names = [f'čítanie_{i}_{r}_ž' for r in range(n)]
+        df = {'read_name': names, 'reverse': [bool(b) for b in rng.integers(0, 2, size=n)], 'saved': [int(b) for b in (rng.random(n) < 0.8)],
+              'l_start_raw': rng.integers(0, 1000, size=n), 'r_end_raw': rng.integers(1000, 9000, size=n)}
+        if kind in (0, 2, 4, 5):
+            df['run_id'] = [f'run_{r % 2}' for r in range(n)]
+        if kind in (0, 3, 4):
+            df['fast5_path'] = [f'/data/x/{i}/{r}.fast5' for r in range(n)]
+        pd.DataFrame(df).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+        if kind == 5 and n:   # a quoted field: the library leaves this table to pandas
+            text = open(os.path.join(loc, 'overview.csv')).read().replace('run_0', '"run,0"', 1)
+            open(os.path.join(loc, 'overview.csv'), 'w').write(text)
+        paths.append(loc)
+        seqs.append('(AGC)')
+    sts = _hostlib.NativeSetup.run_many(paths, seqs, pm, 0.75, False)
+    assert len(sts) == 60
+    n_native = 0
+    for loc, st in zip(paths, sts):
+        one = _hostlib.NativeOverview.open(os.path.join(loc, 'overview.csv'))
+        assert (st.overview is None) == (one is None), loc
+        if one is None:
+            continue
+        n_native += 1
+        got = st.overview
+        assert got.n_saved == one.n_saved and got.n_rows == one.n_rows and got.names == one.names
+        assert got.run_id == one.run_id and got.fast5_path == one.fast5_path
+        for a, b in ((got.saved, one.saved), (got.reverse, one.reverse), (got.lo, one.lo), (got.hi, one.hi)):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+            assert a.flags.writeable and a.base is None   # (its own memory: a locus may change its arrays)
+        one.close()
+    assert 30 <= n_native < 60   # (the quoted tables and the non-ASCII names go to pandas)

@@ -34,7 +34,7 @@ class WshSetup(C.Structure):
 
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
            'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
-           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_vbz_context', 'wsh_gather']
+           'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_vbz_context', 'wsh_gather', 'wsh_loci_counts', 'wsh_loci_columns']
 
 
 def lib():
@@ -65,6 +65,10 @@ def lib():
                     h.wsh_loci_store.argtypes = [C.c_int32] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]
                     h.wsh_loci_setup.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p]
                     h.wsh_loci_setup.restype = None
+                    h.wsh_loci_counts.argtypes = [C.c_int32] + [C.c_void_p] * 5
+                    h.wsh_loci_counts.restype = None
+                    h.wsh_loci_columns.argtypes = [C.c_int32] + [C.c_void_p] * 11
+                    h.wsh_loci_columns.restype = None
                     h.wsh_free.argtypes = [C.c_void_p]
                     h.wsh_free.restype = None
                     h.wsh_collapse_store.argtypes = [C.c_char_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_char_p,
@@ -141,6 +145,16 @@ class NativeOverview:
         self._names = self._split(info.names, info.names_off, n)
         self.run_id = self._split(info.runs, info.runs_off, n) if info.has_run_id else None
         self.fast5_path = self._split(info.f5s, info.f5s_off, n) if info.has_fast5_path else None
+
+    @classmethod
+    def _from_columns(cls, handle, path, owner, n_rows, saved, reverse, lo, hi, names, run_id, fast5_path):
+        """The same object from columns a chunk of loci handed over together (NativeSetup.run_many: wsh_loci_columns)."""
+        self = cls.__new__(cls)
+        self._h, self.path, self._owner = handle, path, owner
+        self.n_saved, self.n_rows = len(saved), n_rows
+        self.saved, self.reverse, self.lo, self.hi = saved, reverse, lo, hi
+        self._names, self.run_id, self.fast5_path = names, run_id, fast5_path
+        return self
 
     @staticmethod
     def _split(blob, off, n):
@@ -295,11 +309,13 @@ class NativeSetup:
     None: the pandas path), `tables` ((template, reverse) AutomatonTables or None: the Python compiler, which raises what
     upstream raises), `similarity` ((CSV text, [warning lines]) or None: the Python form).  None altogether without the library."""
 
-    def __init__(self, raw: WshSetup, locus_path: str, kmersize: int):
+    def __init__(self, raw: WshSetup, locus_path: str, kmersize: int, columns=None):
         self._raw = raw
         self.overview = self.tables = self.similarity = None
         self.overview_status = raw.overview_status
-        if raw.overview_status == 0:
+        if raw.overview_status == 0 and columns is not None:
+            self.overview = NativeOverview._from_columns(raw.locus, os.path.join(locus_path, 'overview.csv'), self, *columns)
+        elif raw.overview_status == 0:
             self.overview = NativeOverview(raw.locus, os.path.join(locus_path, 'overview.csv'), owner=self)
         else:
             NativeOverview.last_refusal = (lib().wsh_locus_error(raw.locus) or b'').decode('utf-8', 'replace')
@@ -342,11 +358,50 @@ class NativeSetup:
         raws = (WshSetup * n)()
         h.wsh_loci_setup(n, (C.c_char_p * n)(*[os.fsencode(p) for p in locus_paths]), (C.c_char_p * n)(*seqs), levels.ctypes.data,
                          int(pore_model.kmersize), float(min_state_similarity), 1 if write_similarity else 0, raws)
+        columns = cls._chunk_columns(h, raws, n)
         out = []
         for i, p in enumerate(locus_paths):   # (each entry owns a copy of its struct: the array may go)
             raw = WshSetup()
             C.memmove(C.byref(raw), C.byref(raws[i]), C.sizeof(WshSetup))
-            out.append(cls(raw, p, int(pore_model.kmersize)))
+            out.append(cls(raw, p, int(pore_model.kmersize), columns.get(i)))
+        return out
+
+    @staticmethod
+    def _chunk_columns(h, raws, n):
+        """{locus of the chunk: (rows, saved rows, reverse, lo, hi, names, run ids or None, fast5 paths or None)} for the loci whose
+        overview the library parsed -- two library calls and a handful of arrays for the chunk instead of one call and seven
+        copies per locus (this part runs under the interpreter's lock: it, not the parsing, set the set-up's wall-clock)."""
+        idx = [i for i in range(n) if raws[i].overview_status == 0]
+        if not idx or not hasattr(h, 'wsh_loci_columns'):
+            return {}
+        m = len(idx)
+        handles = (C.c_void_p * m)(*[raws[i].locus for i in idx])
+        counts, rows, flags, sbytes = np.zeros(m, np.int64), np.zeros(m, np.int64), np.zeros(m, np.int32), np.zeros(3, np.int64)
+        h.wsh_loci_counts(m, handles, counts.ctypes.data, rows.ctypes.data, flags.ctypes.data, sbytes.ctypes.data)
+        total = int(counts.sum())
+        saved, lo, hi = np.zeros(total, np.int64), np.zeros(total, np.int64), np.zeros(total, np.int64)
+        reverse = np.zeros(total, np.uint8)
+        blobs = [C.create_string_buffer(max(int(b), 1)) for b in sbytes]
+        offs = [np.zeros(total + 1, np.int64) for _ in range(3)]
+        h.wsh_loci_columns(m, handles, saved.ctypes.data, reverse.ctypes.data, lo.ctypes.data, hi.ctypes.data, blobs[0], offs[0].ctypes.data,
+                           blobs[1], offs[1].ctypes.data, blobs[2], offs[2].ctypes.data)
+        reverse = reverse.astype(bool)
+
+        def strings(k):
+            raw, o = blobs[k].raw[:int(sbytes[k])], offs[k].tolist()
+            text = raw.decode('utf-8')
+            if len(text) == len(raw):
+                return [text[o[r]:o[r + 1]] for r in range(total)]
+            return [raw[o[r]:o[r + 1]].decode('utf-8') for r in range(total)]   # (non-ASCII: the offsets are bytes)
+        names = strings(0)
+        runs = strings(1) if (flags & 1).any() else None
+        f5s = strings(2) if (flags & 2).any() else None
+        out, at = {}, 0
+        for q, i in enumerate(idx):
+            b = at + int(counts[q])
+            out[i] = (int(rows[q]), saved[at:b].copy(), reverse[at:b].copy(), lo[at:b].copy(), hi[at:b].copy(), names[at:b],
+                      runs[at:b] if flags[q] & 1 else None, f5s[at:b] if flags[q] & 2 else None)
+            at = b
         return out
 
     def __del__(self):

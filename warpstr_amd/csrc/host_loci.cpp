@@ -836,6 +836,54 @@ WSH_EXPORT void wsh_locus_info(void *h, wsh_overview_info *o)
     o->f5s = L.f5s.data(); o->f5s_off = L.f5s_off.data();
 }
 
+// The same for a chunk of loci in two calls instead of one and a dozen copies per locus (a run of thousands of loci spent more time
+// taking the columns over, locus by locus under the interpreter's lock, than parsing them): first the sizes -- per locus the saved
+// rows, all rows and flags (1 = has a run_id column, 2 = has a fast5_path column), and the chunk's bytes of names, run ids, paths --
+// then the columns of all loci back to back into arrays of those sizes; the *_off arrays hold total + 1 offsets into the chunk's
+// blobs (a locus without the column: empty strings).
+WSH_EXPORT void wsh_loci_counts(int32_t n, void *const *handles, int64_t *n_saved, int64_t *n_rows, int32_t *flags, int64_t *string_bytes)
+{
+    string_bytes[0] = string_bytes[1] = string_bytes[2] = 0;
+    for (int32_t i = 0; i < n; i++) {
+        const Locus &L = *static_cast<Locus *>(handles[i]);
+        n_saved[i] = int64_t(L.saved_rows.size());
+        n_rows[i] = L.n_rows;
+        flags[i] = (L.c_run >= 0 ? 1 : 0) | (L.c_f5 >= 0 ? 2 : 0);
+        string_bytes[0] += int64_t(L.names.size());
+        string_bytes[1] += int64_t(L.runs.size());
+        string_bytes[2] += int64_t(L.f5s.size());
+    }
+}
+
+WSH_EXPORT void wsh_loci_columns(int32_t n, void *const *handles, int64_t *saved, uint8_t *reverse, int64_t *lo, int64_t *hi, char *names,
+                                 int64_t *names_off, char *runs, int64_t *runs_off, char *f5s, int64_t *f5s_off)
+{
+    int64_t at = 0, b0 = 0, b1 = 0, b2 = 0;
+    auto strings = [](const std::string &blob, const std::vector<int64_t> &off, int64_t rows, char *out, int64_t *out_off, int64_t at, int64_t &base) {
+        const bool have = int64_t(off.size()) == rows + 1;
+        for (int64_t r = 0; r < rows; r++) out_off[at + r] = base + (have ? off[size_t(r)] : 0);
+        if (have && !blob.empty()) memcpy(out + base, blob.data(), blob.size());
+        base += have ? int64_t(blob.size()) : 0;
+    };
+    for (int32_t i = 0; i < n; i++) {
+        const Locus &L = *static_cast<Locus *>(handles[i]);
+        const int64_t rows = int64_t(L.saved_rows.size());
+        for (int64_t r = 0; r < rows; r++) saved[at + r] = L.saved_rows[size_t(r)];
+        if (rows) {
+            memcpy(reverse + at, L.reverse.data(), size_t(rows));
+            memcpy(lo + at, L.lo.data(), size_t(rows) * 8);
+            memcpy(hi + at, L.hi.data(), size_t(rows) * 8);
+        }
+        strings(L.names, L.names_off, rows, names, names_off, at, b0);
+        strings(L.runs, L.runs_off, rows, runs, runs_off, at, b1);
+        strings(L.f5s, L.f5s_off, rows, f5s, f5s_off, at, b2);
+        at += rows;
+    }
+    names_off[at] = b0;
+    runs_off[at] = b1;
+    f5s_off[at] = b2;
+}
+
 // The text of overview.csv (the bytes that were read), for the DataFrame a caller may ask for later.
 WSH_EXPORT const char *wsh_locus_text(void *h, int64_t *len)
 {
