@@ -255,6 +255,12 @@ def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
             assert f.signal_length(rid) == len(sig)
     with _h5core.Fast5Core(path) as c:
         for rid, sig in reads.items():
+            if fast5._vbz_native() is None:   # (a build without _host_loci.so: the core leaves VBZ to the array reader's decoders)
+                with pytest.raises(_h5core.NeedsNumpy):
+                    c.decode_to(rid, lambda n: 0)
+                with pytest.raises(_h5core.NeedsNumpy):
+                    c.blocks_to(rid, lambda n: 0)
+                continue
             buf = np.full(len(sig) + 4, 777, np.int16)
             assert c.decode_to(rid, lambda n: buf.ctypes.data + 4) == len(sig)
             assert np.array_equal(buf[2:-2], sig) and (buf[:2] == 777).all() and (buf[-2:] == 777).all()
@@ -288,7 +294,8 @@ def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
     arena, cap, base, used, lens, table, _ = _readers.pack_arena(('test_vbz_chunks', 1, items))
     try:
         t = np.frombuffer(table, np.int64).reshape(-1, 6)
-        assert lens == [len(reads[r]) for r in reads] and len(t) == sum(-(-len(s) // 4096) for s in reads.values())
+        assert lens == [len(reads[r]) for r in reads]
+        assert len(t) == (sum(-(-len(s) // 4096) for s in reads.values()) if fast5._vbz_native() is not None else len(reads))
         view = np.memmap(arena, dtype=np.uint8, mode='r')
         got = {r: [] for r in range(len(reads))}
         for r, kind, off, nbytes, ns, nv in t:

@@ -388,7 +388,8 @@ def test_fast5_files_are_read_on_the_worker_processes(tmp_path):
     finally:
         wl.SHARED_BATCH_READS = old_reads
     assert tm_e['reader_mode'] == 'arenas, VBZ decoded on the GPU' and tm_e['vbz_batches'] == tm_e['batches'] >= 4 and tm_e['arena_batches'] == 0
-    assert tm_e['uploaded_bytes'] < 0.75 * tm_e['raw_bytes'] and tm_d['uploaded_bytes'] == tm_d['raw_bytes']
+    # (without _host_loci.so the readers decode with NumPy and hand plain samples over: the same files, no fewer bytes)
+    assert tm_e['uploaded_bytes'] < (0.75 if fast5._vbz_native() is not None else 1.01) * tm_e['raw_bytes'] and tm_d['uploaded_bytes'] == tm_d['raw_bytes']
     # ... and a region is not handed out again before the calling thread has SUBMITTED the batch that used it (an engine that
     # dawdles before it looks at the arenas: the readers would have overwritten them when taking a batch from the queue was enough)
     import time
