@@ -9,8 +9,8 @@
 // frame's content into its page-locked arena); the rest is two prefix sums, done here:
 //   where the bytes of a value start  = sum of the byte lengths before it      (scan over the keys)
 //   the sample                        = sum of the differences up to it, mod 2^16 (scan over the values)
-// vbz_decode_kernel: a workgroup of 256 lanes per block (a read's chunk: 60-170 k samples), 1024 values per round -- a lane takes
-// a key byte, i.e. four values: their lengths, a workgroup scan, <= 16 data bytes, four differences, a second workgroup scan,
+// vbz_decode_kernel: a workgroup of 256 lanes per block (a read's chunk: 60-170 k samples), 2048 values per round -- a lane takes
+// two key bytes 256 apart, of each its four values: their lengths, a workgroup scan, <= 16 data bytes, four differences, a second workgroup scan,
 // four samples; the next round's keys and the 4 KB window its value bytes lie in are fetched a round ahead (the window into LDS).  Integer work, bit-exact against the host decoders (warpstr_amd/fast5.py, csrc/host_loci.cpp).
 #include <hip/hip_runtime.h>
 
@@ -22,11 +22,10 @@
 namespace {
 
 constexpr int VBZ_LANES = 256;
-constexpr int VBZ_WINDOW = VBZ_LANES * 16; // bytes of values a round can ask for (1 024 values of four bytes)
+constexpr int VBZ_TILES = 2;               // key bytes a lane takes per round, 256 key bytes apart: two independent chains between
+                                           // the same two barriers (1: 0.72 ms per 2 048 blocks, 2: 0.665, 4: 0.686)
+constexpr int VBZ_WINDOW = VBZ_TILES * VBZ_LANES * 16; // bytes of values a round can ask for (four bytes each)
 
-// inclusive sum over the 64 lanes of a wavefront in seven data-parallel-primitive adds (no LDS round trips: as six __shfl_up steps
-// -- ds_bpermute -- the two scans of a round were a quarter of its vector instructions and most of its latency): three shifts inside
-// the rows of 16 lanes from the input, two more from the partial sums, then the rows' last lanes broadcast over the rows behind them
 __device__ __forceinline__ int wave_inclusive_sum(int v)
 {
     int r = v;
@@ -63,8 +62,9 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
                                                                const wsx_vbz_block *__restrict__ blocks, int16_t *__restrict__ dst,
                                                                int32_t *__restrict__ status)
 {
-    __shared__ int wsum[2][VBZ_LANES / 64];                      // per wavefront: bytes, differences
-    __shared__ __attribute__((aligned(16))) uint8_t win[2][VBZ_WINDOW + 16]; // the value bytes of this round and of the next
+    constexpr int T = VBZ_TILES, W = VBZ_LANES / 64;
+    __shared__ int wsum[2][T][W];                                                 // per tile and wavefront: bytes, differences
+    __shared__ __attribute__((aligned(16))) uint8_t win[2][VBZ_WINDOW + 16];      // the value bytes of this round and of the next
     const wsx_vbz_block B = blocks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = B.n_samples;
@@ -84,77 +84,100 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
     bool bad = false;
     // A round's chain would be: key byte (global) -> scan -> value bytes (global, at an address the scan gives) -> scan -> store.
     // Both loads are taken out of it: the keys of round r+1 depend on nothing and are fetched in round r; the value bytes of round
-    // r+1 start where round r's end -- known after round r's FIRST scan -- so the 4 KB window that holds them, whatever the keys of
-    // round r+1 will say, is fetched then (one 16-byte load per lane), lands in LDS at the end of round r and is read from there.
-    int key_next = tid < nkeys ? p[tid] : 0;
-    // (the window is 4 096 + 16 bytes: it starts at a 16-byte boundary up to 15 bytes before the round's first value byte; the last
-    // chunk is lane 0's second load)
-    *(vbz_u32x4 *)&win[0][16 * tid] = window_load(data, src, src + src_total, tid);
-    if (tid == 0) *(vbz_u32x4 *)&win[0][VBZ_WINDOW] = window_load(data, src, src + src_total, VBZ_LANES);
-    int par = 0;
-    for (int k0 = 0; k0 < nkeys; k0 += VBZ_LANES, par ^= 1) {
-        const int ki = k0 + tid;
-        const int valid = ki < nkeys ? min(4, n - 4 * ki) : 0; // values of this lane's key byte that exist
-        const int key = key_next;
-        key_next = ki + VBZ_LANES < nkeys ? p[ki + VBZ_LANES] : 0;
-        const int l0 = valid > 0 ? (key & 3) + 1 : 0, l1 = valid > 1 ? ((key >> 2) & 3) + 1 : 0;
-        const int l2 = valid > 2 ? ((key >> 4) & 3) + 1 : 0, l3 = valid > 3 ? (key >> 6) + 1 : 0;
-        const int tl = l0 + l1 + l2 + l3;
-        const int incl = wave_inclusive_sum(tl);
-        if (lane == 63) wsum[0][wave] = incl;
-        __syncthreads(); // (also: the window of this round, written at the end of the last, is in LDS)
-        int before = 0, round_bytes = 0;
+    // r+1 start where round r's end -- known after round r's FIRST scan -- so the window that holds them, whatever the keys of
+    // round r+1 will say, is fetched then (a 16-byte load per lane and tile), lands in LDS at the end of round r and is read from
+    // there.  A lane takes T key bytes per round, one of each tile of 256: their chains are independent, the barriers shared.
+    int key_next[T];
 #pragma unroll
-        for (int w = 0; w < VBZ_LANES / 64; w++) {
-            const int s = wsum[0][w];
-            before += w < wave ? s : 0;
-            round_bytes += s;
+    for (int t = 0; t < T; t++) key_next[t] = t * VBZ_LANES + tid < nkeys ? p[t * VBZ_LANES + tid] : 0;
+    // (the window is T * 4 096 + 16 bytes: it starts at a 16-byte boundary up to 15 bytes before the round's first value byte; the
+    // last chunk is lane 0's extra load)
+#pragma unroll
+    for (int t = 0; t < T; t++) *(vbz_u32x4 *)&win[0][16 * (t * VBZ_LANES + tid)] = window_load(data, src, src + src_total, t * VBZ_LANES + tid);
+    if (tid == 0) *(vbz_u32x4 *)&win[0][VBZ_WINDOW] = window_load(data, src, src + src_total, T * VBZ_LANES);
+    int par = 0;
+    for (int k0 = 0; k0 < nkeys; k0 += T * VBZ_LANES, par ^= 1) {
+        int ki[T], valid[T], len[T][4], tl[T], incl[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            ki[t] = k0 + t * VBZ_LANES + tid;
+            valid[t] = ki[t] < nkeys ? min(4, n - 4 * ki[t]) : 0; // values of this key byte that exist
+            const int key = key_next[t];
+            key_next[t] = ki[t] + T * VBZ_LANES < nkeys ? p[ki[t] + T * VBZ_LANES] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) len[t][j] = valid[t] > j ? ((key >> (2 * j)) & 3) + 1 : 0;
+            tl[t] = len[t][0] + len[t][1] + len[t][2] + len[t][3];
+            incl[t] = wave_inclusive_sum(tl[t]);
+            if (lane == 63) wsum[0][t][wave] = incl[t];
         }
-        const vbz_u32x4 next = window_load(data + doff + round_bytes, src, src + src_total, tid); // (in flight during this round)
-        vbz_u32x4 next_tail = {0, 0, 0, 0};
-        if (tid == 0) next_tail = window_load(data + doff + round_bytes, src, src + src_total, VBZ_LANES);
-        const long long my = doff + before + incl - tl;
-        const int at = (int)(((uintptr_t)(data + doff) & 15) + (my - doff)); // this lane's first byte in the window
-        // (the bytes a value does not have are not read: all sixteen read unconditionally and cut afterwards was slower, 0.81 vs 0.72 ms)
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (my + tl <= data_bytes) {
-            const uint8_t *q = &win[par][at];
-            const int len[4] = {l0, l1, l2, l3};
+        __syncthreads(); // (also: the window of this round, written at the end of the last, is in LDS)
+        int before[T], round_bytes = 0;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            before[t] = round_bytes; // the tiles before this one ...
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int s = wsum[0][t][w];
+                before[t] += w < wave ? s : 0; // ... and the wavefronts before this one in it
+                round_bytes += s;
+            }
+        }
+        vbz_u32x4 next[T], next_tail = {0, 0, 0, 0}; // (in flight during this round)
+#pragma unroll
+        for (int t = 0; t < T; t++) next[t] = window_load(data + doff + round_bytes, src, src + src_total, t * VBZ_LANES + tid);
+        if (tid == 0) next_tail = window_load(data + doff + round_bytes, src, src + src_total, T * VBZ_LANES);
+        const int align = (int)((uintptr_t)(data + doff) & 15);
+        int sum[T][4], total[T], vincl[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int rel = before[t] + incl[t] - tl[t]; // this key byte's first value byte, from the round's first
+            uint32_t v[4] = {0, 0, 0, 0};
+            // (the bytes a value does not have are not read: all sixteen read unconditionally and cut afterwards was slower)
+            if (doff + rel + tl[t] <= data_bytes) {
+                const uint8_t *q = &win[par][align + rel];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t x = 0;
+                    if (len[t][j] > 0) x = q[0];
+                    if (len[t][j] > 1) x |= (uint32_t)q[1] << 8;
+                    if (len[t][j] > 2) x |= (uint32_t)q[2] << 16;
+                    if (len[t][j] > 3) x |= (uint32_t)q[3] << 24;
+                    v[j] = x;
+                    q += len[t][j];
+                }
+            } else if (tl[t] > 0) {
+                bad = true; // the keys ask for bytes the block does not have: zeros from here on
+            }
+            int run = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t x = 0;
-                if (len[j] > 0) x = q[0];
-                if (len[j] > 1) x |= (uint32_t)q[1] << 8;
-                if (len[j] > 2) x |= (uint32_t)q[2] << 16;
-                if (len[j] > 3) x |= (uint32_t)q[3] << 24;
-                v[j] = x;
-                q += len[j];
+                run += zigzag ? (int)((v[j] >> 1) ^ (0u - (v[j] & 1u))) : (int)v[j];
+                sum[t][j] = run;
             }
-        } else if (tl > 0) {
-            bad = true; // the keys ask for bytes the block does not have: zeros from here on
+            total[t] = run;
+            vincl[t] = wave_inclusive_sum(run);
+            if (lane == 63) wsum[1][t][wave] = vincl[t];
         }
-        int d[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = zigzag ? (int)((v[j] >> 1) ^ (0u - (v[j] & 1u))) : (int)v[j];
-        const int s0 = d[0], s1 = s0 + d[1], s2 = s1 + d[2], s3 = s2 + d[3];
-        const int vincl = wave_inclusive_sum(s3);
-        if (lane == 63) wsum[1][wave] = vincl;
-        *(vbz_u32x4 *)&win[par ^ 1][16 * tid] = next; // (last read in the round before this one, two barriers ago)
+        for (int t = 0; t < T; t++) *(vbz_u32x4 *)&win[par ^ 1][16 * (t * VBZ_LANES + tid)] = next[t]; // (last read a round ago, two barriers back)
         if (tid == 0) *(vbz_u32x4 *)&win[par ^ 1][VBZ_WINDOW] = next_tail;
         __syncthreads();
-        int vbefore = 0, round_sum = 0;
+        int round_sum = 0;
 #pragma unroll
-        for (int w = 0; w < VBZ_LANES / 64; w++) {
-            const int s = wsum[1][w];
-            vbefore += w < wave ? s : 0;
-            round_sum += s;
+        for (int t = 0; t < T; t++) {
+            int vbefore = round_sum;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int s = wsum[1][t][w];
+                vbefore += w < wave ? s : 0;
+                round_sum += s;
+            }
+            const int base = acc + vbefore + vincl[t] - total[t];
+            int16_t *o = out + 4 * (size_t)ki[t];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (valid[t] > j) o[j] = (int16_t)(base + sum[t][j]);
         }
-        const int base = acc + vbefore + vincl - s3;
-        int16_t *o = out + 4 * (size_t)ki;
-        if (valid > 0) o[0] = (int16_t)(base + s0);
-        if (valid > 1) o[1] = (int16_t)(base + s1);
-        if (valid > 2) o[2] = (int16_t)(base + s2);
-        if (valid > 3) o[3] = (int16_t)(base + s3);
         acc += round_sum;
         doff += round_bytes;
         // (wsum[0] is written again after the second barrier of this round, wsum[1] after the first of the next: two suffice)
