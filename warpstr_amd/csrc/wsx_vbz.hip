@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/warpstr_hip.h"
 
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
     for (int t = 0; t < T; t++) *(vbz_u32x4 *)&win[0][16 * (t * VBZ_LANES + tid)] = window_load(data, src, src + src_total, t * VBZ_LANES + tid);
     if (tid == 0) *(vbz_u32x4 *)&win[0][VBZ_WINDOW] = window_load(data, src, src + src_total, T * VBZ_LANES);
     int par = 0;
-    for (int k0 = 0; k0 < nkeys; k0 += T * VBZ_LANES, par ^= 1) {
+    // (a round all of whose values exist -- every round but a block's last -- is compiled without the tests for that)
+    auto round = [&](const int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         int ki[T], valid[T], len[T][4], tl[T], incl[T];
 #pragma unroll
         for (int t = 0; t < T; t++) {
             ki[t] = k0 + t * VBZ_LANES + tid;
-            valid[t] = ki[t] < nkeys ? min(4, n - 4 * ki[t]) : 0; // values of this key byte that exist
+            valid[t] = FULL ? 4 : (ki[t] < nkeys ? min(4, n - 4 * ki[t]) : 0); // values of this key byte that exist
             const int key = key_next[t];
             key_next[t] = ki[t] + T * VBZ_LANES < nkeys ? p[ki[t] + T * VBZ_LANES] : 0;
 #pragma unroll
@@ -181,6 +184,10 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
         acc += round_sum;
         doff += round_bytes;
         // (wsum[0] is written again after the second barrier of this round, wsum[1] after the first of the next: two suffice)
+    };
+    for (int k0 = 0; k0 < nkeys; k0 += T * VBZ_LANES, par ^= 1) {
+        if (4 * (k0 + T * VBZ_LANES) <= n) round(k0, std::true_type{});
+        else round(k0, std::false_type{});
     }
     if (bad && status) status[blockIdx.x] = 1;
 }
