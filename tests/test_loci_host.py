@@ -760,3 +760,39 @@ def test_arenas_are_not_used_when_dev_shm_has_no_room_for_them(tmp_path, monkeyp
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_a_few_loci_with_many_reads_get_reader_processes_too(tmp_path, monkeypatch):
+    """configs[3] / [4]: a handful of loci with thousands of reads each.  The reader processes are started by the size of the run's
+    overviews, not only by the number of loci: three loci x 50 reads with the threshold lowered to 100 reads."""
+    import warpstr_amd.loci as wl
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+
+    def make(root):
+        loci = []
+        for li, (pattern, fl) in enumerate([('(AGC)', 16), ('(AAAT)', 30), ('(GGCCCC)', 24)]):
+            locus = synth.make_locus(pattern, fl, 900 + li)
+            loc = os.path.join(root, f'locus{li}')
+            ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
+            rows = [ids[(li + k) % 10] for k in range(50)]
+            pd.DataFrame({'read_name': rows, 'run_id': 'run_0', 'reverse': [bool(k & 1) for k in range(50)], 'saved': 1, 'l_start_raw': 5000,
+                          'r_end_raw': 6500, 'fast5_path': src}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+            loci.append(LocusPath(loc, pattern, fl))
+        return loci
+    a, b = make(str(tmp_path / 'a')), make(str(tmp_path / 'b'))
+    tm_a, tm_b = {}, {}
+    main_wrapper_loci(a, 3, _engine=VbzFakeEngine, quiet=True, timings=tm_a)     # default thresholds: 150 reads are a small run
+    assert tm_a['reader_processes'] == 0 and tm_a['reader_mode'].endswith('filled in this process')
+    monkeypatch.setattr(wl, 'READER_POOL_FROM_READS', 100)
+    main_wrapper_loci(b, 3, _engine=VbzFakeEngine, quiet=True, timings=tm_b)
+    assert tm_b['reader_processes'] == 3 and tm_b['reader_mode'] == 'arenas, VBZ decoded on the GPU'
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel

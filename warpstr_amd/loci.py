@@ -408,12 +408,26 @@ class _InlinePool:
         _readers._drop_arenas(self.owner)
 
 
-def _reader_pool(threads: int, n_loci: int):
-    """Worker processes for the fast5 files of a run, or None: one thread, or fewer than 64 loci (starting the workers takes
-    about a second).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported
-    once and the files are read in this process; what a worker raises while reading is raised by _WorkerPool.map."""
-    if threads <= 1 or n_loci < 64:
+READER_POOL_FROM_LOCI = 64      # reader processes are started for a run of that many loci ...
+READER_POOL_FROM_READS = 2048   # ... or of about that many reads (a few loci with thousands of reads each: configs[3] / [4])
+
+
+def _reader_pool(threads: int, loci):
+    """Worker processes for the fast5 files of a run, or None: one thread, or a run too small to be worth sixteen interpreters
+    (fewer than READER_POOL_FROM_LOCI loci whose overview.csv files -- ~120 bytes a row -- do not hold READER_POOL_FROM_READS reads
+    between them).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported once
+    and the files are read in this process; what a worker raises while reading is raised by _WorkerPool.map."""
+    if threads <= 1:
         return None
+    if len(loci) < READER_POOL_FROM_LOCI:
+        size = 0
+        for locus in loci:
+            try:
+                size += os.stat(os.path.join(locus.path, 'overview.csv')).st_size
+            except (OSError, AttributeError):
+                pass
+        if size < 120 * READER_POOL_FROM_READS:
+            return None
     return _WorkerPool(min(int(threads), os.cpu_count() or 1))
 
 
@@ -499,7 +513,8 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     pore_model: a pore_model.PoreModel (default: the built-in r9.4 table; `pore_model_path` of a configuration).
     batch_*: where the read list is cut -- a batch holds at most that many reads, segment samples and raw bytes.
     threads: threads of the per-locus host work (native code without the GIL: overview, automata, output files); with more than
-    one thread and 64 loci or more the fast5 files are read on as many worker processes.
+    one thread and 64 loci or more (or fewer loci whose overviews hold ~2 000 reads or more) the fast5 files are read on as many
+    worker processes.
     shard=True: the run is one torch.distributed job.  partition: 'loci' = every rank takes whole loci, 'reads' = every rank
     takes its share of every locus's reads, 'auto' = 'loci' from LOCI_PER_RANK_FOR_LOCUS_PARTITION loci per rank on.
     timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure.
@@ -573,7 +588,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     # (the reader processes start first: they come up -- half a second of imports -- while the loci are set up.  On the bench's
     # sandboxed box sixteen interpreters starting slow whatever runs beside them: the set-up 0.3 -> 0.9 s for 3 000 loci; started
     # beside the handle's creation instead they cost that 0.2 -> 1.5 s.)
-    pool = _reader_pool(threads, len(own)) if fast5_on_workers else None
+    pool = _reader_pool(threads, [loci[i] for i in own]) if fast5_on_workers else None
     pools.append(pool)
     tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
