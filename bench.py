@@ -656,18 +656,22 @@ def from_fast5_leg(n_copies, local):
             base = None
     root = tempfile.mkdtemp(prefix='wsx_from_fast5_', dir=base)
     try:
-        def make(tag, n=n_copies):
+        def make(tag, n=n_copies, per_locus=1):
+            """n copies of the file; a locus per `per_locus` copies (its overview lists the reads of all of them)."""
             loci = []
-            for i in range(n):
-                loc = os.path.join(root, tag, f'copy{i:04d}')
-                f5 = os.path.join(root, 'fast5', f'batch_{i:04d}.fast5')
-                if not os.path.exists(f5):
-                    os.makedirs(os.path.dirname(f5), exist_ok=True)
-                    shutil.copyfile(os.path.join(real, 'batch_0.fast5'), f5)
+            for i0 in range(0, n, per_locus):
+                loc = os.path.join(root, tag, f'copy{i0:04d}')
+                rows = []
+                for i in range(i0, min(n, i0 + per_locus)):
+                    f5 = os.path.join(root, 'fast5', f'batch_{i:04d}.fast5')
+                    if not os.path.exists(f5):
+                        os.makedirs(os.path.dirname(f5), exist_ok=True)
+                        shutil.copyfile(os.path.join(real, 'batch_0.fast5'), f5)
+                    rows.append(pd.DataFrame({'read_name': ex['read_name'], 'fast5_path': f5, 'reverse': ex['reverse'].astype(bool),
+                                              'l_start_raw': ex['l_start_raw'], 'r_end_raw': ex['r_end_raw'], 'run_id': 'run_0', 'saved': 1}))
                 ov.store_flanks(loc, [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']])
-                pd.DataFrame({'read_name': ex['read_name'], 'fast5_path': f5, 'reverse': ex['reverse'].astype(bool), 'l_start_raw': ex['l_start_raw'],
-                              'r_end_raw': ex['r_end_raw'], 'run_id': 'run_0', 'saved': 1}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
-                loci.append(LocusPath(loc, fj['sequence'], int(fj['flank_length']), f'copy{i:04d}'))
+                pd.concat(rows, ignore_index=True).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+                loci.append(LocusPath(loc, fj['sequence'], int(fj['flank_length']), f'copy{i0:04d}'))
             return loci
         warm = make('warm', 8)
         main_wrapper_loci(warm, 1, device=local, quiet=True)
@@ -675,20 +679,22 @@ def from_fast5_leg(n_copies, local):
                            f'caller-only layout, files under {base or "the default temporary directory"} (page cache) -> output files',
                'reads': n_copies * len(ex)}
         many = min(16, os.cpu_count() or 1)
-        legs = [('one_process', 1, n_copies), ('sixteen_reader_processes', many, n_copies)]
+        legs = [('one_process', 1, n_copies, 1), ('sixteen_reader_processes', many, n_copies, 1),
+                # configs[4]'s shape from files: the same reads as eight loci (1 875 reads each at the default size)
+                ('sixteen_reader_processes_eight_loci', many, n_copies, -(-n_copies // 8))]
         st = os.statvfs(root)
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
-            legs.append(('sixteen_reader_processes_4x_the_copies', many, 4 * n_copies))   # batch's tail -- weigh less on a longer run)
+            legs.append(('sixteen_reader_processes_4x_the_copies', many, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
         only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
-        for tag, threads, n in [leg for leg in legs if not only or leg[0] == only]:
-            loci = make(tag, n)
+        for tag, threads, n, per_locus in [leg for leg in legs if not only or leg[0] == only]:
+            loci = make(tag, n, per_locus)
             n_reads = n * len(ex)
             tm = {}
             tables = main_wrapper_loci(loci, threads, device=local, quiet=True, timings=tm)
             with contextlib.redirect_stdout(io.StringIO()):
                 calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
-            lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results']) for l in loci[::max(1, n // n_copies)]]
-            out[tag] = {'reads': n_reads, 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
+            lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results'][:len(ex)]) for l in loci[::max(1, n // n_copies)]]
+            out[tag] = {'reads': n_reads, 'loci': len(loci), 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
                         'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
                         'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
                         'inside_submit_upload': tm.get('submit_parts_s'),
