@@ -79,8 +79,8 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
     const int nkeys = (n + 3) >> 2;                       // key bytes that matter: those of the samples wanted
     const int key_area = (B.n_values + 3) >> 2;           // ... of all the values the block codes
     const uint8_t *data = p + key_area;
-    const long long data_bytes = B.src_bytes - key_area; // (>= n_values: checked on the host)
-    long long doff = 0; // bytes of the values before this round (the same in every lane)
+    const int data_bytes = (int)(B.src_bytes - key_area); // (>= n_values and < 2^31: checked on the host)
+    int doff = 0; // bytes of the values before this round (the same in every lane; 32 bits: 64-bit offsets cost two instructions each)
     int acc = 0;        // sum of the differences before this round; only its low 16 bits matter
     bool bad = false;
     // A round's chain would be: key byte (global) -> scan -> value bytes (global, at an address the scan gives) -> scan -> store.
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(VBZ_LANES) void vbz_decode_kernel(const uint8_t *__
             const int rel = before[t] + incl[t] - tl[t]; // this key byte's first value byte, from the round's first
             uint32_t v[4] = {0, 0, 0, 0};
             // (the bytes a value does not have are not read: all sixteen read unconditionally and cut afterwards was slower)
-            if (doff + rel + tl[t] <= data_bytes) {
+            if (rel + tl[t] <= data_bytes - doff) {
                 const uint8_t *q = &win[par][align + rel];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -230,6 +230,10 @@ try {
         if (B.kind < WSX_VBZ_PLAIN || B.kind > WSX_VBZ_SVB || n < 0 || B.src_offset < 0 || B.src_bytes < 0 || B.dst_offset < 0 ||
             B.src_bytes > src_bytes || B.src_offset > src_bytes - B.src_bytes || n > dst_samples || B.dst_offset > dst_samples - n) {
             wsx_internal_set_error("wsx_vbz_decode: a block lies outside src or dst");
+            return WSX_ERR_INVALID;
+        }
+        if (B.src_bytes > 0x7fffffff) {
+            wsx_internal_set_error("wsx_vbz_decode: a block of 2 GB or more");
             return WSX_ERR_INVALID;
         }
         if (B.n_values < B.n_samples || B.reserved != 0) {
