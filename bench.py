@@ -620,9 +620,10 @@ def vbz_kernel_leg(path, local, n_blocks=2048, launches=20):
     hip.close()
     algo = int(blocks['src_bytes'].sum()) + 2 * out
     return {'kernel': 'vbz_decode_kernel', 'blocks_per_launch': n_blocks, 'samples_per_launch': out, 'algorithmic_bytes_per_launch': algo,
-            'launch_ms': ms, 'roofline': {'bound': 'hbm', 'achieved': algo / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algo / ms / 1e6 / 8000.0},
+            'launch_ms': ms, 'roofline': {'bound': 'hbm', 'achieved': algo / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algo / ms / 1e6 / 8000.0,
+                                             'traffic': None},   # (counters: profiles/r05_vbz_pmc.log -- 1.03 x the algorithmic bytes)
             'samples_per_s': out / ms * 1e3, 'equal_to_oracle': bool(ok),
-            'note': 'a workgroup per block, two workgroup scans per 1 024 values; the from_fast5 leg needs 8 x 10^9 samples/s of it'}
+            'note': 'a workgroup per block, two workgroup scans per 2 048 values; bound by the instructions it issues (VALU half busy); the from_fast5 leg needs 9 x 10^9 samples/s of it'}
 
 
 def from_fast5_leg(n_copies, local):

@@ -5,7 +5,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"; do
   tag=$(echo $grp | tr ' ' '_')
   timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_vbz_$tag -o p -- python3 $R/scripts/prof_vbz.py 2048 4 > $O/pmc_vbz.json 2> $O/pmc_vbz.err || { tail -5 $O/pmc_vbz.err; exit 1; }
 done
