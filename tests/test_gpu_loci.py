@@ -331,3 +331,53 @@ def test_reads_whose_datasets_are_several_vbz_chunks(tmp_path, monkeypatch):
     assert tm_a['uploaded_bytes'] < tm_a['raw_bytes'] == tm_b['raw_bytes'] == tm_c['raw_bytes']
     _same(a, b)
     _same(c, b)
+
+
+def test_a_block_that_changed_on_its_way_to_the_device_fails_its_batch(tmp_path):
+    """The readers check every StreamVByte block before it is uploaded; should one still reach the device with keys that ask for
+    more bytes than it has (memory that changed in between), the device decoder flags it and collect() raises -- the batch is
+    not called on samples that were never decoded.  Built by hand: an arena file with a good and a tampered block."""
+    import tempfile
+    import torch
+    from oracle import vbz
+    from warpstr_amd import _lib
+    from warpstr_amd.loci import HipEngine
+    if not os.path.isdir('/dev/shm'):
+        pytest.skip('no /dev/shm')
+    locus = synth.make_locus('(AGC)', 16, 3)
+    engine = HipEngine([locus.template, locus.reverse], [16, 16], None, None, 0)
+    rng = np.random.default_rng(4)
+    raws = [np.cumsum(rng.integers(-30, 31, size=6000)).astype(np.int16) + 500 for _ in range(2)]
+    blocks = [vbz.svb_encode(vbz.values_from_samples(r, True)) for r in raws]
+    blocks[1] = blocks[1].copy()
+    blocks[1][700:1500] = 0xFF                     # the second block's keys now ask for far more bytes than follow them
+    fd, path = tempfile.mkstemp(prefix='warpstr_test_arena_', dir='/dev/shm')
+    try:
+        offs, at = [], 0
+        for b in blocks:
+            at = (at + 15) & ~15
+            offs.append(at)
+            at += len(b)
+        cap = 1 << 20
+        os.ftruncate(fd, cap)
+        with os.fdopen(fd, 'r+b') as fh:
+            for o, b in zip(offs, blocks):
+                fh.seek(o)
+                fh.write(b.tobytes())
+        table = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000],
+                          [1, _lib.VBZ_SVB_ZIGZAG, offs[1], len(blocks[1]), 6000, 6000]], np.int64)
+        part = (path, cap, 0, at, [6000, 6000], table.tobytes())
+        lo, hi, aut = np.array([1000, 1000]), np.array([2999, 2999]), np.array([0, 1], np.int32)
+        ticket = engine.submit_vbz_parts(0, [part], lo, hi, aut)
+        with pytest.raises(RuntimeError, match='wsx_vbz_decode flagged'):
+            engine.collect(ticket)
+        # the same arena with the good block twice: called as ever
+        good = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000],
+                         [1, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000]], np.int64)
+        ticket = engine.submit_vbz_parts(1, [(path, cap, 0, at, [6000, 6000], good.tobytes())], lo, hi, aut)
+        rec = engine.collect(ticket)[0]
+        assert len(rec) == 2
+        torch.cuda.synchronize()
+    finally:
+        engine.close()
+        os.unlink(path)
