@@ -289,13 +289,69 @@ class _WorkerPool:
                     env['WARPSTR_LIBHDF5'], env['WARPSTR_LIBZSTD'] = lib_paths()
                 except RuntimeError:
                     pass   # (a worker says which library is missing when it is asked for its first read)
-                for k in range(n):
-                    self._procs.append(subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE,
-                                                        stdout=subprocess.PIPE, env=env))
+                if hasattr(os, 'fork') and not os.environ.get('WARPSTR_NO_FORK_READERS'):
+                    self._procs = self._forked(n, env)
+                if not self._procs:   # (one interpreter per reader, started from here)
+                    for k in range(n):
+                        self._procs.append(subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', str(k + 1)], stdin=subprocess.PIPE,
+                                                            stdout=subprocess.PIPE, env=env))
             except OSError as e:
                 self._error = e
         self._starter = threading.Thread(target=start, daemon=True)
         self._starter.start()
+
+    @staticmethod
+    def _forked(n: int, env):
+        """n readers forked by ONE interpreter this process starts (`_hostworker --fork`): starting a process costs this one --
+        its address space holds the GPU runtime -- ~10 ms each, and sixteen interpreters importing at once another 80 ms; the
+        helper imports once and forks sixteen times in a few milliseconds.  Returns the readers (objects with the pipe ends, the
+        process number, wait and kill, as far as the pool uses them of a Popen), or [] if the helper did not come up as expected
+        (the caller then starts the readers one by one); raises OSError if it could not be started at all."""
+        import subprocess
+        parent_ends, child_fds = [], []
+        try:
+            for _ in range(n):
+                task_r, task_w = os.pipe()
+                answer_r, answer_w = os.pipe()
+                child_fds += [task_r, answer_w]
+                parent_ends.append((task_w, answer_r))
+            helper = subprocess.Popen([sys.executable, '-m', 'warpstr_amd._hostworker', '--fork'] + [str(fd) for fd in child_fds],
+                                      stdout=subprocess.PIPE, env=env, pass_fds=child_fds)
+        except OSError:
+            for fd in child_fds + [fd for pair in parent_ends for fd in pair]:
+                try:
+                    os.close(fd)
+                except OSError:
+                    pass
+            raise
+        for fd in child_fds:
+            os.close(fd)
+        line = helper.stdout.readline().split()
+        if len(line) != n or not all(x.isdigit() for x in line):
+            helper.kill()
+            for fd in [fd for pair in parent_ends for fd in pair]:
+                os.close(fd)
+            return []
+
+        class Reader:
+            def __init__(self, pid, task_w, answer_r):
+                self.pid, self.stdin, self.stdout = pid, os.fdopen(task_w, 'wb'), os.fdopen(answer_r, 'rb')
+
+            def wait(self, timeout=None):   # (a reader is the helper's child, not ours: the helper ends when all of them have)
+                return helper.wait(timeout=timeout)
+
+            def kill(self):
+                import signal
+                for victim in (self.pid, helper.pid):
+                    try:
+                        os.kill(victim, signal.SIGKILL)
+                    except OSError:
+                        pass
+                try:
+                    helper.wait(timeout=5)
+                except Exception:  # noqa: BLE001
+                    pass
+        return [Reader(int(pid), tw, ar) for pid, (tw, ar) in zip(line, parent_ends)]
 
     @property
     def procs(self):
