@@ -60,6 +60,8 @@ def fork_readers(fds):
                         os.close(w2)
                 os.close(PID_FD)
                 _readers.spread_over_cpus(k + 1)
+                if WARM_REGIONS:
+                    _readers.prepare_arenas(range(WARM_REGIONS))
                 serve(os.fdopen(r, 'rb'), os.fdopen(w, 'wb'))
             finally:
                 os._exit(0)
@@ -77,6 +79,7 @@ def fork_readers(fds):
 
 
 PID_FD = None
+WARM_REGIONS = int(os.environ.get('WARPSTR_WARM_ARENAS', '0') or 0)   # regions a forked reader creates and touches before its first task
 
 if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--fork':

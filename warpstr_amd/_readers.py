@@ -132,6 +132,21 @@ def _arena(region: int, samples: int):
     return _ARENAS[region]
 
 
+def prepare_arenas(regions, samples: int = 8 << 20):
+    """Create the arenas of `regions` ahead of the first task and touch their pages (a reader process does this while the parent
+    still sets its loci up: the first write into a fresh page of a memory-backed file costs a fault, ~50 of them per read).  Best
+    effort: no room, no arenas."""
+    try:
+        for region in regions:
+            rec = _arena(region, samples)
+            view = memoryview(rec[1])
+            for at in range(0, len(view), 4096):
+                view[at] = 0
+            view.release()
+    except (OSError, ValueError):
+        pass
+
+
 def _arena_address(region: int, samples: int) -> int:
     import ctypes
     return ctypes.addressof(_arena(region, samples)[2])

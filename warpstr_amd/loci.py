@@ -289,6 +289,10 @@ class _WorkerPool:
                     env['WARPSTR_LIBHDF5'], env['WARPSTR_LIBZSTD'] = lib_paths()
                 except RuntimeError:
                     pass   # (a worker says which library is missing when it is asked for its first read)
+                if not os.environ.get('WARPSTR_NO_READER_ARENAS'):
+                    # (a forked reader creates its arenas and touches their pages while the loci are still being set up: the first
+                    # write into a fresh page of a memory-backed file is a fault, ~50 per read -- a fifth of a reader's time)
+                    env.setdefault('WARPSTR_WARM_ARENAS', str(BatchQueue.ARENA_REGIONS))
                 if hasattr(os, 'fork') and not os.environ.get('WARPSTR_NO_FORK_READERS'):
                     self._procs = self._forked(n, env)
                 if not self._procs:   # (one interpreter per reader, started from here)
