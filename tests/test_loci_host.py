@@ -617,6 +617,7 @@ def test_garbage_collector_paused_during_a_long_run_and_back_afterwards(tmp_path
             seen.append(gc.isenabled())
             raise RuntimeError('no handle')
     from warpstr_amd import loci as loci_mod
+    monkeypatch.delenv('WARPSTR_KEEP_GC', raising=False)
     monkeypatch.setattr(loci_mod, 'GC_PAUSE_FROM_LOCI', 3)
     loci, sig = _make_loci(str(tmp_path / 'a'))
     kw = dict(signal_loader=_loader(sig), quiet=True)
