@@ -216,6 +216,9 @@ class NativeOverview:
     __del__ = close
 
 
+_COLLAPSE_CONST: dict = {}
+
+
 def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, offsets, header: str, sel, write: bool):
     """collapse_repeats for every called sequence + the complex-unit table: (counts [n x alternatives], CSV text), or None when
     the Python form has to run (library absent, an empty alternative)."""
@@ -223,19 +226,26 @@ def collapse_store(locus_path: str, seq2, off2, len2, reverse, repeat_units, off
     if h is None:
         return None
     n = len(len2)
-    n_alt = np.array([len(u) for u in repeat_units], np.int32)
-    flat = [a.encode('ascii') for u in repeat_units for a in u]
-    alt_off = np.zeros(len(flat) + 1, np.int32)
-    np.cumsum([len(a) for a in flat], out=alt_off[1:])
-    blob = b''.join(flat)
-    counts = np.zeros((n, len(flat)), np.int64)
+    # (what depends on the pattern alone is made once per pattern: a run's loci repeat a few hundred patterns at most, and this
+    # function runs under the interpreter's lock for every locus with more than one unit)
+    key = (header, tuple(tuple(u) for u in repeat_units), tuple(int(x) for x in offsets), tuple(int(x) for x in sel))
+    const = _COLLAPSE_CONST.get(key)
+    if const is None:
+        n_alt = np.array([len(u) for u in repeat_units], np.int32)
+        flat = [a.encode('ascii') for u in repeat_units for a in u]
+        alt_off = np.zeros(len(flat) + 1, np.int32)
+        np.cumsum([len(a) for a in flat], out=alt_off[1:])
+        if len(_COLLAPSE_CONST) > 4096:
+            _COLLAPSE_CONST.clear()
+        const = _COLLAPSE_CONST[key] = (n_alt, b''.join(flat), alt_off, np.ascontiguousarray(offsets, np.int32),
+                                        np.ascontiguousarray(sel, np.int32), header.encode('utf-8'), len(flat))
+    n_alt, blob, alt_off, offs, sel, header_b, n_flat = const
+    counts = np.zeros((n, n_flat), np.int64)
     arrs = [np.ascontiguousarray(seq2, np.uint8), np.ascontiguousarray(off2, np.int64), np.ascontiguousarray(len2, np.int32),
             np.ascontiguousarray(reverse, np.uint8)]
-    offs = np.ascontiguousarray(offsets, np.int32)
-    sel = np.ascontiguousarray(sel, np.int32)
     out, ln = C.c_void_p(), C.c_int64()
     rc = h.wsh_collapse_store(os.fsencode(locus_path), n, *[a.ctypes.data for a in arrs], len(repeat_units), n_alt.ctypes.data, blob,
-                              alt_off.ctypes.data, offs.ctypes.data, header.encode('utf-8'), len(sel), sel.ctypes.data, 1 if write else 0,
+                              alt_off.ctypes.data, offs.ctypes.data, header_b, len(sel), sel.ctypes.data, 1 if write else 0,
                               counts.ctypes.data,
                               C.byref(out), C.byref(ln))
     if rc > 0:
