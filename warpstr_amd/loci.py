@@ -330,7 +330,9 @@ class _WorkerPool:
             raise
         for fd in child_fds:
             os.close(fd)
-        line = helper.stdout.readline().split()
+        import select
+        ready, _, _ = select.select([helper.stdout], [], [], 60.0)   # (an interpreter that does not come up is not waited for)
+        line = helper.stdout.readline().split() if ready else []
         if len(line) != n or not all(x.isdigit() for x in line):
             helper.kill()
             for fd in [fd for pair in parent_ends for fd in pair]:
