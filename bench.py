@@ -405,10 +405,12 @@ MANY_LOCI_PATTERNS = ['(AAAT)', '(AGC)AACAGCCGCCAC(CGC)', '((CAGG){CAGM})(CAGA)(
                       '(AAGGG)(AAAGG)', '(GAA)', '(CAG)CAACAG(CCG)', '(CTG)CTA(CTG)']
 
 
-def make_locus_dirs(root, specs, reads_per_locus, seed):
+def make_locus_dirs(root, specs, reads_per_locus, seed, device=None, info=None):
     """Locus directories as steps 1-2 of the pipeline leave them (overview.csv with the `saved` rows, the flank file) for
     specs = [(name, pattern, flank, (Tmin, Tmax), locus seed)], and the reads as raw int16 DAC segments in host memory
-    ({read name: array}; l_start_raw = 0, r_end_raw = len - 1).  Six clean template reads per locus, noise per read."""
+    ({read name: array}; l_start_raw = 0, r_end_raw = len - 1).  Six clean template reads per locus, noise per read.
+    device: draw the noise on that GPU, a clean template's reads at a time (400 000 reads: seconds instead of a minute);
+    info: a dict that receives per locus name (template index of every read, the synth locus)."""
     import pandas as pd
 
     from warpstr_amd import overview as ov, synth
@@ -427,8 +429,24 @@ def make_locus_dirs(root, specs, reads_per_locus, seed):
         ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
         names = [f'{name}_r{i:05d}' for i in range(reads_per_locus)]
         pick = rng.integers(0, len(tpl), size=reads_per_locus)
+        if info is not None:
+            info[name] = (pick, locus)
         lens = []
-        for nm, k in zip(names, pick):
+        if device is not None:
+            import torch
+            g = torch.Generator(device=device)
+            g.manual_seed(int(rng.integers(0, 2 ** 31)))
+            lens = [len(tpl[k][1]) for k in pick]
+            for k in range(len(tpl)):
+                rows = np.flatnonzero(pick == k)
+                if not len(rows):
+                    continue
+                clean = torch.from_numpy(tpl[k][1]).to(device)
+                x = clean[None, :] + 0.25 * torch.randn((len(rows), len(clean)), generator=g, device=device, dtype=torch.float64)
+                block = torch.clamp(torch.round(x * 70.0 + 500.0), 0, 2047).to(torch.int16).cpu().numpy()
+                for q, i in enumerate(rows):
+                    raws[names[i]] = block[q]
+        for nm, k in (zip(names, pick) if device is None else ()):
             x = tpl[k][1] + 0.25 * rng.standard_normal(len(tpl[k][1]))
             raws[nm] = np.clip(np.round(x * 70.0 + 500.0), 0, 2047).astype(np.int16)
             lens.append(len(x))
@@ -557,6 +575,76 @@ def cfg5_driver_leg(reads_per_locus, local):
         called = int(sum((np.asarray(df['results']) >= 0).sum() for df, _ in tables))
         return {'workload': f'8 loci x {reads_per_locus} reads through main_wrapper_loci, raw int16 reads in host memory -> output files',
                 'reads': n, 'called_ok': called, 'reads_per_s': n / tm['total_s'], 'driver': _driver_timings(tm, len(loci))}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def cfg5_full_leg(reads_per_locus, local):
+    """configs[4] at its FULL size on ONE GPU: 8 loci x 2 strands x reads_per_locus (50 000) reads = 400 000 reads of 500-5 000
+    samples, ~128-state automata, through the product seam in one handle (main_wrapper_loci: raw int16 reads in host memory ->
+    every locus's output files).  Run twice on directories of their own: the second run is the timed one and its files must equal
+    the first's byte for byte (determinism).  Checked against the oracle on a sample of every locus (the loader's host
+    restatement + the C oracle: both lengths identical, both costs within 1e-5), and through the property of
+    tests/test_gpu_parity.py::test_mixed_locus_batch_at_per_gpu_size: reads that are copies of one clean template agree on the
+    allele up to noise."""
+    import filecmp
+    import shutil
+    import tempfile
+
+    import pandas as pd
+    import torch
+
+    from oracle import oracle
+    from warpstr_amd.signal_prep import process_raw
+    from warpstr_amd.wrapper import main_wrapper_loci
+    root = tempfile.mkdtemp(prefix='wsx_cfg5_full_', dir=scratch_dir())
+    try:
+        device = torch.device('cuda', local)
+        specs = [(f'locus{i}', p, cfg5_flank(p, 11 + i), (500, 5000), 11 + i) for i, p in enumerate(CFG5_PATTERNS)]
+        t0 = time.perf_counter()
+        info = {}
+        first, raws = make_locus_dirs(os.path.join(root, 'a'), specs, reads_per_locus, 79, device=device, info=info)
+        second, _ = make_locus_dirs(os.path.join(root, 'b'), specs, reads_per_locus, 79, device=device)
+        gen_s = time.perf_counter() - t0
+        threads = min(8, os.cpu_count() or 1)
+        tm0, tm = {}, {}
+        main_wrapper_loci(first, threads, raw_reads=raws, device=local, quiet=True, timings=tm0)
+        main_wrapper_loci(second, threads, raw_reads=raws, device=local, quiet=True, timings=tm)
+        same = all(filecmp.cmp(os.path.join(a.path, rel), os.path.join(b.path, rel), shallow=False)
+                   for a, b in zip(first, second) for rel in ('overview.csv', 'predictions/sequences/all.fasta'))
+        n = len(second) * reads_per_locus
+        rng = np.random.default_rng(5)
+        bad, checked, called, samples, agree = [], 0, 0, 0, []
+        for (name, pattern, fl, _, _), loc in zip(specs, second):
+            df = pd.read_csv(os.path.join(loc.path, 'overview.csv'), dtype={'read_name': str})
+            called += int((df['results'] >= 0).sum())
+            pick, locus = info[name]
+            oa = {False: oracle.Automaton.from_table(locus.template, fl), True: oracle.Automaton.from_table(locus.reverse, fl)}
+            for i in rng.integers(0, len(df), size=12):
+                raw = raws[df['read_name'][i]]
+                o = oracle.call_read(oa[bool(df['reverse'][i])], process_raw(raw, (0, len(raw) - 1), 'Brute'), debug=False)
+                ok = o.status == 0 and (int(df['orig'][i]), int(df['results'][i])) == (o.len1, o.len2)
+                for a, b in ((float(df['dtw_cost1'][i]), o.cost1), (float(df['dtw_cost2'][i]), o.cost2)):
+                    ok = ok and abs(a - b) <= 1e-5 * max(abs(b), 1e-300)
+                checked += 1
+                if not ok:
+                    bad.append(f'{name}:{i}')
+            l2 = df['results'].to_numpy()
+            for k in np.unique(pick):
+                v = l2[pick == k]
+                agree.append(float(np.mean(np.abs(v - np.median(v)) <= 6)))
+            samples += int(sum(len(raws[nm]) for nm in df['read_name']))
+        return {'workload': f'BASELINE configs[4] at full size on one GPU: 8 loci x 2 strands x {reads_per_locus} reads = {n} reads, T in [500, 5000], '
+                            f'S={min(min(l.template.n_states, l.reverse.n_states) for _, l in info.values())}..'
+                            f'{max(max(l.template.n_states, l.reverse.n_states) for _, l in info.values())} states, one handle, '
+                            'main_wrapper_loci from raw int16 reads in host memory to the output files',
+                'reads': n, 'samples': samples, 'called_ok': called, 'reads_per_s': n / tm['total_s'], 'wall_s': tm['total_s'],
+                'first_run_wall_s': tm0['total_s'], 'generation_s': gen_s, 'driver': _driver_timings(tm, len(second)),
+                'workspace_bytes': tm.get('workspace_bytes'), 'workspace_bytes_per_sample_of_the_run': (tm.get('workspace_bytes') or 0) / max(samples, 1),
+                'deterministic': {'runs': 2, 'files_identical': bool(same)},
+                'verified': {'reads': checked, 'mismatches': len(bad), 'first_mismatches': bad[:5],
+                             'fields': 'orig, results identical; dtw_cost1, dtw_cost2 within 1e-5 relative', 'against': 'oracle/ (CPU)'},
+                'copies_of_one_template_within_6_bases_of_their_median': float(np.mean(agree))}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -775,6 +863,43 @@ def from_fast5_leg(n_copies, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks as a CHILD
+    `python -m torch.distributed.run` of this process -- which has not touched the GPU and never will -- and relay rank 0's JSON
+    line and the job's exit code.  Returns the exit code."""
+    import socket
+    import subprocess
+    backend = os.environ.get('WARPSTR_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl':
+        import torch
+        have = torch.cuda.device_count()   # (counts devices without creating a HIP context on this image)
+        if have < n_gpus:
+            print(f'bench.py: --gpus {n_gpus} over RCCL needs {n_gpus} GPUs on this node, {have} visible '
+                  '(one rank per GPU; WARPSTR_BENCH_BACKEND=gloo runs the ranks on the GPUs there are, as a rehearsal)', file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, WARPSTR_BENCH_LAUNCHED_BY=str(os.getpid()))
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n_gpus)))   # (torchrun would set 1 and say so)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = proc.communicate()
+    lines = out.decode('utf-8', 'replace').splitlines()
+    line = next((l for l in reversed(lines) if l.startswith('{') and '"metric"' in l), None)
+    for l in lines:
+        if l is not line:
+            print(l, file=sys.stderr)
+    if line is not None:
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        print('bench.py: the ranks ended without a result line', file=sys.stderr)
+        return 4
+    return proc.returncode
+
+
 def optional_leg(leg, *a):
     """A leg above the kernels (the product driver) must not take the headline line down with it: an
     exception becomes {'failed': ...} in its place (a result that DIFFERS still fails the run: the callers check that)."""
@@ -803,11 +928,18 @@ def main():
     ap.add_argument('--workspace-limit-gib', type=float, default=0.0,
                     help='wsx_caller_set_workspace_limit for the main handle (default: the library chooses from the free device memory)')
     ap.add_argument('--from-fast5', type=int, default=1500, help='copies of the upstream test fast5 in the from_fast5 leg of the default run (0: leave it out)')
+    ap.add_argument('--cfg5-full', type=int, default=50000, help='reads per locus of the cfg5_full leg of the default run: configs[4] at its full '
+                                                               'size, 8 loci x that many reads, on the one GPU (0: leave it out)')
     ap.add_argument('--many-loci', type=int, default=2000, help='loci of the many_loci leg of the default run (0: leave it out)')
     ap.add_argument('--from-raw', action='store_true',
                     help='also time the path from raw int16 segments (host and HBM resident): loader kernels + caller with the '
                          'called sequences requested; reported as from_raw next to the headline')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be at least 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # not under a launcher: this process becomes the launcher (before torch or HIP is loaded) and the ranks its children
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Exactly one line on stdout: native libraries print there too (RCCL's start-up banner: version, hostname, library
     # path), so file descriptor 1 points at stderr until the JSON line is written to the real stdout at the end.
@@ -822,11 +954,14 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: start bench.py with --gpus {world}, '
+                         'or without a launcher (it starts its own ranks)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
     # one process per GPU; WARPSTR_BENCH_BACKEND=gloo lets the multi-rank logic be exercised on a 1-GPU box
     backend = os.environ.get('WARPSTR_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and world > torch.cuda.device_count():
+        raise SystemExit(f'bench.py: {world} ranks over RCCL need {world} GPUs on this node, {torch.cuda.device_count()} visible (one rank per GPU)')
     local = local % torch.cuda.device_count() if backend != 'nccl' else local
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -925,6 +1060,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    last_k = (step_no[0] - 1) % N_BUF   # the buffer the last timed step's records lie in
     tm = hip.last_timing()  # HIP events on the launch streams, every fill launch of the timed region
     fb, fe, fr = hip.fill_intervals()
     hip.timing_window(False)
@@ -937,6 +1073,20 @@ def main():
     torch.cuda.synchronize()
     ab, ae, _ = hip.fill_intervals()
     hip.set_streams(4)
+    # what proves the ranks and the collective were real: every rank's device, clock and a checksum of the records it computed in
+    # the last timed step, all-gathered as objects; rank 0 compares the checksums with those of the slices the step's own
+    # all-gather (RCCL: all_gather_into_tensor on the gather stream) delivered
+    ranks = None
+    if world > 1 or self_gather:
+        import zlib
+        props = torch.cuda.get_device_properties(local)
+        own_n = len(shards[rank]) if strong else n
+        me = {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': local, 'device_name': props.name,
+              'pci_bus_id': getattr(props, 'pci_bus_id', None), 'uuid': str(getattr(props, 'uuid', '')) or None, 'pid': os.getpid(),
+              'reads': own_n, 'ms_per_step': dt / args.steps * 1e3,
+              'records_crc32': zlib.crc32(res_bufs[last_k][:own_n].cpu().numpy().tobytes())}
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -1016,6 +1166,17 @@ def main():
             # device memory the handle holds for this workload (all work sets of all streams), and per sample of a call
             'workspace': workspace,
         }
+        if ranks is not None:
+            import zlib
+            seen = [zlib.crc32(table[r][:ranks[r]['reads']].tobytes()) for r in range(world)]
+            out['ranks'] = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                            'launched_by': 'bench.py itself (child torch.distributed.run)' if os.environ.get('WARPSTR_BENCH_LAUNCHED_BY') else 'an outer launcher',
+                            'per_rank': ranks, 'ms_per_step_max_over_ranks': dt / args.steps * 1e3,
+                            'distinct_devices': len({(r['device'], r['pci_bus_id'], r['uuid']) for r in ranks}),
+                            'gathered_records_equal_every_ranks_own': bool(all(seen[r] == ranks[r]['records_crc32'] for r in range(world)))}
+            if not out['ranks']['gathered_records_equal_every_ranks_own']:
+                rc = 3
+                print('bench.py: the all-gathered records differ from what the ranks computed', file=sys.stderr)
         if not args.no_verify:
             nv = min(n, 4096 if not args.no_cpu_baseline else 256)
             sample = wl.signal[: int(wl.offsets[nv])].cpu().numpy()
@@ -1058,6 +1219,11 @@ def main():
             out['secondary']['from_raw'] = out['from_raw']
             # the product seam above the kernels: configs[4]'s share and the many-loci regime through main_wrapper_loci
             out['secondary']['cfg5']['through_driver'] = optional_leg(cfg5_driver_leg, 6250, local)
+            if args.cfg5_full > 0:
+                full = out['secondary']['cfg5_full'] = optional_leg(cfg5_full_leg, args.cfg5_full, local)
+                if full.get('verified', {}).get('mismatches') or not full.get('deterministic', {'files_identical': True})['files_identical']:
+                    rc = 3
+                    print('bench.py: cfg5_full: results differ from the oracle or between two runs', file=sys.stderr)
             if args.from_fast5 > 0:
                 out['from_fast5'] = optional_leg(from_fast5_leg, args.from_fast5, local)
             if args.many_loci > 0:

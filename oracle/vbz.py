@@ -9,9 +9,21 @@ inside it a StreamVByte block -- ceil(n/4) key bytes, two bits per value (byte l
 the values' little-endian bytes back to back -- of the differences of consecutive samples (the first against 0), zig-zag mapped
 ((d << 1) ^ (d >> 15)) when the flag is set; the samples are the running sum in the sample type.
 
-Pinned by: the upstream test file itself -- tests/golden/real_aaat.npz holds the normalised segments the upstream functions made
-of the samples h5py + plugin returned in the recording environment (tests/golden/generate_golden.py); a sample decoded wrongly
-moves the whole-read percentiles those depend on (tests/test_fast5.py, tests/test_vbz_oracle.py)."""
+What pins it -- and what does not.  h5py and the filter plugin are absent from every environment this repository has seen, so
+NO sample of the upstream test file was ever decoded by upstream's own stack: tests/golden/real_aaat.npz was recorded by
+tests/golden/generate_golden.py through THIS repository's reader (warpstr_amd.fast5) and upstream's normalisation + caller on top
+of it.  The chain reader -> fixture -> oracle -> kernel is therefore circular as far as the decoding itself goes; the pin is END TO
+END ONLY:
+  * the ten reads decoded this way call to the README's known answer (44, 40): through the unmodified upstream caller when the
+    fixture was recorded (tests/test_fast5.py asserts it of the recorded lengths), through the product from the file itself
+    (tests/test_gpu_loci.py, bench.py's from_fast5 leg) -- a sample decoded wrongly moves the whole-read percentiles the
+    normalisation depends on;
+and these independent, structural facts (tests/test_vbz_oracle.py):
+  * a block typed in by hand from the published format text (all four byte lengths, sign changes, the int16 wrap) decodes to the
+    samples worked out on paper;
+  * for every chunk of the upstream file the zstd frame's declared content size equals ceil(n/4) key bytes + the value bytes those
+    keys announce, to the byte; the chunk's u32 header equals 2 x the dataset's length; the sequencer's `duration` attribute of the
+    read equals the number of samples; the decoded samples stay inside the DAC range of the device (0..2047)."""
 import numpy as np
 
 

@@ -1,6 +1,6 @@
 """The generator of the per-automaton DP fill (warpstr_amd/fillgen.py) on the CPU: its tables describe the automaton it was
 given, its source is valid HIP for gfx950 (hipcc cross-compiles without a GPU), the cache works.  What the generated kernels
-COMPUTE is checked on the GPU (tests/test_gpu_generated_fill.py)."""
+COMPUTE is checked on the GPU (tests/exp_test_gpu_generated_fill.py)."""
 import os
 import shutil
 

@@ -74,3 +74,54 @@ def test_strong_scaling_partition_covers_the_workload_once():
         assert len(allr) == 100000 and len(np.unique(allr)) == 100000
         sizes = [len(s) for s in shards]
         assert max(sizes) - min(sizes) <= 1 and max(sizes) == (100000 + world - 1) // world
+
+
+def test_bare_gpus_n_without_the_gpus_ends_with_one_sentence():
+    """`python bench.py --gpus 8` with no launcher and fewer than 8 GPUs visible (here: none): no rank is started, exit code 2 and
+    one sentence on stderr -- the driver's first scaling run must not die in a stack trace."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip('eight GPUs here')
+    assert out.returncode == 2 and out.stdout.strip() == ''
+    assert 'needs 8 GPUs on this node' in out.stderr and 'Traceback' not in out.stderr
+
+
+def test_launcher_relays_the_line_and_the_exit_code(tmp_path, monkeypatch):
+    """bench.launch_ranks: the child torch.distributed.run's rank-0 line goes to stdout alone, everything else to stderr, and
+    the job's exit code is returned (here the `ranks` are a stand-in script: two gloo ranks, no GPU)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    script = tmp_path / 'fake_bench.py'
+    script.write_text(
+        "import os, sys, json\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "dist.barrier()\n"
+        "if r == 0:\n"
+        "    print('banner of some library')\n"
+        "    print(json.dumps({'metric': 'reads/s', 'world': w, 'argv': sys.argv[1:]}))\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(5 if '--fail' in sys.argv else 0)\n")
+    monkeypatch.setenv('WARPSTR_BENCH_BACKEND', 'gloo')
+    monkeypatch.setattr(bench, '__file__', str(script))
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.__file__ = %r; "
+            "sys.exit(bench.launch_ranks(2, sys.argv[1:]))" % (root, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['WARPSTR_BENCH_BACKEND'] = 'gloo'
+    ok = subprocess.run([sys.executable, '-c', code, '--steps', '3'], capture_output=True, text=True, timeout=300, env=env)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [l for l in ok.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'metric': 'reads/s', 'world': 2, 'argv': ['--steps', '3']}
+    assert 'banner of some library' in ok.stderr
+    bad = subprocess.run([sys.executable, '-c', code, '--fail'], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0

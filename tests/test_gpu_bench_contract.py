@@ -90,6 +90,13 @@ def test_default_run_carries_the_secondary_workloads():
     ref = d['cpu_baseline']['reference_python']
     assert ref['kind'] == 'reference' and ref['value'] > 0 and ref['cores'] == 8
     assert d['config']['name'] == 'headline' and d['verified']['mismatches'] == 0
+    # configs[4] at its FULL size on the one card, through the product seam: 8 loci x 2 strands x 50 000 reads in one handle
+    full = sec['cfg5_full']
+    assert full['reads'] == 400000 and full['called_ok'] >= 0.98 * full['reads'], full
+    assert full['verified']['reads'] >= 64 and full['verified']['mismatches'] == 0
+    assert full['deterministic']['files_identical'] is True
+    assert full['copies_of_one_template_within_6_bases_of_their_median'] > 0.9
+    assert full['workspace_bytes'] > 0 and full['samples'] > 9e8
 
 
 def _free_port():
@@ -121,6 +128,43 @@ def test_bench_two_ranks_as_the_driver_launches_it(scaling):
     assert d['verified']['mismatches'] == 0
 
 
+def _bare_env(**kw):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **kw)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bare_gpus_2_starts_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): bench.py starts torch.distributed.run as a child
+    before anything touches the GPU and relays rank 0's one line and the exit code.  The line proves what ran: world size and
+    backend as torch.distributed reports them, one entry per rank (own process, device, clock), and the records the step's
+    all-gather delivered equal what every rank computed itself.  Both ranks on the one card, gloo."""
+    reads = 5000 if scaling == 'weak' else 7001
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--reads', str(reads),
+                          '--samples', '900', '--scaling', scaling, '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=_bare_env(WARPSTR_BENCH_BACKEND='gloo'))
+    d = _one_line(out)
+    assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['verified']['mismatches'] == 0
+    r = d['ranks']
+    assert r['world_size'] == 2 and r['backend'] == 'gloo' and 'itself' in r['launched_by']
+    assert [e['rank'] for e in r['per_rank']] == [0, 1] and len({e['pid'] for e in r['per_rank']}) == 2
+    assert all(e['ms_per_step'] > 0 and e['reads'] > 0 for e in r['per_rank'])
+    assert abs(d['ms_per_step'] - r['ms_per_step_max_over_ranks']) < 1e-9
+    assert d['ms_per_step'] >= max(e['ms_per_step'] for e in r['per_rank']) * 0.999
+    assert r['gathered_records_equal_every_ranks_own'] is True
+    assert sum(e['reads'] for e in r['per_rank']) == (2 * reads if scaling == 'weak' else reads)
+
+
+def test_bare_gpus_2_over_rccl_on_one_gpu_says_why_not():
+    """RCCL wants a GPU per rank: on the one-GPU box `--gpus 2` ends non-zero with one sentence, before any rank is started."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=_bare_env())
+    assert out.returncode == 2 and out.stdout.strip() == ''
+    assert 'needs 2 GPUs on this node, 1 visible' in out.stderr
+
+
 def test_bench_four_ranks_on_the_one_card():
     """The strong-scaling line at four ranks (configs[3]'s partition at a size the card can host four times: the box allows six
     processes on its GPU, so the driver's --gpus 8 cannot be rehearsed here; the collective is gloo): every read called once,
@@ -148,3 +192,6 @@ def test_bench_rccl_collective_path_with_a_one_rank_group(scaling):
     d = _one_line(out)
     assert 'nccl' in d['config']['results_gather'] and d['scaling'] == scaling
     assert d['config']['called_ok'] == 7001 and d['verified']['mismatches'] == 0
+    r = d['ranks']   # the proof fields of the N > 1 line, through RCCL itself
+    assert r['world_size'] == 1 and r['backend'] == 'nccl' and r['gathered_records_equal_every_ranks_own'] is True
+    assert r['per_rank'][0]['reads'] == 7001 and r['per_rank'][0]['device'] == 0
