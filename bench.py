@@ -745,21 +745,27 @@ def from_fast5_leg(n_copies, local):
             base = None
     root = tempfile.mkdtemp(prefix='wsx_from_fast5_', dir=base)
     try:
+        csv_head = 'read_name,fast5_path,reverse,l_start_raw,r_end_raw,run_id,saved\n'
+        csv_rows = [f'{nm},%s,{bool(rv)},{int(a)},{int(b)},run_0,1\n' for nm, rv, a, b in
+                    zip(ex['read_name'], ex['reverse'].astype(bool), ex['l_start_raw'], ex['r_end_raw'])]
+        flanks = [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']]
+
         def make(tag, n=n_copies, per_locus=1):
-            """n copies of the file; a locus per `per_locus` copies (its overview lists the reads of all of them)."""
+            """n copies of the file; a locus per `per_locus` copies (its overview lists the reads of all of them).  The tables are
+            written as text (the rows pandas would write for these columns: 6 000 loci in a second instead of ten)."""
             loci = []
             for i0 in range(0, n, per_locus):
                 loc = os.path.join(root, tag, f'copy{i0:04d}')
-                rows = []
+                text = [csv_head]
                 for i in range(i0, min(n, i0 + per_locus)):
                     f5 = os.path.join(root, 'fast5', f'batch_{i:04d}.fast5')
                     if not os.path.exists(f5):
                         os.makedirs(os.path.dirname(f5), exist_ok=True)
                         shutil.copyfile(os.path.join(real, 'batch_0.fast5'), f5)
-                    rows.append(pd.DataFrame({'read_name': ex['read_name'], 'fast5_path': f5, 'reverse': ex['reverse'].astype(bool),
-                                              'l_start_raw': ex['l_start_raw'], 'r_end_raw': ex['r_end_raw'], 'run_id': 'run_0', 'saved': 1}))
-                ov.store_flanks(loc, [fj['left_template'], fj['right_template'], fj['left_reverse'], fj['right_reverse']])
-                pd.concat(rows, ignore_index=True).to_csv(os.path.join(loc, 'overview.csv'), index=False)
+                    text += [row % f5 for row in csv_rows]
+                ov.store_flanks(loc, flanks)
+                with open(os.path.join(loc, 'overview.csv'), 'w') as f:
+                    f.writelines(text)
                 loci.append(LocusPath(loc, fj['sequence'], int(fj['flank_length']), f'copy{i0:04d}'))
             return loci
         warm = make('warm', 8)
@@ -768,31 +774,42 @@ def from_fast5_leg(n_copies, local):
                            f'caller-only layout, files under {base or "the default temporary directory"} (page cache) -> output files',
                'reads': n_copies * len(ex)}
         many = min(16, os.cpu_count() or 1)
-        legs = [('one_process', 1, n_copies, 1), ('sixteen_reader_processes', many, n_copies, 1),
+        from warpstr_amd.loci import cpu_share, default_readers
+        out['cpus'] = {'visible': os.cpu_count(), 'usable_under_the_cgroup_quota': cpu_share()}
+        knee = default_readers(many)   # reader processes of a run with sixteen host threads (the knee of reader_sweep below)
+        legs = [('one_process', 1, None, n_copies, 1), ('reader_processes', many, None, n_copies, 1),
                 # configs[4]'s shape from files: the same reads as eight loci (1 875 reads each at the default size)
-                ('sixteen_reader_processes_eight_loci', many, n_copies, -(-n_copies // 8))]
+                ('reader_processes_eight_loci', many, None, n_copies, -(-n_copies // 8))]
         st = os.statvfs(root)
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
-            legs.append(('sixteen_reader_processes_4x_the_copies', many, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
+            legs.append(('reader_processes_4x_the_copies', many, None, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
+            # the reader count swept on the long run (60 000 reads at the default size): same host threads, 16 ... 128 readers
+            legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in (16, 32, 64, 128) if r <= (os.cpu_count() or 1)]
         only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
-        for tag, threads, n, per_locus in [leg for leg in legs if not only or leg[0] == only]:
+        for tag, threads, readers, n, per_locus in [leg for leg in legs if not only or leg[0] == only or leg[0].startswith(only + '.')]:
             loci = make(tag, n, per_locus)
             n_reads = n * len(ex)
             tm = {}
-            tables = main_wrapper_loci(loci, threads, device=local, quiet=True, timings=tm)
+            tables = main_wrapper_loci(loci, threads, readers=readers, device=local, quiet=True, timings=tm)
             with contextlib.redirect_stdout(io.StringIO()):
                 calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
             lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results'][:len(ex)]) for l in loci[::max(1, n // n_copies)]]
-            out[tag] = {'reads': n_reads, 'loci': len(loci), 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
-                        'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6,
-                        'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
-                        'inside_submit_upload': tm.get('submit_parts_s'),
-                        'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
-                                     'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
-                                     'decode_summed_over_reader_processes': tm.get('decode_worker_s'),
-                                     'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
-                        'shared_staging_refused': tm.get('shared_staging_refused'),
-                        'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
+            rec = {'reads': n_reads, 'loci': len(loci), 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
+                   'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6, 'uploaded_MB': tm.get('uploaded_bytes', 0) / 1e6,
+                   'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
+                   'inside_submit_upload': tm.get('submit_parts_s'),
+                   'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
+                                'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
+                                'decode_summed_over_reader_processes': tm.get('decode_worker_s'),
+                                'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
+                   'shared_staging_refused': tm.get('shared_staging_refused'),
+                   'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
+            if tag.startswith('reader_sweep.'):
+                out.setdefault('reader_sweep', {'reads': n_reads, 'default_readers_at_16_threads': knee})[tag.split('.')[1]] = {
+                    k: rec[k] for k in ('reads_per_s', 'wall_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal')}
+                shutil.rmtree(os.path.join(root, tag), ignore_errors=True)
+            else:
+                out[tag] = rec
         # where a read's time goes in one process, COLD -- every read of a run is read exactly once, from a file whose metadata
         # libhdf5 has not parsed yet: 40 fresh copies x 10 reads, each library call timed (ms per read)
         import ctypes as C

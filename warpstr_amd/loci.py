@@ -474,12 +474,12 @@ READER_POOL_FROM_LOCI = 64      # reader processes are started for a run of that
 READER_POOL_FROM_READS = 2048   # ... or of about that many reads (a few loci with thousands of reads each: configs[3] / [4])
 
 
-def _reader_pool(threads: int, loci):
+def _reader_pool(threads: int, loci, readers: Optional[int] = None):
     """Worker processes for the fast5 files of a run, or None: one thread, or a run too small to be worth sixteen interpreters
     (fewer than READER_POOL_FROM_LOCI loci whose overview.csv files -- ~120 bytes a row -- do not hold READER_POOL_FROM_READS reads
     between them).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported once
     and the files are read in this process; what a worker raises while reading is raised by _WorkerPool.map."""
-    if threads <= 1:
+    if threads <= 1 or (readers is not None and readers < 1):
         return None
     if len(loci) < READER_POOL_FROM_LOCI:
         size = 0
@@ -490,7 +490,39 @@ def _reader_pool(threads: int, loci):
                 pass
         if size < 120 * READER_POOL_FROM_READS:
             return None
-    return _WorkerPool(min(int(threads), os.cpu_count() or 1))
+    return _WorkerPool(min(int(readers or default_readers(threads)), os.cpu_count() or 1))   # (an explicit `readers` is the caller's word)
+
+
+def cpu_share() -> int:
+    """CPUs this process may actually use: its affinity mask, cut to the cgroup's CPU quota where there is one (a container
+    with `cpu.max 1600000 100000` sees 256 CPUs and runs on 16: more busy processes than that are throttled, not scheduled)."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', ):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                cpus = min(cpus, max(1, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+    try:   # (cgroup v1)
+        quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if quota > 0 and period > 0:
+            cpus = min(cpus, max(1, -(-quota // period)))
+    except (OSError, ValueError):
+        pass
+    return cpus
+
+
+def default_readers(threads: int) -> int:
+    """Reader processes of a run with `threads` host threads when the caller does not say: as many as threads (upstream's
+    `threads` is its pool size, src/caller/wrapper.py:107-109), never more than the CPUs the process may use (cpu_share) --
+    bench.py's from_fast5.reader_sweep on the bench box, whose cgroup grants 16 CPUs: 16 / 32 / 64 / 128 readers = 49 / 55 / 35 /
+    22 k reads/s on 60 000 reads (profiles/r06_reader_sweep.json): past the share, more readers only take turns."""
+    return max(1, min(int(threads), cpu_share()))
 
 
 def _started(pool, tm):
@@ -563,7 +595,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
                       signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
                       raw_reader: Callable[[str], np.ndarray] = read_raw_signal,
                       raw_reads: Optional[Mapping[str, np.ndarray]] = None, pore_model=None, device: int = 0, shard: bool = False,
-                      partition: str = 'auto', batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
+                      readers: Optional[int] = None, partition: str = 'auto', batch_reads: int = 32768, batch_samples: int = 48 << 20, batch_raw_bytes: int = 1 << 30,
                       timings: Optional[Dict[str, float]] = None, quiet: bool = False, native: bool = True, _engine=None):
     """Step 3 (src/caller/wrapper.py:17-41) for every locus of `loci` -- objects with `.path`, `.sequence`, `.flank_length`
     (upstream's Locus, src/schemas/locus.py) -- through one handle.  Returns a LociTables: [(df_overview, df_collapsed), ...] in
@@ -575,8 +607,8 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     pore_model: a pore_model.PoreModel (default: the built-in r9.4 table; `pore_model_path` of a configuration).
     batch_*: where the read list is cut -- a batch holds at most that many reads, segment samples and raw bytes.
     threads: threads of the per-locus host work (native code without the GIL: overview, automata, output files); with more than
-    one thread and 64 loci or more (or fewer loci whose overviews hold ~2 000 reads or more) the fast5 files are read on as many
-    worker processes.
+    one thread and 64 loci or more (or fewer loci whose overviews hold ~2 000 reads or more) the fast5 files are read on worker
+    processes: `readers` of them (default: default_readers(threads); 0: none).
     shard=True: the run is one torch.distributed job.  partition: 'loci' = every rank takes whole loci, 'reads' = every rank
     takes its share of every locus's reads, 'auto' = 'loci' from LOCI_PER_RANK_FOR_LOCUS_PARTITION loci per rank on.
     timings: a dict that receives where the wall-clock went (seconds), for the bench's per-locus set-up figure.
@@ -597,7 +629,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     try:
         return _main_wrapper_loci(loci, int(threads or 1), pools, executor, caller_config=caller_config, rescaler_config=rescaler_config,
                                   signal_loader=signal_loader, raw_reader=raw_reader, raw_reads=raw_reads, pore_model=pore_model,
-                                  device=device, shard=shard, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
+                                  device=device, shard=shard, readers=readers, partition=partition, batch_reads=batch_reads, batch_samples=batch_samples,
                                   batch_raw_bytes=batch_raw_bytes, timings=timings, quiet=quiet, native=native, _engine=_engine)
     finally:  # the threads and the reader processes end with the call, however it ends
         if paused:
@@ -613,7 +645,7 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
 
 
 def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescaler_config, signal_loader, raw_reader, raw_reads, pore_model,
-                       device, shard, partition, batch_reads, batch_samples, batch_raw_bytes, timings, quiet, native, _engine):
+                       device, shard, readers, partition, batch_reads, batch_samples, batch_raw_bytes, timings, quiet, native, _engine):
     from . import dist as wdist
     from .pore_model import default_pore_model
     t_start = time.perf_counter()
@@ -650,7 +682,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     # (the reader processes start first: they come up -- half a second of imports -- while the loci are set up.  On the bench's
     # sandboxed box sixteen interpreters starting slow whatever runs beside them: the set-up 0.3 -> 0.9 s for 3 000 loci; started
     # beside the handle's creation instead they cost that 0.2 -> 1.5 s.)
-    pool = _reader_pool(threads, [loci[i] for i in own]) if fast5_on_workers else None
+    pool = _reader_pool(threads, [loci[i] for i in own], readers) if fast5_on_workers else None
     pools.append(pool)
     tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
