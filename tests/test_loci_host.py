@@ -753,10 +753,10 @@ def test_arenas_are_not_used_when_dev_shm_has_no_room_for_them(tmp_path, monkeyp
     ids = fast5.Fast5File(src).read_ids()[:10]
     a, b, c = (_fast5_loci(str(tmp_path / t), src, ids) for t in 'abc')
     main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
-    monkeypatch.setattr(wl, 'ARENA_ROOM_PER_READ', 1 << 40)   # (as if every read took a terabyte)
+    monkeypatch.setattr(wl, 'ARENA_ROOM_PER_READ', 1 << 40)   # (as if every read took a terabyte -- and the batches' byte budget let it)
     tm_a, tm_c = {}, {}
-    main_wrapper_loci(a, 3, _engine=ArenaFakeEngine, quiet=True, timings=tm_a)
-    main_wrapper_loci(c, 1, _engine=ArenaFakeEngine, quiet=True, timings=tm_c)
+    main_wrapper_loci(a, 3, _engine=ArenaFakeEngine, quiet=True, timings=tm_a, batch_raw_bytes=1 << 44)
+    main_wrapper_loci(c, 1, _engine=ArenaFakeEngine, quiet=True, timings=tm_c, batch_raw_bytes=1 << 44)
     assert 'MB free' in tm_a['arenas_refused'] and tm_a['reader_mode'] == 'shared staging' and tm_a['arena_batches'] == 0 and tm_a['shared_batches'] > 0
     assert 'MB free' in tm_c['arenas_refused'] and tm_c['arena_batches'] == 0 and tm_c['local_batches'] > 0
     for la, lb, lc in zip(a, b, c):
@@ -796,6 +796,88 @@ def test_a_few_loci_with_many_reads_get_reader_processes_too(tmp_path, monkeypat
     monkeypatch.setattr(wl, 'READER_POOL_FROM_READS', 100)
     main_wrapper_loci(b, 3, _engine=VbzFakeEngine, quiet=True, timings=tm_b)
     assert tm_b['reader_processes'] == 3 and tm_b['reader_mode'] == 'arenas, VBZ decoded on the GPU'
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_arena_batches_are_cut_at_the_byte_budget(tmp_path):
+    """Reader arenas: a batch holds at most batch_raw_bytes / 2 of raw samples, counted -- before anything of a read is known --
+    as the read's segment end (2 (r_end_raw + 1) bytes at least) or the mean of the reads decoded so far, whichever is more.
+    The test file's reads are 59-170 k samples: with a budget of 1 MB a batch holds a handful of reads instead of all of them;
+    same files as the run without a budget to speak of."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    sizes = []
+
+    class Counting(ArenaFakeEngine):
+        def submit_raw_parts(self, region, parts, lo, hi, aut):
+            sizes.append(2 * int(sum(sum(p[3]) for p in parts)))
+            return super().submit_raw_parts(region, parts, lo, hi, aut)
+    a, b = (_fast5_loci(str(tmp_path / t), src, ids, n_loci=80) for t in 'ab')
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    tm = {}
+    main_wrapper_loci(a, 3, _engine=Counting, quiet=True, timings=tm, batch_raw_bytes=2 << 20)
+    assert tm['arena_batches'] == len(sizes) > 8
+    # the batches handed out before anything was decoded know the segment ends only (13-15 kB a read, 64 reads at most); from
+    # then on the mean of what was decoded counts
+    assert max(sizes[2:]) <= (1 << 20) + 400_000, sizes   # (one read over: a batch always takes at least one read)
+    assert max(sizes[:2]) <= 64 * 400_000
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+def test_a_batch_whose_arena_finds_no_room_is_read_through_the_pipes(tmp_path, monkeypatch, capsys):
+    """/dev/shm fills up under a run (or its reads are far longer than the room check assumed): the reader's OSError ends the
+    arena path for THAT batch only -- its reads come back through the pipes and go up from the page-locked ring, said once on
+    stderr -- and the run's files are the same."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    a, b = (_fast5_loci(str(tmp_path / t), src, ids, n_loci=70) for t in 'ab')
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True)
+    calls = []
+    real = wl._decode_arena
+
+    def refusing(args):   # (in-process readers: the arena function of every second batch finds /dev/shm full)
+        calls.append(args[1])
+        if args[1] % 2 == 1:
+            raise OSError('/dev/shm has no room for a reader arena of 123 bytes (WARPSTR_NO_READER_ARENAS=1 reads without arenas)')
+        return real(args)
+    refusing.__name__ = '_decode_arena'
+    monkeypatch.setattr(wl, '_decode_arena', refusing)
+    monkeypatch.setattr(wl, 'SHARED_BATCH_READS', 64)   # (an in-process run cuts a quarter of it: batches of 16 reads)
+    tm = {}
+
+    class Inline(wl._InlinePool):
+        def submit(self, func, item):
+            from concurrent.futures import Future
+            if func is refusing:
+                future = Future()
+                try:
+                    future.set_result(func((f'{self.owner}{item[0]}',) + tuple(item[1:])))
+                except OSError as e:   # (what a worker process reports: a RuntimeError carrying the traceback text)
+                    future.set_exception(RuntimeError(f'_decode_arena failed in a worker process:\nOSError: {e}'))
+                return future
+            return super().submit(func, item)
+    monkeypatch.setattr(wl, '_InlinePool', Inline)
+    main_wrapper_loci(a, 1, _engine=ArenaFakeEngine, quiet=True, timings=tm)
+    assert tm['arena_fallbacks'] >= 2 and tm['arena_batches'] >= 2 and len(set(calls)) >= 4, tm
+    err = capsys.readouterr().err
+    assert err.count('such batches are read without arenas') == 1
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel

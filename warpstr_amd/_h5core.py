@@ -342,7 +342,9 @@ class Fast5Core:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-1])
                     if level != 0:
                         cap = zs.ZSTD_getFrameContentSize(C.cast(C.addressof(buf) + 4, C.c_char_p), size - 4)
-                        if cap >= (1 << 62):
+                        # (a block of n values holds ceil(n/4) key bytes and at most 4 n value bytes: a frame that declares more is
+                        # corrupt -- and would otherwise size an arena)
+                        if cap >= (1 << 62) or cap > 5 * max(chunk_len, want) + 64:
                             raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-2])
                     else:
                         cap = size - 4

@@ -32,6 +32,7 @@ class WshSetup(C.Structure):
                 ('warnings', C.c_char_p)]
 
 
+WSH_ABI = 2   # bumped whenever the exports or their meaning change (csrc/host_loci.cpp: wsh_abi_version)
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
            'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
            'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_vbz_context', 'wsh_gather', 'wsh_loci_counts', 'wsh_loci_columns']
@@ -45,7 +46,7 @@ def lib():
         if os.path.exists(_PATH) and not os.environ.get('WARPSTR_NO_HOST_NATIVE'):
             try:
                 h = C.CDLL(_PATH)
-                if h.wsh_abi_version() == 1:
+                if h.wsh_abi_version() == WSH_ABI:
                     h.wsh_format_float.argtypes = [C.c_double, C.c_char_p]
                     h.wsh_automaton_compile.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(WshAutomaton)]
                     h.wsh_automaton_free.argtypes = [C.POINTER(WshAutomaton)]
@@ -82,8 +83,8 @@ def lib():
                     h.wsh_setup_free.argtypes = [C.POINTER(WshSetup)]
                     h.wsh_setup_free.restype = None
                     _LIB = h
-            except OSError:
-                pass
+            except (OSError, AttributeError):   # (a stale build that lacks an export is no library at all)
+                _LIB = None
     return _LIB
 
 
@@ -179,7 +180,8 @@ class NativeOverview:
         rc = h.wsh_locus_open(os.fsencode(overview_path), C.byref(handle))
         if rc != 0:
             cls.last_refusal = (h.wsh_locus_error(handle) or b'').decode('utf-8', 'replace')
-            h.wsh_locus_free(handle)
+            if handle:
+                h.wsh_locus_free(handle)
             if rc < 0:
                 raise FileNotFoundError(f'Not found the overview file {overview_path} - Please check the "output" in config')
             return None

@@ -53,6 +53,7 @@ def fork_readers(fds):
     for k, (r, w) in enumerate(pairs):
         pid = os.fork()
         if pid == 0:
+            code = 1   # (a reader that dies on an exception says so with its exit code)
             try:
                 for r2, w2 in pairs:
                     if r2 != r:
@@ -63,8 +64,14 @@ def fork_readers(fds):
                 if WARM_REGIONS:
                     _readers.prepare_arenas(range(WARM_REGIONS))
                 serve(os.fdopen(r, 'rb'), os.fdopen(w, 'wb'))
+                code = 0
+            except BaseException:  # noqa: BLE001
+                traceback.print_exc()
             finally:
-                os._exit(0)
+                try:
+                    _readers._drop_arenas()   # (os._exit runs no atexit hook: the arenas' memory-backed files go here)
+                finally:
+                    os._exit(code)
         pids.append(pid)
     for r, w in pairs:
         os.close(r)

@@ -786,12 +786,18 @@ struct wsh_overview_info {
     const char *f5s; const int64_t *f5s_off;
 };
 
-WSH_EXPORT int wsh_abi_version(void) { return 1; }
+WSH_EXPORT int wsh_abi_version(void) { return 2; }   // (2: the exports guard against C++ exceptions; wsh_loci_counts / _columns, wsh_vbz_unpack, wsh_vbz_context)
 
 WSH_EXPORT int wsh_format_float(double x, char *out) { return format_repr(x, out); }
 
 // status 0: *out filled (free with wsh_automaton_free); 1: the Python compiler would raise on this pattern -- run it
+static int wsh_automaton_compile_impl(const char *pattern, int64_t len, const double *levels, int32_t k, wsh_automaton *out);
 WSH_EXPORT int wsh_automaton_compile(const char *pattern, int64_t len, const double *levels, int32_t k, wsh_automaton *out)
+{
+    // (no C++ exception may cross into ctypes: std::bad_alloc and friends become this function's error value)
+    try { return wsh_automaton_compile_impl(pattern, len, levels, k, out); } catch (...) { return 1; }
+}
+static int wsh_automaton_compile_impl(const char *pattern, int64_t len, const double *levels, int32_t k, wsh_automaton *out)
 {
     Automaton *A = new Automaton;
     const int rc = compile_automaton(pattern, len, levels, k, *A);
@@ -815,13 +821,20 @@ WSH_EXPORT void wsh_automaton_free(wsh_automaton *a)
 // caller takes the pandas path.
 WSH_EXPORT int wsh_locus_open(const char *overview_path, void **out)
 {
-    Locus *L = new Locus;
-    *out = L;
-    if (!read_file(overview_path, L->text)) { L->err = "cannot read the file"; return -1; }
-    return parse_overview(*L);
+    *out = nullptr;
+    Locus *L = nullptr;
+    try {
+        L = new Locus;
+        *out = L;
+        if (!read_file(overview_path, L->text)) { L->err = "cannot read the file"; return -1; }
+        return parse_overview(*L);
+    } catch (...) {   // (out of memory on a huge table: declined -- 1 --, the pandas path reports what it finds; *out may be null)
+        if (L) { try { L->err = "out of memory while parsing the table"; } catch (...) {} }
+        return 1;
+    }
 }
 
-WSH_EXPORT const char *wsh_locus_error(void *h) { return static_cast<Locus *>(h)->err.c_str(); }
+WSH_EXPORT const char *wsh_locus_error(void *h) { return h ? static_cast<Locus *>(h)->err.c_str() : "out of memory"; }
 
 WSH_EXPORT void wsh_locus_free(void *h) { delete static_cast<Locus *>(h); }
 
@@ -898,7 +911,15 @@ WSH_EXPORT const char *wsh_locus_text(void *h, int64_t *len)
 // three FASTA files get the called sequences (seq2[off2[r] .. off2[r] + len2[r]) of saved read r).  flags: 1 = write overview.csv,
 // 2 = write the FASTA files.  If `table_out` is not NULL the new overview text is returned there (malloc'ed: wsh_free).
 // 0 = done; -2 = a file could not be written (wsh_locus_error).
+static int wsh_locus_store_impl(void *h, const char *locus_path, const int32_t *len1, const int32_t *len2, const double *cost1,
+                               const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags);
 WSH_EXPORT int wsh_locus_store(void *h, const char *locus_path, const int32_t *len1, const int32_t *len2, const double *cost1,
+                               const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags)
+{
+    // (no C++ exception may cross into ctypes: std::bad_alloc and friends become this function's error value)
+    try { return wsh_locus_store_impl(h, locus_path, len1, len2, cost1, cost2, seq2, off2, flags); } catch (...) { return -2; }
+}
+static int wsh_locus_store_impl(void *h, const char *locus_path, const int32_t *len1, const int32_t *len2, const double *cost1,
                                const double *cost2, const uint8_t *seq2, const int64_t *off2, int32_t flags)
 {
     Locus &L = *static_cast<Locus *>(h);
@@ -1010,14 +1031,28 @@ struct wsh_setup {
 
 // Everything main_wrapper does for a locus before its reads are called, in one call without the GIL: overview.csv parsed,
 // the flank file read, both automata compiled, summaries/state_similarity.csv made (flags & 1: and written).
+static void wsh_locus_setup_impl(const char *locus_path, const char *sequence, const double *levels, int32_t k, double min_state_similarity,
+                                 int32_t flags, wsh_setup *out);
 WSH_EXPORT void wsh_locus_setup(const char *locus_path, const char *sequence, const double *levels, int32_t k, double min_state_similarity,
                                 int32_t flags, wsh_setup *out)
 {
-    Setup *S = new Setup;
-    S->locus = new Locus;
     memset(out, 0, sizeof *out);
+    try {
+        wsh_locus_setup_impl(locus_path, sequence, levels, k, min_state_similarity, flags, out);
+    } catch (...) {   // (std::bad_alloc: everything the library had not finished is the Python form's to do -- or to fail on)
+        out->automata_status = out->similarity_status = 1;   // (a table that was parsed before the failure stays parsed)
+        static const char empty[1] = {0};
+        out->similarity_csv = out->warnings = empty;
+    }
+}
+static void wsh_locus_setup_impl(const char *locus_path, const char *sequence, const double *levels, int32_t k, double min_state_similarity,
+                                 int32_t flags, wsh_setup *out)
+{
+    Setup *S = new Setup;
     out->owner = S;
+    S->locus = new Locus;
     out->locus = S->locus;
+    out->overview_status = 1;   // (until the table is parsed)
     const std::string root(locus_path), seq(sequence);
     if (!read_file((root + "/overview.csv").c_str(), S->locus->text)) { S->locus->err = "cannot read the file"; out->overview_status = -1; }
     else out->overview_status = parse_overview(*S->locus);
@@ -1076,7 +1111,19 @@ WSH_EXPORT void wsh_free(void *p) { free(p); }
 // c shows -- units of the same name share a column, as the keys of upstream's dict do.
 // flags 1: write <locus_path>/predictions/complexSTR_analysis/complex_repeat_units.csv.  Returns 0, or -2 (cannot write), or
 // 1 (an empty alternative: the Python form raises after its iteration limit -- let it).
+static int wsh_collapse_store_impl(const char *locus_path, int32_t n, const uint8_t *seq, const int64_t *off, const int32_t *len,
+                                  const uint8_t *reverse, int32_t n_units, const int32_t *n_alt, const char *alts,
+                                  const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t n_out, const int32_t *sel,
+                                  int32_t flags, int64_t *counts, char **table_out, int64_t *table_len);
 WSH_EXPORT int wsh_collapse_store(const char *locus_path, int32_t n, const uint8_t *seq, const int64_t *off, const int32_t *len,
+                                  const uint8_t *reverse, int32_t n_units, const int32_t *n_alt, const char *alts,
+                                  const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t n_out, const int32_t *sel,
+                                  int32_t flags, int64_t *counts, char **table_out, int64_t *table_len)
+{
+    // (no C++ exception may cross into ctypes: std::bad_alloc and friends become this function's error value)
+    try { return wsh_collapse_store_impl(locus_path, n, seq, off, len, reverse, n_units, n_alt, alts, alt_off, offsets, header, n_out, sel, flags, counts, table_out, table_len); } catch (...) { return -2; }
+}
+static int wsh_collapse_store_impl(const char *locus_path, int32_t n, const uint8_t *seq, const int64_t *off, const int32_t *len,
                                   const uint8_t *reverse, int32_t n_units, const int32_t *n_alt, const char *alts,
                                   const int32_t *alt_off, const int32_t *offsets, const char *header, int32_t n_out, const int32_t *sel,
                                   int32_t flags, int64_t *counts, char **table_out, int64_t *table_len)
@@ -1186,7 +1233,15 @@ WSH_EXPORT void wsh_vbz_context(void *dctx, void *decompress_dctx_fn)
     g_vbz_ctx.fn = reinterpret_cast<zstd_decompress_dctx_fn>(decompress_dctx_fn);
 }
 
+static int64_t wsh_vbz_decode_i16_impl(const uint8_t *chunk, int64_t n_chunk, int32_t zigzag, int32_t zstd_level, void *size_fn, void *decompress_fn,
+                                      int16_t *out, int64_t cap);
 WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int32_t zigzag, int32_t zstd_level, void *size_fn, void *decompress_fn,
+                                      int16_t *out, int64_t cap)
+{
+    // (no C++ exception may cross into ctypes: std::bad_alloc and friends become this function's error value)
+    try { return wsh_vbz_decode_i16_impl(chunk, n_chunk, zigzag, zstd_level, size_fn, decompress_fn, out, cap); } catch (...) { return -3; }
+}
+static int64_t wsh_vbz_decode_i16_impl(const uint8_t *chunk, int64_t n_chunk, int32_t zigzag, int32_t zstd_level, void *size_fn, void *decompress_fn,
                                       int16_t *out, int64_t cap)
 {
     if (n_chunk < 4) return -1;
@@ -1201,7 +1256,9 @@ WSH_EXPORT int64_t wsh_vbz_decode_i16(const uint8_t *chunk, int64_t n_chunk, int
     static thread_local std::vector<uint8_t> scratch;
     if (zstd_level != 0) {
         const unsigned long long size = reinterpret_cast<zstd_size_fn>(size_fn)(svb, size_t(svb_bytes));
-        if (size >= (1ull << 62)) return -2;
+        // (ceil(coded / 4) key bytes + at most 4 bytes a value: a frame that declares more is corrupt, and its size must not size
+        // the scratch buffer)
+        if (size >= (1ull << 62) || size > 5ull * uint64_t(coded) + 64) return -2;
         if (scratch.size() < size + 8) scratch.resize(size + 8);
         const size_t got = zstd_run(decompress_fn, scratch.data(), size, svb, size_t(svb_bytes));
         if (got != size) return -3;
@@ -1295,7 +1352,13 @@ WSH_EXPORT int64_t wsh_vbz_unpack(const uint8_t *chunk, int64_t n_chunk, int32_t
 
 // n pieces of host memory laid end to end into dst (the raw reads of a batch into the page-locked staging buffer the upload
 // starts from), split by bytes over up to `threads` threads: 275 MB in 50 000 pieces is 30 ms of one core's memcpy.
+static void wsh_gather_impl(const void *const *src, const int64_t *bytes, int64_t n, void *dst, int32_t threads);
 WSH_EXPORT void wsh_gather(const void *const *src, const int64_t *bytes, int64_t n, void *dst, int32_t threads)
+{
+    // (no C++ exception may cross into ctypes: std::bad_alloc and friends become this function's error value)
+    try { wsh_gather_impl(src, bytes, n, dst, threads); } catch (...) { int64_t at = 0; for (int64_t i = 0; i < n; i++) if (bytes[i] > 0) { memcpy(static_cast<char *>(dst) + at, src[i], size_t(bytes[i])); at += bytes[i]; } }
+}
+static void wsh_gather_impl(const void *const *src, const int64_t *bytes, int64_t n, void *dst, int32_t threads)
 {
     std::vector<int64_t> at((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; i++) at[i + 1] = at[i] + (bytes[i] > 0 ? bytes[i] : 0);

@@ -269,6 +269,27 @@ from ._readers import (decode_arena as _decode_arena, decode_chunk as _decode_ch
                        pack_arena as _pack_arena, probe_chunk as _probe_chunk, read_chunk as _read_chunk)
 
 
+def _sweep_stale_arenas():
+    """Arena files whose reader process no longer exists (a run that was killed before its pool could shut down: the files are
+    memory): removed.  A file's name carries its reader's process number."""
+    import glob
+    import re
+    from ._readers import ARENA_DIR
+    for path in glob.glob(os.path.join(ARENA_DIR, 'warpstr_arena_*')):
+        m = re.match(r'warpstr_arena_(\d+)_', os.path.basename(path))
+        if not m:
+            continue
+        try:
+            os.kill(int(m.group(1)), 0)   # (signal 0: does the process exist?)
+        except ProcessLookupError:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        except OSError:   # (exists but is not ours)
+            pass
+
+
 class _WorkerPool:
     """`n` worker processes (`python -m warpstr_amd._hostworker`) and an ordered map over them.  Not multiprocessing's pool:
     its spawned children import the parent's main module again, which a library cannot ask of every script that calls it, and
@@ -284,14 +305,16 @@ class _WorkerPool:
 
         def start():   # (on a thread of its own: forking a process with the GPU runtime mapped sixteen times takes a good part of a
             try:       # second, in which the caller parses its overviews)
+                _sweep_stale_arenas()
                 try:   # (the libraries looked up once, here, instead of by every worker)
                     from ._h5core import lib_paths
                     env['WARPSTR_LIBHDF5'], env['WARPSTR_LIBZSTD'] = lib_paths()
                 except RuntimeError:
                     pass   # (a worker says which library is missing when it is asked for its first read)
-                if not os.environ.get('WARPSTR_NO_READER_ARENAS'):
+                if not os.environ.get('WARPSTR_NO_READER_ARENAS') and _arena_room(n, 0) is None:
                     # (a forked reader creates its arenas and touches their pages while the loci are still being set up: the first
-                    # write into a fresh page of a memory-backed file is a fault, ~50 per read -- a fifth of a reader's time)
+                    # write into a fresh page of a memory-backed file is a fault, ~50 per read -- a fifth of a reader's time.
+                    # Only where the run's room check will also pass: warmed pages stay allocated until the readers end.)
                     env.setdefault('WARPSTR_WARM_ARENAS', str(BatchQueue.ARENA_REGIONS))
                 if hasattr(os, 'fork') and not os.environ.get('WARPSTR_NO_FORK_READERS'):
                     self._procs = self._forked(n, env)
@@ -588,6 +611,25 @@ def partition_loci(loci: Sequence, world: int) -> List[np.ndarray]:
 
 GC_PAUSE_FROM_LOCI = 64
 ARENA_ROOM_PER_READ = 400 << 10   # bytes of /dev/shm a read may take in a reader arena (a 200 k-sample read as int16 samples)
+ARENA_MIN_BYTES = 16 << 20        # a reader's arena is at least this big (_readers._arena)
+ARENA_PROBE_READS = 64            # reads of an arena batch while the run has decoded none yet (their mean size then sizes the batches)
+
+
+def _arena_room(workers: int, reads: int, byte_budget: int = 0) -> Optional[str]:
+    """None if /dev/shm has room for the reader arenas of a run -- BatchQueue.ARENA_REGIONS regions of a batch each
+    (ARENA_ROOM_PER_READ a read, or the batch's byte budget if that is smaller; ARENA_MIN_BYTES a reader process at least) and
+    half as much again --, else the sentence that says what is missing.  A container's default /dev/shm of 64 MB has not: the
+    run then takes the staging ring (which falls back to the pipes by itself) or, in one process, the page-locked ring."""
+    if not os.path.isdir('/dev/shm'):
+        return '/dev/shm does not exist'
+    per_batch = reads * ARENA_ROOM_PER_READ
+    if byte_budget:
+        per_batch = min(per_batch, 2 * byte_budget)   # (a batch is cut at its byte budget: arena_batches)
+    need = int(1.5 * BatchQueue.ARENA_REGIONS * max(workers * ARENA_MIN_BYTES, per_batch))
+    st = os.statvfs('/dev/shm')
+    if st.f_bavail * st.f_frsize < need + (64 << 20):
+        return f'/dev/shm has {st.f_bavail * st.f_frsize >> 20} MB free, the reader arenas may take {need >> 20} MB'
+    return None
 
 
 def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
@@ -911,11 +953,22 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 regions = engine_cls.ARENA_REGIONS
                 inflight = collections.deque()
                 b, k, ci = 0, 0, 1
+                # A batch is also cut at its byte budget (batch_raw_bytes / 2, as batches() cuts): nothing is known about a read
+                # before it is decoded except that it reaches its segment's end -- 2 (r_end_raw + 1) bytes at least --, so a read
+                # counts as that or as the mean of the reads decoded so far, whichever is more (ultra-long reads: a batch of 2 048
+                # of them would ask for gigabytes of arena, device buffer and page-locked memory per region)
+                least = 2 * (hi[mine] + 1).clip(min=1)
+                seen = [0, 0]   # reads decoded so far, their bytes
                 while b < len(mine) or inflight:
                     while b < len(mine) and len(inflight) < regions - 1:
                         while cuts[ci] <= b:
                             ci += 1
                         b1 = min(cuts[ci], b + (SHARED_BATCH_READS // 4 if getattr(pool, 'inline', False) else SHARED_BATCH_READS))
+                        mean = seen[1] // seen[0] if seen[0] else 0
+                        if not seen[0]:   # (nothing decoded yet: a small batch tells what this run's reads weigh)
+                            b1 = min(b1, b + ARENA_PROBE_READS)
+                        fit = int(np.searchsorted(np.cumsum(np.maximum(least[b:b1], mean)), raw_budget, side='right'))
+                        b1 = b + max(1, min(b1 - b, fit))
                         t1 = time.perf_counter()
                         region = k % regions
                         if k >= regions:   # (a region's first use waits for nothing -- and the handle may still be in the making)
@@ -939,19 +992,48 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                     b0, b1, region, futures, kb = inflight.popleft()
                     t1 = time.perf_counter()
                     parts = []
-                    for f in futures:
+                    try:
+                        answers = [f.result() for f in futures]
+                    except RuntimeError as e:
+                        if 'no room for a reader arena' not in str(e):
+                            raise
+                        # /dev/shm filled up under the run (another job's files, reads far longer than ARENA_ROOM_PER_READ): this
+                        # batch's reads come back through the pipes instead and go up from the page-locked ring (said once)
+                        if not tm.get('arena_fallbacks'):
+                            print(f'warpstr_amd: {str(e).strip().splitlines()[-1]}; such batches are read without arenas', file=sys.stderr)
+                        tm['arena_fallbacks'] = tm.get('arena_fallbacks', 0) + 1
+                        for f in futures:   # (the chunks that did fit have written their part of the region: nothing to undo)
+                            f.exception()
+                        data = []
+                        if getattr(pool, 'inline', False):
+                            data = _read_chunk([item_of(x) for x in range(b0, b1)])
+                        else:
+                            items = [item_of(x) for x in range(b0, b1)]
+                            step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                            for part in pool.map(_read_chunk, [items[q:q + step] for q in range(0, len(items), step)]):
+                                data += part
+                        seen[0] += b1 - b0
+                        seen[1] += int(sum(d.nbytes for d in data))
+                        tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(sum(d.nbytes for d in data))
+                        submitted[kb].set()   # (no region of the arenas is in use by this batch)
+                        tm['read_s'] += time.perf_counter() - t1
+                        yield b0, b1, data, None, None
+                        continue
+                    seen[0] += b1 - b0
+                    for got in answers:
                         if gpu_vbz:
-                            path, cap, base, used, lens_p, table, busy = f.result()
+                            path, cap, base, used, lens_p, table, busy = got
                             cap //= 2   # (the arena's size in samples, as the engine counts it)
                             parts.append((path, 2 * cap, base, used, lens_p, table))
                             tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + int(used)
                         else:
-                            path, cap, base, lens_p, busy = f.result()
+                            path, cap, base, lens_p, busy = got
                             parts.append((path, cap, base, lens_p))
                             tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + 2 * int(sum(lens_p))
                         page_lock([(path, cap)])   # (here, on the reader thread, while the other chunks are still decoding)
                         tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
                         tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
+                        seen[1] += 2 * int(sum(lens_p))
                     tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
                     tm['read_s'] += time.perf_counter() - t1
                     yield b0, b1, parts, ('vbz' if gpu_vbz else 'arena', region, kb), None
@@ -1025,10 +1107,9 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 # staging ring (which falls back to the pipes by itself) or, in one process, the page-locked ring
                 workers = pool._max_workers if pool is not None else 1
                 reads = min(len(mine), SHARED_BATCH_READS if pool is not None else SHARED_BATCH_READS // 4)
-                need = int(1.5 * probe.ARENA_REGIONS * max(workers * (16 << 20), reads * ARENA_ROOM_PER_READ))
-                st = os.statvfs('/dev/shm')
-                if st.f_bavail * st.f_frsize < need + (64 << 20):
-                    tm['arenas_refused'] = f'/dev/shm has {st.f_bavail * st.f_frsize >> 20} MB free, the reader arenas may take {need >> 20} MB'
+                refused = _arena_room(workers, reads, raw_budget)
+                if refused is not None:
+                    tm['arenas_refused'] = refused
                     arenas = False
             if pool is None and arenas and fast5_on_workers:
                 # no reader processes (one thread, few loci, or they could not be started): the same arenas, filled by the reader
