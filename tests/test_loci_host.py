@@ -827,7 +827,7 @@ def test_arena_batches_are_cut_at_the_byte_budget(tmp_path):
     assert tm['arena_batches'] == len(sizes) > 8
     # the batches handed out before anything was decoded know the segment ends only (13-15 kB a read, 64 reads at most); from
     # then on the mean of what was decoded counts
-    assert max(sizes[2:]) <= (1 << 20) + 400_000, sizes   # (one read over: a batch always takes at least one read)
+    assert np.median(sizes[2:]) <= (1 << 20) and max(sizes[2:]) <= (2 << 20), sizes   # (counted by the mean: a batch of long reads runs over)
     assert max(sizes[:2]) <= 64 * 400_000
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
