@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 12
+#define WSX_ABI_VERSION 13
 
 /* function return codes */
 enum {
@@ -142,6 +142,17 @@ const char *wsx_last_error(void);
 int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
                       const wsx_params *params, void *stream);
 void wsx_caller_destroy(wsx_caller *c);
+
+/*
+ * Append `n_automata` automata to a handle that is in use: *first_index receives the index of the first of them (the
+ * `automaton_id` the reads of later calls name them by; earlier automata keep theirs).  Upstream builds the two automata of a
+ * locus when its loop reaches that locus (WarpSTR.py:33-76 -> CallerWrapper.__init__, src/caller/wrapper.py:63-70); a handle for
+ * all loci of a run would otherwise have to see every locus before the first read is called -- this way the loci of group g+1 are
+ * parsed, compiled, placed and uploaded while the reads of group g are on the device.
+ * May be called while earlier calls of the handle are still running on the device (they keep the table they were enqueued
+ * with); must not be called concurrently with another entry point of the SAME handle.  On failure the handle is unchanged.
+ */
+int wsx_caller_add_automata(wsx_caller *c, const wsx_automaton *automata, int32_t n_automata, int32_t *first_index);
 
 /*
  * Upper bound, in bytes, of the device workspace the handle may allocate.  Default: 60 % of the device memory that is free

@@ -162,3 +162,72 @@ def test_pipelined_calls_with_fitpacks_smoothing_branch():
             got = res.cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
             assert got.tobytes() == w_res.tobytes()
             assert np.array_equal(tr2.cpu().numpy().view(np.uint16), w_extra['trace2'])
+
+
+def test_automata_added_while_calls_are_in_flight():
+    """wsx_caller_add_automata: a handle created with one locus takes three more -- a bigger one (more slots: another kernel
+    variant, more states than any automaton before), a single-slot one, and a copy of the first -- while pipelined calls that name
+    the earlier automata are still running on the handle's streams.  Every call's records and second state paths equal those of
+    a handle that was created with all eight automata at once, and a malformed addition leaves the handle as it was."""
+    import torch
+    loci = [synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64), synth.make_locus('(AAAT)', 110, 5),
+            synth.make_locus('(AGC)', 16, 11), synth.make_locus('(AGC)AACAGCCGCCAC(CGC)', 19, 2024, max_states=64)]
+    flanks = [19, 110, 16, 19]
+    dev = torch.device('cuda:0')
+    stream = torch.cuda.current_stream()
+
+    def batch(li, n, T, seed):
+        sigs, revs, _ = synth.batch(loci[li], n, T, seed, lo=3, hi=12)
+        sig, off = pack_signals(sigs)
+        return torch.from_numpy(sig).to(dev), off, np.array([2 * li + (1 if x else 0) for x in revs], dtype=np.int32)
+    # calls in the order they are enqueued; `after` = how many loci the handle must hold before the call
+    plan = [(0, 12000, 900, 1, 1), (0, 9000, 1100, 2, 1), (1, 3000, (2300, 3200), 3, 2), (0, 6000, 800, 4, 2), (2, 5000, 1200, 5, 3),
+            (1, 2000, (2300, 3000), 6, 3), (3, 7000, 900, 7, 4), (0, 4000, 700, 8, 4)]
+    work = [batch(li, n, T, seed) + (after,) for li, n, T, seed, after in plan]
+    all_tables = [t for l in loci for t in (l.template, l.reverse)]
+    ref = HipCaller(all_tables, [f for f in flanks for _ in range(2)], stream=stream.cuda_stream)
+    want = []
+    for sig, off, aut, _ in work:
+        res = torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        tr2 = torch.zeros(len(sig), dtype=torch.int16, device=dev)
+        ref.call_device(sig.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+        ref.synchronize()
+        want.append((res.cpu().numpy().tobytes(), tr2.cpu().numpy()))
+    names_ref = [ref.kernel_name(a) for a in range(8)]
+    ref.close()
+
+    hip = HipCaller([loci[0].template, loci[0].reverse], [19, 19], stream=stream.cuda_stream)
+    hip.set_pipelined(True)
+    held = 1
+    outs = []
+    for sig, off, aut, after in work:
+        while held < after:   # (the earlier calls are still on the device: nothing is waited for)
+            first = hip.add_automata([loci[held].template, loci[held].reverse], [flanks[held]] * 2)
+            assert first == 2 * held
+            held += 1
+        res = torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        tr2 = torch.zeros(len(sig), dtype=torch.int16, device=dev)
+        hip.call_device(sig.data_ptr(), off, aut, res.data_ptr(), trace2_ptr=tr2.data_ptr())
+        outs.append((res, tr2))
+    # a malformed addition: refused, the handle unchanged
+    bad = synth.make_locus('(AGC)', 16, 11).template
+    import copy
+    bad = copy.copy(bad)
+    bad.pred_idx = np.where(np.arange(len(bad.pred_idx)) == 3, 10 ** 6, bad.pred_idx).astype(np.int32)
+    with pytest.raises(RuntimeError, match='wsx_caller_add_automata'):
+        hip.add_automata([bad], [16], [False])
+    assert len(hip.automata) == 8
+    hip.synchronize()
+    torch.cuda.synchronize()
+    for k, ((res, tr2), (w_res, w_tr2)) in enumerate(zip(outs, want)):
+        assert res.cpu().numpy().tobytes() == w_res, f'call {k}: records differ from the handle created with every automaton'
+        assert np.array_equal(tr2.cpu().numpy(), w_tr2), f'call {k}: state paths differ'
+    assert [hip.kernel_name(a) for a in range(8)] == names_ref
+    assert len({hip.kernel_name(a) for a in range(8)}) >= 3   # single-slot packed, lane-major four-slot, single-slot plain
+    # ... and a call after the refused addition still works
+    sig, off, aut, _ = work[0]
+    res = torch.zeros((len(aut), _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    hip.call_device(sig.data_ptr(), off, aut, res.data_ptr())
+    hip.synchronize()
+    assert res.cpu().numpy().tobytes() == want[0][0]
+    hip.close()

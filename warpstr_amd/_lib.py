@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('WARPSTR_HIP_LIB') or os.path.join(_HERE, 'libwarpstr_
 WSX_MEM_HOST, WSX_MEM_DEVICE = 0, 1
 READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_order', 5: 'fit_smooth', 6: 'no_repeat',
                7: 'segment_range'}
-EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy',
+EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy', 'wsx_caller_add_automata',
            'wsx_caller_set_workspace_limit', 'wsx_caller_get_workspace_limit', 'wsx_caller_set_tuning', 'wsx_caller_create_times', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
            'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw', 'wsx_vbz_decode']
@@ -130,6 +130,7 @@ def load():
     lib.wsx_caller_kernel_name.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_caller_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.wsx_caller_destroy.argtypes = [C.c_void_p]
+    lib.wsx_caller_add_automata.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.wsx_caller_destroy.restype = None
     lib.wsx_caller_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]
     lib.wsx_caller_get_workspace_limit.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]

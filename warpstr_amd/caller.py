@@ -207,26 +207,8 @@ class HipCaller:
             raise RuntimeError('warpstr_amd: no HIP device visible; the caller has no CPU path')
         self.caller_config = caller_config or CallerConfig()
         self.rescaler_config = rescaler_config or RescalerConfig()
-        self.automata = list(automata)
-        self.flank_lengths = [int(f) for f in flank_lengths]
-        self._keep = []
-        arr = (_lib.WsxAutomaton * len(self.automata))()
-        if reverse_flags is None:
-            reverse_flags = [bool(i & 1) for i in range(len(self.automata))]
-        self.reverse_flags = [bool(x) for x in reverse_flags]
-        for i, (t, fl) in enumerate(zip(self.automata, self.flank_lengths)):
-            ptrs = t.__dict__.get('native_ptrs') if 'value' not in t.__dict__ else None
-            if ptrs is not None:  # tables still in the host library's memory (_hostlib.NativeSetup): the pointers as they are
-                self._keep.append(t)
-                arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if self.reverse_flags[i] else 0,
-                                           *ptrs)
-                continue
-            bufs = [np.ascontiguousarray(t.value, np.float64), np.ascontiguousarray(t.seq_idx, np.int32),
-                    np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32),
-                    np.ascontiguousarray(t.repeat_mask, np.uint8), np.ascontiguousarray(t.last_base, np.uint8)]
-            self._keep.append(bufs)
-            arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if self.reverse_flags[i] else 0,
-                                       *[_lib.ptr(b) for b in bufs])
+        self.automata, self.flank_lengths, self.reverse_flags = [], [], []
+        arr, keep = self._pack(automata, flank_lengths, reverse_flags)
         prm = _lib.WsxParams(self.caller_config.min_values_per_state, self.caller_config.states_in_segment,
                              self.rescaler_config.threshold, self.rescaler_config.max_std,
                              1 if self.rescaler_config.method == 'median' else 0,
@@ -236,6 +218,7 @@ class HipCaller:
         t_call = time.perf_counter()
         _lib.check(self.lib.wsx_caller_create(C.byref(self.handle), device, C.byref(arr), len(self.automata),
                                               C.byref(prm), C.c_void_p(stream)), 'wsx_caller_create')
+        del keep   # (the library has copied what it needs)
         self.init_s = {'host_tables': t_call - t_init, 'wsx_caller_create': time.perf_counter() - t_call}
         if workspace_limit:
             _lib.check(self.lib.wsx_caller_set_workspace_limit(self.handle, workspace_limit),
@@ -243,6 +226,55 @@ class HipCaller:
         self.max_states = max(t.n_states for t in self.automata)
         for knob, value in self.default_tuning.items():
             self.set_tuning(knob, value)
+
+    def _pack(self, automata, flank_lengths, reverse_flags):
+        """The wsx_automaton array of `automata` (and what keeps its pointers valid until the library has copied the tables);
+        the handle's lists grow by them.  reverse_flags default: odd positions OF THIS CALL are reverse-strand automata."""
+        automata = list(automata)
+        flank_lengths = [int(f) for f in flank_lengths]
+        if reverse_flags is None:
+            reverse_flags = [bool(i & 1) for i in range(len(automata))]
+        reverse_flags = [bool(x) for x in reverse_flags]
+        if not (len(automata) == len(flank_lengths) == len(reverse_flags)):
+            raise ValueError('one flank length and one strand flag per automaton')
+        arr = (_lib.WsxAutomaton * len(automata))()
+        keep = []
+        for i, (t, fl) in enumerate(zip(automata, flank_lengths)):
+            ptrs = t.__dict__.get('native_ptrs') if 'value' not in t.__dict__ else None
+            if ptrs is not None:  # tables still in the host library's memory (_hostlib.NativeSetup): the pointers as they are
+                keep.append(t)
+                arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if reverse_flags[i] else 0, *ptrs)
+                continue
+            bufs = [np.ascontiguousarray(t.value, np.float64), np.ascontiguousarray(t.seq_idx, np.int32),
+                    np.ascontiguousarray(t.pred_ptr, np.int32), np.ascontiguousarray(t.pred_idx, np.int32),
+                    np.ascontiguousarray(t.repeat_mask, np.uint8), np.ascontiguousarray(t.last_base, np.uint8)]
+            keep.append(bufs)
+            arr[i] = _lib.WsxAutomaton(t.n_states, t.endstate, fl, 1 if reverse_flags[i] else 0, *[_lib.ptr(b) for b in bufs])
+        self.automata += automata
+        self.flank_lengths += flank_lengths
+        self.reverse_flags += reverse_flags
+        return arr, keep
+
+    def add_automata(self, automata: Sequence[AutomatonTable], flank_lengths: Sequence[int],
+                     reverse_flags: Optional[Sequence[bool]] = None) -> int:
+        """wsx_caller_add_automata: more automata for a handle that is in use (the loci of the next group of a run, while the
+        reads of the last are on the device) -> the index of the first of them.  Earlier automata keep their indices; calls
+        already enqueued are not disturbed.  From the thread that makes the handle's calls."""
+        import time
+        t0 = time.perf_counter()
+        n_before = len(self.automata)
+        arr, keep = self._pack(automata, flank_lengths, reverse_flags)
+        first = C.c_int32(-1)
+        t1 = time.perf_counter()
+        rc = self.lib.wsx_caller_add_automata(self.handle, C.byref(arr), len(arr), C.byref(first))
+        if rc != 0:   # (the handle is as it was)
+            del self.automata[n_before:], self.flank_lengths[n_before:], self.reverse_flags[n_before:]
+        _lib.check(rc, 'wsx_caller_add_automata')
+        del keep
+        self.max_states = max(self.max_states, max(t.n_states for t in self.automata[n_before:]))
+        self.init_s['host_tables'] += t1 - t0
+        self.init_s['wsx_caller_add_automata'] = self.init_s.get('wsx_caller_add_automata', 0.0) + time.perf_counter() - t1
+        return int(first.value)
 
     def create_times(self) -> dict:
         """Where wsx_caller_create spent its time (seconds): a handle for all loci of a run places thousands of automata."""

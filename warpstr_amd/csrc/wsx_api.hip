@@ -268,7 +268,9 @@ struct wsx_caller {
     std::vector<Variant> uvar; // the distinct kernel variants among `variant` (each has a back-pointer region of its own)
     WsxTuning tun;             // launch-policy knobs (wsx_caller_set_tuning)
     double create_s[5] = {0, 0, 0, 0, 0}; // wsx_caller_create_times
-    DeviceBuf aut_blob, aut_table;
+    DeviceBuf aut_blob, aut_table;      // the most recent blob / the table of all automata so far
+    std::vector<DeviceBuf> aut_retired; // blobs of earlier wsx_caller_add_automata calls (referenced by the table for good) and tables
+                                        // that calls still in flight may read: released with the handle
     uint64_t ws_limit = 16ull << 30; // set from the device's free memory at creation (wsx_caller_set_workspace_limit overrides)
     // workspace
     // Up to WSX_MAX_STREAMS workspace sets: consecutive chunks rotate over the handle's stream and internal ones,
@@ -430,98 +432,75 @@ __global__ void pack_mask_kernel(const uint8_t *mask, const int64_t *offsets, in
     bits[off / 32 + lr + w] = v;
 }
 
-} // namespace
-
-extern "C" {
-
-int wsx_internal_on_exception(void);
-int wsx_abi_version(void) { return WSX_ABI_VERSION; }
-
-int wsx_device_count(void)
+// Automata appended to a handle: validated, placed (wsx_place.h), packed into a device blob of their own, the table of all
+// automata so far uploaded anew.  wsx_caller_create's first part, and wsx_caller_add_automata.
+static int append_automata(wsx_caller *c, const wsx_automaton *automata, int32_t n_automata)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-const char *wsx_last_error(void) { return g_err.c_str(); }
-
-int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
-                      const wsx_params *params, void *stream)
-try {
-    if (!out || !automata || n_automata <= 0 || !params) {
-        g_err = "wsx_caller_create: null argument";
-        return WSX_ERR_INVALID;
-    }
-    *out = nullptr;
-    if (params->min_values_per_state < 2 || params->states_in_segment < 2 || !(params->threshold > 0) ||
-        !(params->max_std > 0)) {
-        g_err = "wsx_caller_create: invalid parameters (src/config.py:91-119 asserts)";
-        return WSX_ERR_INVALID;
-    }
-    // (rescaling.threshold > 1 is accepted, as upstream accepts it, src/config.py:97-100: a read whose first least-squares fit
-    // leaves FITPACK's polynomial branch -- possible only then -- takes fpcurf's knot-adding and smoothing branch in
-    // fit_smooth_kernel)
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        g_err = "no HIP device available";
-        return WSX_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= ndev) {
-        g_err = "wsx_caller_create: device index out of range";
-        return WSX_ERR_INVALID;
-    }
-    wsx_caller *c = new wsx_caller();
-    struct Guard { // every failure below releases what has been built so far (wsx_caller_destroy takes partial handles)
-        wsx_caller *c;
-        ~Guard() { if (c) wsx_caller_destroy(c); }
-    } guard{c};
-    c->device = device;
-    c->stream = (hipStream_t)stream;
-    c->prm = *params;
-    HIPCHK(hipSetDevice(device));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
     auto t_phase = now();
-
     // validate + size the automaton blob
     size_t blob = 0;
     for (int a = 0; a < n_automata; a++) {
         const wsx_automaton &A = automata[a];
         if (A.n_states <= 0 || A.n_states > 65535 || A.endstate < 0 || A.endstate >= A.n_states || !A.value ||
             !A.seq_idx || !A.pred_ptr || !A.pred_idx || !A.repeat_mask) {
-            g_err = "wsx_caller_create: malformed automaton";
+            g_err = "wsx_caller_create / wsx_caller_add_automata: malformed automaton";
             return WSX_ERR_INVALID;
         }
         const int S = A.n_states;
         if (A.pred_ptr[0] != 0) {
-            g_err = "wsx_caller_create: pred_ptr[0] must be 0";
+            g_err = "wsx_caller_create / wsx_caller_add_automata: pred_ptr[0] must be 0";
             return WSX_ERR_INVALID;
         }
         for (int j = 0; j < S; j++)
             if (A.pred_ptr[j + 1] < A.pred_ptr[j]) {
-                g_err = "wsx_caller_create: pred_ptr not monotone";
+                g_err = "wsx_caller_create / wsx_caller_add_automata: pred_ptr not monotone";
                 return WSX_ERR_INVALID;
             }
         const int E = A.pred_ptr[S]; // (only now known to be >= 0)
         for (int e = 0; e < E; e++)
             if (A.pred_idx[e] < 0 || A.pred_idx[e] >= S) {
-                g_err = "wsx_caller_create: predecessor index out of range";
+                g_err = "wsx_caller_create / wsx_caller_add_automata: predecessor index out of range";
                 return WSX_ERR_INVALID;
             }
         blob += align_up(S * 8) + align_up(S * 4) + align_up((S + 1) * 4) + align_up(std::max(E, 1) * 4) + align_up(S) +
                 align_up((size_t)((S + 63) / 64) * 64 * 8) + align_up(S) + 2 * align_up(((S + 63) / 64) * 64 * 2 + 2 * S) +
                 align_up((size_t)((S + 63) / 64) * WSX_MAX_F * 64 * 2) + align_up((size_t)((S + 63) / 64) * 64 * 2);
     }
-    HIPCHK(c->aut_blob.ensure(blob));
-    HIPCHK(c->aut_table.ensure(sizeof(DevAutomaton) * n_automata));
+    // a blob of its own per call (the table's entries point into it for the life of the handle) and a NEW table for all automata
+    // so far: calls still in flight read the old one
+    const size_t base = c->host_aut.size();   // index of the first automaton of this call
+    DeviceBuf new_blob, new_table;
+    struct Undo {   // a failure below leaves the handle as it was
+        wsx_caller *c;
+        size_t n_aut, n_uvar;
+        int max_states;
+        bool have_bases;
+        DeviceBuf *blob, *table;
+        bool armed = true;
+        ~Undo()
+        {
+            if (!armed) return;
+            c->host_aut.resize(n_aut);
+            c->variant.resize(n_aut);
+            c->n_states.resize(n_aut);
+            c->uvar.resize(n_uvar);
+            c->max_states = max_states;
+            c->have_bases = have_bases;
+            blob->release();
+            table->release();
+        }
+    } undo{c, base, c->uvar.size(), c->max_states, c->have_bases, &new_blob, &new_table};
+    HIPCHK(new_blob.ensure(blob));
+    HIPCHK(new_table.ensure(sizeof(DevAutomaton) * (base + (size_t)n_automata)));
     std::unique_ptr<char[]> hblob_mem(new char[blob]); // (not value-initialised: every byte the device reads is written below)
     char *const hblob = hblob_mem.get();
-    c->create_s[0] = since(t_phase);
+    c->create_s[0] += since(t_phase);
     t_phase = now();
     size_t used = 0;
     auto put = [&](const void *src, size_t bytes) -> void * {
-        void *d = (char *)c->aut_blob.p + used;
+        void *d = (char *)new_blob.p + used;
         memcpy(hblob + used, src, bytes);
         used += align_up(bytes);
         return d;
@@ -710,9 +689,9 @@ try {
                 if (e) std::rethrow_exception(e);
         }
     }
-    c->create_s[1] = since(t_phase);
+    c->create_s[1] += since(t_phase);
     t_phase = now();
-    c->host_aut.reserve((size_t)n_automata);
+    c->host_aut.reserve(base + (size_t)n_automata);
     for (int a = 0; a < n_automata; a++) {
         const wsx_automaton &A = automata[a];
         const int S = A.n_states, E = A.pred_ptr[S];
@@ -730,7 +709,7 @@ try {
         D.value = (const double *)put(A.value, (size_t)S * 8);
         D.seq_idx = (const int32_t *)put(A.seq_idx, (size_t)S * 4);
         if (!first) {
-            const DevAutomaton &R = c->host_aut[(size_t)rep[a]];
+            const DevAutomaton &R = c->host_aut[base + (size_t)rep[a]];
             D.pred_ptr = R.pred_ptr, D.pred_idx = R.pred_idx;
             D.pos = R.pos, D.state_at = R.state_at, D.wslot = R.wslot, D.pred4 = R.pred4, D.paddr = R.paddr;
         } else {
@@ -784,18 +763,93 @@ try {
             for (const auto &u : distinct) seen = seen || u.same(v);
             if (!seen) distinct.push_back(v);
         }
-        for (auto &v : c->variant) {
+        for (size_t q = base; q < c->variant.size(); q++) {   // (the automata of earlier calls keep the kernel their calls in flight use)
+            Variant &v = c->variant[q];
             if (v.generic || v.pk || v.K < 2 || v.F < 3) continue;
             const int f0 = v.F;   // (one step: a variant joins the kernel with ONE candidate more, whatever the order of the automata)
             for (const auto &u : distinct)
                 if (!u.generic && !u.pk && u.K == v.K && u.FL == v.FL && u.lm == v.lm && u.F == f0 + 1) v.F = u.F;
         }
     }
-    for (auto &v : c->variant) {
+    for (size_t q = base; q < c->variant.size(); q++) {
+        const Variant &v = c->variant[q];
         bool seen = false;
         for (auto &u : c->uvar) seen = seen || u.same(v);
         if (!seen) c->uvar.push_back(v);
     }
+    c->create_s[2] += since(t_phase);
+    t_phase = now();
+    // (synchronous copies from pageable memory: the host waits, the device goes on with whatever it is running)
+    HIPCHK(hipMemcpy(new_blob.p, hblob, used, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(new_table.p, c->host_aut.data(), sizeof(DevAutomaton) * c->host_aut.size(), hipMemcpyHostToDevice));
+    c->create_s[3] += since(t_phase);
+    undo.armed = false;
+    if (c->aut_blob.p) c->aut_retired.push_back(c->aut_blob);
+    if (c->aut_table.p) c->aut_retired.push_back(c->aut_table);
+    c->aut_blob = new_blob;
+    c->aut_table = new_table;
+    return WSX_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+int wsx_internal_on_exception(void);
+int wsx_abi_version(void) { return WSX_ABI_VERSION; }
+
+int wsx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *wsx_last_error(void) { return g_err.c_str(); }
+
+int wsx_caller_create(wsx_caller **out, int device, const wsx_automaton *automata, int32_t n_automata,
+                      const wsx_params *params, void *stream)
+try {
+    if (!out || !automata || n_automata <= 0 || !params) {
+        g_err = "wsx_caller_create: null argument";
+        return WSX_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (params->min_values_per_state < 2 || params->states_in_segment < 2 || !(params->threshold > 0) ||
+        !(params->max_std > 0)) {
+        g_err = "wsx_caller_create: invalid parameters (src/config.py:91-119 asserts)";
+        return WSX_ERR_INVALID;
+    }
+    // (rescaling.threshold > 1 is accepted, as upstream accepts it, src/config.py:97-100: a read whose first least-squares fit
+    // leaves FITPACK's polynomial branch -- possible only then -- takes fpcurf's knot-adding and smoothing branch in
+    // fit_smooth_kernel)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device available";
+        return WSX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_err = "wsx_caller_create: device index out of range";
+        return WSX_ERR_INVALID;
+    }
+    wsx_caller *c = new wsx_caller();
+    struct Guard { // every failure below releases what has been built so far (wsx_caller_destroy takes partial handles)
+        wsx_caller *c;
+        ~Guard() { if (c) wsx_caller_destroy(c); }
+    } guard{c};
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->prm = *params;
+    HIPCHK(hipSetDevice(device));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    auto t_phase = now();
+
+    {
+        const int rc_add = append_automata(c, automata, n_automata);
+        if (rc_add != WSX_SUCCESS) return rc_add;
+    }
+    t_phase = now();
     // Workspace limit: what the device can give.  A fixed 16 GiB made a 100 000-read call of 2 kSample reads take eight
     // chunks instead of four (more, smaller chunks lose: the serial per-read stages last as long for 6 000 reads as for
     // 100 000); the handle only ever allocates what a call needs, the limit is an upper bound.
@@ -805,11 +859,7 @@ try {
             c->ws_limit = std::max<uint64_t>(2ull << 30, (uint64_t)((double)free_b * 0.6));
     }
     if (c->prm.threshold > 1.0) HIPCHK(hipHostMalloc((void **)&c->smooth_host, 2 * WSX_MAX_STREAMS * sizeof(int32_t), hipHostMallocDefault));
-    c->create_s[2] = since(t_phase);
-    t_phase = now();
-    HIPCHK(hipMemcpy(c->aut_blob.p, hblob, used, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->aut_table.p, c->host_aut.data(), sizeof(DevAutomaton) * n_automata, hipMemcpyHostToDevice));
-    c->create_s[3] = since(t_phase);
+    c->create_s[2] += since(t_phase);
     t_phase = now();
     HIPCHK(hipEventCreate(&c->ev_begin));
     HIPCHK(hipEventCreate(&c->ev_end));
@@ -839,6 +889,25 @@ try {
     guard.c = nullptr;
     *out = c;
     return WSX_SUCCESS;
+} catch (...) {
+    return wsx_internal_on_exception();
+}
+
+int wsx_caller_add_automata(wsx_caller *c, const wsx_automaton *automata, int32_t n_automata, int32_t *first_index)
+try {
+    if (!c || !automata || n_automata <= 0) {
+        g_err = "wsx_caller_add_automata: null argument";
+        return WSX_ERR_INVALID;
+    }
+    if (c->host_aut.size() + (size_t)n_automata > (size_t)INT32_MAX) {
+        g_err = "wsx_caller_add_automata: too many automata";
+        return WSX_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int32_t first = (int32_t)c->host_aut.size();
+    const int rc = append_automata(c, automata, n_automata);
+    if (rc == WSX_SUCCESS && first_index) *first_index = first;
+    return rc;
 } catch (...) {
     return wsx_internal_on_exception();
 }
@@ -873,6 +942,7 @@ void wsx_caller_destroy(wsx_caller *c)
         v.dev.release();
     }
     for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
+    for (auto &b : c->aut_retired) b.release();
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
     for (auto &w : c->work)
@@ -1878,6 +1948,7 @@ int wsx_caller_workspace(wsx_caller *c, uint64_t *bytes_allocated, double *bytes
 {
     if (!c) return WSX_ERR_INVALID;
     uint64_t total = c->aut_blob.cap + c->aut_table.cap;
+    for (const auto &b : c->aut_retired) total += b.cap;
     for (auto &b : c->meta) total += b.cap;
     for (auto &w : c->work)
         for (const DeviceBuf *b : {&w.samples, &w.reads, &w.bp, &w.stage_sig, &w.stage_out, &w.reps, &w.smooth}) total += b->cap;
