@@ -306,3 +306,62 @@ def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
     finally:
         _readers._drop_arenas('test_vbz_chunks')
     assert ctypes.sizeof(ctypes.c_int16) == 2
+
+
+@needs_hdf5
+def test_native_reader_loop_equals_the_ctypes_reader(tmp_path):
+    """csrc/host_reader.cpp (wsh_reader_pack: one library call per chunk of reads, the chunk's bytes by pread at the address libhdf5
+    names, the zstd frame decompressed straight into the arena) against the ctypes reader it replaces: the same arena bytes, the same
+    block table and lengths -- on the upstream multi-read file, on reads of several VBZ chunks with a filter-skipped chunk, through a
+    small arena that has to grow -- and it declines (the ctypes reader takes over, or raises) what it does not do: a gzip
+    single-read file, a file that is not there."""
+    from tests.helpers import write_vbz_fast5
+    from warpstr_amd import _readers
+    if _readers._native_reader() is None:
+        pytest.skip('warpstr_amd/_host_loci.so is not built with the reader loop (or HDF5 < 1.10.5)')
+    rng = np.random.default_rng(8)
+    reads = {'a': np.cumsum(rng.integers(-200, 201, size=10000)).astype(np.int16), 'b': rng.integers(-32768, 32768, size=4096).astype(np.int16),
+             'c': np.cumsum(rng.integers(-90, 91, size=12289)).astype(np.int16)}
+    multi = write_vbz_fast5(str(tmp_path / 'multi.fast5'), reads, 4096, True, 1, skip_filter_on=(1,))
+    real = os.path.join(REAL, 'batch_0.fast5')
+    ids = fast5.Fast5File(real).read_ids()
+    items = [(str(tmp_path / 'absent.fast5'), real, r) for r in ids] + [(str(tmp_path / 'absent.fast5'), multi, r) for r in reads]
+
+    def run(region, native):
+        old = os.environ.pop('WARPSTR_NO_NATIVE_READER', None)
+        if not native:
+            os.environ['WARPSTR_NO_NATIVE_READER'] = '1'
+        _readers._NATIVE = False
+        try:
+            out = [_readers.pack_arena((region, 1, items[:7])), _readers.pack_arena((region, 1, items[7:]))]   # (the second behind the first)
+        finally:
+            os.environ.pop('WARPSTR_NO_NATIVE_READER', None)
+            if old is not None:
+                os.environ['WARPSTR_NO_NATIVE_READER'] = old
+            _readers._NATIVE = False
+        arena = out[-1][0]
+        used = out[-1][2] + out[-1][3]
+        return out, bytes(np.memmap(arena, dtype=np.uint8, mode='r')[:used])
+    try:
+        (n1, n2), bytes_native = run('native_loop', True)
+        (c1, c2), bytes_ctypes = run('ctypes_loop', False)
+        for a, b in ((n1, c1), (n2, c2)):
+            assert a[2:6] == b[2:6]                      # first byte, bytes used, lengths, block table
+        assert n2[2] == n1[2] + n1[3] or n2[2] == ((n1[2] + n1[3] + 15) & ~15) or n2[2] >= n1[3]
+        # (bytes between blocks are alignment padding: compare block by block)
+        for t in (np.frombuffer(n1[5], np.int64).reshape(-1, 6), np.frombuffer(n2[5], np.int64).reshape(-1, 6)):
+            for _, kind, off, nbytes, ns, nv in t:
+                assert bytes_native[off:off + nbytes] == bytes_ctypes[off:off + nbytes]
+        assert n1[4] + n2[4] == [len(fast5.Fast5File(real).raw_signal(r)) for r in ids] + [len(v) for v in reads.values()]
+        # what it declines: gzip single-read file -> the ctypes reader's plain block; a missing file -> that reader's error
+        gz = str(tmp_path / 'gz.fast5')
+        sig = rng.integers(-2000, 2000, size=3000).astype(np.int16)
+        write_plain_single_read_fast5(gz, sig, chunk=1024, deflate=4)
+        assert _readers._pack_native('declines', 0, [(gz, None, 'x')]) is None
+        out = _readers.pack_arena(('declines', 2, [(gz, None, 'x')]))
+        assert out[4] == [3000] and np.array_equal(np.memmap(out[0], dtype=np.int16, mode='r')[out[2] // 2:out[2] // 2 + 3000], sig)
+        assert _readers._pack_native('declines', 0, [(str(tmp_path / 'nowhere.fast5'), None, 'x')]) is None
+        with pytest.raises(fast5.Fast5Error):
+            _readers.pack_arena(('declines', 3, [(str(tmp_path / 'nowhere.fast5'), None, 'x')]))
+    finally:
+        _readers._drop_arenas()

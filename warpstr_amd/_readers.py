@@ -201,6 +201,74 @@ def decode_arena(args):
     return arena[0], arena[3], base, lens, time.perf_counter() - t0
 
 
+_NATIVE = False   # (library, or None) once asked
+
+
+def _native_reader():
+    """warpstr_amd/_host_loci.so's reader loop (csrc/host_reader.cpp: wsh_reader_pack), bound to the libhdf5 / libzstd this process
+    uses -- or None: the library is not built, lacks the export (a stale build), HDF5 is older than 1.10.5, or
+    WARPSTR_NO_HOST_NATIVE / WARPSTR_NO_NATIVE_READER say so.  The ctypes reader below then does the same work."""
+    global _NATIVE
+    if _NATIVE is False:
+        _NATIVE = None
+        import ctypes as C
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_host_loci.so')
+        if os.path.exists(path) and not os.environ.get('WARPSTR_NO_HOST_NATIVE') and not os.environ.get('WARPSTR_NO_NATIVE_READER'):
+            try:
+                from ._h5core import lib_paths, libs, thread_context, vbz_native
+                libs()                      # (libhdf5 initialised, its error stack silenced, as the ctypes reader has it)
+                lib = C.CDLL(path)
+                fn = lib.wsh_reader_pack
+                fn.restype = C.c_int64
+                fn.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                lib.wsh_reader_init.argtypes = [C.c_char_p, C.c_char_p]
+                h5, zs = lib_paths()
+                if lib.wsh_reader_init(os.fsencode(h5), os.fsencode(zs)) == 0:
+                    vbz_native()            # (binds the per-thread zstd context wsh_vbz_unpack uses)
+                    _NATIVE = (lib, thread_context)
+            except (OSError, AttributeError, RuntimeError):
+                _NATIVE = None
+    return _NATIVE
+
+
+def _pack_native(region: int, at: int, items):
+    """pack_arena's loop in one library call per chunk (more when the arena has to grow): (bytes written up to, [samples of every
+    read], the block table as bytes) or None when a read needs the ctypes reader (another layout or filter, any error: that path
+    then raises what it finds) -- nothing of the chunk counts as written in that case."""
+    native = _native_reader()
+    if native is None:
+        return None
+    import ctypes as C
+    lib, thread_context = native
+    thread_context()
+    n = len(items)
+    enc = os.fsencode
+    paths = (C.c_char_p * n)(*[enc(it[0]) for it in items])
+    falls = (C.c_char_p * n)(*[enc(it[1]) if it[1] is not None else None for it in items])
+    names = (C.c_char_p * n)(*[it[2].encode('utf-8') if it[2] is not None else None for it in items])
+    lens, status = (C.c_int64 * n)(), (C.c_int32 * n)()
+    table_cap = 2 * n + 16
+    table = (C.c_int64 * (6 * table_cap))()
+    pos, n_blocks, need = C.c_int64(at), C.c_int64(0), C.c_int64(0)
+    arena = _arena(region, max((at + 1) // 2, 1))
+    first = 0
+    while first < n:
+        got = lib.wsh_reader_pack(first, n, paths, falls, names, C.addressof(arena[2]), 2 * arena[3], C.byref(pos), lens, status, table,
+                                  table_cap, C.byref(n_blocks), C.byref(need))
+        if got < 0 or (got < n and status[got] != 0):
+            return None
+        if got < n:   # read `got` did not fit: more room, then on from there
+            if need.value == 0:
+                bigger = (C.c_int64 * (12 * table_cap))()
+                C.memmove(bigger, table, 48 * n_blocks.value)
+                table, table_cap = bigger, 2 * table_cap
+            else:
+                arena = _arena(region, (need.value + 1) // 2 + 8)   # (growing keeps what is there: the file is the memory)
+        first = got
+    return pos.value, list(lens), C.string_at(table, 48 * n_blocks.value)
+
+
 def pack_arena(args):
     """decode_arena() for a parent that decodes on the GPU (wsx_vbz_decode): every read's blocks -- StreamVByte blocks as they
     leave zstd, or plain samples -- back to back (16-byte aligned) in the region's arena.  (region, generation, items) ->
@@ -217,6 +285,12 @@ def pack_arena(args):
     if cur[0] != generation:
         cur[0], cur[1] = generation, 0
     base = at = cur[1]
+    done = _pack_native(region, at, items)
+    if done is not None:
+        at, lens, table_bytes = done
+        cur[1] = at
+        arena = _arena(region, max((at + 1) // 2, 1))
+        return arena[0], 2 * arena[3], base, at - base, lens, table_bytes, time.perf_counter() - t0
     lens, table, offs = [], array.array('q'), []
 
     def place(nbytes):   # where the next block goes

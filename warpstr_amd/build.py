@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, 'libwarpstr_hip.so')
 SEAM_SRC = os.path.join(CSRC, 'seam_helper.c')  # CPython-API loops of the Python seam (no compute); optional at run time
 SEAM_LIB = os.path.join(HERE, '_seam_helper.so')
 HOST_SRC = os.path.join(CSRC, 'host_loci.cpp')   # the per-locus host work (overview.csv, automata, output files): plain C++, no HIP
+READER_SRC = os.path.join(CSRC, 'host_reader.cpp')   # ... and the fast5 reader loop of the reader processes (libhdf5 / libzstd by dlopen)
 HOST_LIB = os.path.join(HERE, '_host_loci.so')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fgpu-rdc' if False else '-fno-gpu-rdc']
@@ -57,9 +58,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    if force or _stale(HOST_LIB, [HOST_SRC]):
+    if force or _stale(HOST_LIB, [HOST_SRC, READER_SRC]):
         cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-fvisibility=hidden', '-Wall', '-pthread',
-               HOST_SRC, '-o', HOST_LIB]
+               HOST_SRC, READER_SRC, '-o', HOST_LIB, '-ldl']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
