@@ -32,6 +32,13 @@ class FakeEngine:
         self.key = [int(t.n_states) + int(t.endstate) for t in tables]   # (a property of the automaton, not its place in the handle)
         self.batches = 0
 
+    def add_automata(self, tables, flank_lengths):
+        first = self.n_aut
+        self.key += [int(t.n_states) + int(t.endstate) for t in tables]
+        self.n_aut += len(tables)
+        self.added = getattr(self, 'added', 0) + len(tables)
+        return first
+
     def submit_signals(self, signals, aut):
         self.batches += 1
         n = len(signals)
@@ -881,3 +888,64 @@ def test_a_batch_whose_arena_finds_no_room_is_read_through_the_pipes(tmp_path, m
     for la, lb in zip(a, b):
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+@pytest.mark.parametrize('threads', [1, 3])
+def test_a_long_run_streams_its_set_up_reading_and_calling(tmp_path, threads, monkeypatch):
+    """From STREAM_FROM_LOCI loci on (one rank, fast5 files, reader arenas) the run is one pipeline: the loci are set up part after
+    part on a thread of its own, the readers start on the first part's files, the handle is created from the loci known by then
+    and takes the later ones with add_automata while batches are in flight.  Same files as the run that sets everything up first;
+    the timings say which path ran."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    monkeypatch.setattr(wl, 'STREAM_FROM_LOCI', 100)
+    monkeypatch.setattr(wl, 'SHARED_BATCH_READS', 64)
+    a, b = (_fast5_loci(str(tmp_path / t), src, ids, n_loci=230) for t in 'ab')
+    tm_b = {}
+    main_wrapper_loci(b, 1, _engine=FakeEngine, quiet=True, timings=tm_b)
+    assert 'streamed' not in str(tm_b.get('reader_mode'))
+    added = []
+
+    class Engine(VbzFakeEngine):
+        def add_automata(self, tables, flank_lengths):
+            added.append(len(tables))
+            return super().add_automata(tables, flank_lengths)
+    tm = {}
+    tables = main_wrapper_loci(a, threads, _engine=Engine, quiet=True, timings=tm)
+    assert tm['reader_mode'].endswith('streamed with the set-up') and tm['vbz_batches'] >= 4
+    assert tm['n_loci'] == 230 and tm['n_reads'] == sum(1 + li % 3 for li in range(230))
+    assert len(tables) == 230 and len(tables[229][0]) == 1 + 229 % 3
+    for la, lb in zip(a, b):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+    # (whether automata arrived in flight depends on the race between the set-up and the first batch; when they did, all arrived)
+    assert sum(added) == tm.get('automata_added_in_flight', 0) and sum(added) < 2 * 230
+
+
+def test_a_streamed_run_raises_what_its_set_up_raises(tmp_path, monkeypatch):
+    """A locus without its overview.csv in the middle of a streamed run: upstream's error for it, no batch left in flight, no
+    reader thread left behind."""
+    import threading
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    monkeypatch.setattr(wl, 'STREAM_FROM_LOCI', 100)
+    loci = _fast5_loci(str(tmp_path / 'a'), src, ids, n_loci=200)
+    os.unlink(os.path.join(loci[150].path, 'overview.csv'))
+    before = threading.active_count()
+    with pytest.raises(FileNotFoundError, match='Not found the overview file'):
+        main_wrapper_loci(loci, 1, _engine=VbzFakeEngine, quiet=True)
+    assert threading.active_count() <= before

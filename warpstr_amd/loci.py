@@ -149,6 +149,10 @@ class HipEngine:
     def arena_ready(self, path, samples):
         return self.queue.arena_ready(path, samples)
 
+    def add_automata(self, tables, flank_lengths):
+        """More loci for the handle while its batches are in flight (wsx_caller_add_automata) -> index of the first new automaton."""
+        return self.hip.add_automata(tables, flank_lengths)
+
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
                 'handle_create_s': self.hip.create_times(), 'submit_parts_s': dict(self.queue.parts_s),
@@ -632,6 +636,306 @@ def _arena_room(workers: int, reads: int, byte_budget: int = 0) -> Optional[str]
     return None
 
 
+STREAM_FROM_LOCI = 256   # a run of that many loci (one rank, fast5 files, reader arenas) reads its first loci's files while it still
+                         # sets the later ones up
+
+
+def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings):
+    """Set-up, reading and calling of a run as ONE pipeline (upstream's loop reaches a locus, builds its automata, calls its
+    reads: WarpSTR.py:33-76): the loci are set up part after part on a thread of its own; as soon as the first part is there the
+    reader thread hands its reads' files to the reader processes; the calling thread creates the handle from the loci known by
+    then and ADDS the later ones as they come (wsx_caller_add_automata), submitting every batch as it is decoded.  The readers
+    no longer idle while thousands of loci are parsed and compiled, nor the set-up threads while the files are read.
+    Reader arenas only (loci.main_wrapper_loci decides).  Returns (jobs, first read of every job, records, [seq1 parts], [seq2 parts])."""
+    import collections
+    import queue as _queue
+    import threading
+    cond = threading.Condition()
+    jobs: List[LocusJob] = []
+
+    class Known:   # what is known of the run's reads so far (grown under `cond`; a prefix, once handed out, never changes)
+        n = 0
+        cap = 0
+        lo = hi = span = least = np.zeros(0, np.int64)
+        aut = np.zeros(0, np.int32)
+        locus = row = np.zeros(0, np.int64)
+        first = [0]
+        final = False
+        error: Optional[BaseException] = None
+    K = Known
+
+    def grow(part_jobs):
+        counts = [j.n for j in part_jobs]
+        m = int(sum(counts))
+        base_job = len(jobs)
+        with cond:
+            if K.n + m > K.cap:
+                K.cap = max(2 * K.cap, K.n + m, 4096)
+                for name in ('lo', 'hi', 'span', 'least', 'aut', 'locus', 'row'):
+                    old = getattr(K, name)
+                    new = np.zeros(K.cap, old.dtype)
+                    new[:K.n] = old[:K.n]
+                    setattr(K, name, new)
+            a, b = K.n, K.n + m
+            if m:
+                lo = np.concatenate([j.lo for j in part_jobs])
+                hi = np.concatenate([j.hi for j in part_jobs])
+                loc = np.repeat(np.arange(base_job, base_job + len(part_jobs)), counts)
+                K.lo[a:b], K.hi[a:b] = lo, hi
+                K.span[a:b] = (hi - lo + 1).clip(min=1)
+                K.least[a:b] = 2 * (hi + 1).clip(min=1)
+                K.locus[a:b] = loc
+                K.row[a:b] = np.concatenate([np.arange(c) for c in counts])
+                K.aut[a:b] = (2 * loc + np.concatenate([j.reverse for j in part_jobs])).astype(np.int32)
+            for c in counts:
+                K.first.append(K.first[-1] + c)
+            jobs.extend(part_jobs)
+            K.n = b
+            cond.notify_all()
+
+    t_setup = time.perf_counter()
+
+    def run_setup():
+        try:
+            spread_over_cpus()
+            for part in parts:
+                if stop.is_set():   # (the run has failed elsewhere: nothing more to set up)
+                    break
+                part_jobs, ptm = setup(part)
+                for key, v in ptm.items():
+                    tm[key] = tm.get(key, 0.0) + v
+                print_warnings(part_jobs)
+                grow(part_jobs)
+        except BaseException as e:  # noqa: BLE001 -- raised by the calling thread
+            K.error = e
+        finally:
+            tm['setup_wall_s'] = time.perf_counter() - t_setup
+            with cond:
+                K.final = True
+                cond.notify_all()
+
+    stop, engine_ready = threading.Event(), threading.Event()
+    submitted: Dict[int, threading.Event] = {}
+    handover: '_queue.Queue' = _queue.Queue(maxsize=1)
+    engine = [None]
+    regions = engine_cls.ARENA_REGIONS
+    inline = getattr(pool, 'inline', False)
+    reads_cap = min(batch_reads, SHARED_BATCH_READS // 4 if inline else SHARED_BATCH_READS)
+
+    def item_of(k):
+        job, row = jobs[int(K.locus[k])], int(K.row[k])
+        return (job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row])
+
+    def page_lock(parts_):
+        if not engine_ready.is_set() or engine[0] is None:
+            return False
+        ready = getattr(engine[0], 'arena_ready', None)
+        if ready is not None:
+            for part in parts_:
+                ready(part[0], part[1] // 2 if len(part) == 6 else part[1])
+        return True
+
+    def arena_batches():
+        inflight = collections.deque()
+        b, k = 0, 0
+        seen = [0, 0]
+        while True:
+            while len(inflight) < regions - 1:
+                with cond:
+                    n, final = K.n, K.final
+                    span, least = K.span, K.least
+                if b >= n:
+                    break
+                if not final and n - b < reads_cap // 8 and inflight:
+                    break   # (a sliver of a part: more is on its way, and the readers have work)
+                b1 = min(n, b + reads_cap)
+                if not seen[0]:
+                    b1 = min(b1, b + ARENA_PROBE_READS)
+                mean = seen[1] // seen[0] if seen[0] else 0
+                fit = min(int(np.searchsorted(np.cumsum(np.maximum(least[b:b1], mean)), raw_budget, side='right')),
+                          int(np.searchsorted(np.cumsum(span[b:b1]), batch_samples, side='right')))
+                b1 = b + max(1, min(b1 - b, fit))
+                t1 = time.perf_counter()
+                region = k % regions
+                if k >= regions:
+                    while not submitted[k - regions].wait(0.2):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
+                    engine[0].region_wait(region)
+                    del submitted[k - regions]
+                submitted[k] = threading.Event()
+                items = [item_of(x) for x in range(b, b1)]
+                step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
+                inflight.append((b, b1, region, futures, k))
+                tm['read_s'] += time.perf_counter() - t1
+                b, k = b1, k + 1
+            if not inflight:
+                with cond:
+                    if K.n > b:
+                        continue
+                    if K.final:
+                        return
+                    cond.wait(0.2)
+                if stop.is_set():
+                    return
+                continue
+            b0, b1, region, futures, kb = inflight.popleft()
+            t1 = time.perf_counter()
+            parts_ = []
+            try:
+                answers = [f.result() for f in futures]
+            except RuntimeError as e:
+                if 'no room for a reader arena' not in str(e):
+                    raise
+                if not tm.get('arena_fallbacks'):
+                    print(f'warpstr_amd: {str(e).strip().splitlines()[-1]}; such batches are read without arenas', file=sys.stderr)
+                tm['arena_fallbacks'] = tm.get('arena_fallbacks', 0) + 1
+                for f in futures:
+                    f.exception()
+                items = [item_of(x) for x in range(b0, b1)]
+                data = []
+                if inline:
+                    data = _read_chunk(items)
+                else:
+                    step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                    for part in pool.map(_read_chunk, [items[q:q + step] for q in range(0, len(items), step)]):
+                        data += part
+                seen[0] += b1 - b0
+                seen[1] += int(sum(d.nbytes for d in data))
+                tm['raw_bytes'] = tm.get('raw_bytes', 0) + int(sum(d.nbytes for d in data))
+                submitted[kb].set()
+                tm['read_s'] += time.perf_counter() - t1
+                yield b0, b1, data, None
+                continue
+            seen[0] += b1 - b0
+            for got in answers:
+                if gpu_vbz:
+                    path, cap, base, used, lens_p, table, busy = got
+                    parts_.append((path, cap, base, used, lens_p, table))
+                    tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + int(used)
+                else:
+                    path, cap, base, lens_p, busy = got
+                    parts_.append((path, cap, base, lens_p))
+                    tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + 2 * int(sum(lens_p))
+                page_lock([parts_[-1]])
+                tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
+                tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
+                seen[1] += 2 * int(sum(lens_p))
+            tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
+            tm['read_s'] += time.perf_counter() - t1
+            yield b0, b1, parts_, ('vbz' if gpu_vbz else 'arena', region, kb)
+
+    def produce():
+        try:
+            for item in arena_batches():
+                locked = item[3] is None
+                while not stop.is_set():
+                    locked = locked or page_lock(item[2])
+                    try:
+                        handover.put(item, timeout=0.2 if locked else 0.01)
+                        break
+                    except _queue.Full:
+                        pass
+                if stop.is_set():
+                    return
+            item = None
+        except BaseException as e:  # noqa: BLE001 -- raised by the consumer below
+            item = e
+        while not stop.is_set():
+            try:
+                handover.put(item, timeout=0.2)
+                return
+            except _queue.Full:
+                pass
+
+    held = [0]   # jobs whose automata the handle holds
+
+    def ensure_automata(n_jobs_needed):
+        """The handle holds the automata of every job known by now (at least the first n_jobs_needed)."""
+        with cond:
+            n_jobs = len(jobs)
+        assert n_jobs >= n_jobs_needed
+        if n_jobs == held[0]:
+            return
+        t0 = time.perf_counter()
+        new = jobs[held[0]:n_jobs]
+        tables = [s for j in new for s in (j.temp_sta, j.rev_sta)]
+        flanks = [j.flank_length for j in new for _ in range(2)]
+        if engine[0] is None:
+            engine[0] = engine_cls(tables, flanks, *engine_args)
+            engine_ready.set()
+        else:
+            first_new = engine[0].add_automata(tables, flanks)
+            if first_new != 2 * held[0]:
+                raise RuntimeError(f'the handle numbered the new automata from {first_new}, the run from {2 * held[0]}')
+            tm['automata_added_in_flight'] = tm.get('automata_added_in_flight', 0) + len(tables)
+        held[0] = n_jobs
+        tm['handle_s'] += time.perf_counter() - t0
+
+    rec_parts, seqs, pending = [], [[], []], []
+
+    def finish(ticket, b0, b1):
+        t1 = time.perf_counter()
+        rec, s1, p1, s2, p2 = engine[0].collect(ticket)
+        tm['collect_s'] += time.perf_counter() - t1
+        rec_parts.append((b0, b1, rec))
+        seqs[0].append(s1)
+        seqs[1].append(s2)
+
+    def submit(b0, b1, data, slot):
+        with cond:
+            lo, hi, aut, locus = K.lo, K.hi, K.aut, K.locus
+        ensure_automata(int(locus[b1 - 1]) + 1)
+        t1 = time.perf_counter()
+        if slot is None:
+            ticket = engine[0].submit_raw(data, lo[b0:b1], hi[b0:b1], aut[b0:b1])
+        elif slot[0] == 'vbz':
+            ticket = engine[0].submit_vbz_parts(slot[1], data, lo[b0:b1], hi[b0:b1], aut[b0:b1])
+        else:
+            ticket = engine[0].submit_raw_parts(slot[1], data, lo[b0:b1], hi[b0:b1], aut[b0:b1])
+        tm['submit_s'] += time.perf_counter() - t1
+        if slot is not None:
+            submitted[slot[2]].set()
+        pending.append((ticket, b0, b1))
+        if len(pending) > 2:
+            finish(*pending.pop(0))
+
+    setup_thread = threading.Thread(target=run_setup, name='warpstr-setup', daemon=True)
+    reader = threading.Thread(target=produce, name='warpstr-reader', daemon=True)
+    setup_thread.start()
+    try:
+        reader.start()
+        while True:
+            item = handover.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            submit(*item)
+        while pending:
+            finish(*pending.pop(0))
+    finally:
+        stop.set()
+        engine_ready.set()
+        reader.join()
+        setup_thread.join()
+        if engine[0] is not None:
+            try:
+                tm.update(engine[0].info())
+            finally:
+                engine[0].close()
+    if K.error is not None:
+        raise K.error
+    n_total = K.n
+    records = np.zeros(n_total, dtype=_result_dtype())
+    for b0, b1, rec in rec_parts:
+        records[b0:b1] = rec
+    return jobs, np.asarray(K.first, np.int64), records, seqs
+
+
 def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Optional[CallerConfig] = None,
                       rescaler_config: Optional[RescalerConfig] = None,
                       signal_loader: Optional[Callable[[str, int, int], np.ndarray]] = None,
@@ -732,20 +1036,55 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     error = None
     jobs: List[LocusJob] = []
     t0 = time.perf_counter()
-    try:
-        step = max(1, min(64, len(own) // (4 * max(tm['host_threads'], 1)) or 1))
-        parts = [own[k:k + step] for k in range(0, len(own), step)]
+    step = max(1, min(64, len(own) // (4 * max(tm['host_threads'], 1)) or 1))
+    parts = [own[k:k + step] for k in range(0, len(own), step)]
 
-        def setup(part):
-            ptm: Dict[str, float] = {}
-            t1 = time.perf_counter()
-            chunk = [loci[i] for i in part]
-            sts = _hostlib.NativeSetup.run_many([l.path for l in chunk], [l.sequence.upper() for l in chunk], pore_model,
-                                                caller_config.min_state_similarity, writes) if native else None
-            ptm['native_setup_s'] = time.perf_counter() - t1
-            return [LocusJob(l, pore_model, ptm, caller_config, write=writes, native=native, setup=sts[q] if sts else None)
-                    for q, l in enumerate(chunk)], ptm
-        for part_jobs, ptm in _thread_map(executor, setup, parts):
+    def setup(part):
+        ptm: Dict[str, float] = {}
+        t1 = time.perf_counter()
+        chunk = [loci[i] for i in part]
+        sts = _hostlib.NativeSetup.run_many([l.path for l in chunk], [l.sequence.upper() for l in chunk], pore_model,
+                                            caller_config.min_state_similarity, writes) if native else None
+        ptm['native_setup_s'] = time.perf_counter() - t1
+        return [LocusJob(l, pore_model, ptm, caller_config, write=writes, native=native, setup=sts[q] if sts else None)
+                for q, l in enumerate(chunk)], ptm
+
+    # One rank, fast5 files, reader arenas and many loci: the set-up, the reading and the calling run as one pipeline
+    # (_streamed_run) -- the readers start on the first loci's files while the later loci are still parsed and compiled, and the
+    # handle takes their automata as they come.
+    engine_cls = _engine or HipEngine
+    probe = engine_cls if isinstance(engine_cls, type) else None
+    streamed = None
+    if (fast5_on_workers and not collective and len(own) >= STREAM_FROM_LOCI and probe is not None and not os.environ.get('WARPSTR_NO_STREAMED_RUN')
+            and all(hasattr(probe, a) for a in ('submit_raw_parts', 'ARENA_REGIONS', 'add_automata', 'region_wait'))
+            and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')):
+        pool = _started(pool, tm)
+        workers = pool._max_workers if pool is not None else 1
+        refused = _arena_room(workers, SHARED_BATCH_READS if pool is not None else SHARED_BATCH_READS // 4, batch_raw_bytes // 2)
+        if refused is not None:
+            tm['arenas_refused'] = refused
+        else:
+            if pool is None:
+                pool = _InlinePool()
+                pools.append(pool)
+            gpu_vbz = hasattr(probe, 'submit_vbz_parts') and not os.environ.get('WARPSTR_NO_GPU_VBZ')
+            tm['reader_mode'] = (('arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas') + (', filled in this process' if getattr(pool, 'inline', False) else '')
+                                 + ', streamed with the set-up')
+
+            def print_warnings(part_jobs):
+                if not quiet and writes:
+                    for job in part_jobs:
+                        for line in job.warnings:
+                            print(line)
+            # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results)
+            it = parts if executor is None else executor.map(setup, parts)
+            streamed = _streamed_run(it, (lambda x: x) if executor is not None else setup, tm, pool, engine_cls,
+                                     (caller_config, rescaler_config, local_gpu), batch_reads, batch_samples, batch_raw_bytes // 2, gpu_vbz,
+                                     print_warnings)
+    try:
+        if streamed is not None:
+            jobs = streamed[0]
+        for part_jobs, ptm in (_thread_map(executor, setup, parts) if streamed is None else ()):
             jobs += part_jobs
             for key, v in ptm.items():
                 tm[key] += v   # (CPU seconds, summed over the threads)
@@ -753,10 +1092,11 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         if not collective:
             raise
         error = e
-    tm['setup_wall_s'] = time.perf_counter() - t0
+    if streamed is None:
+        tm['setup_wall_s'] = time.perf_counter() - t0
     if collective:
         wdist.agree_or_raise(error, world, coll_device, 'setting up the loci')
-    if not quiet and writes:
+    if not quiet and writes and streamed is None:
         for job in jobs:
             for line in job.warnings:
                 print(line)
@@ -771,7 +1111,10 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     off1 = off2 = np.zeros(1, np.int64)
     if n_total == 0 and collective:
         wdist.agree_or_raise(None, world, coll_device, 'reading / calling the reads')   # (the other ranks are in this collective)
-    if n_total > 0:
+    if streamed is not None:
+        _, _, records, seqs = streamed
+        mine = np.arange(n_total)
+    if n_total > 0 and streamed is None:
         # ---- the read list: (locus, row) -> automaton, cost ---------------------------------------------------------------
         counts = [j.n for j in jobs]
         locus_of = np.repeat(np.arange(len(jobs)), counts)
@@ -1157,6 +1500,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
         if collective or error is not None:
             wdist.agree_or_raise(error, world if collective else 1, coll_device, 'reading / calling the reads')
 
+    if n_total > 0:
         # ---- the complete table of this rank's loci ---------------------------------------------------------------------------
         t0 = time.perf_counter()
         ok = records['status'] == 0
