@@ -749,7 +749,7 @@ class BatchQueue:
         return self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
 
     # ---- reader arenas (_readers.decode_arena): every reader process decodes its chunks into memory-backed files of its own ----
-    ARENA_REGIONS = 3   # a region is written again only after the batch that used it was uploaded
+    ARENA_REGIONS = int(os.environ.get('WARPSTR_ARENA_REGIONS', '3') or 3)   # a region is written again only after the batch that used it was uploaded
 
     def region_wait(self, region: int):
         """Block until the batch that last used `region` of the readers' arenas has been uploaded."""

@@ -636,17 +636,19 @@ def _arena_room(workers: int, reads: int, byte_budget: int = 0) -> Optional[str]
     return None
 
 
+CHUNKS_PER_READER = int(os.environ.get('WARPSTR_CHUNKS_PER_READER', '2') or 2)   # chunks a batch gives every reader process (a round trip costs ~0.1 ms)
 STREAM_FROM_LOCI = 256   # a run of that many loci (one rank, fast5 files, reader arenas) reads its first loci's files while it still
                          # sets the later ones up
 
 
-def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings):
+def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings, raw_reads=None):
     """Set-up, reading and calling of a run as ONE pipeline (upstream's loop reaches a locus, builds its automata, calls its
     reads: WarpSTR.py:33-76): the loci are set up part after part on a thread of its own; as soon as the first part is there the
     reader thread hands its reads' files to the reader processes; the calling thread creates the handle from the loci known by
     then and ADDS the later ones as they come (wsx_caller_add_automata), submitting every batch as it is decoded.  The readers
     no longer idle while thousands of loci are parsed and compiled, nor the set-up threads while the files are read.
-    Reader arenas only (loci.main_wrapper_loci decides).  Returns (jobs, first read of every job, records, [seq1 parts], [seq2 parts])."""
+    Reader arenas (loci.main_wrapper_loci decides), or -- raw_reads: a mapping read name -> int16 read -- reads that are in host
+    memory already: the batches are then cut from what is known, nothing is read.  Returns (jobs, first read of every job, records, [seq1 parts], [seq2 parts])."""
     import collections
     import queue as _queue
     import threading
@@ -718,7 +720,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
     submitted: Dict[int, threading.Event] = {}
     handover: '_queue.Queue' = _queue.Queue(maxsize=1)
     engine = [None]
-    regions = engine_cls.ARENA_REGIONS
+    regions = getattr(engine_cls, 'ARENA_REGIONS', 3)
     inline = getattr(pool, 'inline', False)
     reads_cap = min(batch_reads, SHARED_BATCH_READS // 4 if inline else SHARED_BATCH_READS)
 
@@ -767,7 +769,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                     del submitted[k - regions]
                 submitted[k] = threading.Event()
                 items = [item_of(x) for x in range(b, b1)]
-                step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
                 futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
                 inflight.append((b, b1, region, futures, k))
                 tm['read_s'] += time.perf_counter() - t1
@@ -800,7 +802,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 if inline:
                     data = _read_chunk(items)
                 else:
-                    step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                    step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
                     for part in pool.map(_read_chunk, [items[q:q + step] for q in range(0, len(items), step)]):
                         data += part
                 seen[0] += b1 - b0
@@ -828,9 +830,39 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
             tm['read_s'] += time.perf_counter() - t1
             yield b0, b1, parts_, ('vbz' if gpu_vbz else 'arena', region, kb)
 
+    def memory_batches():
+        """Reads in host memory: a batch is whatever is known, up to the batch limits -- but not a sliver while more is coming."""
+        b = 0
+        least_reads = min(batch_reads, 4096)
+        while True:
+            with cond:
+                n, final = K.n, K.final
+                span, locus, row = K.span, K.locus, K.row
+                if b >= n or (not final and n - b < least_reads):
+                    if b >= n and final:
+                        return
+                    cond.wait(0.05)
+                    if stop.is_set():
+                        return
+                    continue
+            t1 = time.perf_counter()
+            b1 = min(n, b + batch_reads)
+            b1 = b + max(1, min(b1 - b, int(np.searchsorted(np.cumsum(span[b:b1]), batch_samples, side='right'))))
+            data, acc = [], 0
+            for k in range(b, b1):   # (long raw reads: as many as fit the byte budget, the rest open the next batch)
+                raw = raw_reads[jobs[int(locus[k])].names[int(row[k])]]
+                if data and acc + raw.nbytes > raw_budget:
+                    b1 = k
+                    break
+                data.append(raw)
+                acc += raw.nbytes
+            tm['read_s'] += time.perf_counter() - t1
+            yield b, b1, data, None
+            b = b1
+
     def produce():
         try:
-            for item in arena_batches():
+            for item in (arena_batches() if raw_reads is None else memory_batches()):
                 locked = item[3] is None
                 while not stop.is_set():
                     locked = locked or page_lock(item[2])
@@ -1055,8 +1087,20 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     engine_cls = _engine or HipEngine
     probe = engine_cls if isinstance(engine_cls, type) else None
     streamed = None
-    if (fast5_on_workers and not collective and len(own) >= STREAM_FROM_LOCI and probe is not None and not os.environ.get('WARPSTR_NO_STREAMED_RUN')
-            and all(hasattr(probe, a) for a in ('submit_raw_parts', 'ARENA_REGIONS', 'add_automata', 'region_wait'))
+    def print_warnings(part_jobs):
+        if not quiet and writes:
+            for job in part_jobs:
+                for line in job.warnings:
+                    print(line)
+    can_stream = (not collective and len(own) >= STREAM_FROM_LOCI and probe is not None and hasattr(probe, 'add_automata')
+                  and not os.environ.get('WARPSTR_NO_STREAMED_RUN'))
+    if can_stream and raw_reads is not None and signal_loader is None:
+        # reads in host memory: the handle is created from the first loci and fed while the later ones are set up
+        tm['reader_mode'] = 'reads in host memory, streamed with the set-up'
+        streamed = _streamed_run(parts if executor is None else executor.map(setup, parts), (lambda x: x) if executor is not None else setup, tm,
+                                 None, engine_cls, (caller_config, rescaler_config, local_gpu), batch_reads, batch_samples, batch_raw_bytes // 2,
+                                 False, print_warnings, raw_reads=raw_reads)
+    elif (can_stream and fast5_on_workers and all(hasattr(probe, a) for a in ('submit_raw_parts', 'ARENA_REGIONS', 'region_wait'))
             and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')):
         pool = _started(pool, tm)
         workers = pool._max_workers if pool is not None else 1
@@ -1071,11 +1115,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             tm['reader_mode'] = (('arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas') + (', filled in this process' if getattr(pool, 'inline', False) else '')
                                  + ', streamed with the set-up')
 
-            def print_warnings(part_jobs):
-                if not quiet and writes:
-                    for job in part_jobs:
-                        for line in job.warnings:
-                            print(line)
             # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results)
             it = parts if executor is None else executor.map(setup, parts)
             streamed = _streamed_run(it, (lambda x: x) if executor is not None else setup, tm, pool, engine_cls,
@@ -1200,7 +1239,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             cuts.insert(b + 1, b0 + SHARED_BATCH_READS)
                             b1 = b0 + SHARED_BATCH_READS
                         items = [item_of(k) for k in range(b0, b1)]
-                        step = max(8, -(-len(items) // (2 * pool._max_workers)))   # (two chunks per worker: a round trip costs ~0.1 ms)
+                        step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))   # (two chunks per worker: a round trip costs ~0.1 ms)
                         parts = [items[k:k + step] for k in range(0, len(items), step)]
                         if use_shared:
                             # two steps: lengths, then every read decoded to its place in a staging buffer both sides map
@@ -1326,7 +1365,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             del submitted[k - regions]
                         submitted[k] = threading.Event()
                         items = [item_of(x) for x in range(b, b1)]
-                        step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                        step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
                         futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step]))
                                    for q in range(0, len(items), step)]
                         inflight.append((b, b1, region, futures, k))
@@ -1352,7 +1391,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             data = _read_chunk([item_of(x) for x in range(b0, b1)])
                         else:
                             items = [item_of(x) for x in range(b0, b1)]
-                            step = max(8, -(-len(items) // (2 * pool._max_workers)))
+                            step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
                             for part in pool.map(_read_chunk, [items[q:q + step] for q in range(0, len(items), step)]):
                                 data += part
                         seen[0] += b1 - b0
