@@ -949,39 +949,3 @@ def test_a_streamed_run_raises_what_its_set_up_raises(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError, match='Not found the overview file'):
         main_wrapper_loci(loci, 1, _engine=VbzFakeEngine, quiet=True)
     assert threading.active_count() <= before
-
-
-@pytest.mark.parametrize('threads', [1, 4])
-def test_a_long_run_of_reads_in_host_memory_streams_too(tmp_path, threads, monkeypatch):
-    """raw_reads (reads in host memory: the bench's many_loci leg, a caller that holds its reads) from STREAM_FROM_LOCI loci on: the
-    handle is created from the first loci and takes the later ones while batches are in flight; same files as the run that sets
-    everything up first (here: the same run with streaming switched off)."""
-    import warpstr_amd.loci as wl
-    monkeypatch.setattr(wl, 'STREAM_FROM_LOCI', 20)
-    rng = np.random.default_rng(3)
-    raws = {}
-
-    def make(root):
-        loci = []
-        for li in range(60):
-            pattern, fl = [('(AGC)', 16), ('(AAAT)', 30), ('(GGCCCC)', 24)][li % 3]
-            locus = synth.make_locus(pattern, fl, 700 + li)
-            loc = os.path.join(root, f'locus{li}')
-            ov.store_flanks(loc, [locus.left_t, locus.right_t, locus.left_r, locus.right_r])
-            names = [f'L{li}_r{i}' for i in range(2 + li % 4)]
-            for nm in names:
-                raws.setdefault(nm, rng.integers(300, 700, size=int(rng.integers(900, 1500))).astype(np.int16))
-            pd.DataFrame({'read_name': names, 'run_id': 0, 'reverse': [bool(i & 1) for i in range(len(names))], 'saved': 1, 'l_start_raw': 100,
-                          'r_end_raw': [len(raws[nm]) - 50 for nm in names]}).to_csv(os.path.join(loc, 'overview.csv'), index=False)
-            loci.append(LocusPath(loc, pattern, fl))
-        return loci
-    a, b = make(str(tmp_path / 'a')), make(str(tmp_path / 'b'))
-    tm_a, tm_b = {}, {}
-    main_wrapper_loci(a, threads, raw_reads=raws, _engine=FakeEngine, quiet=True, timings=tm_a, batch_reads=40)
-    monkeypatch.setenv('WARPSTR_NO_STREAMED_RUN', '1')
-    main_wrapper_loci(b, threads, raw_reads=raws, _engine=FakeEngine, quiet=True, timings=tm_b, batch_reads=40)
-    assert tm_a['reader_mode'] == 'reads in host memory, streamed with the set-up' and 'reader_mode' not in tm_b
-    assert tm_a['n_reads'] == tm_b['n_reads'] == sum(2 + li % 4 for li in range(60)) and tm_a['batches'] >= 4
-    for la, lb in zip(a, b):
-        for rel in OUTPUTS:
-            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
