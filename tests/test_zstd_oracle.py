@@ -70,7 +70,7 @@ def inputs():
     yield 'mixed', text[:70000] + bytes(100000) + svb[:150000] + text[:50000]
     yield 'few symbols', bytes(rng.integers(0, 3, size=250000).astype(np.uint8))   # a tiny alphabet: direct weights
     yield 'periodic', bytes(range(256)) * 900
-    yield 'small skewed', bytes(np.minimum(rng.geometric(0.2, size=700), 255).astype(np.uint8))   # Huffman literals in ONE stream
+    yield 'small skewed', bytes(np.minimum(rng.geometric(0.3, size=180), 255).astype(np.uint8))   # Huffman literals in ONE stream
     # a second block whose literals are one byte over and over (RLE literals): copies of pieces of the first, random, block with
     # a single 'a' between them
     first = bytes(rng.integers(0, 256, size=1 << 17).astype(np.uint8))
