@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define WSX_ABI_VERSION 13
+#define WSX_ABI_VERSION 14
 
 /* function return codes */
 enum {
@@ -293,6 +293,32 @@ typedef struct wsx_vbz_block {
 enum { WSX_VBZ_PLAIN = 0, WSX_VBZ_SVB_ZIGZAG = 1, WSX_VBZ_SVB = 2 };
 int wsx_vbz_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const wsx_vbz_block *blocks, int64_t n_blocks,
                    int16_t *dst, int64_t dst_samples, int32_t *status);
+
+/*
+ * The zstd frames of VBZ chunks, decoded on the device (the step in front of wsx_vbz_decode): what the HDF5 filter plugin 32020 asks
+ * of libzstd when h5py reads `Raw/Signal` for Fast5.get_data_processed (src/schemas/fast5.py:50-52; plugin and libzstd are third-party
+ * dependencies that are not in the upstream tree; the format is RFC 8878).  A workgroup per frame: the Huffman-coded literals of
+ * every block are decoded a wavefront per block (the four streams of a block side by side), then one wavefront executes the
+ * blocks' sequences in order.
+ *   src        device: the frames' bytes (each from its magic number on)
+ *   frames     host wsx_zstd_frame[n_frames]: where a frame lies in src, where its content goes in dst and how many bytes that is
+ *              (the content size the frame's header declares).  Checked before anything is enqueued; copied before the call returns
+ *   dst        device: the content of frame i at dst_offset (e.g. the StreamVByte block wsx_vbz_decode then takes from there)
+ *   scratch    device, as large as dst: where the literals of a frame's blocks lie between the two phases
+ *   status     device int32[n_frames] or NULL: 0 decoded; 1 the frame uses what this decoder leaves to the host (a dictionary,
+ *              literals that reuse the previous block's Huffman tree, more than 32 blocks): decompress it there; 2 corrupt (or its
+ *              content is not dst_bytes long).  Output of a frame with a non-zero status is undefined.  Valid in stream order
+ * Enqueued on the handle's stream; returns without waiting.  A wsx_vbz_decode on the same handle that follows reads dst in stream
+ * order.
+ */
+typedef struct wsx_zstd_frame {
+    int64_t src_offset; /* first byte of the frame in src */
+    int64_t src_bytes;  /* its size */
+    int64_t dst_offset; /* where its content goes in dst (and its literals in scratch) */
+    int64_t dst_bytes;  /* the content size it declares (at most 4 MB: 32 blocks) */
+} wsx_zstd_frame;
+int wsx_zstd_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const wsx_zstd_frame *frames, int64_t n_frames, uint8_t *dst,
+                    int64_t dst_bytes, uint8_t *scratch, int32_t *status);
 
 int wsx_caller_synchronize(wsx_caller *c);
 

@@ -31,7 +31,7 @@ def test_exports_match_header(lib):
     assert declared and sorted(_lib.EXPORTS) == declared
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.wsx_abi_version() == 13
+    assert lib.wsx_abi_version() == 14
 
 
 def test_struct_layouts():

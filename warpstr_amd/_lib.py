@@ -18,7 +18,7 @@ READ_STATUS = {0: 'ok', 1: 'shape', 2: 'backtrack', 3: 'fit_points', 4: 'fit_ord
 EXPORTS = ['wsx_abi_version', 'wsx_device_count', 'wsx_last_error', 'wsx_caller_create', 'wsx_caller_destroy', 'wsx_caller_add_automata',
            'wsx_caller_set_workspace_limit', 'wsx_caller_get_workspace_limit', 'wsx_caller_set_tuning', 'wsx_caller_create_times', 'wsx_caller_set_streams', 'wsx_call_batch', 'wsx_call_batch_reads', 'wsx_warp_batch', 'wsx_prepare_signals',
            'wsx_caller_synchronize', 'wsx_caller_set_pipelined', 'wsx_caller_join', 'wsx_caller_timing_window',
-           'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw', 'wsx_vbz_decode']
+           'wsx_caller_last_timing', 'wsx_caller_workspace', 'wsx_caller_fill_intervals', 'wsx_caller_kernel_name', 'wsx_locate_flanks', 'wsx_moves_to_raw', 'wsx_vbz_decode', 'wsx_zstd_decode']
 
 
 # wsx_caller_set_tuning knobs (include/warpstr_hip.h: WSX_TUNE_*)
@@ -54,6 +54,9 @@ VBZ_BLOCK_DTYPE = np.dtype([('src_offset', np.int64), ('src_bytes', np.int64), (
                             ('kind', np.int32), ('n_values', np.int32), ('reserved', np.int32)])
 assert VBZ_BLOCK_DTYPE.itemsize == 40
 VBZ_PLAIN, VBZ_SVB_ZIGZAG, VBZ_SVB = 0, 1, 2
+# numpy view of wsx_zstd_frame (wsx_zstd_decode)
+ZSTD_FRAME_DTYPE = np.dtype([('src_offset', np.int64), ('src_bytes', np.int64), ('dst_offset', np.int64), ('dst_bytes', np.int64)])
+assert ZSTD_FRAME_DTYPE.itemsize == 32
 
 
 class WsxAlignScores(C.Structure):
@@ -130,6 +133,7 @@ def load():
     lib.wsx_caller_kernel_name.argtypes = [C.c_void_p, C.c_int32]
     lib.wsx_caller_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.wsx_caller_destroy.argtypes = [C.c_void_p]
+    lib.wsx_zstd_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.wsx_caller_add_automata.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.wsx_caller_destroy.restype = None
     lib.wsx_caller_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]

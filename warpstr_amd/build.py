@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['wsx_api.hip', 'dtw_kernels.hip', 'mid_kernels.hip', 'wsx_prep.hip', 'wsx_vbz.hip', 'flank_kernels.hip']
+SOURCES = ['wsx_api.hip', 'dtw_kernels.hip', 'mid_kernels.hip', 'wsx_prep.hip', 'wsx_vbz.hip', 'wsx_zstd.hip', 'flank_kernels.hip']
 HEADERS = ['wsx_device.h', 'wsx_place.h', os.path.join('..', '..', 'include', 'warpstr_hip.h')]
 LIB = os.path.join(HERE, 'libwarpstr_hip.so')
 SEAM_SRC = os.path.join(CSRC, 'seam_helper.c')  # CPython-API loops of the Python seam (no compute); optional at run time

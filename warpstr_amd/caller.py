@@ -466,6 +466,15 @@ class HipCaller:
         _lib.check(self.lib.wsx_vbz_decode(self.handle, C.c_void_p(src_ptr), int(src_bytes), _lib.ptr(blocks), len(blocks),
                                            C.c_void_p(dst_ptr), int(dst_samples), C.c_void_p(status_ptr or None)), 'wsx_vbz_decode')
 
+    def zstd_decode_device(self, src_ptr: int, src_bytes: int, frames: np.ndarray, dst_ptr: int, dst_bytes: int, scratch_ptr: int,
+                           status_ptr: int = 0):
+        """wsx_zstd_decode: zstd frames in HBM (the bodies of VBZ chunks as they lie in the file) -> their content in HBM, where
+        `frames` (_lib.ZSTD_FRAME_DTYPE) says; scratch: as large as dst.  Asynchronous, on the handle's stream: a
+        vbz_decode_device that follows reads the content in stream order."""
+        frames = np.ascontiguousarray(frames, _lib.ZSTD_FRAME_DTYPE)
+        _lib.check(self.lib.wsx_zstd_decode(self.handle, C.c_void_p(src_ptr), int(src_bytes), _lib.ptr(frames), len(frames), C.c_void_p(dst_ptr),
+                                            int(dst_bytes), C.c_void_p(scratch_ptr), C.c_void_p(status_ptr or None)), 'wsx_zstd_decode')
+
     def call_device(self, signal_ptr: int, offsets: np.ndarray, automaton_id: np.ndarray, results_ptr: int,
                     trace1_ptr: int = 0, trace2_ptr: int = 0, seq1_ptr: int = 0, seq2_ptr: int = 0):
         """wsx_call_batch on device buffers; asynchronous (see set_pipelined / join / synchronize)."""

@@ -325,7 +325,7 @@ struct wsx_caller {
         size_t host_cap = 0;
         DeviceBuf dev;
         hipEvent_t ev = nullptr;
-    } vbz_ring[3];
+    } vbz_ring[8];   // (two calls a batch -- wsx_zstd_decode, wsx_vbz_decode --, three batches in flight)
     unsigned vbz_turn = 0;
     void *pinned_res = nullptr; // host-buffer calls: the batch's result records land here first
     size_t pinned_res_cap = 0;
@@ -1098,7 +1098,7 @@ hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEv
 // the next slot of the ring wsx_vbz_decode stages its block tables in (csrc/wsx_vbz.hip)
 hipError_t wsx_internal_vbz_slot(wsx_caller *c, size_t bytes, void **host, void **dev, hipEvent_t *last_use)
 {
-    auto &v = c->vbz_ring[c->vbz_turn++ % 3];
+    auto &v = c->vbz_ring[c->vbz_turn++ % 8];
     hipError_t e = hipSuccess;
     if (!v.ev && (e = hipEventCreateWithFlags(&v.ev, hipEventDisableTiming)) != hipSuccess) return e;
     if (bytes > v.host_cap) {
