@@ -268,6 +268,7 @@ struct wsx_caller {
     std::vector<Variant> uvar; // the distinct kernel variants among `variant` (each has a back-pointer region of its own)
     WsxTuning tun;             // launch-policy knobs (wsx_caller_set_tuning)
     double create_s[5] = {0, 0, 0, 0, 0}; // wsx_caller_create_times
+    DeviceBuf zstd_status;              // wsx_zstd_decode: see wsx_internal_zstd_status
     DeviceBuf aut_blob, aut_table;      // the most recent blob / the table of all automata so far
     std::vector<DeviceBuf> aut_retired; // blobs of earlier wsx_caller_add_automata calls (referenced by the table for good) and tables
                                         // that calls still in flight may read: released with the handle
@@ -941,7 +942,7 @@ void wsx_caller_destroy(wsx_caller *c)
         if (v.ev) (void)hipEventDestroy(v.ev);
         v.dev.release();
     }
-    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table}) b->release();
+    for (DeviceBuf *b : {&c->aut_blob, &c->aut_table, &c->zstd_status}) b->release();
     for (auto &b : c->aut_retired) b.release();
     for (auto &b : c->meta) b.release();
     for (auto &b : c->prep_pool) b.release();
@@ -1114,6 +1115,18 @@ hipError_t wsx_internal_vbz_slot(wsx_caller *c, size_t bytes, void **host, void 
     *dev = v.dev.p;
     *last_use = v.ev;
     return hipSuccess;
+}
+// wsx_zstd_decode's own status array (a caller that passes none still needs one between its two kernels): grown when needed -- after
+// the stream has drained: an earlier call's kernels may still use it --, freed with the handle
+hipError_t wsx_internal_zstd_status(wsx_caller *c, size_t bytes, void **p)
+{
+    if (bytes > c->zstd_status.cap) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = c->zstd_status.ensure(bytes);
+    *p = c->zstd_status.p;
+    return e;
 }
 // buffer `slot` of the signal loader's pool, at least `bytes` large (grown when needed, freed with the handle)
 hipError_t wsx_internal_prep_buffer(wsx_caller *c, int slot, size_t bytes, void **p)

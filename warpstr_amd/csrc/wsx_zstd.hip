@@ -30,23 +30,27 @@ hipStream_t wsx_internal_stream(wsx_caller *c);
 void wsx_internal_set_error(const char *msg);
 extern "C" int wsx_internal_on_exception(void);
 hipError_t wsx_internal_vbz_slot(wsx_caller *c, size_t bytes, void **host, void **dev, hipEvent_t *last_use);
+hipError_t wsx_internal_zstd_status(wsx_caller *c, size_t bytes, void **p);
 
 namespace {
 
-constexpr int ZW = 4;             // wavefronts of a workgroup = blocks of a frame whose literals are decoded side by side
+constexpr int ZB = 4;             // literal workgroups (one wavefront each) per frame: its blocks b, b + 4, ... are the b-th's
 constexpr int Z_MAX_BLOCKS = 32;  // blocks per frame (4 MB of content)
 constexpr int HUF_MAX_BITS = 11;
 constexpr int SEQ_CHUNK = 256;    // sequences decoded (lane 0) before the wave executes them
 
 enum { Z_OK = 0, Z_UNSUPPORTED = 1, Z_CORRUPT = 2 };
 
-struct FseTable {   // an FSE decoding table of up to 512 cells
-    uint8_t symbol[512];
-    uint8_t nbits[512];
-    uint16_t base[512];
+template <int N>
+struct FseTableT {   // an FSE decoding table of up to N cells
+    uint8_t symbol[N];
+    uint8_t nbits[N];
+    uint16_t base[N];
     int al;
     int valid;
 };
+typedef FseTableT<512> FseTable;      // the sequences' tables (accuracy <= 9)
+typedef FseTableT<64> FseTableW;      // the table of a Huffman tree's weights (accuracy <= 6)
 
 struct BlockRec {
     int type, src, size;   // block type, first byte behind its header (relative to the frame), Block_Size
@@ -99,9 +103,10 @@ __device__ uint64_t back_bits(const uint8_t *src, int n, int &off)
 }
 
 // 4.1.1 / educational decoder: cells from normalised counts (lane 0; `next` = 256 uint16 of scratch)
-__device__ int fse_build(FseTable &t, const int16_t *freq, int nsym, int al, uint16_t *next)
+template <int N>
+__device__ int fse_build(FseTableT<N> &t, const int16_t *freq, int nsym, int al, uint16_t *next)
 {
-    if (al > 9 || nsym > 256) return Z_CORRUPT;
+    if ((1 << al) > N || nsym > 256) return Z_CORRUPT;
     const int size = 1 << al;
     int high = size;
     t.al = al;
@@ -133,7 +138,8 @@ __device__ int fse_build(FseTable &t, const int16_t *freq, int nsym, int al, uin
 }
 
 // the table description; *took = its bytes.  freq: 256 int16 of scratch
-__device__ int fse_read(FseTable &t, const uint8_t *src, int len, int max_al, int max_sym, int16_t *freq, uint16_t *next, int *took)
+template <int N>
+__device__ int fse_read(FseTableT<N> &t, const uint8_t *src, int len, int max_al, int max_sym, int16_t *freq, uint16_t *next, int *took)
 {
     Fwd in{src, len, 0, false};
     const int al = 5 + (int)fwd_bits(in, 4);
@@ -179,153 +185,251 @@ __constant__ uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 __constant__ uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                     0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
-// the four bytes below `p` of a backward stream as a little-endian word -- bytes below `start` read as zero --, from the aligned
-// word that holds p - 4 (`lo`) and the one above it (`hi`, the previous call's `lo`): one aligned load per refill
-__device__ __forceinline__ uint32_t bytes_below(const uint8_t *p, const uint8_t *start, uint32_t lo, uint32_t hi)
+
+// n bytes from s to d (not overlapping), by the 64 lanes of a wave: 16 bytes a lane and step where the two are aligned alike (the
+// literals of a block without matches before it: the usual case), else a byte a lane.  Independent loads, four in flight per lane.
+__device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, long long n, int lane)
 {
-    uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)((uintptr_t)(p - 4) & 3));
-    const long long have = p - start;   // bytes of the stream below p
-    if (have < 4) v = have <= 0 ? 0u : v & (~0u << (8 * (4 - (int)have)));
-    return v;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    long long at = 0;
+    if ((((uintptr_t)d ^ (uintptr_t)s) & 15) == 0 && n >= 256) {
+        const long long head = (long long)((16 - ((uintptr_t)d & 15)) & 15);
+        if (lane < head) d[lane] = s[lane];
+        const long long nvec = (n - head) >> 4;
+        u32x4 *dv = (u32x4 *)(d + head);
+        const u32x4 *sv = (const u32x4 *)(s + head);
+        long long i = lane;
+        for (; i + 192 < nvec; i += 256) {
+            const u32x4 a = sv[i], b = sv[i + 64], c = sv[i + 128], e = sv[i + 192];
+            dv[i] = a, dv[i + 64] = b, dv[i + 128] = c, dv[i + 192] = e;
+        }
+        for (; i < nvec; i += 64) dv[i] = sv[i];
+        at = head + (nvec << 4);
+    }
+    long long k = at + lane;
+    for (; k + 192 < n; k += 256) {
+        const uint8_t a = s[k], b = s[k + 64], c = s[k + 128], e = s[k + 192];
+        d[k] = a, d[k + 64] = b, d[k + 128] = c, d[k + 192] = e;
+    }
+    for (; k < n; k += 64) d[k] = s[k];
 }
 
-// One Huffman stream (4.2.2): n_out symbols written to out.  table: (nbits << 8) | symbol per cell, max_bits wide.  `floor_`: no
-// byte below it is touched.  Returns Z_OK if the stream ends exactly where its last symbol does.
-__device__ int huf_stream(const uint16_t *table, int max_bits, const uint8_t *src, int len, uint8_t *out, int n_out, const uint8_t *floor_)
+// The frame's header and the walk over its block headers (one lane).  Fills blocks[0 .. *n_blocks); returns the frame's status.
+__device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *blocks, int *n_blocks)
 {
-    if (len < 1 || src[len - 1] == 0) return Z_CORRUPT;
-    const uint8_t *end = src + len;
-    // the container: bit 63 = the stream's last bit; `used` bits of it are consumed (the padding and its marker first)
+    int st = Z_OK, nb = 0, pos = 0;
+    if (flen < 5 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD) st = Z_CORRUPT;
+    else {
+        const int fhd = f[4], flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+        if (fhd & 8) st = Z_CORRUPT;
+        else if (did) st = Z_UNSUPPORTED;
+        pos = 5 + (single ? 0 : 1) + (flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8);
+    }
+    int lit_at = 0;
+    while (st == Z_OK) {
+        if (pos + 3 > flen) { st = Z_CORRUPT; break; }
+        const uint32_t bh = f[pos] | (f[pos + 1] << 8) | ((uint32_t)f[pos + 2] << 16);
+        pos += 3;
+        const int last = bh & 1, type = (bh >> 1) & 3, size = (int)(bh >> 3);
+        if (nb >= Z_MAX_BLOCKS) { st = Z_UNSUPPORTED; break; }
+        if (type == 3 || pos + (type == 1 ? 1 : size) > flen) { st = Z_CORRUPT; break; }
+        BlockRec &B = blocks[nb++];
+        B.type = type, B.src = pos, B.size = size, B.lit_at = lit_at, B.regen = 0, B.seq_at = 0;
+        if (type == 2) {   // the literals header says how many literals the block brings: their place in the literal area
+            if (size < 1) { st = Z_CORRUPT; break; }
+            const int b0 = f[pos], ltype = b0 & 3, sf = (b0 >> 2) & 3;
+            int regen, hl, comp;
+            if (ltype < 2) {
+                hl = (sf == 0 || sf == 2) ? 1 : sf == 1 ? 2 : 3;
+                if (size < hl) { st = Z_CORRUPT; break; }
+                regen = hl == 1 ? b0 >> 3 : hl == 2 ? (b0 >> 4) + (f[pos + 1] << 4) : (b0 >> 4) + (f[pos + 1] << 4) + (f[pos + 2] << 12);
+                comp = ltype == 0 ? regen : 1;
+            } else {
+                hl = sf < 2 ? 3 : sf + 2;
+                if (size < hl) { st = Z_CORRUPT; break; }
+                uint64_t v = 0;
+                for (int i = 0; i < hl; i++) v |= (uint64_t)f[pos + i] << (8 * i);
+                const int w = sf < 2 ? 10 : sf == 2 ? 14 : 18;
+                regen = (int)((v >> 4) & ((1u << w) - 1));
+                comp = (int)((v >> (4 + w)) & ((1u << w) - 1));
+                if (ltype == 3) { st = Z_UNSUPPORTED; break; }
+            }
+            if (hl + comp > size || regen > (1 << 17) || lit_at + regen > cap) { st = Z_CORRUPT; break; }
+            B.regen = regen;
+            B.seq_at = pos + hl + comp;
+            lit_at += regen;
+        }
+        pos += type == 1 ? 1 : size;
+        if (last) break;
+    }
+    *n_blocks = nb;
+    return st;
+}
+
+constexpr int Z_WIN = 256;     // bytes of a stream's compressed input a window holds; the ring of a stream is two windows
+constexpr int Z_OUT = 256;     // symbols a stream decodes between two flushes
+
+// A cell of the decoding table (one per max_bits-bit pattern): the symbol the pattern starts with -- and the next one where both
+// codes fit the pattern (nanopore value bytes average ~5 bits a symbol: two fit most of the time, and a symbol is a chain of
+// dependent look-ups, so two per look-up halves the chain).
+//   bits 0-7 first symbol, 8-15 second symbol, 16-19 bits both take (or the first alone), 20-23 bits of the first, 24-25 count
+__device__ __forceinline__ uint32_t cell2(uint32_t c1, uint32_t c2, int max_bits)
+{
+    const uint32_t l1 = c1 >> 8, l2 = c2 >> 8;
+    if (l1 + l2 <= (uint32_t)max_bits) return (c1 & 255u) | ((c2 & 255u) << 8) | ((l1 + l2) << 16) | (l1 << 20) | (2u << 24);
+    return (c1 & 255u) | (l1 << 16) | (l1 << 20) | (1u << 24);
+}
+
+// The (up to four) Huffman streams of a block side by side (lanes 0..3), with nothing but LDS inside the symbol loop: a global
+// load or store between two look-ups (and the s_waitcnt they share with everything else) costs more than the look-up.
+//   input : every stream has a ring of two 256-byte windows of its compressed bytes (windows are aligned on absolute addresses:
+//           the whole wave fetches the next window of all four streams with one 16-byte load per lane);
+//   output: 256 symbols per stream collect in LDS and leave together (lane = 16 bytes of a stream).
+// q[0..3] / q[4..7]: the streams' bytes [begin, end) as offsets from `base`, q[8..11] their symbol counts (0: no such stream);
+// base_lo / base_hi: the offsets from `base` that may be read at all.  dst: where stream 0's symbols go, stream s's at dst + s * per.
+// Returns Z_OK when every stream ends exactly where its last symbol does.  All 64 lanes call this.
+__device__ int huf_streams(const uint32_t *table, int max_bits, const uint8_t *base, long long base_lo, long long base_hi, const int *q, uint8_t *dst,
+                           int per, uint8_t *ring, uint8_t *obuf, int lane)
+{
+    const int s = lane & 3;                         // the stream a decoding lane works on (lanes 0..3)
+    const int fs = lane >> 4, fj = lane & 15;       // as a fetching / flushing lane: stream fs, its 16-byte piece fj
+    const uintptr_t ab = (uintptr_t)base;
+    const int lo_off = q[s], hi_off = q[4 + s], want = q[8 + s];
+    const bool dec = lane < 4 && want > 0;
+    const bool fetches = q[8 + fs] > 0;
+    int st = Z_OK;
+    if (dec && (hi_off - lo_off < 1 || base[hi_off - 1] == 0)) st = Z_CORRUPT;
     uint64_t cont = 0;
-    for (int i = 0; i < 8; i++) {
-        const uint8_t *q = end - 8 + i;
-        cont |= (uint64_t)(q >= src ? *q : 0) << (8 * i);
-    }
-    int used = 8 - hibit(src[len - 1]);
-    const uint8_t *p = end - 8;                       // the container's lowest byte
-    auto aligned_word = [&](const uint8_t *q) -> uint32_t {   // the aligned 4 bytes that hold q (never below floor_)
-        const uint8_t *a = (const uint8_t *)((uintptr_t)q & ~(uintptr_t)3);
-        if (a < floor_) {   // (the frame's first bytes: byte by byte)
-            uint32_t v = 0;
-            for (int i = 0; i < 4; i++)
-                if (a + i >= floor_) v |= (uint32_t)a[i] << (8 * i);
-            return v;
+    int used = 0, total = 0, done = 0;
+    long long p = (long long)hi_off - 8;            // offset of the container's lowest byte
+    if (dec && st == Z_OK) {
+        for (int i = 0; i < 8; i++) {
+            const long long a = p + i;
+            cont |= (uint64_t)(a >= lo_off ? base[a] : 0) << (8 * i);
         }
-        return *(const uint32_t *)a;
+        used = 8 - hibit(base[hi_off - 1]);
+        total = (hi_off - lo_off) * 8 - used;
+    }
+    // window w of a stream = absolute addresses [w * Z_WIN, (w + 1) * Z_WIN); ring index = address mod 2 Z_WIN
+    auto top_window = [&](int k) { return (long long)(((ab + (uintptr_t)q[4 + k] - 1) / Z_WIN) * Z_WIN); };
+    long long fetch_lo = top_window(fs) + Z_WIN;    // lowest absolute address the ring of MY fetch stream holds (nothing yet)
+    long long my_lo = top_window(s) + Z_WIN;        // the same for the stream this lane decodes
+    auto fetch = [&](bool go) {                     // the next lower window of stream fs (every lane takes part; go: the stream wants it)
+        if (go) {
+            const long long a = fetch_lo - Z_WIN + 16 * fj;             // absolute address of this lane's 16 bytes
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = {0, 0, 0, 0};
+            const long long rel = a - (long long)ab;
+            if (rel >= base_lo && rel + 16 <= base_hi) v = *(const u32x4 *)(uintptr_t)a;
+            else if (rel + 16 > base_lo && rel < base_hi) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int i = 0; i < 16; i++)
+                    if (rel + i >= base_lo && rel + i < base_hi) t[i >> 2] |= (uint32_t)base[rel + i] << (8 * (i & 3));
+                v = u32x4{t[0], t[1], t[2], t[3]};
+            }
+            *(u32x4 *)(ring + fs * 2 * Z_WIN + (int)(a & (2 * Z_WIN - 1))) = v;
+            fetch_lo -= Z_WIN;
+        }
     };
-    // words for the next refills, fetched ahead: hi holds the aligned word of p - 1 (or above), lo the one below it
-    uint32_t hi = aligned_word(p - 1 >= floor_ ? p - 1 : floor_), lo = aligned_word(p - 4 >= floor_ ? p - 4 : floor_);
-    if ((((uintptr_t)(p - 4)) & ~(uintptr_t)3) == (((uintptr_t)(p - 1)) & ~(uintptr_t)3)) hi = lo;   // p aligned: both in one word
-    int total = len * 8 - used;                       // bits the symbols may take
+    fetch(fetches);
+    fetch(fetches);
+    my_lo -= 2 * Z_WIN;
+    wave_sync();
     const int shift = 64 - max_bits;
-    uint32_t acc = 0;
-    int i = 0;
-    for (; i < n_out; i++) {
-        if (used >= 32) {   // refill: four more bytes from below
-            const uint32_t w = bytes_below(p, src, lo, hi);
-            cont = (cont << 32) | w;
-            used -= 32;
-            p -= 4;
-            hi = lo;
-            const uint8_t *nx = p - 4;
-            lo = nx >= floor_ ? aligned_word(nx) : 0u;
+    const uint8_t *myring = ring + s * 2 * Z_WIN;
+    uint8_t *myout = obuf + s * (Z_OUT + 2);
+    int flushed = 0;                                // symbols of MY fetch stream already in dst (every flushing lane of it keeps count)
+    // four more bytes from below into the container; false: the ring does not hold them yet
+    auto refill = [&]() -> bool {
+        const long long a = ((long long)ab + p - 4) & ~3ll;              // absolute address of the aligned word that holds p - 4
+        if (a < my_lo) return false;
+        const uint32_t wlo = *(const uint32_t *)(myring + (int)(a & (2 * Z_WIN - 1)));
+        const uint32_t whi = *(const uint32_t *)(myring + (int)((a + 4) & (2 * Z_WIN - 1)));
+        uint32_t w = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)(((long long)ab + p - 4) & 3));
+        const long long have = p - lo_off;          // bytes of the stream below p: what lies below the stream reads as zero
+        if (have < 4) w = have <= 0 ? 0u : w & (~0u << (8 * (4 - (int)have)));
+        cont = (cont << 32) | w;
+        used -= 32;
+        p -= 4;
+        return true;
+    };
+    for (;;) {
+        int cnt = 0;                                // symbols in the output buffer
+        bool need_input = false;
+        if (dec && st == Z_OK) {
+            // fast: after a refill `used` < 32 and a look-up takes at most 11 bits -- three look-ups (up to six symbols) need no check
+            while (done + 6 <= want && cnt + 6 <= Z_OUT) {
+                if (used >= 32 && !refill()) { need_input = true; break; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
+                    const int bits = (e >> 16) & 15, ns = (int)(e >> 24);
+                    *(uint16_t *)(myout + cnt) = (uint16_t)e;   // (both symbols; a single one's second byte is overwritten by the next)
+                    used += bits, total -= bits, cnt += ns, done += ns;
+                }
+            }
+            // the last few symbols of the stream (or of the buffer) one at a time
+            while (!need_input && done < want && cnt < Z_OUT && (done + 6 > want || cnt + 6 > Z_OUT)) {
+                if (used >= 32 && !refill()) { need_input = true; break; }
+                const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
+                const int bits = (e >> 20) & 15;
+                myout[cnt++] = (uint8_t)e;
+                used += bits, total -= bits, done++;
+            }
         }
-        const uint32_t cell = table[(uint32_t)((cont << used) >> shift)];
-        used += cell >> 8;
-        total -= (int)(cell >> 8);
-        acc |= (cell & 255u) << (8 * (i & 3));
-        if ((i & 3) == 3) {
-            // (the destination of a stream need not be aligned: byte stores)
-            out[i - 3] = (uint8_t)acc, out[i - 2] = (uint8_t)(acc >> 8), out[i - 1] = (uint8_t)(acc >> 16), out[i] = (uint8_t)(acc >> 24);
-            acc = 0;
+        wave_sync();
+        // ---- flush: lane (fs, fj) writes bytes 16 fj .. of stream fs's buffer; then fetch where a stream wants its next window ----
+        const int cnt_fs = __shfl(cnt, fs, 64), need_fs = __shfl((int)need_input, fs, 64);
+        {
+            uint8_t *d = dst + (long long)fs * per + flushed;
+            const uint8_t *o = obuf + fs * (Z_OUT + 2);
+            for (int k = 16 * fj; k < 16 * fj + 16 && k < cnt_fs; k++) d[k] = o[k];
+            flushed += cnt_fs;
         }
+        // a stream takes its next window as soon as the upper one is used up (a refill reads the aligned words around p - 4: up to p + 3)
+        const long long p_fs = ((long long)__shfl((int)(p >> 32), fs, 64) << 32) | (uint32_t)__shfl((int)p, fs, 64);
+        fetch(fetches && (need_fs || ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN));
+        if (dec && (need_input || ((long long)ab + p + 8) <= my_lo + Z_WIN)) my_lo -= Z_WIN;
+        wave_sync();
+        const int left = (dec && st == Z_OK) ? want - done : 0;
+        if (!__any(left > 0)) break;
     }
-    for (int k = i & ~3; k < n_out; k++) out[k] = (uint8_t)(acc >> (8 * (k & 3)));
-    return total == 0 ? Z_OK : Z_CORRUPT;
+    if (dec && st == Z_OK && total != 0) st = Z_CORRUPT;
+    return st;
 }
 
-__global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__restrict__ src, const wsx_zstd_frame *__restrict__ frames,
-                                                            uint8_t *__restrict__ dst, uint8_t *__restrict__ lits, int32_t *__restrict__ status)
+// ---- kernel 1: the literals of block b, b + ZB, ... of a frame (blockIdx = frame * ZB + b), one wavefront --------------------------
+__global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__restrict__ src, long long src_total, const wsx_zstd_frame *__restrict__ frames,
+                                                          uint8_t *__restrict__ lits, int32_t *__restrict__ status)
 {
     __shared__ BlockRec blocks[Z_MAX_BLOCKS];
     __shared__ int n_blocks, frame_status;
-    __shared__ int sh[8];                       // wave 0's sequences section: count, status, header bytes
-    __shared__ uint16_t huf[ZW][1 << HUF_MAX_BITS];
-    __shared__ uint8_t huf_w[ZW][256];          // weights, then code lengths
-    __shared__ int huf_info[ZW][8];             // per wave: max_bits, symbols, status, literals type, streams, stream sizes ...
-    __shared__ int huf_start[ZW][260];          // first cell of every symbol
-    __shared__ FseTable fse[3];                 // LL, OF, ML (they persist from block to block: "repeat" mode)
-    __shared__ FseTable fse_w[ZW];              // the weights' table of each wave
-    __shared__ int16_t freq_s[ZW][256];
-    __shared__ uint16_t next_s[ZW][256];
-    __shared__ uint32_t seq_ll[SEQ_CHUNK], seq_ml[SEQ_CHUNK], seq_of[SEQ_CHUNK];
+    __shared__ uint32_t huf2[1 << HUF_MAX_BITS];                       // the two-symbol table
+    // the one-symbol table it is made from; once it is made the same bytes are the streams' input rings and output buffers
+    __shared__ __attribute__((aligned(16))) uint8_t work[(2 << HUF_MAX_BITS)];
+    static_assert(4 * 2 * Z_WIN + 4 * (Z_OUT + 2) <= (2 << HUF_MAX_BITS), "rings + output buffers fit the one-symbol table's place");
+    __shared__ uint8_t huf_w[256];              // weights, then code lengths
+    __shared__ uint16_t huf_start[256];         // first cell of every symbol
+    __shared__ FseTableW fse_w;
+    __shared__ int16_t freq_s[256];
+    __shared__ uint16_t next_s[256];
+    __shared__ int info[4], strm[12];
 
-    const wsx_zstd_frame F = frames[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frame = blockIdx.x / ZB, slot = blockIdx.x % ZB, lane = threadIdx.x;
+    const wsx_zstd_frame F = frames[frame];
     const uint8_t *f = src + F.src_offset;
     const int flen = (int)F.src_bytes;
-    uint8_t *out = dst + F.dst_offset;
     uint8_t *lit = lits + F.dst_offset;
-    const long long cap = F.dst_bytes;
-
-    // ---- frame header and the walk over the block headers (one lane) ---------------------------------------------------------
-    if (tid == 0) {
-        int st = Z_OK, nb = 0, pos = 0;
-        if (flen < 5 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD) st = Z_CORRUPT;
-        else {
-            const int fhd = f[4], flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
-            if (fhd & 8) st = Z_CORRUPT;
-            else if (did) st = Z_UNSUPPORTED;
-            pos = 5 + (single ? 0 : 1) + (flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8);
-        }
-        int lit_at = 0;
-        while (st == Z_OK) {
-            if (pos + 3 > flen) { st = Z_CORRUPT; break; }
-            const uint32_t bh = f[pos] | (f[pos + 1] << 8) | ((uint32_t)f[pos + 2] << 16);
-            pos += 3;
-            const int last = bh & 1, type = (bh >> 1) & 3, size = (int)(bh >> 3);
-            if (nb >= Z_MAX_BLOCKS) { st = Z_UNSUPPORTED; break; }
-            if (type == 3 || pos + (type == 1 ? 1 : size) > flen) { st = Z_CORRUPT; break; }
-            BlockRec &B = blocks[nb++];
-            B.type = type, B.src = pos, B.size = size, B.lit_at = lit_at, B.regen = 0, B.seq_at = 0;
-            if (type == 2) {   // the literals header says how many literals the block brings: their place in the literal area
-                if (size < 1) { st = Z_CORRUPT; break; }
-                const int b0 = f[pos], ltype = b0 & 3, sf = (b0 >> 2) & 3;
-                int regen, hl, comp;
-                if (ltype < 2) {
-                    hl = (sf == 0 || sf == 2) ? 1 : sf == 1 ? 2 : 3;
-                    if (size < hl) { st = Z_CORRUPT; break; }
-                    regen = hl == 1 ? b0 >> 3 : hl == 2 ? (b0 >> 4) + (f[pos + 1] << 4) : (b0 >> 4) + (f[pos + 1] << 4) + (f[pos + 2] << 12);
-                    comp = ltype == 0 ? regen : 1;
-                } else {
-                    hl = sf < 2 ? 3 : sf + 2;
-                    if (size < hl) { st = Z_CORRUPT; break; }
-                    uint64_t v = 0;
-                    for (int i = 0; i < hl; i++) v |= (uint64_t)f[pos + i] << (8 * i);
-                    const int w = sf < 2 ? 10 : sf == 2 ? 14 : 18;
-                    regen = (int)((v >> 4) & ((1u << w) - 1));
-                    comp = (int)((v >> (4 + w)) & ((1u << w) - 1));
-                    if (ltype == 3) { st = Z_UNSUPPORTED; break; }
-                }
-                if (hl + comp > size || regen > (1 << 17) || lit_at + regen > cap) { st = Z_CORRUPT; break; }
-                B.regen = regen;
-                B.seq_at = pos + hl + comp;
-                lit_at += regen;
-            }
-            pos += type == 1 ? 1 : size;
-            if (last) break;
-        }
+    if (lane == 0) {
+        int nb = 0;
+        frame_status = walk_blocks(f, flen, F.dst_bytes, blocks, &nb);
         n_blocks = nb;
-        frame_status = st;
     }
-    __syncthreads();
-    if (frame_status != Z_OK) {
-        if (tid == 0 && status) status[blockIdx.x] = frame_status;
+    wave_sync();
+    if (frame_status != Z_OK) {   // (kernel 2 walks the headers again and reports it)
         return;
     }
-
-    // ---- the literals of every compressed block, a wave per block -------------------------------------------------------------
-    for (int b = wave; b < n_blocks; b += ZW) {
+    for (int b = slot; b < n_blocks; b += ZB) {
         const BlockRec B = blocks[b];
         if (B.type != 2) continue;
         const uint8_t *p = f + B.src;
@@ -334,7 +438,7 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
         const int regen = B.regen, comp = B.seq_at - B.src - hl;
         uint8_t *L = lit + B.lit_at;
         if (ltype == 0) {
-            for (int i = lane; i < regen; i += 64) L[i] = p[hl + i];
+            wave_copy(L, p + hl, regen, lane);
             continue;
         }
         if (ltype == 1) {
@@ -344,8 +448,7 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
         }
         const int streams = sf == 0 ? 1 : 4;
         const uint8_t *lp = p + hl;
-        int *info = huf_info[wave];
-        uint8_t *w = huf_w[wave];
+        uint8_t *w = huf_w;
         if (lane == 0) {   // the tree description: weights
             int st = Z_OK, n = 0, took = 0;
             const int hb = comp >= 1 ? lp[0] : 0;
@@ -360,9 +463,9 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
             } else {
                 int h = 0;
                 if (hb == 0 || 1 + hb > comp) st = Z_CORRUPT;
-                else st = fse_read(fse_w[wave], lp + 1, hb, 6, 255, freq_s[wave], next_s[wave], &h);
+                else st = fse_read(fse_w, lp + 1, hb, 6, 255, freq_s, next_s, &h);
                 if (st == Z_OK) {
-                    const FseTable &ft = fse_w[wave];
+                    const FseTableW &ft = fse_w;
                     const uint8_t *bs = lp + 1 + h;
                     const int bl = hb - h;
                     if (bl < 1 || bs[bl - 1] == 0) st = Z_CORRUPT;
@@ -409,7 +512,7 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
                         if (idx[0] != (1u << max_bits)) st = Z_CORRUPT;
                         else
                             for (int s = 0; s < n; s++) {
-                                huf_start[wave][s] = w[s] ? (int)idx[w[s]] : 0;
+                                huf_start[s] = w[s] ? (uint16_t)idx[w[s]] : 0;
                                 if (w[s]) idx[w[s]] += 1u << (max_bits - w[s]);
                             }
                     }
@@ -419,58 +522,95 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
         }
         wave_sync();
         if (info[2] != Z_OK) {
-            if (lane == 0) atomicMax(&frame_status, info[2]);
+            if (lane == 0 && status) atomicMax(&status[frame], info[2]);
             continue;
         }
         const int max_bits = info[0], nsym = info[1], took = info[3];
-        for (int s = 0; s < nsym; s++) {   // the table: symbol s fills 2^(max_bits - length) cells
+        uint16_t *huf1 = (uint16_t *)work;
+        for (int s = 0; s < nsym; s++) {   // the one-symbol table: symbol s fills 2^(max_bits - length) cells
             const int len_bits = w[s];
             if (!len_bits) continue;
-            const int cells = 1 << (max_bits - len_bits), c0 = huf_start[wave][s];
+            const int cells = 1 << (max_bits - len_bits), c0 = huf_start[s];
             const uint16_t cell = (uint16_t)((len_bits << 8) | s);
-            for (int i = lane; i < cells; i += 64) huf[wave][c0 + i] = cell;
+            for (int i = lane; i < cells; i += 64) huf1[c0 + i] = cell;
+        }
+        wave_sync();
+        for (int i = lane; i < (1 << max_bits); i += 64) {   // ... and the two-symbol table from it: the cell of what follows the first code
+            const uint32_t c1 = huf1[i];
+            huf2[i] = cell2(c1, huf1[(i << (c1 >> 8)) & ((1 << max_bits) - 1)], max_bits);
         }
         wave_sync();
         const uint8_t *sp = lp + took;
         const int sl = comp - took;
         int st = Z_OK;
-        if (streams == 1) {
-            if (lane == 0) st = huf_stream(huf[wave], max_bits, sp, sl, L, regen, f);
-        } else if (sl < 6) {
-            st = Z_CORRUPT;
-        } else if (lane < 4) {
-            const int s1 = sp[0] | (sp[1] << 8), s2 = sp[2] | (sp[3] << 8), s3 = sp[4] | (sp[5] << 8), s4 = sl - 6 - s1 - s2 - s3;
-            const int per = (regen + 3) / 4, lastn = regen - 3 * per;
-            if (s4 < 1 || lastn < 0) st = Z_CORRUPT;
-            else {
-                const int at = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
-                const int sz = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : s4;
-                st = huf_stream(huf[wave], max_bits, sp + 6 + at, sz, L + lane * per, lane < 3 ? per : lastn, f);
+        if (lane == 0) {
+            const int first = (int)(sp - f);
+            if (streams == 1) {
+                if (sl < 1) st = Z_CORRUPT;
+                strm[0] = first, strm[4] = first + sl, strm[8] = regen;
+                for (int k = 1; k < 4; k++) strm[k] = strm[4 + k] = first, strm[8 + k] = 0;
+                info[1] = regen;   // (the stride between the streams' outputs: irrelevant for one stream)
+            } else {
+                const int s1 = sl >= 6 ? sp[0] | (sp[1] << 8) : 0, s2 = sl >= 6 ? sp[2] | (sp[3] << 8) : 0, s3 = sl >= 6 ? sp[4] | (sp[5] << 8) : 0;
+                const int s4 = sl - 6 - s1 - s2 - s3, per = (regen + 3) / 4, lastn = regen - 3 * per;
+                if (sl < 6 || s4 < 1 || s1 < 1 || s2 < 1 || s3 < 1 || lastn < 1) st = Z_CORRUPT;
+                strm[0] = first + 6, strm[1] = strm[0] + s1, strm[2] = strm[1] + s2, strm[3] = strm[2] + s3;
+                strm[4] = strm[1], strm[5] = strm[2], strm[6] = strm[3], strm[7] = strm[3] + s4;
+                strm[8] = strm[9] = strm[10] = per, strm[11] = lastn;
+                info[1] = per;
             }
+            info[2] = st;
         }
-        if (st != Z_OK) atomicMax(&frame_status, st);
+        wave_sync();
+        st = info[2];
+        // (what may be read: the whole source buffer -- a window is 256 aligned bytes and may reach into the frames beside this one)
+        if (st == Z_OK)
+            st = huf_streams(huf2, max_bits, f, -(long long)F.src_offset, src_total - F.src_offset, strm, L, info[1], work, work + 4 * 2 * Z_WIN, lane);
+        if (st != Z_OK && status) atomicMax(&status[frame], st);
         wave_sync();
     }
-    __threadfence_block();
-    __syncthreads();
-    if (frame_status != Z_OK || wave != 0) {
-        if (tid == 0 && status) status[blockIdx.x] = frame_status;
-        return;
-    }
+}
 
-    // ---- wave 0: the blocks in order -- raw, RLE, or sequences executed over the literals --------------------------------------
+// ---- kernel 2: a wavefront per frame walks its blocks in order -- raw, RLE, or sequences executed over the literals ---------------
+__global__ __launch_bounds__(64) void zstd_sequences_kernel(const uint8_t *__restrict__ src, const wsx_zstd_frame *__restrict__ frames, uint8_t *__restrict__ dst,
+                                                           const uint8_t *__restrict__ lits, int32_t *__restrict__ status)
+{
+    __shared__ BlockRec blocks[Z_MAX_BLOCKS];
+    __shared__ int n_blocks, frame_status;
+    __shared__ int sh[8];                       // the sequences section: count, status, header bytes
+    __shared__ FseTable fse[3];                 // LL, OF, ML (they persist from block to block: "repeat" mode)
+    __shared__ int16_t freq_s[256];
+    __shared__ uint16_t next_s[256];
+    __shared__ uint32_t seq_ll[SEQ_CHUNK], seq_ml[SEQ_CHUNK], seq_of[SEQ_CHUNK];
+
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const wsx_zstd_frame F = frames[frame];
+    const uint8_t *f = src + F.src_offset;
+    uint8_t *out = dst + F.dst_offset;
+    const uint8_t *lit = lits + F.dst_offset;
+    const long long cap = F.dst_bytes;
+    if (lane == 0) {
+        int nb = 0;
+        int st = walk_blocks(f, (int)F.src_bytes, cap, blocks, &nb);
+        if (st == Z_OK && status && status[frame] != 0) st = status[frame];   // (a literal stream of the frame was found corrupt)
+        n_blocks = nb;
+        frame_status = st;
+        fse[0].valid = fse[1].valid = fse[2].valid = 0;
+    }
+    wave_sync();
+    int st = frame_status;
     long long o = 0;               // bytes written
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
-    int st = Z_OK;
-    if (lane == 0) fse[0].valid = fse[1].valid = fse[2].valid = 0;
-    wave_sync();
     for (int b = 0; b < n_blocks && st == Z_OK; b++) {
         const BlockRec B = blocks[b];
         if (B.type == 0 || B.type == 1) {
             if (o + B.size > cap) { st = Z_CORRUPT; break; }
             const uint8_t *p = f + B.src;
-            for (int i = lane; i < B.size; i += 64) out[o + i] = B.type == 0 ? p[i] : p[0];
+            if (B.type == 0) wave_copy(out + o, p, B.size, lane);
+            else
+                for (int i = lane; i < B.size; i += 64) out[o + i] = p[0];
             o += B.size;
+            __threadfence_block();
             continue;
         }
         const uint8_t *L = lit + B.lit_at;
@@ -494,8 +634,8 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
                         const int16_t *def = k == 0 ? LL_DEFAULT : k == 1 ? OF_DEFAULT : ML_DEFAULT;
                         const int ndef = k == 0 ? 36 : k == 1 ? 29 : 53, def_al = k == 1 ? 5 : 6, max_al = k == 1 ? 8 : 9, max_sym = k == 0 ? 35 : k == 1 ? 31 : 52;
                         if (mode == 0) {
-                            for (int i = 0; i < ndef; i++) freq_s[0][i] = def[i];
-                            s2 = fse_build(fse[k], freq_s[0], ndef, def_al, next_s[0]);
+                            for (int i = 0; i < ndef; i++) freq_s[i] = def[i];
+                            s2 = fse_build(fse[k], freq_s, ndef, def_al, next_s);
                         } else if (mode == 1) {
                             if (ql < used + 1 || sq[used] > max_sym) s2 = Z_CORRUPT;
                             else {
@@ -504,7 +644,7 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
                             }
                         } else if (mode == 2) {
                             int h = 0;
-                            s2 = fse_read(fse[k], sq + used, ql - used, max_al, max_sym, freq_s[0], next_s[0], &h);
+                            s2 = fse_read(fse[k], sq + used, ql - used, max_al, max_sym, freq_s, next_s, &h);
                             used += h;
                         } else if (!fse[k].valid) s2 = Z_CORRUPT;   // repeat: the previous block's table
                     }
@@ -520,8 +660,7 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
         if (nseq > 0) {
             const uint8_t *bs = sq + sh[2];
             const int bl = ql - sh[2];
-            // lane 0's decoder state lives in its registers across the chunks
-            int off = 0;
+            int off = 0;                       // (lane 0's decoder state lives in its registers across the chunks)
             uint32_t sl_ = 0, so = 0, sm = 0;
             if (lane == 0) {
                 if (bl < 1 || bs[bl - 1] == 0) sh[1] = Z_CORRUPT;
@@ -542,13 +681,13 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
                         const uint64_t ov = (1ull << oc) + back_bits(bs, oc, off);
                         const uint32_t mlen = ML_BASE[mc] + (uint32_t)back_bits(bs, ML_BITS[mc], off);
                         const uint32_t llen = LL_BASE[lc] + (uint32_t)back_bits(bs, LL_BITS[lc], off);
-                        if (c0 + i + 1 < nseq) {
+                        if (c0 + i + 1 < nseq) {   // the states move on in the order literal length, match length, offset
                             sl_ = fse[0].base[sl_] + (uint32_t)back_bits(bs, fse[0].nbits[sl_], off);
                             sm = fse[2].base[sm] + (uint32_t)back_bits(bs, fse[2].nbits[sm], off);
                             so = fse[1].base[so] + (uint32_t)back_bits(bs, fse[1].nbits[so], off);
                         }
                         if (off < 0) { s2 = Z_CORRUPT; break; }
-                        uint64_t offset;
+                        uint64_t offset;   // 3.1.1.5: repeat offsets
                         if (ov > 3) {
                             offset = ov - 3;
                             rep2 = rep1, rep1 = rep0, rep0 = (uint32_t)offset;
@@ -573,13 +712,13 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
                 for (int i = 0; i < cn; i++) {
                     const uint32_t llen = seq_ll[i], mlen = seq_ml[i], offset = seq_of[i];
                     if (lit_at + (long long)llen > B.regen || o + llen + mlen > cap || offset > o + llen) { st = Z_CORRUPT; break; }
-                    for (uint32_t k = lane; k < llen; k += 64) out[o + k] = L[lit_at + k];
+                    wave_copy(out + o, L + lit_at, llen, lane);
                     o += llen;
                     lit_at += llen;
                     __threadfence_block();   // the match may read what this wave has just written
                     const uint8_t *m = out + o - offset;
                     if (offset >= mlen) {
-                        for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = m[k];
+                        wave_copy(out + o, m, mlen, lane);
                     } else {   // the match overlaps its own output: a pattern of `offset` bytes repeated
                         for (uint32_t k = lane; k < mlen; k += 64) out[o + k] = m[k % offset];
                     }
@@ -592,12 +731,12 @@ __global__ __launch_bounds__(64 * ZW) void zstd_decode_kernel(const uint8_t *__r
         }
         const int rest = B.regen - lit_at;
         if (o + rest > cap) { st = Z_CORRUPT; break; }
-        for (int k = lane; k < rest; k += 64) out[o + k] = L[lit_at + k];
+        wave_copy(out + o, L + lit_at, rest, lane);
         o += rest;
         __threadfence_block();
     }
     if (st == Z_OK && o != cap) st = Z_CORRUPT;   // the frame must bring exactly the content its header declares
-    if (lane == 0 && status) status[blockIdx.x] = st;
+    if (lane == 0 && status) status[frame] = st;
 }
 
 #define ZCHK(call)                                                                                                     \
@@ -620,8 +759,8 @@ try {
         wsx_internal_set_error("wsx_zstd_decode: null or negative argument");
         return WSX_ERR_INVALID;
     }
-    if (n_frames > 0x7fffffff) {
-        wsx_internal_set_error("wsx_zstd_decode: more than 2^31 - 1 frames in one call");
+    if (n_frames > 0x7fffffff / ZB) {
+        wsx_internal_set_error("wsx_zstd_decode: too many frames in one call");
         return WSX_ERR_INVALID;
     }
     for (int64_t i = 0; i < n_frames; i++) {
@@ -647,8 +786,17 @@ try {
     memcpy(h, frames, bytes);
     ZCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
     ZCHK(hipEventRecord(ev, st));
-    if (status) ZCHK(hipMemsetAsync(status, 0, (size_t)n_frames * sizeof(int32_t), st));
-    hipLaunchKernelGGL(zstd_decode_kernel, dim3((unsigned)n_frames), dim3(64 * ZW), 0, st, src, (const wsx_zstd_frame *)d, dst, scratch, status);
+    // the status array is the literal kernel's way to tell the sequence kernel of a corrupt stream: it exists in any case
+    int32_t *st_dev = status;
+    if (!st_dev) {
+        void *p = nullptr;
+        ZCHK(wsx_internal_zstd_status(c, (size_t)n_frames * sizeof(int32_t), &p));
+        st_dev = (int32_t *)p;
+    }
+    ZCHK(hipMemsetAsync(st_dev, 0, (size_t)n_frames * sizeof(int32_t), st));
+    hipLaunchKernelGGL(zstd_literals_kernel, dim3((unsigned)(n_frames * ZB)), dim3(64), 0, st, src, (long long)src_bytes, (const wsx_zstd_frame *)d, scratch, st_dev);
+    ZCHK(hipGetLastError());
+    hipLaunchKernelGGL(zstd_sequences_kernel, dim3((unsigned)n_frames), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, dst, (const uint8_t *)scratch, st_dev);
     ZCHK(hipGetLastError());
     return WSX_SUCCESS;
 } catch (...) {
