@@ -276,7 +276,7 @@ def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
             n, blocks = c.blocks_to(rid, place)
             assert n == len(sig) and len(blocks) == -(-len(sig) // 4096) and sum(b[2] for b in blocks) == n
             pieces = []
-            for (kind, nbytes, ns, nv), off in zip(blocks, offs):
+            for (kind, nbytes, ns, nv, _content), off in zip(blocks, offs):
                 blk = room[off:off + nbytes]
                 assert nv >= ns and (kind == _h5core.PLAIN) == (len(pieces) == 1 and len(blocks) > 1)
                 pieces.append(blk.view(np.int16)[:ns] if kind == _h5core.PLAIN else vbz.decode_block(blk, nv, kind == _h5core.SVB_ZIGZAG)[:ns])
@@ -293,12 +293,12 @@ def test_vbz_datasets_of_several_chunks(tmp_path, zigzag, level):
     items = [(str(tmp_path / 'absent'), path, rid) for rid in reads]
     arena, cap, base, used, lens, table, _ = _readers.pack_arena(('test_vbz_chunks', 1, items))
     try:
-        t = np.frombuffer(table, np.int64).reshape(-1, 6)
+        t = np.frombuffer(table, np.int64).reshape(-1, 7)
         assert lens == [len(reads[r]) for r in reads]
         assert len(t) == (sum(-(-len(s) // 4096) for s in reads.values()) if fast5._vbz_native() is not None else len(reads))
         view = np.memmap(arena, dtype=np.uint8, mode='r')
         got = {r: [] for r in range(len(reads))}
-        for r, kind, off, nbytes, ns, nv in t:
+        for r, kind, off, nbytes, ns, nv, _content in t:
             blk = np.array(view[off:off + nbytes])
             got[int(r)].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(nv), kind == 1)[:ns])
         for r, rid in enumerate(reads):
@@ -349,8 +349,8 @@ def test_native_reader_loop_equals_the_ctypes_reader(tmp_path):
             assert a[2:6] == b[2:6]                      # first byte, bytes used, lengths, block table
         assert n2[2] == n1[2] + n1[3] or n2[2] == ((n1[2] + n1[3] + 15) & ~15) or n2[2] >= n1[3]
         # (bytes between blocks are alignment padding: compare block by block)
-        for t in (np.frombuffer(n1[5], np.int64).reshape(-1, 6), np.frombuffer(n2[5], np.int64).reshape(-1, 6)):
-            for _, kind, off, nbytes, ns, nv in t:
+        for t in (np.frombuffer(n1[5], np.int64).reshape(-1, 7), np.frombuffer(n2[5], np.int64).reshape(-1, 7)):
+            for _, kind, off, nbytes, ns, nv, _content in t:
                 assert bytes_native[off:off + nbytes] == bytes_ctypes[off:off + nbytes]
         assert n1[4] + n2[4] == [len(fast5.Fast5File(real).raw_signal(r)) for r in ids] + [len(v) for v in reads.values()]
         # what it declines: gzip single-read file -> the ctypes reader's plain block; a missing file -> that reader's error

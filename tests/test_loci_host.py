@@ -126,6 +126,7 @@ class ArenaFakeEngine(SharedFakeEngine):
 
 class VbzFakeEngine(ArenaFakeEngine):
     """... and one that takes the reads as the blocks inside their VBZ chunks (wsx_vbz_decode's part played by oracle/vbz.py)."""
+    DEVICE_ZSTD = False
 
     def submit_vbz_parts(self, region, parts, lo, hi, aut):
         from oracle import vbz
@@ -134,11 +135,18 @@ class VbzFakeEngine(ArenaFakeEngine):
         for path, cap, base, used, lens, table in parts:
             view = np.memmap(path, dtype=np.uint8, mode='r')
             assert cap <= len(view) and base + used <= cap
-            t = np.frombuffer(table, np.int64).reshape(-1, 6)
+            t = np.frombuffer(table, np.int64).reshape(-1, 7)
             per_read = [[] for _ in lens]
-            for r, kind, off, nbytes, ns, nv in t:
+            for r, kind, off, nbytes, ns, nv, content in t:
                 assert off % 16 == 0 and base <= off and off + nbytes <= base + used and nv >= ns
                 blk = np.array(view[off:off + nbytes])
+                if kind >= 3:   # the chunk's zstd frame, left for the device: wsx_zstd_decode's part played by oracle/zstd_oracle.c
+                    from oracle import zstd as ozstd
+                    self.zstd_frames = getattr(self, 'zstd_frames', 0) + 1
+                    assert self.DEVICE_ZSTD and ozstd.content_size(blk.tobytes()) == content
+                    blk, kind = np.frombuffer(ozstd.decode(blk.tobytes()), np.uint8), kind - 2
+                else:
+                    assert content == 0
                 per_read[r].append(blk.view(np.int16)[:ns] if kind == 0 else vbz.decode_block(blk, int(nv), kind == 1)[:ns])
             for n, pieces in zip(lens, per_read):
                 raw = np.concatenate(pieces)
@@ -147,7 +155,7 @@ class VbzFakeEngine(ArenaFakeEngine):
         return self.submit_raw(raws, lo, hi, aut)
 
     def info(self):
-        return dict(super().info(), vbz_batches=getattr(self, 'vbz_batches', 0))
+        return dict(super().info(), vbz_batches=getattr(self, 'vbz_batches', 0), zstd_frames=getattr(self, 'zstd_frames', 0))
 
 
 def _make_loci(root, poison=None):
@@ -949,3 +957,41 @@ def test_a_streamed_run_raises_what_its_set_up_raises(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError, match='Not found the overview file'):
         main_wrapper_loci(loci, 1, _engine=VbzFakeEngine, quiet=True)
     assert threading.active_count() <= before
+
+
+class ZstdFakeEngine(VbzFakeEngine):
+    """... and one that also undoes the chunks' zstd frames itself (HipEngine since round 6: wsx_zstd_decode)."""
+    DEVICE_ZSTD = True
+
+
+@pytest.mark.parametrize('threads', [1, 3])
+def test_readers_leave_zstd_to_an_engine_that_decodes_it(tmp_path, threads, monkeypatch):
+    """An engine with DEVICE_ZSTD: the readers hand over every chunk whose frame the device decoder takes as the frame lies in
+    the file (kinds 3 / 4 of the block table, the declared content size beside it) -- all of the upstream file's -- and the run's
+    files are the same as with the frames undone by the readers, in one process and on reader processes, natively and through
+    the ctypes reader."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5, _readers
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    a, b, c = (_fast5_loci(str(tmp_path / t), src, ids, n_loci=70) for t in 'abc')
+    n_reads = sum(1 + li % 3 for li in range(70))
+    tm_a, tm_b, tm_c = {}, {}, {}
+    main_wrapper_loci(b, threads, _engine=VbzFakeEngine, quiet=True, timings=tm_b)
+    main_wrapper_loci(a, threads, _engine=ZstdFakeEngine, quiet=True, timings=tm_a)
+    assert tm_b['zstd_frames'] == 0 and tm_a['zstd_frames'] == n_reads and 'zstd and VBZ decoded on the GPU' in tm_a['reader_mode']
+    monkeypatch.setenv('WARPSTR_NO_NATIVE_READER', '1')   # (reader processes started from here on inherit it)
+    _readers._NATIVE = False
+    try:
+        main_wrapper_loci(c, threads, _engine=ZstdFakeEngine, quiet=True, timings=tm_c)
+    finally:
+        _readers._NATIVE = False
+    assert tm_c['zstd_frames'] == n_reads
+    for la, lb, lc in zip(a, b, c):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+            assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel

@@ -97,6 +97,7 @@ _VBZ_NATIVE = False
 _VBZ_CONTEXT: list = []   # [(wsh_vbz_context, ZSTD_createDCtx, address of ZSTD_decompressDCtx)] once vbz_native() has bound them
 _THREAD = None            # threading.local(): has this thread its decompression context?
 PLAIN, SVB_ZIGZAG, SVB = 0, 1, 2   # what a block written by Fast5Core.blocks_to holds (= WSX_VBZ_* of include/warpstr_hip.h)
+ZSTD_SVB_ZIGZAG, ZSTD_SVB = 3, 4   # ... or the zstd frame around such a block, left for wsx_zstd_decode
 VBZ_ERRORS = {-1: 'VBZ chunk too short', -2: 'VBZ chunk does not hold a sized zstd frame', -3: 'zstd decompression of a VBZ chunk failed',
               -4: 'StreamVByte block shorter than its key area', -5: 'StreamVByte block shorter than its keys say',
               -6: 'a VBZ block does not fit the room made for it'}
@@ -311,10 +312,46 @@ class Fast5Core:
         finally:
             h.H5Dclose(d)
 
-    def blocks_to(self, read_id: Optional[str], place):
+    @staticmethod
+    def frame_for_device(frame: bytes):
+        """The content size a zstd frame declares if the device decoder takes the frame (csrc/wsx_zstd.hip: no dictionary, a declared
+        size, at most 32 blocks, none of a reserved type, no "treeless" literals), else None -- from its headers alone."""
+        b, n = frame, len(frame)
+        if n < 6 or b[:4] != b'\x28\xb5\x2f\xfd':
+            return None
+        fhd = b[4]
+        flag, single, did = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+        if did or fhd & 8:
+            return None
+        pos = 5 + (0 if single else 1)
+        fcs = (1 if single else 0) if flag == 0 else (2, 4, 8)[flag - 1]
+        if fcs == 0 or pos + fcs > n:
+            return None
+        content = int.from_bytes(b[pos:pos + fcs], 'little') + (256 if fcs == 2 else 0)
+        pos += fcs
+        if content > 32 << 17:
+            return None
+        for _ in range(32):
+            if pos + 3 > n:
+                return None
+            bh = int.from_bytes(b[pos:pos + 3], 'little')
+            pos += 3
+            last, btype, size = bh & 1, (bh >> 1) & 3, bh >> 3
+            if btype == 3 or pos + (1 if btype == 1 else size) > n:
+                return None
+            if btype == 2 and (size < 1 or (b[pos] & 3) == 3):
+                return None
+            pos += 1 if btype == 1 else size
+            if last:
+                return content
+        return None
+
+    def blocks_to(self, read_id: Optional[str], place, device_zstd: bool = False):
         """A read as the device decoder takes it (wsx_vbz_decode): every chunk of a VBZ dataset as the StreamVByte block inside
         its zstd frame -- zstd is the part a GPU does not do --, anything else as plain int16 samples.  place(nbytes) -> the address
-        the next block goes to (asked once per block, in order).  Returns (samples of the read, [(kind, bytes, samples wanted, values coded), ...]).
+        the next block goes to (asked once per block, in order).  Returns (samples of the read, [(kind, bytes, samples wanted, values
+        coded, content bytes), ...]); device_zstd: a chunk whose zstd frame the device can decode is left as that frame (kind ZSTD_*,
+        content bytes = what the frame declares; 0 for the other kinds).
         NeedsNumpy as for decode_to (before place() is asked for the first time, or after: the caller starts the read again)."""
         h = self.h
         d, n, vbz, chunk_len = self._open_signal(read_id)
@@ -323,7 +360,7 @@ class Fast5Core:
                 native_i16 = _hid.in_dll(h, 'H5T_NATIVE_SHORT_g').value
                 if h.H5Dread(d, native_i16, 0, 0, 0, C.c_void_p(int(place(2 * n)))) < 0:
                     raise Fast5Error(f'{self.path}: H5Dread failed')
-                return n, [(PLAIN, 2 * n, n, n)]
+                return n, [(PLAIN, 2 * n, n, n, 0)]
             native = vbz_native() if (vbz[0] == 0 and vbz[1] == 2) else None
             if native is None:
                 raise NeedsNumpy()
@@ -336,10 +373,19 @@ class Fast5Core:
                 if plain:  # the filter was skipped when this chunk was written: plain samples
                     got = min(size // 2, want)
                     C.memmove(int(place(2 * got)), buf, 2 * got)
-                    blocks.append((PLAIN, 2 * got, got, got))
+                    blocks.append((PLAIN, 2 * got, got, got, 0))
                 else:
                     if size < 4:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS[-1])
+                    if device_zstd and level != 0:
+                        content = self.frame_for_device(bytes(buf[4:size]))
+                        if content is not None and content <= 5 * max(chunk_len, want) + 64:
+                            C.memmove(int(place(size - 4)), C.addressof(buf) + 4, size - 4)
+                            coded = int.from_bytes(bytes(buf[:4]), 'little') // 2
+                            got = min(want, coded)
+                            blocks.append((kind + 2, size - 4, got, coded, content))
+                            done += got
+                            continue
                     if level != 0:
                         cap = zs.ZSTD_getFrameContentSize(C.cast(C.addressof(buf) + 4, C.c_char_p), size - 4)
                         # (a block of n values holds ceil(n/4) key bytes and at most 4 n value bytes: a frame that declares more is
@@ -352,7 +398,7 @@ class Fast5Core:
                     if nb < 0:
                         raise Fast5Error(f'{self.path}: ' + VBZ_ERRORS.get(int(nb), f'VBZ decoder error {nb}'))
                     got = min(want, int(n_out.value))
-                    blocks.append((kind, int(nb), got, int(n_out.value)))
+                    blocks.append((kind, int(nb), got, int(n_out.value), 0))
                 done += got
             if done != n:
                 raise Fast5Error(f'{self.path}: decoded {done} samples, the dataset holds {n} int16')

@@ -221,7 +221,7 @@ def _native_reader():
                 fn = lib.wsh_reader_pack
                 fn.restype = C.c_int64
                 fn.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
-                               C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                               C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
                 lib.wsh_reader_init.argtypes = [C.c_char_p, C.c_char_p]
                 h5, zs = lib_paths()
                 if lib.wsh_reader_init(os.fsencode(h5), os.fsencode(zs)) == 0:
@@ -232,7 +232,7 @@ def _native_reader():
     return _NATIVE
 
 
-def _pack_native(region: int, at: int, items):
+def _pack_native(region: int, at: int, items, device_zstd: bool = False):
     """pack_arena's loop in one library call per chunk (more when the arena has to grow): (bytes written up to, [samples of every
     read], the block table as bytes) or None when a read needs the ctypes reader (another layout or filter, any error: that path
     then raises what it finds) -- nothing of the chunk counts as written in that case."""
@@ -249,43 +249,46 @@ def _pack_native(region: int, at: int, items):
     names = (C.c_char_p * n)(*[it[2].encode('utf-8') if it[2] is not None else None for it in items])
     lens, status = (C.c_int64 * n)(), (C.c_int32 * n)()
     table_cap = 2 * n + 16
-    table = (C.c_int64 * (6 * table_cap))()
+    table = (C.c_int64 * (7 * table_cap))()
     pos, n_blocks, need = C.c_int64(at), C.c_int64(0), C.c_int64(0)
     arena = _arena(region, max((at + 1) // 2, 1))
     first = 0
     while first < n:
         got = lib.wsh_reader_pack(first, n, paths, falls, names, C.addressof(arena[2]), 2 * arena[3], C.byref(pos), lens, status, table,
-                                  table_cap, C.byref(n_blocks), C.byref(need))
+                                  table_cap, C.byref(n_blocks), C.byref(need), 1 if device_zstd else 0)
         if got < 0 or (got < n and status[got] != 0):
             return None
         if got < n:   # read `got` did not fit: more room, then on from there
             if need.value == 0:
-                bigger = (C.c_int64 * (12 * table_cap))()
-                C.memmove(bigger, table, 48 * n_blocks.value)
+                bigger = (C.c_int64 * (14 * table_cap))()
+                C.memmove(bigger, table, 56 * n_blocks.value)
                 table, table_cap = bigger, 2 * table_cap
             else:
                 arena = _arena(region, (need.value + 1) // 2 + 8)   # (growing keeps what is there: the file is the memory)
         first = got
-    return pos.value, list(lens), C.string_at(table, 48 * n_blocks.value)
+    return pos.value, list(lens), C.string_at(table, 56 * n_blocks.value)
 
 
 def pack_arena(args):
     """decode_arena() for a parent that decodes on the GPU (wsx_vbz_decode): every read's blocks -- StreamVByte blocks as they
     leave zstd, or plain samples -- back to back (16-byte aligned) in the region's arena.  (region, generation, items) ->
     (arena path, its size in bytes, first byte of this chunk, bytes used from there, [samples of every read],
-    int64 sextuples (read of the chunk, kind, first byte in the arena, bytes, samples wanted, values coded) of all blocks as bytes,
-    seconds)."""
+    seven int64 per block (read of the chunk, kind, first byte in the arena, bytes, samples wanted, values coded, content bytes) of all
+    blocks as bytes, seconds).  A fourth element of the argument, if true: the parent decodes zstd on the device too
+    (wsx_zstd_decode) -- a chunk whose frame that decoder takes is left as the frame lies in the file (kinds 3 / 4, content bytes =
+    what the frame declares), and the reader's part of a read is libhdf5 alone."""
     import array
     import time
 
     from ._h5core import PLAIN, NeedsNumpy
-    region, generation, items = args
+    region, generation, items = args[:3]
+    device_zstd = bool(args[3]) if len(args) > 3 else False
     t0 = time.perf_counter()
     cur = _BYTE_CURSOR.setdefault(region, [generation, 0])
     if cur[0] != generation:
         cur[0], cur[1] = generation, 0
     base = at = cur[1]
-    done = _pack_native(region, at, items)
+    done = _pack_native(region, at, items, device_zstd)
     if done is not None:
         at, lens, table_bytes = done
         cur[1] = at
@@ -304,17 +307,17 @@ def pack_arena(args):
         path, read_id = resolve(item)
         mark, n_offs = at, len(offs)
         try:
-            n, blocks = fast5_file(path, arrays=False).blocks_to(read_id, place)
+            n, blocks = fast5_file(path, arrays=False).blocks_to(read_id, place, device_zstd)
         except NeedsNumpy:
             import ctypes
             at = mark
             del offs[n_offs:]
             raw = fast5_file(path).raw_signal(read_id)
             ctypes.memmove(place(2 * len(raw)), raw.ctypes.data, 2 * len(raw))
-            n, blocks = len(raw), [(PLAIN, 2 * len(raw), len(raw), len(raw))]
+            n, blocks = len(raw), [(PLAIN, 2 * len(raw), len(raw), len(raw), 0)]
         lens.append(int(n))
-        for (kind, nbytes, ns, nv), off in zip(blocks, offs[n_offs:]):
-            table.extend((r, kind, off, nbytes, ns, nv))
+        for (kind, nbytes, ns, nv, content), off in zip(blocks, offs[n_offs:]):
+            table.extend((r, kind, off, nbytes, ns, nv, content))
     cur[1] = at
     arena = _arena(region, max((at + 1) // 2, 1))
     return arena[0], 2 * arena[3], base, at - base, lens, table.tobytes(), time.perf_counter() - t0

@@ -843,11 +843,14 @@ class BatchQueue:
             acc[key] = acc.get(key, 0.0) + dt
         return ticket
 
+    DEVICE_ZSTD = True   # submit_vbz_parts also takes chunks whose zstd frame is still around them (wsx_zstd_decode undoes it)
+
     def submit_vbz_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
         """submit_raw_parts() for readers that leave the decoding to the device (_readers.pack_arena): parts = [(arena path, its
-        size in bytes, first byte of the chunk, bytes used, [samples of every read], the blocks' sextuples as bytes), ...] in
-        batch order.  One upload per chunk of what the readers wrote -- StreamVByte blocks, 0.6 of the samples' bytes --, then
-        wsx_vbz_decode into the batch's int16 buffer, then the signal loader and the caller as ever."""
+        size in bytes, first byte of the chunk, bytes used, [samples of every read], the blocks' seven int64 as bytes), ...] in
+        batch order.  One upload per chunk of what the readers wrote -- the zstd frames as they lie in the file (half the
+        samples' bytes) or, where a reader undid zstd, StreamVByte blocks --, then wsx_zstd_decode (frames -> StreamVByte blocks),
+        wsx_vbz_decode (-> the batch's int16 buffer), then the signal loader and the caller as ever."""
         import time
         torch = self.torch
         clock, acc = time.perf_counter, self.parts_s
@@ -861,9 +864,9 @@ class BatchQueue:
         offsets = np.zeros(n + 1, np.int64)
         np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
         # the block table: where a block lies in the batch's byte buffer, where its samples go
-        tables, at_src, first_read, spans = [], 0, 0, []
+        tables, raws, at_src, first_read, spans = [], [], 0, 0, []
         for path, cap, base, used, ls, tb in parts:
-            t = np.frombuffer(tb, np.int64).reshape(-1, 6)
+            t = np.frombuffer(tb, np.int64).reshape(-1, 7)
             blk = np.zeros(len(t), _lib.VBZ_BLOCK_DTYPE)
             if len(t):
                 blk['src_offset'] = at_src + (t[:, 2] - base)
@@ -874,15 +877,31 @@ class BatchQueue:
                 before -= np.repeat(before[starts], np.diff(np.r_[starts, len(t)]))
                 blk['dst_offset'] = roff[first_read + t[:, 0]] + before
             tables.append(blk)
+            raws.append(t[:, 6])
             spans.append((path, cap, base, used, at_src))
             at_src += (int(used) + 15) & ~15
             first_read += len(ls)
         blocks = np.concatenate(tables) if tables else np.zeros(0, _lib.VBZ_BLOCK_DTYPE)
+        content = np.concatenate(raws) if raws else np.zeros(0, np.int64)
+        # blocks that are still zstd frames (kinds 3 / 4): their content gets a place behind the uploaded bytes, in the same buffer
+        framed = np.flatnonzero(blocks['kind'] >= 3)
+        frames, svb_at = np.zeros(len(framed), _lib.ZSTD_FRAME_DTYPE), at_src
+        if len(framed):
+            room = (content[framed] + 15) & ~15
+            place = svb_at + np.cumsum(room) - room
+            frames['src_offset'], frames['src_bytes'] = blocks['src_offset'][framed], blocks['src_bytes'][framed]
+            frames['dst_offset'], frames['dst_bytes'] = place - svb_at, content[framed]
+            blocks['src_offset'][framed], blocks['src_bytes'][framed] = place, content[framed]
+            blocks['kind'][framed] -= 2
+            svb_bytes = int(room.sum())
+        else:
+            svb_bytes = 0
         t1 = clock()
         with torch.cuda.stream(self.stream):
-            src_dev = torch.empty(max(at_src, 16), dtype=torch.uint8, device=self.dev)
+            src_dev = torch.empty(max(at_src + svb_bytes, 16), dtype=torch.uint8, device=self.dev)
+            lit_dev = torch.empty(max(svb_bytes, 16), dtype=torch.uint8, device=self.dev) if svb_bytes else None
             raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
-            status = torch.empty(max(len(blocks), 1), dtype=torch.int32, device=self.dev)
+            status = torch.empty(max(len(blocks), 1) + max(len(frames), 1), dtype=torch.int32, device=self.dev)
             t2 = clock()
             for path, cap, base, used, at in spans:
                 if used:
@@ -893,16 +912,24 @@ class BatchQueue:
             t3 = clock()
             signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
         t4 = clock()
+        zst = status[max(len(blocks), 1):]
+        if len(frames):
+            self.hip.zstd_decode_device(src_dev.data_ptr(), at_src, frames, src_dev.data_ptr() + svb_at, svb_bytes, lit_dev.data_ptr(), zst.data_ptr())
         if len(blocks):
-            self.hip.vbz_decode_device(src_dev.data_ptr(), at_src, blocks, raw_dev.data_ptr(), max(total_raw, 1), status.data_ptr())
+            self.hip.vbz_decode_device(src_dev.data_ptr(), at_src + svb_bytes, blocks, raw_dev.data_ptr(), max(total_raw, 1), status.data_ptr())
         if n:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
         t5 = clock()
         with torch.cuda.stream(self.stream):   # (src_dev and status were allocated on this stream: their memory is reused in its order)
-            bad = status[:len(blocks)].ne(0).any() if len(blocks) else None   # (read with the records: collect())
-        ticket = self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, raw_dev)
+            bad = None
+            if len(blocks):
+                bad = status[:len(blocks)].ne(0).any()
+                if len(frames):
+                    bad = bad | zst[:len(frames)].ne(0).any()
+        ticket = self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, (raw_dev, lit_dev))
         ticket['vbz_bad'] = bad
         self.vbz_bytes = getattr(self, 'vbz_bytes', 0) + at_src
+        self.zstd_frames = getattr(self, 'zstd_frames', 0) + len(frames)
         for key, dt in (('lengths', t1 - t0), ('allocate', t2 - t1 + t4 - t3), ('copies', t3 - t2), ('prepare', t5 - t4), ('launch', clock() - t5)):
             acc[key] = acc.get(key, 0.0) + dt
         return ticket
@@ -943,7 +970,8 @@ class BatchQueue:
         ticket['done'].synchronize()
         if ticket.get('vbz_bad') is not None and bool(ticket['vbz_bad'].item()):
             # (the readers check every block before it is uploaded: this is a block that changed on its way, not a bad file)
-            raise RuntimeError('wsx_vbz_decode flagged a StreamVByte block whose keys ask for more bytes than it has')
+            raise RuntimeError('the device decoders flagged a chunk: a zstd frame that is corrupt (wsx_zstd_decode) or a StreamVByte block whose '
+                               'keys ask for more bytes than it has (wsx_vbz_decode)')
         rec = ticket['rec_host'].numpy().view(_lib.RESULT_DTYPE).reshape(-1)[:n].copy()
         ok = rec['status'] == 0
         out = [rec]

@@ -155,6 +155,36 @@ hid_t open_signal(hid_t fid, const char *read_id)
     return -1;   // (a multi-read file asked without an id: the Python reader walks its root group)
 }
 
+// Can the device decode this frame (csrc/wsx_zstd.hip)?  Read from its headers alone: no dictionary, a declared content size, at
+// most 32 blocks, no block of a reserved type, no literals section that reuses the previous block's Huffman tree ("treeless").
+// *content = the content size it declares.
+bool frame_for_device(const uint8_t *b, int64_t n, int64_t *content)
+{
+    if (n < 6 || b[0] != 0x28 || b[1] != 0xB5 || b[2] != 0x2F || b[3] != 0xFD) return false;
+    const int fhd = b[4], flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    if (did || (fhd & 8)) return false;
+    int64_t pos = 5 + (single ? 0 : 1);
+    const int fcs = flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8;
+    if (fcs == 0 || pos + fcs > n) return false;
+    uint64_t v = 0;
+    for (int i = 0; i < fcs; i++) v |= uint64_t(b[pos + i]) << (8 * i);
+    if (fcs == 2) v += 256;
+    pos += fcs;
+    if (v > (uint64_t(32) << 17)) return false;
+    *content = int64_t(v);
+    for (int blocks = 0;; blocks++) {
+        if (blocks >= 32 || pos + 3 > n) return false;
+        const uint32_t bh = b[pos] | (b[pos + 1] << 8) | (uint32_t(b[pos + 2]) << 16);
+        pos += 3;
+        const int last = bh & 1, type = (bh >> 1) & 3;
+        const int64_t size = bh >> 3;
+        if (type == 3 || pos + (type == 1 ? 1 : size) > n) return false;
+        if (type == 2 && (size < 1 || (b[pos] & 3) == 3)) return false;
+        pos += type == 1 ? 1 : size;
+        if (last) return true;
+    }
+}
+
 }  // namespace
 
 // Binds libhdf5 and libzstd (the paths the process loaded them from).  0: ready; 1: a symbol is missing (an HDF5 older than
@@ -193,8 +223,9 @@ WSH_EXPORT void wsh_reader_close(void)
 // the filter was skipped when the chunk was written, as plain int16 samples (kind 0), each block at the next 16-byte boundary
 // from *at on.  path[i]: the read's own (annotated, single-read) file; fallback[i] (or NULL): the multi-read file that holds it
 // when that one does not exist (caller-only input); name[i]: the read's id in a multi-read file.
-// Per read: lens[i] = its samples.  Per block, six int64 in `table` (at most table_cap blocks): read index, kind, first byte in
-// the arena, bytes, samples wanted from it, values it codes.
+// Per read: lens[i] = its samples.  Per block, SEVEN int64 in `table` (at most table_cap blocks): read index, kind, first byte in
+// the arena, bytes, samples wanted from it, values it codes, and -- device_zstd != 0: a chunk whose zstd frame the device can decode
+// (frame_for_device) is left as it is, kind 3 / 4 = the frame of a kind 1 / 2 block -- the content size the frame declares (else 0).
 // Returns the index of the first read NOT done: n when all are; i < n when read i does not fit (the arena's room: *need bytes
 // from the arena's start, or the table's) -- the caller makes room and calls again with first = i -- or when status[i] != 0:
 //   1  the Python reader must take this read (layout / filter / integer size this file does not do)
@@ -203,7 +234,7 @@ WSH_EXPORT void wsh_reader_close(void)
 // -10  the dataset's chunks do not add up to its length.
 WSH_EXPORT int64_t wsh_reader_pack(int64_t first, int64_t n, const char *const *path, const char *const *fallback, const char *const *name,
                                    uint8_t *arena, int64_t cap, int64_t *at, int64_t *lens, int32_t *status, int64_t *table,
-                                   int64_t table_cap, int64_t *n_blocks, int64_t *need)
+                                   int64_t table_cap, int64_t *n_blocks, int64_t *need, int32_t device_zstd)
 {
     if (!g.ready) return -1;
     try {
@@ -271,7 +302,8 @@ WSH_EXPORT int64_t wsh_reader_pack(int64_t first, int64_t n, const char *const *
                     mask = m2;
                 }
                 const int64_t pos = (*at + 15) & ~int64_t(15);
-                int64_t *row = table + 6 * *n_blocks;
+                int64_t *row = table + 7 * *n_blocks;
+                row[6] = 0;
                 if (mask & 1u) {   // the filter was skipped when this chunk was written: plain samples
                     const int64_t got = std::min<int64_t>(int64_t(size) / 2, want);
                     if (pos + 2 * got > cap) { *at = at0; *n_blocks = blocks0; *need = pos + 2 * got; return i; }
@@ -281,6 +313,22 @@ WSH_EXPORT int64_t wsh_reader_pack(int64_t first, int64_t n, const char *const *
                     done += got;
                 } else {
                     if (size < 4) return fail(-4);
+                    int64_t content = 0;
+                    if (device_zstd && level != 0 && frame_for_device(t_chunk.data() + 4, int64_t(size) - 4, &content) &&
+                        content <= 5 * std::max<int64_t>(int64_t(chunk_len), want) + 64) {
+                        // the frame as it lies in the file: wsx_zstd_decode undoes it (kinds 3 / 4 = a zstd frame around kinds 1 / 2)
+                        const int64_t fb = int64_t(size) - 4;
+                        if (pos + fb > cap) { *at = at0; *n_blocks = blocks0; *need = pos + fb; return i; }
+                        memcpy(arena + pos, t_chunk.data() + 4, size_t(fb));
+                        uint32_t nbytes;
+                        memcpy(&nbytes, t_chunk.data(), 4);
+                        const int64_t coded = nbytes / 2, got = std::min<int64_t>(want, coded);
+                        row[0] = i; row[1] = kind + 2; row[2] = pos; row[3] = fb; row[4] = got; row[5] = coded; row[6] = content;
+                        *at = pos + fb;
+                        done += got;
+                        ++*n_blocks;
+                        continue;
+                    }
                     int64_t room = int64_t(size) - 4;
                     if (level != 0) {
                         typedef unsigned long long (*size_fn)(const void *, size_t);

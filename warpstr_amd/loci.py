@@ -136,6 +136,7 @@ class HipEngine:
 
     # (methods, not attributes: main_wrapper_loci asks the CLASS what an engine can do before it creates one)
     ARENA_REGIONS = BatchQueue.ARENA_REGIONS
+    DEVICE_ZSTD = BatchQueue.DEVICE_ZSTD   # (submit_vbz_parts takes chunks whose zstd frame is still around them)
 
     def submit_raw_parts(self, *a):
         return self.queue.submit_raw_parts(*a)
@@ -156,6 +157,7 @@ class HipEngine:
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
                 'handle_create_s': self.hip.create_times(), 'submit_parts_s': dict(self.queue.parts_s),
+                'zstd_frames_decoded_on_the_gpu': getattr(self.queue, 'zstd_frames', 0),
                 'kernels': sorted({self.hip.kernel_name(a) for a in range(min(len(self.hip.automata), 256))})}
 
     def close(self):
@@ -641,7 +643,7 @@ STREAM_FROM_LOCI = 256   # a run of that many loci (one rank, fast5 files, reade
                          # sets the later ones up
 
 
-def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings):
+def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings, gpu_zstd=False):
     """Set-up, reading and calling of a run as ONE pipeline (upstream's loop reaches a locus, builds its automata, calls its
     reads: WarpSTR.py:33-76): the loci are set up part after part on a thread of its own; as soon as the first part is there the
     reader thread hands its reads' files to the reader processes; the calling thread creates the handle from the loci known by
@@ -771,7 +773,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 submitted[k] = threading.Event()
                 items = [item_of(x) for x in range(b, b1)]
                 step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
-                futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step])) for q in range(0, len(items), step)]
+                futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step], gpu_zstd) if gpu_vbz else (region, k, items[q:q + step])) for q in range(0, len(items), step)]
                 inflight.append((b, b1, region, futures, k))
                 tm['read_s'] += time.perf_counter() - t1
                 b, k = b1, k + 1
@@ -1077,14 +1079,15 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 pool = _InlinePool()
                 pools.append(pool)
             gpu_vbz = hasattr(probe, 'submit_vbz_parts') and not os.environ.get('WARPSTR_NO_GPU_VBZ')
-            tm['reader_mode'] = (('arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas') + (', filled in this process' if getattr(pool, 'inline', False) else '')
-                                 + ', streamed with the set-up')
+            gpu_zstd = gpu_vbz and bool(getattr(probe, 'DEVICE_ZSTD', False)) and not os.environ.get('WARPSTR_NO_GPU_ZSTD')
+            tm['reader_mode'] = ((('arenas, zstd and VBZ decoded on the GPU' if gpu_zstd else 'arenas, VBZ decoded on the GPU') if gpu_vbz else 'arenas')
+                                 + (', filled in this process' if getattr(pool, 'inline', False) else '') + ', streamed with the set-up')
 
             # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results)
             it = parts if executor is None else executor.map(setup, parts)
             streamed = _streamed_run(it, (lambda x: x) if executor is not None else setup, tm, pool, engine_cls,
                                      (caller_config, rescaler_config, local_gpu), batch_reads, batch_samples, batch_raw_bytes // 2, gpu_vbz,
-                                     print_warnings)
+                                     print_warnings, gpu_zstd)
     try:
         if streamed is not None:
             jobs = streamed[0]
@@ -1331,7 +1334,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                         submitted[k] = threading.Event()
                         items = [item_of(x) for x in range(b, b1)]
                         step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
-                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step]))
+                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step], gpu_zstd) if gpu_vbz else (region, k, items[q:q + step]))
                                    for q in range(0, len(items), step)]
                         inflight.append((b, b1, region, futures, k))
                         tm['read_s'] += time.perf_counter() - t1
@@ -1467,10 +1470,13 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             # (and if the engine decodes VBZ itself -- wsx_vbz_decode -- the readers stop at the zstd frame's content: StreamVByte,
             # zig-zag and the running sum are a quarter of a reader's time per read and 0.6 of the bytes to upload)
             gpu_vbz = arenas and hasattr(probe, 'submit_vbz_parts') and not os.environ.get('WARPSTR_NO_GPU_VBZ')
+            # (... and if it decodes zstd as well -- wsx_zstd_decode -- a reader's part of a read is libhdf5 alone)
+            gpu_zstd = gpu_vbz and bool(getattr(probe, 'DEVICE_ZSTD', False)) and not os.environ.get('WARPSTR_NO_GPU_ZSTD')
             reader = None
             try:
                 if arenas:
-                    tm['reader_mode'] = ('arenas, VBZ decoded on the GPU' if gpu_vbz else 'arenas') + (', filled in this process' if getattr(pool, 'inline', False) else '')
+                    tm['reader_mode'] = ((('arenas, zstd and VBZ decoded on the GPU' if gpu_zstd else 'arenas, VBZ decoded on the GPU') if gpu_vbz else 'arenas')
+                                         + (', filled in this process' if getattr(pool, 'inline', False) else ''))
                     reader = threading.Thread(target=produce, args=(arena_batches,), name='warpstr-reader', daemon=True)
                     reader.start()
                 make_engine()
