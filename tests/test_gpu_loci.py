@@ -245,17 +245,19 @@ def test_many_loci_through_a_one_rank_rccl_group(tmp_path, partition):
     _same(one, [LocusPath(os.path.join(tmp_path, 'rccl', f'locus{li:02d}'), *MANY[li % len(MANY)][:2]) for li in range(n_loci)])
 
 
-@pytest.mark.parametrize('mode', ['arenas, VBZ decoded on the GPU', 'arenas', 'shared staging'])
+@pytest.mark.parametrize('mode', ['arenas, zstd and VBZ decoded on the GPU', 'arenas, VBZ decoded on the GPU', 'arenas', 'shared staging'])
 def test_fast5_reads_decoded_by_reader_processes_into_the_upload_buffers(tmp_path, monkeypatch, mode):
     """The path real input takes, on the GPU: 70 loci whose reads are the upstream test file's ten VBZ reads (caller-only layout),
     read in this process against three reader processes that decode straight into page-locked memory both sides map -- arenas of
-    their own, handed out a batch ahead (_readers.decode_arena; or only as far as the StreamVByte blocks inside the chunks' zstd
-    frames, _readers.pack_arena, the rest on the device: wsx_vbz_decode), or the staging ring of caller.SharedStaging (lengths
+    their own, handed out a batch ahead (_readers.decode_arena; or the chunks' zstd frames as they lie in the file, the rest on
+    the device: wsx_zstd_decode + wsx_vbz_decode; or as far as the StreamVByte blocks inside those frames, _readers.pack_arena), or the staging ring of caller.SharedStaging (lengths
     first, then every read to its place) -- the same files, and the reads were uploaded from there."""
     if mode == 'shared staging':
         monkeypatch.setenv('WARPSTR_NO_READER_ARENAS', '1')
     if mode == 'arenas':
         monkeypatch.setenv('WARPSTR_NO_GPU_VBZ', '1')
+    if mode == 'arenas, VBZ decoded on the GPU':
+        monkeypatch.setenv('WARPSTR_NO_GPU_ZSTD', '1')
     monkeypatch.setattr('warpstr_amd.loci.SHARED_BATCH_READS', 24)   # (several batches: every arena region is used again)
     from tests.helpers import GOLDEN
     from warpstr_amd import fast5
