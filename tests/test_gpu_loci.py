@@ -328,8 +328,8 @@ def test_reads_whose_datasets_are_several_vbz_chunks(tmp_path, monkeypatch):
     main_wrapper_loci(c, 1, quiet=True, timings=tm_c)
     monkeypatch.setenv('WARPSTR_NO_GPU_VBZ', '1')
     main_wrapper_loci(b, 3, quiet=True, timings=tm_b)
-    assert tm_a['reader_mode'] == 'arenas, VBZ decoded on the GPU' and tm_b['reader_mode'] == 'arenas'
-    assert tm_c['reader_mode'] == 'arenas, VBZ decoded on the GPU, filled in this process'
+    assert tm_a['reader_mode'] == 'arenas, zstd and VBZ decoded on the GPU' and tm_b['reader_mode'] == 'arenas'
+    assert tm_c['reader_mode'] == 'arenas, zstd and VBZ decoded on the GPU, filled in this process'
     assert tm_a['uploaded_bytes'] < tm_a['raw_bytes'] == tm_b['raw_bytes'] == tm_c['raw_bytes']
     _same(a, b)
     _same(c, b)
@@ -366,19 +366,39 @@ def test_a_block_that_changed_on_its_way_to_the_device_fails_its_batch(tmp_path)
             for o, b in zip(offs, blocks):
                 fh.seek(o)
                 fh.write(b.tobytes())
-        table = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000],
-                          [1, _lib.VBZ_SVB_ZIGZAG, offs[1], len(blocks[1]), 6000, 6000]], np.int64)
+        table = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000, 0],
+                          [1, _lib.VBZ_SVB_ZIGZAG, offs[1], len(blocks[1]), 6000, 6000, 0]], np.int64)
         part = (path, cap, 0, at, [6000, 6000], table.tobytes())
         lo, hi, aut = np.array([1000, 1000]), np.array([2999, 2999]), np.array([0, 1], np.int32)
         ticket = engine.submit_vbz_parts(0, [part], lo, hi, aut)
-        with pytest.raises(RuntimeError, match='wsx_vbz_decode flagged'):
+        with pytest.raises(RuntimeError, match='the device decoders flagged a chunk'):
             engine.collect(ticket)
         # the same arena with the good block twice: called as ever
-        good = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000],
-                         [1, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000]], np.int64)
+        good = np.array([[0, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000, 0],
+                         [1, _lib.VBZ_SVB_ZIGZAG, offs[0], len(blocks[0]), 6000, 6000, 0]], np.int64)
         ticket = engine.submit_vbz_parts(1, [(path, cap, 0, at, [6000, 6000], good.tobytes())], lo, hi, aut)
         rec = engine.collect(ticket)[0]
         assert len(rec) == 2
+        # ... and a chunk handed over as its zstd frame (kind 3) whose frame is cut short: wsx_zstd_decode flags it
+        from tests.test_zstd_oracle import compress
+        frame = compress(blocks[0].tobytes(), 1)
+        with open(path, 'r+b') as fh:
+            fh.seek(offs[0])
+            fh.write(frame[:-9] + bytes(9))
+        framed = np.array([[0, 3, offs[0], len(frame), 6000, 6000, len(blocks[0])], [1, _lib.VBZ_SVB_ZIGZAG, offs[1], len(blocks[0]), 6000, 6000, 0]], np.int64)
+        with open(path, 'r+b') as fh:
+            fh.seek(offs[1])
+            fh.write(blocks[0].tobytes())
+        ticket = engine.submit_vbz_parts(2, [(path, cap, 0, at, [6000, 6000], framed.tobytes())], lo, hi, aut)
+        with pytest.raises(RuntimeError, match='the device decoders flagged a chunk'):
+            engine.collect(ticket)
+        # the whole frame: decoded on the device, the same records as the block a reader had undone
+        with open(path, 'r+b') as fh:
+            fh.seek(offs[0])
+            fh.write(frame)
+        ticket = engine.submit_vbz_parts(0, [(path, cap, 0, at, [6000, 6000], framed.tobytes())], lo, hi, aut)
+        rec2 = engine.collect(ticket)[0]
+        assert rec2.tobytes() == rec.tobytes()
         torch.cuda.synchronize()
     finally:
         engine.close()

@@ -631,6 +631,7 @@ class BatchQueue:
         self.dev = torch.device('cuda', hip.device)
         self.down = torch.cuda.Stream(device=self.dev)  # ordered after every call so far (wsx_caller_join): the records come down here
         self.pack = torch.cuda.Stream(device=self.dev)  # packs a finished batch's sequences: waits for THAT batch only
+        self.up = torch.cuda.Stream(device=self.dev)    # uploads of the reader arenas' bytes (submit_vbz_parts), beside the kernels
         self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
         self._turn = 0
         self._shared = None  # SharedStaging: buffers the reader processes fill (stage_shared)
@@ -903,11 +904,19 @@ class BatchQueue:
             raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
             status = torch.empty(max(len(blocks), 1) + max(len(frames), 1), dtype=torch.int32, device=self.dev)
             t2 = clock()
-            for path, cap, base, used, at in spans:
-                if used:
-                    src_dev[at:at + used].copy_(self._arena_tensor(path, cap // 2).view(torch.uint8)[base:base + used], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            # the upload on a stream of its own: it runs beside the kernels of the batch before (one stream would put 4-8 ms of copies
+            # between two batches' kernels); the buffer was allocated in the handle's stream order, the decoders wait for the copies
+            allocated = torch.cuda.Event()
+            allocated.record()
+            src_dev.record_stream(self.up)
+            with torch.cuda.stream(self.up):
+                self.up.wait_event(allocated)
+                for path, cap, base, used, at in spans:
+                    if used:
+                        src_dev[at:at + used].copy_(self._arena_tensor(path, cap // 2).view(torch.uint8)[base:base + used], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self.stream.wait_event(ev)
             self._region_events[region] = ev
             t3 = clock()
             signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
