@@ -714,6 +714,75 @@ def vbz_kernel_leg(path, local, n_blocks=2048, launches=20):
             'note': 'a workgroup per block, two workgroup scans per 2 048 values; bound by the instructions it issues (VALU half busy); the from_fast5 leg needs 9 x 10^9 samples/s of it'}
 
 
+def zstd_kernel_leg(path, local, n_frames=2048, launches=10):
+    """wsx_zstd_decode alone at the size of a from_fast5 batch: n_frames frames cycling through the upstream test file's ten chunks
+    (their real zstd frames), HIP-event time per launch on the handle's stream; its output checked against libzstd for the first
+    ten frames.  The bytes it has to move: the frames in, their content out (and once more through the literal area)."""
+    import ctypes as C
+
+    import torch
+
+    from warpstr_amd import _lib, fast5, synth
+    from warpstr_amd.caller import HipCaller
+    h, zs = fast5._libs()
+    real = []
+    with fast5.Fast5File(path) as f:
+        for rid in f.read_ids():
+            d, n, prm, chunk_len = f._open_signal(rid)
+            try:
+                for _, _, buf, size, plain in f._chunks(d, n, chunk_len):
+                    frame = bytes(buf[4:size])
+                    real.append((np.frombuffer(frame, np.uint8), int(zs.ZSTD_getFrameContentSize(frame, len(frame)))))
+            finally:
+                h.H5Dclose(d)
+    locus = synth.make_locus('(AGC)', 16, 1)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.Stream(device=dev)
+    hip = HipCaller([locus.template, locus.reverse], [16, 16], device=local, stream=stream.cuda_stream)
+    blobs = [real[i % len(real)] for i in range(n_frames)]
+    table = np.zeros(n_frames, _lib.ZSTD_FRAME_DTYPE)
+    at = out = 0
+    parts = []
+    for i, (fr, m) in enumerate(blobs):
+        pad = -len(fr) % 16
+        parts += [fr, np.zeros(pad, np.uint8)]
+        table[i] = (at, len(fr), out, m)
+        at += len(fr) + pad
+        out += m + (-m % 16)
+    src = np.concatenate(parts)
+    with torch.cuda.stream(stream):
+        src_d = torch.from_numpy(src).to(dev)
+        dst_d = torch.empty(out, dtype=torch.uint8, device=dev)
+        scr_d = torch.empty(out, dtype=torch.uint8, device=dev)
+        st_d = torch.empty(n_frames, dtype=torch.int32, device=dev)
+        args = (src_d.data_ptr(), len(src), table, dst_d.data_ptr(), out, scr_d.data_ptr(), st_d.data_ptr())
+        for _ in range(2):
+            hip.zstd_decode_device(*args)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+        ev[0].record()
+        for k in range(launches):
+            hip.zstd_decode_device(*args)
+            ev[k + 1].record()
+        stream.synchronize()
+    ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(launches)]))
+    ok = int(st_d.sum()) == 0
+    got = dst_d.cpu().numpy()
+    for i in range(min(10, n_frames)):
+        fr, m = blobs[i]
+        ref = np.empty(m, np.uint8)
+        ok = ok and zs.ZSTD_decompress(ref.ctypes.data, m, fr.tobytes(), len(fr)) == m and np.array_equal(got[int(table[i]['dst_offset']):][:m], ref)
+    hip.close()
+    frames_b, content_b = int(table['src_bytes'].sum()), int(table['dst_bytes'].sum())
+    algo = frames_b + content_b
+    return {'kernels': ['zstd_literals_kernel', 'zstd_sequences_kernel'], 'frames_per_launch': n_frames, 'frame_bytes_per_launch': frames_b,
+            'content_bytes_per_launch': content_b, 'algorithmic_bytes_per_launch': algo, 'launch_ms': ms,
+            'roofline': {'bound': 'hbm', 'achieved': algo / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algo / ms / 1e6 / 8000.0, 'traffic': None},
+            'frames_per_s': n_frames / ms * 1e3, 'equal_to_libzstd': bool(ok),
+            'note': 'a Huffman stream is a chain of dependent table look-ups (two symbols a look-up where both codes fit 11 bits): four lanes of a '
+                    'wavefront per block, bound by instruction issue and LDS latency, not by HBM; libzstd takes 0.06 ms of one core per frame '
+                    '(2 048 frames: 123 ms of CPU, 7.7 ms on the 16 cores of the box)'}
+
+
 def from_fast5_leg(n_copies, local):
     """The path real input takes: .fast5 files on disk -> output files (upstream: get_workload opens one fast5 per read through
     Fast5.get_data_processed, src/caller/wrapper.py:44-54, src/schemas/fast5.py:45-57).  n_copies copies of the upstream test
@@ -776,7 +845,7 @@ def from_fast5_leg(n_copies, local):
         many = min(16, os.cpu_count() or 1)
         from warpstr_amd.loci import cpu_share, default_readers
         out['cpus'] = {'visible': os.cpu_count(), 'usable_under_the_cgroup_quota': cpu_share()}
-        knee = default_readers(many)   # reader processes of a run with sixteen host threads (the knee of reader_sweep below)
+        knee = default_readers(many, True)   # reader processes of a run with sixteen host threads (the knee of reader_sweep below)
         legs = [('one_process', 1, None, n_copies, 1), ('reader_processes', many, None, n_copies, 1),
                 # configs[4]'s shape from files: the same reads as eight loci (1 875 reads each at the default size)
                 ('reader_processes_eight_loci', many, None, n_copies, -(-n_copies // 8))]
@@ -784,7 +853,7 @@ def from_fast5_leg(n_copies, local):
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
             legs.append(('reader_processes_4x_the_copies', many, None, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
             # the reader count swept on the long run (60 000 reads at the default size): same host threads, 16 ... 128 readers
-            legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in (16, 32, 64, 128) if r <= (os.cpu_count() or 1)]
+            legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in (4, 8, 16, 32, 64, 128) if r <= (os.cpu_count() or 1)]
         only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
         for tag, threads, readers, n, per_locus in [leg for leg in legs if not only or leg[0] == only or leg[0].startswith(only + '.')]:
             loci = make(tag, n, per_locus)
@@ -875,6 +944,7 @@ def from_fast5_leg(n_copies, local):
                      'call includes a second zstd pass, subtracted')
         out['per_read_ms_one_process_cold'] = t
         out['vbz_decode_kernel'] = vbz_kernel_leg(os.path.join(real, 'batch_0.fast5'), local)
+        out['zstd_decode_kernels'] = zstd_kernel_leg(os.path.join(real, 'batch_0.fast5'), local)
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)

@@ -503,7 +503,7 @@ READER_POOL_FROM_LOCI = 64      # reader processes are started for a run of that
 READER_POOL_FROM_READS = 2048   # ... or of about that many reads (a few loci with thousands of reads each: configs[3] / [4])
 
 
-def _reader_pool(threads: int, loci, readers: Optional[int] = None):
+def _reader_pool(threads: int, loci, readers: Optional[int] = None, device_zstd: bool = False):
     """Worker processes for the fast5 files of a run, or None: one thread, or a run too small to be worth sixteen interpreters
     (fewer than READER_POOL_FROM_LOCI loci whose overview.csv files -- ~120 bytes a row -- do not hold READER_POOL_FROM_READS reads
     between them).  Only the START of the processes may fail here (no interpreter, no file descriptors): that is reported once
@@ -519,7 +519,7 @@ def _reader_pool(threads: int, loci, readers: Optional[int] = None):
                 pass
         if size < 120 * READER_POOL_FROM_READS:
             return None
-    return _WorkerPool(min(int(readers or default_readers(threads)), os.cpu_count() or 1))   # (an explicit `readers` is the caller's word)
+    return _WorkerPool(min(int(readers or default_readers(threads, device_zstd)), os.cpu_count() or 1))   # (an explicit `readers` is the caller's word)
 
 
 def cpu_share() -> int:
@@ -546,12 +546,16 @@ def cpu_share() -> int:
     return cpus
 
 
-def default_readers(threads: int) -> int:
+def default_readers(threads: int, device_zstd: bool = False) -> int:
     """Reader processes of a run with `threads` host threads when the caller does not say: as many as threads (upstream's
     `threads` is its pool size, src/caller/wrapper.py:107-109), never more than the CPUs the process may use (cpu_share) --
     bench.py's from_fast5.reader_sweep on the bench box, whose cgroup grants 16 CPUs: 16 / 32 / 64 / 128 readers = 49 / 55 / 35 /
-    22 k reads/s on 60 000 reads (profiles/r06_reader_sweep.json): past the share, more readers only take turns."""
-    return max(1, min(int(threads), cpu_share()))
+    22 k reads/s on 60 000 reads (profiles/r06_reader_sweep.json): past the share, more readers only take turns.  device_zstd: the
+    engine undoes the chunks' zstd frames itself (wsx_zstd_decode) and a reader's part of a read is libhdf5 alone (0.05 ms instead
+    of 0.14): half as many readers feed it, and the other half of the share is this process's own threads' -- 4 / 8 / 16 / 32
+    readers = 50 / 66 / 60 / 49 k reads/s (profiles/r06_reader_sweep_device_zstd.json)."""
+    n = max(1, min(int(threads), cpu_share()))
+    return max(2, n // 2) if device_zstd and n >= 4 else n
 
 
 def _started(pool, tm):
@@ -1033,7 +1037,10 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     # (the reader processes start first: they come up -- half a second of imports -- while the loci are set up.  On the bench's
     # sandboxed box sixteen interpreters starting slow whatever runs beside them: the set-up 0.3 -> 0.9 s for 3 000 loci; started
     # beside the handle's creation instead they cost that 0.2 -> 1.5 s.)
-    pool = _reader_pool(threads, [loci[i] for i in own], readers) if fast5_on_workers else None
+    engine_probe = _engine or HipEngine
+    zstd_on_device = (bool(getattr(engine_probe, 'DEVICE_ZSTD', False)) and hasattr(engine_probe, 'submit_vbz_parts')
+                      and not os.environ.get('WARPSTR_NO_GPU_ZSTD') and not os.environ.get('WARPSTR_NO_GPU_VBZ') and not os.environ.get('WARPSTR_NO_READER_ARENAS'))
+    pool = _reader_pool(threads, [loci[i] for i in own], readers, zstd_on_device) if fast5_on_workers else None
     pools.append(pool)
     tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
