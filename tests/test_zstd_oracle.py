@@ -14,8 +14,6 @@ from warpstr_amd import fast5
 
 try:
     _, ZS = fast5._libs()
-    ZS.ZSTD_compress.restype = C.c_size_t
-    ZS.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
     ZS.ZSTD_compressBound.restype = C.c_size_t
     ZS.ZSTD_compressBound.argtypes = [C.c_size_t]
     HAVE = True
@@ -41,7 +39,9 @@ def compress(data: bytes, level: int, checksum=False, no_size=False) -> bytes:
         n = ZS.ZSTD_compress2(cctx, dst.ctypes.data, cap, src.ctypes.data, len(src))
         ZS.ZSTD_freeCCtx(cctx)
     else:
-        n = ZS.ZSTD_compress(dst.ctypes.data, cap, src.ctypes.data, len(src), level)
+        # (through a prototype of its own: tests/helpers.py declares the library object's ZSTD_compress with other argument types)
+        fn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int)(('ZSTD_compress', ZS))
+        n = fn(dst.ctypes.data, cap, src.ctypes.data, len(src), level)
     assert not ZS.ZSTD_isError(n)
     return dst[:n].tobytes()
 
