@@ -7,19 +7,21 @@
 // The format is RFC 8878.  What a VBZ chunk of nanopore samples holds is almost nothing but Huffman-coded literals (the value bytes
 // of the StreamVByte block; the key bytes are the few matches): blocks of <= 128 KB, four interleaved-by-position streams each, a
 // handful of sequences.  Hence the shape of the kernel:
-//   * a workgroup per frame, a wavefront per block for the literals: lane 0 reads the tree description (direct weights, or FSE-coded
-//     weights decoded with two states), the wave builds the 2^max_bits-entry decoding table in LDS, lanes 0..3 decode the four
-//     streams side by side (a stream is a chain of dependent table look-ups: no parallelism inside it; the refill words are
-//     fetched a refill ahead);
-//   * then wave 0 alone walks the blocks in order: sequences section (predefined / RLE / FSE / repeat tables, built by lane 0 in
-//     LDS), decoded by lane 0 a few hundred sequences at a time, executed by the whole wave (literal run, match -- overlapping
-//     matches as a periodic copy), repeat offsets carried from block to block.
+//   * zstd_index_kernel: a thread per frame walks its block headers and lists its Huffman-coded blocks;
+//   * zstd_literals_kernel: a wavefront takes four blocks of the list (16 lanes each): lane 0 of a group reads the tree description
+//     (direct weights, or FSE-coded weights decoded with two states), the wave builds the 2^max_bits-cell decoding tables in LDS --
+//     two symbols a cell where both codes fit --, lanes 0..3 of every group decode the block's four streams side by side (a stream is
+//     a chain of dependent table look-ups: no parallelism inside it; the loop is branch-free and holds nothing but LDS);
+//   * zstd_sequences_kernel: a wavefront per frame walks the blocks in order: sequences section (predefined / RLE / FSE / repeat
+//     tables, built by lane 0 in LDS), decoded by lane 0 a few hundred sequences at a time, executed by the whole wave (literal run,
+//     match -- overlapping matches as a periodic copy), repeat offsets carried from block to block.
 // Everything the format allows is decoded except dictionaries, treeless literals (a block that reuses the tree of the block
-// before it: blocks are decoded side by side here) and frames of more than 32 blocks: the host never hands those over
+// before it: blocks are decoded side by side, whatever frame they belong to) and frames of more than 32 blocks: the host never hands those over
 // (warpstr_amd/_h5core.py / csrc/host_reader.cpp look at the headers and decompress such a frame themselves); a frame that turns out
 // corrupt sets its status and leaves its output undefined.  Pinned against libzstd (tests/test_gpu_zstd.py) and oracle/zstd_oracle.c.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -34,7 +36,6 @@ hipError_t wsx_internal_zstd_status(wsx_caller *c, size_t bytes, void **p);
 
 namespace {
 
-constexpr int ZB = 4;             // literal workgroups (one wavefront each) per frame: its blocks b, b + 4, ... are the b-th's
 constexpr int Z_MAX_BLOCKS = 32;  // blocks per frame (4 MB of content)
 constexpr int HUF_MAX_BITS = 11;
 constexpr int SEQ_CHUNK = 256;    // sequences decoded (lane 0) before the wave executes them
@@ -267,7 +268,9 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *
 }
 
 constexpr int Z_WIN = 256;     // bytes of a stream's compressed input a window holds; the ring of a stream is two windows
-constexpr int Z_OUT = 256;     // symbols a stream decodes between two flushes
+constexpr int Z_LOOKUPS = 66;  // look-ups a stream makes between two flushes (22 refills of three)
+constexpr int Z_OUT = 2 * Z_LOOKUPS + 2;   // ... and the room for their symbols (two a look-up, the last store may spill one byte)
+constexpr int ZG = 4;          // Huffman blocks a wavefront decodes side by side (a group of 16 lanes each: 4 decode, 16 fetch and flush)
 
 // A cell of the decoding table (one per max_bits-bit pattern): the symbol the pattern starts with -- and the next one where both
 // codes fit the pattern (nanopore value bytes average ~5 bits a symbol: two fit most of the time, and a symbol is a chain of
@@ -280,214 +283,122 @@ __device__ __forceinline__ uint32_t cell2(uint32_t c1, uint32_t c2, int max_bits
     return (c1 & 255u) | (l1 << 16) | (l1 << 20) | (1u << 24);
 }
 
-// The (up to four) Huffman streams of a block side by side (lanes 0..3), with nothing but LDS inside the symbol loop: a global
-// load or store between two look-ups (and the s_waitcnt they share with everything else) costs more than the look-up.
-//   input : every stream has a ring of two 256-byte windows of its compressed bytes (windows are aligned on absolute addresses:
-//           the whole wave fetches the next window of all four streams with one 16-byte load per lane);
-//   output: 256 symbols per stream collect in LDS and leave together (lane = 16 bytes of a stream).
-// q[0..3] / q[4..7]: the streams' bytes [begin, end) as offsets from `base`, q[8..11] their symbol counts (0: no such stream);
-// base_lo / base_hi: the offsets from `base` that may be read at all.  dst: where stream 0's symbols go, stream s's at dst + s * per.
-// Returns Z_OK when every stream ends exactly where its last symbol does.  All 64 lanes call this.
-__device__ int huf_streams(const uint32_t *table, int max_bits, const uint8_t *base, long long base_lo, long long base_hi, const int *q, uint8_t *dst,
-                           int per, uint8_t *ring, uint8_t *obuf, int lane)
-{
-    const int s = lane & 3;                         // the stream a decoding lane works on (lanes 0..3)
-    const int fs = lane >> 4, fj = lane & 15;       // as a fetching / flushing lane: stream fs, its 16-byte piece fj
-    const uintptr_t ab = (uintptr_t)base;
-    const int lo_off = q[s], hi_off = q[4 + s], want = q[8 + s];
-    const bool dec = lane < 4 && want > 0;
-    const bool fetches = q[8 + fs] > 0;
-    int st = Z_OK;
-    if (dec && (hi_off - lo_off < 1 || base[hi_off - 1] == 0)) st = Z_CORRUPT;
-    uint64_t cont = 0;
-    int used = 0, total = 0, done = 0;
-    long long p = (long long)hi_off - 8;            // offset of the container's lowest byte
-    if (dec && st == Z_OK) {
-        for (int i = 0; i < 8; i++) {
-            const long long a = p + i;
-            cont |= (uint64_t)(a >= lo_off ? base[a] : 0) << (8 * i);
-        }
-        used = 8 - hibit(base[hi_off - 1]);
-        total = (hi_off - lo_off) * 8 - used;
-    }
-    // window w of a stream = absolute addresses [w * Z_WIN, (w + 1) * Z_WIN); ring index = address mod 2 Z_WIN
-    auto top_window = [&](int k) { return (long long)(((ab + (uintptr_t)q[4 + k] - 1) / Z_WIN) * Z_WIN); };
-    long long fetch_lo = top_window(fs) + Z_WIN;    // lowest absolute address the ring of MY fetch stream holds (nothing yet)
-    long long my_lo = top_window(s) + Z_WIN;        // the same for the stream this lane decodes
-    auto fetch = [&](bool go) {                     // the next lower window of stream fs (every lane takes part; go: the stream wants it)
-        if (go) {
-            const long long a = fetch_lo - Z_WIN + 16 * fj;             // absolute address of this lane's 16 bytes
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 v = {0, 0, 0, 0};
-            const long long rel = a - (long long)ab;
-            if (rel >= base_lo && rel + 16 <= base_hi) v = *(const u32x4 *)(uintptr_t)a;
-            else if (rel + 16 > base_lo && rel < base_hi) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int i = 0; i < 16; i++)
-                    if (rel + i >= base_lo && rel + i < base_hi) t[i >> 2] |= (uint32_t)base[rel + i] << (8 * (i & 3));
-                v = u32x4{t[0], t[1], t[2], t[3]};
-            }
-            *(u32x4 *)(ring + fs * 2 * Z_WIN + (int)(a & (2 * Z_WIN - 1))) = v;
-            fetch_lo -= Z_WIN;
-        }
-    };
-    fetch(fetches);
-    fetch(fetches);
-    my_lo -= 2 * Z_WIN;
-    wave_sync();
-    const int shift = 64 - max_bits;
-    const uint8_t *myring = ring + s * 2 * Z_WIN;
-    uint8_t *myout = obuf + s * (Z_OUT + 2);
-    int flushed = 0;                                // symbols of MY fetch stream already in dst (every flushing lane of it keeps count)
-    // four more bytes from below into the container; false: the ring does not hold them yet
-    auto refill = [&]() -> bool {
-        const long long a = ((long long)ab + p - 4) & ~3ll;              // absolute address of the aligned word that holds p - 4
-        if (a < my_lo) return false;
-        const uint32_t wlo = *(const uint32_t *)(myring + (int)(a & (2 * Z_WIN - 1)));
-        const uint32_t whi = *(const uint32_t *)(myring + (int)((a + 4) & (2 * Z_WIN - 1)));
-        uint32_t w = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)(((long long)ab + p - 4) & 3));
-        const long long have = p - lo_off;          // bytes of the stream below p: what lies below the stream reads as zero
-        if (have < 4) w = have <= 0 ? 0u : w & (~0u << (8 * (4 - (int)have)));
-        cont = (cont << 32) | w;
-        used -= 32;
-        p -= 4;
-        return true;
-    };
-    for (;;) {
-        int cnt = 0;                                // symbols in the output buffer
-        bool need_input = false;
-        if (dec && st == Z_OK) {
-            // fast: after a refill `used` < 32 and a look-up takes at most 11 bits -- three look-ups (up to six symbols) need no check
-            while (done + 6 <= want && cnt + 6 <= Z_OUT) {
-                if (used >= 32 && !refill()) { need_input = true; break; }
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
-                    const int bits = (e >> 16) & 15, ns = (int)(e >> 24);
-                    *(uint16_t *)(myout + cnt) = (uint16_t)e;   // (both symbols; a single one's second byte is overwritten by the next)
-                    used += bits, total -= bits, cnt += ns, done += ns;
-                }
-            }
-            // the last few symbols of the stream (or of the buffer) one at a time
-            while (!need_input && done < want && cnt < Z_OUT && (done + 6 > want || cnt + 6 > Z_OUT)) {
-                if (used >= 32 && !refill()) { need_input = true; break; }
-                const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
-                const int bits = (e >> 20) & 15;
-                myout[cnt++] = (uint8_t)e;
-                used += bits, total -= bits, done++;
-            }
-        }
-        wave_sync();
-        // ---- flush: lane (fs, fj) writes bytes 16 fj .. of stream fs's buffer; then fetch where a stream wants its next window ----
-        const int cnt_fs = __shfl(cnt, fs, 64), need_fs = __shfl((int)need_input, fs, 64);
-        {
-            uint8_t *d = dst + (long long)fs * per + flushed;
-            const uint8_t *o = obuf + fs * (Z_OUT + 2);
-            for (int k = 16 * fj; k < 16 * fj + 16 && k < cnt_fs; k++) d[k] = o[k];
-            flushed += cnt_fs;
-        }
-        // a stream takes its next window as soon as the upper one is used up (a refill reads the aligned words around p - 4: up to p + 3)
-        const long long p_fs = ((long long)__shfl((int)(p >> 32), fs, 64) << 32) | (uint32_t)__shfl((int)p, fs, 64);
-        fetch(fetches && (need_fs || ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN));
-        if (dec && (need_input || ((long long)ab + p + 8) <= my_lo + Z_WIN)) my_lo -= Z_WIN;
-        wave_sync();
-        const int left = (dec && st == Z_OK) ? want - done : 0;
-        if (!__any(left > 0)) break;
-    }
-    if (dec && st == Z_OK && total != 0) st = Z_CORRUPT;
-    return st;
-}
+// a Huffman block of a launch: what zstd_index_kernel leaves for zstd_literals_kernel
+struct HufWork {
+    int frame;     // index into frames[]
+    int src;       // first byte of the block's literals section, relative to the frame
+    int comp_end;  // ... and of its sequences section (where the literals section ends)
+    int lit_at;    // where the block's literals go in the frame's literal area
+    int regen;     // how many there are
+    int reserved;
+};
 
-// ---- kernel 1: the literals of block b, b + ZB, ... of a frame (blockIdx = frame * ZB + b), one wavefront --------------------------
-__global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__restrict__ src, long long src_total, const wsx_zstd_frame *__restrict__ frames,
-                                                          uint8_t *__restrict__ lits, int32_t *__restrict__ status)
+// ---- kernel 0: a thread per frame walks its block headers and lists its Huffman-coded blocks ------------------------------------
+__global__ __launch_bounds__(64) void zstd_index_kernel(const uint8_t *__restrict__ src, const wsx_zstd_frame *__restrict__ frames, int n_frames,
+                                                      HufWork *__restrict__ work, int *__restrict__ n_work, int32_t *__restrict__ status)
 {
-    __shared__ BlockRec blocks[Z_MAX_BLOCKS];
-    __shared__ int n_blocks, frame_status;
-    __shared__ uint32_t huf2[1 << HUF_MAX_BITS];                       // the two-symbol table
-    // the one-symbol table it is made from; once it is made the same bytes are the streams' input rings and output buffers
-    __shared__ __attribute__((aligned(16))) uint8_t work[(2 << HUF_MAX_BITS)];
-    static_assert(4 * 2 * Z_WIN + 4 * (Z_OUT + 2) <= (2 << HUF_MAX_BITS), "rings + output buffers fit the one-symbol table's place");
-    __shared__ uint8_t huf_w[256];              // weights, then code lengths
-    __shared__ uint16_t huf_start[256];         // first cell of every symbol
-    __shared__ FseTableW fse_w;
-    __shared__ int16_t freq_s[256];
-    __shared__ uint16_t next_s[256];
-    __shared__ int info[4], strm[12];
-
-    const int frame = blockIdx.x / ZB, slot = blockIdx.x % ZB, lane = threadIdx.x;
+    const int frame = blockIdx.x * 64 + threadIdx.x;
+    if (frame >= n_frames) return;
     const wsx_zstd_frame F = frames[frame];
-    const uint8_t *f = src + F.src_offset;
-    const int flen = (int)F.src_bytes;
-    uint8_t *lit = lits + F.dst_offset;
-    if (lane == 0) {
-        int nb = 0;
-        frame_status = walk_blocks(f, flen, F.dst_bytes, blocks, &nb);
-        n_blocks = nb;
-    }
-    wave_sync();
-    if (frame_status != Z_OK) {   // (kernel 2 walks the headers again and reports it)
+    BlockRec blocks[Z_MAX_BLOCKS];
+    int nb = 0;
+    const int st = walk_blocks(src + F.src_offset, (int)F.src_bytes, F.dst_bytes, blocks, &nb);
+    if (st != Z_OK) {
+        status[frame] = st;
         return;
     }
-    for (int b = slot; b < n_blocks; b += ZB) {
-        const BlockRec B = blocks[b];
-        if (B.type != 2) continue;
-        const uint8_t *p = f + B.src;
-        const int b0 = p[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
-        const int hl = ltype < 2 ? ((sf == 0 || sf == 2) ? 1 : sf == 1 ? 2 : 3) : (sf < 2 ? 3 : sf + 2);
-        const int regen = B.regen, comp = B.seq_at - B.src - hl;
-        uint8_t *L = lit + B.lit_at;
-        if (ltype == 0) {
-            wave_copy(L, p + hl, regen, lane);
-            continue;
-        }
-        if (ltype == 1) {
-            const uint8_t v = p[hl];
-            for (int i = lane; i < regen; i += 64) L[i] = v;
-            continue;
-        }
-        const int streams = sf == 0 ? 1 : 4;
-        const uint8_t *lp = p + hl;
-        uint8_t *w = huf_w;
-        if (lane == 0) {   // the tree description: weights
-            int st = Z_OK, n = 0, took = 0;
-            const int hb = comp >= 1 ? lp[0] : 0;
-            if (comp < 1) st = Z_CORRUPT;
-            else if (hb >= 128) {
-                n = hb - 127;
-                const int bytes = (n + 1) / 2;
-                if (1 + bytes > comp) st = Z_CORRUPT;
-                else
-                    for (int i = 0; i < n; i++) w[i] = (i & 1) ? lp[1 + i / 2] & 15 : lp[1 + i / 2] >> 4;
-                took = 1 + bytes;
-            } else {
-                int h = 0;
-                if (hb == 0 || 1 + hb > comp) st = Z_CORRUPT;
-                else st = fse_read(fse_w, lp + 1, hb, 6, 255, freq_s, next_s, &h);
-                if (st == Z_OK) {
-                    const FseTableW &ft = fse_w;
-                    const uint8_t *bs = lp + 1 + h;
-                    const int bl = hb - h;
-                    if (bl < 1 || bs[bl - 1] == 0) st = Z_CORRUPT;
-                    else {
-                        int off = bl * 8 - (8 - hibit(bs[bl - 1]));
-                        uint32_t s1 = (uint32_t)back_bits(bs, ft.al, off), s2 = (uint32_t)back_bits(bs, ft.al, off);
-                        for (;;) {
-                            if (n >= 255) { st = Z_CORRUPT; break; }
-                            w[n++] = ft.symbol[s1];
-                            s1 = ft.base[s1] + (uint32_t)back_bits(bs, ft.nbits[s1], off);
-                            if (off < 0) { w[n++] = ft.symbol[s2]; break; }
-                            if (n >= 255) { st = Z_CORRUPT; break; }
-                            w[n++] = ft.symbol[s2];
-                            s2 = ft.base[s2] + (uint32_t)back_bits(bs, ft.nbits[s2], off);
-                            if (off < 0) { w[n++] = ft.symbol[s1]; break; }
+    const uint8_t *f = src + F.src_offset;
+    for (int b = 0; b < nb; b++) {
+        if (blocks[b].type != 2 || (f[blocks[b].src] & 3) != 2) continue;   // (raw and RLE literals: the sequence kernel reads them where they lie)
+        const int at = atomicAdd(n_work, 1);
+        work[at] = HufWork{frame, blocks[b].src, blocks[b].seq_at, blocks[b].lit_at, blocks[b].regen, 0};
+    }
+}
+
+// ---- kernel 1: the Huffman literals, four blocks to a wavefront ------------------------------------------------------------------
+// Lane = 16 g + j: group g works on block 4 w + g of the list.  Its lane 0 reads the tree description; all 64 lanes build the four
+// tables one after the other; then lanes j < 4 decode the block's four streams while all sixteen lanes of the group fetch the
+// streams' next input windows and flush their symbols.  The symbol loop is branch-free and holds nothing but LDS: a stream is a chain
+// of dependent look-ups, a global load or store between two of them (and the s_waitcnt they share with everything else) costs more
+// than the look-up, and so does the bookkeeping of lanes that leave a loop at different times.
+//   input : every stream has a ring of two 256-byte windows of its compressed bytes, aligned on absolute addresses; between two
+//           flushes a stream takes at most 66 x 11 bits = 91 bytes, and its next window is fetched as soon as the upper one is used
+//           up -- so a refill never finds the ring short;
+//   output: up to 132 symbols a stream collect in LDS and leave together.
+__global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__restrict__ src, long long src_total, const wsx_zstd_frame *__restrict__ frames,
+                                                          const HufWork *__restrict__ work, const int *__restrict__ n_work_p, uint8_t *__restrict__ lits,
+                                                          int32_t *__restrict__ status)
+{
+    __shared__ uint32_t huf2[ZG][1 << HUF_MAX_BITS];                  // the two-symbol tables
+    // scratch of the set-up (normalised counts; the one-symbol table a two-symbol table is made from), then the streams' input rings
+    // and output buffers
+    constexpr int RING_BYTES = ZG * 4 * 2 * Z_WIN, OBUF_BYTES = ZG * 4 * Z_OUT;
+    constexpr int WORK_BYTES = RING_BYTES + OBUF_BYTES > (2 << HUF_MAX_BITS) ? RING_BYTES + OBUF_BYTES : (2 << HUF_MAX_BITS);
+    __shared__ __attribute__((aligned(16))) uint8_t workmem[WORK_BYTES];
+    static_assert(ZG * 1024 <= WORK_BYTES, "the groups' count arrays fit the scratch");
+    __shared__ uint8_t huf_w[ZG][256];           // weights, then code lengths
+    __shared__ uint16_t huf_start[ZG][256];      // first cell of every symbol
+    __shared__ FseTableW fse_w[ZG];
+    __shared__ int info[ZG][4], strm[ZG][12];
+
+    const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+    const int n_work = *n_work_p;
+    for (int base_item = blockIdx.x * ZG; base_item < n_work; base_item += gridDim.x * ZG) {
+        const int item = base_item + g;
+        const bool have = item < n_work;
+        const HufWork W = have ? work[item] : HufWork{0, 0, 0, 0, 0, 0};
+        const wsx_zstd_frame F = frames[W.frame];
+        const uint8_t *f = src + F.src_offset;
+        const uint8_t *p = f + W.src;
+        // ---- the tree description of the group's block (its lane 0) ----
+        if (j == 0) {
+            int st = have ? Z_OK : Z_UNSUPPORTED, n = 0, took = 0, max_bits = 0, hl = 0, comp = 0, streams = 1;
+            uint8_t *w = huf_w[g];
+            int16_t *freq_s = (int16_t *)(workmem + g * 1024);
+            uint16_t *next_s = (uint16_t *)(workmem + g * 1024 + 512);
+            if (st == Z_OK) {
+                const int sf = (p[0] >> 2) & 3;
+                hl = sf < 2 ? 3 : sf + 2;
+                comp = W.comp_end - W.src - hl;
+                streams = sf == 0 ? 1 : 4;
+                const uint8_t *lp = p + hl;
+                const int hb = comp >= 1 ? lp[0] : 0;
+                if (comp < 1) st = Z_CORRUPT;
+                else if (hb >= 128) {
+                    n = hb - 127;
+                    const int bytes = (n + 1) / 2;
+                    if (1 + bytes > comp) st = Z_CORRUPT;
+                    else
+                        for (int i = 0; i < n; i++) w[i] = (i & 1) ? lp[1 + i / 2] & 15 : lp[1 + i / 2] >> 4;
+                    took = 1 + bytes;
+                } else {
+                    int h = 0;
+                    if (hb == 0 || 1 + hb > comp) st = Z_CORRUPT;
+                    else st = fse_read(fse_w[g], lp + 1, hb, 6, 255, freq_s, next_s, &h);
+                    if (st == Z_OK) {
+                        const FseTableW &ft = fse_w[g];
+                        const uint8_t *bs = lp + 1 + h;
+                        const int bl = hb - h;
+                        if (bl < 1 || bs[bl - 1] == 0) st = Z_CORRUPT;
+                        else {
+                            int off = bl * 8 - (8 - hibit(bs[bl - 1]));
+                            uint32_t s1 = (uint32_t)back_bits(bs, ft.al, off), s2 = (uint32_t)back_bits(bs, ft.al, off);
+                            for (;;) {
+                                if (n >= 255) { st = Z_CORRUPT; break; }
+                                w[n++] = ft.symbol[s1];
+                                s1 = ft.base[s1] + (uint32_t)back_bits(bs, ft.nbits[s1], off);
+                                if (off < 0) { w[n++] = ft.symbol[s2]; break; }
+                                if (n >= 255) { st = Z_CORRUPT; break; }
+                                w[n++] = ft.symbol[s2];
+                                s2 = ft.base[s2] + (uint32_t)back_bits(bs, ft.nbits[s2], off);
+                                if (off < 0) { w[n++] = ft.symbol[s1]; break; }
+                            }
                         }
                     }
+                    took = 1 + hb;
                 }
-                took = 1 + hb;
             }
             // weights -> code lengths (the last weight completes a power of two), then the first cell of every symbol
-            int max_bits = 0;
             if (st == Z_OK) {
                 uint64_t sum = 0;
                 for (int i = 0; i < n; i++) {
@@ -512,68 +423,165 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                         if (idx[0] != (1u << max_bits)) st = Z_CORRUPT;
                         else
                             for (int s = 0; s < n; s++) {
-                                huf_start[s] = w[s] ? (uint16_t)idx[w[s]] : 0;
+                                huf_start[g][s] = w[s] ? (uint16_t)idx[w[s]] : 0;
                                 if (w[s]) idx[w[s]] += 1u << (max_bits - w[s]);
                             }
                     }
                 }
             }
-            info[0] = max_bits, info[1] = n, info[2] = st, info[3] = took;
-        }
-        wave_sync();
-        if (info[2] != Z_OK) {
-            if (lane == 0 && status) atomicMax(&status[frame], info[2]);
-            continue;
-        }
-        const int max_bits = info[0], nsym = info[1], took = info[3];
-        uint16_t *huf1 = (uint16_t *)work;
-        for (int s = 0; s < nsym; s++) {   // the one-symbol table: symbol s fills 2^(max_bits - length) cells
-            const int len_bits = w[s];
-            if (!len_bits) continue;
-            const int cells = 1 << (max_bits - len_bits), c0 = huf_start[s];
-            const uint16_t cell = (uint16_t)((len_bits << 8) | s);
-            for (int i = lane; i < cells; i += 64) huf1[c0 + i] = cell;
-        }
-        wave_sync();
-        for (int i = lane; i < (1 << max_bits); i += 64) {   // ... and the two-symbol table from it: the cell of what follows the first code
-            const uint32_t c1 = huf1[i];
-            huf2[i] = cell2(c1, huf1[(i << (c1 >> 8)) & ((1 << max_bits) - 1)], max_bits);
-        }
-        wave_sync();
-        const uint8_t *sp = lp + took;
-        const int sl = comp - took;
-        int st = Z_OK;
-        if (lane == 0) {
-            const int first = (int)(sp - f);
-            if (streams == 1) {
-                if (sl < 1) st = Z_CORRUPT;
-                strm[0] = first, strm[4] = first + sl, strm[8] = regen;
-                for (int k = 1; k < 4; k++) strm[k] = strm[4 + k] = first, strm[8 + k] = 0;
-                info[1] = regen;   // (the stride between the streams' outputs: irrelevant for one stream)
-            } else {
-                const int s1 = sl >= 6 ? sp[0] | (sp[1] << 8) : 0, s2 = sl >= 6 ? sp[2] | (sp[3] << 8) : 0, s3 = sl >= 6 ? sp[4] | (sp[5] << 8) : 0;
-                const int s4 = sl - 6 - s1 - s2 - s3, per = (regen + 3) / 4, lastn = regen - 3 * per;
-                if (sl < 6 || s4 < 1 || s1 < 1 || s2 < 1 || s3 < 1 || lastn < 1) st = Z_CORRUPT;
-                strm[0] = first + 6, strm[1] = strm[0] + s1, strm[2] = strm[1] + s2, strm[3] = strm[2] + s3;
-                strm[4] = strm[1], strm[5] = strm[2], strm[6] = strm[3], strm[7] = strm[3] + s4;
-                strm[8] = strm[9] = strm[10] = per, strm[11] = lastn;
-                info[1] = per;
+            // the streams: their bytes and how many symbols each brings
+            int *q = strm[g];
+            for (int k = 0; k < 12; k++) q[k] = 0;
+            int per = W.regen;
+            if (st == Z_OK) {
+                const uint8_t *sp = p + hl + took;
+                const int sl = comp - took, first = (int)(sp - f);
+                if (streams == 1) {
+                    if (sl < 1) st = Z_CORRUPT;
+                    q[0] = first, q[4] = first + sl, q[8] = W.regen;
+                } else {
+                    const int s1 = sl >= 6 ? sp[0] | (sp[1] << 8) : 0, s2 = sl >= 6 ? sp[2] | (sp[3] << 8) : 0, s3 = sl >= 6 ? sp[4] | (sp[5] << 8) : 0;
+                    const int s4 = sl - 6 - s1 - s2 - s3, lastn = W.regen - 3 * ((W.regen + 3) / 4);
+                    per = (W.regen + 3) / 4;
+                    if (sl < 6 || s4 < 1 || s1 < 1 || s2 < 1 || s3 < 1 || lastn < 1) st = Z_CORRUPT;
+                    q[0] = first + 6, q[1] = q[0] + s1, q[2] = q[1] + s2, q[3] = q[2] + s3;
+                    q[4] = q[1], q[5] = q[2], q[6] = q[3], q[7] = q[3] + s4;
+                    q[8] = q[9] = q[10] = per, q[11] = lastn;
+                }
+                if (st != Z_OK)
+                    for (int k = 8; k < 12; k++) q[k] = 0;
             }
-            info[2] = st;
+            info[g][0] = max_bits, info[g][1] = n, info[g][2] = st, info[g][3] = per;
+            if (have && st != Z_OK && status) atomicMax(&status[W.frame], st);
         }
         wave_sync();
-        st = info[2];
-        // (what may be read: the whole source buffer -- a window is 256 aligned bytes and may reach into the frames beside this one)
-        if (st == Z_OK)
-            st = huf_streams(huf2, max_bits, f, -(long long)F.src_offset, src_total - F.src_offset, strm, L, info[1], work, work + 4 * 2 * Z_WIN, lane);
-        if (st != Z_OK && status) atomicMax(&status[frame], st);
+        // ---- the four tables, one after the other, by all 64 lanes ----
+        for (int t = 0; t < ZG; t++) {
+            if (info[t][2] != Z_OK) continue;
+            const int max_bits = info[t][0], nsym = info[t][1];
+            uint16_t *huf1 = (uint16_t *)workmem;
+            for (int s = 0; s < nsym; s++) {   // the one-symbol table: symbol s fills 2^(max_bits - length) cells
+                const int len_bits = huf_w[t][s];
+                if (!len_bits) continue;
+                const int cells = 1 << (max_bits - len_bits), c0 = huf_start[t][s];
+                const uint16_t cell = (uint16_t)((len_bits << 8) | s);
+                for (int i = lane; i < cells; i += 64) huf1[c0 + i] = cell;
+            }
+            wave_sync();
+            for (int i = lane; i < (1 << max_bits); i += 64) {   // ... and the two-symbol table: the cell of what follows the first code
+                const uint32_t c1 = huf1[i];
+                huf2[t][i] = cell2(c1, huf1[(i << (c1 >> 8)) & ((1 << max_bits) - 1)], max_bits);
+            }
+            wave_sync();
+        }
+        // ---- the streams ----
+        const int *q = strm[g];
+        const bool ok = info[g][2] == Z_OK;
+        const int max_bits = ok ? info[g][0] : HUF_MAX_BITS, per = info[g][3];
+        uint8_t *L = lits + F.dst_offset + W.lit_at;
+        const long long base_lo = -(long long)F.src_offset, base_hi = src_total - F.src_offset;   // what may be read, relative to f
+        const uintptr_t ab = (uintptr_t)f;
+        const int s = j & 3;                            // the stream a decoding lane works on (j < 4)
+        const int fs = j >> 2, fj = j & 3;              // as a fetching / flushing lane: stream fs, its quarter fj
+        const int lo_off = q[s], hi_off = q[4 + s], want = q[8 + s];
+        const bool dec = ok && j < 4 && want > 0;
+        const bool fetches = ok && q[8 + fs] > 0;
+        int st = Z_OK;
+        if (dec && (hi_off - lo_off < 1 || f[hi_off - 1] == 0)) st = Z_CORRUPT;
+        uint64_t cont = 0;
+        int used = 0, total = 0, done = 0;
+        long long pp = (long long)hi_off - 8;           // offset of the container's lowest byte
+        if (dec && st == Z_OK) {
+            for (int i = 0; i < 8; i++) {
+                const long long a = pp + i;
+                cont |= (uint64_t)(a >= lo_off ? f[a] : 0) << (8 * i);
+            }
+            used = 8 - hibit(f[hi_off - 1]);
+            total = (hi_off - lo_off) * 8 - used;
+        }
+        const bool live = dec && st == Z_OK;
+        uint8_t *ring = workmem + (g * 4) * 2 * Z_WIN, *obuf = workmem + RING_BYTES + (g * 4) * Z_OUT;
+        // window w of a stream = absolute addresses [w * Z_WIN, (w + 1) * Z_WIN); ring index = address mod 2 Z_WIN
+        long long fetch_lo = fetches ? (long long)(((ab + (uintptr_t)q[4 + fs] - 1) / Z_WIN) * Z_WIN) + Z_WIN : 0;   // lowest address held
+        auto fetch = [&](bool go) {                     // the next lower window of stream fs: four lanes, four 16-byte pieces each
+            if (go) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long a = fetch_lo - Z_WIN + 64 * k + 16 * fj;
+                    u32x4 v = {0, 0, 0, 0};
+                    const long long rel = a - (long long)ab;
+                    if (rel >= base_lo && rel + 16 <= base_hi) v = *(const u32x4 *)(uintptr_t)a;
+                    else if (rel + 16 > base_lo && rel < base_hi) {
+                        uint32_t t4[4] = {0, 0, 0, 0};
+                        for (int i = 0; i < 16; i++)
+                            if (rel + i >= base_lo && rel + i < base_hi) t4[i >> 2] |= (uint32_t)f[rel + i] << (8 * (i & 3));
+                        v = u32x4{t4[0], t4[1], t4[2], t4[3]};
+                    }
+                    *(u32x4 *)(ring + fs * 2 * Z_WIN + (int)(a & (2 * Z_WIN - 1))) = v;
+                }
+                fetch_lo -= Z_WIN;
+            }
+        };
+        fetch(fetches);
+        fetch(fetches);
+        wave_sync();
+        const int shift = 64 - max_bits;
+        const uint8_t *myring = ring + s * 2 * Z_WIN;
+        uint8_t *myout = obuf + s * Z_OUT;
+        const uint32_t *table = huf2[g];
+        int flushed = 0;                                // symbols of MY fetch stream already written
+        for (;;) {
+            int cnt = 0;
+            if (live) {
+                for (int it = 0; it < Z_LOOKUPS / 3; it++) {
+                    // four more bytes from below when 32 bits are used up (the ring holds them: see above); no branch
+                    const long long a = ((long long)ab + pp - 4) & ~3ll;
+                    const uint32_t wlo = *(const uint32_t *)(myring + (int)(a & (2 * Z_WIN - 1)));
+                    const uint32_t whi = *(const uint32_t *)(myring + (int)((a + 4) & (2 * Z_WIN - 1)));
+                    uint32_t w = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)(((long long)ab + pp - 4) & 3));
+                    const long long below = pp - lo_off;   // bytes of the stream below pp: what lies below the stream reads as zero
+                    w = below >= 4 ? w : below <= 0 ? 0u : w & (~0u << (8 * (4 - (int)below)));
+                    const bool re = used >= 32;
+                    cont = re ? (cont << 32) | w : cont;
+                    used = re ? used - 32 : used;
+                    pp = re ? pp - 4 : pp;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
+                        const int ns = (int)(e >> 24), rem = want - done;
+                        const int take = ns < rem ? ns : rem;
+                        const int bits = take == ns ? (int)((e >> 16) & 15) : take ? (int)((e >> 20) & 15) : 0;
+                        *(uint16_t *)(myout + cnt) = (uint16_t)e;   // (both symbols; what is not taken is overwritten or never flushed)
+                        used += bits, total -= bits, cnt += take, done += take;
+                    }
+                }
+            }
+            wave_sync();
+            // ---- flush: the four lanes of stream fs write a quarter of its buffer each; then its next window where the upper is used up ----
+            const int src_lane = (lane & ~15) | fs;
+            const int cnt_fs = __shfl(cnt, src_lane, 64);
+            {
+                uint8_t *d = L + (long long)fs * per + flushed;
+                const uint8_t *o = obuf + fs * Z_OUT;
+                const int q0 = (cnt_fs * fj) >> 2, q1 = (cnt_fs * (fj + 1)) >> 2;
+                for (int k = q0; k < q1; k++) d[k] = o[k];
+                flushed += cnt_fs;
+            }
+            const long long p_fs = ((long long)__shfl((int)(pp >> 32), src_lane, 64) << 32) | (uint32_t)__shfl((int)pp, src_lane, 64);
+            fetch(fetches && ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN);   // (a refill reads the aligned words around pp - 4: up to pp + 3)
+            wave_sync();
+            if (!__any(live && done < want)) break;
+        }
+        if (live && total != 0) st = Z_CORRUPT;
+        if (dec && st != Z_OK && status) atomicMax(&status[W.frame], st);
         wave_sync();
     }
 }
 
 // ---- kernel 2: a wavefront per frame walks its blocks in order -- raw, RLE, or sequences executed over the literals ---------------
 __global__ __launch_bounds__(64) void zstd_sequences_kernel(const uint8_t *__restrict__ src, const wsx_zstd_frame *__restrict__ frames, uint8_t *__restrict__ dst,
-                                                           const uint8_t *__restrict__ lits, int32_t *__restrict__ status)
+                                                           uint8_t *lits_w, int32_t *__restrict__ status)
 {
     __shared__ BlockRec blocks[Z_MAX_BLOCKS];
     __shared__ int n_blocks, frame_status;
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(64) void zstd_sequences_kernel(const uint8_t *__res
     const wsx_zstd_frame F = frames[frame];
     const uint8_t *f = src + F.src_offset;
     uint8_t *out = dst + F.dst_offset;
-    const uint8_t *lit = lits + F.dst_offset;
+    const uint8_t *lit = lits_w + F.dst_offset;
     const long long cap = F.dst_bytes;
     if (lane == 0) {
         int nb = 0;
@@ -614,6 +622,18 @@ __global__ __launch_bounds__(64) void zstd_sequences_kernel(const uint8_t *__res
             continue;
         }
         const uint8_t *L = lit + B.lit_at;
+        {   // raw and RLE literals are not in the literal area yet (zstd_literals_kernel does the Huffman-coded ones): put them there
+            const uint8_t *lp = f + B.src;
+            const int ltype = lp[0] & 3, sf = (lp[0] >> 2) & 3;
+            if (ltype < 2) {
+                const int hl = (sf == 0 || sf == 2) ? 1 : sf == 1 ? 2 : 3;
+                uint8_t *Lw = lits_w + F.dst_offset + B.lit_at;
+                if (ltype == 0) wave_copy(Lw, lp + hl, B.regen, lane);
+                else
+                    for (int i = lane; i < B.regen; i += 64) Lw[i] = lp[hl];
+                __threadfence_block();
+            }
+        }
         const uint8_t *sq = f + B.seq_at;
         const int ql = B.src + B.size - B.seq_at;
         // the section's header and its three tables (lane 0), then chunks of sequences: decoded by lane 0, executed by the wave
@@ -759,7 +779,7 @@ try {
         wsx_internal_set_error("wsx_zstd_decode: null or negative argument");
         return WSX_ERR_INVALID;
     }
-    if (n_frames > 0x7fffffff / ZB) {
+    if (n_frames > 0x7fffffff / Z_MAX_BLOCKS) {
         wsx_internal_set_error("wsx_zstd_decode: too many frames in one call");
         return WSX_ERR_INVALID;
     }
@@ -786,17 +806,28 @@ try {
     memcpy(h, frames, bytes);
     ZCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
     ZCHK(hipEventRecord(ev, st));
-    // the status array is the literal kernel's way to tell the sequence kernel of a corrupt stream: it exists in any case
-    int32_t *st_dev = status;
-    if (!st_dev) {
-        void *p = nullptr;
-        ZCHK(wsx_internal_zstd_status(c, (size_t)n_frames * sizeof(int32_t), &p));
-        st_dev = (int32_t *)p;
-    }
+    // device scratch of the call: the status array (the index and literal kernels tell the sequence kernel of a corrupt frame through
+    // it: it exists whether the caller wants it or not), the counter and the list of Huffman blocks
+    const size_t st_bytes = ((size_t)n_frames * sizeof(int32_t) + 63) & ~(size_t)63;
+    const size_t list_bytes = (size_t)n_frames * Z_MAX_BLOCKS * sizeof(HufWork);
+    void *pscr = nullptr;
+    ZCHK(wsx_internal_zstd_status(c, st_bytes + 64 + list_bytes, &pscr));
+    int32_t *st_own = (int32_t *)pscr;
+    int *counter = (int *)((char *)pscr + st_bytes);
+    HufWork *list = (HufWork *)((char *)pscr + st_bytes + 64);
+    int32_t *st_dev = status ? status : st_own;
     ZCHK(hipMemsetAsync(st_dev, 0, (size_t)n_frames * sizeof(int32_t), st));
-    hipLaunchKernelGGL(zstd_literals_kernel, dim3((unsigned)(n_frames * ZB)), dim3(64), 0, st, src, (long long)src_bytes, (const wsx_zstd_frame *)d, scratch, st_dev);
+    ZCHK(hipMemsetAsync(counter, 0, sizeof(int), st));
+    hipLaunchKernelGGL(zstd_index_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, (int)n_frames, list, counter, st_dev);
     ZCHK(hipGetLastError());
-    hipLaunchKernelGGL(zstd_sequences_kernel, dim3((unsigned)n_frames), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, dst, (const uint8_t *)scratch, st_dev);
+    // blocks a launch may bring: a block holds at most 128 KB of content; the grid strides over whatever the count turns out to be
+    int64_t est = n_frames;
+    for (int64_t i = 0; i < n_frames; i++) est += frames[i].dst_bytes >> 17;
+    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((est + ZG - 1) / ZG, 1), 1 << 20);
+    hipLaunchKernelGGL(zstd_literals_kernel, dim3(grid), dim3(64), 0, st, src, (long long)src_bytes, (const wsx_zstd_frame *)d, (const HufWork *)list, (const int *)counter,
+                       scratch, st_dev);
+    ZCHK(hipGetLastError());
+    hipLaunchKernelGGL(zstd_sequences_kernel, dim3((unsigned)n_frames), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, dst, scratch, st_dev);
     ZCHK(hipGetLastError());
     return WSX_SUCCESS;
 } catch (...) {
