@@ -70,6 +70,13 @@ def inputs():
     yield 'mixed', text[:70000] + bytes(100000) + svb[:150000] + text[:50000]
     yield 'few symbols', bytes(rng.integers(0, 3, size=250000).astype(np.uint8))   # a tiny alphabet: direct weights
     yield 'periodic', bytes(range(256)) * 900
+    # two frequent bytes and forty that occur twice each -- their codes are the longest the format has (11 bits) -- standing in a row:
+    # what a decoder's bit container has to survive (six 11-bit look-ups between two refills)
+    rare = np.arange(60, 100, dtype=np.uint8)
+    body = rng.integers(0, 2, size=300000).astype(np.uint8)
+    for at in (1000, 150000):
+        body[at:at + 40] = rare if at == 1000 else rare[::-1]
+    yield 'longest codes in a row', bytes(body)
     yield 'small skewed', bytes(np.minimum(rng.geometric(0.3, size=180), 255).astype(np.uint8))   # Huffman literals in ONE stream
     # a second block whose literals are one byte over and over (RLE literals): copies of pieces of the first, random, block with
     # a single 'a' between them

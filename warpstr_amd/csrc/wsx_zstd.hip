@@ -268,7 +268,7 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *
 }
 
 constexpr int Z_WIN = 256;     // bytes of a stream's compressed input a window holds; the ring of a stream is two windows
-constexpr int Z_LOOKUPS = 66;  // look-ups a stream makes between two flushes (22 refills of three)
+constexpr int Z_LOOKUPS = 66;  // look-ups a stream makes between two flushes (33 refills of two)
 constexpr int Z_OUT = 2 * Z_LOOKUPS + 2;   // ... and the room for their symbols (two a look-up, the last store may spill one byte)
 constexpr int ZG = 4;          // Huffman blocks a wavefront decodes side by side (a group of 16 lanes each: 4 decode, 16 fetch and flush)
 
@@ -534,7 +534,9 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
         for (;;) {
             int cnt = 0;
             if (live) {
-                for (int it = 0; it < Z_LOOKUPS / 3; it++) {
+                // At the top of an iteration `used` <= 31: two look-ups of at most 11 bits leave it <= 53, and a refill (which needs 32
+                // used bits to make room) brings that back to <= 21.  (Three look-ups a refill would reach 64 and come back as 32.)
+                for (int it = 0; it < Z_LOOKUPS / 2; it++) {
                     // four more bytes from below when 32 bits are used up (the ring holds them: see above); no branch
                     const long long a = ((long long)ab + pp - 4) & ~3ll;
                     const uint32_t wlo = *(const uint32_t *)(myring + (int)(a & (2 * Z_WIN - 1)));
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                     used = re ? used - 32 : used;
                     pp = re ? pp - 4 : pp;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
+                    for (int k = 0; k < 2; k++) {
                         const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
                         const int ns = (int)(e >> 24), rem = want - done;
                         const int take = ns < rem ? ns : rem;
