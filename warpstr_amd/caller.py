@@ -864,26 +864,30 @@ class BatchQueue:
         lo, hi = np.ascontiguousarray(lo, np.int64), np.ascontiguousarray(hi, np.int64)
         offsets = np.zeros(n + 1, np.int64)
         np.cumsum(slice_lengths(lo, hi, lens), out=offsets[1:])
-        # the block table: where a block lies in the batch's byte buffer, where its samples go
-        tables, raws, at_src, first_read, spans = [], [], 0, 0, []
-        for path, cap, base, used, ls, tb in parts:
-            t = np.frombuffer(tb, np.int64).reshape(-1, 7)
-            blk = np.zeros(len(t), _lib.VBZ_BLOCK_DTYPE)
-            if len(t):
-                blk['src_offset'] = at_src + (t[:, 2] - base)
-                blk['src_bytes'], blk['n_samples'], blk['kind'], blk['n_values'] = t[:, 3], t[:, 4], t[:, 1], t[:, 5]
-                # samples of the read's earlier blocks (a read is several blocks when its dataset has several chunks)
-                before = np.cumsum(t[:, 4]) - t[:, 4]
-                starts = np.flatnonzero(np.r_[True, t[1:, 0] != t[:-1, 0]])
-                before -= np.repeat(before[starts], np.diff(np.r_[starts, len(t)]))
-                blk['dst_offset'] = roff[first_read + t[:, 0]] + before
-            tables.append(blk)
-            raws.append(t[:, 6])
-            spans.append((path, cap, base, used, at_src))
-            at_src += (int(used) + 15) & ~15
-            first_read += len(ls)
-        blocks = np.concatenate(tables) if tables else np.zeros(0, _lib.VBZ_BLOCK_DTYPE)
-        content = np.concatenate(raws) if raws else np.zeros(0, np.int64)
+        # the block table: where a block lies in the batch's byte buffer, where its samples go -- for all parts at once (a batch has
+        # two chunks per reader: per-part NumPy calls were a tenth of a second of a 0.85 s run)
+        n_parts = len(parts)
+        used_p = np.fromiter((p[3] for p in parts), np.int64, n_parts)
+        base_p = np.fromiter((p[2] for p in parts), np.int64, n_parts)
+        reads_p = np.fromiter((len(p[4]) for p in parts), np.int64, n_parts)
+        at_p = np.zeros(n_parts + 1, np.int64)
+        np.cumsum((used_p + 15) & ~15, out=at_p[1:])
+        first_p = np.cumsum(reads_p) - reads_p
+        at_src = int(at_p[-1])
+        spans = [(p[0], p[1], p[2], p[3], int(at_p[k])) for k, p in enumerate(parts)]
+        t = np.frombuffer(b''.join(p[5] for p in parts), np.int64).reshape(-1, 7)
+        blocks = np.zeros(len(t), _lib.VBZ_BLOCK_DTYPE)
+        if len(t):
+            part_of = np.repeat(np.arange(n_parts), np.fromiter((len(p[5]) // 56 for p in parts), np.int64, n_parts))
+            read_of = first_p[part_of] + t[:, 0]
+            blocks['src_offset'] = at_p[part_of] + (t[:, 2] - base_p[part_of])
+            blocks['src_bytes'], blocks['n_samples'], blocks['kind'], blocks['n_values'] = t[:, 3], t[:, 4], t[:, 1], t[:, 5]
+            # samples of the read's earlier blocks (a read is several blocks when its dataset has several chunks)
+            before = np.cumsum(t[:, 4]) - t[:, 4]
+            starts = np.flatnonzero(np.r_[True, read_of[1:] != read_of[:-1]])
+            before -= np.repeat(before[starts], np.diff(np.r_[starts, len(t)]))
+            blocks['dst_offset'] = roff[read_of] + before
+        content = t[:, 6]
         # blocks that are still zstd frames (kinds 3 / 4): their content gets a place behind the uploaded bytes, in the same buffer
         framed = np.flatnonzero(blocks['kind'] >= 3)
         frames, svb_at = np.zeros(len(framed), _lib.ZSTD_FRAME_DTYPE), at_src

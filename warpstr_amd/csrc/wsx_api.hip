@@ -318,9 +318,14 @@ struct wsx_caller {
     size_t sched_used = 0;
     PinRing ring_up, ring_down; // host-buffer calls only (allocated on first use)
     DeviceBuf prep_pool[12];    // wsx_prepare_signals: histograms and per-chunk buffers, kept between calls
-    void *prep_pinned = nullptr; // ... and its metadata staging (pinned), with the event recorded after the last use
-    size_t prep_pinned_cap = 0;
-    hipEvent_t ev_prep = nullptr;
+    // ... and its metadata staging (pinned): a ring, each slot with the event recorded after its last use -- with one buffer a call
+    // waited for the call before it to have uploaded its metadata, i.e. for most of the batch before it (a driver that submits
+    // batch after batch lost 2-10 ms a batch there)
+    static constexpr int kPrepSlots = 4;
+    void *prep_pinned[kPrepSlots] = {};
+    size_t prep_pinned_cap[kPrepSlots] = {};
+    hipEvent_t ev_prep[kPrepSlots] = {};
+    unsigned prep_turn = 0;
     struct VbzSlot {             // wsx_vbz_decode: block tables on their way to the device (three calls may be in flight)
         void *host = nullptr;
         size_t host_cap = 0;
@@ -935,8 +940,10 @@ void wsx_caller_destroy(wsx_caller *c)
     c->ring_down.release();
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
     if (c->smooth_host) (void)hipHostFree(c->smooth_host);
-    if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
-    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    for (int k = 0; k < wsx_caller::kPrepSlots; k++) {
+        if (c->prep_pinned[k]) (void)hipHostFree(c->prep_pinned[k]);
+        if (c->ev_prep[k]) (void)hipEventDestroy(c->ev_prep[k]);
+    }
     for (auto &v : c->vbz_ring) {
         if (v.host) (void)hipHostFree(v.host);
         if (v.ev) (void)hipEventDestroy(v.ev);
@@ -1082,18 +1089,19 @@ int wsx_internal_on_exception(void)
 uint64_t wsx_internal_workspace_limit(wsx_caller *c) { return c->ws_limit; }
 hipError_t wsx_internal_prep_pinned(wsx_caller *c, size_t bytes, void **p, hipEvent_t *last_use)
 {
+    const int k = (int)(c->prep_turn++ % wsx_caller::kPrepSlots);
     hipError_t e = hipSuccess;
-    if (!c->ev_prep && (e = hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming)) != hipSuccess) return e;
-    if (bytes > c->prep_pinned_cap) {
-        if ((e = hipEventSynchronize(c->ev_prep)) != hipSuccess) return e; // uploads from the old buffer
-        if (c->prep_pinned) (void)hipHostFree(c->prep_pinned);
-        c->prep_pinned = nullptr;
-        c->prep_pinned_cap = 0;
-        if ((e = hipHostMalloc(&c->prep_pinned, bytes + bytes / 4, hipHostMallocDefault)) != hipSuccess) return e;
-        c->prep_pinned_cap = bytes + bytes / 4;
+    if (!c->ev_prep[k] && (e = hipEventCreateWithFlags(&c->ev_prep[k], hipEventDisableTiming)) != hipSuccess) return e;
+    if (bytes > c->prep_pinned_cap[k]) {
+        if ((e = hipEventSynchronize(c->ev_prep[k])) != hipSuccess) return e; // uploads from the old buffer
+        if (c->prep_pinned[k]) (void)hipHostFree(c->prep_pinned[k]);
+        c->prep_pinned[k] = nullptr;
+        c->prep_pinned_cap[k] = 0;
+        if ((e = hipHostMalloc(&c->prep_pinned[k], bytes + bytes / 4, hipHostMallocDefault)) != hipSuccess) return e;
+        c->prep_pinned_cap[k] = bytes + bytes / 4;
     }
-    *p = c->prep_pinned;
-    *last_use = c->ev_prep;
+    *p = c->prep_pinned[k];
+    *last_use = c->ev_prep[k];
     return hipSuccess;
 }
 // the next slot of the ring wsx_vbz_decode stages its block tables in (csrc/wsx_vbz.hip)
