@@ -533,7 +533,16 @@ def test_a_call_that_no_longer_fits_is_planned_again_under_a_smaller_limit():
     torch.cuda.empty_cache()
     free = torch.cuda.mem_get_info()[0]
     left = int(0.6 * need)   # what is left does not hold the call's work sets, whichever way their sizes are rounded
-    hog = torch.empty(free - left, dtype=torch.uint8, device=dev)
+    hog = [torch.empty(free - left, dtype=torch.uint8, device=dev)]
+    # (torch may have served part of that from blocks it still held -- blocks of an earlier test that were in use on a second stream
+    # are not released by empty_cache() until their events have been seen --, which leaves the driver with more than `left`: take
+    # the rest too)
+    for _ in range(6):
+        torch.cuda.synchronize()
+        now = torch.cuda.mem_get_info()[0]
+        if now <= left + (8 << 20):
+            break
+        hog.append(torch.empty(now - left, dtype=torch.uint8, device=dev))
     try:
         late.call_device(dsig.data_ptr(), off, aut, res.data_ptr())
         late.synchronize()

@@ -215,8 +215,11 @@ __device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, long lon
     for (; k < n; k += 64) d[k] = s[k];
 }
 
-// The frame's header and the walk over its block headers (one lane).  Fills blocks[0 .. *n_blocks); returns the frame's status.
-__device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *blocks, int *n_blocks)
+// The frame's header and the walk over its block headers (one lane).  on_block(index, record) is told of every block; returns the
+// frame's status, *n_blocks = how many there were.  (A visitor, not an array: a per-thread array of records is scratch memory --
+// 784 bytes a lane of zstd_index_kernel made the runtime set aside hundreds of megabytes for the queue.)
+template <class Visit>
+__device__ int walk_blocks(const uint8_t *f, int flen, long long cap, int *n_blocks, Visit &&on_block)
 {
     int st = Z_OK, nb = 0, pos = 0;
     if (flen < 5 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD) st = Z_CORRUPT;
@@ -234,7 +237,7 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *
         const int last = bh & 1, type = (bh >> 1) & 3, size = (int)(bh >> 3);
         if (nb >= Z_MAX_BLOCKS) { st = Z_UNSUPPORTED; break; }
         if (type == 3 || pos + (type == 1 ? 1 : size) > flen) { st = Z_CORRUPT; break; }
-        BlockRec &B = blocks[nb++];
+        BlockRec B;
         B.type = type, B.src = pos, B.size = size, B.lit_at = lit_at, B.regen = 0, B.seq_at = 0;
         if (type == 2) {   // the literals header says how many literals the block brings: their place in the literal area
             if (size < 1) { st = Z_CORRUPT; break; }
@@ -260,6 +263,7 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, BlockRec *
             B.seq_at = pos + hl + comp;
             lit_at += regen;
         }
+        on_block(nb++, B);
         pos += type == 1 ? 1 : size;
         if (last) break;
     }
@@ -300,19 +304,20 @@ __global__ __launch_bounds__(64) void zstd_index_kernel(const uint8_t *__restric
     const int frame = blockIdx.x * 64 + threadIdx.x;
     if (frame >= n_frames) return;
     const wsx_zstd_frame F = frames[frame];
-    BlockRec blocks[Z_MAX_BLOCKS];
+    const uint8_t *f = src + F.src_offset;
+    // a first walk decides whether the frame is one to decode at all (a frame that fails half-way must leave nothing on the list),
+    // a second one lists its Huffman-coded blocks
     int nb = 0;
-    const int st = walk_blocks(src + F.src_offset, (int)F.src_bytes, F.dst_bytes, blocks, &nb);
+    const int st = walk_blocks(f, (int)F.src_bytes, F.dst_bytes, &nb, [](int, const BlockRec &) {});
     if (st != Z_OK) {
         status[frame] = st;
         return;
     }
-    const uint8_t *f = src + F.src_offset;
-    for (int b = 0; b < nb; b++) {
-        if (blocks[b].type != 2 || (f[blocks[b].src] & 3) != 2) continue;   // (raw and RLE literals: the sequence kernel reads them where they lie)
+    walk_blocks(f, (int)F.src_bytes, F.dst_bytes, &nb, [&](int, const BlockRec &B) {
+        if (B.type != 2 || (f[B.src] & 3) != 2) return;   // (raw and RLE literals: the sequence kernel reads them where they lie)
         const int at = atomicAdd(n_work, 1);
-        work[at] = HufWork{frame, blocks[b].src, blocks[b].seq_at, blocks[b].lit_at, blocks[b].regen, 0};
-    }
+        work[at] = HufWork{frame, B.src, B.seq_at, B.lit_at, B.regen, 0};
+    });
 }
 
 // ---- kernel 1: the Huffman literals, four blocks to a wavefront ------------------------------------------------------------------
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(64) void zstd_sequences_kernel(const uint8_t *__res
     const long long cap = F.dst_bytes;
     if (lane == 0) {
         int nb = 0;
-        int st = walk_blocks(f, (int)F.src_bytes, cap, blocks, &nb);
+        int st = walk_blocks(f, (int)F.src_bytes, cap, &nb, [&](int b, const BlockRec &B) { blocks[b] = B; });
         if (st == Z_OK && status && status[frame] != 0) st = status[frame];   // (a literal stream of the frame was found corrupt)
         n_blocks = nb;
         frame_status = st;
