@@ -306,7 +306,7 @@ int wsx_vbz_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const w
  *   dst        device: the content of frame i at dst_offset (e.g. the StreamVByte block wsx_vbz_decode then takes from there)
  *   scratch    device, as large as dst: where the literals of a frame's blocks lie between the two phases
  *   status     device int32[n_frames] or NULL: 0 decoded; 1 the frame uses what this decoder leaves to the host (a dictionary,
- *              literals that reuse the previous block's Huffman tree, more than 32 blocks): decompress it there; 2 corrupt (or its
+ *              more than 32 blocks): decompress it there; 2 corrupt (or its
  *              content is not dst_bytes long).  Output of a frame with a non-zero status is undefined.  Valid in stream order
  * Enqueued on the handle's stream; returns without waiting.  A wsx_vbz_decode on the same handle that follows reads dst in stream
  * order.

@@ -80,20 +80,43 @@ def test_the_upstream_files_chunks_decode_like_libzstd():
 
 @pytest.mark.parametrize('level', [1, 3, 9, 19, -5])
 def test_frames_libzstd_makes_decode_like_libzstd(level):
-    """Every input of the oracle's corpus (tests/test_zstd_oracle.py) compressed at `level`: status 0 and libzstd's bytes -- or
-    status 1 exactly where a frame uses treeless literals (a block that reuses the previous block's Huffman tree), which this
-    decoder leaves to the host."""
+    """Every input of the oracle's corpus (tests/test_zstd_oracle.py) compressed at `level`: status 0 and libzstd's bytes --
+    treeless literals (a block coded with the Huffman tree of an earlier block) included: across the levels the corpus has them."""
     named = [(name, data) for name, data in inputs() if data]
     frames = [(compress(data, level), len(data)) for _, data in named]
     got, status = decode_on_device(frames)
-    n_ok = 0
     for (name, data), (frame, _), g, st in zip(named, frames, got, status):
-        treeless = any(ft[0] == 'literals' and ft[1] == 3 for ft in frame_features(frame))
-        assert st == (1 if treeless else 0), (name, level, st, treeless)
-        if st == 0:
-            assert g == data, (name, level)
-            n_ok += 1
-    assert n_ok >= 8
+        assert st == 0, (name, level, st)
+        assert g == data, (name, level)
+
+
+def test_treeless_literals_take_the_tree_of_an_earlier_block():
+    """The corpus holds frames with treeless literals (or this test would prove nothing); one of them decodes with its treeless block
+    listed apart from the block that brought the tree.  And a frame whose FIRST Huffman-coded block is made treeless by hand -- no
+    tree to take -- is corrupt, on the device as for the host's look at the headers."""
+    from warpstr_amd._h5core import Fast5Core
+    seen = 0
+    for level in (1, 3, 9):
+        for name, data in inputs():
+            if not data:
+                continue
+            frame = compress(data, level)
+            feats = frame_features(frame)
+            if any(ft[0] == 'literals' and ft[1] == 3 for ft in feats):
+                seen += 1
+                assert Fast5Core.frame_for_device(frame) == len(data), name
+    assert seen >= 2, 'the corpus no longer has a frame with treeless literals'
+    data = dict(inputs())['skewed bytes']
+    frame = bytearray(compress(data, 3))
+    # the first compressed block's literals header: type bits 2 -> 3 where it is Huffman-coded
+    pos = 5 + (0 if frame[4] & 0x20 else 1) + ((1 if frame[4] & 0x20 else 0) if frame[4] >> 6 == 0 else (2, 4, 8)[(frame[4] >> 6) - 1])
+    bh = int.from_bytes(frame[pos:pos + 3], 'little')
+    assert (bh >> 1) & 3 == 2 and frame[pos + 3] & 3 == 2, 'the first block of this frame used to be Huffman-coded'
+    assert Fast5Core.frame_for_device(bytes(frame)) == len(data)
+    frame[pos + 3] |= 1
+    assert Fast5Core.frame_for_device(bytes(frame)) is None
+    _, status = decode_on_device([(bytes(frame), len(data))])
+    assert status[0] == 2
 
 
 def test_a_corrupt_frame_says_so_and_the_others_are_untouched():

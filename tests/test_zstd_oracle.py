@@ -196,3 +196,27 @@ def test_the_corpus_covers_the_format():
     modes = {m for f in seen if f[0] == 'sequences' and f[1] is not None for m in f[1:]}
     assert modes == {0, 1, 2, 3}, modes
     assert ('sequences', None) in seen
+
+
+def test_the_readers_look_at_a_frames_headers_takes_treeless_literals_behind_a_tree():
+    """`Fast5Core.frame_for_device` (what a reader asks before it leaves a frame to the GPU): every frame of the corpus is one the
+    device takes -- the ones with treeless literals too, their tree comes from an earlier block --; a frame whose first
+    Huffman-coded block is turned treeless by hand has no tree to take and is refused, and the oracle calls it corrupt."""
+    from warpstr_amd._h5core import Fast5Core
+    treeless = 0
+    for level in (1, 3, 9):
+        for name, data in inputs():
+            frame = compress(data, level)
+            assert Fast5Core.frame_for_device(frame) == len(data), (name, level)   # (at most four blocks each)
+            treeless += any(ft[0] == 'literals' and ft[1] == 3 for ft in frame_features(frame))
+    assert treeless >= 2
+    data = dict(inputs())['skewed bytes']
+    frame = bytearray(compress(data, 3))
+    fhd = frame[4]
+    pos = 5 + (0 if fhd & 0x20 else 1) + ((1 if fhd & 0x20 else 0) if fhd >> 6 == 0 else (2, 4, 8)[(fhd >> 6) - 1])
+    bh = int.from_bytes(frame[pos:pos + 3], 'little')
+    assert (bh >> 1) & 3 == 2 and frame[pos + 3] & 3 == 2
+    frame[pos + 3] |= 1
+    assert Fast5Core.frame_for_device(bytes(frame)) is None
+    with pytest.raises(Exception):
+        ozstd.decode(bytes(frame))

@@ -315,7 +315,8 @@ class Fast5Core:
     @staticmethod
     def frame_for_device(frame: bytes):
         """The content size a zstd frame declares if the device decoder takes the frame (csrc/wsx_zstd.hip: no dictionary, a declared
-        size, at most 32 blocks, none of a reserved type, no "treeless" literals), else None -- from its headers alone."""
+        size, at most 32 blocks, none of a reserved type, no "treeless" literals before a block has brought a Huffman tree), else None --
+        from its headers alone."""
         b, n = frame, len(frame)
         if n < 6 or b[:4] != b'\x28\xb5\x2f\xfd':
             return None
@@ -331,6 +332,7 @@ class Fast5Core:
         pos += fcs
         if content > 32 << 17:
             return None
+        tree = False
         for _ in range(32):
             if pos + 3 > n:
                 return None
@@ -339,8 +341,10 @@ class Fast5Core:
             last, btype, size = bh & 1, (bh >> 1) & 3, bh >> 3
             if btype == 3 or pos + (1 if btype == 1 else size) > n:
                 return None
-            if btype == 2 and (size < 1 or (b[pos] & 3) == 3):
-                return None
+            if btype == 2:
+                if size < 1 or ((b[pos] & 3) == 3 and not tree):
+                    return None
+                tree = tree or (b[pos] & 3) == 2
             pos += 1 if btype == 1 else size
             if last:
                 return content

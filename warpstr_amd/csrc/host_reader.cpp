@@ -156,7 +156,7 @@ hid_t open_signal(hid_t fid, const char *read_id)
 }
 
 // Can the device decode this frame (csrc/wsx_zstd.hip)?  Read from its headers alone: no dictionary, a declared content size, at
-// most 32 blocks, no block of a reserved type, no literals section that reuses the previous block's Huffman tree ("treeless").
+// most 32 blocks, no block of a reserved type, no "treeless" literals section before a block has brought a Huffman tree.
 // *content = the content size it declares.
 bool frame_for_device(const uint8_t *b, int64_t n, int64_t *content)
 {
@@ -172,6 +172,7 @@ bool frame_for_device(const uint8_t *b, int64_t n, int64_t *content)
     pos += fcs;
     if (v > (uint64_t(32) << 17)) return false;
     *content = int64_t(v);
+    bool tree = false;
     for (int blocks = 0;; blocks++) {
         if (blocks >= 32 || pos + 3 > n) return false;
         const uint32_t bh = b[pos] | (b[pos + 1] << 8) | (uint32_t(b[pos + 2]) << 16);
@@ -179,7 +180,10 @@ bool frame_for_device(const uint8_t *b, int64_t n, int64_t *content)
         const int last = bh & 1, type = (bh >> 1) & 3;
         const int64_t size = bh >> 3;
         if (type == 3 || pos + (type == 1 ? 1 : size) > n) return false;
-        if (type == 2 && (size < 1 || (b[pos] & 3) == 3)) return false;
+        if (type == 2) {
+            if (size < 1 || ((b[pos] & 3) == 3 && !tree)) return false;
+            tree = tree || (b[pos] & 3) == 2;
+        }
         pos += type == 1 ? 1 : size;
         if (last) return true;
     }

@@ -15,8 +15,9 @@
 //   * zstd_sequences_kernel: a wavefront per frame walks the blocks in order: sequences section (predefined / RLE / FSE / repeat
 //     tables, built by lane 0 in LDS), decoded by lane 0 a few hundred sequences at a time, executed by the whole wave (literal run,
 //     match -- overlapping matches as a periodic copy), repeat offsets carried from block to block.
-// Everything the format allows is decoded except dictionaries, treeless literals (a block that reuses the tree of the block
-// before it: blocks are decoded side by side, whatever frame they belong to) and frames of more than 32 blocks: the host never hands those over
+// Everything the format allows is decoded except dictionaries and frames of more than 32 blocks (treeless literals -- a block coded
+// with the tree of an earlier block -- build their table from that block's description: blocks are decoded side by side and wait
+// for nobody): the host never hands those over
 // (warpstr_amd/_h5core.py / csrc/host_reader.cpp look at the headers and decompress such a frame themselves); a frame that turns out
 // corrupt sets its status and leaves its output undefined.  Pinned against libzstd (tests/test_gpu_zstd.py) and oracle/zstd_oracle.c.
 #include <hip/hip_runtime.h>
@@ -57,6 +58,8 @@ struct BlockRec {
     int type, src, size;   // block type, first byte behind its header (relative to the frame), Block_Size
     int lit_at, regen;     // where its literals lie in the frame's literal area, how many there are
     int seq_at;            // first byte of its sequences section (relative to the frame); compressed blocks only
+    int tree;              // the literals section whose Huffman tree description its literals are coded with: its own, or -- "treeless"
+                           // literals -- that of the latest block before it that brought one; -1: its literals are raw or RLE
 };
 
 __device__ __forceinline__ int hibit(uint32_t x) { return 31 - __builtin_clz(x); }   // x != 0
@@ -229,7 +232,7 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, int *n_blo
         else if (did) st = Z_UNSUPPORTED;
         pos = 5 + (single ? 0 : 1) + (flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8);
     }
-    int lit_at = 0;
+    int lit_at = 0, tree_at = -1;
     while (st == Z_OK) {
         if (pos + 3 > flen) { st = Z_CORRUPT; break; }
         const uint32_t bh = f[pos] | (f[pos + 1] << 8) | ((uint32_t)f[pos + 2] << 16);
@@ -238,7 +241,7 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, int *n_blo
         if (nb >= Z_MAX_BLOCKS) { st = Z_UNSUPPORTED; break; }
         if (type == 3 || pos + (type == 1 ? 1 : size) > flen) { st = Z_CORRUPT; break; }
         BlockRec B;
-        B.type = type, B.src = pos, B.size = size, B.lit_at = lit_at, B.regen = 0, B.seq_at = 0;
+        B.type = type, B.src = pos, B.size = size, B.lit_at = lit_at, B.regen = 0, B.seq_at = 0, B.tree = -1;
         if (type == 2) {   // the literals header says how many literals the block brings: their place in the literal area
             if (size < 1) { st = Z_CORRUPT; break; }
             const int b0 = f[pos], ltype = b0 & 3, sf = (b0 >> 2) & 3;
@@ -256,7 +259,9 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, int *n_blo
                 const int w = sf < 2 ? 10 : sf == 2 ? 14 : 18;
                 regen = (int)((v >> 4) & ((1u << w) - 1));
                 comp = (int)((v >> (4 + w)) & ((1u << w) - 1));
-                if (ltype == 3) { st = Z_UNSUPPORTED; break; }
+                if (ltype == 2) tree_at = pos;
+                else if (tree_at < 0) { st = Z_CORRUPT; break; }   // treeless, and no block before it brought a tree
+                B.tree = tree_at;
             }
             if (hl + comp > size || regen > (1 << 17) || lit_at + regen > cap) { st = Z_CORRUPT; break; }
             B.regen = regen;
@@ -294,7 +299,7 @@ struct HufWork {
     int comp_end;  // ... and of its sequences section (where the literals section ends)
     int lit_at;    // where the block's literals go in the frame's literal area
     int regen;     // how many there are
-    int reserved;
+    int tree;      // the literals section that holds the tree description (src itself unless the block's literals are treeless)
 };
 
 // ---- kernel 0: a thread per frame walks its block headers and lists its Huffman-coded blocks ------------------------------------
@@ -314,9 +319,9 @@ __global__ __launch_bounds__(64) void zstd_index_kernel(const uint8_t *__restric
         return;
     }
     walk_blocks(f, (int)F.src_bytes, F.dst_bytes, &nb, [&](int, const BlockRec &B) {
-        if (B.type != 2 || (f[B.src] & 3) != 2) return;   // (raw and RLE literals: the sequence kernel reads them where they lie)
+        if (B.type != 2 || B.tree < 0) return;   // (raw and RLE literals: the sequence kernel reads them where they lie)
         const int at = atomicAdd(n_work, 1);
-        work[at] = HufWork{frame, B.src, B.seq_at, B.lit_at, B.regen, 0};
+        work[at] = HufWork{frame, B.src, B.seq_at, B.lit_at, B.regen, B.tree};
     });
 }
 
@@ -366,19 +371,26 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                 hl = sf < 2 ? 3 : sf + 2;
                 comp = W.comp_end - W.src - hl;
                 streams = sf == 0 ? 1 : 4;
-                const uint8_t *lp = p + hl;
-                const int hb = comp >= 1 ? lp[0] : 0;
-                if (comp < 1) st = Z_CORRUPT;
+                // the tree description: at the head of this block's literals section, or -- treeless literals -- of an earlier block's
+                // (every work item builds its table from a description, so a treeless block waits for nobody)
+                const uint8_t *tp = f + W.tree;
+                const int tsf = (tp[0] >> 2) & 3, thl = tsf < 2 ? 3 : tsf + 2, tw = tsf < 2 ? 10 : tsf == 2 ? 14 : 18;
+                uint64_t tv = 0;
+                for (int i = 0; i < thl; i++) tv |= (uint64_t)tp[i] << (8 * i);
+                const int tcomp = (int)((tv >> (4 + tw)) & ((1u << tw) - 1));   // (walk_blocks found that section inside its block)
+                const uint8_t *lp = tp + thl;
+                const int hb = tcomp >= 1 ? lp[0] : 0;
+                if (comp < 1 || tcomp < 1) st = Z_CORRUPT;
                 else if (hb >= 128) {
                     n = hb - 127;
                     const int bytes = (n + 1) / 2;
-                    if (1 + bytes > comp) st = Z_CORRUPT;
+                    if (1 + bytes > tcomp) st = Z_CORRUPT;
                     else
                         for (int i = 0; i < n; i++) w[i] = (i & 1) ? lp[1 + i / 2] & 15 : lp[1 + i / 2] >> 4;
                     took = 1 + bytes;
                 } else {
                     int h = 0;
-                    if (hb == 0 || 1 + hb > comp) st = Z_CORRUPT;
+                    if (hb == 0 || 1 + hb > tcomp) st = Z_CORRUPT;
                     else st = fse_read(fse_w[g], lp + 1, hb, 6, 255, freq_s, next_s, &h);
                     if (st == Z_OK) {
                         const FseTableW &ft = fse_w[g];
@@ -402,6 +414,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                     }
                     took = 1 + hb;
                 }
+                if (W.tree != W.src) took = 0;   // (treeless: the streams start right behind the literals header)
             }
             // weights -> code lengths (the last weight completes a power of two), then the first cell of every symbol
             if (st == Z_OK) {
