@@ -853,12 +853,13 @@ def from_fast5_leg(n_copies, local):
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
             legs.append(('reader_processes_4x_the_copies', many, None, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
             # the reader count swept on the long run (60 000 reads at the default size): same host threads, 16 ... 128 readers
-            legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in (4, 8, 16, 32, 64, 128) if r <= (os.cpu_count() or 1)]
+            sweep = [int(r) for r in os.environ.get('WARPSTR_BENCH_READER_SWEEP', '4,8,16,32,64,128').split(',')]
+            legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in sweep if r <= (os.cpu_count() or 1)]
         only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
         for tag, threads, readers, n, per_locus in [leg for leg in legs if not only or leg[0] == only or leg[0].startswith(only + '.')]:
             loci = make(tag, n, per_locus)
             n_reads = n * len(ex)
-            tm = {}
+            tm = {'timeline': []} if os.environ.get('WARPSTR_BENCH_TIMELINE') else {}   # (the run's events, for scripts/exp_from_fast5.py)
             tables = main_wrapper_loci(loci, threads, readers=readers, device=local, quiet=True, timings=tm)
             with contextlib.redirect_stdout(io.StringIO()):
                 calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
@@ -873,9 +874,11 @@ def from_fast5_leg(n_copies, local):
                                 'submit_upload': tm['submit_s'], 'wait_for_gpu': tm['collect_s'], 'outputs': tm['store_s']},
                    'shared_staging_refused': tm.get('shared_staging_refused'),
                    'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
+            if tm.get('timeline'):
+                rec['timeline'] = [f'{t:8.4f} {name}' for name, t in tm['timeline']]
             if tag.startswith('reader_sweep.'):
                 out.setdefault('reader_sweep', {'reads': n_reads, 'default_readers_at_16_threads': knee})[tag.split('.')[1]] = {
-                    k: rec[k] for k in ('reads_per_s', 'wall_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal')}
+                    k: rec[k] for k in ('reads_per_s', 'wall_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal', 'timeline') if k in rec}
                 shutil.rmtree(os.path.join(root, tag), ignore_errors=True)
             else:
                 out[tag] = rec

@@ -902,27 +902,27 @@ class BatchQueue:
         else:
             svb_bytes = 0
         t1 = clock()
-        with torch.cuda.stream(self.stream):
+        # The upload on a stream of its own, into a buffer that BELONGS to that stream (allocated under it): it runs beside the kernels
+        # of the batch before.  (A buffer allocated in the handle's stream order may be memory an earlier batch's kernels still use,
+        # so the copies had to wait for everything enqueued there -- the batch before included: 3 ms of copies between two
+        # batches' kernels, profiles/r06_from_fast5_60k_trace.log.)  The decoders wait for the copies; the allocator hears that the
+        # handle's stream uses the buffer, and hands it out again only when that stream has passed the point where it was dropped.
+        with torch.cuda.stream(self.up):
             src_dev = torch.empty(max(at_src + svb_bytes, 16), dtype=torch.uint8, device=self.dev)
+            src_dev.record_stream(self.stream)
+            t2 = clock()
+            for path, cap, base, used, at in spans:
+                if used:
+                    src_dev[at:at + used].copy_(self._arena_tensor(path, cap // 2).view(torch.uint8)[base:base + used], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        t3 = clock()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            self._region_events[region] = ev
             lit_dev = torch.empty(max(svb_bytes, 16), dtype=torch.uint8, device=self.dev) if svb_bytes else None
             raw_dev = torch.empty(max(total_raw, 1), dtype=torch.int16, device=self.dev)
             status = torch.empty(max(len(blocks), 1) + max(len(frames), 1), dtype=torch.int32, device=self.dev)
-            t2 = clock()
-            # the upload on a stream of its own: it runs beside the kernels of the batch before (one stream would put 4-8 ms of copies
-            # between two batches' kernels); the buffer was allocated in the handle's stream order, the decoders wait for the copies
-            allocated = torch.cuda.Event()
-            allocated.record()
-            src_dev.record_stream(self.up)
-            with torch.cuda.stream(self.up):
-                self.up.wait_event(allocated)
-                for path, cap, base, used, at in spans:
-                    if used:
-                        src_dev[at:at + used].copy_(self._arena_tensor(path, cap // 2).view(torch.uint8)[base:base + used], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-            self.stream.wait_event(ev)
-            self._region_events[region] = ev
-            t3 = clock()
             signal = torch.empty(max(int(offsets[-1]), 1), dtype=torch.float64, device=self.dev)
         t4 = clock()
         zst = status[max(len(blocks), 1):]
@@ -933,7 +933,7 @@ class BatchQueue:
         if n:
             self.hip.prepare_device(raw_dev.data_ptr(), roff, lo, hi, signal.data_ptr(), offsets, self.spike)
         t5 = clock()
-        with torch.cuda.stream(self.stream):   # (src_dev and status were allocated on this stream: their memory is reused in its order)
+        with torch.cuda.stream(self.stream):   # (status was allocated on this stream: its memory is reused in its order)
             bad = None
             if len(blocks):
                 bad = status[:len(blocks)].ne(0).any()

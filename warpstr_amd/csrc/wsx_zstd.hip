@@ -292,6 +292,9 @@ __device__ __forceinline__ uint32_t cell2(uint32_t c1, uint32_t c2, int max_bits
     return (c1 & 255u) | (l1 << 16) | (l1 << 20) | (1u << 24);
 }
 
+constexpr int Z_CLASSES = 9;   // a block by its literals, in steps of 16 K (0 .. 128 K)
+__device__ __forceinline__ int size_class(int regen) { return regen >> 14 > Z_CLASSES - 1 ? Z_CLASSES - 1 : regen >> 14; }
+
 // a Huffman block of a launch: what zstd_index_kernel leaves for zstd_literals_kernel
 struct HufWork {
     int frame;     // index into frames[]
@@ -322,7 +325,33 @@ __global__ __launch_bounds__(64) void zstd_index_kernel(const uint8_t *__restric
         if (B.type != 2 || B.tree < 0) return;   // (raw and RLE literals: the sequence kernel reads them where they lie)
         const int at = atomicAdd(n_work, 1);
         work[at] = HufWork{frame, B.src, B.seq_at, B.lit_at, B.regen, B.tree};
+        atomicAdd(n_work + 1 + size_class(B.regen), 1);
     });
+}
+
+// ---- kernel 0b: the list in the order it is worked off -- the blocks with the most literals first ---------------------------------
+// A block's time is its longest stream's chain of look-ups, in proportion to its literals; a wavefront lasts as long as the longest of
+// its four blocks, and the launch as long as the wavefront that ends last.  In the order the frames are walked a 128 KB block and
+// the 50 KB rest of its chunk alternate: every wavefront lasted as long as a full block, and the last quarter of them started
+// when the first three quarters were done (768 wavefronts fit the chip: 5.2 ms for 4 096 blocks; 2.9 ms ordered).
+__global__ __launch_bounds__(256) void zstd_order_kernel(const HufWork *__restrict__ work, int *__restrict__ counters, HufWork *__restrict__ ordered)
+{
+    const int n_work = counters[0];
+    int first[Z_CLASSES];   // (indexed by constants only: registers)
+    int run = 0;
+#pragma unroll
+    for (int k = Z_CLASSES - 1; k >= 0; k--) {
+        first[k] = run;
+        run += counters[1 + k];
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_work; i += gridDim.x * 256) {
+        const HufWork W = work[i];
+        const int k = size_class(W.regen);
+        int base = 0;
+#pragma unroll
+        for (int q = 0; q < Z_CLASSES; q++) base = q == k ? first[q] : base;
+        ordered[base + atomicAdd(counters + 1 + Z_CLASSES + k, 1)] = W;
+    }
 }
 
 // ---- kernel 1: the Huffman literals, four blocks to a wavefront ------------------------------------------------------------------
@@ -507,16 +536,17 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
         int st = Z_OK;
         if (dec && (hi_off - lo_off < 1 || f[hi_off - 1] == 0)) st = Z_CORRUPT;
         uint64_t cont = 0;
-        int used = 0, total = 0, done = 0;
-        long long pp = (long long)hi_off - 8;           // offset of the container's lowest byte
+        int used = 0, done = 0;
+        int pp = hi_off - 8;                            // offset of the container's lowest byte (relative to the frame)
         if (dec && st == Z_OK) {
             for (int i = 0; i < 8; i++) {
-                const long long a = pp + i;
+                const int a = pp + i;
                 cont |= (uint64_t)(a >= lo_off ? f[a] : 0) << (8 * i);
             }
             used = 8 - hibit(f[hi_off - 1]);
-            total = (hi_off - lo_off) * 8 - used;
         }
+        // (the bits of the stream not yet consumed = 8 (pp + 8 - lo_off) - used, at any time: a refill keeps it; zero when the last
+        // symbol is out, or the stream is corrupt)
         const bool live = dec && st == Z_OK;
         uint8_t *ring = workmem + (g * 4) * 2 * Z_WIN, *obuf = workmem + RING_BYTES + (g * 4) * Z_OUT;
         // window w of a stream = absolute addresses [w * Z_WIN, (w + 1) * Z_WIN); ring index = address mod 2 Z_WIN
@@ -549,19 +579,49 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
         uint8_t *myout = obuf + s * Z_OUT;
         const uint32_t *table = huf2[g];
         int flushed = 0;                                // symbols of MY fetch stream already written
+        const uint32_t ab32 = (uint32_t)ab;             // (the ring is indexed by the low bits of the absolute address)
         for (;;) {
             int cnt = 0;
-            if (live) {
-                // At the top of an iteration `used` <= 31: two look-ups of at most 11 bits leave it <= 53, and a refill (which needs 32
-                // used bits to make room) brings that back to <= 21.  (Three look-ups a refill would reach 64 and come back as 32.)
+            // At the top of an iteration `used` <= 31: two look-ups of at most 11 bits leave it <= 53, and a refill (which needs 32
+            // used bits to make room) brings that back to <= 21.  (Three look-ups a refill would reach 64 and come back as 32.)
+            // A period (33 iterations) takes at most 132 symbols and 136 bytes: while every stream of the wavefront is further than
+            // that from both its ends -- all but the last period or two of a block -- the loop is the bare chain: a refill that
+            // selects, two look-ups, no end in sight to test for.
+            const bool far = !live || (want - done >= 2 * Z_LOOKUPS && pp - lo_off >= 2 * Z_LOOKUPS + 8);
+            if (__all(far)) {
+                if (live) {
+                    // (the four bytes below the container are read an iteration ahead: the look-ups do not wait for the ring)
+                    auto below4 = [&](int at) {
+                        const uint32_t a = ab32 + (uint32_t)at - 4u;
+                        const uint32_t wlo = *(const uint32_t *)(myring + ((a & ~3u) & (2 * Z_WIN - 1)));
+                        const uint32_t whi = *(const uint32_t *)(myring + (((a & ~3u) + 4u) & (2 * Z_WIN - 1)));
+                        return __builtin_amdgcn_alignbyte(whi, wlo, a & 3u);
+                    };
+                    uint32_t w = below4(pp);
+                    for (int it = 0; it < Z_LOOKUPS / 2; it++) {
+                        const bool re = used >= 32;
+                        cont = re ? (cont << 32) | w : cont;
+                        used = re ? used - 32 : used;
+                        pp = re ? pp - 4 : pp;
+                        w = below4(pp);
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const uint32_t e = table[(uint32_t)((cont << used) >> shift)];
+                            *(uint16_t *)(myout + cnt) = (uint16_t)e;
+                            used += (int)((e >> 16) & 15), cnt += (int)(e >> 24);
+                        }
+                    }
+                    done += cnt;
+                }
+            } else if (live) {
                 for (int it = 0; it < Z_LOOKUPS / 2; it++) {
                     // four more bytes from below when 32 bits are used up (the ring holds them: see above); no branch
-                    const long long a = ((long long)ab + pp - 4) & ~3ll;
-                    const uint32_t wlo = *(const uint32_t *)(myring + (int)(a & (2 * Z_WIN - 1)));
-                    const uint32_t whi = *(const uint32_t *)(myring + (int)((a + 4) & (2 * Z_WIN - 1)));
-                    uint32_t w = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)(((long long)ab + pp - 4) & 3));
-                    const long long below = pp - lo_off;   // bytes of the stream below pp: what lies below the stream reads as zero
-                    w = below >= 4 ? w : below <= 0 ? 0u : w & (~0u << (8 * (4 - (int)below)));
+                    const uint32_t a = ab32 + (uint32_t)pp - 4u;
+                    const uint32_t wlo = *(const uint32_t *)(myring + ((a & ~3u) & (2 * Z_WIN - 1)));
+                    const uint32_t whi = *(const uint32_t *)(myring + (((a & ~3u) + 4u) & (2 * Z_WIN - 1)));
+                    uint32_t w = __builtin_amdgcn_alignbyte(whi, wlo, a & 3u);
+                    const int below = pp - lo_off;   // bytes of the stream below pp: what lies below the stream reads as zero
+                    w = below >= 4 ? w : below <= 0 ? 0u : w & (~0u << (8 * (4 - below)));
                     const bool re = used >= 32;
                     cont = re ? (cont << 32) | w : cont;
                     used = re ? used - 32 : used;
@@ -573,7 +633,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                         const int take = ns < rem ? ns : rem;
                         const int bits = take == ns ? (int)((e >> 16) & 15) : take ? (int)((e >> 20) & 15) : 0;
                         *(uint16_t *)(myout + cnt) = (uint16_t)e;   // (both symbols; what is not taken is overwritten or never flushed)
-                        used += bits, total -= bits, cnt += take, done += take;
+                        used += bits, cnt += take, done += take;
                     }
                 }
             }
@@ -588,12 +648,12 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                 for (int k = q0; k < q1; k++) d[k] = o[k];
                 flushed += cnt_fs;
             }
-            const long long p_fs = ((long long)__shfl((int)(pp >> 32), src_lane, 64) << 32) | (uint32_t)__shfl((int)pp, src_lane, 64);
+            const int p_fs = __shfl(pp, src_lane, 64);
             fetch(fetches && ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN);   // (a refill reads the aligned words around pp - 4: up to pp + 3)
             wave_sync();
             if (!__any(live && done < want)) break;
         }
-        if (live && total != 0) st = Z_CORRUPT;
+        if (live && 8 * (pp + 8 - lo_off) - used != 0) st = Z_CORRUPT;
         if (dec && st != Z_OK && status) atomicMax(&status[W.frame], st);
         wave_sync();
     }
@@ -831,20 +891,24 @@ try {
     const size_t st_bytes = ((size_t)n_frames * sizeof(int32_t) + 63) & ~(size_t)63;
     const size_t list_bytes = (size_t)n_frames * Z_MAX_BLOCKS * sizeof(HufWork);
     void *pscr = nullptr;
-    ZCHK(wsx_internal_zstd_status(c, st_bytes + 64 + list_bytes, &pscr));
+    ZCHK(wsx_internal_zstd_status(c, st_bytes + 128 + 2 * list_bytes, &pscr));
     int32_t *st_own = (int32_t *)pscr;
-    int *counter = (int *)((char *)pscr + st_bytes);
-    HufWork *list = (HufWork *)((char *)pscr + st_bytes + 64);
+    int *counter = (int *)((char *)pscr + st_bytes);   // the blocks listed; how many of every size class; the ordering's cursors
+    static_assert((1 + 2 * Z_CLASSES) * sizeof(int) <= 128, "the counters fit their place");
+    HufWork *list = (HufWork *)((char *)pscr + st_bytes + 128);
+    HufWork *ordered = (HufWork *)((char *)pscr + st_bytes + 128 + list_bytes);
     int32_t *st_dev = status ? status : st_own;
     ZCHK(hipMemsetAsync(st_dev, 0, (size_t)n_frames * sizeof(int32_t), st));
-    ZCHK(hipMemsetAsync(counter, 0, sizeof(int), st));
+    ZCHK(hipMemsetAsync(counter, 0, 128, st));
     hipLaunchKernelGGL(zstd_index_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, (int)n_frames, list, counter, st_dev);
     ZCHK(hipGetLastError());
     // blocks a launch may bring: a block holds at most 128 KB of content; the grid strides over whatever the count turns out to be
     int64_t est = n_frames;
     for (int64_t i = 0; i < n_frames; i++) est += frames[i].dst_bytes >> 17;
     const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((est + ZG - 1) / ZG, 1), 1 << 20);
-    hipLaunchKernelGGL(zstd_literals_kernel, dim3(grid), dim3(64), 0, st, src, (long long)src_bytes, (const wsx_zstd_frame *)d, (const HufWork *)list, (const int *)counter,
+    hipLaunchKernelGGL(zstd_order_kernel, dim3((unsigned)std::min<int64_t>((est + 255) / 256, 256)), dim3(256), 0, st, (const HufWork *)list, counter, ordered);
+    ZCHK(hipGetLastError());
+    hipLaunchKernelGGL(zstd_literals_kernel, dim3(grid), dim3(64), 0, st, src, (long long)src_bytes, (const wsx_zstd_frame *)d, (const HufWork *)ordered, (const int *)counter,
                        scratch, st_dev);
     ZCHK(hipGetLastError());
     hipLaunchKernelGGL(zstd_sequences_kernel, dim3((unsigned)n_frames), dim3(64), 0, st, src, (const wsx_zstd_frame *)d, dst, scratch, st_dev);

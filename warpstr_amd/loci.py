@@ -647,6 +647,14 @@ STREAM_FROM_LOCI = 256   # a run of that many loci (one rank, fast5 files, reade
                          # sets the later ones up
 
 
+def _mark(tm, name):
+    """A point of a run's timeline -- seconds since main_wrapper_loci was called, and the CPU seconds this process has used since --
+    kept when the caller's `timings` dict has a 'timeline' list (WARPSTR_BENCH_TIMELINE=1 scripts/exp_from_fast5.py)."""
+    tl = tm.get('timeline')
+    if tl is not None:
+        tl.append((f'{name} [cpu {time.process_time() - tm["_c0"]:.3f}]', round(time.perf_counter() - tm['_t0'], 4)))
+
+
 def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, batch_samples, raw_budget, gpu_vbz, print_warnings, gpu_zstd=False):
     """Set-up, reading and calling of a run as ONE pipeline (upstream's loop reaches a locus, builds its automata, calls its
     reads: WarpSTR.py:33-76): the loci are set up part after part on a thread of its own; as soon as the first part is there the
@@ -703,6 +711,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
             cond.notify_all()
 
     t_setup = time.perf_counter()
+    _mark(tm, 'the streamed run begins')
 
     def run_setup():
         try:
@@ -715,10 +724,12 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                     tm[key] = tm.get(key, 0.0) + v
                 print_warnings(part_jobs)
                 grow(part_jobs)
+                _mark(tm, 'part set up')
         except BaseException as e:  # noqa: BLE001 -- raised by the calling thread
             K.error = e
         finally:
             tm['setup_wall_s'] = time.perf_counter() - t_setup
+            _mark(tm, 'set-up done')
             with cond:
                 K.final = True
                 cond.notify_all()
@@ -780,6 +791,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step], gpu_zstd) if gpu_vbz else (region, k, items[q:q + step])) for q in range(0, len(items), step)]
                 inflight.append((b, b1, region, futures, k))
                 tm['read_s'] += time.perf_counter() - t1
+                _mark(tm, f'batch {k} handed to the readers ({b1 - b} reads)')
                 b, k = b1, k + 1
             if not inflight:
                 with cond:
@@ -835,6 +847,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 seen[1] += 2 * int(sum(lens_p))
             tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
             tm['read_s'] += time.perf_counter() - t1
+            _mark(tm, f'batch {kb} answered')
             yield b0, b1, parts_, ('vbz' if gpu_vbz else 'arena', region, kb)
 
     def produce():
@@ -883,6 +896,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
             tm['automata_added_in_flight'] = tm.get('automata_added_in_flight', 0) + len(tables)
         held[0] = n_jobs
         tm['handle_s'] += time.perf_counter() - t0
+        _mark(tm, f'handle holds {n_jobs} loci')
 
     rec_parts, seqs, pending = [], [[], []], []
 
@@ -890,6 +904,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
         t1 = time.perf_counter()
         rec, s1, p1, s2, p2 = engine[0].collect(ticket)
         tm['collect_s'] += time.perf_counter() - t1
+        _mark(tm, f'reads {b0}-{b1} collected')
         rec_parts.append((b0, b1, rec))
         seqs[0].append(s1)
         seqs[1].append(s2)
@@ -906,6 +921,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
         else:
             ticket = engine[0].submit_raw_parts(slot[1], data, lo[b0:b1], hi[b0:b1], aut[b0:b1])
         tm['submit_s'] += time.perf_counter() - t1
+        _mark(tm, f'reads {b0}-{b1} submitted')
         if slot is not None:
             submitted[slot[2]].set()
         pending.append((ticket, b0, b1))
@@ -929,6 +945,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
     finally:
         stop.set()
         engine_ready.set()
+        _mark(tm, 'last batch collected')
         reader.join()
         setup_thread.join()
         if engine[0] is not None:
@@ -936,6 +953,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 tm.update(engine[0].info())
             finally:
                 engine[0].close()
+                _mark(tm, 'handle closed')
     if K.error is not None:
         raise K.error
     n_total = K.n
@@ -1005,6 +1023,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     from .pore_model import default_pore_model
     t_start = time.perf_counter()
     tm = timings if timings is not None else {}
+    tm['_t0'], tm['_c0'] = t_start, time.process_time()
     for key in ('native_setup_s', 'overview_s', 'automata_s', 'similarity_s', 'handle_s', 'read_s', 'submit_s', 'collect_s', 'gather_s', 'store_s'):
         tm[key] = 0.0
     if partition not in ('auto', 'loci', 'reads'):
@@ -1041,6 +1060,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     zstd_on_device = (bool(getattr(engine_probe, 'DEVICE_ZSTD', False)) and hasattr(engine_probe, 'submit_vbz_parts')
                       and not os.environ.get('WARPSTR_NO_GPU_ZSTD') and not os.environ.get('WARPSTR_NO_GPU_VBZ') and not os.environ.get('WARPSTR_NO_READER_ARENAS'))
     pool = _reader_pool(threads, [loci[i] for i in own], readers, zstd_on_device) if fast5_on_workers else None
+    _mark(tm, 'reader pool made')
     pools.append(pool)
     tm['reader_processes'] = pool._max_workers if pool is not None else 0
 
@@ -1077,6 +1097,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     if (can_stream and fast5_on_workers and all(hasattr(probe, a) for a in ('submit_raw_parts', 'ARENA_REGIONS', 'region_wait'))
             and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')):
         pool = _started(pool, tm)
+        _mark(tm, 'reader processes started')
         workers = pool._max_workers if pool is not None else 1
         refused = _arena_room(workers, SHARED_BATCH_READS if pool is not None else SHARED_BATCH_READS // 4, batch_raw_bytes // 2)
         if refused is not None:
@@ -1128,6 +1149,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
     if streamed is not None:
         _, _, records, seqs = streamed
         mine = np.arange(n_total)
+        _mark(tm, 'all reads called')
     if n_total > 0 and streamed is None:
         # ---- the read list: (locus, row) -> automaton, cost ---------------------------------------------------------------
         counts = [j.n for j in jobs]
@@ -1583,6 +1605,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             raise
         error = e
     tm['store_s'] += time.perf_counter() - t0
+    _mark(tm, 'outputs written')
     if collective:
         wdist.agree_or_raise(error, world, coll_device, 'writing the outputs')
         if first_bad < len(loci):  # (another rank's locus: it has raised ReadCallError, agree_or_raise named it here)
@@ -1593,6 +1616,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             units_gt1 = sum(ch == '(' for ch in loci[i].sequence) > 0
             entries[i] = ('disk', loci[i].path, units_gt1)
     tm['total_s'] = time.perf_counter() - t_start
+    tm.pop('_t0', None), tm.pop('_c0', None)
     return LociTables(entries)
 
 
