@@ -860,14 +860,17 @@ def from_fast5_leg(n_copies, local):
             loci = make(tag, n, per_locus)
             n_reads = n * len(ex)
             tm = {'timeline': []} if os.environ.get('WARPSTR_BENCH_TIMELINE') else {}   # (the run's events, for scripts/exp_from_fast5.py)
+            t_call = time.perf_counter()
             tables = main_wrapper_loci(loci, threads, readers=readers, device=local, quiet=True, timings=tm)
+            call_s = time.perf_counter() - t_call   # (with what follows the outputs: the reader processes sent home, the handle closed)
             with contextlib.redirect_stdout(io.StringIO()):
                 calls = [run_genotyping_overview(None, l.path, None).alleles for l in (loci[0], loci[-1])]
             lens = [tuple(int(v) for v in pd.read_csv(os.path.join(l.path, 'overview.csv'))['results'][:len(ex)]) for l in loci[::max(1, n // n_copies)]]
-            rec = {'reads': n_reads, 'loci': len(loci), 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'host_threads': tm.get('host_threads'),
+            rec = {'reads': n_reads, 'loci': len(loci), 'reads_per_s': n_reads / tm['total_s'], 'wall_s': tm['total_s'], 'call_returns_after_s': call_s,
+                   'host_threads': tm.get('host_threads'),
                    'reader_processes': tm.get('reader_processes'), 'raw_MB': tm.get('raw_bytes', 0) / 1e6, 'uploaded_MB': tm.get('uploaded_bytes', 0) / 1e6,
                    'reader_mode': tm.get('reader_mode'), 'inside_wsx_caller_create': tm.get('handle_create_s'),
-                   'inside_submit_upload': tm.get('submit_parts_s'),
+                   'inside_submit_upload': tm.get('submit_parts_s'), 'inside_wait_for_gpu': tm.get('collect_parts_s'),
                    'phases_s': {'setup': tm.get('setup_wall_s'), 'handle': tm['handle_s'], 'read_total': tm['read_s'],
                                 'read_probe_lengths': tm.get('probe_s'), 'read_decode_into_staging': tm.get('decode_s'),
                                 'decode_summed_over_reader_processes': tm.get('decode_worker_s'),
@@ -878,7 +881,7 @@ def from_fast5_leg(n_copies, local):
                 rec['timeline'] = [f'{t:8.4f} {name}' for name, t in tm['timeline']]
             if tag.startswith('reader_sweep.'):
                 out.setdefault('reader_sweep', {'reads': n_reads, 'default_readers_at_16_threads': knee})[tag.split('.')[1]] = {
-                    k: rec[k] for k in ('reads_per_s', 'wall_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal', 'timeline') if k in rec}
+                    k: rec[k] for k in ('reads_per_s', 'wall_s', 'call_returns_after_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal', 'timeline') if k in rec}
                 shutil.rmtree(os.path.join(root, tag), ignore_errors=True)
             else:
                 out[tag] = rec

@@ -30,6 +30,28 @@ def fast5_file(path: str, arrays: bool = True):
     return f
 
 
+ROWS = '\0rows'   # first element of an item that stands for several reads of one locus (loci.LocusJob.rows_for_readers)
+
+
+def expand(items):
+    """The per-read items (annotated fast5 path, multi-read fall-back or None, read name) of what the parent sent: such items as
+    they are, a locus's rows -- (ROWS, {run id: directory of its annotated files}, [run id] or None, [name], [fall-back] or None) --
+    put together here, on the reader's CPU (upstream's path of a read: src/caller/wrapper.py:49-50)."""
+    if not any(len(it) == 5 and it[0] == ROWS for it in items):
+        return items
+    out = []
+    join = os.path.join
+    for it in items:
+        if len(it) == 5 and it[0] == ROWS:
+            _, dirs, runs, names, falls = it
+            only = dirs['0'] if runs is None else None
+            for k, name in enumerate(names):
+                out.append((join(only if runs is None else dirs[runs[k]], name + '.fast5'), falls[k] if falls is not None else None, name))
+        else:
+            out.append(it)
+    return out
+
+
 def resolve(item):
     path, fallback, name = item
     if not os.path.exists(path) and fallback is not None:
@@ -175,6 +197,7 @@ def decode_arena(args):
     from ._h5core import NeedsNumpy
     region, generation, items = args
     t0 = time.perf_counter()
+    items = expand(items)
     cur = _CURSOR.setdefault(region, [generation, 0])
     if cur[0] != generation:
         cur[0], cur[1] = generation, 0
@@ -284,6 +307,7 @@ def pack_arena(args):
     region, generation, items = args[:3]
     device_zstd = bool(args[3]) if len(args) > 3 else False
     t0 = time.perf_counter()
+    items = expand(items)
     cur = _BYTE_CURSOR.setdefault(region, [generation, 0])
     if cur[0] != generation:
         cur[0], cur[1] = generation, 0

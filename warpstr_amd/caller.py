@@ -613,6 +613,59 @@ class SharedStaging:
             pass
 
 
+class ArenaTable:
+    """The reader processes' arenas (memory-backed files, warpstr_amd/_readers.py) as this process uses them: mapped, and registered
+    with the runtime so that an upload starts from them directly -- once per file and size, by whichever thread asks first."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.dev = device if isinstance(device, torch.device) else torch.device('cuda', int(device))
+        self.entries = {}    # path -> (mmap, page-locked int16 tensor, registered, address)
+        self.lock = threading.Lock()
+
+    def tensor(self, path: str, samples: int):
+        """The arena as a page-locked int16 tensor of at least `samples` samples.  Page-locking -- 48 arenas of 16 MB: ~0.1 s,
+        scripts/exp_arena_register.py -- belongs on a thread that is not the submitting one (BatchQueue.arena_ready, called by the thread
+        that waits for the readers as soon as an answer names the arena); hence the lock.  (Page-locking all of them ahead, while the
+        loci are set up, was slower: 48 x 16 MB took 0.3 s beside sixteen set-up threads and sixteen readers on sixteen CPUs.)"""
+        import mmap
+        torch = self.torch
+        got = self.entries.get(path)
+        if got is not None and got[1].numel() >= samples:
+            return got[1]   # (without the lock: the other thread may hold it for the milliseconds page-locking ANOTHER arena takes)
+        with self.lock:
+            got = self.entries.get(path)
+            if got is None or got[1].numel() < samples:
+                if got is not None:
+                    self._unregister(got)
+                with open(path, 'r+b') as fh:
+                    size = os.fstat(fh.fileno()).st_size
+                    mm = mmap.mmap(fh.fileno(), size)   # (not pre-faulted: page-locking maps the pages, and faster)
+                view = np.frombuffer(mm, dtype=np.int16)
+                registered = False
+                try:
+                    with torch.cuda.device(self.dev):
+                        registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
+                except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
+                    pass
+                got = self.entries[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
+            return got[1]
+
+    def _unregister(self, got):
+        if got[2]:
+            try:
+                self.torch.cuda.cudart().cudaHostUnregister(got[3])
+            except Exception:  # noqa: BLE001
+                pass
+
+    def close(self):
+        with self.lock:
+            for got in self.entries.values():
+                self._unregister(got)
+            self.entries.clear()
+
+
 class BatchQueue:
     """Back-to-back batches on one handle without draining the GPU in between: submit() enqueues the upload, the signal
     loader and the caller of a batch and returns at once; collect() waits for that batch only and returns its records and
@@ -635,9 +688,9 @@ class BatchQueue:
         self._staging = {}   # dtype -> list of [pinned tensor, event of its last upload]
         self._turn = 0
         self._shared = None  # SharedStaging: buffers the reader processes fill (stage_shared)
-        self._arenas = {}    # reader arena path -> (mmap, page-locked int16 tensor, registered, address)
-        self._arena_lock = threading.Lock()
+        self.arenas = ArenaTable(self.dev)   # the readers' arenas, mapped and page-locked
         self.parts_s = {}    # where submit_raw_parts spent its time (seconds, summed over the batches)
+        self.collect_parts = {}   # ... and collect: waiting for the batch, packing its sequences
         self._region_events = {}   # arena region -> event of the upload that last read it
         hip.set_pipelined(True)
 
@@ -768,42 +821,12 @@ class BatchQueue:
             ev.synchronize()
 
     def _arena_tensor(self, path: str, samples: int):
-        """A reader's arena file as a page-locked tensor (mapped, and registered with the runtime, once per size).  Called by the
-        thread that waits for the readers as soon as a chunk's answer names the arena (arena_ready), so that page-locking --
-        48 arenas of 16 MB: ~0.1 s, scripts/exp_arena_register.py -- is not on the submitting thread's path; hence the lock."""
-        import mmap
-        torch = self.torch
-        got = self._arenas.get(path)
-        if got is not None and got[1].numel() >= samples:
-            return got[1]   # (without the lock: the other thread may hold it for the milliseconds page-locking ANOTHER arena takes)
-        with self._arena_lock:
-            got = self._arenas.get(path)
-            if got is None or got[1].numel() < samples:
-                if got is not None:
-                    self._unregister(got)
-                with open(path, 'r+b') as fh:
-                    size = os.fstat(fh.fileno()).st_size
-                    mm = mmap.mmap(fh.fileno(), size)   # (not pre-faulted: page-locking maps the pages, and faster)
-                view = np.frombuffer(mm, dtype=np.int16)
-                registered = False
-                try:
-                    with torch.cuda.device(self.dev):
-                        registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
-                except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
-                    pass
-                got = self._arenas[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
-            return got[1]
+        """A reader's arena file as a page-locked tensor (ArenaTable.tensor)."""
+        return self.arenas.tensor(path, samples)
 
     def arena_ready(self, path: str, samples: int):
         """Map and page-lock a reader's arena ahead of the submit_raw_parts() that uploads from it (any thread)."""
         self._arena_tensor(path, samples)
-
-    def _unregister(self, got):
-        if got[2]:
-            try:
-                self.torch.cuda.cudart().cudaHostUnregister(got[3])
-            except Exception:  # noqa: BLE001
-                pass
 
     def submit_raw_parts(self, region: int, parts, lo: np.ndarray, hi: np.ndarray, aut: np.ndarray):
         """submit_raw() for a batch whose reads lie in the readers' arenas: parts = [(arena path, its size in samples, start of the
@@ -936,9 +959,12 @@ class BatchQueue:
         with torch.cuda.stream(self.stream):   # (status was allocated on this stream: its memory is reused in its order)
             bad = None
             if len(blocks):
-                bad = status[:len(blocks)].ne(0).any()
+                flag = status[:len(blocks)].ne(0).any()
                 if len(frames):
-                    bad = bad | zst[:len(frames)].ne(0).any()
+                    flag = flag | zst[:len(frames)].ne(0).any()
+                # (on its way to the host with the batch: `done` of the ticket covers the copy, collect reads a byte of host memory)
+                bad = torch.empty(1, dtype=torch.bool, pin_memory=True)
+                bad.copy_(flag.reshape(1), non_blocking=True)
         ticket = self._launch(n, offsets, np.ascontiguousarray(aut, np.int32), signal, (raw_dev, lit_dev))
         ticket['vbz_bad'] = bad
         self.vbz_bytes = getattr(self, 'vbz_bytes', 0) + at_src
@@ -954,9 +980,7 @@ class BatchQueue:
         for ev in self._region_events.values():
             ev.synchronize()
         self._region_events.clear()
-        for got in self._arenas.values():
-            self._unregister(got)
-        self._arenas.clear()
+        self.arenas.close()
 
     def submit_signals(self, signals: Sequence[np.ndarray], aut: np.ndarray):
         """Already normalised float64 segments (a `signal_loader`, or ReadSignal workloads)."""
@@ -979,8 +1003,14 @@ class BatchQueue:
     def collect(self, ticket):
         """-> (records, seq1, pos1, seq2, pos2): read r's seq is seq1[pos1[r] : pos1[r + 1]] (empty for a failed read)."""
         torch = self.torch
+        import time
         n = ticket['n']
+        clock = time.perf_counter
+        acc = self.collect_parts
+        t0 = clock()
         ticket['done'].synchronize()
+        t1 = clock()
+        acc['wait'] = acc.get('wait', 0.0) + t1 - t0
         if ticket.get('vbz_bad') is not None and bool(ticket['vbz_bad'].item()):
             # (the readers check every block before it is uploaded: this is a block that changed on its way, not a bad file)
             raise RuntimeError('the device decoders flagged a chunk: a zstd frame that is corrupt (wsx_zstd_decode) or a StreamVByte block whose '
@@ -1008,6 +1038,7 @@ class BatchQueue:
             self.pack.synchronize()
         for host, pos, total in packed:
             out += [host.numpy()[:total].copy(), pos]
+        acc['pack'] = acc.get('pack', 0.0) + clock() - t1
         return tuple(out)
 
 

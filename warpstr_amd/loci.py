@@ -27,7 +27,7 @@ from typing import Callable, Dict, List, Mapping, Optional, Sequence
 
 import numpy as np
 
-from . import _hostlib, overview as ov
+from . import _hostlib, _readers, overview as ov
 from .caller import BatchQueue, CallerConfig, CallerResults, HipCaller, ReadCallError, RescalerConfig, similarity_report
 from .fast5 import read_raw_signal
 
@@ -110,6 +110,19 @@ class LocusJob:
         from .wrapper import annot_fast5_path
         return annot_fast5_path(self.locus.path, self.run_id[k] if self.run_id is not None else 0, self.names[k])
 
+    def rows_for_readers(self, r0: int, r1: int):
+        """Saved rows [r0, r1) as ONE item for a reader process (_readers.expand makes the per-read items of it there): the directory
+        of the annotated files by run id, the rows' run ids (None: all '0'), names and multi-read fall-backs (None: none).  The
+        parent's share of a read is a slice of three lists -- putting 1 700 paths together per batch held the interpreter's lock
+        for 7 ms of every 11."""
+        pre = self.__dict__.get('_annot_dirs')
+        if pre is None:
+            from .wrapper import ANNOT_SUBDIR, FAST5_SUBDIR
+            runs = set(map(str, self.run_id)) if self.run_id is not None else {'0'}
+            pre = self._annot_dirs = {r: os.path.join(self.locus.path, FAST5_SUBDIR, r, ANNOT_SUBDIR) for r in runs}
+        return (_readers.ROWS, pre, list(map(str, self.run_id[r0:r1])) if self.run_id is not None else None, list(self.names[r0:r1]),
+                list(map(str, self.fast5_path[r0:r1])) if self.fast5_path is not None else None)
+
     def raw_read(self, k: int, raw_reader) -> np.ndarray:
         """The whole raw read of saved row k (int16), as get_raw_workload finds it."""
         path = self.fast5_of(k)
@@ -150,13 +163,14 @@ class HipEngine:
     def arena_ready(self, path, samples):
         return self.queue.arena_ready(path, samples)
 
+
     def add_automata(self, tables, flank_lengths):
         """More loci for the handle while its batches are in flight (wsx_caller_add_automata) -> index of the first new automaton."""
         return self.hip.add_automata(tables, flank_lengths)
 
     def info(self) -> dict:
         return {'workspace_bytes': self.hip.workspace()['bytes_allocated'], 'workspace_limit_bytes': self.hip.workspace_limit(),
-                'handle_create_s': self.hip.create_times(), 'submit_parts_s': dict(self.queue.parts_s),
+                'handle_create_s': self.hip.create_times(), 'submit_parts_s': dict(self.queue.parts_s), 'collect_parts_s': dict(self.queue.collect_parts),
                 'zstd_frames_decoded_on_the_gpu': getattr(self.queue, 'zstd_frames', 0),
                 'kernels': sorted({self.hip.kernel_name(a) for a in range(min(len(self.hip.automata), 256))})}
 
@@ -552,10 +566,12 @@ def default_readers(threads: int, device_zstd: bool = False) -> int:
     bench.py's from_fast5.reader_sweep on the bench box, whose cgroup grants 16 CPUs: 16 / 32 / 64 / 128 readers = 49 / 55 / 35 /
     22 k reads/s on 60 000 reads (profiles/r06_reader_sweep.json): past the share, more readers only take turns.  device_zstd: the
     engine undoes the chunks' zstd frames itself (wsx_zstd_decode) and a reader's part of a read is libhdf5 alone (0.05 ms instead
-    of 0.14): half as many readers feed it, and the other half of the share is this process's own threads' -- 4 / 8 / 16 / 32
-    readers = 50 / 66 / 60 / 49 k reads/s (profiles/r06_reader_sweep_device_zstd.json)."""
+    of 0.14); this process's submitting and collecting threads then want a CPU or two of the share for themselves: 8 / 10 / 14 /
+    16 readers = 69 / 92 / 89 / 85 k reads/s (medians of three runs each, profiles/r06_reader_sweep_late.json; while the uploads
+    still waited for the kernels of the batch before and the readers' items were put together in this process, eight readers were
+    the knee: profiles/r06_reader_sweep_device_zstd.json)."""
     n = max(1, min(int(threads), cpu_share()))
-    return max(2, n // 2) if device_zstd and n >= 4 else n
+    return n - max(1, n // 8) if device_zstd and n >= 4 else n
 
 
 def _started(pool, tm):
@@ -746,6 +762,17 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
         job, row = jobs[int(K.locus[k])], int(K.row[k])
         return (job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row])
 
+    def rows_of(x0, x1):
+        """Reads [x0, x1) of the run as the readers take them: a piece per locus (LocusJob.rows_for_readers)."""
+        out, j = [], int(K.locus[x0])
+        while x0 < x1:
+            job, r0 = jobs[j], x0 - K.first[j]
+            r1 = min(job.n, r0 + x1 - x0)
+            if r1 > r0:
+                out.append(job.rows_for_readers(r0, r1))
+            x0, j = x0 + r1 - r0, j + 1
+        return out
+
     def page_lock(parts_):
         if not engine_ready.is_set() or engine[0] is None:
             return False
@@ -786,9 +813,11 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                     engine[0].region_wait(region)
                     del submitted[k - regions]
                 submitted[k] = threading.Event()
-                items = [item_of(x) for x in range(b, b1)]
-                step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
-                futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step], gpu_zstd) if gpu_vbz else (region, k, items[q:q + step])) for q in range(0, len(items), step)]
+                step = max(8, -(-(b1 - b) // (CHUNKS_PER_READER * pool._max_workers)))
+                futures = []
+                for q in range(b, b1, step):
+                    items = rows_of(q, min(q + step, b1))
+                    futures.append(pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items, gpu_zstd) if gpu_vbz else (region, k, items)))
                 inflight.append((b, b1, region, futures, k))
                 tm['read_s'] += time.perf_counter() - t1
                 _mark(tm, f'batch {k} handed to the readers ({b1 - b} reads)')
@@ -898,7 +927,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
         tm['handle_s'] += time.perf_counter() - t0
         _mark(tm, f'handle holds {n_jobs} loci')
 
-    rec_parts, seqs, pending = [], [[], []], []
+    rec_parts, seqs = [], [[], []]
 
     def finish(ticket, b0, b1):
         t1 = time.perf_counter()
@@ -924,24 +953,53 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
         _mark(tm, f'reads {b0}-{b1} submitted')
         if slot is not None:
             submitted[slot[2]].set()
-        pending.append((ticket, b0, b1))
-        if len(pending) > 2:
-            finish(*pending.pop(0))
+        collect_q.put((ticket, b0, b1))   # (three batches may wait there: the submitting thread then waits for the collecting one)
+        if collector_error:
+            raise collector_error[0]
+
+    # The batches' results are fetched on a thread of their own: packing a batch's sequences is a dozen small launches that queue
+    # behind the next batch's kernels (3 ms a batch, none of it this process's work) -- the thread that submits does not wait for it.
+    collect_q: '_queue.Queue' = _queue.Queue(maxsize=3)
+    collector_error: List[BaseException] = []
+
+    def run_collector():
+        while True:
+            got = collect_q.get()
+            if got is None:
+                return
+            if collector_error:
+                continue   # (the run has failed: what is still queued is dropped, the submitting thread raises)
+            try:
+                finish(*got)
+            except BaseException as e:  # noqa: BLE001 -- raised by the submitting thread
+                collector_error.append(e)
+                stop.set()
 
     setup_thread = threading.Thread(target=run_setup, name='warpstr-setup', daemon=True)
     reader = threading.Thread(target=produce, name='warpstr-reader', daemon=True)
+    collector = threading.Thread(target=run_collector, name='warpstr-collector', daemon=True)
     setup_thread.start()
+    collector.start()
     try:
-        reader.start()
-        while True:
-            item = handover.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            submit(*item)
-        while pending:
-            finish(*pending.pop(0))
+        try:
+            reader.start()
+            while True:
+                try:
+                    item = handover.get(timeout=0.2)
+                except _queue.Empty:
+                    if collector_error:   # (the reader thread has stopped with the run: nothing more will come)
+                        raise collector_error[0]
+                    continue
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                submit(*item)
+        finally:
+            collect_q.put(None)
+            collector.join()
+        if collector_error:
+            raise collector_error[0]
     finally:
         stop.set()
         engine_ready.set()
