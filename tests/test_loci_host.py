@@ -995,3 +995,25 @@ def test_readers_leave_zstd_to_an_engine_that_decodes_it(tmp_path, threads, monk
         for rel in OUTPUTS:
             assert filecmp.cmp(os.path.join(la.path, rel), os.path.join(lb.path, rel), shallow=False), rel
             assert filecmp.cmp(os.path.join(lc.path, rel), os.path.join(lb.path, rel), shallow=False), rel
+
+
+@pytest.mark.parametrize('native', [True, False])
+def test_a_locus_rows_as_one_item_expand_to_the_per_read_items(tmp_path, native):
+    """What the streamed run sends its readers -- a locus's rows in one piece (LocusJob.rows_for_readers) -- becomes, in the
+    reader (_readers.expand), exactly the items the run used to put together itself: upstream's path of a read's annotated file
+    (src/caller/wrapper.py:49-50), the multi-read fall-back, the read's name; with and without a fast5_path / run_id column,
+    whole and in slices, beside items that are per-read already."""
+    from warpstr_amd import _readers, loci as L
+    from warpstr_amd.caller import CallerConfig
+    from warpstr_amd.pore_model import default_pore_model
+    src = str(tmp_path / 'reads.fast5')
+    made = _fast5_loci(str(tmp_path), src, [f'read{k}' for k in range(10)], n_loci=6)
+    plain, _ = _make_loci(str(tmp_path / 'plain'))     # run_id 0, no fast5_path column, unsaved rows at the end
+    for locus in made + plain:
+        job = L.LocusJob(locus, default_pore_model(), {}, CallerConfig(), native=native)
+        want = [(job.fast5_of(k), str(job.fast5_path[k]) if job.fast5_path is not None else None, job.names[k]) for k in range(job.n)]
+        assert _readers.expand([job.rows_for_readers(0, job.n)]) == want
+        if job.n >= 2:
+            got = _readers.expand([job.rows_for_readers(0, 1), ('/x/y.fast5', None, 'z'), job.rows_for_readers(1, job.n)])
+            assert got == want[:1] + [('/x/y.fast5', None, 'z')] + want[1:]
+    assert _readers.expand([('/a', '/b', 'c')]) == [('/a', '/b', 'c')]

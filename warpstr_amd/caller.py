@@ -622,7 +622,8 @@ class ArenaTable:
         self.torch = torch
         self.dev = device if isinstance(device, torch.device) else torch.device('cuda', int(device))
         self.entries = {}    # path -> (mmap, page-locked int16 tensor, registered, address)
-        self.lock = threading.Lock()
+        self.lock = threading.Lock()   # guards `entries` and `busy`; page-locking itself runs under the PATH's lock, several at a time
+        self.busy = {}       # path -> lock of whoever is mapping / page-locking it
 
     def tensor(self, path: str, samples: int):
         """The arena as a page-locked int16 tensor of at least `samples` samples.  Page-locking -- 48 arenas of 16 MB: ~0.1 s,
@@ -633,8 +634,10 @@ class ArenaTable:
         torch = self.torch
         got = self.entries.get(path)
         if got is not None and got[1].numel() >= samples:
-            return got[1]   # (without the lock: the other thread may hold it for the milliseconds page-locking ANOTHER arena takes)
+            return got[1]   # (without the lock: another thread may be page-locking ANOTHER arena)
         with self.lock:
+            mine = self.busy.setdefault(path, threading.Lock())
+        with mine:
             got = self.entries.get(path)
             if got is None or got[1].numel() < samples:
                 if got is not None:
@@ -649,7 +652,9 @@ class ArenaTable:
                         registered = int(torch.cuda.cudart().cudaHostRegister(view.ctypes.data, size, 0)) == 0
                 except Exception:  # noqa: BLE001 -- a pageable buffer uploads as well, only slower
                     pass
-                got = self.entries[path] = (mm, torch.from_numpy(view), registered, view.ctypes.data)
+                got = (mm, torch.from_numpy(view), registered, view.ctypes.data)
+                with self.lock:
+                    self.entries[path] = got
             return got[1]
 
     def _unregister(self, got):

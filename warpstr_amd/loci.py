@@ -778,9 +778,36 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
             return False
         ready = getattr(engine[0], 'arena_ready', None)
         if ready is not None:
+            t1 = time.perf_counter()
             for part in parts_:
                 ready(part[0], part[1] // 2 if len(part) == 6 else part[1])
+            if time.perf_counter() - t1 > 2e-4:   # (an arena that was not page-locked yet)
+                tm['page_lock_s'] = tm.get('page_lock_s', 0.0) + time.perf_counter() - t1
         return True
+
+    def lock_early(future):
+        """A chunk's answer has come (this runs on the thread that serves its reader): the arena it names is page-locked now, beside
+        the other readers' -- not one after the other when the batch's last answer is in (2 ms each: the run's first three batches,
+        whose arenas are all new, each waited 30-60 ms for that)."""
+        try:
+            if future.exception() is None:
+                got = future.result()
+                page_lock([(got[0], got[1], None, None, None, None) if gpu_vbz else (got[0], got[1])])
+        except Exception:  # noqa: BLE001 -- best effort: arena_batches page-locks what is not yet
+            pass
+
+    def lock_all(parts_):
+        """What lock_early has left (answers that came before the handle existed): the arenas side by side, not one after the other."""
+        if len(parts_) > 1 and engine_ready.is_set() and engine[0] is not None:
+            distinct = list({part[0]: part for part in parts_}.values())
+            threads_ = [threading.Thread(target=page_lock, args=([part],), daemon=True) for part in distinct[1:]]
+            for t in threads_:
+                t.start()
+            page_lock(distinct[:1])
+            for t in threads_:
+                t.join()
+        else:
+            page_lock(parts_)
 
     def arena_batches():
         inflight = collections.deque()
@@ -818,6 +845,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                 for q in range(b, b1, step):
                     items = rows_of(q, min(q + step, b1))
                     futures.append(pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items, gpu_zstd) if gpu_vbz else (region, k, items)))
+                    futures[-1].add_done_callback(lock_early)
                 inflight.append((b, b1, region, futures, k))
                 tm['read_s'] += time.perf_counter() - t1
                 _mark(tm, f'batch {k} handed to the readers ({b1 - b} reads)')
@@ -870,10 +898,10 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
                     path, cap, base, lens_p, busy = got
                     parts_.append((path, cap, base, lens_p))
                     tm['uploaded_bytes'] = tm.get('uploaded_bytes', 0) + 2 * int(sum(lens_p))
-                page_lock([parts_[-1]])
                 tm['decode_worker_s'] = tm.get('decode_worker_s', 0.0) + float(busy)
                 tm['raw_bytes'] = tm.get('raw_bytes', 0) + 2 * int(sum(lens_p))
                 seen[1] += 2 * int(sum(lens_p))
+            lock_all(parts_)
             tm['decode_s'] = tm.get('decode_s', 0.0) + time.perf_counter() - t1
             tm['read_s'] += time.perf_counter() - t1
             _mark(tm, f'batch {kb} answered')
@@ -884,7 +912,7 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
             for item in arena_batches():
                 locked = item[3] is None
                 while not stop.is_set():
-                    locked = locked or page_lock(item[2])
+                    locked = locked or (engine_ready.is_set() and engine[0] is not None and (lock_all(item[2]) or True))
                     try:
                         handover.put(item, timeout=0.2 if locked else 0.01)
                         break
