@@ -853,6 +853,10 @@ def from_fast5_leg(n_copies, local):
         if st.f_bavail * st.f_frsize > 4 * n_copies * size * 3 + (4 << 30):   # (the run's fixed parts -- set-up, handle, the last
             legs.append(('reader_processes_4x_the_copies', many, None, 4 * n_copies, 1))   # batch's tail -- weigh less on a longer run)
             # the reader count swept on the long run (60 000 reads at the default size): same host threads, 16 ... 128 readers
+            # ... and, on request, a run four times as long again (240 000 reads at the default size, 25 GB of copies, 16 s of the bench):
+            # 91 k reads/s -- 24 000 loci take 0.6 s to set up, the readers 0.08 ms a read with four times the files (profiles/r06_from_fast5_240k.json)
+            if st.f_bavail * st.f_frsize > 16 * n_copies * size * 2 + (16 << 30) and os.environ.get('WARPSTR_BENCH_LONG_FAST5'):
+                legs.append(('reader_processes_16x_the_copies', many, None, 16 * n_copies, 1))
             sweep = [int(r) for r in os.environ.get('WARPSTR_BENCH_READER_SWEEP', '4,8,16,32,64,128').split(',')]
             legs += [(f'reader_sweep.{r}', many, r, 4 * n_copies, 1) for r in sweep if r <= (os.cpu_count() or 1)]
         only = os.environ.get('WARPSTR_BENCH_FAST5_ONLY')   # (a profiler run wants one leg: e.g. one_process -- no child processes)
@@ -879,6 +883,13 @@ def from_fast5_leg(n_copies, local):
                    'genotype_first_last': [list(c) for c in calls], 'all_loci_equal': bool(len(set(lens)) == 1)}
             if tm.get('timeline'):
                 rec['timeline'] = [f'{t:8.4f} {name}' for name, t in tm['timeline']]
+            if tag == 'reader_processes_16x_the_copies':   # (25 GB of copies: gone before the sweep makes its own)
+                shutil.rmtree(os.path.join(root, tag), ignore_errors=True)
+                for i in range(4 * n_copies, n):
+                    try:
+                        os.unlink(os.path.join(root, 'fast5', f'batch_{i:04d}.fast5'))
+                    except OSError:
+                        pass
             if tag.startswith('reader_sweep.'):
                 out.setdefault('reader_sweep', {'reads': n_reads, 'default_readers_at_16_threads': knee})[tag.split('.')[1]] = {
                     k: rec[k] for k in ('reads_per_s', 'wall_s', 'call_returns_after_s', 'reader_processes', 'phases_s', 'genotype_first_last', 'all_loci_equal', 'timeline') if k in rec}

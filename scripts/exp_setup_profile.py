@@ -48,6 +48,14 @@ try:
         return jobs, t2 - t1, time.perf_counter() - t2
 
     setup(loci[:64])
+    # the same on eight threads, as a run does it: the native part side by side, the Python part one thread at a time -- the wall-clock
+    # is about the Python part's
+    from concurrent.futures import ThreadPoolExecutor
+    for _ in range(3):
+        with ThreadPoolExecutor(8, initializer=L.spread_over_cpus) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(setup, [loci[k:k + 64] for k in range(64, n, 64)]))
+            print(json.dumps({'threads': 8, 'loci': n - 64, 'wall_s': time.perf_counter() - t0, 'us_per_locus': (time.perf_counter() - t0) / (n - 64) * 1e6}))
     pr = cProfile.Profile()
     nat = py = 0.0
     t0 = time.perf_counter()

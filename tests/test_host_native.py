@@ -352,3 +352,25 @@ def test_a_chunk_of_loci_hands_its_columns_over_together(tmp_path):
             assert a.flags.writeable and a.base is None   # (its own memory: a locus may change its arrays)
         one.close()
     assert 30 <= n_native < 60   # (the quoted tables and the non-ASCII names go to pandas)
+
+
+def test_a_chunks_string_columns_are_cut_when_looked_at():
+    """_hostlib._Strings: rows [a, b) of a column a chunk of loci handed over as one text -- a sequence of str like the list it
+    replaces (index, negative index, slice, iteration, comparison), for a text whose offsets count characters and for a blob with
+    non-ASCII names whose offsets count bytes."""
+    from warpstr_amd._hostlib import _Strings
+    rows = ['read_a', 'b', '', 'čtení-4', 'read_e']
+    text = ''.join(rows)
+    off = np.cumsum([0] + [len(r) for r in rows]).tolist()
+    raw = text.encode('utf-8')
+    boff = np.cumsum([0] + [len(r.encode('utf-8')) for r in rows]).tolist()
+    for col in (_Strings(text, off, 1, 5), _Strings(raw, boff, 1, 5, True)):
+        want = rows[1:5]
+        assert len(col) == 4 and list(col) == want and col == want and col[:] == want
+        assert [col[k] for k in range(4)] == want and col[-1] == 'read_e' and col[1:3] == want[1:3] and col[::2] == want[::2]
+        assert list(map(str, col[0:2])) == want[0:2] and set(col) == set(want)
+        with pytest.raises(IndexError):
+            col[4]
+        with pytest.raises(IndexError):
+            col[-5]
+    assert len(_Strings(text, off, 2, 2)) == 0 and list(_Strings(text, off, 2, 2)) == []

@@ -2,6 +2,7 @@
 out, the two automata, FASTA files, the complex-unit table -- as native code that runs without the GIL.  The Python forms
 (automata.py, overview.py, units.py) are the definition; every entry here either reproduces them byte for byte or declines
 (returns None), and the caller then runs the Python form.  WARPSTR_NO_HOST_NATIVE=1 turns the library off."""
+import collections.abc
 import ctypes as C
 import os
 from typing import Optional
@@ -127,6 +128,44 @@ def compile_automaton(pattern: str, pore_model):
                               repend=a.repend)
     finally:
         h.wsh_automaton_free(C.byref(a))
+
+
+def _under(directory: str, name: str) -> str:
+    """os.path.join(directory, name) for a plain file name (a tenth of its time: this runs per locus under the interpreter's lock)."""
+    return directory + name if directory.endswith(os.sep) else directory + os.sep + name if directory else name
+
+
+class _Strings(collections.abc.Sequence):
+    """Rows [a, b) of a string column that a chunk of loci handed over in one piece (text + the rows' offsets): the strings are made
+    when somebody looks at them -- a run of thousands of loci looks at a read's name when it hands the read to a reader, thirty
+    strings per locus made under the interpreter's lock were a quarter of the set-up's wall-clock."""
+    __slots__ = ('_text', '_off', '_a', '_b', '_bytes')
+
+    def __init__(self, text, off, a, b, as_bytes=False):
+        self._text, self._off, self._a, self._b, self._bytes = text, off, a, b, as_bytes
+
+    def __len__(self):
+        return self._b - self._a
+
+    def _one(self, r):
+        piece = self._text[self._off[r]:self._off[r + 1]]
+        return piece.decode('utf-8') if self._bytes else piece   # (a blob with non-ASCII names is kept as bytes: the offsets are bytes)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self._one(self._a + r) for r in range(*k.indices(self._b - self._a))]
+        n = self._b - self._a
+        if k < 0:
+            k += n
+        if not 0 <= k < n:
+            raise IndexError(k)
+        return self._one(self._a + k)
+
+    def __iter__(self):
+        return (self._one(r) for r in range(self._a, self._b))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
 
 
 class NativeOverview:
@@ -326,9 +365,9 @@ class NativeSetup:
         self.overview = self.tables = self.similarity = None
         self.overview_status = raw.overview_status
         if raw.overview_status == 0 and columns is not None:
-            self.overview = NativeOverview._from_columns(raw.locus, os.path.join(locus_path, 'overview.csv'), self, *columns)
+            self.overview = NativeOverview._from_columns(raw.locus, _under(locus_path, 'overview.csv'), self, *columns)
         elif raw.overview_status == 0:
-            self.overview = NativeOverview(raw.locus, os.path.join(locus_path, 'overview.csv'), owner=self)
+            self.overview = NativeOverview(raw.locus, _under(locus_path, 'overview.csv'), owner=self)
         else:
             NativeOverview.last_refusal = (lib().wsh_locus_error(raw.locus) or b'').decode('utf-8', 'replace')
         if raw.automata_status == 0:
@@ -399,20 +438,20 @@ class NativeSetup:
                            blobs[1], offs[1].ctypes.data, blobs[2], offs[2].ctypes.data)
         reverse = reverse.astype(bool)
 
-        def strings(k):
+        def strings(k):   # (text, offsets, the text is bytes) of column k: _Strings cuts a locus's rows out of it when asked
             raw, o = blobs[k].raw[:int(sbytes[k])], offs[k].tolist()
             text = raw.decode('utf-8')
-            if len(text) == len(raw):
-                return [text[o[r]:o[r + 1]] for r in range(total)]
-            return [raw[o[r]:o[r + 1]].decode('utf-8') for r in range(total)]   # (non-ASCII: the offsets are bytes)
+            return (text, o, False) if len(text) == len(raw) else (raw, o, True)   # (non-ASCII: the offsets are bytes)
         names = strings(0)
         runs = strings(1) if (flags & 1).any() else None
         f5s = strings(2) if (flags & 2).any() else None
         out, at = {}, 0
+        counts_l, rows_l, flags_l = counts.tolist(), rows.tolist(), flags.tolist()
         for q, i in enumerate(idx):
-            b = at + int(counts[q])
-            out[i] = (int(rows[q]), saved[at:b].copy(), reverse[at:b].copy(), lo[at:b].copy(), hi[at:b].copy(), names[at:b],
-                      runs[at:b] if flags[q] & 1 else None, f5s[at:b] if flags[q] & 2 else None)
+            b = at + counts_l[q]
+            out[i] = (rows_l[q], saved[at:b].copy(), reverse[at:b].copy(), lo[at:b].copy(), hi[at:b].copy(), _Strings(names[0], names[1], at, b, names[2]),
+                      _Strings(runs[0], runs[1], at, b, runs[2]) if flags_l[q] & 1 else None,
+                      _Strings(f5s[0], f5s[1], at, b, f5s[2]) if flags_l[q] & 2 else None)
             at = b
         return out
 

@@ -48,7 +48,7 @@ class LocusJob:
         self.locus = locus
         self.sequence = locus.sequence.upper()
         self.flank_length = int(locus.flank_length)
-        self.overview_path = os.path.join(locus.path, ov.OVERVIEW_NAME)
+        self.overview_path = _hostlib._under(locus.path, ov.OVERVIEW_NAME)
         self._df = None
         lim = caller_config.min_state_similarity if caller_config is not None else 0.0
         # overview.csv, the flank file, both automata and state_similarity.csv in one library call without the GIL; whatever
