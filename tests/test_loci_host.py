@@ -959,6 +959,39 @@ def test_a_streamed_run_raises_what_its_set_up_raises(tmp_path, monkeypatch):
     assert threading.active_count() <= before
 
 
+@pytest.mark.parametrize('threads', [1, 3])
+def test_a_streamed_run_raises_what_collecting_a_batch_raises(tmp_path, threads, monkeypatch):
+    """The batches' results are collected on a thread of their own: what that thread raises ends the run -- the submitting thread
+    raises it, the reader thread and the reader processes stop, nothing is left behind -- whether the error comes with the first
+    batch or in the middle of the run."""
+    import threading
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    monkeypatch.setattr(wl, 'STREAM_FROM_LOCI', 100)
+    monkeypatch.setattr(wl, 'SHARED_BATCH_READS', 64)
+    for fail_at in (0, 3):
+        loci = _fast5_loci(str(tmp_path / f'a{fail_at}'), src, ids, n_loci=230)
+        seen = []
+
+        class Engine(VbzFakeEngine):
+            def collect(self, ticket):
+                seen.append(1)
+                if len(seen) == fail_at + 1:
+                    raise RuntimeError('the device decoders flagged a chunk')
+                return super().collect(ticket)
+        before = threading.active_count()
+        with pytest.raises(RuntimeError, match='flagged a chunk'):
+            main_wrapper_loci(loci, threads, _engine=Engine, quiet=True)
+        assert threading.active_count() <= before and len(seen) == fail_at + 1
+
+
 class ZstdFakeEngine(VbzFakeEngine):
     """... and one that also undoes the chunks' zstd frames itself (HipEngine since round 6: wsx_zstd_decode)."""
     DEVICE_ZSTD = True
