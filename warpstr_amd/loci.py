@@ -163,6 +163,9 @@ class HipEngine:
     def arena_ready(self, path, samples):
         return self.queue.arena_ready(path, samples)
 
+    def arena_is_ready(self, path, samples):
+        return self.queue.arena_is_ready(path, samples)
+
 
     def add_automata(self, tables, flank_lengths):
         """More loci for the handle while its batches are in flight (wsx_caller_add_automata) -> index of the first new automaton."""
@@ -798,12 +801,13 @@ def _streamed_run(parts, setup, tm, pool, engine_cls, engine_args, batch_reads, 
 
     def lock_all(parts_):
         """What lock_early has left (answers that came before the handle existed): the arenas side by side, not one after the other."""
-        if len(parts_) > 1 and engine_ready.is_set() and engine[0] is not None:
-            distinct = list({part[0]: part for part in parts_}.values())
-            threads_ = [threading.Thread(target=page_lock, args=([part],), daemon=True) for part in distinct[1:]]
+        known = getattr(engine[0], 'arena_is_ready', None) if engine_ready.is_set() and engine[0] is not None else None
+        if known is not None:   # (after a run's first batches every arena is: nothing to start threads for)
+            todo = [part for part in {part[0]: part for part in parts_}.values() if not known(part[0], part[1] // 2 if len(part) == 6 else part[1])]
+            threads_ = [threading.Thread(target=page_lock, args=([part],), daemon=True) for part in todo[1:]]
             for t in threads_:
                 t.start()
-            page_lock(distinct[:1])
+            page_lock(todo[:1])
             for t in threads_:
                 t.join()
         else:
