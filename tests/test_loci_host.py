@@ -1050,3 +1050,47 @@ def test_a_locus_rows_as_one_item_expand_to_the_per_read_items(tmp_path, native)
             got = _readers.expand([job.rows_for_readers(0, 1), ('/x/y.fast5', None, 'z'), job.rows_for_readers(1, job.n)])
             assert got == want[:1] + [('/x/y.fast5', None, 'z')] + want[1:]
     assert _readers.expand([('/a', '/b', 'c')]) == [('/a', '/b', 'c')]
+
+
+def test_default_readers_leave_this_process_a_share_when_the_engine_decodes_zstd(monkeypatch):
+    """default_readers: as many readers as host threads, capped by the CPUs the cgroup grants; an engine that decodes zstd itself gets
+    the share less an eighth (two of sixteen: the submitting and the collecting thread want CPUs of their own)."""
+    import warpstr_amd.loci as wl
+    monkeypatch.setattr(wl, 'cpu_share', lambda: 16)
+    assert [wl.default_readers(t) for t in (1, 4, 16, 64)] == [1, 4, 16, 16]
+    assert [wl.default_readers(t, True) for t in (1, 2, 4, 8, 16, 64)] == [1, 2, 3, 7, 14, 14]
+    monkeypatch.setattr(wl, 'cpu_share', lambda: 3)
+    assert wl.default_readers(16, True) == 3 and wl.default_readers(16) == 3
+
+
+def test_a_run_keeps_its_timeline_when_asked(tmp_path, monkeypatch):
+    """timings={'timeline': []}: the streamed run's events -- set-up, batches handed to the readers and answered, submitted and
+    collected, the handle closed, the outputs written -- with the seconds since the call, in order; without the key nothing is kept,
+    and the helpers' keys are gone from the dict either way."""
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    import warpstr_amd.loci as wl
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    monkeypatch.setattr(wl, 'STREAM_FROM_LOCI', 100)
+    monkeypatch.setattr(wl, 'SHARED_BATCH_READS', 64)
+    loci = _fast5_loci(str(tmp_path / 'a'), src, ids, n_loci=150)
+    tm = {'timeline': []}
+    main_wrapper_loci(loci, 1, _engine=VbzFakeEngine, quiet=True, timings=tm)
+    names = [name.split(' [cpu')[0] for name, _ in tm['timeline']]
+    times = [t for _, t in tm['timeline']]
+    assert '_t0' not in tm and '_c0' not in tm
+    for must in ('the streamed run begins', 'part set up', 'set-up done', 'batch 0 answered', 'last batch collected', 'handle closed',
+                 'all reads called', 'outputs written'):
+        assert must in names, must
+    assert any(n.startswith('batch 0 handed to the readers') for n in names) and any(n.endswith('submitted') for n in names)
+    assert names.index('last batch collected') < names.index('handle closed') < names.index('all reads called') < names.index('outputs written')
+    assert all(t >= 0 for t in times) and times[-1] == max(times) and times[-1] <= tm['total_s'] + 1e-3   # (times are rounded to 0.1 ms)
+    assert sum(n.endswith('collected') and n.startswith('reads') for n in names) == sum(n.endswith('submitted') for n in names)
+    tm2 = {}
+    main_wrapper_loci(_fast5_loci(str(tmp_path / 'b'), src, ids, n_loci=150), 1, _engine=VbzFakeEngine, quiet=True, timings=tm2)
+    assert 'timeline' not in tm2 and '_t0' not in tm2
