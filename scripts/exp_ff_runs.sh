@@ -9,7 +9,10 @@ import json, sys
 r = json.load(open(sys.argv[1]))['reader_sweep'][sys.argv[2]]
 ev = {}
 for l in r['timeline']:
-    ev.setdefault(l.split(None, 1)[1].split(' [cpu')[0], float(l.split()[0]))
+    name = l.split(None, 1)[1].split(' [cpu')[0]
+    ev.setdefault(name.split(' (its ')[0], float(l.split()[0]))
+    if name.startswith('batch') and 'answered' in name and int(name.split()[1]) in (2, 3, 4, 5, 20):
+        print('   ', l.split(' [cpu')[0])
 print(round(r['reads_per_s']), 'wall', round(r['wall_s'], 3), 'returns', round(r['call_returns_after_s'], 3), {k: ev.get(k) for k in
       ('the streamed run begins', 'part set up', 'batch 0 handed to the readers (64 reads)', 'set-up done', 'batch 2 answered', 'batch 5 answered', 'batch 10 answered', 'last batch collected', 'handle closed', 'outputs written')}, flush=True)
 PY

@@ -48,6 +48,24 @@ try:
         return jobs, t2 - t1, time.perf_counter() - t2
 
     setup(loci[:64])
+    # the library call by itself (one thread): what is left of a part's time is Python
+    h = _hostlib.lib()
+    real, spent = h.wsh_loci_setup, [0.0]
+
+    def timed(*a):
+        t = time.perf_counter()
+        try:
+            return real(*a)
+        finally:
+            spent[0] += time.perf_counter() - t
+    h.wsh_loci_setup = timed
+    t0 = time.perf_counter()
+    for k in range(64, n, 64):
+        setup(loci[k:k + 64])
+    wall = time.perf_counter() - t0
+    h.wsh_loci_setup = real
+    print(json.dumps({'threads': 1, 'loci': n - 64, 'wall_s': wall, 'inside_wsh_loci_setup_s': spent[0], 'python_us_per_locus': (wall - spent[0]) / (n - 64) * 1e6,
+                      'native_us_per_locus': spent[0] / (n - 64) * 1e6}))
     # the same on eight threads, as a run does it: the native part side by side, the Python part one thread at a time -- the wall-clock
     # is about the Python part's
     from concurrent.futures import ThreadPoolExecutor

@@ -27,6 +27,13 @@ class WshOverviewInfo(C.Structure):
                 ('runs', C.c_void_p), ('runs_off', C.c_void_p), ('f5s', C.c_void_p), ('f5s_off', C.c_void_p)]
 
 
+_AUT_DTYPE = np.dtype([(k, np.int32) for k in ('n_states', 'endstate', 'repstart', 'repend', 'n_edges', 'reserved')]
+                      + [(k, np.uint64) for k in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer', 'owner')])
+_SETUP_DTYPE = np.dtype([('owner', np.uint64), ('locus', np.uint64), ('overview_status', np.int32), ('automata_status', np.int32),
+                         ('similarity_status', np.int32), ('reserved', np.int32), ('aut', _AUT_DTYPE, (2,)), ('similarity_csv', np.uint64),
+                         ('warnings', np.uint64)])   # WshSetup, field for field (checked when the library is loaded)
+
+
 class WshSetup(C.Structure):
     _fields_ = [('owner', C.c_void_p), ('locus', C.c_void_p), ('overview_status', C.c_int32), ('automata_status', C.c_int32),
                 ('similarity_status', C.c_int32), ('reserved', C.c_int32), ('aut', WshAutomaton * 2), ('similarity_csv', C.c_char_p),
@@ -34,6 +41,10 @@ class WshSetup(C.Structure):
 
 
 WSH_ABI = 2   # bumped whenever the exports or their meaning change (csrc/host_loci.cpp: wsh_abi_version)
+assert _SETUP_DTYPE.itemsize == C.sizeof(WshSetup) and _AUT_DTYPE.itemsize == C.sizeof(WshAutomaton)
+assert all(_SETUP_DTYPE.fields[k][1] == getattr(WshSetup, k).offset for k in _SETUP_DTYPE.names)
+assert all(_AUT_DTYPE.fields[k][1] == getattr(WshAutomaton, k).offset for k in _AUT_DTYPE.names)
+
 EXPORTS = ['wsh_abi_version', 'wsh_format_float', 'wsh_automaton_compile', 'wsh_automaton_free', 'wsh_locus_open', 'wsh_locus_error',
            'wsh_locus_free', 'wsh_locus_info', 'wsh_locus_text', 'wsh_locus_store', 'wsh_free', 'wsh_collapse_store', 'wsh_locus_setup',
            'wsh_setup_free', 'wsh_locus_table', 'wsh_loci_store', 'wsh_loci_setup', 'wsh_vbz_decode_i16', 'wsh_vbz_unpack', 'wsh_vbz_context', 'wsh_gather', 'wsh_loci_counts', 'wsh_loci_columns']
@@ -311,12 +322,16 @@ def _native_table(a: WshAutomaton, kmersize: int, owner):
 
         class _Lazy(AutomatonTable):
             def __init__(self, a, kmersize, owner):  # noqa: D107 -- no arrays yet
-                self.n_states, self.endstate, self.repstart, self.repend = a.n_states, a.endstate, a.repstart, a.repend
+                # a: a WshAutomaton, or its fields as plain numbers (n_states, endstate, repstart, repend, n_edges, then the seven
+                # pointers: a chunk of loci reads all its structs at once -- NativeSetup.run_many -- a ctypes field costs ten list items)
+                if type(a) is not tuple:
+                    a = (a.n_states, a.endstate, a.repstart, a.repend, a.n_edges, a.value, a.seq_idx, a.pred_ptr, a.pred_idx, a.repeat_mask,
+                         a.last_base, a.kmer)
+                self.n_states, self.endstate, self.repstart, self.repend, self._n_edges = a[:5]
                 self.kmersize, self._kmers, self._succ = kmersize, None, None
-                self._n_edges = a.n_edges
                 self._owner = owner
-                self.native_ptrs = (a.value, a.seq_idx, a.pred_ptr, a.pred_idx, a.repeat_mask, a.last_base)
-                self._kmer_ptr = a.kmer
+                self.native_ptrs = a[5:11]
+                self._kmer_ptr = a[11]
 
             def __getattr__(self, name):  # only reached for attributes that are not set yet: the arrays
                 if name in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer_codes'):
@@ -360,20 +375,29 @@ class NativeSetup:
     None: the pandas path), `tables` ((template, reverse) AutomatonTables or None: the Python compiler, which raises what
     upstream raises), `similarity` ((CSV text, [warning lines]) or None: the Python form).  None altogether without the library."""
 
-    def __init__(self, raw: WshSetup, locus_path: str, kmersize: int, columns=None):
+    def __init__(self, raw: WshSetup, locus_path: str, kmersize: int, columns=None, flat=None):
+        """flat: the struct's fields as plain numbers (run_many reads a chunk's structs at once): (owner, locus, overview status,
+        automata status, similarity status, the two automata's twelve fields each, address of the similarity text, of the warnings)."""
         self._raw = raw
         self.overview = self.tables = self.similarity = None
-        self.overview_status = raw.overview_status
-        if raw.overview_status == 0 and columns is not None:
-            self.overview = NativeOverview._from_columns(raw.locus, _under(locus_path, 'overview.csv'), self, *columns)
-        elif raw.overview_status == 0:
-            self.overview = NativeOverview(raw.locus, _under(locus_path, 'overview.csv'), owner=self)
+        if flat is None:
+            flat = (raw.owner, raw.locus, raw.overview_status, raw.automata_status, raw.similarity_status, raw.aut[0], raw.aut[1],
+                    raw.similarity_csv or b'', raw.warnings or b'')
+        locus, ov_status = flat[1], flat[2]
+        self.overview_status = ov_status
+        if ov_status == 0 and columns is not None:
+            self.overview = NativeOverview._from_columns(locus, _under(locus_path, 'overview.csv'), self, *columns)
+        elif ov_status == 0:
+            self.overview = NativeOverview(locus, _under(locus_path, 'overview.csv'), owner=self)
         else:
-            NativeOverview.last_refusal = (lib().wsh_locus_error(raw.locus) or b'').decode('utf-8', 'replace')
-        if raw.automata_status == 0:
-            self.tables = (_native_table(raw.aut[0], kmersize, self), _native_table(raw.aut[1], kmersize, self))
-        if raw.similarity_status == 0:
-            self.similarity = ((raw.similarity_csv or b'').decode('ascii'), (raw.warnings or b'').decode('ascii').splitlines())
+            NativeOverview.last_refusal = (lib().wsh_locus_error(locus) or b'').decode('utf-8', 'replace')
+        if flat[3] == 0:
+            self.tables = (_native_table(flat[5], kmersize, self), _native_table(flat[6], kmersize, self))
+        if flat[4] == 0:
+            text, warn = flat[7], flat[8]
+            if type(text) is int:   # (addresses: C strings in the library's memory)
+                text, warn = C.string_at(text) if text else b'', C.string_at(warn) if warn else b''
+            self.similarity = (text.decode('ascii'), warn.decode('ascii').splitlines())
 
     @classmethod
     def run(cls, locus_path: str, sequence: str, pore_model, min_state_similarity: float, write_similarity: bool):
@@ -409,24 +433,34 @@ class NativeSetup:
         raws = (WshSetup * n)()
         h.wsh_loci_setup(n, (C.c_char_p * n)(*[os.fsencode(p) for p in locus_paths]), (C.c_char_p * n)(*seqs), levels.ctypes.data,
                          int(pore_model.kmersize), float(min_state_similarity), 1 if write_similarity else 0, raws)
-        columns = cls._chunk_columns(h, raws, n)
+        # the chunk's structs read at once (a NumPy view of the array, its columns as lists): per locus this loop runs under the
+        # interpreter's lock, and a ctypes field costs what ten list items cost
+        rec = np.frombuffer(raws, _SETUP_DTYPE, n)
+        head = [rec[k].tolist() for k in ('owner', 'locus', 'overview_status', 'automata_status', 'similarity_status', 'similarity_csv', 'warnings')]
+        aut = rec['aut']
+        ints = np.stack([aut[k] for k in ('n_states', 'endstate', 'repstart', 'repend', 'n_edges')], axis=2).tolist()     # [locus][strand][5]
+        ptrs = np.stack([aut[k] for k in ('value', 'seq_idx', 'pred_ptr', 'pred_idx', 'repeat_mask', 'last_base', 'kmer')], axis=2).tolist()
+        columns = cls._chunk_columns(h, raws, n, head[2], head[1])
+        kmersize = int(pore_model.kmersize)
         out = []
-        for i, p in enumerate(locus_paths):   # (each entry owns a copy of its struct: the array may go)
-            raw = WshSetup()
-            C.memmove(C.byref(raw), C.byref(raws[i]), C.sizeof(WshSetup))
-            out.append(cls(raw, p, int(pore_model.kmersize), columns.get(i)))
+        for i, p in enumerate(locus_paths):   # (each entry keeps the array alive through its element: wsh_setup_free takes the element)
+            flat = (head[0][i], head[1][i], head[2][i], head[3][i], head[4][i], tuple(ints[i][0] + ptrs[i][0]), tuple(ints[i][1] + ptrs[i][1]),
+                    head[5][i], head[6][i])
+            out.append(cls(raws[i], p, kmersize, columns.get(i), flat))
         return out
 
     @staticmethod
-    def _chunk_columns(h, raws, n):
+    def _chunk_columns(h, raws, n, status=None, locus=None):
         """{locus of the chunk: (rows, saved rows, reverse, lo, hi, names, run ids or None, fast5 paths or None)} for the loci whose
         overview the library parsed -- two library calls and a handful of arrays for the chunk instead of one call and seven
         copies per locus (this part runs under the interpreter's lock: it, not the parsing, set the set-up's wall-clock)."""
-        idx = [i for i in range(n) if raws[i].overview_status == 0]
+        if status is None:
+            status, locus = [raws[i].overview_status for i in range(n)], [raws[i].locus for i in range(n)]
+        idx = [i for i in range(n) if status[i] == 0]
         if not idx or not hasattr(h, 'wsh_loci_columns'):
             return {}
         m = len(idx)
-        handles = (C.c_void_p * m)(*[raws[i].locus for i in idx])
+        handles = (C.c_void_p * m)(*[locus[i] for i in idx])
         counts, rows, flags, sbytes = np.zeros(m, np.int64), np.zeros(m, np.int64), np.zeros(m, np.int32), np.zeros(3, np.int64)
         h.wsh_loci_counts(m, handles, counts.ctypes.data, rows.ctypes.data, flags.ctypes.data, sbytes.ctypes.data)
         total = int(counts.sum())
