@@ -1204,16 +1204,7 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                                  + (', filled in this process' if getattr(pool, 'inline', False) else '') + ', streamed with the set-up')
 
             # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results)
-            setup_threads = int(os.environ.get('WARPSTR_STREAM_SETUP_THREADS', '0') or 0)
-            if executor is not None and 0 < setup_threads < tm['host_threads']:
-                # (experiment: fewer threads for the set-up while the pipeline runs beside it -- they take turns for the
-                # interpreter's lock with the threads that feed the readers and the GPU)
-                from concurrent.futures import ThreadPoolExecutor
-                small = ThreadPoolExecutor(max_workers=setup_threads, initializer=spread_over_cpus)
-                pools.append(small)
-                it = small.map(setup, parts)
-            else:
-                it = parts if executor is None else executor.map(setup, parts)
+            it = parts if executor is None else executor.map(setup, parts)
             streamed = _streamed_run(it, (lambda x: x) if executor is not None else setup, tm, pool, engine_cls,
                                      (caller_config, rescaler_config, local_gpu), batch_reads, batch_samples, batch_raw_bytes // 2, gpu_vbz,
                                      print_warnings, gpu_zstd)
