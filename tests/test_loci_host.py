@@ -1094,3 +1094,50 @@ def test_a_run_keeps_its_timeline_when_asked(tmp_path, monkeypatch):
     tm2 = {}
     main_wrapper_loci(_fast5_loci(str(tmp_path / 'b'), src, ids, n_loci=150), 1, _engine=VbzFakeEngine, quiet=True, timings=tm2)
     assert 'timeline' not in tm2 and '_t0' not in tm2
+
+
+def _rank_fast5(rank, world, port, root, src, ids, out_dir, partition):
+    import json
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    loci = _fast5_loci(root, src, ids, n_loci=70) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        pats = [('(AGC)', 16), ('(AAAT)', 30), ('(CAG)CAACAG(CCG)', 20), ('(GGCCCC)', 24)]
+        loci = [LocusPath(os.path.join(root, f'locus{li}'), *pats[li % 4]) for li in range(70)]
+    tm, msg = {}, 'ok'
+    try:
+        main_wrapper_loci(loci, 3, _engine=VbzFakeEngine, quiet=True, shard=True, partition=partition, timings=tm)
+    except Exception as e:  # noqa: BLE001
+        msg = f'{type(e).__name__}: {e}'
+    with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as f:
+        json.dump({'msg': msg, 'partition': tm.get('partition'), 'reader_mode': tm.get('reader_mode'), 'vbz_batches': tm.get('vbz_batches')}, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('partition', ['reads', 'loci'])
+def test_two_ranks_read_their_share_of_the_files_through_reader_arenas(tmp_path, partition):
+    """fast5 files, two ranks, reader processes with arenas on each: by read every rank takes a share of every locus's reads -- rows
+    that are not next to each other in their loci go to the readers as the pieces they form (rows_of) --, by locus whole loci; the
+    files equal one rank's either way."""
+    import json
+    from tests.helpers import GOLDEN
+    from warpstr_amd import fast5
+    try:
+        fast5._libs()
+    except fast5.Fast5Error as e:
+        pytest.skip(str(e))
+    src = os.path.join(GOLDEN, 'real', 'batch_0.fast5')
+    ids = fast5.Fast5File(src).read_ids()[:10]
+    one = _fast5_loci(str(tmp_path / 'one'), src, ids, n_loci=70)
+    main_wrapper_loci(one, 1, _engine=FakeEngine, quiet=True)
+    world, root = 2, str(tmp_path / 'two')
+    mp.spawn(_rank_fast5, args=(world, _free_port(), root, src, ids, str(tmp_path), partition), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(world)]
+    assert all(g['msg'] == 'ok' and g['partition'] == partition for g in got), got
+    assert all('arenas' in str(g['reader_mode']) and g['vbz_batches'] >= 1 for g in got), got
+    for li, l1 in enumerate(one):
+        for rel in OUTPUTS:
+            assert filecmp.cmp(os.path.join(l1.path, rel), os.path.join(root, f'locus{li}', rel), shallow=False), (li, rel)

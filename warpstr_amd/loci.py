@@ -1301,6 +1301,15 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                 job, row = jobs[locus_of[mine[k]]], int(row_of[mine[k]])
                 return (job.fast5_of(row), str(job.fast5_path[row]) if job.fast5_path is not None else None, job.names[row])
 
+            def rows_of(x0, x1):
+                """Reads [x0, x1) of this rank as the readers take them: one item per run of consecutive rows of a locus
+                (LocusJob.rows_for_readers; _readers.expand makes item_of's items of it on the reader's CPU)."""
+                g = mine[x0:x1]
+                lj, rr = locus_of[g], row_of[g]
+                cut = np.flatnonzero((lj[1:] != lj[:-1]) | (rr[1:] != rr[:-1] + 1)) + 1
+                bounds = [0] + cut.tolist() + [x1 - x0]
+                return [jobs[int(lj[a])].rows_for_readers(int(rr[a]), int(rr[a]) + z - a) for a, z in zip(bounds[:-1], bounds[1:])]
+
             def finish(ticket, b0, b1):
                 t1 = time.perf_counter()
                 rec, s1, p1, s2, p2 = queue.collect(ticket)
@@ -1453,10 +1462,11 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                             queue.region_wait(region)   # ... and uploaded
                             del submitted[k - regions]
                         submitted[k] = threading.Event()
-                        items = [item_of(x) for x in range(b, b1)]
-                        step = max(8, -(-len(items) // (CHUNKS_PER_READER * pool._max_workers)))
-                        futures = [pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items[q:q + step], gpu_zstd) if gpu_vbz else (region, k, items[q:q + step]))
-                                   for q in range(0, len(items), step)]
+                        step = max(8, -(-(b1 - b) // (CHUNKS_PER_READER * pool._max_workers)))
+                        futures = []
+                        for q in range(b, b1, step):
+                            items = rows_of(q, min(q + step, b1))
+                            futures.append(pool.submit(_pack_arena if gpu_vbz else _decode_arena, (region, k, items, gpu_zstd) if gpu_vbz else (region, k, items)))
                         inflight.append((b, b1, region, futures, k))
                         tm['read_s'] += time.perf_counter() - t1
                         b, k = b1, k + 1
