@@ -8,10 +8,12 @@
 // of the StreamVByte block; the key bytes are the few matches): blocks of <= 128 KB, four interleaved-by-position streams each, a
 // handful of sequences.  Hence the shape of the kernel:
 //   * zstd_index_kernel: a thread per frame walks its block headers and lists its Huffman-coded blocks;
+//   * zstd_order_kernel: the list again, the blocks with the most literals first (a launch is then as long as ONE full block's chain);
 //   * zstd_literals_kernel: a wavefront takes four blocks of the list (16 lanes each): lane 0 of a group reads the tree description
 //     (direct weights, or FSE-coded weights decoded with two states), the wave builds the 2^max_bits-cell decoding tables in LDS --
 //     two symbols a cell where both codes fit --, lanes 0..3 of every group decode the block's four streams side by side (a stream is
-//     a chain of dependent table look-ups: no parallelism inside it; the loop is branch-free and holds nothing but LDS);
+//     a chain of dependent table look-ups: no parallelism inside it; the loop holds nothing but LDS, and away from a stream's ends
+//     nothing but the chain: a refill that selects, two look-ups);
 //   * zstd_sequences_kernel: a wavefront per frame walks the blocks in order: sequences section (predefined / RLE / FSE / repeat
 //     tables, built by lane 0 in LDS), decoded by lane 0 a few hundred sequences at a time, executed by the whole wave (literal run,
 //     match -- overlapping matches as a periodic copy), repeat offsets carried from block to block.
