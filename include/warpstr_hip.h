@@ -297,9 +297,9 @@ int wsx_vbz_decode(wsx_caller *c, const uint8_t *src, int64_t src_bytes, const w
 /*
  * The zstd frames of VBZ chunks, decoded on the device (the step in front of wsx_vbz_decode): what the HDF5 filter plugin 32020 asks
  * of libzstd when h5py reads `Raw/Signal` for Fast5.get_data_processed (src/schemas/fast5.py:50-52; plugin and libzstd are third-party
- * dependencies that are not in the upstream tree; the format is RFC 8878).  Three kernels: the Huffman-coded blocks of all frames are
- * listed, their literals decoded four blocks to a wavefront (the four streams of a block side by side), then a wavefront per frame
- * executes its blocks' sequences in order.
+ * dependencies that are not in the upstream tree; the format is RFC 8878).  Four kernels: the Huffman-coded blocks of all frames are
+ * listed, the list ordered (most literals first), the literals decoded four blocks to a wavefront (the four streams of a block side
+ * by side), then a wavefront per frame executes its blocks' sequences in order.
  *   src        device: the frames' bytes (each from its magic number on)
  *   frames     host wsx_zstd_frame[n_frames]: where a frame lies in src, where its content goes in dst and how many bytes that is
  *              (the content size the frame's header declares).  Checked before anything is enqueued; copied before the call returns
