@@ -294,6 +294,7 @@ __device__ __forceinline__ uint32_t cell2(uint32_t c1, uint32_t c2, int max_bits
     return (c1 & 255u) | (l1 << 16) | (l1 << 20) | (1u << 24);
 }
 
+constexpr int TREE_STAGE = 144;  // a literals header (<= 5 bytes) and a Huffman tree description (<= 129)
 constexpr int SEQ_STAGE = 4096;  // bytes of a sequences section the sequence kernel reads from LDS
 constexpr int Z_CLASSES = 9;   // a block by its literals, in steps of 16 K (0 .. 128 K)
 __device__ __forceinline__ int size_class(int regen) { return regen >> 14 > Z_CLASSES - 1 ? Z_CLASSES - 1 : regen >> 14; }
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
     __shared__ uint16_t huf_start[ZG][256];      // first cell of every symbol
     __shared__ FseTableW fse_w[ZG];
     __shared__ int info[ZG][4], strm[ZG][12];
+    __shared__ uint8_t tree_stage[ZG][TREE_STAGE];
 
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const int n_work = *n_work_p;
@@ -393,6 +395,10 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
         const uint8_t *f = src + F.src_offset;
         const uint8_t *p = f + W.src;
         // ---- the tree description of the group's block (its lane 0) ----
+        // (the group fetches it first -- the literals header and at most 129 bytes of description --: lane 0 reads it a few bits at a
+        // time, every read waiting for the one before)
+        for (int i = j; i < TREE_STAGE; i += 16) tree_stage[g][i] = have && W.tree + i < F.src_bytes ? f[W.tree + i] : 0;
+        wave_sync();
         if (j == 0) {
             int st = have ? Z_OK : Z_UNSUPPORTED, n = 0, took = 0, max_bits = 0, hl = 0, comp = 0, streams = 1;
             uint8_t *w = huf_w[g];
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
                 streams = sf == 0 ? 1 : 4;
                 // the tree description: at the head of this block's literals section, or -- treeless literals -- of an earlier block's
                 // (every work item builds its table from a description, so a treeless block waits for nobody)
-                const uint8_t *tp = f + W.tree;
+                const uint8_t *tp = tree_stage[g];
                 const int tsf = (tp[0] >> 2) & 3, thl = tsf < 2 ? 3 : tsf + 2, tw = tsf < 2 ? 10 : tsf == 2 ? 14 : 18;
                 uint64_t tv = 0;
                 for (int i = 0; i < thl; i++) tv |= (uint64_t)tp[i] << (8 * i);
