@@ -297,7 +297,8 @@ __device__ int walk_blocks(const uint8_t *f, int flen, long long cap, int *n_blo
 }
 
 constexpr int Z_WIN = 256;     // bytes of a stream's compressed input a window holds; the ring of a stream is two windows
-constexpr int Z_LOOKUPS = 66;  // look-ups a stream makes between two flushes (33 refills of two)
+constexpr int Z_LOOKUPS = 56;  // look-ups a stream makes between two flushes (28 refills of two: at most 112 bytes and the 8 of the words around --
+                               // less than half a window, which is what lets a window arrive a period after it was asked for)
 constexpr int Z_OUT = 2 * Z_LOOKUPS + 2;   // ... and the room for their symbols (two a look-up, the last store may spill one byte)
 constexpr int ZG = 4;          // Huffman blocks a wavefront decodes side by side (a group of 16 lanes each: 4 decode, 16 fetch and flush)
 
@@ -383,9 +384,9 @@ __global__ __launch_bounds__(256) void zstd_order_kernel(const HufWork *__restri
 // of dependent look-ups, a global load or store between two of them (and the s_waitcnt they share with everything else) costs more
 // than the look-up, and so does the bookkeeping of lanes that leave a loop at different times.
 //   input : every stream has a ring of two 256-byte windows of its compressed bytes, aligned on absolute addresses; between two
-//           flushes a stream takes at most 66 x 11 bits = 91 bytes, and its next window is fetched as soon as the upper one is used
-//           up -- so a refill never finds the ring short;
-//   output: up to 132 symbols a stream collect in LDS and leave together.
+//           flushes a stream moves at most 28 refills x 4 bytes, and its next window is asked for as soon as the upper one is used
+//           up and put into the ring at the flush after -- so a refill never finds the ring short;
+//   output: up to 112 symbols a stream collect in LDS and leave together.
 __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__restrict__ src, long long src_total, const wsx_zstd_frame *__restrict__ frames,
                                                           const HufWork *__restrict__ work, const int *__restrict__ n_work_p, uint8_t *__restrict__ lits,
                                                           int32_t *__restrict__ status)
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
     constexpr int RING_BYTES = ZG * 4 * 2 * Z_WIN, OBUF_BYTES = ZG * 4 * Z_OUT;
     constexpr int WORK_BYTES = RING_BYTES + OBUF_BYTES > (2 << HUF_MAX_BITS) ? RING_BYTES + OBUF_BYTES : (2 << HUF_MAX_BITS);
     __shared__ __attribute__((aligned(16))) uint8_t workmem[WORK_BYTES];
+    static_assert(2 * Z_LOOKUPS + 8 + 8 <= Z_WIN / 2, "a period moves a stream less than half a window");
     static_assert(ZG * 1024 <= WORK_BYTES, "the groups' count arrays fit the scratch");
     __shared__ uint8_t huf_w[ZG][256];           // weights, then code lengths
     __shared__ uint16_t huf_start[ZG][256];      // first cell of every symbol
@@ -578,28 +580,48 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
         uint8_t *ring = workmem + (g * 4) * 2 * Z_WIN, *obuf = workmem + RING_BYTES + (g * 4) * Z_OUT;
         // window w of a stream = absolute addresses [w * Z_WIN, (w + 1) * Z_WIN); ring index = address mod 2 Z_WIN
         long long fetch_lo = fetches ? (long long)(((ab + (uintptr_t)q[4 + fs] - 1) / Z_WIN) * Z_WIN) + Z_WIN : 0;   // lowest address held
-        auto fetch = [&](bool go) {                     // the next lower window of stream fs: four lanes, four 16-byte pieces each
+        // The next lower window of stream fs (four lanes, four 16-byte pieces each) is ASKED FOR at one flush and PUT INTO THE RING at the
+        // next: the loads are in flight while the streams decode a period (nearly every flush some stream of the wavefront wants a
+        // window, and a load waited for on the spot was ~1.3 us of every ~8).  Safe: a window is asked for at the first flush that
+        // finds the upper one used up -- the stream is then more than half a window above the lower one's bottom (it moves less than
+        // half a window a period), so the period in between stays inside what the ring holds.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 asked[4] = {};
+        long long asked_at = 0;
+        bool asked_for = false;
+        auto ask = [&](bool go) {
             if (go) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const long long a = fetch_lo - Z_WIN + 64 * k + 16 * fj;
                     u32x4 v = {0, 0, 0, 0};
                     const long long rel = a - (long long)ab;
-                    if (rel >= base_lo && rel + 16 <= base_hi) v = *(const u32x4 *)(uintptr_t)a;
+                    // (through `f`, a pointer into the kernel's argument: a GLOBAL load -- an address made from an integer is a flat one,
+                    // which every wait for LDS in the symbol loop would wait for too)
+                    if (rel >= base_lo && rel + 16 <= base_hi) v = *(const u32x4 *)(f + rel);
                     else if (rel + 16 > base_lo && rel < base_hi) {
                         uint32_t t4[4] = {0, 0, 0, 0};
                         for (int i = 0; i < 16; i++)
                             if (rel + i >= base_lo && rel + i < base_hi) t4[i >> 2] |= (uint32_t)f[rel + i] << (8 * (i & 3));
                         v = u32x4{t4[0], t4[1], t4[2], t4[3]};
                     }
-                    *(u32x4 *)(ring + fs * 2 * Z_WIN + (int)(a & (2 * Z_WIN - 1))) = v;
+                    asked[k] = v;
                 }
+                asked_at = fetch_lo - Z_WIN;
+                asked_for = true;
                 fetch_lo -= Z_WIN;
             }
         };
-        fetch(fetches);
-        fetch(fetches);
+        auto put = [&]() {
+            if (asked_for) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    *(u32x4 *)(ring + fs * 2 * Z_WIN + (int)((asked_at + 64 * k + 16 * fj) & (2 * Z_WIN - 1))) = asked[k];
+                asked_for = false;
+            }
+        };
+        ask(fetches), put();
+        ask(fetches), put();
         wave_sync();
         const int shift = 64 - max_bits;
         const uint8_t *myring = ring + s * 2 * Z_WIN;
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
             int cnt = 0;
             // At the top of an iteration `used` <= 31: two look-ups of at most 11 bits leave it <= 53, and a refill (which needs 32
             // used bits to make room) brings that back to <= 21.  (Three look-ups a refill would reach 64 and come back as 32.)
-            // A period (33 iterations) takes at most 132 symbols and 136 bytes: while every stream of the wavefront is further than
+            // A period (28 iterations) takes at most 112 symbols and 120 bytes: while every stream of the wavefront is further than
             // that from both its ends -- all but the last period or two of a block -- the loop is the bare chain: a refill that
             // selects, two look-ups, no end in sight to test for.
             const bool far = !live || (want - done >= 2 * Z_LOOKUPS && pp - lo_off >= 2 * Z_LOOKUPS + 8);
@@ -668,15 +690,16 @@ __global__ __launch_bounds__(64) void zstd_literals_kernel(const uint8_t *__rest
             // ---- flush: the four lanes of stream fs write a quarter of its buffer each; then its next window where the upper is used up ----
             const int src_lane = (lane & ~15) | fs;
             const int cnt_fs = __shfl(cnt, src_lane, 64);
-            {
+            const int p_fs = __shfl(pp, src_lane, 64);
+            put();   // (the window asked for a period ago; then the next one is asked for BEFORE the symbols leave: loads and stores
+            ask(fetches && ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN);   // complete in order, a load behind them would wait for them)
+            {        // (a refill reads the aligned words around pp - 4: up to pp + 3)
                 uint8_t *d = L + (long long)fs * per + flushed;
                 const uint8_t *o = obuf + fs * Z_OUT;
                 const int q0 = (cnt_fs * fj) >> 2, q1 = (cnt_fs * (fj + 1)) >> 2;
                 for (int k = q0; k < q1; k++) d[k] = o[k];
                 flushed += cnt_fs;
             }
-            const int p_fs = __shfl(pp, src_lane, 64);
-            fetch(fetches && ((long long)ab + p_fs + 8) <= fetch_lo + Z_WIN);   // (a refill reads the aligned words around pp - 4: up to pp + 3)
             wave_sync();
             if (!__any(live && done < want)) break;
         }
