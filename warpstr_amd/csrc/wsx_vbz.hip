@@ -46,14 +46,17 @@ typedef uint32_t vbz_u32x4 __attribute__((ext_vector_type(4)));
 // inside [lo, hi) (the whole of src), byte by byte at the two ends of the buffer
 __device__ __forceinline__ vbz_u32x4 window_load(const uint8_t *from, const uint8_t *lo, const uint8_t *hi, int chunk)
 {
-    const uint8_t *a = (const uint8_t *)((uintptr_t)from & ~(uintptr_t)15) + 16 * chunk;
+    // (the address as an offset from `lo`, the kernel's own argument: a GLOBAL load.  A pointer made from an integer is a flat one, and
+    // a flat load counts as an LDS operation too: the loads that are meant to be in flight during a round were waited for at the round's
+    // first wait for LDS)
+    const long long rel = (from - lo) - (long long)((uintptr_t)from & 15) + 16 * chunk, n = hi - lo;
     vbz_u32x4 w = {0, 0, 0, 0};
-    if (a >= lo && a + 16 <= hi) {
-        w = *(const vbz_u32x4 *)a;
-    } else if (a + 16 > lo && a < hi) {
+    if (rel >= 0 && rel + 16 <= n) {
+        w = *(const vbz_u32x4 *)(lo + rel);
+    } else if (rel + 16 > 0 && rel < n) {
         uint32_t t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++)
-            if (a + i >= lo && a + i < hi) t[i >> 2] |= (uint32_t)a[i] << (8 * (i & 3));
+            if (rel + i >= 0 && rel + i < n) t[i >> 2] |= (uint32_t)lo[rel + i] << (8 * (i & 3));
         w = vbz_u32x4{t[0], t[1], t[2], t[3]};
     }
     return w;
