@@ -1188,13 +1188,16 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
                   and not os.environ.get('WARPSTR_NO_STREAMED_RUN'))
     if (can_stream and fast5_on_workers and all(hasattr(probe, a) for a in ('submit_raw_parts', 'ARENA_REGIONS', 'region_wait'))
             and os.path.isdir('/dev/shm') and not os.environ.get('WARPSTR_NO_READER_ARENAS')):
-        pool = _started(pool, tm)
-        _mark(tm, 'reader processes started')
         workers = pool._max_workers if pool is not None else 1
         refused = _arena_room(workers, SHARED_BATCH_READS if pool is not None else SHARED_BATCH_READS // 4, batch_raw_bytes // 2)
         if refused is not None:
             tm['arenas_refused'] = refused
         else:
+            # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results -- started before the
+            # reader processes are waited for: their helper takes 20 ms to fork them, the first loci are set up meanwhile)
+            it = parts if executor is None else executor.map(setup, parts)
+            pool = _started(pool, tm)
+            _mark(tm, 'reader processes started')
             if pool is None:
                 pool = _InlinePool()
                 pools.append(pool)
@@ -1203,8 +1206,6 @@ def _main_wrapper_loci(loci, threads, pools, executor, *, caller_config, rescale
             tm['reader_mode'] = ((('arenas, zstd and VBZ decoded on the GPU' if gpu_zstd else 'arenas, VBZ decoded on the GPU') if gpu_vbz else 'arenas')
                                  + (', filled in this process' if getattr(pool, 'inline', False) else '') + ', streamed with the set-up')
 
-            # (with threads the parts are set up `threads` at a time and taken in order: executor.map's results)
-            it = parts if executor is None else executor.map(setup, parts)
             streamed = _streamed_run(it, (lambda x: x) if executor is not None else setup, tm, pool, engine_cls,
                                      (caller_config, rescaler_config, local_gpu), batch_reads, batch_samples, batch_raw_bytes // 2, gpu_vbz,
                                      print_warnings, gpu_zstd)
