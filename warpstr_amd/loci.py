@@ -1091,6 +1091,18 @@ def main_wrapper_loci(loci: Sequence, threads: int = 1, *, caller_config: Option
     if threads and int(threads) > 1 and len(loci) > 1:
         from concurrent.futures import ThreadPoolExecutor
         executor = ThreadPoolExecutor(max_workers=min(int(threads), 64), initializer=spread_over_cpus)
+        if len(loci) >= GC_PAUSE_FROM_LOCI:
+            # (its threads started now, while nothing runs: the executor starts one per task handed in until it has them all, and a
+            # thread start waits until the new thread has run -- 20-45 ms for sixteen of them once the first are busy setting loci up)
+            import threading
+            gate = threading.Barrier(executor._max_workers + 1)
+            waiting = [executor.submit(gate.wait, 5.0) for _ in range(executor._max_workers)]
+            try:
+                gate.wait(5.0)
+                for w in waiting:
+                    w.result()
+            except threading.BrokenBarrierError:
+                pass   # (a machine that cannot start the threads in five seconds starts them when they are needed)
     try:
         return _main_wrapper_loci(loci, int(threads or 1), pools, executor, caller_config=caller_config, rescaler_config=rescaler_config,
                                   signal_loader=signal_loader, raw_reader=raw_reader, raw_reads=raw_reads, pore_model=pore_model,
