@@ -132,3 +132,16 @@ def test_a_corrupt_frame_says_so_and_the_others_are_untouched():
     assert status[1] in (0, 2)                     # (a flipped literal bit may still be a valid stream: then the content differs)
     if status[1] == 0:
         assert got[1] != got[0]
+
+
+def test_no_frames_and_frames_of_no_content():
+    """A call without frames is a success that launches nothing; a frame whose content is empty (libzstd writes one for b'') decodes
+    to nothing, beside frames of one byte and of a few, without touching a neighbour's place."""
+    hip, stream = _handle()
+    assert hip.zstd_decode_device(0, 0, np.zeros(0, _lib.ZSTD_FRAME_DTYPE), 0, 0, 0, 0) is None
+    hip.close()
+    items = [b'', b'x', b'', b'hello, hello, hello', b'']
+    frames = [(compress(d, 3), len(d)) for d in items]
+    got, status = decode_on_device(frames)
+    assert (status == 0).all(), status
+    assert got == items
